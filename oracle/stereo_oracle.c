@@ -1,0 +1,432 @@
+/*
+ * stereo_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C, single-threaded, CPU restatement of the arithmetic of the reference's depth-to-stereo
+ * hot path (reference: stereoimage_generation.py), in the one dialect that can be executed and
+ * pinned in the build container: "D32" = the reference's no-numba fallback under NumPy 2 scalar
+ * promotion rules.  Every function cites the reference lines it follows.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and
+ * only as the checker.  The product (comfystereo_amd/) never links or calls it.
+ *
+ * Parity is PINNED: tests/golden/ holds inputs + outputs captured by importing the reference in
+ * the build container (tools/make_goldens.py); tests/test_oracle_goldens.py checks this file
+ * against every one of them bit-for-bit.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).  -ffp-contract=off is
+ * REQUIRED: the dialect's float32 roundings are explicit, the only fused multiply-adds are the
+ * fma()/fmaf() calls written out below.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "oracle_math.h"
+
+#define EXPORT __attribute__((visibility("default")))
+
+enum {
+    FILL_NONE = 0,
+    FILL_NAIVE = 1,
+    FILL_NAIVE_INTERP = 2,
+    FILL_POLY_SOFT = 3,
+    FILL_POLY_SHARP = 4,
+    FILL_INVERSE = 5,
+    FILL_HYBRID_EDGE = 6,
+};
+
+EXPORT float oracle_powf(float x, float y) { return om_powf(x, y); }
+EXPORT double oracle_exp(double x) { return om_exp(x); }
+
+/* numpy float32 -> uint8 `astype` on x86-64: cvttss2si to int32, then keep the low byte
+ * ([65025., 300.7, -3.2, 255.9, 256., 1e10] -> [1, 44, 253, 255, 0, 0]). */
+static inline uint8_t f32_to_u8_wrap(float v) {
+    int32_t i;
+    if (!(v > -2147483904.0f && v < 2147483648.0f)) i = INT32_MIN; /* "integer indefinite" */
+    else i = (int32_t)v;
+    return (uint8_t)(uint32_t)i;
+}
+
+/* `sign_d * (abs(d) ** e) * divergence_px` in D32: powf, then two float32 multiplies
+ * (reference :1637,1677,1698,1724,1865,1926; Appendix A rows 2-3). */
+static inline float disparity_f32(float d, float e32, float div32) {
+    float sign = d >= 0.0f ? 1.0f : -1.0f;
+    float p = om_powf(fabsf(d), e32);
+    float sp = sign * p;
+    return sp * div32;
+}
+
+/* -------------------------------------------------------------------------------------------
+ * apply_stereo_divergence_naive (reference :1850-1910): fill 'none' / 'naive' /
+ * 'naive_interpolating'.  img, out: [h][w][3] uint8; nd: [h][w] float32 (already normalised and
+ * convergence-shifted).  div_px / sep_px / exponent are the Python floats (doubles).
+ * ------------------------------------------------------------------------------------------- */
+EXPORT void oracle_naive(const uint8_t *img, const float *nd, int h, int w, double div_px, double sep_px,
+                         double exponent, int fill, uint8_t *out) {
+    float e32 = (float)exponent, div32 = (float)div_px, sep32 = (float)sep_px;
+    uint8_t *derived = out;
+    uint8_t *filled = (uint8_t *)calloc((size_t)h * w, 1);
+    memset(derived, 0, (size_t)h * w * 3);
+    for (int row = 0; row < h; row++) {
+        /* :1862 sweep order so that the later (closer) write wins */
+        int asc = div_px < 0;
+        for (int n = 0; n < w; n++) {
+            int col = asc ? n : w - 1 - n;
+            float d = nd[(size_t)row * w + col];
+            float off = disparity_f32(d, e32, div32) + sep32; /* :1865 */
+            int col_d = col + (int)off;                        /* int(): trunc toward zero */
+            if (0 <= col_d && col_d < w) {
+                memcpy(&derived[((size_t)row * w + col_d) * 3], &img[((size_t)row * w + col) * 3], 3);
+                filled[(size_t)row * w + col_d] = 1;
+            }
+        }
+    }
+    if (fill == FILL_NAIVE_INTERP) {
+        /* :1871-1892.  sum() of a uint8 pixel wraps mod 256 in D32 (quirk Q5). */
+        for (int row = 0; row < h; row++) {
+            uint8_t *drow = &derived[(size_t)row * w * 3];
+            const uint8_t *frow = &filled[(size_t)row * w];
+#define SUM8(p) ((uint8_t)((p)[0] + (p)[1] + (p)[2]))
+            for (int l = 0; l < w; l++) {
+                if (SUM8(&drow[l * 3]) != 0 || frow[l]) continue;
+                uint8_t lb[3] = {0, 0, 0}, rb[3] = {0, 0, 0};
+                if (l > 0) memcpy(lb, &drow[(l - 1) * 3], 3);
+                int r = l + 1;
+                while (r < w) {
+                    if (SUM8(&drow[r * 3]) != 0 && frow[r]) {
+                        memcpy(rb, &drow[r * 3], 3);
+                        break;
+                    }
+                    r++;
+                }
+                if (SUM8(lb) == 0) memcpy(lb, rb, 3);
+                else if (SUM8(rb) == 0) memcpy(rb, lb, 3);
+                float total_steps = (float)(1 + r - l);
+                float step[3];
+                for (int c = 0; c < 3; c++) step[c] = ((float)rb[c] - (float)lb[c]) / total_steps; /* :1889 */
+                for (int col = l; col < r; col++) {
+                    float k = (float)(col - l + 1);
+                    for (int c = 0; c < 3; c++)
+                        drow[col * 3 + c] = (uint8_t)(lb[c] + f32_to_u8_wrap(step[c] * k)); /* :1891 */
+                }
+            }
+#undef SUM8
+        }
+    } else if (fill == FILL_NAIVE) {
+        /* :1893-1908: nearest filled pixel, right before left, reading the pre-fill image. */
+        uint8_t *pre = (uint8_t *)malloc((size_t)h * w * 3);
+        memcpy(pre, derived, (size_t)h * w * 3);
+        int lim = abs((int)div_px) + 2; /* range(1, abs(int(divergence_px)) + 2) */
+        for (int row = 0; row < h; row++) {
+            const uint8_t *frow = &filled[(size_t)row * w];
+            for (int col = 0; col < w; col++) {
+                if (frow[col]) continue;
+                for (int o = 1; o < lim; o++) {
+                    int ro = col + o, lo = col - o;
+                    if (ro < w && frow[ro]) {
+                        memcpy(&derived[((size_t)row * w + col) * 3], &pre[((size_t)row * w + ro) * 3], 3);
+                        break;
+                    }
+                    if (0 <= lo && frow[lo]) {
+                        memcpy(&derived[((size_t)row * w + col) * 3], &pre[((size_t)row * w + lo) * 3], 3);
+                        break;
+                    }
+                }
+            }
+        }
+        free(pre);
+    }
+    free(filled);
+}
+
+/* -------------------------------------------------------------------------------------------
+ * apply_stereo_divergence_polylines (reference :1912-1992), 'polylines_soft' (sharp = 0) and
+ * 'polylines_sharp' (sharp = 1).  Literal transcription; the scalar typing (which values are
+ * np.float32 and which are Python floats at each step) follows SURVEY.md Appendix A.
+ * Returns 0, or -1 if the reference's `csg` scratch (5*int(|div_px|)+25 rows) would overflow
+ * (the reference raises IndexError there).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    float x, z, c;
+} pt_t;
+typedef struct {
+    float x0, z0, c0, x1, z1, c1;
+} sg_t;
+
+EXPORT int oracle_polylines(const uint8_t *img, const float *nd, int h, int w, double div_px, double sep_px,
+                            double exponent, int sharp, uint8_t *out) {
+    const double EPS = 1e-7;
+    const float eps32 = (float)1e-7;
+    float e32 = (float)exponent, div32 = (float)div_px, sep32 = (float)sep_px;
+    float half32 = (float)0.45;
+    int npt_max = 5 + 2 * w;
+    pt_t *pt = (pt_t *)malloc(sizeof(pt_t) * npt_max);
+    sg_t *sg = (sg_t *)malloc(sizeof(sg_t) * npt_max);
+    int csg_cap = 5 * (int)fabs(div_px) + 25;
+    sg_t *csg = (sg_t *)malloc(sizeof(sg_t) * csg_cap);
+    int rc = 0;
+    for (int row = 0; row < h && rc == 0; row++) {
+        const uint8_t *irow = &img[(size_t)row * w * 3];
+        memset(pt, 0, sizeof(pt_t) * npt_max);
+        int pt_end = 0;
+        pt[pt_end++] = (pt_t){(float)(-1.0 * w), 0.0f, 0.0f}; /* :1921 */
+        for (int col = 0; col < w; col++) {
+            float d = nd[(size_t)row * w + col];
+            float coord_d = disparity_f32(d, e32, div32);                 /* :1926 */
+            float coord_x = ((float)(col + 0.5) + coord_d) + sep32;      /* :1927 */
+            if (!sharp) {
+                pt[pt_end++] = (pt_t){coord_x, fabsf(coord_d), (float)col};
+            } else {
+                pt[pt_end++] = (pt_t){coord_x - half32, fabsf(coord_d), (float)col};
+                pt[pt_end++] = (pt_t){coord_x + half32, fabsf(coord_d), (float)col};
+            }
+        }
+        pt[pt_end++] = (pt_t){(float)(2.0 * w), 0.0f, (float)(w - 1)}; /* :1935 */
+        int sg_end = pt_end - 1;
+        for (int i = 0; i < sg_end; i++)
+            sg[i] = (sg_t){pt[i].x, pt[i].z, pt[i].c, pt[i + 1].x, pt[i + 1].z, pt[i + 1].c};
+        /* :1941-1946 insertion sort of pt[0..sg_end) by x, segments permuted in lock-step */
+        for (int i = 1; i < sg_end; i++) {
+            int u = i - 1;
+            while (u >= 0 && pt[u].x > pt[u + 1].x) {
+                pt_t tp = pt[u]; pt[u] = pt[u + 1]; pt[u + 1] = tp;
+                sg_t ts = sg[u]; sg[u] = sg[u + 1]; sg[u + 1] = ts;
+                u--;
+            }
+        }
+        memset(csg, 0, sizeof(sg_t) * csg_cap);
+        int csg_end = 0, sg_pointer = 0, pt_i = 0;
+        for (int col = 0; col < w && rc == 0; col++) {
+            float color[3] = {0.5f, 0.5f, 0.5f};
+            while (pt[pt_i].x < (float)col) pt_i++;
+            pt_i--;
+            while (pt[pt_i].x < (float)(col + 1)) {
+                /* coord_from = max(col, pt.x) + EPSILON ; coord_to = min(col+1, next.x) - EPSILON */
+                int from64, to64;
+                double from_d = 0, to_d = 0;
+                float from_f = 0, to_f = 0;
+                if (pt[pt_i].x > (float)col) { from64 = 0; from_f = pt[pt_i].x + eps32; }
+                else { from64 = 1; from_d = (double)col + EPS; }
+                if (pt[pt_i + 1].x < (float)(col + 1)) { to64 = 0; to_f = pt[pt_i + 1].x - eps32; }
+                else { to64 = 1; to_d = (double)(col + 1) - EPS; }
+                int sig64;
+                double sig_d = 0;
+                float sig_f = 0, center;
+                if (from64 && to64) {
+                    sig64 = 1;
+                    sig_d = to_d - from_d;
+                    double center_d = from_d + 0.5 * sig_d;
+                    center = (float)center_d; /* every later use compares/combines it with float32 */
+                } else {
+                    sig64 = 0;
+                    float tf = to64 ? (float)to_d : to_f;
+                    float ff = from64 ? (float)from_d : from_f;
+                    sig_f = tf - ff;
+                    center = ff + 0.5f * sig_f;
+                }
+                while (sg_pointer < sg_end && sg[sg_pointer].x0 < center) {
+                    if (csg_end >= csg_cap) { rc = -1; break; }
+                    csg[csg_end++] = sg[sg_pointer++];
+                }
+                if (rc) break;
+                int ci = 0;
+                while (ci < csg_end) {
+                    if (csg[ci].x1 < center) { csg[ci] = csg[csg_end - 1]; csg_end--; }
+                    else ci++;
+                }
+                int best = 0;
+                if (csg_end != 1) {
+                    float best_closeness = (float)(-EPS);
+                    for (ci = 0; ci < csg_end; ci++) {
+                        float ip_k = (center - csg[ci].x0) / (csg[ci].x1 - csg[ci].x0);
+                        float closeness = (1.0f - ip_k) * csg[ci].z0 + ip_k * csg[ci].z1;
+                        if (best_closeness < closeness && 0.0f < ip_k && ip_k < 1.0f) {
+                            best_closeness = closeness;
+                            best = ci;
+                        }
+                    }
+                }
+                int col_l = (int)(csg[best].c0 + eps32);
+                int col_r = (int)(csg[best].c1 + eps32);
+                if (col_l == col_r) {
+                    for (int c = 0; c < 3; c++) {
+                        if (sig64) color[c] = (float)((double)color[c] + (double)irow[col_l * 3 + c] * sig_d);
+                        else color[c] = color[c] + (float)irow[col_l * 3 + c] * sig_f;
+                    }
+                } else {
+                    float ip_k = (center - csg[best].x0) / (csg[best].x1 - csg[best].x0);
+                    float om = 1.0f - ip_k;
+                    float s = sig64 ? (float)sig_d : sig_f;
+                    for (int c = 0; c < 3; c++) {
+                        float a = (float)irow[col_l * 3 + c] * om;
+                        float b = (float)irow[col_r * 3 + c] * ip_k;
+                        color[c] = color[c] + (a + b) * s;
+                    }
+                }
+                pt_i++;
+            }
+            for (int c = 0; c < 3; c++) out[((size_t)row * w + col) * 3 + c] = f32_to_u8_wrap(color[c]);
+        }
+    }
+    free(pt); free(sg); free(csg);
+    return rc;
+}
+
+/* -------------------------------------------------------------------------------------------
+ * apply_stereo_divergence_inverse (reference :1715-1737): z-buffered two-column splat.
+ * ------------------------------------------------------------------------------------------- */
+EXPORT void oracle_inverse(const uint8_t *img, const float *nd, int h, int w, double div_px, double sep_px,
+                           double exponent, uint8_t *out) {
+    float e32 = (float)exponent, div32 = (float)div_px, sep32 = (float)sep_px;
+    float *zb = (float *)malloc(sizeof(float) * w);
+    memset(out, 0, (size_t)h * w * 3);
+    for (int row = 0; row < h; row++) {
+        for (int x = 0; x < w; x++) zb[x] = -1.0f;
+        for (int x = 0; x < w; x++) {
+            float d = nd[(size_t)row * w + x];
+            float off = disparity_f32(d, e32, div32);
+            float dest_x = ((float)(x + 0.5) + off) + sep32; /* :1725 */
+            float fl = floorf(dest_x);
+            long j = (long)fl;
+            for (int t = 0; t < 2; t++) {
+                long jj = j + t;
+                if (0 <= jj && jj < w && d > zb[jj]) {
+                    memcpy(&out[((size_t)row * w + jj) * 3], &img[((size_t)row * w + x) * 3], 3);
+                    zb[jj] = d;
+                }
+            }
+        }
+    }
+    free(zb);
+}
+
+/* -------------------------------------------------------------------------------------------
+ * apply_stereo_divergence_hybrid_edge (reference :1837-1848) =
+ *   enhanced_inverse_mapping_with_mask (:1622-1661) + rgb2gray (:1740-1742) +
+ *   edge_aware_gap_fill (:1745-1774).
+ * mask_out (optional, [h][w]) receives the splat-coverage mask (1 = touched).
+ * ------------------------------------------------------------------------------------------- */
+EXPORT void oracle_hybrid_edge(const uint8_t *img, const float *nd, int h, int w, double div_px, double sep_px,
+                               double exponent, uint8_t *out, uint8_t *mask_out) {
+    float e32 = (float)exponent, div32 = (float)div_px, sep32 = (float)sep_px;
+    size_t hw = (size_t)h * w;
+    float *accum = (float *)calloc(hw * 3, sizeof(float));
+    float *wsum = (float *)calloc(hw, sizeof(float));
+    uint8_t *mask = (uint8_t *)calloc(hw, 1);
+    uint8_t *base = (uint8_t *)calloc(hw * 3, 1);
+    for (int row = 0; row < h; row++) {
+        for (int x = 0; x < w; x++) {
+            float d = nd[(size_t)row * w + x];
+            float off = disparity_f32(d, e32, div32);           /* :1637 */
+            float dest_x = ((float)(x + 0.5) + off) + sep32;   /* :1638 */
+            long jc = (long)floorf(dest_x);
+            for (int dd = -1; dd <= 1; dd++) {
+                long j = jc + dd;
+                if (j < 0 || j >= w) continue;
+                float diff = dest_x - (float)j;
+                float arg = -(diff * diff) / 2.0f;             /* float32 until math.exp */
+                double wght = om_exp((double)arg);             /* :1644 */
+                size_t o = (size_t)row * w + j;
+                for (int c = 0; c < 3; c++)                    /* :1646 uint8*float -> f64; f32+f64 -> f64 -> store f32 */
+                    accum[o * 3 + c] = (float)((double)accum[o * 3 + c] + (double)img[((size_t)row * w + x) * 3 + c] * wght);
+                wsum[o] = wsum[o] + (float)wght;               /* :1647 */
+                mask[o] = 1;
+            }
+        }
+    }
+    for (size_t o = 0; o < hw; o++) {
+        if (wsum[o] > 0) {
+            for (int c = 0; c < 3; c++) {
+                float val = accum[o * 3 + c] / wsum[o];
+                if (val < 0) val = 0;
+                else if (val > 255) val = 255;
+                base[o * 3 + c] = (uint8_t)(int)val;
+            }
+        }
+    }
+    /* edge_aware_gap_fill: window 3, sigma_s 1, sigma_r 10; guidance from the UNWARPED source. */
+    double *guid = (double *)malloc(hw * sizeof(double));
+    for (size_t o = 0; o < hw; o++)
+        guid[o] = (0.299 * (double)img[o * 3] + 0.587 * (double)img[o * 3 + 1]) + 0.114 * (double)img[o * 3 + 2];
+    for (int i = 0; i < h; i++) {
+        for (int j = 0; j < w; j++) {
+            size_t o = (size_t)i * w + j;
+            float res[3] = {(float)base[o * 3], (float)base[o * 3 + 1], (float)base[o * 3 + 2]};
+            if (mask[o] == 0) {
+                float nv[3] = {0, 0, 0};
+                double wt = 0.0;
+                for (int di = -1; di <= 1; di++)
+                    for (int dj = -1; dj <= 1; dj++) {
+                        int ni = i + di, nj = j + dj;
+                        if (ni < 0 || ni >= h || nj < 0 || nj >= w) continue;
+                        size_t no = (size_t)ni * w + nj;
+                        if (mask[no] == 0) continue;
+                        int dsq = di * di + dj * dj;
+                        double w_s = om_exp(-(double)dsq / 2.0);
+                        double diff = guid[o] - guid[no];
+                        double w_r = om_exp(-(diff * diff) / 200.0);
+                        double wg = w_s * w_r;
+                        float wg32 = (float)wg;
+                        for (int c = 0; c < 3; c++) nv[c] = nv[c] + (float)base[no * 3 + c] * wg32;
+                        wt += wg;
+                    }
+                if (wt > 0) {
+                    float wt32 = (float)wt;
+                    for (int c = 0; c < 3; c++) res[c] = nv[c] / wt32;
+                }
+            }
+            for (int c = 0; c < 3; c++) {
+                float v = res[c];
+                if (v < 0.0f) v = 0.0f;
+                if (v > 255.0f) v = 255.0f;
+                out[o * 3 + c] = (uint8_t)(int)v;
+            }
+        }
+    }
+    if (mask_out) memcpy(mask_out, mask, hw);
+    free(accum); free(wsum); free(mask); free(base); free(guid);
+}
+
+/* -------------------------------------------------------------------------------------------
+ * apply_stereo_divergence (reference :1576-1620): per-image min/max normalisation, convergence
+ * shift, percent -> pixels, dispatch.  depth: [h][w] float32.  Returns 0 / -1 (csg overflow) /
+ * -2 (unknown fill: the reference returns the image unchanged -- mirrored here).
+ * nd_out (optional) receives the normalised, convergence-shifted depth.
+ * ------------------------------------------------------------------------------------------- */
+EXPORT int oracle_apply_stereo_divergence(const uint8_t *img, const float *depth, int h, int w, double divergence,
+                                          double separation, double exponent, int fill, double convergence,
+                                          uint8_t *out, float *nd_out) {
+    size_t hw = (size_t)h * w;
+    float *nd = (float *)malloc(hw * sizeof(float));
+    float dmin = depth[0], dmax = depth[0];
+    for (size_t i = 1; i < hw; i++) {
+        if (depth[i] < dmin) dmin = depth[i];
+        if (depth[i] > dmax) dmax = depth[i];
+    }
+    float conv32 = (float)convergence;
+    if (dmax == dmin) {
+        for (size_t i = 0; i < hw; i++) nd[i] = 0.0f - conv32;
+    } else {
+        float range = dmax - dmin;
+        for (size_t i = 0; i < hw; i++) nd[i] = ((depth[i] - dmin) / range) - conv32; /* :1594,:1600 */
+    }
+    double div_px = (divergence / 100.0) * (double)w; /* :1602 */
+    double sep_px = (separation / 100.0) * (double)w; /* :1603 */
+    int rc = 0;
+    switch (fill) {
+    case FILL_NONE: case FILL_NAIVE: case FILL_NAIVE_INTERP:
+        oracle_naive(img, nd, h, w, div_px, sep_px, exponent, fill, out); break;
+    case FILL_POLY_SOFT: case FILL_POLY_SHARP:
+        rc = oracle_polylines(img, nd, h, w, div_px, sep_px, exponent, fill == FILL_POLY_SHARP, out); break;
+    case FILL_INVERSE:
+        oracle_inverse(img, nd, h, w, div_px, sep_px, exponent, out); break;
+    case FILL_HYBRID_EDGE:
+        oracle_hybrid_edge(img, nd, h, w, div_px, sep_px, exponent, out, NULL); break;
+    default:
+        memcpy(out, img, hw * 3); rc = -2; break;
+    }
+    if (nd_out) memcpy(nd_out, nd, hw * sizeof(float));
+    free(nd);
+    return rc;
+}
