@@ -430,3 +430,234 @@ EXPORT int oracle_apply_stereo_divergence(const uint8_t *img, const float *depth
     free(nd);
     return rc;
 }
+
+/* -------------------------------------------------------------------------------------------
+ * directional_motion_blur_gpu (reference :1171-1251) + _edge_distance_weight_gpu (:1131-1168)
+ * as executed by CPU torch in the build container: every conv2d
+ * equals raster-order (kh outer, kw inner) fmaf accumulation from 0 with zero padding; all other
+ * steps are separate IEEE float32 elementwise ops.  depth: [B][H][W] on the 0..255 scale.
+ * `falloff` is exact for 0.5 / 1 / 2 / 3 (torch.pow special-cases them); any other exponent goes
+ * through the powf clone and is only approximately what torch's vectorised pow returns (F5).
+ * ------------------------------------------------------------------------------------------- */
+static float torch_pow_scalar(float x, double e) {
+    if (e == 2.0) return x * x;
+    if (e == 1.0) return x;
+    if (e == 0.5) return sqrtf(x);
+    if (e == 3.0) return (x * x) * x;
+    if (e == 0.0) return 1.0f;
+    return om_powf(x, (float)e);
+}
+
+static void edge_distance_weight(const uint8_t *edge, int W, int radius, double falloff, float *wout) {
+    /* two running-max scans give the distance to the nearest edge pixel in the row (:1149-1167) */
+    float large = (float)(radius + 1);
+    float last = -1.0f;
+    for (int c = 0; c < W; c++) {
+        if (edge[c]) last = (float)c;
+        wout[c] = last >= 0.0f ? (float)c - last : large;
+    }
+    last = -1.0f;
+    for (int p = 0; p < W; p++) { /* p indexes the flipped row */
+        int c = W - 1 - p;
+        if (edge[c]) last = (float)p;
+        float dr = last >= 0.0f ? (float)p - last : large;
+        float dist = wout[c] < dr ? wout[c] : dr;
+        float t = 1.0f - dist / (float)radius;
+        t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+        wout[c] = torch_pow_scalar(t, falloff);
+    }
+}
+
+EXPORT void oracle_blur(const float *depth, int B, int H, int W, double strength, double edge_threshold,
+                        double falloff, int vert, float *outL, float *outR) {
+    size_t hw = (size_t)H * W;
+    if (strength <= 0) { /* :1194 */
+        memcpy(outL, depth, sizeof(float) * hw * B);
+        memcpy(outR, depth, sizeof(float) * hw * B);
+        return;
+    }
+    int bs = (int)nearbyint(strength); /* Python round(): half to even */
+    int radius = (int)strength;        /* int(blur_mask_width) */
+    float den = (float)(10.0 * edge_threshold);
+    float *wl = (float *)malloc(sizeof(float) * hw), *wr = (float *)malloc(sizeof(float) * hw);
+    float *tl = (float *)malloc(sizeof(float) * hw), *tr = (float *)malloc(sizeof(float) * hw);
+    uint8_t *el = (uint8_t *)malloc(W), *er = (uint8_t *)malloc(W);
+    static const float SOB[3][3] = {{-1, 0, 1}, {-2, 0, 2}, {-1, 0, 1}};
+    for (int b = 0; b < B; b++) {
+        const float *d = depth + hw * b;
+        for (int y = 0; y < H; y++) {
+            for (int x = 0; x < W; x++) {
+                float g = 0.0f;
+                for (int ky = 0; ky < 3; ky++)
+                    for (int kx = 0; kx < 3; kx++) {
+                        int yy = y + ky - 1, xx = x + kx - 1;
+                        float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? d[(size_t)yy * W + xx] : 0.0f;
+                        g = fmaf(SOB[ky][kx], v, g);
+                    }
+                float es = fabsf(g) / den;
+                es = es < 0.0f ? 0.0f : (es > 1.0f ? 1.0f : es);
+                el[x] = (g > 0.0f) && (es > 0.5f);
+                er[x] = (g < 0.0f) && (es > 0.5f);
+            }
+            edge_distance_weight(el, W, radius, falloff, wl + (size_t)y * W);
+            edge_distance_weight(er, W, radius, falloff, wr + (size_t)y * W);
+        }
+        if (vert > 0) { /* :1229-1233 vertical box on the weights, zero padding */
+            float kv = 1.0f / (float)(2 * vert + 1);
+            for (int y = 0; y < H; y++)
+                for (int x = 0; x < W; x++) {
+                    float a = 0.0f, c = 0.0f;
+                    for (int ky = 0; ky < 2 * vert + 1; ky++) {
+                        int yy = y + ky - vert;
+                        float vl = (yy >= 0 && yy < H) ? wl[(size_t)yy * W + x] : 0.0f;
+                        float vr = (yy >= 0 && yy < H) ? wr[(size_t)yy * W + x] : 0.0f;
+                        a = fmaf(kv, vl, a);
+                        c = fmaf(kv, vr, c);
+                    }
+                    tl[(size_t)y * W + x] = a;
+                    tr[(size_t)y * W + x] = c;
+                }
+            memcpy(wl, tl, sizeof(float) * hw);
+            memcpy(wr, tr, sizeof(float) * hw);
+        }
+        float kb = 1.0f / (float)bs;
+        int pad = bs / 2;
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                float acc = 0.0f;
+                for (int k = 0; k < bs; k++) {
+                    int xx = x + k - pad;
+                    float v = (xx >= 0 && xx < W) ? d[(size_t)y * W + xx] : 0.0f;
+                    acc = fmaf(kb, v, acc);
+                }
+                size_t o = (size_t)y * W + x;
+                float dv = d[o];
+                outL[hw * b + o] = wl[o] * acc + (1.0f - wl[o]) * dv; /* :1243 */
+                outR[hw * b + o] = wr[o] * acc + (1.0f - wr[o]) * dv; /* :1244 */
+            }
+    }
+    free(wl); free(wr); free(tl); free(tr); free(el); free(er);
+}
+
+/* -------------------------------------------------------------------------------------------
+ * forward_warp_gpu (reference :277-450) as executed by CPU torch (deterministic: gather from the
+ * pre-iteration state, then a sequential scatter where the highest pair index wins and
+ * non-winners write back what they gathered -- quirk Q3; "nearest right" = the row's rightmost
+ * filled column -- quirk Q2).  image: [B][3][H][W] f32 0..1; depth: [B][H][W]; out: [B][3][H][W];
+ * mask: [B][H][W] (1 = disocclusion gap before filling).  The gap mask is exact for exponents
+ * 2 / 1 / 0.5; colours follow the grid_sample coordinate round trip and are compared with a
+ * tolerance (torch's vectorised bilinear kernel is not bit-reproducible).
+ * ------------------------------------------------------------------------------------------- */
+EXPORT void oracle_forward_warp_gpu(const float *image, const float *depth, int B, int H, int W, double div_px,
+                                    double sep_px, double exponent, double convergence, float *out, uint8_t *mask) {
+    size_t hw = (size_t)H * W;
+    int any_gt1 = 0;
+    for (size_t i = 0; i < hw * B; i++)
+        if (depth[i] > 1.0f) { any_gt1 = 1; break; }
+    float div32 = (float)div_px, sep32 = (float)sep_px, conv32 = (float)convergence;
+    float *nd = (float *)malloc(sizeof(float) * W), *po = (float *)malloc(sizeof(float) * W);
+    float *dest = (float *)malloc(sizeof(float) * W);
+    float *src = (float *)malloc(sizeof(float) * W), *zb = (float *)malloc(sizeof(float) * W);
+    float *nz = (float *)malloc(sizeof(float) * W), *ns = (float *)malloc(sizeof(float) * W);
+    long *cs = (long *)malloc(sizeof(long) * W);
+    float sx = (float)(W - 1);
+    /* torch.linspace(-1, 1, H): symmetric fill, float32 (gpu_warp tolerance) */
+    float *gy = (float *)malloc(sizeof(float) * H);
+    {
+        float step = H > 1 ? (1.0f - (-1.0f)) / (float)(H - 1) : 0.0f;
+        int half = H / 2;
+        for (int i = 0; i < H; i++) gy[i] = i < half ? -1.0f + step * (float)i : 1.0f - step * (float)(H - i - 1);
+    }
+    for (int b = 0; b < B; b++) {
+        const float *db = depth + hw * b;
+        float dmin = INFINITY, dmax = -INFINITY;
+        for (size_t i = 0; i < hw; i++) {
+            float v = any_gt1 ? db[i] / 255.0f : db[i];
+            if (v < dmin) dmin = v;
+            if (v > dmax) dmax = v;
+        }
+        float range = dmax - dmin;
+        float crange = range < (float)1e-6 ? (float)1e-6 : range;
+        for (int y = 0; y < H; y++) {
+            for (int x = 0; x < W; x++) {
+                float v = any_gt1 ? db[(size_t)y * W + x] / 255.0f : db[(size_t)y * W + x];
+                float n = range > (float)1e-6 ? (v - dmin) / crange : 0.0f;
+                nd[x] = n;
+                float s = n - conv32;
+                float sg = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
+                float od = sg * torch_pow_scalar(fabsf(s), exponent);
+                po[x] = od * div32 + sep32;
+                dest[x] = (float)x + po[x];
+                src[x] = -1.0f;
+                zb[x] = -1.0f;
+            }
+            for (int k = 0; k < 8; k++) {
+                for (int i = 0; i < W - 1; i++) {
+                    int connected = fabsf(po[i + 1] - po[i]) < 1.5f;
+                    float dl = dest[i], dr = dest[i + 1];
+                    float dmn = dl < dr ? dl : dr;
+                    long c = (long)floorf(dmn) + k;
+                    long c_safe = c < 0 ? 0 : (c > W - 1 ? W - 1 : c);
+                    float sw = dr - dl;
+                    float safe = fabsf(sw) < (float)1e-4 ? 1.0f : sw;
+                    float frac = ((float)c - dl) / safe;
+                    int valid = connected && c >= 0 && c < W && frac >= 0.0f && frac < 1.0f;
+                    float sp = (float)i + frac;
+                    float iz = nd[i] * (1.0f - frac) + nd[i + 1] * frac;
+                    float cz = zb[c_safe], csrc = src[c_safe];
+                    int better = valid && (iz > cz + (float)1e-6);
+                    nz[i] = better ? iz : cz;
+                    ns[i] = better ? sp : csrc;
+                    cs[i] = c_safe;
+                }
+                for (int i = 0; i < W - 1; i++) { zb[cs[i]] = nz[i]; src[cs[i]] = ns[i]; }
+            }
+            /* step 5: gap fill */
+            uint8_t *mrow = mask + hw * b + (size_t)y * W;
+            long rightmost = -1;
+            for (int x = 0; x < W; x++) { mrow[x] = src[x] < 0.0f; if (!mrow[x]) rightmost = x; }
+            long left = -1;
+            for (int x = 0; x < W; x++) {
+                if (!mrow[x]) { left = x; ns[x] = src[x]; continue; }
+                long right = (rightmost >= x) ? rightmost : -1; /* Q2 */
+                int has_l = left >= 0, has_r = right >= 0;
+                long li = left < 0 ? 0 : left, ri = right < 0 ? 0 : right;
+                float lsrc = src[li], rsrc = src[ri], lz = zb[li], rz = zb[ri];
+                float ld = (float)(x - left), rd = (float)(right - x);
+                float tot = ld + rd; if (tot < 1.0f) tot = 1.0f;
+                float t = ld / tot;
+                if (!has_l) t = 1.0f;
+                if (!has_r) t = 0.0f;
+                float tb = (lz < rz) ? sqrtf(t) : 1.0f - sqrtf(1.0f - t);
+                float g = lsrc * (1.0f - tb) + rsrc * tb;
+                ns[x] = (has_l || has_r) ? g : src[x];
+            }
+            /* step 6: grid_sample(bilinear, border, align_corners=True) through the [-1,1] round trip */
+            float yy = (gy[y] + 1.0f) * ((float)(H - 1) / 2.0f);
+            yy = yy < 0.0f ? 0.0f : (yy > (float)(H - 1) ? (float)(H - 1) : yy);
+            float yn = floorf(yy);
+            float wn = yy - yn, ws_ = 1.0f - wn;
+            long iy0 = (long)yn, iy1 = iy0 + 1;
+            if (iy1 > H - 1) iy1 = H - 1;
+            for (int x = 0; x < W; x++) {
+                float s = ns[x];
+                s = s < 0.0f ? 0.0f : (s > sx ? sx : s);
+                float gx = s * 2.0f / sx - 1.0f;
+                float xx = (gx + 1.0f) * (sx / 2.0f);
+                xx = xx < 0.0f ? 0.0f : (xx > sx ? sx : xx);
+                float xw = floorf(xx);
+                float ww = xx - xw, we = 1.0f - ww;
+                long ix0 = (long)xw, ix1 = ix0 + 1;
+                if (ix1 > W - 1) ix1 = W - 1;
+                float nw = ws_ * we, ne = ws_ * ww, sw2 = wn * we, se = wn * ww;
+                for (int c = 0; c < 3; c++) {
+                    const float *pl = image + ((size_t)b * 3 + c) * hw;
+                    float v = pl[(size_t)iy0 * W + ix0] * nw + pl[(size_t)iy0 * W + ix1] * ne +
+                              pl[(size_t)iy1 * W + ix0] * sw2 + pl[(size_t)iy1 * W + ix1] * se;
+                    out[((size_t)b * 3 + c) * hw + (size_t)y * W + x] = v;
+                }
+            }
+        }
+    }
+    free(nd); free(po); free(dest); free(src); free(zb); free(nz); free(ns); free(cs); free(gy);
+}

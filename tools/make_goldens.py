@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the imported reference on seeded synthetic inputs.
+
+Build-container only (needs /root/reference, which never travels to the GPU box).  The committed
+fixtures are DATA: inputs and the reference's outputs, plus a manifest of the environment that
+produced them.  Dialect: D32 (no numba, NumPy 2 promotion rules) -- the only one executable here.
+
+  python tools/make_goldens.py            # regenerate everything (~3-4 min)
+"""
+import hashlib
+import json
+import os
+import platform
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import refload  # noqa: E402
+import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+FILLS = ["none", "naive", "naive_interpolating", "polylines_soft", "polylines_sharp", "inverse", "hybrid_edge"]
+UI_FILLS = {
+    "gpu_warp": "GPU Warp (Fast)", "none": "No fill", "inverse": "No fill - Reverse projection",
+    "hybrid_edge": "Imperfect fill - Hybrid Edge", "naive": "Fill - Naive",
+    "naive_interpolating": "Fill - Naive interpolating", "polylines_soft": "Fill - Polylines Soft",
+    "polylines_sharp": "Fill - Polylines Sharp",
+}
+MODES = ["left-right", "right-left", "top-bottom", "bottom-top", "red-cyan-anaglyph"]
+
+# (divergence %, separation %, exponent, convergence): both signs, the hard exponents, sep != 0
+ASD_PARAMS = [(5.0, 0.0, 2.0, 0.5), (-5.0, 0.0, 2.0, 0.5), (8.0, 1.3, 1.3, 0.7), (-12.0, -1.3, 0.5, 0.0),
+              (3.0, 0.0, 1.0, 0.3), (-3.5, 0.4, 0.1, 1.0)]
+ASD_KINDS = ["radial", "stepped", "noisy_ramp", "random8", "blobs"]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def gen_apply_stereo_divergence(sig):
+    """Fixture for apply_stereo_divergence (reference :1576-1620 and every row kernel below it)."""
+    H, W = 16, 96
+    cases, arrays = [], {}
+    for ki, kind in enumerate(ASD_KINDS):
+        for pi, (div, sep, e, conv) in enumerate(ASD_PARAMS):
+            if kind == "random8" and abs(div) > 6:
+                div = 4.0 if div > 0 else -4.0  # keep the reference's csg scratch from overflowing
+            img = synth.image_u8(H, W, seed=10 * ki + pi)
+            depth = synth.DEPTHS[kind](H, W) * np.float32(255.0)
+            cid = f"{kind}_{pi}"
+            arrays[f"{cid}/img"] = img
+            arrays[f"{cid}/depth"] = depth
+            for fill in FILLS:
+                arrays[f"{cid}/out/{fill}"] = sig.apply_stereo_divergence(img, depth, div, sep, e, fill, conv)
+            cases.append(dict(id=cid, kind=kind, divergence=div, separation=sep, exponent=e, convergence=conv))
+    # flat depth (max == min branch, :1591) and a zero-disparity case
+    img = synth.image_u8(8, 40, seed=77)
+    for cid, depth, div in (("flat", np.full((8, 40), 93.0, np.float32), 6.0),
+                            ("tinydiv", synth.radial(8, 40) * np.float32(255), 0.01)):
+        arrays[f"{cid}/img"] = img
+        arrays[f"{cid}/depth"] = depth
+        for fill in FILLS:
+            arrays[f"{cid}/out/{fill}"] = sig.apply_stereo_divergence(img, depth, div, 0.0, 2.0, fill, 0.5)
+        cases.append(dict(id=cid, kind=cid, divergence=div, separation=0.0, exponent=2.0, convergence=0.5))
+    # larger frames: digests only (inputs come from tools/synth.py, also shipped)
+    digests = []
+    for (H2, W2, kind, div, sep, e, conv) in [(64, 512, "blobs", 6.0, 0.0, 2.0, 0.5), (64, 512, "stepped", -8.0, 0.5, 1.5, 0.4),
+                                               (48, 640, "noisy_ramp", 3.5, 0.0, 0.7, 0.5)]:
+        img = synth.image_u8(H2, W2, seed=5)
+        depth = synth.DEPTHS[kind](H2, W2) * np.float32(255.0)
+        d = dict(h=H2, w=W2, kind=kind, divergence=div, separation=sep, exponent=e, convergence=conv, img_seed=5,
+                 img_sha=sha(img), depth_sha=sha(depth), out={})
+        for fill in FILLS:
+            d["out"][fill] = sha(sig.apply_stereo_divergence(img, depth, div, sep, e, fill, conv))
+        digests.append(d)
+    np.savez_compressed(os.path.join(OUT, "apply_stereo_divergence.npz"),
+                        meta=json.dumps(dict(cases=cases, fills=FILLS, digests=digests)), **arrays)
+    print("apply_stereo_divergence:", len(cases), "cases x", len(FILLS), "fills +", len(digests), "digest cases")
+
+
+def gen_blur(sig):
+    """Fixture for directional_motion_blur_gpu (reference :1171-1251) on CPU torch."""
+    arrays, cases = {}, []
+    specs = [(256, 256, 1, "blobs", 20, 20, 2.0, 6), (256, 256, 2, "stepped", 21, 6, 2.0, 3),
+             (270, 480, 1, "blobs", 5.4, 0.5, 1.0, 15), (256, 256, 1, "noisy_ramp", 20, 20, 0.5, 0)]
+    for i, (H, W, B, kind, st, thr, fo, v) in enumerate(specs):
+        d8 = np.stack([np.round(synth.DEPTHS[kind](H, W, **({} if kind in ("radial", "stepped") else {"seed": j})) * 255)
+                       for j in range(B)]).astype(np.uint8)
+        if kind == "stepped":
+            d8 = np.stack([np.round(synth.stepped(H, W, cx=W / 2 + 9 * j) * 255) for j in range(B)]).astype(np.uint8)
+        depth = d8.astype(np.float32)
+        t = torch.from_numpy(depth.copy())
+        L, R = sig.directional_motion_blur_gpu(t if B > 1 else t[0], st, thr, st, falloff_exponent=fo, vert_smooth_px=v)
+        arrays[f"c{i}/depth_u8"] = d8
+        arrays[f"c{i}/L"] = L.numpy().reshape(depth.shape)
+        arrays[f"c{i}/R"] = R.numpy().reshape(depth.shape)
+        cases.append(dict(id=f"c{i}", strength=st, edge_threshold=thr, falloff=fo, vert=v, batch=B))
+    digests = []
+    for (H, W, kind, st, thr, fo, v) in [(540, 960, "blobs", 20, 20, 2.0, 6), (1080, 1920, "blobs", 20, 20, 2.0, 6)]:
+        depth = np.round(synth.DEPTHS[kind](H, W, seed=1) * 255).astype(np.float32)
+        L, R = sig.directional_motion_blur_gpu(torch.from_numpy(depth.copy()), st, thr, st, falloff_exponent=fo,
+                                               vert_smooth_px=v)
+        digests.append(dict(h=H, w=W, kind=kind, seed=1, strength=st, edge_threshold=thr, falloff=fo, vert=v,
+                            depth_sha=sha(depth), L=sha(L.numpy()), R=sha(R.numpy())))
+    np.savez_compressed(os.path.join(OUT, "blur.npz"), meta=json.dumps(dict(cases=cases, digests=digests)), **arrays)
+    print("blur:", len(cases), "cases +", len(digests), "digests")
+
+
+def gen_forward_warp(sig):
+    """Fixture for forward_warp_gpu (reference :277-450) on CPU torch."""
+    arrays, cases = {}, []
+    specs = [(64, 96, 2, "stepped", 16.8, 0.0, 2.0, 0.5, 255.0), (64, 96, 1, "blobs", -16.8, 1.5, 2.0, 0.5, 1.0),
+             (48, 160, 1, "noisy_ramp", 12.0, -1.0, 1.0, 0.3, 255.0), (32, 128, 1, "random8", -7.0, 0.0, 0.5, 0.7, 255.0),
+             (48, 160, 1, "blobs", 10.0, 0.0, 1.3, 0.5, 255.0)]
+    for i, (H, W, B, kind, dpx, spx, e, conv, scale) in enumerate(specs):
+        d8 = np.stack([np.round((synth.DEPTHS[kind](H, W, cx=W / 2 + 7 * j) if kind in ("radial", "stepped")
+                                 else synth.DEPTHS[kind](H, W, seed=j)) * 255) for j in range(B)]).astype(np.uint8)
+        depth = d8.astype(np.float32) * np.float32(scale / 255.0) if scale == 1.0 else d8.astype(np.float32)
+        if scale == 1.0:
+            depth = d8.astype(np.float32) / np.float32(255.0)
+        img8 = np.random.default_rng(40 + i).integers(0, 256, (B, 3, H, W), dtype=np.uint8)
+        img = img8.astype(np.float32) / np.float32(255.0)
+        wr, mr = sig.forward_warp_gpu(torch.from_numpy(img), torch.from_numpy(depth), dpx, spx, e, conv)
+        arrays[f"c{i}/img_u8"] = img8
+        arrays[f"c{i}/depth_u8"] = d8
+        arrays[f"c{i}/warped"] = wr.numpy()
+        arrays[f"c{i}/mask"] = np.packbits(mr.numpy())
+        cases.append(dict(id=f"c{i}", divergence_px=dpx, separation_px=spx, exponent=e, convergence=conv,
+                          depth_scale=scale, shape=[B, H, W]))
+    np.savez_compressed(os.path.join(OUT, "forward_warp_gpu.npz"), meta=json.dumps(dict(cases=cases)), **arrays)
+    print("forward_warp_gpu:", len(cases), "cases")
+
+
+def smooth_image(n, h, w, seed):
+    """Low-entropy 8-bit image batch (keeps the committed fixture small); includes black pixels."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    frames = []
+    for i in range(n):
+        r = (x * 255 // max(w - 1, 1) + 13 * i) % 256
+        g = (y * 255 // max(h - 1, 1)) % 256
+        b = ((x // 8 + y // 8) % 2) * 200 + 20
+        f = np.stack([r, g, b], -1).astype(np.uint8)
+        f[rng.integers(0, h, 12), rng.integers(0, w, 12)] = 0
+        frames.append(f)
+    return np.stack(frames)
+
+
+def gen_node(gs):
+    """Fixture for StereoImageNode.generate (reference GenerateStereo.py:79-353): every UI technique x mode."""
+    node = gs.StereoImageNode()
+    arrays, cases = {}, []
+
+    def run(cid, img8, depth, fill, mode, div=8.0, sep=0.0, bal=0.0, conv=0.5, e=2.0, thr=20.0, st=20.0, blur=False, **kw):
+        image = torch.from_numpy(img8.astype(np.float32) / np.float32(255.0))
+        outs = node.generate(image, torch.from_numpy(depth), div, sep, mode, bal, conv, e, UI_FILLS[fill], thr, st, blur, **kw)
+        stereo, dl, dr, mask = [o.numpy() for o in outs]
+        if fill == "gpu_warp":
+            arrays[f"{cid}/stereo"] = stereo
+            arrays[f"{cid}/dl"] = dl[..., 0].copy()
+            arrays[f"{cid}/dr"] = dr[..., 0].copy()
+        else:  # CPU techniques: every output value is k/255 exactly -> store k
+            for name, a in (("stereo", stereo), ("dl", dl[..., 0]), ("dr", dr[..., 0])):
+                k = np.round(a * 255.0).astype(np.uint8)
+                assert np.array_equal(k.astype(np.float32) / np.float32(255.0), a)
+                arrays[f"{cid}/{name}_u8"] = k
+            assert np.array_equal(dl[..., 0], dl[..., 1]) and np.array_equal(dl[..., 0], dl[..., 2])
+        assert set(np.unique(mask)) <= {0.0, 1.0}
+        arrays[f"{cid}/mask"] = np.packbits(mask.astype(bool))
+        cases.append(dict(id=cid, fill=fill, mode=mode, divergence=div, separation=sep, balance=bal, convergence=conv,
+                          exponent=e, edge_threshold=thr, strength=st, blur=blur, kw=kw,
+                          shapes=dict(stereo=list(stereo.shape), depth=list(dl.shape), mask=list(mask.shape))))
+
+    # (i) every technique x mode, N=2, 32x64, blur off (tiny frames + blur take a different oneDNN kernel)
+    img8 = np.stack([synth.image_u8(32, 64, seed=s) for s in (1, 2)])
+    depth = synth.depth_batch("stepped", 2, 32, 64, channels=3)
+    arrays["small/img_u8"] = img8
+    arrays["small/depth"] = depth
+    for fill in UI_FILLS:
+        for mode in MODES:
+            run(f"small/{fill}/{mode}", img8, depth, fill, mode, batch_size=12)
+    # (ii) parameter variants on the same inputs: balance, separation, exponent, convergence, sub-batching (Q9/Q10)
+    img8 = np.stack([synth.image_u8(24, 80, seed=s) for s in (3, 4, 5)])
+    depth1 = synth.depth_batch("blobs", 3, 24, 80, channels=1)
+    arrays["var/img_u8"] = img8
+    arrays["var/depth"] = depth1
+    run("var/poly_bal", img8, depth1, "polylines_soft", "left-right", div=6.0, bal=0.4, sep=0.5, conv=0.35, e=1.3, batch_size=2)
+    run("var/none_onesided", img8, depth1, "none", "red-cyan-anaglyph", div=0.05, bal=0.95, batch_size=1)
+    run("var/naive_interp", img8, depth1, "naive_interpolating", "top-bottom", div=9.0, bal=-0.3, e=0.5, conv=1.0)
+    run("var/gpu_defaults", img8, depth1, "gpu_warp", "left-right", div=4.5, batch_size=2)
+    run("var/hybrid", img8, depth1, "hybrid_edge", "right-left", div=7.0, sep=-0.7)
+    # (iii) blur ON at 256x256 (bit-reproducible conv path), smooth image so the fixture stays small
+    img8 = smooth_image(2, 256, 256, 9)
+    depth8 = np.stack([np.round(synth.blobs(256, 256, seed=j) * 255) for j in range(2)]).astype(np.uint8)
+    depthb = np.repeat((depth8.astype(np.float32) / np.float32(255.0))[..., None], 3, -1)
+    arrays["blur/img_u8"] = img8
+    arrays["blur/depth_u8"] = depth8
+    kw = dict(depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+    run("blur/polylines_soft", img8, depthb, "polylines_soft", "left-right", div=4.5, blur=True, **kw)
+    run("blur/none_anaglyph", img8, depthb, "none", "red-cyan-anaglyph", div=4.5, blur=True, **kw)
+    run("blur/gpu_warp", img8, depthb, "gpu_warp", "left-right", div=4.5, blur=True, **kw)
+    # (iv) depth size != image size (bilinear resize, GenerateStereo.py:214-220) -- tolerance-checked
+    img8 = np.stack([synth.image_u8(32, 64, seed=8)])
+    depth_small = synth.depth_batch("radial", 1, 20, 36, channels=3)
+    arrays["resize/img_u8"] = img8
+    arrays["resize/depth"] = depth_small
+    run("resize/none", img8, depth_small, "none", "left-right", div=5.0)
+    np.savez_compressed(os.path.join(OUT, "node_generate.npz"), meta=json.dumps(dict(cases=cases)), **arrays)
+    print("node_generate:", len(cases), "cases")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    refload.quiet()
+    torch.manual_seed(0)
+    sig = refload.load_sig()
+    gs = refload.load_node()
+    manifest = dict(dialect="D32 (numba absent, NumPy NEP-50 scalar promotion)", python=platform.python_version(),
+                    numpy=np.__version__, torch=torch.__version__, torch_threads=torch.get_num_threads(),
+                    glibc=platform.libc_ver()[1], machine=platform.machine(),
+                    reference="Dobidop/ComfyStereo v2.1.3 @ /root/reference (read-only)",
+                    generator="tools/make_goldens.py")
+    gen_apply_stereo_divergence(sig)
+    gen_blur(sig)
+    gen_forward_warp(sig)
+    gen_node(gs)
+    with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("fixtures written to", OUT, "total bytes", tot)
+
+
+if __name__ == "__main__":
+    main()
