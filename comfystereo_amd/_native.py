@@ -1,0 +1,100 @@
+"""ctypes binding of libcomfystereo_hip.so (the C ABI declared in include/comfystereo_amd.h).
+
+There is no CPU fallback: if the HIP library is missing or does not load, importing this module's
+`lib()` raises.  Build it with `python __graft_entry__.py` or `make -C comfystereo_amd/csrc`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcomfystereo_hip.so")
+
+CS_OK, CS_EINVAL, CS_EWORKSPACE, CS_ELIMIT, CS_EHIP = 0, -1, -2, -3, -4
+
+FILL = {
+    "none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3, "polylines_sharp": 4, "inverse": 5,
+    "hybrid_edge": 6, "gpu_warp": 7,
+}
+MODE = {
+    "left-right": 0, "right-left": 1, "top-bottom": 2, "bottom-top": 3, "red-cyan-anaglyph": 4, "left-only": 5,
+    "only-right": 6, "cyan-red-reverseanaglyph": 7,
+}
+
+EXPORTS = [
+    "cs_version", "cs_last_error", "cs_max_width", "cs_output_shape", "cs_workspace_bytes", "cs_generate",
+    "cs_asd_workspace_bytes", "cs_apply_stereo_divergence", "cs_blur_workspace_bytes", "cs_directional_blur",
+    "cs_warp_workspace_bytes", "cs_forward_warp", "cs_test_powf", "cs_test_exp",
+]
+
+
+class Params(ctypes.Structure):
+    """struct cs_params (include/comfystereo_amd.h)."""
+    _fields_ = [
+        ("n", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32),
+        ("depth_h", ctypes.c_int32), ("depth_w", ctypes.c_int32), ("depth_c", ctypes.c_int32),
+        ("fill", ctypes.c_int32), ("mode", ctypes.c_int32), ("batch_size", ctypes.c_int32),
+        ("depth_map_blur", ctypes.c_int32), ("depth_blur_vert_smooth", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("divergence", ctypes.c_double), ("separation", ctypes.c_double), ("stereo_balance", ctypes.c_double),
+        ("convergence_point", ctypes.c_double), ("stereo_offset_exponent", ctypes.c_double),
+        ("depth_blur_strength", ctypes.c_double), ("depth_blur_edge_threshold", ctypes.c_double),
+        ("depth_blur_falloff", ctypes.c_double),
+    ]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"comfystereo_amd native call failed ({code}): {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is not built (run `python __graft_entry__.py` or "
+            "`make -C comfystereo_amd/csrc`).  comfystereo_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, c_int, c_double, c_size = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+    pp = ctypes.POINTER(Params)
+    ip = ctypes.POINTER(ctypes.c_int)
+    L.cs_version.restype = c_int
+    L.cs_version.argtypes = []
+    L.cs_last_error.restype = ctypes.c_char_p
+    L.cs_last_error.argtypes = []
+    L.cs_max_width.restype = c_int
+    L.cs_max_width.argtypes = [c_int]
+    L.cs_output_shape.restype = c_int
+    L.cs_output_shape.argtypes = [pp, ip, ip, ip, ip]
+    L.cs_workspace_bytes.restype = c_size
+    L.cs_workspace_bytes.argtypes = [pp]
+    L.cs_generate.restype = c_int
+    L.cs_generate.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, c_size, vp]
+    L.cs_asd_workspace_bytes.restype = c_size
+    L.cs_asd_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    L.cs_apply_stereo_divergence.restype = c_int
+    L.cs_apply_stereo_divergence.argtypes = [vp, vp, c_int, c_int, c_int, c_double, c_double, c_double, c_int, c_double,
+                                             vp, vp, c_size, vp]
+    L.cs_blur_workspace_bytes.restype = c_size
+    L.cs_blur_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    L.cs_directional_blur.restype = c_int
+    L.cs_directional_blur.argtypes = [vp, c_int, c_int, c_int, c_double, c_double, c_double, c_int, vp, vp, vp, c_size, vp]
+    L.cs_warp_workspace_bytes.restype = c_size
+    L.cs_warp_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    L.cs_forward_warp.restype = c_int
+    L.cs_forward_warp.argtypes = [vp, vp, c_int, c_int, c_int, c_double, c_double, c_double, c_double, vp, vp, vp, c_size, vp]
+    L.cs_test_powf.restype = c_int
+    L.cs_test_powf.argtypes = [vp, ctypes.c_float, vp, c_size, vp]
+    L.cs_test_exp.restype = c_int
+    L.cs_test_exp.argtypes = [vp, vp, c_size, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != CS_OK:
+        raise NativeError(rc, lib().cs_last_error().decode("utf-8", "replace"))

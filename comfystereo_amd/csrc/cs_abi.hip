@@ -1,0 +1,443 @@
+// cs_abi.hip -- the extern "C" boundary (include/comfystereo_amd.h) and the small streaming kernels
+// around the row kernels: depth grayscale + per-frame min/max, bilinear depth resize, per-frame
+// decisions (0..255 scaling), device self-tests of the libm-exact math.
+#include <stdio.h>
+#include <string.h>
+
+#include "cs_common.h"
+#include "cs_kernels.h"
+
+namespace cs {
+
+static thread_local char g_err[256] = "";
+static int fail(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+static int fail_hip(hipError_t e, const char* where) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return CS_EHIP;
+}
+
+// ---------------------------------------------------------------------------------------------
+// streaming kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void k_stats_init(uint32_t* stats, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * ST_WORDS) return;
+    int wd = i % ST_WORDS;
+    bool is_min = wd == ST_GRAY_MIN || wd == ST_L_MIN || wd == ST_R_MIN;
+    stats[i] = is_min ? 0xffffffffu : 0u;
+}
+
+__device__ __forceinline__ void block_minmax_commit(float mn, float mx, uint32_t* st_min, uint32_t* st_max) {
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if (lane_id() == 0) {
+        atomicMin(st_min, csm::f2ord(mn));
+        atomicMax(st_max, csm::f2ord(mx));
+    }
+}
+
+// gray = (0.2989 R + 0.5870 G) + 0.1140 B with separate float32 roundings (GenerateStereo.py:134-139,
+// 206-209); C == 1 -> the channel; other C -> channel 0.  grid: (blocks, n).
+__global__ void __launch_bounds__(256) k_gray(const float* __restrict__ depth, float* __restrict__ gray, int hw,
+                                              int c, uint32_t* stats, int do_minmax) {
+    const int frame = blockIdx.y;
+    const float* src = depth + (size_t)frame * hw * c;
+    float* dst = gray + (size_t)frame * hw;
+    float mn = INFINITY, mx = -INFINITY;
+    const int stride = gridDim.x * blockDim.x;
+    if (c == 3 && (hw & 3) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < hw / 4; q += stride) {
+            float4 a = s4[3 * q], b = s4[3 * q + 1], cc = s4[3 * q + 2];
+            float4 g;
+            g.x = (0.2989f * a.x + 0.5870f * a.y) + 0.1140f * a.z;
+            g.y = (0.2989f * a.w + 0.5870f * b.x) + 0.1140f * b.y;
+            g.z = (0.2989f * b.z + 0.5870f * b.w) + 0.1140f * cc.x;
+            g.w = (0.2989f * cc.y + 0.5870f * cc.z) + 0.1140f * cc.w;
+            d4[q] = g;
+            mn = fminf(fminf(mn, g.x), fminf(g.y, fminf(g.z, g.w)));
+            mx = fmaxf(fmaxf(mx, g.x), fmaxf(g.y, fmaxf(g.z, g.w)));
+        }
+    } else {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += stride) {
+            float g;
+            if (c == 3) g = (0.2989f * src[3 * i] + 0.5870f * src[3 * i + 1]) + 0.1140f * src[3 * i + 2];
+            else g = src[(size_t)i * c];
+            dst[i] = g;
+            mn = fminf(mn, g);
+            mx = fmaxf(mx, g);
+        }
+    }
+    if (do_minmax) block_minmax_commit(mn, mx, &stats[frame * ST_WORDS + ST_GRAY_MIN], &stats[frame * ST_WORDS + ST_GRAY_MAX]);
+}
+
+// per-frame min/max of a [n][hw] float array into the given stats words
+__global__ void __launch_bounds__(256) k_minmax(const float* __restrict__ a, int hw, uint32_t* stats, int wmin, int wmax) {
+    const int frame = blockIdx.y;
+    const float* src = a + (size_t)frame * hw;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+        float g = src[i];
+        mn = fminf(mn, g);
+        mx = fmaxf(mx, g);
+    }
+    block_minmax_commit(mn, mx, &stats[frame * ST_WORDS + wmin], &stats[frame * ST_WORDS + wmax]);
+}
+
+// F.interpolate(mode='bilinear', align_corners=False) of the gray depth (GenerateStereo.py:141-148,
+// 214-220) + min/max of the result.
+__global__ void __launch_bounds__(256) k_resize_bilinear(const float* __restrict__ in, int ih, int iw,
+                                                         float* __restrict__ out, int oh, int ow, uint32_t* stats) {
+    const int frame = blockIdx.y;
+    const float* src = in + (size_t)frame * ih * iw;
+    float* dst = out + (size_t)frame * oh * ow;
+    const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < oh * ow; i += gridDim.x * blockDim.x) {
+        int y = i / ow, x = i - y * ow;
+        float fy = fmaxf(sy * ((float)y + 0.5f) - 0.5f, 0.0f), fx = fmaxf(sx * ((float)x + 0.5f) - 0.5f, 0.0f);
+        int y0 = min((int)fy, ih - 1), x0 = min((int)fx, iw - 1);
+        int y1 = min(y0 + 1, ih - 1), x1 = min(x0 + 1, iw - 1);
+        float ly = fy - (float)y0, lx = fx - (float)x0;
+        float hy = 1.0f - ly, hx = 1.0f - lx;
+        float v = hy * (hx * src[y0 * iw + x0] + lx * src[y0 * iw + x1]) +
+                  ly * (hx * src[y1 * iw + x0] + lx * src[y1 * iw + x1]);
+        dst[i] = v;
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    block_minmax_commit(mn, mx, &stats[frame * ST_WORDS + ST_GRAY_MIN], &stats[frame * ST_WORDS + ST_GRAY_MAX]);
+}
+
+// per-frame decisions that the reference takes on host scalars (kept on device: no sync)
+//   CPU techniques: `if depthmap.max() <= 1.0: depthmap *= 255`, per frame (:1475)
+//   gpu_warp:       `if depth_tensor.amax() <= 1.0` over the sub-batch (:1045)
+__global__ void k_finalize_stats(uint32_t* stats, int n, int group, int blur) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    float gmax = csm::ord2f(stats[f * ST_WORDS + ST_GRAY_MAX]);
+    float gmin = csm::ord2f(stats[f * ST_WORDS + ST_GRAY_MIN]);
+    float dec = gmax;
+    if (group > 0) {
+        int g0 = (f / group) * group, g1 = min(g0 + group, n);
+        for (int k = g0; k < g1; k++) dec = fmaxf(dec, csm::ord2f(stats[k * ST_WORDS + ST_GRAY_MAX]));
+    }
+    uint32_t sc = dec <= 1.0f ? 1u : 0u;
+    stats[f * ST_WORDS + ST_SCALE255] = sc;
+    if (!blur) {
+        float s = sc ? 255.0f : 1.0f;
+        uint32_t mn = csm::f2ord(gmin * s), mx = csm::f2ord(gmax * s);
+        stats[f * ST_WORDS + ST_L_MIN] = mn;
+        stats[f * ST_WORDS + ST_R_MIN] = mn;
+        stats[f * ST_WORDS + ST_L_MAX] = mx;
+        stats[f * ST_WORDS + ST_R_MAX] = mx;
+    }
+}
+
+__global__ void k_test_powf(const float* x, float y, float* out, size_t n) {
+    __shared__ csm::PowfTables T;
+    const csm::PowfTables init = CS_POWF_TABLES_INIT;
+    if (threadIdx.x == 0) T = init;
+    __syncthreads();
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = csm::powf_exact(x[i], y, &T);
+}
+
+__device__ const unsigned long long d_exp_tab[256] = {CS_EXP_TAB_VALUES};
+
+__global__ void k_test_exp(const double* x, double* out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = csm::exp_exact(x[i], d_exp_tab);
+}
+
+static int grid_for(size_t items, int threads) {
+    size_t b = (items + threads - 1) / threads;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+// eye geometry / parameters for one call (reference :1533-1541, :1060-1065)
+static void eye_setup(EyeArgs& E, double div_percent_signed, double sep_percent_signed, int w) {
+    double div_px = (div_percent_signed / 100.0) * (double)w;
+    double sep_px = (sep_percent_signed / 100.0) * (double)w;
+    E.div32 = (float)div_px;
+    E.sep32 = (float)sep_px;
+    E.asc = div_px < 0 ? 1 : 0;
+    E.naive_lim = abs((int)div_px) + 2;
+    E.csg_cap = 5 * (int)fabs(div_px) + 25;
+    E.enabled = 1;
+    E.xoff = E.yoff = 0;
+}
+
+static int threads_for(int fill, int w) {
+    (void)fill;
+    if (w <= 256) return 256;
+    if (w <= 1024) return 512;
+    return 1024;
+}
+
+}  // namespace cs
+
+using namespace cs;
+
+extern "C" {
+
+int cs_version(void) { return CS_ABI_VERSION; }
+const char* cs_last_error(void) { return g_err; }
+
+int cs_max_width(int fill) {
+    if (fill == CS_FILL_GPU_WARP) return gpuwarp_max_width();
+    if (fill == CS_FILL_HYBRID_EDGE) return hybrid_max_width();
+    int lo = 0, hi = 1 << 16;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) / 2;
+        if (rowwarp_lds_bytes(fill, mid) <= CS_LDS_BYTES && poly_npt(mid, 1) < 65535) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+int cs_output_shape(const cs_params* p, int* out_h, int* out_w, int* mask_h, int* mask_w) {
+    if (!p) return fail(CS_EINVAL, "null params");
+    int oh = p->h, ow = p->w;
+    switch (p->mode) {
+    case CS_MODE_LEFT_RIGHT: case CS_MODE_RIGHT_LEFT: ow = 2 * p->w; break;
+    case CS_MODE_TOP_BOTTOM: case CS_MODE_BOTTOM_TOP: oh = 2 * p->h; break;
+    case CS_MODE_RED_CYAN_ANAGLYPH: case CS_MODE_CYAN_RED_REVERSEANAGLYPH:
+    case CS_MODE_LEFT_ONLY: case CS_MODE_ONLY_RIGHT: break;
+    default: return fail(CS_EINVAL, "Unknown mode");
+    }
+    if (out_h) *out_h = oh;
+    if (out_w) *out_w = ow;
+    // CPU techniques: the mask is computed from the assembled output (GenerateStereo.py:355-361);
+    // gpu_warp: left_mask | right_mask, eye-shaped (stereoimage_generation.py:1090).
+    if (mask_h) *mask_h = p->fill == CS_FILL_GPU_WARP ? p->h : oh;
+    if (mask_w) *mask_w = p->fill == CS_FILL_GPU_WARP ? p->w : ow;
+    return CS_OK;
+}
+
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct WsLayout {
+    size_t stats, gray_src, gray, L, R, wl, wr, extra, total;
+};
+static WsLayout ws_layout(const cs_params* p) {
+    WsLayout W;
+    size_t hw = (size_t)p->h * p->w, n = p->n, o = 0;
+    W.stats = o; o += al256(n * ST_WORDS * 4);
+    bool resize = p->depth_h != p->h || p->depth_w != p->w;
+    W.gray_src = o; if (resize) o += al256(n * (size_t)p->depth_h * p->depth_w * 4);
+    W.gray = o; o += al256(n * hw * 4);
+    bool blur = p->depth_map_blur && (p->fill != CS_FILL_GPU_WARP || p->depth_blur_strength > 0);
+    W.L = o; if (blur) o += al256(n * hw * 4);
+    W.R = o; if (blur) o += al256(n * hw * 4);
+    W.wl = o; if (blur) o += al256(n * hw * 4);
+    W.wr = o; if (blur) o += al256(n * hw * 4);
+    W.extra = o;
+    if (p->fill == CS_FILL_HYBRID_EDGE) o += al256(hybrid_workspace_bytes(p->n, p->h, p->w));
+    if (p->fill == CS_FILL_GPU_WARP) o += al256(gpuwarp_workspace_bytes(p->n, p->h, p->w));
+    W.total = o;
+    return W;
+}
+
+size_t cs_workspace_bytes(const cs_params* p) { return p ? ws_layout(p).total : 0; }
+
+int cs_generate(const cs_params* p, const float* image, const float* depth, float* stereo, float* depth_l,
+                float* depth_r, float* mask, void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p || !image || !depth || !stereo || !depth_l || !depth_r || !mask || !workspace) return fail(CS_EINVAL, "null pointer");
+    if (p->n <= 0 || p->h <= 0 || p->w <= 0 || p->depth_h <= 0 || p->depth_w <= 0 || p->depth_c <= 0)
+        return fail(CS_EINVAL, "non-positive size");
+    if (p->fill < 0 || p->fill > CS_FILL_GPU_WARP) return fail(CS_EINVAL, "unknown fill technique");
+    int out_h, out_w, mask_h, mask_w;
+    int rc = cs_output_shape(p, &out_h, &out_w, &mask_h, &mask_w);
+    if (rc) return rc;
+    if (p->w > cs_max_width(p->fill)) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
+    WsLayout W = ws_layout(p);
+    if (workspace_bytes < W.total) return fail(CS_EWORKSPACE, "workspace too small");
+    char* ws = (char*)workspace;
+    uint32_t* stats = (uint32_t*)(ws + W.stats);
+    float* gray = (float*)(ws + W.gray);
+    const int n = p->n, h = p->h, w = p->w, hw = h * w;
+    const bool gpu_warp = p->fill == CS_FILL_GPU_WARP;
+    const bool blur = p->depth_map_blur && (!gpu_warp || p->depth_blur_strength > 0);
+
+    hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);
+    const bool resize = p->depth_h != h || p->depth_w != w;
+    if (resize) {
+        float* gs = (float*)(ws + W.gray_src);
+        int shw = p->depth_h * p->depth_w;
+        hipLaunchKernelGGL(k_gray, dim3(grid_for(shw / 4 + 1, 256), n), dim3(256), 0, stream, depth, gs, shw, p->depth_c, stats, 0);
+        hipLaunchKernelGGL(k_resize_bilinear, dim3(grid_for(hw, 256), n), dim3(256), 0, stream, gs, p->depth_h, p->depth_w, gray, h, w, stats);
+    } else {
+        hipLaunchKernelGGL(k_gray, dim3(grid_for(hw / 4 + 1, 256), n), dim3(256), 0, stream, depth, gray, hw, p->depth_c, stats, 1);
+    }
+    hipLaunchKernelGGL(k_finalize_stats, dim3((n + 63) / 64), dim3(64), 0, stream, stats, n,
+                       gpu_warp ? (p->batch_size > 0 ? (p->batch_size < n ? p->batch_size : n) : n) : 0, blur ? 1 : 0);
+    const float* dL = gray;
+    const float* dR = gray;
+    int scale_from_stats = 1;
+    if (blur) {
+        float* L = (float*)(ws + W.L);
+        float* R = (float*)(ws + W.R);
+        rc = launch_blur(gray, n, h, w, p->depth_blur_strength, p->depth_blur_edge_threshold, p->depth_blur_falloff,
+                         p->depth_blur_vert_smooth, L, R, (float*)(ws + W.wl), (float*)(ws + W.wr), stats, 1, stream);
+        if (rc) return fail(rc, "depth blur: unsupported parameters (strength must round to >= 1)");
+        dL = L; dR = R;
+        scale_from_stats = 0;  // the blur kernel already wrote scaled depth
+    }
+    const double left_div = p->divergence * (1 + p->stereo_balance);
+    const double right_div = p->divergence * (1 - p->stereo_balance);
+
+    if (gpu_warp) {
+        rc = launch_gpuwarp_node(p, image, dL, dR, scale_from_stats, stats, stereo, depth_l, depth_r, mask, out_h, out_w,
+                                 ws + W.extra, stream);
+        if (rc) return fail(rc, "gpu_warp launch failed");
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? CS_OK : fail_hip(e, "cs_generate");
+    }
+
+    RowArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n = n; A.h = h; A.w = w;
+    A.image_f32 = image;
+    A.stats = stats; A.stats_rw = stats;
+    A.scale_from_stats = scale_from_stats;
+    A.e32 = (float)p->stereo_offset_exponent;
+    A.conv32 = (float)p->convergence_point;
+    A.neyes = 2;
+    eye_setup(A.eye[0], +1 * left_div, -1 * p->separation, w);
+    eye_setup(A.eye[1], -1 * right_div, p->separation, w);
+    A.eye[0].enabled = !(left_div < 0.001);
+    A.eye[1].enabled = !(right_div < 0.001);
+    A.eye[0].depth = dL; A.eye[0].st_min = ST_L_MIN; A.eye[0].st_max = ST_L_MAX;
+    A.eye[1].depth = dR; A.eye[1].st_min = ST_R_MIN; A.eye[1].st_max = ST_R_MAX;
+    A.stereo = stereo; A.mask = mask; A.depth_l = depth_l; A.depth_r = depth_r;
+    A.out_h = out_h; A.out_w = out_w;
+    A.single = -1;
+    switch (p->mode) {
+    case CS_MODE_LEFT_RIGHT: A.eye[1].xoff = w; break;
+    case CS_MODE_RIGHT_LEFT: A.eye[0].xoff = w; break;
+    case CS_MODE_TOP_BOTTOM: A.eye[1].yoff = h; break;
+    case CS_MODE_BOTTOM_TOP: A.eye[0].yoff = h; break;
+    case CS_MODE_RED_CYAN_ANAGLYPH: A.anaglyph = 1; break;
+    case CS_MODE_CYAN_RED_REVERSEANAGLYPH: A.anaglyph = 2; break;
+    case CS_MODE_LEFT_ONLY: A.single = 0; break;
+    case CS_MODE_ONLY_RIGHT: A.single = 1; break;
+    }
+    if (p->fill == CS_FILL_HYBRID_EDGE) {
+        rc = launch_hybrid(A, ws + W.extra, stream);
+        if (rc) return fail(rc, "hybrid_edge launch failed");
+    } else {
+        hipError_t e = launch_rowwarp(p->fill, A, threads_for(p->fill, w), stream);
+        if (e != hipSuccess) return fail_hip(e, "row kernel launch");
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CS_OK : fail_hip(e, "cs_generate");
+}
+
+size_t cs_asd_workspace_bytes(int n, int h, int w) {
+    return al256((size_t)n * ST_WORDS * 4) + al256(hybrid_workspace_bytes(n, h, w));
+}
+
+int cs_apply_stereo_divergence(const uint8_t* image_u8, const float* depth, int n, int h, int w, double divergence,
+                               double separation, double exponent, int fill, double convergence, uint8_t* out_u8,
+                               void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!image_u8 || !depth || !out_u8 || !workspace) return fail(CS_EINVAL, "null pointer");
+    if (n <= 0 || h <= 0 || w <= 0) return fail(CS_EINVAL, "non-positive size");
+    if (fill < 0 || fill > CS_FILL_HYBRID_EDGE) return fail(CS_EINVAL, "unknown fill technique");
+    if (w > cs_max_width(fill)) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
+    if (workspace_bytes < cs_asd_workspace_bytes(n, h, w)) return fail(CS_EWORKSPACE, "workspace too small");
+    uint32_t* stats = (uint32_t*)workspace;
+    hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);
+    hipLaunchKernelGGL(k_minmax, dim3(grid_for((size_t)h * w, 256), n), dim3(256), 0, stream, depth, h * w, stats, ST_L_MIN, ST_L_MAX);
+    RowArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n = n; A.h = h; A.w = w;
+    A.image_u8 = image_u8;
+    A.stats = stats; A.stats_rw = stats;
+    A.scale_from_stats = 0;
+    A.e32 = (float)exponent;
+    A.conv32 = (float)convergence;
+    A.neyes = 1;
+    eye_setup(A.eye[0], divergence, separation, w);
+    A.eye[0].depth = depth; A.eye[0].st_min = ST_L_MIN; A.eye[0].st_max = ST_L_MAX;
+    A.out_u8 = out_u8;
+    A.single = -1;
+    if (fill == CS_FILL_HYBRID_EDGE) {
+        int rc = launch_hybrid(A, (char*)workspace + al256((size_t)n * ST_WORDS * 4), stream);
+        if (rc) return fail(rc, "hybrid_edge launch failed");
+    } else {
+        hipError_t e = launch_rowwarp(fill, A, threads_for(fill, w), stream);
+        if (e != hipSuccess) return fail_hip(e, "row kernel launch");
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CS_OK : fail_hip(e, "cs_apply_stereo_divergence");
+}
+
+size_t cs_blur_workspace_bytes(int n, int h, int w) { return al256((size_t)n * ST_WORDS * 4) + 2 * al256((size_t)n * h * w * 4); }
+
+int cs_directional_blur(const float* depth, int n, int h, int w, double blur_strength, double edge_threshold,
+                        double falloff_exponent, int vert_smooth_px, float* out_l, float* out_r, void* workspace,
+                        size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!depth || !out_l || !out_r || !workspace) return fail(CS_EINVAL, "null pointer");
+    if (n <= 0 || h <= 0 || w <= 0) return fail(CS_EINVAL, "non-positive size");
+    if (workspace_bytes < cs_blur_workspace_bytes(n, h, w)) return fail(CS_EWORKSPACE, "workspace too small");
+    size_t hw = (size_t)h * w;
+    if (blur_strength <= 0) {  // reference :1194 returns the input twice
+        hipError_t e1 = hipMemcpyAsync(out_l, depth, n * hw * 4, hipMemcpyDeviceToDevice, stream);
+        hipError_t e2 = hipMemcpyAsync(out_r, depth, n * hw * 4, hipMemcpyDeviceToDevice, stream);
+        return (e1 == hipSuccess && e2 == hipSuccess) ? CS_OK : fail_hip(e1 != hipSuccess ? e1 : e2, "cs_directional_blur");
+    }
+    char* ws = (char*)workspace;
+    uint32_t* stats = (uint32_t*)ws;
+    float* wl = (float*)(ws + al256((size_t)n * ST_WORDS * 4));
+    float* wr = wl + al256(n * hw * 4) / 4;
+    hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);
+    int rc = launch_blur(depth, n, h, w, blur_strength, edge_threshold, falloff_exponent, vert_smooth_px, out_l, out_r, wl,
+                         wr, stats, 0, stream);
+    if (rc) return fail(rc, "depth blur: unsupported parameters (strength must round to >= 1)");
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CS_OK : fail_hip(e, "cs_directional_blur");
+}
+
+size_t cs_warp_workspace_bytes(int n, int h, int w) { return al256((size_t)n * ST_WORDS * 4) + al256(gpuwarp_workspace_bytes(n, h, w)); }
+
+int cs_forward_warp(const float* image, const float* depth, int n, int h, int w, double divergence_px,
+                    double separation_px, double exponent, double convergence, float* warped, uint8_t* gap_mask,
+                    void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!image || !depth || !warped || !gap_mask || !workspace) return fail(CS_EINVAL, "null pointer");
+    if (n <= 0 || h <= 0 || w <= 0) return fail(CS_EINVAL, "non-positive size");
+    if (w > gpuwarp_max_width()) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
+    if (workspace_bytes < cs_warp_workspace_bytes(n, h, w)) return fail(CS_EWORKSPACE, "workspace too small");
+    uint32_t* stats = (uint32_t*)workspace;
+    hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);
+    hipLaunchKernelGGL(k_minmax, dim3(grid_for((size_t)h * w, 256), n), dim3(256), 0, stream, depth, h * w, stats, ST_L_MIN, ST_L_MAX);
+    int rc = launch_gpuwarp_plain(image, depth, n, h, w, divergence_px, separation_px, exponent, convergence, warped,
+                                  gap_mask, stats, (char*)workspace + al256((size_t)n * ST_WORDS * 4), stream);
+    if (rc) return fail(rc, "gpu_warp launch failed");
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CS_OK : fail_hip(e, "cs_forward_warp");
+}
+
+int cs_test_powf(const float* x, float y, float* out, size_t count, void* stream) {
+    if (!x || !out) return fail(CS_EINVAL, "null pointer");
+    hipLaunchKernelGGL(k_test_powf, dim3(grid_for(count, 256)), dim3(256), 0, (hipStream_t)stream, x, y, out, count);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CS_OK : fail_hip(e, "cs_test_powf");
+}
+
+int cs_test_exp(const double* x, double* out, size_t count, void* stream) {
+    if (!x || !out) return fail(CS_EINVAL, "null pointer");
+    hipLaunchKernelGGL(k_test_exp, dim3(grid_for(count, 256)), dim3(256), 0, (hipStream_t)stream, x, out, count);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CS_OK : fail_hip(e, "cs_test_exp");
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// cs_common.h -- shared definitions of the gfx950 kernels (device-side helpers, workspace layout).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/comfystereo_amd.h"
+#include "cs_math.h"
+
+#define CS_LDS_BYTES 163840  // 160 KiB per CU on gfx950, all of it usable by one workgroup
+#define CS_WAVE 64
+
+// Per-frame statistics block in the workspace (uint32 words; floats stored through csm::f2ord so
+// that integer atomics order them).  Written by the prep / blur kernels, read by the row kernels.
+enum {
+    ST_GRAY_MIN = 0,  // min / max of the gray depth as delivered (before the 0..255 scaling)
+    ST_GRAY_MAX = 1,
+    ST_L_MIN = 2,  // min / max of the left-eye depth the warp normalises with (scaled, post-blur)
+    ST_L_MAX = 3,
+    ST_R_MIN = 4,
+    ST_R_MAX = 5,
+    ST_SCALE255 = 6,  // 1 -> the reference multiplies this frame's depth by 255 (max <= 1)
+    ST_WARP_DIV255_L = 7,  // gpu_warp: forward_warp_gpu divides the (sub-batch's) depth by 255 again
+    ST_WARP_DIV255_R = 8,
+    ST_ERROR = 9,  // set by kernels on internal capacity overflow (diagnostics)
+    ST_FALLBACK_ROWS = 10,  // polylines: rows that took the sequential path (diagnostics)
+    ST_WORDS = 16
+};
+
+namespace cs {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+struct OpAdd {
+    __device__ __forceinline__ int operator()(int a, int b) const { return a + b; }
+};
+struct OpMax {
+    __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; }
+};
+struct OpMin {
+    __device__ __forceinline__ int operator()(int a, int b) const { return a < b ? a : b; }
+};
+
+// In-place inclusive scan of a[0..n) in LDS by the whole workgroup.  Each thread owns a contiguous
+// chunk; chunk totals are combined with wave shuffles (64-wide) and one cross-wave step.
+// `wsum` is LDS scratch of >= 16 ints.  If `reverse`, the scan runs from the last element down.
+template <class T, class Op>
+__device__ void block_scan_inclusive(T* a, int n, int identity, Op op, int* wsum, bool reverse = false) {
+    const int nt = blockDim.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+    const int L = (n + nt - 1) / nt;
+    const int b = tid * L, e = min(b + L, n);
+    int acc = identity;
+    for (int i = b; i < e; i++) {
+        int j = reverse ? n - 1 - i : i;
+        acc = op(acc, (int)a[j]);
+        a[j] = (T)acc;
+    }
+    int v = acc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int u = __shfl_up(v, off);
+        if (lane >= off) v = op(u, v);
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    if (wave == 0) {
+        int nw = nt >> 6;
+        int s = lane < nw ? wsum[lane] : identity;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            int u = __shfl_up(s, off);
+            if (lane >= off) s = op(u, s);
+        }
+        if (lane < nw) wsum[lane] = s;
+    }
+    __syncthreads();
+    int ex = __shfl_up(v, 1);
+    if (lane == 0) ex = identity;
+    int prefix = op(wave > 0 ? wsum[wave - 1] : identity, ex);
+    for (int i = b; i < e; i++) {
+        int j = reverse ? n - 1 - i : i;
+        a[j] = (T)op(prefix, (int)a[j]);
+    }
+    __syncthreads();
+}
+
+// atomic add on element `i` of a uint16 array that lives in LDS as packed pairs; returns the old value.
+__device__ __forceinline__ unsigned atomic_add_u16(uint16_t* a, int i, unsigned v) {
+    unsigned* w = reinterpret_cast<unsigned*>(a) + (i >> 1);
+    unsigned sh = (i & 1) * 16;
+    unsigned old = atomicAdd(w, v << sh);
+    return (old >> sh) & 0xffffu;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+}  // namespace cs

@@ -1,0 +1,72 @@
+// cs_kernels.h -- internal interface between cs_abi.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/comfystereo_amd.h"
+
+namespace cs {
+
+__host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ __device__ inline int poly_npt(int w, int sharp) { return (sharp ? 2 * w : w) + 2; }
+
+struct EyeArgs {
+    const float* depth;  // [n][h][w] depth this eye warps with (unscaled when scale_from_stats)
+    float div32, sep32;  // (float)divergence_px, (float)separation_px -- signed
+    int enabled;         // 0: eye = source image (divergence < 0.001, quirk Q10)
+    int asc;             // divergence_px < 0: sweep ascending (max source column wins)
+    int naive_lim;       // abs(int(divergence_px)) + 2
+    int csg_cap;         // 5 * int(abs(divergence_px)) + 25 (reference's active-list capacity)
+    int st_min, st_max;  // stats words holding this eye's depth min / max
+    int xoff, yoff;      // slot of this eye in the output layout
+};
+
+struct RowArgs {
+    int n, h, w;
+    const float* image_f32;   // [n][h][w][3] 0..1   (node path)   or null
+    const uint8_t* image_u8;  // [n][h][w][3]        (asd path)    or null
+    const uint32_t* stats;    // [n][ST_WORDS]
+    uint32_t* stats_rw;
+    int scale_from_stats;     // depth rows are multiplied by 255 when stats[ST_SCALE255]
+    float e32, conv32;
+    EyeArgs eye[2];
+    int neyes;
+    // outputs
+    uint8_t* out_u8;  // asd path: [n][h][w][3]
+    float* stereo;    // node path: [n][out_h][out_w][3]
+    float* mask;      //            [n][out_h][out_w]
+    float* depth_l;   //            [n][h][w][3]
+    float* depth_r;
+    int out_h, out_w;
+    int anaglyph;  // 0: eyes go to their slots; 1: R from eye0, GB from eye1; 2: R from eye1, GB from eye0
+    int single;    // -1, or the only eye that is written (left-only / only-right)
+};
+
+
+// cs_rowwarp.hip
+hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream);
+size_t rowwarp_lds_bytes(int fill, int w);
+
+// cs_blur.hip: directional depth blur; if `scale_from_stats`, the input is multiplied by 255 for frames
+// whose stats say so, and the per-frame min/max of both outputs are accumulated into stats.
+int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double falloff,
+                int vert, float* out_l, float* out_r, float* wl, float* wr, uint32_t* stats, int node_path,
+                hipStream_t stream);
+
+// cs_hybrid.hip
+size_t hybrid_workspace_bytes(int n, int h, int w);
+int hybrid_max_width();
+int launch_hybrid(const RowArgs& A, void* workspace, hipStream_t stream);
+
+// cs_gpuwarp.hip
+size_t gpuwarp_workspace_bytes(int n, int h, int w);
+int gpuwarp_max_width();
+int launch_gpuwarp_plain(const float* image, const float* depth, int n, int h, int w, double div_px, double sep_px,
+                         double exponent, double convergence, float* warped, uint8_t* gap_mask, uint32_t* stats,
+                         void* workspace, hipStream_t stream);
+int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL, const float* dR, int scale_from_stats,
+                        uint32_t* stats, float* stereo, float* depth_l, float* depth_r, float* mask, int out_h,
+                        int out_w, void* workspace, hipStream_t stream);
+
+}  // namespace cs

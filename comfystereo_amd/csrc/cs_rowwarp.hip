@@ -1,0 +1,683 @@
+// cs_rowwarp.hip -- the per-row forward-warp + hole-fill kernels (gfx950).
+//
+// One workgroup owns one image row of one frame and produces BOTH eyes of it: the source row
+// (uint8 RGB) is staged once in LDS, the disparity of every source pixel is computed with the
+// libm-exact powf (cs_math.h), and the fill technique runs entirely out of LDS:
+//   none / naive / naive_interpolating  reference stereoimage_generation.py:1850-1910
+//   inverse                              reference :1715-1737
+//   polylines_soft / polylines_sharp     reference :1912-1992
+// The eye row is then converted and written straight into its slot of the output layout
+// (side-by-side, top-bottom, anaglyph; reference :1543-1562) together with the no-fill mask
+// (GenerateStereo.py:355-361) and the two depth-map outputs (:1511-1516, :365-378), so no
+// per-eye intermediate image ever touches HBM.
+//
+// The sequential CPU sweeps are restated as data-parallel steps with identical results:
+//   * forward map: "later write wins" == max (div<0) / min (div>=0) source column per
+//     destination -> LDS atomicMax/atomicMin
+//   * naive fill: nearest filled pixel, right before left -> prefix-max / suffix-min scans
+//   * naive_interpolating: the sweep only couples pixels between two consecutive "good" pixels,
+//     so every such interval is replayed literally by one lane
+//   * inverse: z-buffer with strict '>' and ascending x == argmax over (closeness, -x) ->
+//     64-bit LDS atomicMax
+//   * polylines: counting-sort of the polyline points by output pixel + in-bin ranking (== the
+//     reference's stable insertion sort), per-pixel segment lists (CSR) and one lane per output
+//     pixel; rows whose result would depend on the reference's active-list ORDER (exact ties,
+//     non-monotone centres, list overflow) are detected and replayed sequentially by lane 0.
+//
+// Compile with -ffp-contract=off (see cs_math.h).
+#include "cs_common.h"
+#include "cs_kernels.h"
+
+namespace cs {
+
+// ---------------------------------------------------------------------------------------------
+// LDS carving
+// ---------------------------------------------------------------------------------------------
+struct Lds {
+    float* lut;                // [256] k/255
+    csm::PowfTables* tabs;     // libm tables
+    int* misc;                 // [32] flags / counters / scan scratch
+    uint8_t* img;              // [3w]
+    uint8_t* res;              // [3w] eye result
+    uint8_t* ana;              // [2w] channels stashed from the first eye of an anaglyph
+    float* nd;                 // [w] normalised depth (forward/inverse) or coord_d (polylines)
+    char* tech;                // technique-specific area
+};
+
+
+__host__ __device__ inline size_t lds_common_bytes(int w) {
+    return 1024 + align16(sizeof(csm::PowfTables)) + 128 + 2 * align16(3 * (size_t)w) + align16(2 * (size_t)w) +
+           align16(4 * (size_t)w);
+}
+__host__ __device__ inline int poly_cap(int w, int sharp) { return (sharp ? 4 : 3) * w + 64; }
+__host__ __device__ inline size_t lds_tech_bytes(int fill, int w) {
+    switch (fill) {
+    case CS_FILL_NONE: return align16(4 * (size_t)w);                       // winner
+    case CS_FILL_NAIVE: return 3 * align16(4 * (size_t)w);                   // winner, L, R
+    case CS_FILL_NAIVE_INTERPOLATING: return align16(4 * (size_t)w) + align16((size_t)w);
+    case CS_FILL_INVERSE: return align16(8 * (size_t)w);
+    case CS_FILL_POLYLINES_SOFT:
+    case CS_FILL_POLYLINES_SHARP: {
+        int sharp = fill == CS_FILL_POLYLINES_SHARP;
+        size_t npt = poly_npt(w, sharp);
+        return align16(4 * npt) + align16(2 * npt) + align16(2 * ((size_t)w + 4)) + align16(2 * ((size_t)w + 2)) +
+               align16(2 * (size_t)poly_cap(w, sharp)) + align16(2 * 1024);
+    }
+    default: return 0;
+    }
+}
+
+__device__ inline Lds carve(char* base, int w) {
+    Lds L;
+    size_t o = 0;
+    L.lut = (float*)(base + o); o += 1024;
+    L.tabs = (csm::PowfTables*)(base + o); o += align16(sizeof(csm::PowfTables));
+    L.misc = (int*)(base + o); o += 128;
+    L.img = (uint8_t*)(base + o); o += align16(3 * (size_t)w);
+    L.res = (uint8_t*)(base + o); o += align16(3 * (size_t)w);
+    L.ana = (uint8_t*)(base + o); o += align16(2 * (size_t)w);
+    L.nd = (float*)(base + o); o += align16(4 * (size_t)w);
+    L.tech = base + o;
+    return L;
+}
+
+__constant__ csm::PowfTables c_powf_tables = CS_POWF_TABLES_INIT;
+
+// `sign_d * (abs(d) ** e) * divergence_px` in the reference's float32 dialect.
+__device__ __forceinline__ float disparity(float d, float e32, float div32, const csm::PowfTables* T) {
+    float s = d >= 0.0f ? 1.0f : -1.0f;
+    float p = csm::powf_exact(fabsf(d), e32, T);
+    return (s * p) * div32;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward map shared by none / naive / naive_interpolating
+// ---------------------------------------------------------------------------------------------
+__device__ void forward_map(const Lds& L, int w, const EyeArgs& E, float e32, int* winner) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int init = E.asc ? -1 : 0x7fffffff;
+    for (int c = tid; c < w; c += nt) winner[c] = init;
+    __syncthreads();
+    for (int c = tid; c < w; c += nt) {
+        float off = disparity(L.nd[c], e32, E.div32, L.tabs) + E.sep32;
+        // int(): truncation toward zero; keep the conversion defined for absurd offsets
+        int io = off >= 2147483520.0f ? 0x7fffff00 : (off <= -2147483520.0f ? -0x7fffff00 : (int)off);
+        long long cd = (long long)c + io;
+        if (cd >= 0 && cd < w) {
+            if (E.asc) atomicMax(&winner[(int)cd], c);
+            else atomicMin(&winner[(int)cd], c);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < w; c += nt) {
+        int s = winner[c];
+        bool f = s != init;
+        L.res[3 * c + 0] = f ? L.img[3 * s + 0] : 0;
+        L.res[3 * c + 1] = f ? L.img[3 * s + 1] : 0;
+        L.res[3 * c + 2] = f ? L.img[3 * s + 2] : 0;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ unsigned sum8(const uint8_t* p) { return (unsigned)(p[0] + p[1] + p[2]) & 0xffu; }
+
+template <int FILL>
+__device__ void technique_forward(const Lds& L, int w, const EyeArgs& E, float e32) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int* winner = (int*)L.tech;
+    const int init = E.asc ? -1 : 0x7fffffff;
+    forward_map(L, w, E, e32, winner);
+    if (FILL == CS_FILL_NAIVE) {
+        // nearest filled pixel: Lf[c] = last filled <= c, Rf[c] = first filled >= c
+        int* Lf = (int*)(L.tech + align16(4 * (size_t)w));
+        int* Rf = (int*)(L.tech + 2 * align16(4 * (size_t)w));
+        const int BIG = 1 << 29;
+        for (int c = tid; c < w; c += nt) {
+            bool f = winner[c] != init;
+            Lf[c] = f ? c : -BIG;
+            Rf[c] = f ? c : BIG;
+        }
+        __syncthreads();
+        block_scan_inclusive(Lf, w, -BIG, OpMax(), L.misc + 8);
+        block_scan_inclusive(Rf, w, BIG, OpMin(), L.misc + 8, true);
+        for (int c = tid; c < w; c += nt) {
+            if (winner[c] != init) continue;
+            int dr = Rf[c] - c, dl = c - Lf[c];
+            int src = -1;
+            if (dr <= dl) { if (dr < E.naive_lim) src = Rf[c]; }
+            else if (dl < E.naive_lim) src = Lf[c];
+            if (src >= 0) {  // sources are filled pixels, which this loop never modifies
+                L.res[3 * c + 0] = L.res[3 * src + 0];
+                L.res[3 * c + 1] = L.res[3 * src + 1];
+                L.res[3 * c + 2] = L.res[3 * src + 2];
+            }
+        }
+        __syncthreads();
+    } else if (FILL == CS_FILL_NAIVE_INTERPOLATING) {
+        // "good" = filled and channel sum != 0 (mod 256): never overwritten, bounds every fill.
+        uint8_t* flags = (uint8_t*)(L.tech + align16(4 * (size_t)w));  // bit0 filled, bit1 good
+        for (int c = tid; c < w; c += nt) {
+            bool f = winner[c] != init;
+            bool g = f && sum8(&L.res[3 * c]) != 0;
+            flags[c] = (uint8_t)((f ? 1 : 0) | (g ? 2 : 0));
+        }
+        __syncthreads();
+        for (int s = tid; s < w; s += nt) {
+            if ((flags[s] & 2) || (s > 0 && !(flags[s - 1] & 2))) continue;  // not the start of an interval
+            for (int l = s; l < w && !(flags[l] & 2); l++) {
+                if (sum8(&L.res[3 * l]) != 0 || (flags[l] & 1)) continue;
+                uint8_t lb[3] = {0, 0, 0}, rb[3] = {0, 0, 0};
+                if (l > 0) { lb[0] = L.res[3 * l - 3]; lb[1] = L.res[3 * l - 2]; lb[2] = L.res[3 * l - 1]; }
+                int r = l + 1;
+                while (r < w) {
+                    if (sum8(&L.res[3 * r]) != 0 && (flags[r] & 1)) {
+                        rb[0] = L.res[3 * r]; rb[1] = L.res[3 * r + 1]; rb[2] = L.res[3 * r + 2];
+                        break;
+                    }
+                    r++;
+                }
+                if (sum8(lb) == 0) { lb[0] = rb[0]; lb[1] = rb[1]; lb[2] = rb[2]; }
+                else if (sum8(rb) == 0) { rb[0] = lb[0]; rb[1] = lb[1]; rb[2] = lb[2]; }
+                float total = (float)(1 + r - l);
+                float st0 = ((float)rb[0] - (float)lb[0]) / total;
+                float st1 = ((float)rb[1] - (float)lb[1]) / total;
+                float st2 = ((float)rb[2] - (float)lb[2]) / total;
+                for (int c = l; c < r; c++) {
+                    float k = (float)(c - l + 1);
+                    L.res[3 * c + 0] = (uint8_t)(lb[0] + csm::f32_to_u8_wrap(st0 * k));
+                    L.res[3 * c + 1] = (uint8_t)(lb[1] + csm::f32_to_u8_wrap(st1 * k));
+                    L.res[3 * c + 2] = (uint8_t)(lb[2] + csm::f32_to_u8_wrap(st2 * k));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// inverse: two-column z-buffered splat
+// ---------------------------------------------------------------------------------------------
+__device__ void technique_inverse(const Lds& L, int w, const EyeArgs& E, float e32) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    unsigned long long* key = (unsigned long long*)L.tech;
+    const unsigned long long init = ((unsigned long long)csm::f2ord(-1.0f) << 32) | 0xffffffffull;
+    for (int c = tid; c < w; c += nt) key[c] = init;
+    __syncthreads();
+    for (int x = tid; x < w; x += nt) {
+        float d = L.nd[x];
+        float off = disparity(d, e32, E.div32, L.tabs);
+        float dest = ((float)x + 0.5f + off) + E.sep32;
+        float fl = floorf(dest);
+        if (!(fl >= -2.0f && fl <= (float)w)) continue;
+        int j = (int)fl;
+        unsigned long long k = ((unsigned long long)csm::f2ord(d) << 32) | (unsigned long long)(0xffffffffu - (unsigned)x);
+        if (j >= 0 && j < w) atomicMax(&key[j], k);
+        if (j + 1 >= 0 && j + 1 < w) atomicMax(&key[j + 1], k);
+    }
+    __syncthreads();
+    for (int c = tid; c < w; c += nt) {
+        unsigned long long k = key[c];
+        bool f = k > init;
+        int s = (int)(0xffffffffu - (unsigned)(k & 0xffffffffull));
+        L.res[3 * c + 0] = f ? L.img[3 * s + 0] : 0;
+        L.res[3 * c + 1] = f ? L.img[3 * s + 1] : 0;
+        L.res[3 * c + 2] = f ? L.img[3 * s + 2] : 0;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// polylines
+// ---------------------------------------------------------------------------------------------
+struct Poly {
+    int w, npt, sharp, cap;
+    float* px;          // [npt] x of polyline point o (unsorted, reference order)
+    uint16_t* perm;     // [npt] sorted position -> point
+    uint16_t* binoff;   // [w+3] after the fill pass: END of bin b (bin 0: x<0, bin c+1: [c,c+1), bin w+1: x>=w)
+    uint16_t* segoff;   // [w+1] after the fill pass: END of pixel p's segment list
+    uint16_t* entries;  // [cap] segment ids (also: in-bin scratch during sorting, csg during the fallback)
+    uint16_t* longs;    // [1024] long segments
+    const float* cd;    // [w] coord_d
+};
+
+__device__ __forceinline__ int poly_col(const Poly& P, int o) {
+    if (o <= 0) return 0;
+    if (o >= P.npt - 1) return P.w - 1;
+    return P.sharp ? (o - 1) >> 1 : o - 1;
+}
+__device__ __forceinline__ float poly_z(const Poly& P, int o) {
+    if (o <= 0 || o >= P.npt - 1) return 0.0f;
+    return fabsf(P.cd[P.sharp ? (o - 1) >> 1 : o - 1]);
+}
+__device__ __forceinline__ int poly_bin(const Poly& P, float x) {
+    if (x < 0.0f) return 0;
+    if (x >= (float)P.w) return P.w + 1;
+    return (int)x + 1;
+}
+
+// colour contribution of one sub-interval (reference :1981-1989 with the D32 typing of Appendix A)
+__device__ __forceinline__ void poly_accumulate(const Poly& P, const uint8_t* img, int seg, float center, bool sig64,
+                                                double sig_d, float sig_f, float color[3]) {
+    int col_l = poly_col(P, seg), col_r = poly_col(P, seg + 1);
+    if (col_l == col_r) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (sig64) color[c] = (float)((double)color[c] + (double)img[3 * col_l + c] * sig_d);
+            else color[c] = color[c] + (float)img[3 * col_l + c] * sig_f;
+        }
+    } else {
+        float x0 = P.px[seg], x1 = P.px[seg + 1];
+        float ip_k = (center - x0) / (x1 - x0);
+        float om = 1.0f - ip_k;
+        float s = sig64 ? (float)sig_d : sig_f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float a = (float)img[3 * col_l + c] * om;
+            float b = (float)img[3 * col_r + c] * ip_k;
+            color[c] = color[c] + (a + b) * s;
+        }
+    }
+}
+
+// sub-interval [max(col, a), min(col+1, b)] shrunk by EPSILON on both sides (reference :1957-1960)
+struct SubInt {
+    bool sig64;
+    double sig_d;
+    float sig_f, center;
+};
+__device__ __forceinline__ SubInt poly_subinterval(int col, float a, float b) {
+    const float eps32 = (float)1e-7;
+    SubInt s;
+    bool from64 = !(a > (float)col), to64 = !(b < (float)(col + 1));
+    if (from64 && to64) {
+        double from_d = (double)col + 1e-7, to_d = (double)(col + 1) - 1e-7;
+        s.sig64 = true;
+        s.sig_d = to_d - from_d;
+        s.sig_f = 0.0f;
+        s.center = (float)(from_d + 0.5 * s.sig_d);
+    } else {
+        float ff = from64 ? (float)((double)col + 1e-7) : a + eps32;
+        float tf = to64 ? (float)((double)(col + 1) - 1e-7) : b - eps32;
+        s.sig64 = false;
+        s.sig_d = 0.0;
+        s.sig_f = tf - ff;
+        s.center = ff + 0.5f * s.sig_f;
+    }
+    return s;
+}
+
+// literal replay of the reference sweep for one row by one lane (rows flagged as order-dependent)
+__device__ int poly_sequential(const Poly& P, const Lds& L, int csg_cap_ref) {
+    const int w = P.w, sg_end = P.npt - 1;
+    uint16_t* csg = P.entries;
+    int cap = min(csg_cap_ref, P.cap);
+    int csg_end = 0, sg_pointer = 0, pt_i = 0;
+    for (int col = 0; col < w; col++) {
+        float color[3] = {0.5f, 0.5f, 0.5f};
+        while (P.px[P.perm[pt_i]] < (float)col) pt_i++;
+        pt_i--;
+        while (P.px[P.perm[pt_i]] < (float)(col + 1)) {
+            SubInt s = poly_subinterval(col, P.px[P.perm[pt_i]], P.px[P.perm[pt_i + 1]]);
+            while (sg_pointer < sg_end && P.px[P.perm[sg_pointer]] < s.center) {
+                if (csg_end >= cap) return -1;
+                csg[csg_end++] = P.perm[sg_pointer++];
+            }
+            int ci = 0;
+            while (ci < csg_end) {
+                if (P.px[csg[ci] + 1] < s.center) { csg[ci] = csg[csg_end - 1]; csg_end--; }
+                else ci++;
+            }
+            int best = 0;
+            if (csg_end != 1) {
+                float bc = (float)(-1e-7);
+                for (ci = 0; ci < csg_end; ci++) {
+                    int o = csg[ci];
+                    float x0 = P.px[o], x1 = P.px[o + 1];
+                    float ip_k = (s.center - x0) / (x1 - x0);
+                    float cl = (1.0f - ip_k) * poly_z(P, o) + ip_k * poly_z(P, o + 1);
+                    if (bc < cl && 0.0f < ip_k && ip_k < 1.0f) { bc = cl; best = ci; }
+                }
+            }
+            // csg_end == 0 cannot happen (the polyline is connected from -w to 2w); slot 0 then
+            // still holds a valid (stale) id because the list is never empty after its first fill.
+            poly_accumulate(P, L.img, csg[best], s.center, s.sig64, s.sig_d, s.sig_f, color);
+            pt_i++;
+        }
+        L.res[3 * col + 0] = csm::f32_to_u8_wrap(color[0]);
+        L.res[3 * col + 1] = csm::f32_to_u8_wrap(color[1]);
+        L.res[3 * col + 2] = csm::f32_to_u8_wrap(color[2]);
+    }
+    return 0;
+}
+
+// rasterise the forward segments into per-pixel lists; PASS 0 counts, PASS 1 fills
+template <int PASS>
+__device__ __forceinline__ void poly_seg_pixels(const Poly& P, int o, int& p0, int& p1) {
+    float x0 = P.px[o], x1 = P.px[o + 1];
+    p0 = 1; p1 = 0;
+    if (!(x0 < x1)) return;  // reversed / degenerate segments are never active
+    float f0 = floorf(x0), f1 = floorf(x1);
+    if (f1 < 0.0f || f0 > (float)(P.w - 1)) return;
+    p0 = f0 < 0.0f ? 0 : (int)f0;
+    p1 = f1 > (float)(P.w - 1) ? P.w - 1 : (int)f1;
+}
+
+template <int SHARP>
+__device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float e32, uint32_t* stats_rw) {
+    const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
+    Poly P;
+    P.w = w; P.sharp = SHARP; P.npt = poly_npt(w, SHARP); P.cap = poly_cap(w, SHARP);
+    char* t = L.tech;
+    P.px = (float*)t; t += align16(4 * (size_t)P.npt);
+    P.perm = (uint16_t*)t; t += align16(2 * (size_t)P.npt);
+    P.binoff = (uint16_t*)t; t += align16(2 * ((size_t)w + 4));
+    P.segoff = (uint16_t*)t; t += align16(2 * ((size_t)w + 2));
+    P.entries = (uint16_t*)t; t += align16(2 * (size_t)P.cap);
+    P.longs = (uint16_t*)t;
+    P.cd = L.nd;
+    const int npt = P.npt, nbin = w + 2, LONGCAP = 1024;
+    int* flag_hazard = L.misc + 0;
+    int* nlong = L.misc + 1;
+    int* ntotal = L.misc + 2;
+    int* scan_ws = L.misc + 8;
+    const float half32 = (float)0.45;
+
+    // P1: coord_d (in place over nd), point x's, histogram of bins (count of bin b at binoff[b+1])
+    for (int c = tid; c < w; c += nt) L.nd[c] = disparity(L.nd[c], e32, E.div32, L.tabs);
+    for (int i = tid; i < (w + 4) / 2; i += nt) ((unsigned*)P.binoff)[i] = 0;
+    for (int i = tid; i < (w + 2) / 2; i += nt) ((unsigned*)P.segoff)[i] = 0;
+    if (tid == 0) { *flag_hazard = 0; *nlong = 0; *ntotal = 0; }
+    __syncthreads();
+    for (int o = tid; o < npt; o += nt) {
+        float x;
+        if (o == 0) x = (float)(-1.0 * w);
+        else if (o == npt - 1) x = (float)(2.0 * w);
+        else {
+            int c = SHARP ? (o - 1) >> 1 : o - 1;
+            x = ((float)c + 0.5f + P.cd[c]) + E.sep32;
+            if (SHARP) x = ((o - 1) & 1) ? x + half32 : x - half32;
+        }
+        P.px[o] = x;
+        atomic_add_u16(P.binoff, poly_bin(P, x) + 1, 1);
+    }
+    __syncthreads();
+    // P2: counting sort by bin, then rank inside the bin by (x, reference index) == the reference's
+    // stable insertion sort (:1941-1946).  After the scatter binoff[b] = END of bin b.
+    block_scan_inclusive(P.binoff, nbin + 1, 0, OpAdd(), scan_ws);
+    uint16_t* scratch = P.entries;
+    for (int o = tid; o < npt; o += nt) {
+        unsigned slot = atomic_add_u16(P.binoff, poly_bin(P, P.px[o]), 1);
+        scratch[slot] = (uint16_t)o;
+    }
+    __syncthreads();
+    for (int k = tid; k < npt; k += nt) {
+        int o = scratch[k];
+        float x = P.px[o];
+        int b = poly_bin(P, x);
+        int bs = b > 0 ? P.binoff[b - 1] : 0, be = P.binoff[b];
+        int r = 0;
+        for (int j = bs; j < be; j++) {
+            int o2 = scratch[j];
+            float x2 = P.px[o2];
+            r += (x2 < x || (x2 == x && o2 < o)) ? 1 : 0;
+        }
+        P.perm[bs + r] = (uint16_t)o;
+    }
+    __syncthreads();
+    // P3a/b: per-pixel lists of the forward segments that can be active inside the pixel (CSR).
+    // Segments spanning > 3 pixels (disocclusion bridges) are rasterised cooperatively, 64 pixels
+    // per wave step, instead of serialising one lane.
+    int local = 0;
+    for (int o = tid; o < npt - 1; o += nt) {
+        int p0, p1;
+        poly_seg_pixels<0>(P, o, p0, p1);
+        if (p0 > p1) continue;
+        if (p1 - p0 <= 2) {
+            for (int p = p0; p <= p1; p++) atomic_add_u16(P.segoff, p + 1, 1);
+            local += p1 - p0 + 1;
+        } else {
+            int idx = atomicAdd(nlong, 1);
+            if (idx < LONGCAP) P.longs[idx] = (uint16_t)o;
+            local += p1 - p0 + 1;
+        }
+    }
+    atomicAdd(ntotal, local);
+    __syncthreads();
+    const int nl = min(*nlong, LONGCAP);
+    const bool overflow = *nlong > LONGCAP || *ntotal > P.cap;
+    if (!overflow) {
+        for (int li = wave; li < nl; li += nwaves) {
+            int p0, p1;
+            poly_seg_pixels<0>(P, P.longs[li], p0, p1);
+            for (int p = p0 + lane; p <= p1; p += 64) atomic_add_u16(P.segoff, p + 1, 1);
+        }
+        __syncthreads();
+        block_scan_inclusive(P.segoff, w + 1, 0, OpAdd(), scan_ws);
+        for (int o = tid; o < npt - 1; o += nt) {
+            int p0, p1;
+            poly_seg_pixels<1>(P, o, p0, p1);
+            if (p0 > p1 || p1 - p0 > 2) continue;
+            for (int p = p0; p <= p1; p++) P.entries[atomic_add_u16(P.segoff, p, 1)] = (uint16_t)o;
+        }
+        for (int li = wave; li < nl; li += nwaves) {
+            int p0, p1, o = P.longs[li];
+            poly_seg_pixels<1>(P, o, p0, p1);
+            for (int p = p0 + lane; p <= p1; p += 64) P.entries[atomic_add_u16(P.segoff, p, 1)] = (uint16_t)o;
+        }
+        __syncthreads();
+        // P3c: one lane per output pixel (reference :1951-1991)
+        for (int col = tid; col < w; col += nt) {
+            float color[3] = {0.5f, 0.5f, 0.5f};
+            const int pos0 = P.binoff[col], pos1 = P.binoff[col + 1];  // bin col+1 = [col, col+1)
+            const int ls = col > 0 ? P.segoff[col - 1] : 0, le = P.segoff[col];
+            float prev = (float)col;
+            bool hazard = false;
+            float a = P.px[P.perm[pos0 - 1]];
+            for (int k = pos0 - 1; k < pos1; k++) {
+                float b = P.px[P.perm[k + 1]];
+                SubInt s = poly_subinterval(col, a, b);
+                a = b;
+                if (s.center < prev || s.center > (float)(col + 1)) hazard = true;
+                prev = s.center;
+                if (s.sig64 ? s.sig_d == 0.0 : s.sig_f == 0.0f) continue;  // adds exactly nothing
+                int nact = 0, nqual = 0, best = -1, single = -1;
+                float bc = (float)(-1e-7);
+                bool tie = false;
+                for (int e = ls; e < le; e++) {
+                    int o = P.entries[e];
+                    float x0 = P.px[o], x1 = P.px[o + 1];
+                    if (!(x0 < s.center) || x1 < s.center) continue;
+                    nact++;
+                    single = o;
+                    float ip_k = (s.center - x0) / (x1 - x0);
+                    if (0.0f < ip_k && ip_k < 1.0f) {
+                        float cl = (1.0f - ip_k) * poly_z(P, o) + ip_k * poly_z(P, o + 1);
+                        nqual++;
+                        if (bc < cl) { bc = cl; best = o; tie = false; }
+                        else if (cl == bc) tie = true;
+                    }
+                }
+                int seg;
+                if (nact == 1) seg = single;
+                else if (nqual == 0 || tie) { hazard = true; seg = single; }
+                else seg = best;
+                if (seg >= 0) poly_accumulate(P, L.img, seg, s.center, s.sig64, s.sig_d, s.sig_f, color);
+            }
+            if (hazard) *flag_hazard = 1;
+            L.res[3 * col + 0] = csm::f32_to_u8_wrap(color[0]);
+            L.res[3 * col + 1] = csm::f32_to_u8_wrap(color[1]);
+            L.res[3 * col + 2] = csm::f32_to_u8_wrap(color[2]);
+        }
+    }
+    __syncthreads();
+    if (overflow || *flag_hazard) {
+        // order-dependent row: replay the reference sweep literally on one lane
+        if (tid == 0) {
+            int rc = poly_sequential(P, L, E.csg_cap);
+            if (stats_rw) {
+                atomicAdd(&stats_rw[ST_FALLBACK_ROWS], 1u);
+                if (rc) atomicOr(&stats_rw[ST_ERROR], 1u);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the row kernel
+// ---------------------------------------------------------------------------------------------
+template <int FILL>
+__global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int row = blockIdx.x, frame = blockIdx.y;
+    const int w = A.w, h = A.h;
+    Lds L = carve(smem, w);
+    const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
+    uint32_t* st_rw = A.stats_rw ? A.stats_rw + (size_t)frame * ST_WORDS : nullptr;
+
+    // constants into LDS
+    for (int i = tid; i < 256; i += nt) L.lut[i] = (float)i / 255.0f;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_powf_tables);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(L.tabs);
+        for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += nt) dst[i] = src[i];
+    }
+    // source row -> uint8 RGB (np.clip(x*255, 0, 255).astype(uint8), reference :1508)
+    const size_t rowpix = ((size_t)frame * h + row) * w;
+    if (A.image_f32) {
+        const float* src = A.image_f32 + rowpix * 3;
+        if ((w & 3) == 0) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            for (int i = tid; i < (3 * w) / 4; i += nt) {
+                float4 v = s4[i];
+                float f[4] = {v.x, v.y, v.z, v.w};
+                uint32_t pk = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float x = f[j] * 255.0f;
+                    x = fminf(fmaxf(x, 0.0f), 255.0f);
+                    pk |= (uint32_t)(uint8_t)(int)x << (8 * j);
+                }
+                reinterpret_cast<uint32_t*>(L.img)[i] = pk;
+            }
+        } else {
+            for (int i = tid; i < 3 * w; i += nt) {
+                float x = src[i] * 255.0f;
+                x = fminf(fmaxf(x, 0.0f), 255.0f);
+                L.img[i] = (uint8_t)(int)x;
+            }
+        }
+    } else {
+        const uint8_t* src = A.image_u8 + rowpix * 3;
+        for (int i = tid; i < 3 * w; i += nt) L.img[i] = src[i];
+    }
+    __syncthreads();
+
+    const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
+    for (int e = 0; e < A.neyes; e++) {
+        const EyeArgs& E = A.eye[e];
+        if (A.single >= 0 && A.single != e) continue;
+        if (E.enabled) {
+            // normalised depth: (d - min) / (max - min) - convergence (reference :1587-1600)
+            float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
+            const float* drow = E.depth + rowpix;
+            const bool flat = dmax == dmin;
+            const float range = dmax - dmin;
+            for (int c = tid; c < w; c += nt) {
+                float d = drow[c] * scale;
+                L.nd[c] = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
+            }
+            __syncthreads();
+            if (FILL == CS_FILL_NONE || FILL == CS_FILL_NAIVE || FILL == CS_FILL_NAIVE_INTERPOLATING)
+                technique_forward<FILL>(L, w, E, A.e32);
+            else if (FILL == CS_FILL_INVERSE) technique_inverse(L, w, E, A.e32);
+            else if (FILL == CS_FILL_POLYLINES_SOFT) technique_polylines<0>(L, w, E, A.e32, st_rw);
+            else if (FILL == CS_FILL_POLYLINES_SHARP) technique_polylines<1>(L, w, E, A.e32, st_rw);
+        } else {
+            for (int i = tid; i < 3 * w; i += nt) L.res[i] = L.img[i];
+            __syncthreads();
+        }
+        // ---- store -------------------------------------------------------------------------
+        if (A.out_u8) {
+            uint8_t* dst = A.out_u8 + rowpix * 3;
+            for (int i = tid; i < 3 * w; i += nt) dst[i] = L.res[i];
+        } else {
+            const bool last = (e == A.neyes - 1) || A.single >= 0;
+            if (A.anaglyph && !last) {
+                // first eye of an anaglyph: keep the channels the composite takes from it
+                for (int c = tid; c < w; c += nt) {
+                    if (A.anaglyph == 1) L.ana[c] = L.res[3 * c];  // red from the left eye
+                    else { L.ana[2 * c] = L.res[3 * c + 1]; L.ana[2 * c + 1] = L.res[3 * c + 2]; }
+                }
+                __syncthreads();
+            } else {
+                if (A.anaglyph) {
+                    // red-cyan: R from eye0 (stashed), G,B from eye1 (res).  reverse: R from eye1, G,B from eye0
+                    for (int c = tid; c < w; c += nt) {
+                        if (A.anaglyph == 1) L.res[3 * c] = L.ana[c];
+                        else { L.res[3 * c + 1] = L.ana[2 * c]; L.res[3 * c + 2] = L.ana[2 * c + 1]; }
+                    }
+                    __syncthreads();
+                }
+                const int oy = row + E.yoff, ox = E.xoff;
+                float* dst = A.stereo + (((size_t)frame * A.out_h + oy) * A.out_w + ox) * 3;
+                if ((w & 3) == 0) {
+                    float4* d4 = reinterpret_cast<float4*>(dst);
+                    for (int i = tid; i < (3 * w) / 4; i += nt) {
+                        uint32_t pk = reinterpret_cast<const uint32_t*>(L.res)[i];
+                        d4[i] = make_float4(L.lut[pk & 0xff], L.lut[(pk >> 8) & 0xff], L.lut[(pk >> 16) & 0xff],
+                                            L.lut[pk >> 24]);
+                    }
+                } else {
+                    for (int i = tid; i < 3 * w; i += nt) dst[i] = L.lut[L.res[i]];
+                }
+                // mask: 1 where the OUTPUT pixel is black (GenerateStereo.py:355-361)
+                float* m = A.mask + ((size_t)frame * A.out_h + oy) * A.out_w + ox;
+                for (int c = tid; c < w; c += nt)
+                    m[c] = ((int)L.res[3 * c] + (int)L.res[3 * c + 1] + (int)L.res[3 * c + 2]) == 0 ? 1.0f : 0.0f;
+            }
+        }
+        __syncthreads();
+    }
+    // depth-map outputs: (depth*255).astype(uint8) wraps mod 256 (quirk Q7), then /255, 3 channels
+    if (A.depth_l) {
+        for (int e = 0; e < 2; e++) {
+            const float* drow = A.eye[e].depth + rowpix;
+            float* dst = (e == 0 ? A.depth_l : A.depth_r) + rowpix * 3;
+            for (int c = tid; c < w; c += nt) {
+                float v = L.lut[csm::f32_to_u8_wrap((drow[c] * scale) * 255.0f)];
+                dst[3 * c + 0] = v; dst[3 * c + 1] = v; dst[3 * c + 2] = v;
+            }
+        }
+    }
+}
+
+// host-side launcher (called from cs_abi.hip)
+hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream) {
+    size_t lds = lds_common_bytes(A.w) + lds_tech_bytes(fill, A.w);
+    dim3 grid(A.h, A.n), block(threads);
+#define CS_LAUNCH(F)                                                                                              \
+    case F: {                                                                                                     \
+        hipError_t e = hipFuncSetAttribute((const void*)k_rowwarp<F>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           (int)lds);                                                             \
+        if (e != hipSuccess) return e;                                                                            \
+        hipLaunchKernelGGL(k_rowwarp<F>, grid, block, lds, stream, A);                                            \
+        break;                                                                                                    \
+    }
+    switch (fill) {
+        CS_LAUNCH(CS_FILL_NONE)
+        CS_LAUNCH(CS_FILL_NAIVE)
+        CS_LAUNCH(CS_FILL_NAIVE_INTERPOLATING)
+        CS_LAUNCH(CS_FILL_POLYLINES_SOFT)
+        CS_LAUNCH(CS_FILL_POLYLINES_SHARP)
+        CS_LAUNCH(CS_FILL_INVERSE)
+    default: return hipErrorInvalidValue;
+    }
+#undef CS_LAUNCH
+    return hipGetLastError();
+}
+
+size_t rowwarp_lds_bytes(int fill, int w) { return lds_common_bytes(w) + lds_tech_bytes(fill, w); }
+
+}  // namespace cs

@@ -1,0 +1,157 @@
+"""Device-side engine: thin torch-tensor wrappers over the C ABI (libcomfystereo_hip.so).
+
+Everything here takes and returns tensors that live on the MI355X (`cuda` device in PyTorch-ROCm);
+PyTorch only provides the memory and the stream -- the arithmetic is in the HIP kernels.
+"""
+import ctypes
+
+import torch
+
+from . import _native
+from ._native import FILL, MODE, Params
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise ValueError("comfystereo_amd engine calls need device-resident tensors (there is no CPU path)")
+    return t
+
+
+def make_params(n, h, w, depth_h, depth_w, depth_c, fill, mode, divergence, separation, stereo_balance,
+                convergence_point, stereo_offset_exponent, depth_map_blur, depth_blur_strength,
+                depth_blur_edge_threshold, depth_blur_falloff, depth_blur_vert_smooth, batch_size):
+    if mode not in MODE:
+        raise ValueError(f"Unknown mode: {mode}")
+    p = Params()
+    p.n, p.h, p.w, p.depth_h, p.depth_w, p.depth_c = n, h, w, depth_h, depth_w, depth_c
+    p.fill, p.mode, p.batch_size = FILL[fill], MODE[mode], int(batch_size)
+    p.depth_map_blur, p.depth_blur_vert_smooth = int(bool(depth_map_blur)), int(depth_blur_vert_smooth)
+    p.divergence, p.separation, p.stereo_balance = float(divergence), float(separation), float(stereo_balance)
+    p.convergence_point, p.stereo_offset_exponent = float(convergence_point), float(stereo_offset_exponent)
+    p.depth_blur_strength, p.depth_blur_edge_threshold = float(depth_blur_strength), float(depth_blur_edge_threshold)
+    p.depth_blur_falloff = float(depth_blur_falloff)
+    return p
+
+
+def output_shape(p):
+    L = _native.lib()
+    oh, ow, mh, mw = (ctypes.c_int() for _ in range(4))
+    _native.check(L.cs_output_shape(ctypes.byref(p), ctypes.byref(oh), ctypes.byref(ow), ctypes.byref(mh), ctypes.byref(mw)))
+    return oh.value, ow.value, mh.value, mw.value
+
+
+class Plan:
+    """Pre-allocated outputs + workspace for repeated calls of one configuration (what bench.py times)."""
+
+    def __init__(self, p, device):
+        L = _native.lib()
+        self.p = p
+        oh, ow, mh, mw = output_shape(p)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.stereo = torch.empty((p.n, oh, ow, 3), **f32)
+        self.depth_l = torch.empty((p.n, p.h, p.w, 3), **f32)
+        self.depth_r = torch.empty((p.n, p.h, p.w, 3), **f32)
+        self.mask = torch.empty((p.n, mh, mw), **f32)
+        self.ws_bytes = L.cs_workspace_bytes(ctypes.byref(p))
+        self.ws = torch.empty((max(self.ws_bytes, 256),), dtype=torch.uint8, device=device)
+
+    def run(self, image, depth):
+        L = _native.lib()
+        _native.check(L.cs_generate(ctypes.byref(self.p), _ptr(image), _ptr(depth), _ptr(self.stereo), _ptr(self.depth_l),
+                                    _ptr(self.depth_r), _ptr(self.mask), _ptr(self.ws), self.ws_bytes, _stream()))
+        return self.stereo, self.depth_l, self.depth_r, self.mask
+
+    def stats(self):
+        """Per-frame diagnostics words (see cs_common.h ST_*), e.g. polylines rows replayed sequentially."""
+        return self.ws[: self.p.n * 64].view(torch.int32).view(self.p.n, 16).cpu()
+
+
+def generate(image, depth_map, divergence, separation, modes, stereo_balance, convergence_point,
+             stereo_offset_exponent, fill, depth_blur_edge_threshold, depth_blur_strength, depth_map_blur,
+             depth_blur_falloff=1.0, depth_blur_vert_smooth=0, batch_size=4):
+    """Fused batch path on device tensors: image [N,H,W,3], depth_map [N,H',W',C] float32 -> 4 device tensors."""
+    image = _dev(image).contiguous().float()
+    depth_map = _dev(depth_map).contiguous().float()
+    n, h, w, c = image.shape
+    if c != 3:
+        raise ValueError("image must be [N,H,W,3]")
+    p = make_params(n, h, w, depth_map.shape[1], depth_map.shape[2], depth_map.shape[3], fill, modes, divergence,
+                    separation, stereo_balance, convergence_point, stereo_offset_exponent, depth_map_blur,
+                    depth_blur_strength, depth_blur_edge_threshold, depth_blur_falloff, depth_blur_vert_smooth, batch_size)
+    return Plan(p, image.device).run(image, depth_map)
+
+
+def apply_stereo_divergence(image_u8, depth, divergence, separation, stereo_offset_exponent, fill, convergence_point=0.5):
+    """reference stereoimage_generation.py:1576-1620 for [N,H,W,3] uint8 + [N,H,W] float32 device tensors."""
+    L = _native.lib()
+    image_u8 = _dev(image_u8).contiguous()
+    depth = _dev(depth).contiguous().float()
+    assert image_u8.dtype == torch.uint8
+    squeeze = image_u8.dim() == 3
+    if squeeze:
+        image_u8, depth = image_u8[None], depth[None]
+    n, h, w, _ = image_u8.shape
+    out = torch.empty_like(image_u8)
+    nb = L.cs_asd_workspace_bytes(n, h, w)
+    ws = torch.empty((max(nb, 256),), dtype=torch.uint8, device=image_u8.device)
+    _native.check(L.cs_apply_stereo_divergence(_ptr(image_u8), _ptr(depth), n, h, w, float(divergence), float(separation),
+                                               float(stereo_offset_exponent), FILL[fill], float(convergence_point),
+                                               _ptr(out), _ptr(ws), nb, _stream()))
+    return out[0] if squeeze else out
+
+
+def directional_blur(depth, blur_strength, edge_threshold, falloff_exponent=1.0, vert_smooth_px=0):
+    """reference stereoimage_generation.py:1171-1251 for a [N,H,W] (or [H,W]) float32 device tensor, 0..255 scale."""
+    L = _native.lib()
+    depth = _dev(depth).contiguous().float()
+    shp = depth.shape
+    d3 = depth.reshape((-1,) + tuple(shp[-2:]))
+    n, h, w = d3.shape
+    out_l, out_r = torch.empty_like(d3), torch.empty_like(d3)
+    nb = L.cs_blur_workspace_bytes(n, h, w)
+    ws = torch.empty((max(nb, 256),), dtype=torch.uint8, device=depth.device)
+    _native.check(L.cs_directional_blur(_ptr(d3), n, h, w, float(blur_strength), float(edge_threshold),
+                                        float(falloff_exponent), int(vert_smooth_px), _ptr(out_l), _ptr(out_r), _ptr(ws),
+                                        nb, _stream()))
+    return out_l.reshape(shp), out_r.reshape(shp)
+
+
+def forward_warp(image, depth, divergence_px, separation_px, stereo_offset_exponent, convergence_point=0.5):
+    """reference stereoimage_generation.py:277-450: image [B,3,H,W], depth [B,H,W] -> (warped, gap mask bool)."""
+    L = _native.lib()
+    image = _dev(image).contiguous().float()
+    depth = _dev(depth).contiguous().float()
+    b, c, h, w = image.shape
+    assert c == 3
+    warped = torch.empty_like(image)
+    mask = torch.empty((b, h, w), dtype=torch.uint8, device=image.device)
+    nb = L.cs_warp_workspace_bytes(b, h, w)
+    ws = torch.empty((max(nb, 256),), dtype=torch.uint8, device=image.device)
+    _native.check(L.cs_forward_warp(_ptr(image), _ptr(depth), b, h, w, float(divergence_px), float(separation_px),
+                                    float(stereo_offset_exponent), float(convergence_point), _ptr(warped), _ptr(mask),
+                                    _ptr(ws), nb, _stream()))
+    return warped, mask.bool()
+
+
+def test_powf(x, y):
+    L = _native.lib()
+    x = _dev(x).contiguous().float()
+    out = torch.empty_like(x)
+    _native.check(L.cs_test_powf(_ptr(x), float(y), _ptr(out), x.numel(), _stream()))
+    return out
+
+
+def test_exp(x):
+    L = _native.lib()
+    x = _dev(x).contiguous().double()
+    out = torch.empty_like(x)
+    _native.check(L.cs_test_exp(_ptr(x), _ptr(out), x.numel(), _stream()))
+    return out

@@ -1,0 +1,151 @@
+/*
+ * comfystereo_amd.h -- C ABI of the MI355X-native depth-to-stereo engine (libcomfystereo_hip.so).
+ *
+ * The reference (Dobidop/ComfyStereo) is pure Python and has no FFI; its only seam is the Python
+ * module boundary `GenerateStereo.py` -> `stereoimage_generation.py`.  The entry points below are what
+ * a binding for that seam binds: each one cites the reference interface it replaces.  They are
+ * called by comfystereo_amd/_native.py (ctypes) on behalf of the drop-in module functions
+ * `create_stereoimages` / `create_stereoimages_gpu` and of `StereoImageNode.generate`.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer is caller-owned DEVICE memory (HIP), row-major,
+ *     contiguous in the stated shape; no allocation happens inside the library
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it
+ *   - return value: CS_OK (0) or a negative CS_E* code; cs_last_error() returns a thread-local
+ *     message for the last failing call
+ *   - scalar parameters are doubles because they are Python floats in the reference, which rounds
+ *     them to float32 at specific points of the arithmetic
+ *   - re-entrant per stream as long as each concurrent call gets its own workspace
+ */
+#ifndef COMFYSTEREO_AMD_H
+#define COMFYSTEREO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CS_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define CS_API __attribute__((visibility("default")))
+#else
+#define CS_API
+#endif
+
+enum cs_status {
+    CS_OK = 0,
+    CS_EINVAL = -1,    /* bad argument (null pointer, size <= 0, unknown enum) */
+    CS_EWORKSPACE = -2,/* workspace too small: see cs_workspace_bytes */
+    CS_ELIMIT = -3,    /* frame too wide for the LDS-resident row kernels (see cs_max_width) */
+    CS_EHIP = -4       /* a HIP runtime call failed */
+};
+
+/* fill_technique keys of reference GenerateStereo.py:88-100 (the UI-reachable ones) */
+enum cs_fill {
+    CS_FILL_NONE = 0,                /* 'none'                 stereoimage_generation.py:1850-1910 */
+    CS_FILL_NAIVE = 1,               /* 'naive'                :1893-1908 */
+    CS_FILL_NAIVE_INTERPOLATING = 2, /* 'naive_interpolating'  :1871-1892 */
+    CS_FILL_POLYLINES_SOFT = 3,      /* 'polylines_soft'       :1912-1992 */
+    CS_FILL_POLYLINES_SHARP = 4,     /* 'polylines_sharp'      :1912-1992 */
+    CS_FILL_INVERSE = 5,             /* 'inverse'              :1715-1737 */
+    CS_FILL_HYBRID_EDGE = 6,         /* 'hybrid_edge'          :1837-1848 */
+    CS_FILL_GPU_WARP = 7             /* 'gpu_warp'             forward_warp_gpu :277-450 */
+};
+
+/* output modes of reference stereoimage_generation.py:1543-1562 / :1093-1120 */
+enum cs_mode {
+    CS_MODE_LEFT_RIGHT = 0,
+    CS_MODE_RIGHT_LEFT = 1,
+    CS_MODE_TOP_BOTTOM = 2,
+    CS_MODE_BOTTOM_TOP = 3,
+    CS_MODE_RED_CYAN_ANAGLYPH = 4,
+    CS_MODE_LEFT_ONLY = 5,
+    CS_MODE_ONLY_RIGHT = 6,
+    CS_MODE_CYAN_RED_REVERSEANAGLYPH = 7
+};
+
+/* One call of StereoImageNode.generate (reference GenerateStereo.py:79-80): widget values + shapes. */
+typedef struct cs_params {
+    int32_t n, h, w;            /* image batch [n][h][w][3] float32 0..1 (ComfyUI IMAGE)            */
+    int32_t depth_h, depth_w;   /* depth batch [n][depth_h][depth_w][depth_c] float32               */
+    int32_t depth_c;            /* 3 -> 0.2989 R + 0.5870 G + 0.1140 B; 1 -> as is; else channel 0  */
+    int32_t fill;               /* enum cs_fill                                                     */
+    int32_t mode;               /* enum cs_mode                                                     */
+    int32_t batch_size;         /* gpu_warp only: frames per reference sub-batch (its 0..255 test is
+                                   global over a sub-batch, stereoimage_generation.py:1045, :315)   */
+    int32_t depth_map_blur;     /* bool: direction-aware depth blur on/off                          */
+    int32_t depth_blur_vert_smooth;
+    int32_t reserved;
+    double divergence, separation, stereo_balance, convergence_point, stereo_offset_exponent;
+    double depth_blur_strength, depth_blur_edge_threshold, depth_blur_falloff;
+} cs_params;
+
+CS_API int cs_version(void);
+CS_API const char *cs_last_error(void);
+
+/* Largest frame width the LDS-resident row kernels accept for `fill` (160 KiB LDS per CU). */
+CS_API int cs_max_width(int fill);
+
+/* Shape of the outputs of cs_generate for `p`: stereoscope [n][*out_h][*out_w][3],
+ * mask [n][*mask_h][*mask_w] (output-shaped for the CPU techniques, eye-shaped for gpu_warp). */
+CS_API int cs_output_shape(const cs_params *p, int *out_h, int *out_w, int *mask_h, int *mask_w);
+
+/* Scratch bytes cs_generate needs for `p` (intermediate gray/blurred depth, per-frame statistics). */
+CS_API size_t cs_workspace_bytes(const cs_params *p);
+
+/*
+ * The fused batch path.  Replaces StereoImageNode.generate's per-frame loop
+ * (GenerateStereo.py:117-269: grayscale, resize, create_stereoimages[_gpu], convertResult,
+ * generate_mask) for device-resident tensors:
+ *   image     [n][h][w][3]            float32 in 0..1
+ *   depth     [n][depth_h][depth_w][depth_c] float32
+ *   stereo    [n][out_h][out_w][3]    float32   "stereoscope"
+ *   depth_l/r [n][h][w][3]            float32   "blurred_depthmap_left/right"
+ *   mask      [n][mask_h][mask_w]     float32   "no_fill_imperfect_mask"
+ */
+CS_API int cs_generate(const cs_params *p, const float *image, const float *depth, float *stereo, float *depth_l,
+                float *depth_r, float *mask, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * apply_stereo_divergence (reference stereoimage_generation.py:1576-1620) for one eye of `n`
+ * independent frames: per-frame min/max normalisation, convergence shift, percent -> pixels, row
+ * kernel `fill` (any CPU technique).  image_u8 [n][h][w][3] uint8, depth [n][h][w] float32,
+ * out_u8 [n][h][w][3].  workspace: cs_asd_workspace_bytes(n, h, w).
+ */
+CS_API size_t cs_asd_workspace_bytes(int n, int h, int w);
+CS_API int cs_apply_stereo_divergence(const uint8_t *image_u8, const float *depth, int n, int h, int w, double divergence,
+                               double separation, double stereo_offset_exponent, int fill, double convergence_point,
+                               uint8_t *out_u8, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * directional_motion_blur_gpu (reference stereoimage_generation.py:1171-1251, called with
+ * blur_mask_width = blur_strength as at :1051-1054 / :1479-1482).  depth, out_l, out_r: [n][h][w]
+ * float32 on the 0..255 scale.  workspace: cs_blur_workspace_bytes(n, h, w).
+ */
+CS_API size_t cs_blur_workspace_bytes(int n, int h, int w);
+CS_API int cs_directional_blur(const float *depth, int n, int h, int w, double blur_strength, double edge_threshold,
+                        double falloff_exponent, int vert_smooth_px, float *out_l, float *out_r, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+/*
+ * forward_warp_gpu (reference stereoimage_generation.py:277-450) for a sub-batch:
+ * image [n][3][h][w] float32, depth [n][h][w] float32 -> warped [n][3][h][w] float32,
+ * gap_mask [n][h][w] uint8 (1 = disocclusion).  workspace: cs_warp_workspace_bytes(n, h, w).
+ */
+CS_API size_t cs_warp_workspace_bytes(int n, int h, int w);
+CS_API int cs_forward_warp(const float *image, const float *depth, int n, int h, int w, double divergence_px,
+                    double separation_px, double stereo_offset_exponent, double convergence_point, float *warped,
+                    uint8_t *gap_mask, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Device self-tests of the libm-exact scalar routines (used by the parity tests):
+ * out[i] = powf(x[i], y) / out[i] = exp(x[i]) evaluated by the same device code the kernels use. */
+CS_API int cs_test_powf(const float *x, float y, float *out, size_t count, void *stream);
+CS_API int cs_test_exp(const double *x, double *out, size_t count, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

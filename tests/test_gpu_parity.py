@@ -1,0 +1,118 @@
+"""Parity of the HIP kernels (through the C ABI) against the CPU oracle and the golden fixtures.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from conftest import node_case_expected, node_case_inputs
+from oracle import node_oracle, oracle
+
+pytestmark = pytest.mark.gpu
+
+CPU_FILLS = ["none", "naive", "naive_interpolating", "polylines_soft", "polylines_sharp", "inverse", "hybrid_edge"]
+GPU_WARP_COLOUR_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from comfystereo_amd import engine as e
+    assert torch.cuda.is_available()
+    return e
+
+
+def cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_device_powf_bit_exact(engine):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.random(2_000_000, dtype=np.float32), np.float32([0, 1, 0.5, 1e-30, 1e-40, 1e-44, 2.5, 100.0])])
+    L = oracle.lib()
+    for e in [i / 10 for i in range(1, 21)] + [2.7, 0.05]:
+        got = engine.test_powf(cuda(x), e).cpu().numpy()
+        want = np.array([L.oracle_powf(float(v), float(np.float32(e))) for v in x[:: 97]], dtype=np.float32)
+        assert np.array_equal(got[:: 97].view(np.uint32), want.view(np.uint32)), e
+
+
+def test_device_exp_bit_exact(engine):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([-rng.random(200000) * 330.0, -(rng.random(200000, dtype=np.float32).astype(np.float64) ** 2) * 2,
+                        [0.0, -0.0, -0.5, -1.0, -1e-300]])
+    got = engine.test_exp(cuda(x)).cpu().numpy()
+    L = oracle.lib()
+    want = np.array([L.oracle_exp(float(v)) for v in x[:: 13]])
+    assert np.array_equal(got[:: 13].view(np.uint64), want.view(np.uint64))
+
+
+@pytest.mark.parametrize("fill", CPU_FILLS)
+def test_apply_stereo_divergence_goldens(engine, golden_asd, fill):
+    """Bit-exact against the outputs captured from the imported reference."""
+    g = golden_asd
+    for case in g.meta["cases"]:
+        cid = case["id"]
+        got = engine.apply_stereo_divergence(cuda(g[f"{cid}/img"]), cuda(g[f"{cid}/depth"]), case["divergence"],
+                                             case["separation"], case["exponent"], fill, case["convergence"])
+        assert np.array_equal(got.cpu().numpy(), g[f"{cid}/out/{fill}"]), (cid, fill)
+
+
+@pytest.mark.parametrize("fill", CPU_FILLS)
+@pytest.mark.parametrize("kind", ["blobs", "stepped", "noisy_ramp", "radial", "random8"])
+def test_apply_stereo_divergence_vs_oracle(engine, fill, kind):
+    """Seeded inputs at sizes the oracle finishes in seconds, batch of frames, both signs, exponents, separation."""
+    h, w, n = 40, 640, 3
+    params = [(6.0, 0.0, 2.0, 0.5), (-6.0, 0.4, 1.3, 0.4), (3.0, -0.8, 0.5, 0.0), (-9.0, 0.0, 1.0, 1.0)]
+    for pi, (div, sep, e, conv) in enumerate(params):
+        if kind == "random8" and fill.startswith("poly"):
+            div = 1.2 if div > 0 else -1.2
+        img = np.stack([synth.image_u8(h, w, seed=10 * pi + j) for j in range(n)])
+        depth = np.stack([synth.DEPTHS[kind](h, w, **({"cx": w / 2 + 31 * j} if kind in ("radial", "stepped") else {"seed": j}))
+                          for j in range(n)]) * np.float32(255.0)
+        got = engine.apply_stereo_divergence(cuda(img), cuda(depth), div, sep, e, fill, conv).cpu().numpy()
+        for j in range(n):
+            want = oracle.apply_stereo_divergence(img[j], depth[j], div, sep, e, fill, conv)
+            bad = np.argwhere(got[j] != want)
+            assert bad.size == 0, (fill, kind, pi, j, len(bad), bad[:4].tolist())
+
+
+def test_node_goldens(engine, golden_node):
+    """StereoImageNode.generate outputs captured from the reference (every UI technique x mode + variants)."""
+    g = golden_node
+    ran = 0
+    for case in g.meta["cases"]:
+        img, depth = node_case_inputs(g, case)
+        kw = dict(case["kw"])
+        got = engine.generate(cuda(img), cuda(depth), case["divergence"], case["separation"], case["mode"], case["balance"],
+                              case["convergence"], case["exponent"], case["fill"], case["edge_threshold"], case["strength"],
+                              case["blur"], **kw)
+        got = [t.cpu().numpy() for t in got]
+        want = node_case_expected(g, case)
+        cid = case["id"]
+        assert list(got[0].shape) == case["shapes"]["stereo"] and list(got[3].shape) == case["shapes"]["mask"], cid
+        if cid.startswith("resize/"):
+            assert np.mean(got[0] != want[0]) < 0.02, cid  # bilinear resize: tolerance (different float order)
+            continue
+        if case["fill"] == "gpu_warp":
+            assert np.abs(got[0] - want[0]).max() <= GPU_WARP_COLOUR_TOL, (cid, np.abs(got[0] - want[0]).max())
+        else:
+            assert np.array_equal(got[0], want[0]), (cid, int((got[0] != want[0]).sum()))
+        assert np.array_equal(got[1][..., 0], want[1]) and np.array_equal(got[2][..., 0], want[2]), cid
+        assert np.array_equal(got[1][..., 0], got[1][..., 2]), cid
+        assert np.array_equal(got[3], want[3]), cid
+        ran += 1
+    assert ran >= 45
+
+
+@pytest.mark.parametrize("fill,mode", [("polylines_soft", "left-right"), ("none", "red-cyan-anaglyph"),
+                                       ("naive_interpolating", "top-bottom"), ("inverse", "right-left"),
+                                       ("hybrid_edge", "bottom-top"), ("polylines_sharp", "left-right")])
+def test_node_vs_oracle_blur_on(engine, fill, mode):
+    n, h, w = 2, 256, 384
+    img = synth.image_f32(n, h, w, seed=4)
+    depth = synth.depth_batch("blobs", n, h, w, channels=3)
+    args = (4.5, 0.0, mode, 0.0, 0.5, 2.0)
+    ui = {v: k for k, v in node_oracle.FILL_KEYS.items()}[fill]
+    kw = dict(depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+    got = engine.generate(cuda(img), cuda(depth), *args, fill, 20.0, 20.0, True, **kw)
+    want = node_oracle.generate(img, depth, *args, ui, 20.0, 20.0, True, **kw)
+    for gt, wv, name in zip(got, want, ("stereo", "dl", "dr", "mask")):
+        assert np.array_equal(gt.cpu().numpy(), wv), (fill, mode, name)
