@@ -1,0 +1,342 @@
+// cs_gpuwarp.hip -- the 'gpu_warp' technique: forward_warp_gpu (reference
+// stereoimage_generation.py:277-450) and its batched driver create_stereoimages_gpu (:1005-1128).
+//
+// The reference issues ~1000 full-frame ATen launches per eye pair (8 gather/scatter rounds, two
+// cummax scans, grid_sample).  Here one workgroup owns one image row and keeps the whole state of
+// the row (normalised depth, pixel offsets, z-buffer, inverse source map) in LDS:
+//   * each of the 8 rounds: every adjacent pixel pair proposes a target column; torch's CPU
+//     scatter_ is sequential, so the HIGHEST pair index targeting a column decides it, and a
+//     non-improving winner writes back what it gathered (quirk Q3).  -> LDS atomicMax over pair
+//     indices picks the deciding pair, which alone updates (z, src) of its column.
+//   * gap fill: "left nearest" = prefix-max scan; "right nearest" is the row's RIGHTMOST filled
+//     column (quirk Q2) = one block-wide max.
+//   * sampling: the bilinear grid_sample through the [-1,1] coordinate round trip (both axes), read
+//     straight from the source image in HBM (rows y, y+1 are L2-resident neighbours).
+// Gap mask: bit-exact for exponents 2 / 1 / 0.5 (torch.pow is exact there); colours are float32 with
+// a stated tolerance against torch's vectorised bilinear kernel (tests).
+#include "cs_common.h"
+#include "cs_kernels.h"
+#include <string.h>
+
+namespace cs {
+
+struct GwEye {
+    const float* depth;  // [n][h][w]
+    float div32, sep32;
+    int enabled;
+    int st_min, st_max, st_div;  // stats words: depth min / max (pre-division), divide-by-255 flag
+    int xoff, yoff;
+    int chan_mask;  // which channels of the output pixel this eye writes (bit c)
+};
+
+struct GwArgs {
+    int n, h, w;
+    const float* image;            // pixel (f, y, x, c) at f*img_sf + y*img_sy + x*img_sx + c*img_sc
+    long long img_sf, img_sy, img_sx, img_sc;
+    const uint32_t* stats;
+    int scale_from_stats;
+    int pow_mode;  // 0: x, 1: sqrt, 2: x*x, 3: x*x*x, 4: powf, 5: ones
+    float e32, conv32;
+    GwEye eye[2];
+    int neyes;
+    float* out;                    // pixel (f, y, x, c) at f*out_sf + y*out_sy + x*out_sx + c*out_sc
+    long long out_sf, out_sy, out_sx, out_sc;
+    uint8_t* mask_u8;  // plain: [n][h][w]
+    float* mask_f32;   // node:  [n][h][w] (left | right)
+    float* depth_l; float* depth_r;  // node: [n][h][w][3]
+};
+
+__constant__ csm::PowfTables c_gw_powf_tables = CS_POWF_TABLES_INIT;
+
+__device__ __forceinline__ float torch_pow(float x, int mode, float e32, const csm::PowfTables* T) {
+    switch (mode) {
+    case 0: return x;
+    case 1: return sqrtf(x);
+    case 2: return x * x;
+    case 3: return (x * x) * x;
+    case 5: return 1.0f;
+    default: return csm::powf_exact(x, e32, T);
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id();
+    const int y = blockIdx.x, frame = blockIdx.y, w = A.w, h = A.h;
+    float* ndn = (float*)smem;     // normalised depth (not convergence-shifted)
+    float* po = ndn + w;           // pixel offset
+    float* zb = po + w;            // z-buffer
+    float* sm = zb + w;            // source map
+    int* winner = (int*)(sm + w);  // deciding pair per column; later: left-nearest scan
+    uint8_t* gap = (uint8_t*)(winner + w);
+    int* ws = (int*)(gap + align16((size_t)w));
+    csm::PowfTables* T = (csm::PowfTables*)(ws + 32);
+    if (A.pow_mode == 4) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_gw_powf_tables);
+        for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += nt) reinterpret_cast<uint32_t*>(T)[i] = src[i];
+    }
+    const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
+    const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
+    for (int x = tid; x < w; x += nt) gap[x] = 0;
+    __syncthreads();
+    // torch.linspace(-1, 1, H)[y] (symmetric two-sided fill) and its unnormalisation
+    float gy;
+    {
+        float step = h > 1 ? 2.0f / (float)(h - 1) : 0.0f;
+        gy = y < h / 2 ? -1.0f + step * (float)y : 1.0f - step * (float)(h - y - 1);
+    }
+    float yy = (gy + 1.0f) * ((float)(h - 1) / 2.0f);
+    yy = fminf(fmaxf(yy, 0.0f), (float)(h - 1));
+    const float yn = floorf(yy);
+    const float wn = yy - yn, wsth = 1.0f - wn;
+    const int iy0 = (int)yn, iy1 = min(iy0 + 1, h - 1);
+    const float sxw = (float)(w - 1);
+
+    for (int e = 0; e < A.neyes; e++) {
+        const GwEye& E = A.eye[e];
+        if (!E.enabled) {
+            // eye = source image (divergence < 0.001): plain copy into the slot
+            if (A.out)
+                for (int x = tid; x < w; x += nt)
+                    for (int c = 0; c < 3; c++)
+                        if (E.chan_mask & (1 << c))
+                            A.out[frame * A.out_sf + (y + E.yoff) * A.out_sy + (x + E.xoff) * A.out_sx + c * A.out_sc] =
+                                A.image[frame * A.img_sf + y * A.img_sy + x * A.img_sx + c * A.img_sc];
+            continue;
+        }
+        const bool div255 = st[E.st_div] != 0;
+        float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
+        if (div255) { dmin = dmin / 255.0f; dmax = dmax / 255.0f; }
+        const float range = dmax - dmin;
+        const float crange = fmaxf(range, (float)1e-6);
+        const bool has_range = range > (float)1e-6;
+        const float* drow = E.depth + ((size_t)frame * h + y) * w;
+        for (int x = tid; x < w; x += nt) {
+            float v = drow[x] * scale;
+            if (div255) v = v / 255.0f;
+            float nrm = has_range ? (v - dmin) / crange : 0.0f;
+            ndn[x] = nrm;
+            float s = nrm - A.conv32;
+            float sg = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
+            float od = sg * torch_pow(fabsf(s), A.pow_mode, A.e32, T);
+            po[x] = od * E.div32 + E.sep32;
+            zb[x] = -1.0f;
+            sm[x] = -1.0f;
+        }
+        __syncthreads();
+        for (int k = 0; k < 8; k++) {
+            for (int x = tid; x < w; x += nt) winner[x] = -1;
+            __syncthreads();
+            for (int i = tid; i < w - 1; i += nt) {
+                float dl = (float)i + po[i], dr = (float)(i + 1) + po[i + 1];
+                float fs = floorf(fminf(dl, dr));
+                float cf = fminf(fmaxf(fs + (float)k, 0.0f), sxw);  // clamp(c, 0, W-1)
+                atomicMax(&winner[(int)cf], i);
+            }
+            __syncthreads();
+            for (int i = tid; i < w - 1; i += nt) {
+                float dl = (float)i + po[i], dr = (float)(i + 1) + po[i + 1];
+                float fs = floorf(fminf(dl, dr));
+                float cfl = fs + (float)k;  // exact: |fs| << 2^24
+                int cs_ = (int)fminf(fmaxf(cfl, 0.0f), sxw);
+                if (winner[cs_] != i) continue;
+                bool connected = fabsf(po[i + 1] - po[i]) < 1.5f;
+                float sw = dr - dl;
+                float safe = fabsf(sw) < (float)1e-4 ? 1.0f : sw;
+                float frac = (cfl - dl) / safe;
+                bool valid = connected && cfl >= 0.0f && cfl < (float)w && frac >= 0.0f && frac < 1.0f;
+                float iz = ndn[i] * (1.0f - frac) + ndn[i + 1] * frac;
+                if (valid && iz > zb[cs_] + (float)1e-6) {
+                    zb[cs_] = iz;
+                    sm[cs_] = (float)i + frac;
+                }
+            }
+            __syncthreads();
+        }
+        // gap fill (:393-438)
+        int myright = -1;
+        for (int x = tid; x < w; x += nt) {
+            bool filled = !(sm[x] < 0.0f);
+            winner[x] = filled ? x : -1;
+            if (filled) myright = max(myright, x);
+            if (!filled) gap[x] = 1;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) myright = max(myright, __shfl_xor(myright, off));
+        if (lane == 0) ws[16 + wave] = myright;
+        __syncthreads();
+        int rightmost = -1;
+        for (int i = 0; i < (nt >> 6); i++) rightmost = max(rightmost, ws[16 + i]);
+        __syncthreads();
+        block_scan_inclusive(winner, w, -1, OpMax(), ws);
+        // po is dead now: reuse it for the final source positions
+        for (int x = tid; x < w; x += nt) {
+            float s = sm[x];
+            if (s < 0.0f) {
+                int left = winner[x];
+                int right = rightmost >= x ? rightmost : -1;
+                bool hl = left >= 0, hr = right >= 0;
+                int li = hl ? left : 0, ri = hr ? right : 0;
+                float lsrc = sm[li], rsrc = sm[ri], lz = zb[li], rz = zb[ri];
+                float ld = (float)(x - left), rd = (float)(right - x);
+                float tot = fmaxf(ld + rd, 1.0f);
+                float t = ld / tot;
+                if (!hl) t = 1.0f;
+                if (!hr) t = 0.0f;
+                float tb = (lz < rz) ? sqrtf(t) : 1.0f - sqrtf(1.0f - t);
+                float g = lsrc * (1.0f - tb) + rsrc * tb;
+                if (hl || hr) s = g;
+            }
+            po[x] = fminf(fmaxf(s, 0.0f), sxw);
+        }
+        __syncthreads();
+        // bilinear sample through the grid_sample coordinate round trip (:440-448)
+        for (int x = tid; x < w; x += nt) {
+            float gx = po[x] * 2.0f / sxw - 1.0f;
+            float xx = (gx + 1.0f) * (sxw / 2.0f);
+            xx = fminf(fmaxf(xx, 0.0f), sxw);
+            float xw = floorf(xx);
+            float ww = xx - xw, we = 1.0f - ww;
+            int ix0 = (int)xw, ix1 = min(ix0 + 1, w - 1);
+            float nw = wsth * we, ne = wsth * ww, sw2 = wn * we, se = wn * ww;
+            const float* p00 = A.image + frame * A.img_sf + iy0 * A.img_sy + ix0 * A.img_sx;
+            const float* p01 = A.image + frame * A.img_sf + iy0 * A.img_sy + ix1 * A.img_sx;
+            const float* p10 = A.image + frame * A.img_sf + iy1 * A.img_sy + ix0 * A.img_sx;
+            const float* p11 = A.image + frame * A.img_sf + iy1 * A.img_sy + ix1 * A.img_sx;
+            float* o = A.out + frame * A.out_sf + (y + E.yoff) * A.out_sy + (x + E.xoff) * A.out_sx;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                if (!(E.chan_mask & (1 << c))) continue;
+                float v = p00[c * A.img_sc] * nw + p01[c * A.img_sc] * ne + p10[c * A.img_sc] * sw2 + p11[c * A.img_sc] * se;
+                o[c * A.out_sc] = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (A.mask_u8)
+        for (int x = tid; x < w; x += nt) A.mask_u8[((size_t)frame * h + y) * w + x] = gap[x];
+    if (A.mask_f32)
+        for (int x = tid; x < w; x += nt) A.mask_f32[((size_t)frame * h + y) * w + x] = gap[x] ? 1.0f : 0.0f;
+    if (A.depth_l) {
+        // left_depth / 255 if its (sub-batch) max > 1 (:1125-1126), clamp(0,1), 3 channels (GenerateStereo.py:165-168)
+        for (int e = 0; e < 2; e++) {
+            const GwEye& E = A.eye[e];
+            const bool div255 = st[E.st_div] != 0;
+            const float* drow = E.depth + ((size_t)frame * h + y) * w;
+            float* dst = (e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + y) * w) * 3;
+            for (int x = tid; x < w; x += nt) {
+                float v = drow[x] * scale;
+                if (div255) v = v / 255.0f;
+                v = fminf(fmaxf(v, 0.0f), 1.0f);
+                dst[3 * x] = v; dst[3 * x + 1] = v; dst[3 * x + 2] = v;
+            }
+        }
+    }
+}
+
+// forward_warp_gpu's `if (d_max_all > 1.0).any(): d = d / 255.0` is global over the tensor it is handed,
+// i.e. over one reference sub-batch (`group` frames).
+__global__ void k_gpuwarp_flags(uint32_t* stats, int n, int group) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    int g0 = (f / group) * group, g1 = min(g0 + group, n);
+    uint32_t fl = 0, fr = 0;
+    for (int k = g0; k < g1; k++) {
+        if (csm::ord2f(stats[k * ST_WORDS + ST_L_MAX]) > 1.0f) fl = 1;
+        if (csm::ord2f(stats[k * ST_WORDS + ST_R_MAX]) > 1.0f) fr = 1;
+    }
+    stats[f * ST_WORDS + ST_WARP_DIV255_L] = fl;
+    stats[f * ST_WORDS + ST_WARP_DIV255_R] = fr;
+}
+
+static size_t gw_lds_bytes(int w) {
+    return 5 * (size_t)w * 4 + align16((size_t)w) + 32 * 4 + sizeof(csm::PowfTables) + 64;
+}
+size_t gpuwarp_workspace_bytes(int, int, int) { return 256; }
+int gpuwarp_max_width() {
+    int lo = 2, hi = 1 << 15;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) / 2;
+        if (gw_lds_bytes(mid) <= CS_LDS_BYTES) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+static int pow_mode_of(double e) { return e == 1.0 ? 0 : e == 0.5 ? 1 : e == 2.0 ? 2 : e == 3.0 ? 3 : e == 0.0 ? 5 : 4; }
+
+static int gw_launch(GwArgs& A, hipStream_t stream) {
+    size_t lds = gw_lds_bytes(A.w);
+    int threads = A.w <= 256 ? 256 : (A.w <= 1024 ? 512 : 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_gpuwarp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return CS_EHIP;
+    hipLaunchKernelGGL(k_gpuwarp, dim3(A.h, A.n), dim3(threads), lds, stream, A);
+    return CS_OK;
+}
+
+int launch_gpuwarp_plain(const float* image, const float* depth, int n, int h, int w, double div_px, double sep_px,
+                         double exponent, double convergence, float* warped, uint8_t* gap_mask, uint32_t* stats,
+                         void*, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gpuwarp_flags, dim3((n + 63) / 64), dim3(64), 0, stream, stats, n, n);
+    GwArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n = n; A.h = h; A.w = w;
+    A.image = image;
+    A.img_sf = 3LL * h * w; A.img_sc = (long long)h * w; A.img_sy = w; A.img_sx = 1;
+    A.stats = stats;
+    A.scale_from_stats = 0;
+    A.pow_mode = pow_mode_of(exponent);
+    A.e32 = (float)exponent; A.conv32 = (float)convergence;
+    A.neyes = 1;
+    A.eye[0].depth = depth;
+    A.eye[0].div32 = (float)div_px; A.eye[0].sep32 = (float)sep_px;
+    A.eye[0].enabled = 1;
+    A.eye[0].st_min = ST_L_MIN; A.eye[0].st_max = ST_L_MAX; A.eye[0].st_div = ST_WARP_DIV255_L;
+    A.eye[0].chan_mask = 7;
+    A.out = warped;
+    A.out_sf = A.img_sf; A.out_sc = A.img_sc; A.out_sy = w; A.out_sx = 1;
+    A.mask_u8 = gap_mask;
+    return gw_launch(A, stream);
+}
+
+int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL, const float* dR, int scale_from_stats,
+                        uint32_t* stats, float* stereo, float* depth_l, float* depth_r, float* mask, int out_h,
+                        int out_w, void*, hipStream_t stream) {
+    const int n = p->n, h = p->h, w = p->w;
+    int group = p->batch_size > 0 ? (p->batch_size < n ? p->batch_size : n) : n;
+    hipLaunchKernelGGL(k_gpuwarp_flags, dim3((n + 63) / 64), dim3(64), 0, stream, stats, n, group);
+    GwArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n = n; A.h = h; A.w = w;
+    A.image = image;
+    A.img_sf = 3LL * h * w; A.img_sy = 3LL * w; A.img_sx = 3; A.img_sc = 1;
+    A.stats = stats;
+    A.scale_from_stats = scale_from_stats;
+    A.pow_mode = pow_mode_of(p->stereo_offset_exponent);
+    A.e32 = (float)p->stereo_offset_exponent; A.conv32 = (float)p->convergence_point;
+    A.neyes = 2;
+    const double left_div = p->divergence * (1 + p->stereo_balance), right_div = p->divergence * (1 - p->stereo_balance);
+    const double lpx = (left_div / 100.0) * w, rpx = (right_div / 100.0) * w, spx = (p->separation / 100.0) * w;
+    A.eye[0].depth = dL; A.eye[0].div32 = (float)(+lpx); A.eye[0].sep32 = (float)(-spx);
+    A.eye[1].depth = dR; A.eye[1].div32 = (float)(-rpx); A.eye[1].sep32 = (float)(spx);
+    A.eye[0].enabled = !(left_div < 0.001); A.eye[1].enabled = !(right_div < 0.001);
+    A.eye[0].st_min = ST_L_MIN; A.eye[0].st_max = ST_L_MAX; A.eye[0].st_div = ST_WARP_DIV255_L;
+    A.eye[1].st_min = ST_R_MIN; A.eye[1].st_max = ST_R_MAX; A.eye[1].st_div = ST_WARP_DIV255_R;
+    A.eye[0].chan_mask = A.eye[1].chan_mask = 7;
+    switch (p->mode) {
+    case CS_MODE_LEFT_RIGHT: A.eye[1].xoff = w; break;
+    case CS_MODE_RIGHT_LEFT: A.eye[0].xoff = w; break;
+    case CS_MODE_TOP_BOTTOM: A.eye[1].yoff = h; break;
+    case CS_MODE_BOTTOM_TOP: A.eye[0].yoff = h; break;
+    case CS_MODE_RED_CYAN_ANAGLYPH: A.eye[0].chan_mask = 1; A.eye[1].chan_mask = 6; break;
+    case CS_MODE_CYAN_RED_REVERSEANAGLYPH: A.eye[0].chan_mask = 6; A.eye[1].chan_mask = 1; break;
+    case CS_MODE_LEFT_ONLY: A.eye[1].chan_mask = 0; break;
+    case CS_MODE_ONLY_RIGHT: A.eye[0].chan_mask = 0; break;
+    default: return CS_EINVAL;
+    }
+    A.out = stereo;
+    A.out_sf = 3LL * out_h * out_w; A.out_sy = 3LL * out_w; A.out_sx = 3; A.out_sc = 1;
+    A.mask_f32 = mask;
+    A.depth_l = depth_l; A.depth_r = depth_r;
+    return gw_launch(A, stream);
+}
+
+}  // namespace cs

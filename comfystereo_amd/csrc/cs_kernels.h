@@ -41,6 +41,9 @@ struct RowArgs {
     int out_h, out_w;
     int anaglyph;  // 0: eyes go to their slots; 1: R from eye0, GB from eye1; 2: R from eye1, GB from eye0
     int single;    // -1, or the only eye that is written (left-only / only-right)
+    // hybrid_edge scratch (HBM): splat result of every eye, written by k_hybrid_splat
+    uint8_t* hyb_base;  // [n][neyes][h][w][3]
+    uint8_t* hyb_mask;  // [n][neyes][h][w]
 };
 
 

@@ -56,6 +56,8 @@ __host__ __device__ inline size_t lds_tech_bytes(int fill, int w) {
     case CS_FILL_NAIVE: return 3 * align16(4 * (size_t)w);                   // winner, L, R
     case CS_FILL_NAIVE_INTERPOLATING: return align16(4 * (size_t)w) + align16((size_t)w);
     case CS_FILL_INVERSE: return align16(8 * (size_t)w);
+    case CS_FILL_HYBRID_EDGE:  // splat kernel: dest_x, bin offsets, scratch, sorted ids, exp table
+        return align16(4 * (size_t)w) + 3 * align16(2 * ((size_t)w + 4)) + 2048;
     case CS_FILL_POLYLINES_SOFT:
     case CS_FILL_POLYLINES_SHARP: {
         int sharp = fill == CS_FILL_POLYLINES_SHARP;
@@ -524,6 +526,175 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
 }
 
 // ---------------------------------------------------------------------------------------------
+// hybrid_edge (reference :1837-1848)
+//   k_hybrid_splat : enhanced_inverse_mapping_with_mask (:1622-1661).  Every source pixel adds
+//     colour*w and w to destination columns j_c-1, j_c, j_c+1 IN SOURCE-x ORDER with a float64
+//     intermediate per addition.  One lane per DESTINATION column replays exactly the additions that
+//     target it: sources are counting-sorted by j_c (bins -1..w), ranked by x inside each bin, and the
+//     lane merges bins j-1, j, j+1 in ascending x.  Result (uint8 image + touched mask) goes to HBM
+//     scratch because the fill below needs the rows above and below.
+//   technique_hybrid_fill : edge_aware_gap_fill (:1745-1774), 3x3 window over touched neighbours,
+//     guidance = float64 luma of the UNWARPED source (:1740-1742, :1845).  Reads only the splat
+//     result, so it is embarrassingly parallel.
+// ---------------------------------------------------------------------------------------------
+__device__ const unsigned long long d_hyb_exp_tab[256] = {CS_EXP_TAB_VALUES};
+
+__device__ __forceinline__ uint8_t src_u8(const RowArgs& A, int frame, int y, int x, int c) {
+    size_t o = (((size_t)frame * A.h + y) * A.w + x) * 3 + c;
+    if (A.image_u8) return A.image_u8[o];
+    float v = A.image_f32[o] * 255.0f;
+    v = fminf(fmaxf(v, 0.0f), 255.0f);
+    return (uint8_t)(int)v;
+}
+
+__global__ void __launch_bounds__(1024) k_hybrid_splat(RowArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int row = blockIdx.x, frame = blockIdx.y, eyei = blockIdx.z;
+    const int w = A.w, h = A.h;
+    const EyeArgs& E = A.eye[eyei];
+    Lds L = carve(smem, w);
+    char* t = L.tech;
+    float* destx = (float*)t; t += align16(4 * (size_t)w);
+    uint16_t* binoff = (uint16_t*)t; t += align16(2 * ((size_t)w + 4));   // bin b = j_c + 1, b in [0, w+1]
+    uint16_t* scratch = (uint16_t*)t; t += align16(2 * ((size_t)w + 4));
+    uint16_t* sorted = (uint16_t*)t; t += align16(2 * ((size_t)w + 4));
+    unsigned long long* etab = (unsigned long long*)t;
+    const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
+    uint8_t* base = A.hyb_base + ((((size_t)frame * A.neyes + eyei) * h + row) * w) * 3;
+    uint8_t* maskrow = A.hyb_mask + (((size_t)frame * A.neyes + eyei) * h + row) * w;
+    if (!E.enabled) return;  // eye = source image; the fill pass never reads this slot
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_powf_tables);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(L.tabs);
+        for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += nt) dst[i] = src[i];
+        for (int i = tid; i < 256; i += nt) etab[i] = d_hyb_exp_tab[i];
+    }
+    for (int x = tid; x < w; x += nt)
+        for (int c = 0; c < 3; c++) L.img[3 * x + c] = src_u8(A, frame, row, x, c);
+    for (int i = tid; i < (w + 4) / 2 + 1; i += nt) ((unsigned*)binoff)[i] = 0;
+    __syncthreads();
+    const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
+    const float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
+    const bool flat = dmax == dmin;
+    const float range = dmax - dmin;
+    const float* drow = E.depth + ((size_t)frame * h + row) * w;
+    const int nbin = w + 2;
+    for (int x = tid; x < w; x += nt) {
+        float d = drow[x] * scale;
+        float nd = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
+        float off = disparity(nd, A.e32, E.div32, L.tabs);
+        float dx = ((float)x + 0.5f + off) + E.sep32;
+        destx[x] = dx;
+        float fl = floorf(dx);
+        int b = fl < -1.0f ? -1 : (fl > (float)w ? -1 : (int)fl + 1);  // j_c in [-1, w] can still touch a column
+        L.nd[x] = __int_as_float(b);
+        if (b >= 0) atomic_add_u16(binoff, b + 1, 1);
+    }
+    __syncthreads();
+    block_scan_inclusive(binoff, nbin + 1, 0, OpAdd(), L.misc + 8);
+    for (int x = tid; x < w; x += nt) {
+        int b = __float_as_int(L.nd[x]);
+        if (b >= 0) scratch[atomic_add_u16(binoff, b, 1)] = (uint16_t)x;
+    }
+    __syncthreads();
+    const int total = binoff[nbin - 1];
+    for (int k = tid; k < total; k += nt) {
+        int x = scratch[k];
+        int b = __float_as_int(L.nd[x]);
+        int bs = b > 0 ? binoff[b - 1] : 0, be = binoff[b];
+        int r = 0;
+        for (int j = bs; j < be; j++) r += scratch[j] < x ? 1 : 0;
+        sorted[bs + r] = (uint16_t)x;
+    }
+    __syncthreads();
+    for (int j = tid; j < w; j += nt) {
+        // bins of j_c = j-1, j, j+1  ->  bin indices j, j+1, j+2
+        int p0 = j > 0 ? binoff[j - 1] : 0, e0 = binoff[j];
+        int p1 = e0, e1 = binoff[j + 1];
+        int p2 = e1, e2 = binoff[j + 2];
+        float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, ws = 0.0f;
+        bool touched = false;
+        while (p0 < e0 || p1 < e1 || p2 < e2) {
+            int x0 = p0 < e0 ? sorted[p0] : 0x7fffffff;
+            int x1 = p1 < e1 ? sorted[p1] : 0x7fffffff;
+            int x2 = p2 < e2 ? sorted[p2] : 0x7fffffff;
+            int x;
+            if (x0 < x1 && x0 < x2) { x = x0; p0++; }
+            else if (x1 < x2) { x = x1; p1++; }
+            else { x = x2; p2++; }
+            float diff = destx[x] - (float)j;
+            float arg = -(diff * diff) / 2.0f;
+            double wg = csm::exp_exact((double)arg, etab);
+            acc0 = (float)((double)acc0 + (double)L.img[3 * x + 0] * wg);
+            acc1 = (float)((double)acc1 + (double)L.img[3 * x + 1] * wg);
+            acc2 = (float)((double)acc2 + (double)L.img[3 * x + 2] * wg);
+            ws = ws + (float)wg;
+            touched = true;
+        }
+        uint8_t o0 = 0, o1 = 0, o2 = 0;
+        if (ws > 0.0f) {
+            float v0 = acc0 / ws, v1 = acc1 / ws, v2 = acc2 / ws;
+            v0 = v0 < 0.0f ? 0.0f : (v0 > 255.0f ? 255.0f : v0);
+            v1 = v1 < 0.0f ? 0.0f : (v1 > 255.0f ? 255.0f : v1);
+            v2 = v2 < 0.0f ? 0.0f : (v2 > 255.0f ? 255.0f : v2);
+            o0 = (uint8_t)(int)v0; o1 = (uint8_t)(int)v1; o2 = (uint8_t)(int)v2;
+        }
+        base[3 * j + 0] = o0; base[3 * j + 1] = o1; base[3 * j + 2] = o2;
+        maskrow[j] = touched ? 1 : 0;
+    }
+}
+
+__device__ __forceinline__ double hyb_guidance(const RowArgs& A, int frame, int y, int x) {
+    return (0.299 * (double)src_u8(A, frame, y, x, 0) + 0.587 * (double)src_u8(A, frame, y, x, 1)) +
+           0.114 * (double)src_u8(A, frame, y, x, 2);
+}
+
+__device__ void technique_hybrid_fill(const Lds& L, const RowArgs& A, int frame, int row, int eyei) {
+    const int tid = threadIdx.x, nt = blockDim.x, w = A.w, h = A.h;
+    unsigned long long* etab = (unsigned long long*)(L.tech + align16(4 * (size_t)w) + 3 * align16(2 * ((size_t)w + 4)));
+    for (int i = tid; i < 256; i += nt) etab[i] = d_hyb_exp_tab[i];
+    __syncthreads();
+    const uint8_t* base = A.hyb_base + (((size_t)frame * A.neyes + eyei) * h) * (size_t)w * 3;
+    const uint8_t* mask = A.hyb_mask + (((size_t)frame * A.neyes + eyei) * h) * (size_t)w;
+    for (int j = tid; j < w; j += nt) {
+        const uint8_t* b = base + ((size_t)row * w + j) * 3;
+        float r0 = (float)b[0], r1 = (float)b[1], r2 = (float)b[2];
+        if (mask[(size_t)row * w + j] == 0) {
+            float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
+            double wt = 0.0;
+            double g0 = 0.0;
+            bool have_g0 = false;
+            for (int di = -1; di <= 1; di++)
+                for (int dj = -1; dj <= 1; dj++) {
+                    int ni = row + di, nj = j + dj;
+                    if (ni < 0 || ni >= h || nj < 0 || nj >= w) continue;
+                    if (mask[(size_t)ni * w + nj] == 0) continue;
+                    if (!have_g0) { g0 = hyb_guidance(A, frame, row, j); have_g0 = true; }
+                    int dsq = di * di + dj * dj;
+                    double w_s = csm::exp_exact(-(double)dsq / 2.0, etab);
+                    double diff = g0 - hyb_guidance(A, frame, ni, nj);
+                    double w_r = csm::exp_exact(-(diff * diff) / 200.0, etab);
+                    double wg = w_s * w_r;
+                    float wg32 = (float)wg;
+                    const uint8_t* nb = base + ((size_t)ni * w + nj) * 3;
+                    n0 = n0 + (float)nb[0] * wg32;
+                    n1 = n1 + (float)nb[1] * wg32;
+                    n2 = n2 + (float)nb[2] * wg32;
+                    wt += wg;
+                }
+            if (wt > 0.0) {
+                float wt32 = (float)wt;
+                r0 = n0 / wt32; r1 = n1 / wt32; r2 = n2 / wt32;
+            }
+        }
+        r0 = fminf(fmaxf(r0, 0.0f), 255.0f); r1 = fminf(fmaxf(r1, 0.0f), 255.0f); r2 = fminf(fmaxf(r2, 0.0f), 255.0f);
+        L.res[3 * j + 0] = (uint8_t)(int)r0; L.res[3 * j + 1] = (uint8_t)(int)r1; L.res[3 * j + 2] = (uint8_t)(int)r2;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // the row kernel
 // ---------------------------------------------------------------------------------------------
 template <int FILL>
@@ -594,6 +765,7 @@ __global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
             else if (FILL == CS_FILL_INVERSE) technique_inverse(L, w, E, A.e32);
             else if (FILL == CS_FILL_POLYLINES_SOFT) technique_polylines<0>(L, w, E, A.e32, st_rw);
             else if (FILL == CS_FILL_POLYLINES_SHARP) technique_polylines<1>(L, w, E, A.e32, st_rw);
+            else if (FILL == CS_FILL_HYBRID_EDGE) technique_hybrid_fill(L, A, frame, row, e);
         } else {
             for (int i = tid; i < 3 * w; i += nt) L.res[i] = L.img[i];
             __syncthreads();
@@ -672,6 +844,7 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
         CS_LAUNCH(CS_FILL_POLYLINES_SOFT)
         CS_LAUNCH(CS_FILL_POLYLINES_SHARP)
         CS_LAUNCH(CS_FILL_INVERSE)
+        CS_LAUNCH(CS_FILL_HYBRID_EDGE)
     default: return hipErrorInvalidValue;
     }
 #undef CS_LAUNCH
@@ -679,5 +852,27 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
 }
 
 size_t rowwarp_lds_bytes(int fill, int w) { return lds_common_bytes(w) + lds_tech_bytes(fill, w); }
+
+size_t hybrid_workspace_bytes(int n, int h, int w) { return (size_t)n * 2 * h * w * 4 + 256; }
+int hybrid_max_width() {
+    int lo = 0, hi = 1 << 15;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) / 2;
+        if (rowwarp_lds_bytes(CS_FILL_HYBRID_EDGE, mid) <= CS_LDS_BYTES) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream) {
+    RowArgs A = A0;
+    A.hyb_base = (uint8_t*)workspace;
+    A.hyb_mask = A.hyb_base + (size_t)A.n * A.neyes * A.h * A.w * 3;
+    size_t lds = rowwarp_lds_bytes(CS_FILL_HYBRID_EDGE, A.w);
+    int threads = A.w <= 256 ? 256 : (A.w <= 1024 ? 512 : 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_hybrid_splat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return CS_EHIP;
+    hipLaunchKernelGGL(k_hybrid_splat, dim3(A.h, A.n, A.neyes), dim3(threads), lds, stream, A);
+    e = launch_rowwarp(CS_FILL_HYBRID_EDGE, A, threads, stream);
+    return e == hipSuccess ? CS_OK : CS_EHIP;
+}
 
 }  // namespace cs

@@ -116,3 +116,71 @@ def test_node_vs_oracle_blur_on(engine, fill, mode):
     want = node_oracle.generate(img, depth, *args, ui, 20.0, 20.0, True, **kw)
     for gt, wv, name in zip(got, want, ("stereo", "dl", "dr", "mask")):
         assert np.array_equal(gt.cpu().numpy(), wv), (fill, mode, name)
+
+
+def test_blur_goldens(engine, golden_blur):
+    g = golden_blur
+    for case in g.meta["cases"]:
+        cid = case["id"]
+        depth = g[f"{cid}/depth_u8"].astype(np.float32)
+        L, R = engine.directional_blur(cuda(depth), case["strength"], case["edge_threshold"], case["falloff"], case["vert"])
+        assert np.array_equal(L.cpu().numpy().view(np.uint32), g[f"{cid}/L"].view(np.uint32)), cid
+        assert np.array_equal(R.cpu().numpy().view(np.uint32), g[f"{cid}/R"].view(np.uint32)), cid
+
+
+@pytest.mark.parametrize("shape", [(1, 1080, 1920), (2, 300, 517)])
+@pytest.mark.parametrize("prm", [(20, 20, 2.0, 6), (21, 6, 1.0, 0), (7.5, 2.0, 0.5, 15), (3, 40, 3.0, 1)])
+def test_blur_vs_oracle(engine, shape, prm):
+    n, h, w = shape
+    depth = np.stack([np.round(synth.blobs(h, w, seed=j) * 255) for j in range(n)]).astype(np.float32)
+    L, R = engine.directional_blur(cuda(depth), *prm)
+    oL, oR = oracle.blur(depth, *prm)
+    assert np.array_equal(L.cpu().numpy().view(np.uint32), oL.view(np.uint32))
+    assert np.array_equal(R.cpu().numpy().view(np.uint32), oR.view(np.uint32))
+
+
+def test_forward_warp_goldens(engine, golden_warp):
+    g = golden_warp
+    for case in g.meta["cases"]:
+        cid = case["id"]
+        img = g[f"{cid}/img_u8"].astype(np.float32) / np.float32(255.0)
+        d8 = g[f"{cid}/depth_u8"].astype(np.float32)
+        depth = d8 / np.float32(255.0) if case["depth_scale"] == 1.0 else d8
+        warped, mask = engine.forward_warp(cuda(img), cuda(depth), case["divergence_px"], case["separation_px"],
+                                           case["exponent"], case["convergence"])
+        warped, mask = warped.cpu().numpy(), mask.cpu().numpy()
+        want_mask = np.unpackbits(g[f"{cid}/mask"])[: mask.size].reshape(mask.shape).astype(bool)
+        err = np.abs(warped - g[f"{cid}/warped"])
+        if case["exponent"] in (2.0, 1.0, 0.5):
+            assert np.array_equal(mask, want_mask), cid
+            assert err.max() <= GPU_WARP_COLOUR_TOL, (cid, err.max())
+        else:
+            assert (mask != want_mask).mean() <= 1e-3 and np.quantile(err, 0.999) <= 1e-3, cid
+
+
+@pytest.mark.parametrize("kind", ["blobs", "stepped", "noisy_ramp", "random8"])
+def test_forward_warp_vs_oracle(engine, kind):
+    b, h, w = 2, 96, 1280
+    img = synth.image_f32(b, h, w, seed=6).transpose(0, 3, 1, 2).copy()
+    for (dpx, spx, e, conv, scale) in [(44.8, 0.0, 2.0, 0.5, 255.0), (-44.8, 3.0, 1.0, 0.3, 1.0), (-20.0, 0.0, 0.5, 0.8, 255.0)]:
+        depth = np.stack([synth.DEPTHS[kind](h, w, **({"cx": w / 2 + 40 * j} if kind == "stepped" else {"seed": j}))
+                          for j in range(b)]) * np.float32(scale)
+        warped, mask = engine.forward_warp(cuda(img), cuda(depth), dpx, spx, e, conv)
+        ow, om = oracle.forward_warp_gpu(img, depth, dpx, spx, e, conv)
+        assert np.array_equal(mask.cpu().numpy(), om), (kind, dpx)
+        # same arithmetic as the oracle (which mirrors torch within GPU_WARP_COLOUR_TOL): tight tolerance
+        assert np.abs(warped.cpu().numpy() - ow).max() <= 2e-6, (kind, dpx, np.abs(warped.cpu().numpy() - ow).max())
+
+
+def test_node_gpu_warp_vs_oracle_blur_on(engine):
+    n, h, w = 3, 256, 320
+    img = synth.image_f32(n, h, w, seed=5)
+    depth = synth.depth_batch("blobs", n, h, w, channels=3)
+    for mode in ("left-right", "red-cyan-anaglyph", "top-bottom"):
+        args = (4.5, 0.3, mode, 0.2, 0.5, 2.0)
+        kw = dict(depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=2)
+        got = engine.generate(cuda(img), cuda(depth), *args, "gpu_warp", 20.0, 20.0, True, **kw)
+        want = node_oracle.generate(img, depth, *args, "GPU Warp (Fast)", 20.0, 20.0, True, **kw)
+        assert np.abs(got[0].cpu().numpy() - want[0]).max() <= 2e-6, mode
+        for k in (1, 2, 3):
+            assert np.array_equal(got[k].cpu().numpy(), want[k]), (mode, k)

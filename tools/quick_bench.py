@@ -1,0 +1,41 @@
+"""Ad-hoc timing of the fused batch path (development aid; bench.py is the contract)."""
+import argparse
+import sys, os
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import synth
+from comfystereo_amd import engine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=4)
+ap.add_argument("--h", type=int, default=2160)
+ap.add_argument("--w", type=int, default=3840)
+ap.add_argument("--fill", default="polylines_soft")
+ap.add_argument("--mode", default="left-right")
+ap.add_argument("--kind", default="stepped")
+ap.add_argument("--div", type=float, default=8.0)
+ap.add_argument("--blur", type=int, default=0)
+ap.add_argument("--iters", type=int, default=5)
+a = ap.parse_args()
+
+dev = torch.device("cuda:0")
+img = torch.from_numpy(synth.image_f32(1, a.h, a.w, seed=1)).to(dev).expand(a.n, -1, -1, -1).contiguous()
+depth = torch.from_numpy(synth.depth_batch(a.kind, a.n, a.h, a.w, channels=3)).to(dev)
+p = engine.make_params(a.n, a.h, a.w, a.h, a.w, 3, a.fill, a.mode, a.div, 0.0, 0.0, 0.5, 2.0, bool(a.blur), 20.0, 20.0, 2.0, 6, 12)
+plan = engine.Plan(p, dev)
+plan.run(img, depth); torch.cuda.synchronize()
+st = plan.stats()
+print("fallback rows per frame:", st[:, 10].tolist(), "error flags:", st[:, 9].tolist())
+t0 = time.perf_counter()
+for _ in range(a.iters):
+    plan.run(img, depth)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.iters
+hw = a.h * a.w
+print(f"{a.fill} {a.mode} {a.kind} n={a.n} {a.w}x{a.h} blur={a.blur}: {dt*1e3:.2f} ms/batch, {a.n/dt:.1f} fps, "
+      f"{a.n*80*hw/dt/1e9:.1f} GB/s algorithmic")
