@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline metric of BASELINE.json on MI355X.
+
+  metric : SBS frames/s (+ achieved HBM GB/s) for 4K (3840x2160) forward warp + polylines_soft hole fill,
+           divergence 8.0, left-right side-by-side, stepped synthetic depth, widget defaults otherwise
+           (direction-aware depth blur ON: strength 20, threshold 20, falloff 2.0, vert 6).
+  step   : one pass of the whole hot path (cs_generate: gray depth + min/max, depth blur, warp + fill +
+           SBS/mask/depth-map assembly) over the batch of N_FRAMES frames, inputs resident in HBM;
+           with --gpus N > 1 the batch is sharded by frame (strong scaling: total work fixed) and the step
+           ends with the RCCL all-gather that reassembles the stereoscope tensor on every rank.
+
+  python bench.py [--gpus N --steps K --warmup W] [--frames F] [--no-blur] [--no-cpu-baseline]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     : dominant kernel (k_rowwarp<polylines_soft>) -- algorithmic bytes per launch / its mean
+                 duration measured with HIP events on the launch stream inside the timed region
+  cpu_baseline : the CPU oracle (C port of the reference's D32 arithmetic, 1 thread) on a bounded sample
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+H, W = 2160, 3840
+B_ALG_PER_PIXEL = 80  # float32 node boundary, SBS, CPU-technique mask
+HBM_PEAK_GBS = 8000.0
+
+
+def make_inputs(torch, frames, first, device):
+    """Synthetic batch on the device: 8-bit-origin random RGB; stepped radial depth with a moving centre."""
+    g = torch.Generator(device=device)
+    imgs, deps = [], []
+    yy, xx = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float64),
+                            torch.arange(W, device=device, dtype=torch.float64), indexing="ij")
+    for i in range(first, first + frames):
+        g.manual_seed(1000 + i)
+        imgs.append(torch.randint(0, 256, (H, W, 3), generator=g, device=device, dtype=torch.int32).to(torch.float32) / 255.0)
+        cx, cy = W / 2 + (17 * i) % (W // 4), H / 2 + (11 * i) % (H // 4)
+        r = torch.sqrt((yy - cy) ** 2 + (xx - cx) ** 2)
+        d = torch.floor((1.0 - r / r.max()) * 6) / 6
+        deps.append(d.to(torch.float32)[..., None].expand(H, W, 3))
+    return torch.stack(imgs).contiguous(), torch.stack(deps).contiguous()
+
+
+def cpu_baseline(frames_sample, blur):
+    """The oracle (test infrastructure) timed as the reported CPU baseline: full node path, 1 thread."""
+    import numpy as np
+    import synth
+    from oracle import node_oracle
+    img = synth.image_f32(frames_sample, H, W, seed=1)
+    depth = synth.depth_batch("stepped", frames_sample, H, W, channels=3)
+    t0 = time.perf_counter()
+    node_oracle.generate(img, depth, 8.0, 0.0, "left-right", 0.0, 0.5, 2.0, "Fill - Polylines Soft", 20.0, 20.0, blur,
+                         depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+    dt = time.perf_counter() - t0
+    return {"value": frames_sample / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{frames_sample} frame(s) of the same workload (4K, both eyes, full node path) through the C oracle, "
+                      f"{dt:.1f} s on {os.cpu_count()} visible host cores (1 used)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=64, help="total frames in the batch (sharded over the GPUs)")
+    ap.add_argument("--no-blur", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from comfystereo_amd import _native, engine, sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    blur = not a.no_blur
+
+    bounds = sharding.shard_bounds(a.frames, world)
+    b0, b1 = bounds[rank], bounds[rank + 1]
+    nloc = b1 - b0
+    image, depth = make_inputs(torch, nloc, b0, device)
+    p = engine.make_params(nloc, H, W, H, W, 3, "polylines_soft", "left-right", 8.0, 0.0, 0.0, 0.5, 2.0, blur, 20.0, 20.0,
+                           2.0, 6, 12)
+    plan = engine.Plan(p, device)
+    gathered = torch.empty((a.frames, H, 2 * W, 3), dtype=torch.float32, device=device) if world > 1 else None
+
+    def step():
+        stereo, _, _, _ = plan.run(image, depth)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, stereo)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    L = _native.lib()
+    for _ in range(a.warmup):
+        step()
+    fence()
+    L.cs_profile(1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    tot_ms, launches = ctypes.c_double(), ctypes.c_int()
+    _native.check(L.cs_profile_read(ctypes.byref(tot_ms), ctypes.byref(launches)))
+    L.cs_profile(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fallback_rows = int(plan.stats()[:, 10].sum())
+    err_flags = int(plan.stats()[:, 9].sum())
+
+    if rank == 0:
+        fps = a.frames * a.steps / dt
+        kern_ms = tot_ms.value / max(launches.value, 1)
+        alg_bytes = nloc * B_ALG_PER_PIXEL * H * W  # per launch of the dominant kernel on this rank
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = f"polylines_soft_4k_blur{int(blur)}"
+                if key in tj:
+                    traffic = tj[key]["bytes_per_frame"] * nloc
+            except Exception:  # noqa: BLE001
+                traffic = None
+        line = {
+            "metric": "SBS frames/sec, 4K warp+polylines_soft", "value": fps, "unit": "frames/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "4K 3840x2160, polylines_soft, left-right SBS, divergence 8.0, stepped depth, "
+                                   f"depth blur {'on' if blur else 'off'} (widget defaults)",
+                       "frames_total": a.frames, "frames_per_gpu": nloc, "sharding": "by frame, contiguous blocks",
+                       "collective": "all_gather(stereoscope) over RCCL" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_rowwarp<polylines_soft>", "kernel_ms": kern_ms, "launches": launches.value,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "pipeline_achieved": a.frames * a.steps * B_ALG_PER_PIXEL * H * W / dt / 1e9 / world},
+            "diagnostics": {"polylines_rows_replayed_sequentially": fallback_rows, "kernel_error_flags": err_flags},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(a.cpu_frames, blur)
+        elif not a.no_cpu_baseline:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,7 +23,7 @@ MODE = {
 EXPORTS = [
     "cs_version", "cs_last_error", "cs_max_width", "cs_output_shape", "cs_workspace_bytes", "cs_generate",
     "cs_asd_workspace_bytes", "cs_apply_stereo_divergence", "cs_blur_workspace_bytes", "cs_directional_blur",
-    "cs_warp_workspace_bytes", "cs_forward_warp", "cs_test_powf", "cs_test_exp",
+    "cs_warp_workspace_bytes", "cs_forward_warp", "cs_profile", "cs_profile_read", "cs_test_powf", "cs_test_exp",
 ]
 
 
@@ -33,7 +33,7 @@ class Params(ctypes.Structure):
         ("n", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32),
         ("depth_h", ctypes.c_int32), ("depth_w", ctypes.c_int32), ("depth_c", ctypes.c_int32),
         ("fill", ctypes.c_int32), ("mode", ctypes.c_int32), ("batch_size", ctypes.c_int32),
-        ("depth_map_blur", ctypes.c_int32), ("depth_blur_vert_smooth", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("depth_map_blur", ctypes.c_int32), ("depth_blur_vert_smooth", ctypes.c_int32), ("flags", ctypes.c_int32),
         ("divergence", ctypes.c_double), ("separation", ctypes.c_double), ("stereo_balance", ctypes.c_double),
         ("convergence_point", ctypes.c_double), ("stereo_offset_exponent", ctypes.c_double),
         ("depth_blur_strength", ctypes.c_double), ("depth_blur_edge_threshold", ctypes.c_double),
@@ -87,6 +87,10 @@ def lib():
     L.cs_warp_workspace_bytes.argtypes = [c_int, c_int, c_int]
     L.cs_forward_warp.restype = c_int
     L.cs_forward_warp.argtypes = [vp, vp, c_int, c_int, c_int, c_double, c_double, c_double, c_double, vp, vp, vp, c_size, vp]
+    L.cs_profile.restype = c_int
+    L.cs_profile.argtypes = [c_int]
+    L.cs_profile_read.restype = c_int
+    L.cs_profile_read.argtypes = [ctypes.POINTER(c_double), ip]
     L.cs_test_powf.restype = c_int
     L.cs_test_powf.argtypes = [vp, ctypes.c_float, vp, c_size, vp]
     L.cs_test_exp.restype = c_int

@@ -154,6 +154,26 @@ __global__ void k_test_exp(const double* x, double* out, size_t n) {
         out[i] = csm::exp_exact(x[i], d_exp_tab);
 }
 
+// ---- measurement hook (cs_profile / cs_profile_read) ------------------------------------------
+static const int PROF_MAX = 4096;
+static bool g_prof_on = false;
+static hipEvent_t g_prof_ev[2 * PROF_MAX];
+static int g_prof_made = 0, g_prof_used = 0;
+struct ProfScope {
+    hipStream_t s; int slot;
+    explicit ProfScope(hipStream_t stream) : s(stream), slot(-1) {
+        if (!g_prof_on || g_prof_used >= PROF_MAX) return;
+        while (g_prof_made <= g_prof_used) {
+            if (hipEventCreate(&g_prof_ev[2 * g_prof_made]) != hipSuccess) return;
+            if (hipEventCreate(&g_prof_ev[2 * g_prof_made + 1]) != hipSuccess) return;
+            g_prof_made++;
+        }
+        slot = g_prof_used++;
+        (void)hipEventRecord(g_prof_ev[2 * slot], s);
+    }
+    ~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof_ev[2 * slot + 1], s); }
+};
+
 static int grid_for(size_t items, int threads) {
     size_t b = (items + threads - 1) / threads;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -292,6 +312,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     const double left_div = p->divergence * (1 + p->stereo_balance);
     const double right_div = p->divergence * (1 - p->stereo_balance);
 
+    ProfScope prof(stream);
     if (gpu_warp) {
         rc = launch_gpuwarp_node(p, image, dL, dR, scale_from_stats, stats, stereo, depth_l, depth_r, mask, out_h, out_w,
                                  ws + W.extra, stream);
@@ -424,6 +445,28 @@ int cs_forward_warp(const float* image, const float* depth, int n, int h, int w,
     if (rc) return fail(rc, "gpu_warp launch failed");
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CS_OK : fail_hip(e, "cs_forward_warp");
+}
+
+int cs_profile(int enable) {
+    g_prof_on = enable != 0;
+    if (enable) g_prof_used = 0;
+    return CS_OK;
+}
+
+int cs_profile_read(double* total_ms, int* launches) {
+    double tot = 0.0;
+    for (int i = 0; i < g_prof_used; i++) {
+        hipError_t e = hipEventSynchronize(g_prof_ev[2 * i + 1]);
+        if (e != hipSuccess) return fail_hip(e, "cs_profile_read");
+        float ms = 0.0f;
+        e = hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]);
+        if (e != hipSuccess) return fail_hip(e, "cs_profile_read");
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = g_prof_used;
+    g_prof_used = 0;
+    return CS_OK;
 }
 
 int cs_test_powf(const float* x, float y, float* out, size_t count, void* stream) {

@@ -44,6 +44,7 @@ struct GwArgs {
     uint8_t* mask_u8;  // plain: [n][h][w]
     float* mask_f32;   // node:  [n][h][w] (left | right)
     float* depth_l; float* depth_r;  // node: [n][h][w][3]
+    int noclamp;
 };
 
 __constant__ csm::PowfTables c_gw_powf_tables = CS_POWF_TABLES_INIT;
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
             for (int x = tid; x < w; x += nt) {
                 float v = drow[x] * scale;
                 if (div255) v = v / 255.0f;
-                v = fminf(fmaxf(v, 0.0f), 1.0f);
+                if (!A.noclamp) v = fminf(fmaxf(v, 0.0f), 1.0f);
                 dst[3 * x] = v; dst[3 * x + 1] = v; dst[3 * x + 2] = v;
             }
         }
@@ -336,6 +337,7 @@ int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL,
     A.out_sf = 3LL * out_h * out_w; A.out_sy = 3LL * out_w; A.out_sx = 3; A.out_sc = 1;
     A.mask_f32 = mask;
     A.depth_l = depth_l; A.depth_r = depth_r;
+    A.noclamp = p->flags & 1;
     return gw_launch(A, stream);
 }
 

@@ -1,0 +1,155 @@
+"""Drop-in for the two module functions GenerateStereo.py calls in the reference
+(`from . import stereoimage_generation as sig`, reference GenerateStereo.py:25,151,222):
+
+    create_stereoimages      reference stereoimage_generation.py:1422-1574
+    create_stereoimages_gpu  reference stereoimage_generation.py:1005-1128
+
+Same names, argument order, defaults, return types and error behaviour; the arithmetic runs in the
+HIP kernels behind the C ABI (there is no CPU fallback: without a GPU these functions raise).
+Extras kept for callers of the reference's building blocks: apply_stereo_divergence (:1576-1620),
+directional_motion_blur_gpu (:1171-1251), forward_warp_gpu (:277-450).
+"""
+import numpy as np
+import torch
+from PIL import Image
+
+from . import engine
+
+_CPU_FILLS = ('none', 'naive', 'naive_interpolating', 'polylines_soft', 'polylines_sharp', 'inverse', 'hybrid_edge')
+_UNPORTED = ('none_post', 'inverse_post', 'hybrid_edge_plus')  # UI-unreachable in the reference
+_MODES = ('left-right', 'right-left', 'top-bottom', 'bottom-top', 'red-cyan-anaglyph', 'left-only', 'only-right',
+          'cyan-red-reverseanaglyph')
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("comfystereo_amd needs an MI355X (PyTorch-ROCm `cuda` device); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_u8(x):
+    """float32 outputs of the CPU-technique path are k/255 exactly -> recover k."""
+    return torch.round(x * 255.0).to(torch.uint8)
+
+
+def create_stereoimages(original_image, depthmap, divergence, separation=0.0, modes=None,
+                        stereo_balance=0.0, stereo_offset_exponent=1.0, fill_technique='polylines_sharp',
+                        depth_blur_strength=0.0, depth_blur_edge_threshold=6.0,
+                        direction_aware_depth_blur=False, return_modified_depth=True, convergence_point=0.5,
+                        depth_blur_falloff=1.0, depth_blur_vert_smooth=0):
+    """One frame, CPU-technique semantics: returns PIL images like the reference.
+
+    original_image: torch [3,H,W] (or [H,W,3]) float 0..1;  depthmap: torch [H,W] (or [1,H,W]).
+    -> (list[PIL RGB], PIL L left, PIL L right) | (list, PIL L) | list       (reference :1564-1574)
+    """
+    if modes is None:
+        modes = ['left-right']
+    if not isinstance(modes, list):
+        modes = [modes]
+    if len(modes) == 0:
+        return []
+    if not (isinstance(depthmap, torch.Tensor) and isinstance(original_image, torch.Tensor)):
+        raise NotImplementedError("numpy/PIL inputs take the reference's scipy blur path (reflect borders), which "
+                                  "the node never uses; pass torch tensors")
+    if fill_technique in _UNPORTED:
+        raise NotImplementedError(f"fill_technique '{fill_technique}' is UI-unreachable in the reference and not ported yet")
+    for m in modes:
+        if m not in _MODES:
+            raise Exception('Unknown mode')
+    dev = _device()
+    depth = depthmap.to(dev, torch.float32)
+    if depth.dim() == 3:
+        depth = depth.squeeze()
+    img = original_image.to(dev, torch.float32)
+    if img.dim() == 3 and img.shape[0] == 3:
+        img = img.permute(1, 2, 0)
+    h, w = depth.shape
+    assert tuple(img.shape[:2]) == (h, w), 'Depthmap and the image must have the same size'
+    img = img.contiguous()[None]
+    dep = depth.contiguous()[None, :, :, None]
+    # an unknown technique falls through the reference's dispatch and returns the source image for both eyes (:1620)
+    fill = fill_technique if fill_technique in _CPU_FILLS else 'none'
+    div = divergence if fill_technique in _CPU_FILLS else 0.0
+    results, left8, right8 = [], None, None
+    for m in modes:
+        stereo, dl, dr, _ = engine.generate(img, dep, div, separation, m, stereo_balance, convergence_point,
+                                            stereo_offset_exponent, fill, depth_blur_edge_threshold, depth_blur_strength,
+                                            direction_aware_depth_blur, depth_blur_falloff, depth_blur_vert_smooth, 1)
+        results.append(_to_u8(stereo[0]).cpu().numpy())
+        left8, right8 = _to_u8(dl[0, :, :, 0]).cpu().numpy(), _to_u8(dr[0, :, :, 0]).cpu().numpy()
+    stereo_images = [Image.fromarray(r) for r in results]
+    if return_modified_depth:
+        if direction_aware_depth_blur:
+            return stereo_images, Image.fromarray(left8), Image.fromarray(right8)
+        return stereo_images, Image.fromarray(left8)
+    return stereo_images
+
+
+def create_stereoimages_gpu(image_tensor, depth_tensor, divergence, separation=0.0, modes=None,
+                            stereo_balance=0.0, stereo_offset_exponent=1.0, convergence_point=0.5,
+                            depth_blur_strength=0.0, depth_blur_edge_threshold=6.0,
+                            direction_aware_depth_blur=False, depth_blur_falloff=1.0,
+                            depth_blur_vert_smooth=0):
+    """Batched 'gpu_warp' driver: image [B,C,H,W] 0..1, depth [B,H,W] ->
+    (list[Tensor[B,C,H',W']], left_depth [B,H,W], right_depth [B,H,W], BoolTensor[B,H,W]) on the device."""
+    if modes is None:
+        modes = ['left-right']
+    if not isinstance(modes, list):
+        modes = [modes]
+    if len(modes) == 0:
+        return [], None, None, None
+    for m in modes:
+        if m not in _MODES:
+            raise ValueError(f'Unknown mode: {m}')
+    dev = _device()
+    img = image_tensor.to(dev, torch.float32).permute(0, 2, 3, 1).contiguous()
+    dep = depth_tensor.to(dev, torch.float32).contiguous()[..., None]
+    b, h, w, _ = img.shape
+    results, lo, ro, mask = [], None, None, None
+    for m in modes:
+        p = engine.make_params(b, h, w, h, w, 1, 'gpu_warp', m, divergence, separation, stereo_balance, convergence_point,
+                               stereo_offset_exponent, direction_aware_depth_blur, depth_blur_strength,
+                               depth_blur_edge_threshold, depth_blur_falloff, depth_blur_vert_smooth, b)
+        p.flags = 1  # module-level depth outputs are not clamped (the node clamps them afterwards)
+        stereo, dl, dr, mk = engine.Plan(p, dev).run(img, dep)
+        results.append(stereo.permute(0, 3, 1, 2))
+        lo, ro, mask = dl[..., 0], dr[..., 0], mk > 0.5
+    return results, lo, ro, mask
+
+
+def apply_stereo_divergence(original_image, depth, divergence, separation, stereo_offset_exponent, fill_technique,
+                            convergence_point=0.5):
+    """uint8 [H,W,3] image + float32 [H,W] depth (numpy or torch) -> uint8 [H,W,3] numpy (reference :1576-1620)."""
+    dev = _device()
+    img = torch.as_tensor(np.asarray(original_image) if not isinstance(original_image, torch.Tensor) else original_image)
+    dep = torch.as_tensor(np.asarray(depth) if not isinstance(depth, torch.Tensor) else depth)
+    assert tuple(img.shape[:2]) == tuple(dep.shape), 'Depthmap and the image must have the same size'
+    if fill_technique in _UNPORTED:
+        raise NotImplementedError(f"fill_technique '{fill_technique}' is not ported yet")
+    if fill_technique not in _CPU_FILLS:
+        return img.cpu().numpy()  # reference fallback (:1620)
+    out = engine.apply_stereo_divergence(img.to(dev, torch.uint8), dep.to(dev, torch.float32), divergence, separation,
+                                         stereo_offset_exponent, fill_technique, convergence_point)
+    return out.cpu().numpy()
+
+
+def directional_motion_blur_gpu(depth_tensor, blur_strength, edge_threshold, blur_mask_width=5,
+                                falloff_exponent=1.0, vert_smooth_px=0):
+    """[H,W] or [B,H,W] depth on the 0..255 scale -> (left, right) device tensors (reference :1171-1251).
+    The reference always passes blur_mask_width = blur_strength (:1051-1054, :1479-1482); so does the kernel."""
+    if blur_strength <= 0:
+        return depth_tensor, depth_tensor
+    if float(blur_mask_width) != float(blur_strength):
+        raise NotImplementedError("blur_mask_width != blur_strength is never used by the reference's callers")
+    return engine.directional_blur(depth_tensor.to(_device(), torch.float32), blur_strength, edge_threshold,
+                                   falloff_exponent, vert_smooth_px)
+
+
+def forward_warp_gpu(image_tensor, depth_tensor, divergence_px, separation_px, stereo_offset_exponent,
+                     convergence_point=0.5, gradient_threshold=1.5, max_stretch=8):
+    """reference :277-450 -> (warped [B,C,H,W], gap_mask bool [B,H,W])."""
+    if gradient_threshold != 1.5 or max_stretch != 8:
+        raise NotImplementedError("the kernel implements the reference's only call-site values (1.5, 8)")
+    dev = _device()
+    return engine.forward_warp(image_tensor.to(dev, torch.float32), depth_tensor.to(dev, torch.float32), divergence_px,
+                               separation_px, stereo_offset_exponent, convergence_point)

@@ -78,7 +78,8 @@ typedef struct cs_params {
                                    global over a sub-batch, stereoimage_generation.py:1045, :315)   */
     int32_t depth_map_blur;     /* bool: direction-aware depth blur on/off                          */
     int32_t depth_blur_vert_smooth;
-    int32_t reserved;
+    int32_t flags;              /* bit 0: gpu_warp depth outputs are NOT clamped to 0..1 (module-level
+                                   create_stereoimages_gpu returns them unclamped, :1125-1126)      */
     double divergence, separation, stereo_balance, convergence_point, stereo_offset_exponent;
     double depth_blur_strength, depth_blur_edge_threshold, depth_blur_falloff;
 } cs_params;
@@ -139,6 +140,15 @@ CS_API size_t cs_warp_workspace_bytes(int n, int h, int w);
 CS_API int cs_forward_warp(const float *image, const float *depth, int n, int h, int w, double divergence_px,
                     double separation_px, double stereo_offset_exponent, double convergence_point, float *warped,
                     uint8_t *gap_mask, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Measurement hook for bench.py: while enabled, cs_generate brackets the launch of its dominant
+ * kernel (the row warp + fill kernel of the selected technique) with HIP events on the caller's
+ * stream.  cs_profile_read waits for the recorded events, returns the summed kernel time in
+ * milliseconds and the number of launches, and clears the record.
+ */
+CS_API int cs_profile(int enable);
+CS_API int cs_profile_read(double *total_ms, int *launches);
 
 /* Device self-tests of the libm-exact scalar routines (used by the parity tests):
  * out[i] = powf(x[i], y) / out[i] = exp(x[i]) evaluated by the same device code the kernels use. */
