@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--frames", type=int, default=64, help="total frames in the batch (sharded over the GPUs)")
     ap.add_argument("--no-blur", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=10)
     a = ap.parse_args()
 
     import torch
