@@ -2,6 +2,7 @@
 // around the row kernels: depth grayscale + per-frame min/max, bilinear depth resize, per-frame
 // decisions (0..255 scaling), device self-tests of the libm-exact math.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "cs_common.h"
@@ -339,6 +340,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     A.stereo = stereo; A.mask = mask; A.depth_l = depth_l; A.depth_r = depth_r;
     A.out_h = out_h; A.out_w = out_w;
     A.single = -1;
+    { const char* dbg = getenv("CS_DBG"); A.dbg = dbg ? atoi(dbg) : 0; }
     switch (p->mode) {
     case CS_MODE_LEFT_RIGHT: A.eye[1].xoff = w; break;
     case CS_MODE_RIGHT_LEFT: A.eye[0].xoff = w; break;

@@ -101,42 +101,63 @@ __global__ void __launch_bounds__(1024) k_blur_weights(BlurArgs A) {
     }
 }
 
-__global__ void __launch_bounds__(1024) k_blur_apply(BlurArgs A) {
+// pass B, tiled: a workgroup of 256 threads produces a TW x TR tile of both outputs.  The weight
+// rows y0-v .. y0+TR-1+v and the depth columns x0-pad .. x0+TW-1+(bs-1-pad) of the tile are staged in
+// LDS once (zero outside the frame == the reference's zero padding; fmaf(k, 0, acc) == acc exactly),
+// so every weight is fetched from HBM/L2 (TR+2v)/TR times instead of 2v+1 times.
+#define BLUR_TW 64
+#define BLUR_TR 32
+__global__ void __launch_bounds__(256) k_blur_apply(BlurArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int y = blockIdx.x, frame = blockIdx.y, w = A.w, h = A.h;
-    float* row = (float*)smem;  // depth row, scaled
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * BLUR_TW, y0 = blockIdx.y * BLUR_TR, frame = blockIdx.z;
+    const int w = A.w, h = A.h, v = A.vert, bs = A.bs, pad = A.bs / 2;
+    const int wrows = BLUR_TR + 2 * v, dcols = BLUR_TW + bs - 1;
+    float* wlt = (float*)smem;                    // [wrows][TW]
+    float* wrt = wlt + wrows * BLUR_TW;           // [wrows][TW]
+    float* dt = wrt + wrows * BLUR_TW;            // [TR][dcols]
     const float scale = (A.stats && A.stats[frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
-    const float* d = A.depth + ((size_t)frame * h + y) * w;
-    for (int x = tid; x < w; x += nt) row[x] = d[x] * scale;
-    __syncthreads();
-    const float kb = 1.0f / (float)A.bs;
-    const int pad = A.bs / 2;
-    const float kv = 1.0f / (float)(2 * A.vert + 1);
     const float* wl = A.wl + (size_t)frame * h * w;
     const float* wr = A.wr + (size_t)frame * h * w;
+    const float* d = A.depth + (size_t)frame * h * w;
+    for (int i = tid; i < wrows * BLUR_TW; i += 256) {
+        int r = i / BLUR_TW, c = i - r * BLUR_TW;
+        int yy = y0 - v + r, xx = x0 + c;
+        bool ok = yy >= 0 && yy < h && xx < w;
+        wlt[i] = ok ? wl[(size_t)yy * w + xx] : 0.0f;
+        wrt[i] = ok ? wr[(size_t)yy * w + xx] : 0.0f;
+    }
+    for (int i = tid; i < BLUR_TR * dcols; i += 256) {
+        int r = i / dcols, c = i - r * dcols;
+        int yy = y0 + r, xx = x0 - pad + c;
+        bool ok = yy < h && xx >= 0 && xx < w;
+        dt[i] = ok ? d[(size_t)yy * w + xx] * scale : 0.0f;
+    }
+    __syncthreads();
+    const int tx = tid & (BLUR_TW - 1), ty = tid >> 6;
+    const float kb = 1.0f / (float)bs, kv = 1.0f / (float)(2 * v + 1);
     float lmin = INFINITY, lmax = -INFINITY, rmin = INFINITY, rmax = -INFINITY;
-    for (int x = tid; x < w; x += nt) {
+    const int x = x0 + tx;
+    for (int rr = 0; rr < BLUR_TR / 4; rr++) {
+        const int r = ty * (BLUR_TR / 4) + rr, y = y0 + r;
+        if (y >= h || x >= w) continue;
         float a, b;
-        if (A.vert > 0) {
+        if (v > 0) {
             a = 0.0f; b = 0.0f;
-            for (int ky = 0; ky < 2 * A.vert + 1; ky++) {
-                int yy = y + ky - A.vert;
-                if (yy < 0 || yy >= h) continue;  // zero padding: fmaf(kv, 0, acc) == acc
-                a = fmaf(kv, wl[(size_t)yy * w + x], a);
-                b = fmaf(kv, wr[(size_t)yy * w + x], b);
+            const float* pl = wlt + r * BLUR_TW + tx;
+            const float* pr = wrt + r * BLUR_TW + tx;
+            for (int ky = 0; ky < 2 * v + 1; ky++) {
+                a = fmaf(kv, pl[ky * BLUR_TW], a);
+                b = fmaf(kv, pr[ky * BLUR_TW], b);
             }
         } else {
-            a = wl[(size_t)y * w + x];
-            b = wr[(size_t)y * w + x];
+            a = wlt[r * BLUR_TW + tx];
+            b = wrt[r * BLUR_TW + tx];
         }
+        const float* pd = dt + r * dcols + tx;
         float acc = 0.0f;
-        for (int k = 0; k < A.bs; k++) {
-            int xx = x + k - pad;
-            if (xx < 0 || xx >= w) continue;
-            acc = fmaf(kb, row[xx], acc);
-        }
-        float dv = row[x];
+        for (int k = 0; k < bs; k++) acc = fmaf(kb, pd[k], acc);
+        float dv = pd[pad];
         float ol = a * acc + (1.0f - a) * dv;
         float orr = b * acc + (1.0f - b) * dv;
         A.out_l[((size_t)frame * h + y) * w + x] = ol;
@@ -171,14 +192,14 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
     A.wl = wl; A.wr = wr; A.out_l = out_l; A.out_r = out_r;
     int threads = w <= 256 ? 256 : (w <= 1024 ? 512 : 1024);
     size_t ldsA = 4 * (size_t)w * 4 + 32 * 4 + sizeof(csm::PowfTables) + 64;
-    size_t ldsB = (size_t)w * 4;
-    if (ldsA > CS_LDS_BYTES) return CS_ELIMIT;
+    size_t ldsB = ((size_t)(BLUR_TR + 2 * A.vert) * BLUR_TW * 2 + (size_t)BLUR_TR * (BLUR_TW + A.bs - 1)) * 4;
+    if (ldsA > CS_LDS_BYTES || ldsB > CS_LDS_BYTES) return CS_ELIMIT;
     hipError_t e = hipFuncSetAttribute((const void*)k_blur_weights, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA);
     if (e != hipSuccess) return CS_EHIP;
     e = hipFuncSetAttribute((const void*)k_blur_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB);
     if (e != hipSuccess) return CS_EHIP;
     hipLaunchKernelGGL(k_blur_weights, dim3(h, n), dim3(threads), ldsA, stream, A);
-    hipLaunchKernelGGL(k_blur_apply, dim3(h, n), dim3(threads), ldsB, stream, A);
+    hipLaunchKernelGGL(k_blur_apply, dim3((w + BLUR_TW - 1) / BLUR_TW, (h + BLUR_TR - 1) / BLUR_TR, n), dim3(256), ldsB, stream, A);
     return CS_OK;
 }
 

@@ -44,6 +44,7 @@ struct RowArgs {
     // hybrid_edge scratch (HBM): splat result of every eye, written by k_hybrid_splat
     uint8_t* hyb_base;  // [n][neyes][h][w][3]
     uint8_t* hyb_mask;  // [n][neyes][h][w]
+    int dbg;            // development only (env CS_DBG): stop the polylines technique after phase `dbg`
 };
 
 

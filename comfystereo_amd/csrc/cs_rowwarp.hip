@@ -45,8 +45,12 @@ struct Lds {
 };
 
 
-__host__ __device__ inline size_t lds_common_bytes(int w) {
-    return 1024 + align16(sizeof(csm::PowfTables)) + 128 + 2 * align16(3 * (size_t)w) + align16(2 * (size_t)w) +
+__host__ __device__ constexpr bool fill_uses_res(int fill) {
+    return fill != CS_FILL_POLYLINES_SOFT && fill != CS_FILL_POLYLINES_SHARP;  // polylines emits pixels directly
+}
+__host__ __device__ inline size_t lds_common_bytes(int fill, int w, int anaglyph) {
+    return 1024 + align16(sizeof(csm::PowfTables)) + 128 + align16(3 * (size_t)w) +
+           (fill_uses_res(fill) ? align16(3 * (size_t)w) : 0) + (anaglyph ? align16(2 * (size_t)w) : 0) +
            align16(4 * (size_t)w);
 }
 __host__ __device__ inline int poly_cap(int w, int sharp) { return (sharp ? 4 : 3) * w + 64; }
@@ -62,22 +66,22 @@ __host__ __device__ inline size_t lds_tech_bytes(int fill, int w) {
     case CS_FILL_POLYLINES_SHARP: {
         int sharp = fill == CS_FILL_POLYLINES_SHARP;
         size_t npt = poly_npt(w, sharp);
-        return align16(4 * npt) + align16(2 * npt) + align16(2 * ((size_t)w + 4)) + align16(2 * ((size_t)w + 2)) +
+        return align16(2 * npt) + align16(2 * ((size_t)w + 4)) + align16(2 * ((size_t)w + 2)) +
                align16(2 * (size_t)poly_cap(w, sharp)) + align16(2 * 1024);
     }
     default: return 0;
     }
 }
 
-__device__ inline Lds carve(char* base, int w) {
+__device__ inline Lds carve(char* base, int fill, int w, int anaglyph) {
     Lds L;
     size_t o = 0;
     L.lut = (float*)(base + o); o += 1024;
     L.tabs = (csm::PowfTables*)(base + o); o += align16(sizeof(csm::PowfTables));
     L.misc = (int*)(base + o); o += 128;
     L.img = (uint8_t*)(base + o); o += align16(3 * (size_t)w);
-    L.res = (uint8_t*)(base + o); o += align16(3 * (size_t)w);
-    L.ana = (uint8_t*)(base + o); o += align16(2 * (size_t)w);
+    L.res = (uint8_t*)(base + o); if (fill_uses_res(fill)) o += align16(3 * (size_t)w);
+    L.ana = (uint8_t*)(base + o); if (anaglyph) o += align16(2 * (size_t)w);
     L.nd = (float*)(base + o); o += align16(4 * (size_t)w);
     L.tech = base + o;
     return L;
@@ -233,7 +237,7 @@ __device__ void technique_inverse(const Lds& L, int w, const EyeArgs& E, float e
 // ---------------------------------------------------------------------------------------------
 struct Poly {
     int w, npt, sharp, cap;
-    float* px;          // [npt] x of polyline point o (unsorted, reference order)
+    float sep32;        // x of polyline point o is recomputed from coord_d on every use (saves 4*npt bytes of LDS)
     uint16_t* perm;     // [npt] sorted position -> point
     uint16_t* binoff;   // [w+3] after the fill pass: END of bin b (bin 0: x<0, bin c+1: [c,c+1), bin w+1: x>=w)
     uint16_t* segoff;   // [w+1] after the fill pass: END of pixel p's segment list
@@ -242,6 +246,17 @@ struct Poly {
     const float* cd;    // [w] coord_d
 };
 
+// x of polyline point o in reference order (:1921-1935): sentinels at -w and 2w, else
+// col + 0.5 + coord_d + separation_px (float32 step by step), -/+ 0.45 for the two 'sharp' points.
+__device__ __forceinline__ float poly_x(const Poly& P, int o) {
+    if (o <= 0) return (float)(-1.0 * P.w);
+    if (o >= P.npt - 1) return (float)(2.0 * P.w);
+    const float half32 = (float)0.45;
+    int c = P.sharp ? (o - 1) >> 1 : o - 1;
+    float x = ((float)c + 0.5f + P.cd[c]) + P.sep32;
+    if (P.sharp) x = ((o - 1) & 1) ? x + half32 : x - half32;
+    return x;
+}
 __device__ __forceinline__ int poly_col(const Poly& P, int o) {
     if (o <= 0) return 0;
     if (o >= P.npt - 1) return P.w - 1;
@@ -268,7 +283,7 @@ __device__ __forceinline__ void poly_accumulate(const Poly& P, const uint8_t* im
             else color[c] = color[c] + (float)img[3 * col_l + c] * sig_f;
         }
     } else {
-        float x0 = P.px[seg], x1 = P.px[seg + 1];
+        float x0 = poly_x(P, seg), x1 = poly_x(P, seg + 1);
         float ip_k = (center - x0) / (x1 - x0);
         float om = 1.0f - ip_k;
         float s = sig64 ? (float)sig_d : sig_f;
@@ -309,24 +324,25 @@ __device__ __forceinline__ SubInt poly_subinterval(int col, float a, float b) {
 }
 
 // literal replay of the reference sweep for one row by one lane (rows flagged as order-dependent)
-__device__ int poly_sequential(const Poly& P, const Lds& L, int csg_cap_ref) {
+template <class Emit>
+__device__ int poly_sequential(const Poly& P, const Lds& L, int csg_cap_ref, const Emit& emit) {
     const int w = P.w, sg_end = P.npt - 1;
     uint16_t* csg = P.entries;
     int cap = min(csg_cap_ref, P.cap);
     int csg_end = 0, sg_pointer = 0, pt_i = 0;
     for (int col = 0; col < w; col++) {
         float color[3] = {0.5f, 0.5f, 0.5f};
-        while (P.px[P.perm[pt_i]] < (float)col) pt_i++;
+        while (poly_x(P, P.perm[pt_i]) < (float)col) pt_i++;
         pt_i--;
-        while (P.px[P.perm[pt_i]] < (float)(col + 1)) {
-            SubInt s = poly_subinterval(col, P.px[P.perm[pt_i]], P.px[P.perm[pt_i + 1]]);
-            while (sg_pointer < sg_end && P.px[P.perm[sg_pointer]] < s.center) {
+        while (poly_x(P, P.perm[pt_i]) < (float)(col + 1)) {
+            SubInt s = poly_subinterval(col, poly_x(P, P.perm[pt_i]), poly_x(P, P.perm[pt_i + 1]));
+            while (sg_pointer < sg_end && poly_x(P, P.perm[sg_pointer]) < s.center) {
                 if (csg_end >= cap) return -1;
                 csg[csg_end++] = P.perm[sg_pointer++];
             }
             int ci = 0;
             while (ci < csg_end) {
-                if (P.px[csg[ci] + 1] < s.center) { csg[ci] = csg[csg_end - 1]; csg_end--; }
+                if (poly_x(P, csg[ci] + 1) < s.center) { csg[ci] = csg[csg_end - 1]; csg_end--; }
                 else ci++;
             }
             int best = 0;
@@ -334,7 +350,7 @@ __device__ int poly_sequential(const Poly& P, const Lds& L, int csg_cap_ref) {
                 float bc = (float)(-1e-7);
                 for (ci = 0; ci < csg_end; ci++) {
                     int o = csg[ci];
-                    float x0 = P.px[o], x1 = P.px[o + 1];
+                    float x0 = poly_x(P, o), x1 = poly_x(P, o + 1);
                     float ip_k = (s.center - x0) / (x1 - x0);
                     float cl = (1.0f - ip_k) * poly_z(P, o) + ip_k * poly_z(P, o + 1);
                     if (bc < cl && 0.0f < ip_k && ip_k < 1.0f) { bc = cl; best = ci; }
@@ -345,9 +361,7 @@ __device__ int poly_sequential(const Poly& P, const Lds& L, int csg_cap_ref) {
             poly_accumulate(P, L.img, csg[best], s.center, s.sig64, s.sig_d, s.sig_f, color);
             pt_i++;
         }
-        L.res[3 * col + 0] = csm::f32_to_u8_wrap(color[0]);
-        L.res[3 * col + 1] = csm::f32_to_u8_wrap(color[1]);
-        L.res[3 * col + 2] = csm::f32_to_u8_wrap(color[2]);
+        emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
     }
     return 0;
 }
@@ -355,7 +369,7 @@ __device__ int poly_sequential(const Poly& P, const Lds& L, int csg_cap_ref) {
 // rasterise the forward segments into per-pixel lists; PASS 0 counts, PASS 1 fills
 template <int PASS>
 __device__ __forceinline__ void poly_seg_pixels(const Poly& P, int o, int& p0, int& p1) {
-    float x0 = P.px[o], x1 = P.px[o + 1];
+    float x0 = poly_x(P, o), x1 = poly_x(P, o + 1);
     p0 = 1; p1 = 0;
     if (!(x0 < x1)) return;  // reversed / degenerate segments are never active
     float f0 = floorf(x0), f1 = floorf(x1);
@@ -364,13 +378,14 @@ __device__ __forceinline__ void poly_seg_pixels(const Poly& P, int o, int& p0, i
     p1 = f1 > (float)(P.w - 1) ? P.w - 1 : (int)f1;
 }
 
-template <int SHARP>
-__device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float e32, uint32_t* stats_rw) {
+template <int SHARP, class Emit>
+__device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float e32, uint32_t* stats_rw,
+                                    const Emit& emit, int dbg) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
     Poly P;
     P.w = w; P.sharp = SHARP; P.npt = poly_npt(w, SHARP); P.cap = poly_cap(w, SHARP);
+    P.sep32 = E.sep32;
     char* t = L.tech;
-    P.px = (float*)t; t += align16(4 * (size_t)P.npt);
     P.perm = (uint16_t*)t; t += align16(2 * (size_t)P.npt);
     P.binoff = (uint16_t*)t; t += align16(2 * ((size_t)w + 4));
     P.segoff = (uint16_t*)t; t += align16(2 * ((size_t)w + 2));
@@ -382,50 +397,40 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
     int* nlong = L.misc + 1;
     int* ntotal = L.misc + 2;
     int* scan_ws = L.misc + 8;
-    const float half32 = (float)0.45;
-
     // P1: coord_d (in place over nd), point x's, histogram of bins (count of bin b at binoff[b+1])
     for (int c = tid; c < w; c += nt) L.nd[c] = disparity(L.nd[c], e32, E.div32, L.tabs);
     for (int i = tid; i < (w + 4) / 2; i += nt) ((unsigned*)P.binoff)[i] = 0;
     for (int i = tid; i < (w + 2) / 2; i += nt) ((unsigned*)P.segoff)[i] = 0;
     if (tid == 0) { *flag_hazard = 0; *nlong = 0; *ntotal = 0; }
     __syncthreads();
-    for (int o = tid; o < npt; o += nt) {
-        float x;
-        if (o == 0) x = (float)(-1.0 * w);
-        else if (o == npt - 1) x = (float)(2.0 * w);
-        else {
-            int c = SHARP ? (o - 1) >> 1 : o - 1;
-            x = ((float)c + 0.5f + P.cd[c]) + E.sep32;
-            if (SHARP) x = ((o - 1) & 1) ? x + half32 : x - half32;
-        }
-        P.px[o] = x;
-        atomic_add_u16(P.binoff, poly_bin(P, x) + 1, 1);
-    }
+    if (dbg == 1) return;
+    for (int o = tid; o < npt; o += nt) atomic_add_u16(P.binoff, poly_bin(P, poly_x(P, o)) + 1, 1);
     __syncthreads();
+    if (dbg == 2) return;
     // P2: counting sort by bin, then rank inside the bin by (x, reference index) == the reference's
     // stable insertion sort (:1941-1946).  After the scatter binoff[b] = END of bin b.
     block_scan_inclusive(P.binoff, nbin + 1, 0, OpAdd(), scan_ws);
     uint16_t* scratch = P.entries;
     for (int o = tid; o < npt; o += nt) {
-        unsigned slot = atomic_add_u16(P.binoff, poly_bin(P, P.px[o]), 1);
+        unsigned slot = atomic_add_u16(P.binoff, poly_bin(P, poly_x(P, o)), 1);
         scratch[slot] = (uint16_t)o;
     }
     __syncthreads();
     for (int k = tid; k < npt; k += nt) {
         int o = scratch[k];
-        float x = P.px[o];
+        float x = poly_x(P, o);
         int b = poly_bin(P, x);
         int bs = b > 0 ? P.binoff[b - 1] : 0, be = P.binoff[b];
         int r = 0;
         for (int j = bs; j < be; j++) {
             int o2 = scratch[j];
-            float x2 = P.px[o2];
+            float x2 = poly_x(P, o2);
             r += (x2 < x || (x2 == x && o2 < o)) ? 1 : 0;
         }
         P.perm[bs + r] = (uint16_t)o;
     }
     __syncthreads();
+    if (dbg == 3) return;
     // P3a/b: per-pixel lists of the forward segments that can be active inside the pixel (CSR).
     // Segments spanning > 3 pixels (disocclusion bridges) are rasterised cooperatively, 64 pixels
     // per wave step, instead of serialising one lane.
@@ -467,6 +472,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
             for (int p = p0 + lane; p <= p1; p += 64) P.entries[atomic_add_u16(P.segoff, p, 1)] = (uint16_t)o;
         }
         __syncthreads();
+        if (dbg == 4) return;
         // P3c: one lane per output pixel (reference :1951-1991)
         for (int col = tid; col < w; col += nt) {
             float color[3] = {0.5f, 0.5f, 0.5f};
@@ -474,9 +480,9 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
             const int ls = col > 0 ? P.segoff[col - 1] : 0, le = P.segoff[col];
             float prev = (float)col;
             bool hazard = false;
-            float a = P.px[P.perm[pos0 - 1]];
+            float a = poly_x(P, P.perm[pos0 - 1]);
             for (int k = pos0 - 1; k < pos1; k++) {
-                float b = P.px[P.perm[k + 1]];
+                float b = poly_x(P, P.perm[k + 1]);
                 SubInt s = poly_subinterval(col, a, b);
                 a = b;
                 if (s.center < prev || s.center > (float)(col + 1)) hazard = true;
@@ -487,7 +493,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                 bool tie = false;
                 for (int e = ls; e < le; e++) {
                     int o = P.entries[e];
-                    float x0 = P.px[o], x1 = P.px[o + 1];
+                    float x0 = poly_x(P, o), x1 = poly_x(P, o + 1);
                     if (!(x0 < s.center) || x1 < s.center) continue;
                     nact++;
                     single = o;
@@ -506,16 +512,15 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                 if (seg >= 0) poly_accumulate(P, L.img, seg, s.center, s.sig64, s.sig_d, s.sig_f, color);
             }
             if (hazard) *flag_hazard = 1;
-            L.res[3 * col + 0] = csm::f32_to_u8_wrap(color[0]);
-            L.res[3 * col + 1] = csm::f32_to_u8_wrap(color[1]);
-            L.res[3 * col + 2] = csm::f32_to_u8_wrap(color[2]);
+            else if (dbg == 5) { if (color[0] == 12345.0f) emit(col, 1, 2, 3); }
+            else emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
         }
     }
     __syncthreads();
     if (overflow || *flag_hazard) {
         // order-dependent row: replay the reference sweep literally on one lane
         if (tid == 0) {
-            int rc = poly_sequential(P, L, E.csg_cap);
+            int rc = poly_sequential(P, L, E.csg_cap, emit);
             if (stats_rw) {
                 atomicAdd(&stats_rw[ST_FALLBACK_ROWS], 1u);
                 if (rc) atomicOr(&stats_rw[ST_ERROR], 1u);
@@ -553,7 +558,7 @@ __global__ void __launch_bounds__(1024) k_hybrid_splat(RowArgs A) {
     const int row = blockIdx.x, frame = blockIdx.y, eyei = blockIdx.z;
     const int w = A.w, h = A.h;
     const EyeArgs& E = A.eye[eyei];
-    Lds L = carve(smem, w);
+    Lds L = carve(smem, CS_FILL_HYBRID_EDGE, w, 1);
     char* t = L.tech;
     float* destx = (float*)t; t += align16(4 * (size_t)w);
     uint16_t* binoff = (uint16_t*)t; t += align16(2 * ((size_t)w + 4));   // bin b = j_c + 1, b in [0, w+1]
@@ -697,15 +702,44 @@ __device__ void technique_hybrid_fill(const Lds& L, const RowArgs& A, int frame,
 // ---------------------------------------------------------------------------------------------
 // the row kernel
 // ---------------------------------------------------------------------------------------------
+// Destination of one eye row: converts uint8 pixels to the output layout as they are produced.
+struct RowOut {
+    const RowArgs* A;
+    const Lds* L;
+    int frame, row, eye, w;
+    bool stash;  // first eye of an anaglyph: only remember the channels the composite takes from it
+    __device__ __forceinline__ void operator()(int c, uint8_t r, uint8_t g, uint8_t b) const {
+        const RowArgs& a = *A;
+        if (a.out_u8) {
+            uint8_t* d = a.out_u8 + (((size_t)frame * a.h + row) * w + c) * 3;
+            d[0] = r; d[1] = g; d[2] = b;
+            return;
+        }
+        if (stash) {
+            if (a.anaglyph == 1) L->ana[c] = r;
+            else { L->ana[2 * c] = g; L->ana[2 * c + 1] = b; }
+            return;
+        }
+        if (a.anaglyph == 1) r = L->ana[c];
+        else if (a.anaglyph == 2) { g = L->ana[2 * c]; b = L->ana[2 * c + 1]; }
+        const EyeArgs& E = a.eye[eye];
+        const size_t o = ((size_t)frame * a.out_h + row + E.yoff) * a.out_w + E.xoff + c;
+        float* d = a.stereo + o * 3;
+        d[0] = L->lut[r]; d[1] = L->lut[g]; d[2] = L->lut[b];
+        a.mask[o] = ((int)r + (int)g + (int)b) == 0 ? 1.0f : 0.0f;  // GenerateStereo.py:355-361
+    }
+};
+
 template <int FILL>
 __global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int row = blockIdx.x, frame = blockIdx.y;
     const int w = A.w, h = A.h;
-    Lds L = carve(smem, w);
+    Lds L = carve(smem, FILL, w, A.anaglyph);
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
     uint32_t* st_rw = A.stats_rw ? A.stats_rw + (size_t)frame * ST_WORDS : nullptr;
+    constexpr bool DIRECT = !fill_uses_res(FILL);  // the technique emits pixels itself
 
     // constants into LDS
     for (int i = tid; i < 256; i += nt) L.lut[i] = (float)i / 255.0f;
@@ -749,43 +783,42 @@ __global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
     for (int e = 0; e < A.neyes; e++) {
         const EyeArgs& E = A.eye[e];
         if (A.single >= 0 && A.single != e) continue;
+        const bool last = (e == A.neyes - 1) || A.single >= 0;
+        RowOut out{&A, &L, frame, row, e, w, A.anaglyph != 0 && !last};
         if (E.enabled) {
             // normalised depth: (d - min) / (max - min) - convergence (reference :1587-1600)
             float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
             const float* drow = E.depth + rowpix;
             const bool flat = dmax == dmin;
             const float range = dmax - dmin;
-            for (int c = tid; c < w; c += nt) {
-                float d = drow[c] * scale;
-                L.nd[c] = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
+            if (FILL != CS_FILL_HYBRID_EDGE) {
+                for (int c = tid; c < w; c += nt) {
+                    float d = drow[c] * scale;
+                    L.nd[c] = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
+                }
+                __syncthreads();
             }
-            __syncthreads();
             if (FILL == CS_FILL_NONE || FILL == CS_FILL_NAIVE || FILL == CS_FILL_NAIVE_INTERPOLATING)
                 technique_forward<FILL>(L, w, E, A.e32);
             else if (FILL == CS_FILL_INVERSE) technique_inverse(L, w, E, A.e32);
-            else if (FILL == CS_FILL_POLYLINES_SOFT) technique_polylines<0>(L, w, E, A.e32, st_rw);
-            else if (FILL == CS_FILL_POLYLINES_SHARP) technique_polylines<1>(L, w, E, A.e32, st_rw);
+            else if (FILL == CS_FILL_POLYLINES_SOFT) technique_polylines<0>(L, w, E, A.e32, st_rw, out, A.dbg);
+            else if (FILL == CS_FILL_POLYLINES_SHARP) technique_polylines<1>(L, w, E, A.e32, st_rw, out, A.dbg);
             else if (FILL == CS_FILL_HYBRID_EDGE) technique_hybrid_fill(L, A, frame, row, e);
+        } else if (DIRECT) {
+            for (int c = tid; c < w; c += nt) out(c, L.img[3 * c], L.img[3 * c + 1], L.img[3 * c + 2]);
         } else {
             for (int i = tid; i < 3 * w; i += nt) L.res[i] = L.img[i];
             __syncthreads();
         }
-        // ---- store -------------------------------------------------------------------------
-        if (A.out_u8) {
-            uint8_t* dst = A.out_u8 + rowpix * 3;
-            for (int i = tid; i < 3 * w; i += nt) dst[i] = L.res[i];
-        } else {
-            const bool last = (e == A.neyes - 1) || A.single >= 0;
-            if (A.anaglyph && !last) {
-                // first eye of an anaglyph: keep the channels the composite takes from it
-                for (int c = tid; c < w; c += nt) {
-                    if (A.anaglyph == 1) L.ana[c] = L.res[3 * c];  // red from the left eye
-                    else { L.ana[2 * c] = L.res[3 * c + 1]; L.ana[2 * c + 1] = L.res[3 * c + 2]; }
-                }
-                __syncthreads();
+        // ---- store the eye row held in LDS (techniques that do not emit directly) -----------------
+        if (!DIRECT) {
+            if (A.out_u8) {
+                uint8_t* dst = A.out_u8 + rowpix * 3;
+                for (int i = tid; i < 3 * w; i += nt) dst[i] = L.res[i];
+            } else if (out.stash) {
+                for (int c = tid; c < w; c += nt) out(c, L.res[3 * c], L.res[3 * c + 1], L.res[3 * c + 2]);
             } else {
                 if (A.anaglyph) {
-                    // red-cyan: R from eye0 (stashed), G,B from eye1 (res).  reverse: R from eye1, G,B from eye0
                     for (int c = tid; c < w; c += nt) {
                         if (A.anaglyph == 1) L.res[3 * c] = L.ana[c];
                         else { L.res[3 * c + 1] = L.ana[2 * c]; L.res[3 * c + 2] = L.ana[2 * c + 1]; }
@@ -804,7 +837,6 @@ __global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
                 } else {
                     for (int i = tid; i < 3 * w; i += nt) dst[i] = L.lut[L.res[i]];
                 }
-                // mask: 1 where the OUTPUT pixel is black (GenerateStereo.py:355-361)
                 float* m = A.mask + ((size_t)frame * A.out_h + oy) * A.out_w + ox;
                 for (int c = tid; c < w; c += nt)
                     m[c] = ((int)L.res[3 * c] + (int)L.res[3 * c + 1] + (int)L.res[3 * c + 2]) == 0 ? 1.0f : 0.0f;
@@ -827,7 +859,7 @@ __global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
 
 // host-side launcher (called from cs_abi.hip)
 hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream) {
-    size_t lds = lds_common_bytes(A.w) + lds_tech_bytes(fill, A.w);
+    size_t lds = lds_common_bytes(fill, A.w, A.anaglyph) + lds_tech_bytes(fill, A.w);
     dim3 grid(A.h, A.n), block(threads);
 #define CS_LAUNCH(F)                                                                                              \
     case F: {                                                                                                     \
@@ -851,7 +883,7 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
     return hipGetLastError();
 }
 
-size_t rowwarp_lds_bytes(int fill, int w) { return lds_common_bytes(w) + lds_tech_bytes(fill, w); }
+size_t rowwarp_lds_bytes(int fill, int w) { return lds_common_bytes(fill, w, 1) + lds_tech_bytes(fill, w); }
 
 size_t hybrid_workspace_bytes(int n, int h, int w) { return (size_t)n * 2 * h * w * 4 + 256; }
 int hybrid_max_width() {

@@ -1,0 +1,68 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/comfystereo_amd.h declares;
+argument validation that needs no device work behaves as documented (not gpu)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from comfystereo_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "comfystereo_amd.h")).read()
+    return sorted(set(re.findall(r"CS_API\s+[\w\s\*]+?\b(cs_\w+)\s*\(", hdr)))
+
+
+def test_library_is_built_and_exports_every_declared_symbol():
+    L = _native.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 14 and set(syms) == set(_native.EXPORTS)
+    for s in syms:
+        assert hasattr(L, s), s
+    assert L.cs_version() == 1
+
+
+def test_enums_match_header():
+    hdr = open(os.path.join(ROOT, "include", "comfystereo_amd.h")).read()
+    for key, name in (("none", "CS_FILL_NONE"), ("polylines_soft", "CS_FILL_POLYLINES_SOFT"), ("gpu_warp", "CS_FILL_GPU_WARP"),
+                      ("hybrid_edge", "CS_FILL_HYBRID_EDGE")):
+        assert int(re.search(name + r"\s*=\s*(\d+)", hdr).group(1)) == _native.FILL[key]
+    for key, name in (("left-right", "CS_MODE_LEFT_RIGHT"), ("red-cyan-anaglyph", "CS_MODE_RED_CYAN_ANAGLYPH"),
+                      ("cyan-red-reverseanaglyph", "CS_MODE_CYAN_RED_REVERSEANAGLYPH")):
+        assert int(re.search(name + r"\s*=\s*(\d+)", hdr).group(1)) == _native.MODE[key]
+
+
+def test_params_struct_layout():
+    assert ctypes.sizeof(_native.Params) == 12 * 4 + 8 * 8
+    assert _native.Params.divergence.offset == 48
+
+
+def test_host_side_queries_without_gpu():
+    L = _native.lib()
+    from comfystereo_amd import engine
+    p = engine.make_params(4, 2160, 3840, 2160, 3840, 3, "polylines_soft", "left-right", 8.0, 0.0, 0.0, 0.5, 2.0, True, 20.0,
+                           20.0, 2.0, 6, 12)
+    assert engine.output_shape(p) == (2160, 7680, 2160, 7680)
+    p.mode = _native.MODE["top-bottom"]
+    assert engine.output_shape(p) == (4320, 3840, 4320, 3840)
+    p.mode, p.fill = _native.MODE["red-cyan-anaglyph"], _native.FILL["gpu_warp"]
+    assert engine.output_shape(p) == (2160, 3840, 2160, 3840)
+    assert L.cs_workspace_bytes(ctypes.byref(p)) > 4 * 2160 * 3840 * 4
+    for f in range(8):
+        assert L.cs_max_width(f) >= 3840, f  # every technique handles a 4K row in LDS
+    p.mode = 99
+    oh = ctypes.c_int()
+    assert L.cs_output_shape(ctypes.byref(p), ctypes.byref(oh), None, None, None) == _native.CS_EINVAL
+    assert b"Unknown mode" in L.cs_last_error()
+
+
+def test_null_pointers_are_rejected_before_any_device_work():
+    L = _native.lib()
+    assert L.cs_apply_stereo_divergence(None, None, 1, 8, 8, 1.0, 0.0, 1.0, 0, 0.5, None, None, 0, None) == _native.CS_EINVAL
+    assert L.cs_directional_blur(None, 1, 8, 8, 5.0, 6.0, 1.0, 0, None, None, None, 0, None) == _native.CS_EINVAL
+    with pytest.raises(ValueError):
+        from comfystereo_amd import engine
+        engine.make_params(1, 8, 8, 8, 8, 3, "none", "sideways", 1, 0, 0, 0.5, 1, False, 0, 6, 1, 0, 1)

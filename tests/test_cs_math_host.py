@@ -1,0 +1,58 @@
+"""comfystereo_amd/csrc/cs_math.h (the routines the HIP kernels use) compiled for the HOST and pinned against the
+live libm -- runs without a GPU.  The device build of the same header is checked in tests/test_gpu_parity.py."""
+import os
+import platform
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = r'''
+#include <stdio.h>
+#include <math.h>
+#include <initializer_list>
+#include "cs_math.h"
+int main() {
+    static const csm::PowfTables T = CS_POWF_TABLES_INIT;
+    long bad = 0, n = 0;
+    for (int e = 1; e <= 20; e++) {
+        float y = (float)(e / 10.0);
+        for (uint32_t u = 0; u <= 0x3f800000u; u += 4099) {
+            float x = csm::u2f(u);
+            if (csm::f2u(powf(x, y)) != csm::f2u(csm::powf_exact(x, y, &T))) bad++;
+            n++;
+        }
+    }
+    for (uint32_t u = 0; u <= 0x40a00000u; u += 257) {
+        float d = csm::u2f(u); float a = -(d * d) / 2.0f;
+        if (csm::d2u(exp((double)a)) != csm::d2u(csm::exp_exact((double)a, cs_exp_tab))) bad++;
+        n++;
+    }
+    for (int i = 0; i < 2000000; i++) {
+        double x = -330.0 * (double)i / 2000000.0;
+        if (csm::d2u(exp(x)) != csm::d2u(csm::exp_exact(x, cs_exp_tab))) bad++;
+        n++;
+    }
+    float q[] = {65025.f, 300.7f, -3.2f, 255.9f, 256.f, 1e10f};
+    int want[] = {1, 44, 253, 255, 0, 0};
+    for (int i = 0; i < 6; i++) if (csm::f32_to_u8_wrap(q[i]) != want[i]) bad++;
+    for (float f : {-3.5f, -0.0f, 0.0f, 1e-30f, 2.0f}) if (csm::ord2f(csm::f2ord(f)) != f) bad++;
+    if (!(csm::f2ord(-1.0f) < csm::f2ord(-0.5f) && csm::f2ord(-0.5f) < csm::f2ord(0.25f))) bad++;
+    printf("%ld %ld\n", n, bad);
+    return bad != 0;
+}
+'''
+
+
+@pytest.mark.skipif(platform.libc_ver()[1] != "2.35" or platform.machine() != "x86_64",
+                    reason="pinned to glibc 2.35 x86-64 (FMA ifunc variant)")
+def test_device_math_header_matches_libm_on_host(tmp_path):
+    src = tmp_path / "t.cpp"
+    src.write_text(SRC)
+    exe = tmp_path / "t"
+    fma = ["-mfma"] if " fma " in open("/proc/cpuinfo").read() else []
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", *fma, "-I", os.path.join(ROOT, "comfystereo_amd", "csrc"),
+                           str(src), "-o", str(exe), "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    n, bad = map(int, out.stdout.split())
+    assert out.returncode == 0 and bad == 0 and n > 9_000_000

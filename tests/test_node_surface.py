@@ -1,0 +1,76 @@
+"""The drop-in surface: node attributes, module function signatures and error behaviour mirror the reference
+(GenerateStereo.py:46-80,460-466; stereoimage_generation.py:1005-1009,1422-1426).  Not gpu."""
+import inspect
+
+import pytest
+import torch
+
+from comfystereo_amd import GenerateStereo as gs
+from comfystereo_amd import stereoimage_generation as sig
+
+
+def test_node_protocol():
+    n = gs.StereoImageNode
+    assert n.RETURN_TYPES == ("IMAGE", "IMAGE", "IMAGE", "MASK")
+    assert n.RETURN_NAMES == ("stereoscope", "blurred_depthmap_left", "blurred_depthmap_right", "no_fill_imperfect_mask")
+    assert n.FUNCTION == "generate" and not hasattr(n, "CATEGORY")
+    assert gs.NODE_CLASS_MAPPINGS == {"StereoImageNode": n}
+    assert gs.NODE_DISPLAY_NAME_MAPPINGS == {"StereoImageNode": "Stereo Image Node"}
+    it = n.INPUT_TYPES()
+    assert list(it["required"]) == ["image", "depth_map", "modes", "fill_technique"]
+    assert it["required"]["modes"][0] == ["left-right", "right-left", "top-bottom", "bottom-top", "red-cyan-anaglyph"]
+    fills, opts = it["required"]["fill_technique"]
+    assert fills == ['GPU Warp (Fast)', 'No fill', 'No fill - Reverse projection', 'Imperfect fill - Hybrid Edge',
+                     'Fill - Naive', 'Fill - Naive interpolating', 'Fill - Polylines Soft', 'Fill - Polylines Sharp']
+    assert opts["default"] == "GPU Warp (Fast)"
+    want = {"divergence": (4.5, 0.05, 15, 0.01), "separation": (0, -5, 5, 0.01), "stereo_balance": (0, -0.95, 0.95, 0.05),
+            "convergence_point": (0.5, 0.0, 1.0, 0.05), "stereo_offset_exponent": (2, 0.1, 2, 0.1),
+            "depth_blur_edge_threshold": (20, 0.1, 60, 0.1), "depth_blur_strength": (20, 0.1, 200, 0.1),
+            "depth_blur_falloff": (2.0, 0.1, 4.0, 0.1), "depth_blur_vert_smooth": (6, 0, 15, 1), "batch_size": (12, 1, 64, 1)}
+    for k, (d, lo, hi, st) in want.items():
+        o = it["optional"][k][1]
+        assert (o["default"], o["min"], o["max"], o["step"]) == (d, lo, hi, st), k
+    assert it["optional"]["depth_map_blur"] == ("BOOLEAN", {"default": True, "tooltip": it["optional"]["depth_map_blur"][1]["tooltip"]})
+
+
+def test_generate_signature_matches_reference():
+    params = list(inspect.signature(gs.StereoImageNode.generate).parameters.values())
+    names = [p.name for p in params]
+    assert names == ["self", "image", "depth_map", "divergence", "separation", "modes", "stereo_balance", "convergence_point",
+                     "stereo_offset_exponent", "fill_technique", "depth_blur_edge_threshold", "depth_blur_strength",
+                     "depth_map_blur", "depth_blur_falloff", "depth_blur_vert_smooth", "batch_size"]
+    d = {p.name: p.default for p in params if p.default is not inspect._empty}
+    assert d == {"depth_blur_falloff": 1.0, "depth_blur_vert_smooth": 0, "batch_size": 4}  # quirk Q9
+
+
+def test_module_function_signatures():
+    s = inspect.signature(sig.create_stereoimages)
+    assert list(s.parameters) == ["original_image", "depthmap", "divergence", "separation", "modes", "stereo_balance",
+                                  "stereo_offset_exponent", "fill_technique", "depth_blur_strength",
+                                  "depth_blur_edge_threshold", "direction_aware_depth_blur", "return_modified_depth",
+                                  "convergence_point", "depth_blur_falloff", "depth_blur_vert_smooth"]
+    assert s.parameters["fill_technique"].default == "polylines_sharp" and s.parameters["stereo_offset_exponent"].default == 1.0
+    g = inspect.signature(sig.create_stereoimages_gpu)
+    assert list(g.parameters) == ["image_tensor", "depth_tensor", "divergence", "separation", "modes", "stereo_balance",
+                                  "stereo_offset_exponent", "convergence_point", "depth_blur_strength",
+                                  "depth_blur_edge_threshold", "direction_aware_depth_blur", "depth_blur_falloff",
+                                  "depth_blur_vert_smooth"]
+
+
+def test_empty_modes_and_unknown_mode():
+    img, dep = torch.zeros(3, 4, 4), torch.zeros(4, 4)
+    assert sig.create_stereoimages(img, dep, 5.0, modes=[]) == []
+    assert sig.create_stereoimages_gpu(img[None], dep[None], 5.0, modes=[]) == ([], None, None, None)
+    with pytest.raises(Exception, match="Unknown mode"):
+        sig.create_stereoimages(img, dep, 5.0, modes=["sideways"])
+    with pytest.raises(ValueError, match="Unknown mode: sideways"):
+        sig.create_stereoimages_gpu(img[None], dep[None], 5.0, modes=["sideways"])
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_a_gpu():
+    img, dep = torch.zeros(1, 4, 4, 3), torch.zeros(1, 4, 4, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gs.StereoImageNode().generate(img, dep, 4.5, 0, "left-right", 0, 0.5, 2, "Fill - Polylines Soft", 20, 20, True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sig.create_stereoimages(img[0].permute(2, 0, 1), dep[0, :, :, 0], 5.0)

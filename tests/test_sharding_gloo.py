@@ -1,0 +1,73 @@
+"""Frame sharding + all-gather with 2 gloo processes on CPU (the N>1 path of bench.py / sharding.py).
+The local compute is stood in for by the CPU oracle -- the thing under test is the partition + collective."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from comfystereo_amd import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds():
+    assert sharding.shard_bounds(64, 8) == [0, 8, 16, 24, 32, 40, 48, 56, 64]
+    assert sharding.shard_bounds(10, 4) == [0, 3, 6, 8, 10]
+    assert sharding.shard_bounds(5, 8) == [0, 1, 2, 3, 4, 5, 5, 5, 5]
+    b = sharding.shard_bounds(256, 8, align=12)  # gpu_warp: boundaries on reference sub-batch boundaries
+    assert b[0] == 0 and b[-1] == 256 and all(x % 12 == 0 for x in b[:-1]) and b == sorted(b)
+    assert sharding.shard_bounds(7, 2, align=12) == [0, 7, 7]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fill, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import synth
+    from oracle import node_oracle
+    h, w = 16, 48
+    img = synth.image_f32(n, h, w, seed=2)
+    dep = synth.depth_batch("stepped", n, h, w, channels=3)
+    ui = {v: k for k, v in node_oracle.FILL_KEYS.items()}[fill]
+    args = (6.0, 0.0, "left-right", 0.0, 0.5, 2.0, ui, 20.0, 20.0, False)
+
+    def run_local(ib, db):
+        return tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in
+                     node_oracle.generate(ib.numpy(), db.numpy(), *args, batch_size=2))
+
+    out, bounds = sharding.generate_sharded(run_local, torch.from_numpy(img), torch.from_numpy(dep), fill, 2)
+    full = node_oracle.generate(img, dep, *args, batch_size=2)
+    ok = np.array_equal(out["stereoscope"].numpy(), full[0]) and np.array_equal(out["mask"].numpy(), full[3])
+    ok = ok and out["depth_left"].shape[0] == bounds[rank + 1] - bounds[rank]
+    q.put((rank, bool(ok), bounds))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fill,n", [("polylines_soft", 5), ("gpu_warp", 6), ("none", 1)])
+def test_two_rank_gather_equals_unsharded(fill, n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, fill, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
