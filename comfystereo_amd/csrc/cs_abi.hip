@@ -3,6 +3,7 @@
 // decisions (0..255 scaling), device self-tests of the libm-exact math.
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 #include "cs_common.h"
@@ -175,6 +176,7 @@ struct ProfScope {
     ~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof_ev[2 * slot + 1], s); }
 };
 
+static int threads_for(int fill, int w);
 static int grid_for(size_t items, int threads) {
     size_t b = (items + threads - 1) / threads;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -191,6 +193,32 @@ static void eye_setup(EyeArgs& E, double div_percent_signed, double sep_percent_
     E.csg_cap = 5 * (int)fabs(div_px) + 25;
     E.enabled = 1;
     E.xoff = E.yoff = 0;
+}
+
+// halo of the tiled polylines path: every source column within S of an output pixel can reach it.
+// |nd| <= max(|c|, |1-c|) because the normalised depth lies in [0, 1] (flat depth: nd = -c).
+static int poly_halo(double div_percent_a, double div_percent_b, double sep_percent, double exponent, double conv, int w) {
+    double m = fmax(fabs(conv), fabs(1.0 - conv));
+    double d = fmax(fabs(div_percent_a), fabs(div_percent_b)) / 100.0 * w;
+    double s = d * pow(m, exponent) * 1.0001 + fabs(sep_percent / 100.0 * w);
+    if (!(s < 1e6)) return 1 << 20;
+    return (int)ceil(s) + 2;
+}
+
+// polylines: tiled fast path + general row kernel over the rows it flagged; everything else: row kernel
+static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_t stream) {
+    const bool poly = fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP;
+    const char* no_tile = getenv("CS_NO_TILE");
+    if (poly && !A.anaglyph && halo <= polytile_max_halo() && rowflag && !(no_tile && atoi(no_tile))) {
+        hipError_t e = hipMemsetAsync(rowflag, 0, (size_t)A.n * A.h, stream);
+        if (e != hipSuccess) return fail_hip(e, "rowflag memset");
+        e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, A, halo, rowflag, stream);
+        if (e != hipSuccess) return fail_hip(e, "tiled polylines launch");
+        A.only_flagged = rowflag;
+    }
+    hipError_t e = launch_rowwarp(fill, A, threads_for(fill, A.w), stream);
+    if (e != hipSuccess) return fail_hip(e, "row kernel launch");
+    return CS_OK;
 }
 
 static int threads_for(int fill, int w) {
@@ -243,12 +271,13 @@ int cs_output_shape(const cs_params* p, int* out_h, int* out_w, int* mask_h, int
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t stats, gray_src, gray, L, R, wl, wr, extra, total;
+    size_t stats, rowflag, gray_src, gray, L, R, wl, wr, extra, total;
 };
 static WsLayout ws_layout(const cs_params* p) {
     WsLayout W;
     size_t hw = (size_t)p->h * p->w, n = p->n, o = 0;
     W.stats = o; o += al256(n * ST_WORDS * 4);
+    W.rowflag = o; o += al256(n * (size_t)p->h);
     bool resize = p->depth_h != p->h || p->depth_w != p->w;
     W.gray_src = o; if (resize) o += al256(n * (size_t)p->depth_h * p->depth_w * 4);
     W.gray = o; o += al256(n * hw * 4);
@@ -355,15 +384,16 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
         rc = launch_hybrid(A, ws + W.extra, stream);
         if (rc) return fail(rc, "hybrid_edge launch failed");
     } else {
-        hipError_t e = launch_rowwarp(p->fill, A, threads_for(p->fill, w), stream);
-        if (e != hipSuccess) return fail_hip(e, "row kernel launch");
+        int halo = poly_halo(left_div, right_div, p->separation, p->stereo_offset_exponent, p->convergence_point, w);
+        rc = run_rows(p->fill, A, halo, (uint8_t*)(ws + W.rowflag), stream);
+        if (rc) return rc;
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CS_OK : fail_hip(e, "cs_generate");
 }
 
 size_t cs_asd_workspace_bytes(int n, int h, int w) {
-    return al256((size_t)n * ST_WORDS * 4) + al256(hybrid_workspace_bytes(n, h, w));
+    return al256((size_t)n * ST_WORDS * 4) + al256((size_t)n * h) + al256(hybrid_workspace_bytes(n, h, w));
 }
 
 int cs_apply_stereo_divergence(const uint8_t* image_u8, const float* depth, int n, int h, int w, double divergence,
@@ -392,11 +422,12 @@ int cs_apply_stereo_divergence(const uint8_t* image_u8, const float* depth, int 
     A.out_u8 = out_u8;
     A.single = -1;
     if (fill == CS_FILL_HYBRID_EDGE) {
-        int rc = launch_hybrid(A, (char*)workspace + al256((size_t)n * ST_WORDS * 4), stream);
+        int rc = launch_hybrid(A, (char*)workspace + al256((size_t)n * ST_WORDS * 4) + al256((size_t)n * h), stream);
         if (rc) return fail(rc, "hybrid_edge launch failed");
     } else {
-        hipError_t e = launch_rowwarp(fill, A, threads_for(fill, w), stream);
-        if (e != hipSuccess) return fail_hip(e, "row kernel launch");
+        int halo = poly_halo(divergence, divergence, separation, exponent, convergence, w);
+        int rc = run_rows(fill, A, halo, (uint8_t*)workspace + al256((size_t)n * ST_WORDS * 4), stream);
+        if (rc) return rc;
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CS_OK : fail_hip(e, "cs_apply_stereo_divergence");

@@ -23,6 +23,7 @@ enum {
     ST_WARP_DIV255_R = 8,
     ST_ERROR = 9,  // set by kernels on internal capacity overflow (diagnostics)
     ST_FALLBACK_ROWS = 10,  // polylines: rows that took the sequential path (diagnostics)
+    ST_TILE_REDO_ROWS = 11,  // polylines: rows the tiled fast path handed to the general row kernel
     ST_WORDS = 16
 };
 

@@ -44,6 +44,7 @@ struct RowArgs {
     // hybrid_edge scratch (HBM): splat result of every eye, written by k_hybrid_splat
     uint8_t* hyb_base;  // [n][neyes][h][w][3]
     uint8_t* hyb_mask;  // [n][neyes][h][w]
+    const uint8_t* only_flagged;  // [n][h] or null: process only rows whose flag is set (tiled-path fallback)
     int dbg;            // development only (env CS_DBG): stop the polylines technique after phase `dbg`
 };
 
@@ -51,6 +52,10 @@ struct RowArgs {
 // cs_rowwarp.hip
 hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream);
 size_t rowwarp_lds_bytes(int fill, int w);
+
+// cs_polytile.hip: tiled fast path of polylines; flags rows it cannot do for the general kernel
+hipError_t launch_polytile(int sharp, const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream);
+int polytile_max_halo();
 
 // cs_blur.hip: directional depth blur; if `scale_from_stats`, the input is multiplied by 255 for frames
 // whose stats say so, and the per-frame min/max of both outputs are accumulated into stats.

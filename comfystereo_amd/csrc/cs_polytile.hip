@@ -1,0 +1,448 @@
+// cs_polytile.hip -- tiled fast path of the polylines technique (reference
+// stereoimage_generation.py:1912-1992), the kernel behind the headline metric.
+//
+// The row kernel in cs_rowwarp.hip keeps a whole 4K row (~77 KB) in LDS, so only two workgroups fit
+// on a CU and every phase is a block-wide barrier.  Polylines is LOCAL: output pixel p only depends on
+// source pixels within S = ceil(|divergence_px| * max(c, 1-c)^e + |separation_px|) + 1 columns
+// (c = convergence point; normalised depth lies in [0,1]).  So the row is cut into tiles of T output
+// pixels; one 256-thread workgroup owns one tile of one eye and only looks at the source columns
+// [o0-S-1, o0+T+S+1): ~20 KB of LDS, 6-8 workgroups per CU, three cheap barriers, no prefix sums:
+//   1. stage the source pixels (f32 -> u8) and coord_d = libm-exact disparity of the halo'ed range
+//   2. REGISTER: every polyline point drops its index into the (fixed-capacity) slot list of the output
+//      pixel it falls in; every forward segment drops its index into the slot lists of the pixels it
+//      overlaps (segments longer than 3 pixels -- disocclusion bridges -- are written by the whole wave,
+//      64 pixels per step, picked with a ballot)
+//   3. EVALUATE: one lane per output pixel sorts its <= KP points by (x, index) in registers (== the
+//      reference's stable insertion sort restricted to the pixel), walks the sub-intervals in order and
+//      picks the active segment with the largest interpolated |disparity| exactly like the reference
+//      (float32/float64 typing of SURVEY.md Appendix A); results are staged in LDS and written as
+//      full float4 rows into the SBS/TB slot together with the mask and this eye's depth-map output.
+// Anything the fast path cannot prove order-independent -- exact closeness ties, no qualifying
+// candidate, non-monotone centres, a slot list overflowing -- flags the ROW; flagged rows are redone
+// by the general row kernel (cs_rowwarp.hip, `only_flagged`), whose results are authoritative.
+// The neighbours of the first/last point of a pixel never enter the arithmetic (max(col, x) and
+// min(col+1, x) discard them), which is why no global sort is needed.
+#include "cs_common.h"
+#include "cs_kernels.h"
+#include <stdlib.h>
+
+namespace cs {
+
+#define PT_T 512      // output pixels per tile
+#define PT_THREADS 256
+
+__constant__ csm::PowfTables c_pt_powf_tables = CS_POWF_TABLES_INIT;
+
+struct TSub {
+    bool sig64;
+    double sig_d;
+    float sig_f, center;
+};
+// sub-interval [max(col, a), min(col+1, b)] shrunk by EPSILON on both sides (reference :1957-1960, D32 typing)
+__device__ __forceinline__ TSub pt_subinterval(int col, float a, float b) {
+    const float eps32 = (float)1e-7;
+    TSub s;
+    bool from64 = !(a > (float)col), to64 = !(b < (float)(col + 1));
+    if (from64 && to64) {
+        double from_d = (double)col + 1e-7, to_d = (double)(col + 1) - 1e-7;
+        s.sig64 = true;
+        s.sig_d = to_d - from_d;
+        s.sig_f = 0.0f;
+        s.center = (float)(from_d + 0.5 * s.sig_d);
+    } else {
+        float ff = from64 ? (float)((double)col + 1e-7) : a + eps32;
+        float tf = to64 ? (float)((double)(col + 1) - 1e-7) : b - eps32;
+        s.sig64 = false;
+        s.sig_d = 0.0;
+        s.sig_f = tf - ff;
+        s.center = ff + 0.5f * s.sig_f;
+    }
+    return s;
+}
+
+struct PolyTileArgs {
+    int n, h, w, S;
+    const float* image_f32;
+    const uint8_t* image_u8;
+    const uint32_t* stats;
+    uint32_t* stats_rw;
+    int scale_from_stats;
+    float e32, conv32;
+    EyeArgs eye[2];
+    int neyes, single;
+    uint8_t* out_u8;
+    float* stereo; float* mask; float* depth_l; float* depth_r;
+    int out_h, out_w;
+    uint8_t* rowflag;  // [n][h] set to 1 when the row must be redone by the general kernel
+    int dbg;           // development only (env CS_DBG): 11 = stop after staging, 12 = after REGISTER, 13 = no stores
+};
+
+// PT_KP / PT_KS: polyline points / forward segments per output pixel the fast path can hold (more -> row redo)
+template <int SHARP, int PT_KP, int PT_KS, int MINW>
+__global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tiles = (A.w + PT_T - 1) / PT_T;
+    const int tile = blockIdx.x % tiles, row = blockIdx.x / tiles, frame = blockIdx.y;
+    const int eyei = A.single >= 0 ? A.single : (int)blockIdx.z;
+    const EyeArgs& E = A.eye[eyei];
+    const int w = A.w, h = A.h;
+    const int o0 = tile * PT_T, wt = min(PT_T, w - o0);
+    const int s0 = max(0, (o0 - A.S - 1) & ~3), s1 = min(w, o0 + wt + A.S + 1), ns = s1 - s0;  // s0 % 4 == 0: float4 staging
+    const int nsmax = PT_T + 2 * A.S + 6;
+
+    // Local point ids: 0 = left sentinel (x = -w), then the points of source s0 + j in reference order
+    // (soft: 1 + j; sharp: 1 + 2j and 2 + 2j), last = right sentinel (x = 2w).  The sentinels only take
+    // part when the staged range touches the frame border.
+    const int npts = (SHARP ? 2 * ns : ns) + 2;
+    const int nptmax = (SHARP ? 2 * nsmax : nsmax) + 2;
+
+    // LDS carve
+    float* lut = (float*)smem;                                                  // [256]
+    csm::PowfTables* tabs = (csm::PowfTables*)(lut + 256);
+    float* px = (float*)((char*)tabs + align16(sizeof(csm::PowfTables)));       // [nptmax] x of point o
+    float* pz = px + ((nptmax + 3) & ~3);                                       // [nptmax] |coord_d| of point o
+    uint32_t* img = (uint32_t*)(pz + ((nptmax + 3) & ~3));                      // [nsmax] R | G<<8 | B<<16
+    unsigned* cnt = (unsigned*)(img + ((nsmax + 3) & ~3));                      // [PT_T] low16: points, high16: segments
+    uint16_t* pts = (uint16_t*)(cnt + PT_T);                                    // [PT_T][PT_KP]
+    uint16_t* sgs = pts + PT_T * PT_KP;                                         // [PT_T][PT_KS]
+    uint8_t* res = (uint8_t*)(sgs + PT_T * PT_KS);                              // [3*PT_T]
+    int* flags = (int*)(res + align16(3 * PT_T));                               // [4]
+
+    const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
+    const size_t rowpix = ((size_t)frame * h + row) * w;
+    for (int i = tid; i < 256; i += PT_THREADS) lut[i] = (float)i / 255.0f;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_pt_powf_tables);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(tabs);
+        for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += PT_THREADS) dst[i] = src[i];
+    }
+    for (int i = tid; i < PT_T; i += PT_THREADS) cnt[i] = 0;
+    if (tid == 0) flags[0] = 0;
+    // stage the source pixels of the halo'ed range as packed uint8 RGB (reference :1508)
+    if (A.image_f32) {
+        const float* src = A.image_f32 + (rowpix + s0) * 3;
+        const int nq = (w & 3) == 0 ? ns / 4 : 0;  // (rowpix + s0) % 4 == 0 -> 16-byte aligned groups of 4 pixels
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        for (int i = tid; i < nq; i += PT_THREADS) {
+            float4 v0 = s4[3 * i], v1 = s4[3 * i + 1], v2 = s4[3 * i + 2];
+            float f[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+            uint32_t pk[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t r = (uint32_t)(int)fminf(fmaxf(f[3 * k] * 255.0f, 0.0f), 255.0f);
+                uint32_t g = (uint32_t)(int)fminf(fmaxf(f[3 * k + 1] * 255.0f, 0.0f), 255.0f);
+                uint32_t b = (uint32_t)(int)fminf(fmaxf(f[3 * k + 2] * 255.0f, 0.0f), 255.0f);
+                pk[k] = r | (g << 8) | (b << 16);
+            }
+            reinterpret_cast<uint4*>(img)[i] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+        for (int j = 4 * nq + tid; j < ns; j += PT_THREADS) {
+            uint32_t r = (uint32_t)(int)fminf(fmaxf(src[3 * j] * 255.0f, 0.0f), 255.0f);
+            uint32_t g = (uint32_t)(int)fminf(fmaxf(src[3 * j + 1] * 255.0f, 0.0f), 255.0f);
+            uint32_t b = (uint32_t)(int)fminf(fmaxf(src[3 * j + 2] * 255.0f, 0.0f), 255.0f);
+            img[j] = r | (g << 8) | (b << 16);
+        }
+    } else {
+        const uint8_t* src = A.image_u8 + (rowpix + s0) * 3;
+        for (int j = tid; j < ns; j += PT_THREADS)
+            img[j] = (uint32_t)src[3 * j] | ((uint32_t)src[3 * j + 1] << 8) | ((uint32_t)src[3 * j + 2] << 16);
+    }
+    const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
+    const float* drow = E.depth + rowpix;
+    __syncthreads();  // tables ready
+    if (E.enabled) {
+        const float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
+        const bool flat = dmax == dmin;
+        const float range = dmax - dmin;
+        for (int j = tid; j < ns; j += PT_THREADS) {
+            float d = drow[s0 + j] * scale;
+            float nd = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
+            float sgn = nd >= 0.0f ? 1.0f : -1.0f;
+            float pw = csm::powf_exact(fabsf(nd), A.e32, tabs);
+            float cdj = (sgn * pw) * E.div32;                                     // coord_d   (:1926)
+            float x = ((float)(s0 + j) + 0.5f + cdj) + E.sep32;                   // coord_x   (:1927)
+            float z = fabsf(cdj);
+            if (SHARP) {
+                px[1 + 2 * j] = x - (float)0.45; pz[1 + 2 * j] = z;
+                px[2 + 2 * j] = x + (float)0.45; pz[2 + 2 * j] = z;
+            } else {
+                px[1 + j] = x; pz[1 + j] = z;
+            }
+        }
+        if (tid == 0) {
+            px[0] = (float)(-1.0 * w); pz[0] = 0.0f;
+            px[npts - 1] = (float)(2.0 * w); pz[npts - 1] = 0.0f;
+        }
+    }
+    __syncthreads();
+
+    if (A.dbg == 11) return;
+    const bool left_edge = s0 == 0, right_edge = s1 == w;
+    bool hazard = false;
+
+    if (E.enabled) {
+        // ---- REGISTER points and forward segments into the per-pixel slot lists ------------------
+        const int ofirst = left_edge ? 0 : 1, olast = right_edge ? npts - 1 : npts - 2;
+        const int niter = (olast - ofirst + 1 + PT_THREADS - 1) / PT_THREADS;
+        for (int it = 0; it < niter; it++) {
+            const int o = ofirst + it * PT_THREADS + tid;
+            const bool live = o <= olast;
+            int p0 = 1, p1 = 0;
+            if (live) {
+                const float x0 = px[o];
+                if (x0 >= (float)o0 && x0 < (float)(o0 + wt)) {
+                    int q = (int)x0 - o0;
+                    unsigned idx = atomicAdd(&cnt[q], 1u) & 0xffffu;
+                    if (idx < PT_KP) pts[q * PT_KP + idx] = (uint16_t)o;
+                    else hazard = true;
+                }
+                if (o < olast) {  // segment o -> o+1
+                    const float x1 = px[o + 1];
+                    if (x0 < x1) {  // reversed / degenerate segments are never active
+                        float f0 = floorf(x0), f1 = floorf(x1);
+                        if (!(f1 < (float)o0 || f0 > (float)(o0 + wt - 1))) {
+                            p0 = f0 < (float)o0 ? o0 : (int)f0;
+                            p1 = f1 > (float)(o0 + wt - 1) ? o0 + wt - 1 : (int)f1;
+                        }
+                    }
+                }
+            }
+            const bool is_long = p1 - p0 > 3;
+            if (p0 <= p1 && !is_long) {
+                for (int p = p0; p <= p1; p++) {
+                    unsigned idx = atomicAdd(&cnt[p - o0], 0x10000u) >> 16;
+                    if (idx < PT_KS) sgs[(p - o0) * PT_KS + idx] = (uint16_t)o;
+                    else hazard = true;
+                }
+            }
+            // long segments (disocclusion bridges): the whole wave writes them, 64 pixels per step
+            unsigned long long m = __ballot(is_long);
+            while (m) {
+                int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                int lp0 = __shfl(p0, src), lp1 = __shfl(p1, src), lo = __shfl(o, src);
+                for (int p = lp0 + lane; p <= lp1; p += 64) {
+                    unsigned idx = atomicAdd(&cnt[p - o0], 0x10000u) >> 16;
+                    if (idx < PT_KS) sgs[(p - o0) * PT_KS + idx] = (uint16_t)lo;
+                    else hazard = true;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    if (A.dbg == 12) return;
+    // ---- EVALUATE one output pixel per lane -------------------------------------------------------
+    for (int q = tid; q < wt; q += PT_THREADS) {
+        const int col = o0 + q;
+        uint32_t rgb;
+        if (!E.enabled) {
+            rgb = img[col - s0];
+        } else {
+            const unsigned c = cnt[q];
+            const int np = min((int)(c & 0xffffu), PT_KP), nsg = min((int)(c >> 16), PT_KS);
+            // wave-uniform bounds: unrolled bodies beyond them are skipped by scalar branches
+            int wnp = np, wns = nsg;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                wnp = max(wnp, __shfl_xor(wnp, off));
+                wns = max(wns, __shfl_xor(wns, off));
+            }
+            wnp = __builtin_amdgcn_readfirstlane(wnp);
+            wns = __builtin_amdgcn_readfirstlane(wns);
+            // the pixel's points sorted by (x, id) == the reference's stable insertion sort inside the pixel
+            float xs[PT_KP];
+            int os[PT_KP];
+#pragma unroll
+            for (int k = 0; k < PT_KP; k++) { xs[k] = INFINITY; os[k] = 0x7fffffff; }
+#pragma unroll
+            for (int k = 0; k < PT_KP; k++) {
+                if (k < wnp) {
+                    int o = k < np ? (int)pts[q * PT_KP + k] : 0x7fffffff;
+                    float x = k < np ? px[o] : INFINITY;
+#pragma unroll
+                    for (int m2 = 0; m2 <= k; m2++) {
+                        bool lt = x < xs[m2] || (x == xs[m2] && o < os[m2]);
+                        float tx = lt ? xs[m2] : x; int to = lt ? os[m2] : o;
+                        xs[m2] = lt ? x : xs[m2]; os[m2] = lt ? o : os[m2];
+                        x = tx; o = to;
+                    }
+                }
+            }
+            // forward segments overlapping this pixel
+            float sx0[PT_KS], sx1[PT_KS];
+            int so[PT_KS];
+#pragma unroll
+            for (int k = 0; k < PT_KS; k++) { so[k] = 0; sx0[k] = INFINITY; sx1[k] = -INFINITY; }
+#pragma unroll
+            for (int k = 0; k < PT_KS; k++) {
+                if (k < wns && k < nsg) {
+                    so[k] = (int)sgs[q * PT_KS + k];
+                    sx0[k] = px[so[k]];
+                    sx1[k] = px[so[k] + 1];
+                }
+            }
+            float color0 = 0.5f, color1 = 0.5f, color2 = 0.5f;
+            float prev = (float)col, a = -INFINITY;
+            for (int k = 0; k <= np; k++) {
+                float b = INFINITY;
+#pragma unroll
+                for (int m2 = 0; m2 < PT_KP; m2++) b = (m2 == k && k < np) ? xs[m2] : b;
+                TSub s = pt_subinterval(col, a, b);
+                a = b;
+                if (s.center < prev || s.center > (float)(col + 1)) hazard = true;
+                prev = s.center;
+                if (s.sig64 ? s.sig_d == 0.0 : s.sig_f == 0.0f) continue;  // adds exactly nothing
+                int nact = 0, pick = -1;
+#pragma unroll
+                for (int e = 0; e < PT_KS; e++) {
+                    if (e < wns) {
+                        bool act = (sx0[e] < s.center) && !(sx1[e] < s.center);
+                        nact += act ? 1 : 0;
+                        pick = act ? e : pick;
+                    }
+                }
+                if (nact != 1) {
+                    int nqual = 0, best = -1;
+                    float bc = (float)(-1e-7);
+                    bool tie = false;
+#pragma unroll
+                    for (int e = 0; e < PT_KS; e++) {
+                        if (e < wns) {
+                            bool act = (sx0[e] < s.center) && !(sx1[e] < s.center);
+                            if (act) {
+                                float ip_k = (s.center - sx0[e]) / (sx1[e] - sx0[e]);
+                                if (0.0f < ip_k && ip_k < 1.0f) {
+                                    float cl = (1.0f - ip_k) * pz[so[e]] + ip_k * pz[so[e] + 1];
+                                    nqual++;
+                                    if (bc < cl) { bc = cl; best = e; tie = false; }
+                                    else if (cl == bc) tie = true;
+                                }
+                            }
+                        }
+                    }
+                    if (nqual == 0 || tie) hazard = true;
+                    pick = best >= 0 ? best : pick;
+                }
+                if (pick < 0) continue;
+                // colour contribution (reference :1981-1989, D32 typing)
+                float x0 = 0.0f, x1 = 0.0f;
+                int o = 0;
+#pragma unroll
+                for (int e = 0; e < PT_KS; e++)
+                    if (e < wns && e == pick) { x0 = sx0[e]; x1 = sx1[e]; o = so[e]; }
+                const int jl = min(max(SHARP ? (o - 1) >> 1 : o - 1, 0), ns - 1);
+                const int jr = min(max(SHARP ? o >> 1 : o, 0), ns - 1);
+                const uint32_t il = img[jl];
+                const float l0 = (float)(il & 0xff), l1 = (float)((il >> 8) & 0xff), l2 = (float)((il >> 16) & 0xff);
+                if (jl == jr) {
+                    if (s.sig64) {
+                        color0 = (float)((double)color0 + (double)l0 * s.sig_d);
+                        color1 = (float)((double)color1 + (double)l1 * s.sig_d);
+                        color2 = (float)((double)color2 + (double)l2 * s.sig_d);
+                    } else {
+                        color0 = color0 + l0 * s.sig_f;
+                        color1 = color1 + l1 * s.sig_f;
+                        color2 = color2 + l2 * s.sig_f;
+                    }
+                } else {
+                    const uint32_t ir = img[jr];
+                    const float r0 = (float)(ir & 0xff), r1 = (float)((ir >> 8) & 0xff), r2 = (float)((ir >> 16) & 0xff);
+                    float ip_k = (s.center - x0) / (x1 - x0);
+                    float om = 1.0f - ip_k;
+                    float sg = s.sig64 ? (float)s.sig_d : s.sig_f;
+                    color0 = color0 + (l0 * om + r0 * ip_k) * sg;
+                    color1 = color1 + (l1 * om + r1 * ip_k) * sg;
+                    color2 = color2 + (l2 * om + r2 * ip_k) * sg;
+                }
+            }
+            rgb = (uint32_t)csm::f32_to_u8_wrap(color0) | ((uint32_t)csm::f32_to_u8_wrap(color1) << 8) |
+                  ((uint32_t)csm::f32_to_u8_wrap(color2) << 16);
+        }
+        res[3 * q] = (uint8_t)rgb; res[3 * q + 1] = (uint8_t)(rgb >> 8); res[3 * q + 2] = (uint8_t)(rgb >> 16);
+    }
+    if (hazard) flags[0] = 1;
+    __syncthreads();
+    if (flags[0]) {
+        // the general kernel redoes this row (both eyes) and overwrites whatever is stored below
+        if (tid == 0) A.rowflag[(size_t)frame * h + row] = 1;
+    }
+    if (A.dbg == 13) return;
+    // ---- store the tile ------------------------------------------------------------------------------
+    if (A.out_u8) {
+        uint8_t* dst = A.out_u8 + (rowpix + o0) * 3;
+        for (int i = tid; i < 3 * wt; i += PT_THREADS) dst[i] = res[i];
+    } else {
+        const size_t o = ((size_t)frame * A.out_h + row + E.yoff) * A.out_w + E.xoff + o0;
+        float* dst = A.stereo + o * 3;
+        if ((wt & 3) == 0 && (w & 3) == 0) {
+            float4* d4 = reinterpret_cast<float4*>(dst);
+            for (int i = tid; i < (3 * wt) / 4; i += PT_THREADS) {
+                uint32_t pk = reinterpret_cast<const uint32_t*>(res)[i];
+                d4[i] = make_float4(lut[pk & 0xff], lut[(pk >> 8) & 0xff], lut[(pk >> 16) & 0xff], lut[pk >> 24]);
+            }
+        } else {
+            for (int i = tid; i < 3 * wt; i += PT_THREADS) dst[i] = lut[res[i]];
+        }
+        float* m = A.mask + o;
+        for (int q = tid; q < wt; q += PT_THREADS)
+            m[q] = ((int)res[3 * q] + (int)res[3 * q + 1] + (int)res[3 * q + 2]) == 0 ? 1.0f : 0.0f;
+        // this eye's depth-map output for the tile ((depth*255).astype(uint8) wraps, quirk Q7)
+        float* dd = (eyei == 0 ? A.depth_l : A.depth_r);
+        if (dd) {
+            dd += (rowpix + o0) * 3;
+            for (int q = tid; q < wt; q += PT_THREADS) {
+                float v = lut[csm::f32_to_u8_wrap((drow[o0 + q] * scale) * 255.0f)];
+                dd[3 * q] = v; dd[3 * q + 1] = v; dd[3 * q + 2] = v;
+            }
+        }
+    }
+}
+
+static size_t polytile_lds(int S, int sharp, int PT_KP, int PT_KS) {
+    int nsmax = PT_T + 2 * S + 6;
+    int nptmax = (sharp ? 2 * nsmax : nsmax) + 2;
+    return 1024 + align16(sizeof(csm::PowfTables)) + 2 * 4 * (size_t)((nptmax + 3) & ~3) + 4 * (size_t)((nsmax + 3) & ~3) +
+           4 * PT_T + 2 * PT_T * (PT_KP + PT_KS) + align16(3 * PT_T) + 64;
+}
+
+// Largest halo the tiled path accepts: beyond this the staged range dwarfs the tile and the row kernel wins.
+int polytile_max_halo() { return PT_T / 2; }
+
+// Launch the tiled fast path for the eyes of `A0` (SBS / TB / single-eye / uint8 outputs; no anaglyph).
+// `rowflag` must be zeroed by the caller; afterwards the general kernel is run over the flagged rows.
+hipError_t launch_polytile(int sharp, const RowArgs& R, int S, uint8_t* rowflag, hipStream_t stream) {
+    PolyTileArgs A;
+    A.n = R.n; A.h = R.h; A.w = R.w; A.S = S;
+    A.image_f32 = R.image_f32; A.image_u8 = R.image_u8;
+    A.stats = R.stats; A.stats_rw = R.stats_rw;
+    A.scale_from_stats = R.scale_from_stats;
+    A.e32 = R.e32; A.conv32 = R.conv32;
+    A.eye[0] = R.eye[0]; A.eye[1] = R.eye[1];
+    A.neyes = R.neyes; A.single = R.neyes == 1 ? 0 : R.single;
+    A.out_u8 = R.out_u8; A.stereo = R.stereo; A.mask = R.mask; A.depth_l = R.depth_l; A.depth_r = R.depth_r;
+    A.out_h = R.out_h; A.out_w = R.out_w;
+    A.rowflag = rowflag;
+    A.dbg = R.dbg;
+    const int tiles = (A.w + PT_T - 1) / PT_T;
+    dim3 grid(tiles * A.h, A.n, A.single >= 0 ? 1 : 2), block(PT_THREADS);
+    const char* ev = getenv("CS_PT_VARIANT");
+    const int variant = ev ? atoi(ev) : 0;
+#define PT_LAUNCH(SH, KP, KS, MW)                                                                                   \
+    {                                                                                                               \
+        size_t lds = polytile_lds(S, SH, KP, KS);                                                                   \
+        hipError_t e = hipFuncSetAttribute((const void*)k_polytile<SH, KP, KS, MW>,                                 \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+        if (e != hipSuccess) return e;                                                                              \
+        hipLaunchKernelGGL((k_polytile<SH, KP, KS, MW>), grid, block, lds, stream, A);                              \
+    }
+    if (sharp) PT_LAUNCH(1, 6, 8, 4)
+    else if (variant == 1) PT_LAUNCH(0, 6, 8, 6)
+    else if (variant == 5) PT_LAUNCH(0, 3, 4, 8)
+    else PT_LAUNCH(0, 4, 6, 6)
+#undef PT_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace cs

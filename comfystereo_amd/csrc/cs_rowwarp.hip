@@ -736,9 +736,11 @@ __global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int row = blockIdx.x, frame = blockIdx.y;
     const int w = A.w, h = A.h;
+    if (A.only_flagged && !A.only_flagged[(size_t)frame * h + row]) return;
     Lds L = carve(smem, FILL, w, A.anaglyph);
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
     uint32_t* st_rw = A.stats_rw ? A.stats_rw + (size_t)frame * ST_WORDS : nullptr;
+    if (A.only_flagged && st_rw && tid == 0) atomicAdd(&st_rw[ST_TILE_REDO_ROWS], 1u);
     constexpr bool DIRECT = !fill_uses_res(FILL);  // the technique emits pixels itself
 
     // constants into LDS

@@ -30,7 +30,7 @@ p = engine.make_params(a.n, a.h, a.w, a.h, a.w, 3, a.fill, a.mode, a.div, 0.0, 0
 plan = engine.Plan(p, dev)
 plan.run(img, depth); torch.cuda.synchronize()
 st = plan.stats()
-print("fallback rows per frame:", st[:, 10].tolist(), "error flags:", st[:, 9].tolist())
+print("seq-fallback rows:", st[:, 10].tolist(), "tile-redo rows:", st[:, 11].tolist(), "errors:", st[:, 9].tolist())
 t0 = time.perf_counter()
 for _ in range(a.iters):
     plan.run(img, depth)
