@@ -33,12 +33,8 @@ __global__ void k_stats_init(uint32_t* stats, int n) {
 }
 
 __device__ __forceinline__ void block_minmax_commit(float mn, float mx, uint32_t* st_min, uint32_t* st_max) {
-    mn = wave_min(mn);
-    mx = wave_max(mx);
-    if (lane_id() == 0) {
-        atomicMin(st_min, csm::f2ord(mn));
-        atomicMax(st_max, csm::f2ord(mx));
-    }
+    __shared__ float red[2 * 16];
+    block_minmax_update(mn, mx, st_min, st_max, red);
 }
 
 // gray = (0.2989 R + 0.5870 G) + 0.1140 B with separate float32 roundings (GenerateStereo.py:134-139,

@@ -14,6 +14,7 @@
 // through the libm-exact powf and only approximate torch's vectorised pow.
 #include "cs_common.h"
 #include "cs_kernels.h"
+#include <stdlib.h>
 
 namespace cs {
 
@@ -28,6 +29,7 @@ struct BlurArgs {
     float fall32;
     float* wl; float* wr;  // [n][h][w]
     float* out_l; float* out_r;
+    int dbg;  // development only (env CS_DBG)
 };
 
 __constant__ csm::PowfTables c_blur_powf_tables = CS_POWF_TABLES_INIT;
@@ -166,13 +168,199 @@ __global__ void __launch_bounds__(256) k_blur_apply(BlurArgs A) {
         rmin = fminf(rmin, orr); rmax = fmaxf(rmax, orr);
     }
     if (A.stats_rw) {
+        __shared__ float red[2 * 16];
         uint32_t* st = A.stats_rw + frame * ST_WORDS;
-        lmin = wave_min(lmin); lmax = wave_max(lmax); rmin = wave_min(rmin); rmax = wave_max(rmax);
-        if (lane_id() == 0) {
-            atomicMin(&st[ST_L_MIN], csm::f2ord(lmin)); atomicMax(&st[ST_L_MAX], csm::f2ord(lmax));
-            atomicMin(&st[ST_R_MIN], csm::f2ord(rmin)); atomicMax(&st[ST_R_MAX], csm::f2ord(rmax));
+        block_minmax_update(lmin, lmax, &st[ST_L_MIN], &st[ST_L_MAX], red);
+        block_minmax_update(rmin, rmax, &st[ST_R_MIN], &st[ST_R_MAX], red);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused single-kernel blur (the default whenever its tiles fit in LDS; the two-pass kernels above
+// are the general fallback for very wide kernels).  One 256-thread workgroup produces a 64 x 32
+// tile of both outputs from ONE staged depth tile:
+//   1. depth tile with halos (rows +-(v+1), cols +-(R+1), zero outside the frame) -> LDS
+//   2. Sobel-x + edge tests for every (weight row, column in +-R); the two edge masks of a row are
+//      built 64 columns at a time with wave ballots and kept as bit rows in LDS
+//   3. nearest-edge distance = clz/ctz on the bit row (only edges closer than R can give a non-zero
+//      weight, so a +-R window is exact), weight = clamp(1 - d/R, 0, 1) ** falloff -> LDS
+//   4. vertical (2v+1) box of the weights and k-tap box of the depth as fmaf chains (8 independent
+//      chains per lane, operands fetched 8 at a time), blend, store, per-frame min/max.
+// The weight maps never exist in HBM: traffic per pixel is ~10 B read + 8 B written.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mask_dist_left(const unsigned long long* m, int p) {
+    // distance from bit p to the nearest set bit at or below p, or -1
+    int wi = p >> 6;
+    unsigned long long cur = m[wi] & (~0ull >> (63 - (p & 63)));
+    while (true) {
+        if (cur) return p - (wi * 64 + 63 - __clzll((long long)cur));
+        if (--wi < 0) return -1;
+        cur = m[wi];
+    }
+}
+__device__ __forceinline__ int mask_dist_right(const unsigned long long* m, int nw, int p) {
+    int wi = p >> 6;
+    unsigned long long cur = m[wi] & (~0ull << (p & 63));
+    while (true) {
+        if (cur) return wi * 64 + __ffsll((long long)cur) - 1 - p;
+        if (++wi >= nw) return -1;
+        cur = m[wi];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_blur_fused(BlurArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * BLUR_TW, y0 = blockIdx.y * BLUR_TR, frame = blockIdx.z;
+    const int w = A.w, h = A.h, v = A.vert, bs = A.bs, pad = A.bs / 2, R = A.radius;
+    const int WR = BLUR_TR + 2 * v;          // weight rows: frame rows y0 - v ..
+    const int EW = BLUR_TW + 2 * R;          // edge columns: frame cols x0 - R ..
+    const int DR = WR + 2, DC = EW + 2;      // depth tile: rows y0 - v - 1 .., cols x0 - R - 1 ..
+    const int NW = (EW + 63) >> 6;           // 64-bit words per mask row
+    float* D = (float*)smem;                                   // [DR][DC]
+    float* wlt = D + ((DR * DC + 3) & ~3);                     // [WR][TW]
+    float* wrt = wlt + WR * BLUR_TW;                           // [WR][TW]
+    unsigned long long* mL = (unsigned long long*)(wrt + WR * BLUR_TW);  // [WR][NW]
+    unsigned long long* mR = mL + WR * NW;                     // [WR][NW]
+    csm::PowfTables* T = (csm::PowfTables*)(mR + WR * NW);
+    if (A.fall_mode == 4) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_blur_powf_tables);
+        for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += 256) reinterpret_cast<uint32_t*>(T)[i] = src[i];
+    }
+    const float scale = (A.stats && A.stats[frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
+    const float* d = A.depth + (size_t)frame * h * w;
+    for (int r = wave; r < DR; r += 4) {  // one wave per tile row: coalesced, no index division
+        const int yy = y0 - v - 1 + r;
+        const bool rowok = yy >= 0 && yy < h;
+        const float* drow = d + (size_t)(rowok ? yy : 0) * w;
+        for (int c = lane; c < DC; c += 64) {
+            const int xx = x0 - R - 1 + c;
+            D[r * DC + c] = (rowok && xx >= 0 && xx < w) ? drow[xx] * scale : 0.0f;
         }
     }
+    __syncthreads();
+    if (A.dbg == 21) return;
+    // 2. edge masks, one (row, 64-column chunk) per wave step
+    for (int item = wave; item < WR * NW; item += 4) {
+        const int r = item / NW, ch = item - r * NW;
+        const int e = ch * 64 + lane;                 // edge column index, frame col x0 - R + e
+        const int yy = y0 - v + r, xx = x0 - R + e;
+        bool le = false, re = false;
+        if (e < EW && yy >= 0 && yy < h && xx >= 0 && xx < w) {
+            const float* p = D + r * DC + e;          // D row r is frame row yy - 1; column e is frame col xx - 1
+            float g = 0.0f;
+            g = fmaf(-1.0f, p[0], g); g = fmaf(1.0f, p[2], g);
+            g = fmaf(-2.0f, p[DC], g); g = fmaf(2.0f, p[DC + 2], g);
+            g = fmaf(-1.0f, p[2 * DC], g); g = fmaf(1.0f, p[2 * DC + 2], g);
+            float es = fminf(fmaxf(fabsf(g) / A.den, 0.0f), 1.0f);
+            le = (g > 0.0f) && (es > 0.5f);
+            re = (g < 0.0f) && (es > 0.5f);
+        }
+        unsigned long long bl = __ballot(le), br = __ballot(re);
+        if (lane == 0) { mL[item] = bl; mR[item] = br; }
+    }
+    __syncthreads();
+    if (A.dbg == 22) return;
+    // 3. weights from the bit rows
+    const float large = (float)(R + 1), rad = (float)R;
+    for (int i = tid; i < WR * BLUR_TW; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const int yy = y0 - v + r;
+        float wl = 0.0f, wr = 0.0f;
+        if (yy >= 0 && yy < h && x0 + c < w) {
+            const int p = c + R;
+            // an edge at distance >= R gives clamp(1 - d/R) == 0 exactly, like "no edge" (large = R + 1)
+            int a = mask_dist_left(mL + r * NW, p), b = mask_dist_right(mL + r * NW, NW, p);
+            int dmin = min(a >= 0 ? a : R + 1, b >= 0 ? b : R + 1);
+            float t = dmin < R ? 1.0f - (float)dmin / rad : 0.0f;
+            wl = falloff_pow(fminf(fmaxf(t, 0.0f), 1.0f), A.fall_mode, A.fall32, T);
+            a = mask_dist_left(mR + r * NW, p); b = mask_dist_right(mR + r * NW, NW, p);
+            dmin = min(a >= 0 ? a : R + 1, b >= 0 ? b : R + 1);
+            t = dmin < R ? 1.0f - (float)dmin / rad : 0.0f;
+            wr = falloff_pow(fminf(fmaxf(t, 0.0f), 1.0f), A.fall_mode, A.fall32, T);
+        }
+        wlt[i] = wl; wrt[i] = wr;
+    }
+    __syncthreads();
+    if (A.dbg == 23) return;
+    // 4. boxes + blend: lane = column tx, 8 consecutive rows
+    const int tx = tid & 63, ty = tid >> 6;
+    const int x = x0 + tx;
+    const float kb = 1.0f / (float)bs, kv = 1.0f / (float)(2 * v + 1);
+    float a8[8], b8[8], acc[8];
+    const int rbase = ty * 8;
+    if (v > 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) { a8[j] = 0.0f; b8[j] = 0.0f; }
+        const int nv = 2 * v + 1;
+        for (int k0 = 0; k0 < nv; k0 += 8) {
+            float vl[15], vr[15];
+#pragma unroll
+            for (int i = 0; i < 15; i++) {
+                int rr = rbase + k0 + i;
+                bool ok = rr < WR;
+                vl[i] = ok ? wlt[rr * BLUR_TW + tx] : 0.0f;
+                vr[i] = ok ? wrt[rr * BLUR_TW + tx] : 0.0f;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) {
+                if (k0 + kk < nv) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        a8[j] = fmaf(kv, vl[j + kk], a8[j]);
+                        b8[j] = fmaf(kv, vr[j + kk], b8[j]);
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) { a8[j] = wlt[(rbase + j) * BLUR_TW + tx]; b8[j] = wrt[(rbase + j) * BLUR_TW + tx]; }
+    }
+    if (A.dbg == 24) return;
+    // horizontal box: depth row of output row r is D row r + v + 1; tap k of column tx is D column tx + R + 1 - pad + k
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.0f;
+    const float* dbase = D + (rbase + v + 1) * DC + tx + R + 1 - pad;
+    for (int k0 = 0; k0 < bs; k0 += 8) {
+        float dv[8][8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) dv[j][kk] = (k0 + kk < bs) ? dbase[j * DC + k0 + kk] : 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+            if (k0 + kk < bs) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] = fmaf(kb, dv[j][kk], acc[j]);
+            }
+        }
+    }
+    float lmin = INFINITY, lmax = -INFINITY, rmin = INFINITY, rmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int y = y0 + rbase + j;
+        if (y < h && x < w) {
+            float dvv = dbase[j * DC + pad];
+            float ol = a8[j] * acc[j] + (1.0f - a8[j]) * dvv;
+            float orr = b8[j] * acc[j] + (1.0f - b8[j]) * dvv;
+            A.out_l[((size_t)frame * h + y) * w + x] = ol;
+            A.out_r[((size_t)frame * h + y) * w + x] = orr;
+            lmin = fminf(lmin, ol); lmax = fmaxf(lmax, ol);
+            rmin = fminf(rmin, orr); rmax = fmaxf(rmax, orr);
+        }
+    }
+    if (A.stats_rw) {
+        __shared__ float red[2 * 16];
+        uint32_t* st = A.stats_rw + frame * ST_WORDS;
+        block_minmax_update(lmin, lmax, &st[ST_L_MIN], &st[ST_L_MAX], red);
+        block_minmax_update(rmin, rmax, &st[ST_R_MIN], &st[ST_R_MAX], red);
+    }
+}
+
+static size_t blur_fused_lds(int v, int R) {
+    int WR = BLUR_TR + 2 * v, EW = BLUR_TW + 2 * R, DR = WR + 2, DC = EW + 2, NW = (EW + 63) >> 6;
+    return (size_t)((DR * DC + 3) & ~3) * 4 + 2 * (size_t)WR * BLUR_TW * 4 + 2 * (size_t)WR * NW * 8 + sizeof(csm::PowfTables) + 64;
 }
 
 int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double falloff,
@@ -190,6 +378,15 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
     A.fall32 = (float)falloff;
     A.fall_mode = falloff == 1.0 ? 0 : falloff == 0.5 ? 1 : falloff == 2.0 ? 2 : falloff == 3.0 ? 3 : falloff == 0.0 ? 5 : 4;
     A.wl = wl; A.wr = wr; A.out_l = out_l; A.out_r = out_r;
+    { const char* dbg = getenv("CS_DBG"); A.dbg = dbg ? atoi(dbg) : 0; }
+    const char* nofuse = getenv("CS_BLUR_TWO_PASS");
+    size_t ldsF = blur_fused_lds(A.vert, A.radius);
+    if (ldsF <= 64 * 1024 && A.radius >= 1 && !(nofuse && atoi(nofuse))) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_blur_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
+        if (e != hipSuccess) return CS_EHIP;
+        hipLaunchKernelGGL(k_blur_fused, dim3((w + BLUR_TW - 1) / BLUR_TW, (h + BLUR_TR - 1) / BLUR_TR, n), dim3(256), ldsF, stream, A);
+        return CS_OK;
+    }
     int threads = w <= 256 ? 256 : (w <= 1024 ? 512 : 1024);
     size_t ldsA = 4 * (size_t)w * 4 + 32 * 4 + sizeof(csm::PowfTables) + 64;
     size_t ldsB = ((size_t)(BLUR_TR + 2 * A.vert) * BLUR_TW * 2 + (size_t)BLUR_TR * (BLUR_TW + A.bs - 1)) * 4;

@@ -104,4 +104,25 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+
+// Per-frame min/max into order-preserving uint keys with as little atomic traffic as possible: thousands of
+// workgroups updating the same few words serialise in L2 (measured: 0.24 ms per 4K frame), so (1) reduce inside
+// the workgroup through LDS, (2) one lane compares against the current value (agent-scope relaxed load; a stale
+// value can only cause a redundant atomic, never a missed one, because min only falls and max only rises) and
+// (3) only then issue the atomic.  `red` is LDS scratch of 2 * (blockDim.x / 64) floats.
+__device__ __forceinline__ void block_minmax_update(float mn, float mx, uint32_t* st_min, uint32_t* st_max, float* red) {
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const int nw = blockDim.x >> 6;
+    if (lane_id() == 0) { red[2 * wave_id()] = mn; red[2 * wave_id() + 1] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < nw; i++) { mn = fminf(mn, red[2 * i]); mx = fmaxf(mx, red[2 * i + 1]); }
+        uint32_t kmn = csm::f2ord(mn), kmx = csm::f2ord(mx);
+        if (kmn < __hip_atomic_load(st_min, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(st_min, kmn);
+        if (kmx > __hip_atomic_load(st_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st_max, kmx);
+    }
+    __syncthreads();
+}
+
 }  // namespace cs
