@@ -223,6 +223,8 @@ __global__ void __launch_bounds__(256) k_blur_fused(BlurArgs A) {
     unsigned long long* mL = (unsigned long long*)(wrt + WR * BLUR_TW);  // [WR][NW]
     unsigned long long* mR = mL + WR * NW;                     // [WR][NW]
     csm::PowfTables* T = (csm::PowfTables*)(mR + WR * NW);
+    int* any_edge = (int*)(T + 1);
+    if (tid == 0) *any_edge = 0;
     if (A.fall_mode == 4) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_blur_powf_tables);
         for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += 256) reinterpret_cast<uint32_t*>(T)[i] = src[i];
@@ -257,9 +259,32 @@ __global__ void __launch_bounds__(256) k_blur_fused(BlurArgs A) {
             re = (g < 0.0f) && (es > 0.5f);
         }
         unsigned long long bl = __ballot(le), br = __ballot(re);
-        if (lane == 0) { mL[item] = bl; mR[item] = br; }
+        if (lane == 0) {
+            mL[item] = bl; mR[item] = br;
+            if (bl | br) *any_edge = 1;
+        }
     }
     __syncthreads();
+    if (*any_edge == 0 && A.fall_mode != 5) {
+        // no edge anywhere in the halo'ed tile: every weight is exactly 0, so 0*blur + (1-0)*depth == depth
+        float mn = INFINITY, mx = -INFINITY;
+        for (int i = tid; i < BLUR_TR * BLUR_TW; i += 256) {
+            const int r = i >> 6, c = i & 63, y = y0 + r, x = x0 + c;
+            if (y < h && x < w) {
+                float dvv = D[(r + v + 1) * DC + c + R + 1];
+                A.out_l[((size_t)frame * h + y) * w + x] = dvv;
+                A.out_r[((size_t)frame * h + y) * w + x] = dvv;
+                mn = fminf(mn, dvv); mx = fmaxf(mx, dvv);
+            }
+        }
+        if (A.stats_rw) {
+            __shared__ float red2[2 * 16];
+            uint32_t* st = A.stats_rw + frame * ST_WORDS;
+            block_minmax_update(mn, mx, &st[ST_L_MIN], &st[ST_L_MAX], red2);
+            block_minmax_update(mn, mx, &st[ST_R_MIN], &st[ST_R_MAX], red2);
+        }
+        return;
+    }
     if (A.dbg == 22) return;
     // 3. weights from the bit rows
     const float large = (float)(R + 1), rad = (float)R;

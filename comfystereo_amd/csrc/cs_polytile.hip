@@ -285,77 +285,97 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
             }
             float color0 = 0.5f, color1 = 0.5f, color2 = 0.5f;
             float prev = (float)col, a = -INFINITY;
-            for (int k = 0; k <= np; k++) {
+            // per-pixel constants of the float64 ("Python float") branch of the sub-interval arithmetic
+            const double from_d = (double)col + 1e-7, to_d = (double)(col + 1) - 1e-7;
+            const double sig_dd = to_d - from_d;
+            const float ff64 = (float)from_d, tf64 = (float)to_d, center64 = (float)(from_d + 0.5 * sig_dd);
+            const float eps32 = (float)1e-7;
+            for (int k = 0; k <= wnp; k++) {   // wave-uniform trip count; lanes with k > np idle
+                const bool live = k <= np;
                 float b = INFINITY;
 #pragma unroll
                 for (int m2 = 0; m2 < PT_KP; m2++) b = (m2 == k && k < np) ? xs[m2] : b;
-                TSub s = pt_subinterval(col, a, b);
-                a = b;
-                if (s.center < prev || s.center > (float)(col + 1)) hazard = true;
-                prev = s.center;
-                if (s.sig64 ? s.sig_d == 0.0 : s.sig_f == 0.0f) continue;  // adds exactly nothing
+                // sub-interval [max(col, a), min(col+1, b)] shrunk by EPSILON (reference :1957-1960, D32 typing)
+                const bool from64 = !(a > (float)col), to64 = !(b < (float)(col + 1));
+                const bool sig64 = from64 && to64;
+                const float ff = from64 ? ff64 : a + eps32;
+                const float tf = to64 ? tf64 : b - eps32;
+                const float sig_f = tf - ff;
+                const float center = sig64 ? center64 : ff + 0.5f * sig_f;
+                a = live ? b : a;
+                if (live && (center < prev || center > (float)(col + 1))) hazard = true;
+                prev = live ? center : prev;
+                const bool work = live && (sig64 ? sig_dd != 0.0 : sig_f != 0.0f);  // a zero-length piece adds exactly 0
                 int nact = 0, pick = -1;
 #pragma unroll
                 for (int e = 0; e < PT_KS; e++) {
                     if (e < wns) {
-                        bool act = (sx0[e] < s.center) && !(sx1[e] < s.center);
+                        bool act = (sx0[e] < center) && !(sx1[e] < center);
                         nact += act ? 1 : 0;
                         pick = act ? e : pick;
                     }
                 }
-                if (nact != 1) {
-                    int nqual = 0, best = -1;
-                    float bc = (float)(-1e-7);
-                    bool tie = false;
+                if (__any(work && nact != 1)) {
+                    // overlapping layers (or none): the reference picks the largest interpolated |disparity|
+                    // among candidates with 0 < ip_k < 1, first one on ties -> ties are order-dependent: flag.
+                    if (work && nact != 1) {
+                        int nqual = 0, best = -1;
+                        float bc = (float)(-1e-7);
+                        bool tie = false;
 #pragma unroll
-                    for (int e = 0; e < PT_KS; e++) {
-                        if (e < wns) {
-                            bool act = (sx0[e] < s.center) && !(sx1[e] < s.center);
-                            if (act) {
-                                float ip_k = (s.center - sx0[e]) / (sx1[e] - sx0[e]);
-                                if (0.0f < ip_k && ip_k < 1.0f) {
-                                    float cl = (1.0f - ip_k) * pz[so[e]] + ip_k * pz[so[e] + 1];
-                                    nqual++;
-                                    if (bc < cl) { bc = cl; best = e; tie = false; }
-                                    else if (cl == bc) tie = true;
+                        for (int e = 0; e < PT_KS; e++) {
+                            if (e < wns) {
+                                bool act = (sx0[e] < center) && !(sx1[e] < center);
+                                if (act) {
+                                    float ip_k = (center - sx0[e]) / (sx1[e] - sx0[e]);
+                                    if (0.0f < ip_k && ip_k < 1.0f) {
+                                        float cl = (1.0f - ip_k) * pz[so[e]] + ip_k * pz[so[e] + 1];
+                                        nqual++;
+                                        if (bc < cl) { bc = cl; best = e; tie = false; }
+                                        else if (cl == bc) tie = true;
+                                    }
                                 }
                             }
                         }
+                        if (nqual == 0 || tie) hazard = true;
+                        pick = best >= 0 ? best : pick;
                     }
-                    if (nqual == 0 || tie) hazard = true;
-                    pick = best >= 0 ? best : pick;
                 }
-                if (pick < 0) continue;
-                // colour contribution (reference :1981-1989, D32 typing)
-                float x0 = 0.0f, x1 = 0.0f;
-                int o = 0;
+                const bool contrib = work && pick >= 0;
+                // colour contribution (reference :1981-1989, D32 typing); idle lanes compute on dummy operands
+                float x0 = 0.0f, x1 = 1.0f;
+                int o = 1;
 #pragma unroll
                 for (int e = 0; e < PT_KS; e++)
-                    if (e < wns && e == pick) { x0 = sx0[e]; x1 = sx1[e]; o = so[e]; }
+                    if (e < wns) { bool hit = e == pick; x0 = hit ? sx0[e] : x0; x1 = hit ? sx1[e] : x1; o = hit ? so[e] : o; }
                 const int jl = min(max(SHARP ? (o - 1) >> 1 : o - 1, 0), ns - 1);
                 const int jr = min(max(SHARP ? o >> 1 : o, 0), ns - 1);
-                const uint32_t il = img[jl];
-                const float l0 = (float)(il & 0xff), l1 = (float)((il >> 8) & 0xff), l2 = (float)((il >> 16) & 0xff);
-                if (jl == jr) {
-                    if (s.sig64) {
-                        color0 = (float)((double)color0 + (double)l0 * s.sig_d);
-                        color1 = (float)((double)color1 + (double)l1 * s.sig_d);
-                        color2 = (float)((double)color2 + (double)l2 * s.sig_d);
-                    } else {
-                        color0 = color0 + l0 * s.sig_f;
-                        color1 = color1 + l1 * s.sig_f;
-                        color2 = color2 + l2 * s.sig_f;
+                const uint32_t il = img[jl], ir = img[jr];
+                // (the compiler folds these into v_cvt_f32_ubyte0/1/2)
+                const float l0 = (float)(il & 0xffu), l1 = (float)((il >> 8) & 0xffu), l2 = (float)((il >> 16) & 0xffu);
+                const float r0 = (float)(ir & 0xffu), r1 = (float)((ir >> 8) & 0xffu), r2 = (float)((ir >> 16) & 0xffu);
+                const float ip_k = (center - x0) / (x1 - x0);
+                const float om = 1.0f - ip_k;
+                const float sg = sig64 ? (float)sig_dd : sig_f;
+                float n0 = color0 + (l0 * om + r0 * ip_k) * sg;
+                float n1 = color1 + (l1 * om + r1 * ip_k) * sg;
+                float n2 = color2 + (l2 * om + r2 * ip_k) * sg;
+                if (__any(contrib && jl == jr)) {  // segment inside one source pixel (sentinel pieces; every other 'sharp' piece)
+                    if (jl == jr) {
+                        if (sig64) {
+                            n0 = (float)((double)color0 + (double)l0 * sig_dd);
+                            n1 = (float)((double)color1 + (double)l1 * sig_dd);
+                            n2 = (float)((double)color2 + (double)l2 * sig_dd);
+                        } else {
+                            n0 = color0 + l0 * sig_f;
+                            n1 = color1 + l1 * sig_f;
+                            n2 = color2 + l2 * sig_f;
+                        }
                     }
-                } else {
-                    const uint32_t ir = img[jr];
-                    const float r0 = (float)(ir & 0xff), r1 = (float)((ir >> 8) & 0xff), r2 = (float)((ir >> 16) & 0xff);
-                    float ip_k = (s.center - x0) / (x1 - x0);
-                    float om = 1.0f - ip_k;
-                    float sg = s.sig64 ? (float)s.sig_d : s.sig_f;
-                    color0 = color0 + (l0 * om + r0 * ip_k) * sg;
-                    color1 = color1 + (l1 * om + r1 * ip_k) * sg;
-                    color2 = color2 + (l2 * om + r2 * ip_k) * sg;
                 }
+                color0 = contrib ? n0 : color0;
+                color1 = contrib ? n1 : color1;
+                color2 = contrib ? n2 : color2;
             }
             rgb = (uint32_t)csm::f32_to_u8_wrap(color0) | ((uint32_t)csm::f32_to_u8_wrap(color1) << 8) |
                   ((uint32_t)csm::f32_to_u8_wrap(color2) << 16);
