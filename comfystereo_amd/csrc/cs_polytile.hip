@@ -243,14 +243,119 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
             const unsigned c = cnt[q];
             const int np = min((int)(c & 0xffffu), PT_KP), nsg = min((int)(c >> 16), PT_KS);
             // wave-uniform bounds: unrolled bodies beyond them are skipped by scalar branches
-            int wnp = np, wns = nsg;
+            // (ballots, not shuffles: a shuffle reduction is a chain of LDS-crossbar round trips)
+            int wnp = 0, wns = 0;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                wnp = max(wnp, __shfl_xor(wnp, off));
-                wns = max(wns, __shfl_xor(wns, off));
+            for (int t = 1; t <= PT_KP; t++) wnp = __any(np >= t) ? t : wnp;
+#pragma unroll
+            for (int t = 1; t <= PT_KS; t++) wns = __any(nsg >= t) ? t : wns;
+            // per-pixel constants of the float64 ("Python float") branch of the sub-interval arithmetic
+            const double from_d = (double)col + 1e-7, to_d = (double)(col + 1) - 1e-7;
+            const double sig_dd = to_d - from_d;
+            const float ff64 = (float)from_d, tf64 = (float)to_d, center64 = (float)(from_d + 0.5 * sig_dd);
+            const float eps32 = (float)1e-7;
+
+            // ---- fast path: "single chain" pixel -------------------------------------------------------
+            // The pixel's points are CONSECUTIVE polyline points o1 .. o1+np-1 with strictly increasing x and
+            // the only segments registered for the pixel are the np+1 chain segments (incoming, internal,
+            // outgoing).  Then sub-interval k can only be covered by chain segment k = (o1-1+k -> o1+k): two
+            // compares verify it, no list search, x's and colours are loaded once.  Anything else -> generic.
+            bool chain = nsg == np + 1 && np < PT_KP;
+            int o1;
+            {
+                int omin = 0x7fffffff, omax = -1;
+#pragma unroll
+                for (int k = 0; k < PT_KP; k++) {
+                    if (k < wnp) {
+                        int o = k < np ? (int)pts[q * PT_KP + k] : omin;
+                        omin = min(omin, o);
+                        omax = k < np ? max(omax, o) : omax;
+                    }
+                }
+                // np == 0: the single registered segment is the chain; its start point plays the role of o1 - 1
+                o1 = np == 0 ? (nsg == 1 ? (int)sgs[q * PT_KS] + 1 : 1) : omin;
+                chain = chain && (np == 0 || omax - omin == np - 1);   // distinct ids in a span of np -> consecutive
             }
-            wnp = __builtin_amdgcn_readfirstlane(wnp);
-            wns = __builtin_amdgcn_readfirstlane(wns);
+            float cx[PT_KP + 2];     // cx[k] = x of point o1 - 1 + k, k = 0 .. np + 1
+            uint32_t cc[PT_KP + 2];  // colour of the source pixel that point refers to
+            int cj[PT_KP + 2];
+            if (__any(chain)) {
+#pragma unroll
+                for (int k = 0; k < PT_KP + 2; k++) {
+                    if (k <= wnp + 1) {
+                        const int o = chain && k <= np + 1 ? o1 - 1 + k : 0;
+                        cx[k] = px[o];
+                        cj[k] = min(max(SHARP ? (o - 1) >> 1 : o - 1, 0), ns - 1);
+                        cc[k] = img[cj[k]];
+                    } else { cx[k] = 0.0f; cj[k] = 0; cc[k] = 0; }
+                }
+                // every chain segment must be forward (then it is registered for this pixel, and with nsg == np + 1
+                // the registered set IS the chain: no other layer passes through the pixel)
+#pragma unroll
+                for (int k = 0; k <= PT_KP; k++)
+                    if (k <= wnp) chain = chain && (k > np || cx[k] < cx[k + 1]);
+                float color0 = 0.5f, color1 = 0.5f, color2 = 0.5f;
+                float prev = (float)col;
+#pragma unroll
+                for (int k = 0; k <= PT_KP; k++) {
+                    if (k <= wnp) {
+                        const bool live = chain && k <= np;
+                        const float a = k == 0 ? -INFINITY : cx[k];
+                        const float b = k < np ? cx[k + 1] : INFINITY;
+                        const bool from64 = !(a > (float)col), to64 = !(b < (float)(col + 1));
+                        const bool sig64 = from64 && to64;
+                        const float ff = from64 ? ff64 : a + eps32;
+                        const float tf = to64 ? tf64 : b - eps32;
+                        const float sig_f = tf - ff;
+                        const float center = sig64 ? center64 : ff + 0.5f * sig_f;
+                        const bool work = live && (sig64 ? sig_dd != 0.0 : sig_f != 0.0f);
+                        // chain segment k must be the active one: x0 < centre <= x1, centres monotone inside the pixel
+                        const bool ok = (cx[k] < center) && !(cx[k + 1] < center) && !(center < prev) &&
+                                        !(center > (float)(col + 1));
+                        chain = chain && (!live || !work || ok) && (!live || (!(center < prev) && !(center > (float)(col + 1))));
+                        prev = live ? center : prev;
+                        const float ip_k = (center - cx[k]) / (cx[k + 1] - cx[k]);
+                        const float om = 1.0f - ip_k;
+                        const float sg = sig64 ? (float)sig_dd : sig_f;
+                        const uint32_t il = cc[k], ir = cc[k + 1];
+                        const float l0 = (float)(il & 0xffu), l1 = (float)((il >> 8) & 0xffu), l2 = (float)((il >> 16) & 0xffu);
+                        const float r0 = (float)(ir & 0xffu), r1 = (float)((ir >> 8) & 0xffu), r2 = (float)((ir >> 16) & 0xffu);
+                        float n0 = color0 + (l0 * om + r0 * ip_k) * sg;
+                        float n1 = color1 + (l1 * om + r1 * ip_k) * sg;
+                        float n2 = color2 + (l2 * om + r2 * ip_k) * sg;
+                        const bool flat = cj[k] == cj[k + 1];
+                        if (__any(work && flat)) {
+                            if (flat) {
+                                if (sig64) {
+                                    n0 = (float)((double)color0 + (double)l0 * sig_dd);
+                                    n1 = (float)((double)color1 + (double)l1 * sig_dd);
+                                    n2 = (float)((double)color2 + (double)l2 * sig_dd);
+                                } else {
+                                    n0 = color0 + l0 * sig_f;
+                                    n1 = color1 + l1 * sig_f;
+                                    n2 = color2 + l2 * sig_f;
+                                }
+                            }
+                        }
+                        color0 = work ? n0 : color0;
+                        color1 = work ? n1 : color1;
+                        color2 = work ? n2 : color2;
+                    }
+                }
+                rgb = (uint32_t)csm::f32_to_u8_wrap(color0) | ((uint32_t)csm::f32_to_u8_wrap(color1) << 8) |
+                      ((uint32_t)csm::f32_to_u8_wrap(color2) << 16);
+            }
+            if (A.dbg == 14 && A.stats_rw) {  // development: how many pixels take which path
+                unsigned long long mc = __ballot(chain), mg = __ballot(!chain);
+                if (lane == 0) {
+                    atomicAdd(&A.stats_rw[(size_t)frame * ST_WORDS + 12], (unsigned)__popcll(mc));
+                    atomicAdd(&A.stats_rw[(size_t)frame * ST_WORDS + 13], (unsigned)__popcll(mg));
+                    atomicAdd(&A.stats_rw[(size_t)frame * ST_WORDS + 14], mg ? 1u : 0u);
+                    atomicAdd(&A.stats_rw[(size_t)frame * ST_WORDS + 15], 1u);
+                }
+            }
+            if (__any(!chain)) {
+            if (!chain) {
             // the pixel's points sorted by (x, id) == the reference's stable insertion sort inside the pixel
             float xs[PT_KP];
             int os[PT_KP];
@@ -285,11 +390,6 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
             }
             float color0 = 0.5f, color1 = 0.5f, color2 = 0.5f;
             float prev = (float)col, a = -INFINITY;
-            // per-pixel constants of the float64 ("Python float") branch of the sub-interval arithmetic
-            const double from_d = (double)col + 1e-7, to_d = (double)(col + 1) - 1e-7;
-            const double sig_dd = to_d - from_d;
-            const float ff64 = (float)from_d, tf64 = (float)to_d, center64 = (float)(from_d + 0.5 * sig_dd);
-            const float eps32 = (float)1e-7;
             for (int k = 0; k <= wnp; k++) {   // wave-uniform trip count; lanes with k > np idle
                 const bool live = k <= np;
                 float b = INFINITY;
@@ -379,6 +479,8 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
             }
             rgb = (uint32_t)csm::f32_to_u8_wrap(color0) | ((uint32_t)csm::f32_to_u8_wrap(color1) << 8) |
                   ((uint32_t)csm::f32_to_u8_wrap(color2) << 16);
+            }
+            }
         }
         res[3 * q] = (uint8_t)rgb; res[3 * q + 1] = (uint8_t)(rgb >> 8); res[3 * q + 2] = (uint8_t)(rgb >> 16);
     }
