@@ -13,7 +13,7 @@
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline     : dominant kernel (k_rowwarp<polylines_soft>) -- algorithmic bytes per launch / its mean
+  roofline     : dominant kernel (k_polytile: warp + polylines fill + assembly) -- algorithmic bytes per launch / its mean
                  duration measured with HIP events on the launch stream inside the timed region
   cpu_baseline : the CPU oracle (C port of the reference's D32 arithmetic, 1 thread) on a bounded sample
 """
@@ -129,6 +129,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     fallback_rows = int(plan.stats()[:, 10].sum())
+    tile_redo_rows = int(plan.stats()[:, 11].sum())
     err_flags = int(plan.stats()[:, 9].sum())
 
     if rank == 0:
@@ -156,10 +157,11 @@ def main():
                        "collective": "all_gather(stereoscope) over RCCL" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_rowwarp<polylines_soft>", "kernel_ms": kern_ms, "launches": launches.value,
+                         "kernel": "k_polytile<soft> (+ k_rowwarp<polylines_soft> over the rows it flags)", "kernel_ms": kern_ms, "launches": launches.value,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "pipeline_achieved": a.frames * a.steps * B_ALG_PER_PIXEL * H * W / dt / 1e9 / world},
-            "diagnostics": {"polylines_rows_replayed_sequentially": fallback_rows, "kernel_error_flags": err_flags},
+            "diagnostics": {"rows_redone_by_general_kernel": tile_redo_rows, "rows_replayed_sequentially": fallback_rows,
+                            "kernel_error_flags": err_flags},
         }
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.cpu_frames, blur)
