@@ -1,0 +1,127 @@
+"""Full-size (4K) checks of the HIP path: one whole frame against the oracle, plus size-independent properties
+(batch independence, run-to-run determinism, layout consistency between modes, Q10 pass-through) and ragged /
+extreme shapes against the oracle.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import node_oracle, oracle
+
+pytestmark = pytest.mark.gpu
+H4, W4 = 2160, 3840
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from comfystereo_amd import engine as e
+    assert torch.cuda.is_available()
+    return e
+
+
+def cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def gen(engine, img, depth, fill, mode, blur=True, div=8.0, **kw):
+    kw = dict(dict(depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12), **kw)
+    return [t.cpu().numpy() for t in engine.generate(cuda(img), cuda(depth), div, 0.0, mode, 0.0, 0.5, 2.0, fill, 20.0, 20.0,
+                                                     blur, **kw)]
+
+
+def test_4k_frame_bit_exact_vs_oracle(engine):
+    """The bench workload itself (one frame of it): 4K, stepped depth, divergence 8, polylines_soft, blur on."""
+    img = synth.image_f32(1, H4, W4, seed=1)
+    depth = synth.depth_batch("stepped", 1, H4, W4, channels=3)
+    got = gen(engine, img, depth, "polylines_soft", "left-right")
+    want = node_oracle.generate(img, depth, 8.0, 0.0, "left-right", 0.0, 0.5, 2.0, "Fill - Polylines Soft", 20.0, 20.0, True,
+                                depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+    for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+        assert np.array_equal(g, w_), name
+
+
+@pytest.mark.parametrize("fill", ["polylines_soft", "none", "hybrid_edge", "gpu_warp"])
+def test_4k_batch_independence_and_determinism(engine, fill):
+    """Frame i of a batch == that frame processed alone; two runs are bit-identical (no atomic-order effects)."""
+    n = 3
+    img = synth.image_f32(n, H4, W4, seed=2)
+    depth = synth.depth_batch("blobs", n, H4, W4, channels=1)
+    a = gen(engine, img, depth, fill, "left-right", batch_size=1)
+    b = gen(engine, img, depth, fill, "left-right", batch_size=1)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    solo = gen(engine, img[1:2], depth[1:2], fill, "left-right", batch_size=1)
+    for x, y in zip(a, solo):
+        assert np.array_equal(x[1:2], y)
+
+
+def test_4k_layout_consistency(engine):
+    """left-right / right-left / top-bottom / anaglyph / single-eye outputs are re-arrangements of the same two eyes."""
+    img = synth.image_f32(1, H4, W4, seed=3)
+    depth = synth.depth_batch("stepped", 1, H4, W4, channels=3)
+    lr = gen(engine, img, depth, "polylines_soft", "left-right")
+    L, R = lr[0][:, :, :W4], lr[0][:, :, W4:]
+    rl = gen(engine, img, depth, "polylines_soft", "right-left")
+    assert np.array_equal(rl[0][:, :, :W4], R) and np.array_equal(rl[0][:, :, W4:], L)
+    tb = gen(engine, img, depth, "polylines_soft", "top-bottom")
+    assert np.array_equal(tb[0][:, :H4], L) and np.array_equal(tb[0][:, H4:], R)
+    assert np.array_equal(tb[3][:, :H4], lr[3][:, :, :W4]) and np.array_equal(tb[3][:, H4:], lr[3][:, :, W4:])
+    an = gen(engine, img, depth, "polylines_soft", "red-cyan-anaglyph")
+    assert np.array_equal(an[0][..., 0], L[..., 0]) and np.array_equal(an[0][..., 1:], R[..., 1:])
+    assert np.array_equal(an[3], (an[0].sum(-1) == 0).astype(np.float32))
+    for k in (1, 2):
+        assert np.array_equal(lr[k], rl[k]) and np.array_equal(lr[k], tb[k])
+
+
+def test_4k_tiny_divergence_passes_the_image_through(engine):
+    """Q10: an eye whose divergence is < 0.001 is the source image (here: both eyes)."""
+    img = synth.image_f32(1, H4, W4, seed=4)
+    depth = synth.depth_batch("radial", 1, H4, W4, channels=3)
+    out = gen(engine, img, depth, "polylines_soft", "left-right", blur=False, div=0.0009)
+    k = np.clip(img * np.float32(255), 0, 255).astype(np.uint8).astype(np.float32) / np.float32(255.0)
+    assert np.array_equal(out[0][:, :, :W4], k) and np.array_equal(out[0][:, :, W4:], k)
+
+
+@pytest.mark.parametrize("shape", [(1, 7), (3, 2), (5, 33), (17, 130), (9, 515), (4, 1030), (2, 3841)])
+@pytest.mark.parametrize("fill", ["none", "naive", "naive_interpolating", "polylines_soft", "polylines_sharp", "inverse",
+                                  "hybrid_edge"])
+def test_ragged_shapes_vs_oracle(engine, shape, fill):
+    """Widths that are not multiples of 4 / 64 / the tile, single rows, 4K+1: every technique, both signs."""
+    h, w = shape
+    if w > 3000 and fill in ("polylines_soft", "polylines_sharp", "hybrid_edge"):
+        h = 1
+    img = synth.image_u8(h, w, seed=h * 1000 + w, hazards=True)
+    depth = synth.noisy_ramp(h, w, seed=w, amp=0.02) * np.float32(255)
+    for div, sep in ((5.0, 0.0), (-5.0, 0.7)):
+        got = engine.apply_stereo_divergence(cuda(img), cuda(depth), div, sep, 2.0, fill, 0.5).cpu().numpy()
+        want = oracle.apply_stereo_divergence(img, depth, div, sep, 2.0, fill, 0.5)
+        assert np.array_equal(got, want), (shape, fill, div, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("fill", ["polylines_soft", "polylines_sharp"])
+def test_large_halo_takes_the_row_kernel(engine, fill):
+    """Divergence 15 %, balance 0.9, convergence 0 at 1080p: the halo (> 256 px) exceeds the tiled path; same answer."""
+    h, w = 6, 1920
+    img = synth.image_f32(1, h, w, seed=9)
+    depth = synth.depth_batch("blobs", 1, h, w, channels=3)
+    ui = {v: k for k, v in node_oracle.FILL_KEYS.items()}[fill]
+    args = (15.0, 1.0, "left-right", 0.9, 0.0, 1.0)
+    got = engine.generate(cuda(img), cuda(depth), *args, fill, 20.0, 20.0, False)
+    want = node_oracle.generate(img, depth, *args, ui, 20.0, 20.0, False)
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g.cpu().numpy(), w_)
+
+
+def test_flat_and_one_channel_depth(engine):
+    h, w = 32, 200
+    img = synth.image_f32(2, h, w, seed=5)
+    flat = np.full((2, h, w, 1), 0.37, np.float32)
+    for fill, ui in (("polylines_soft", "Fill - Polylines Soft"), ("gpu_warp", "GPU Warp (Fast)"), ("inverse", "No fill - Reverse projection")):
+        args = (6.0, 0.0, "left-right", 0.0, 0.5, 2.0)
+        got = engine.generate(cuda(img), cuda(flat), *args, fill, 20.0, 20.0, False)
+        want = node_oracle.generate(img, flat, *args, ui, 20.0, 20.0, False)
+        for k, (g, w_) in enumerate(zip(got, want)):
+            if fill == "gpu_warp" and k == 0:
+                assert np.abs(g.cpu().numpy() - w_).max() <= 2e-6
+            else:
+                assert np.array_equal(g.cpu().numpy(), w_), (fill, k)
