@@ -141,8 +141,11 @@ __global__ void k_test_powf(const float* x, float y, float* out, size_t n) {
     const csm::PowfTables init = CS_POWF_TABLES_INIT;
     if (threadIdx.x == 0) T = init;
     __syncthreads();
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = csm::powf_exact(x[i], y, &T);
+    // both forms: the SIMT-shaped one the kernels use must equal the plain one bit for bit
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float a = csm::powf_exact(x[i], y, &T), b = csm::powf_exact_simt(x[i], y, &T);
+        out[i] = csm::f2u(a) == csm::f2u(b) ? a : csm::u2f(0x7fc00001u);
+    }
 }
 
 __device__ const unsigned long long d_exp_tab[256] = {CS_EXP_TAB_VALUES};

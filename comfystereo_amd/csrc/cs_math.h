@@ -112,6 +112,48 @@ CS_HD float powf_exact(float x, float y, const PowfTables* T) {
     return (float)res;
 }
 
+// Same function, shaped for SIMT: the main path runs unconditionally on a sanitised operand (no divergent
+// branches: they cost scalar-unit instructions on every wave), and lanes that need the special cases (x zero /
+// subnormal / inf / nan, |y*log2 x| >= 126, y zero / inf / nan) are redone by powf_exact() behind ONE
+// wave-uniform branch.  `any_special` tells whether any lane of the wave took that path (device: __any).
+#if defined(__HIPCC__)
+__device__ __forceinline__ float powf_exact_simt(float x, float y, const PowfTables* T) {
+    uint32_t ix = f2u(x) & 0x7fffffffu;
+    const uint32_t iy = f2u(y);
+    bool special = (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) || (2u * iy - 1u >= 2u * 0x7f800000u - 1u);
+    ix = special ? 0x3f800000u : ix;
+    uint32_t tmp = ix - 0x3f330000u;
+    uint32_t i = (tmp >> 19) & 15u;
+    uint32_t top = tmp & 0xff800000u;
+    double z = (double)u2f(ix - top);
+    double k = (double)((int32_t)top >> 23);
+    double r = fma(z, T->invc[i], -1.0);
+    double y0 = T->logc[i] + k;
+    double r2 = r * r;
+    double hi = fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
+    double mid = fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+    double r4 = r2 * r2;
+    double q = fma(0x1.71547652ab82bp+0, r, y0);
+    q = fma(mid, r2, q);
+    double ylogx = (double)y * fma(hi, r4, q);
+    special = special || (((d2u(ylogx) >> 47) & 0xffff) >= (d2u(126.0) >> 47));
+    const double SH = 0x1.8p+47;
+    double kd = ylogx + SH;
+    uint64_t ki = d2u(kd);
+    kd -= SH;
+    double rr = ylogx - kd;
+    double s = u2d(T->exp2t[ki & 31u] + (ki << 47));
+    double c01 = fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
+    double rr2 = rr * rr;
+    double c2 = fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
+    float res = (float)(fma(c01, rr2, c2) * s);
+    if (__any(special)) {
+        if (special) res = powf_exact(x, y, T);
+    }
+    return res;
+}
+#endif
+
 // exp for |x| < 512 (pinned); larger magnitudes saturate to 0 / inf without the libm corner cases.
 // `tab` is the 256-entry {tail, scale bits} table (cs_exp_tab, or an LDS copy).
 CS_HD double exp_exact(double x, const unsigned long long* tab) {

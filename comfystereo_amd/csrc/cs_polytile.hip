@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
     uint16_t* pts = (uint16_t*)(cnt + PT_T);                                    // [PT_T][PT_KP]
     uint16_t* sgs = pts + PT_T * PT_KP;                                         // [PT_T][PT_KS]
     uint8_t* res = (uint8_t*)(sgs + PT_T * PT_KS);                              // [3*PT_T]
-    int* flags = (int*)(res + align16(3 * PT_T));                               // [4]
+    uint8_t* dep8 = res + align16(3 * PT_T);                                    // [PT_T] depth-map output code of this eye
+    int* flags = (int*)(dep8 + PT_T);                                           // [4]
 
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
     const size_t rowpix = ((size_t)frame * h + row) * w;
@@ -151,15 +152,21 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
     const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
     const float* drow = E.depth + rowpix;
     __syncthreads();  // tables ready
+    if (!E.enabled) {
+        for (int q = tid; q < wt; q += PT_THREADS) dep8[q] = csm::f32_to_u8_wrap((drow[o0 + q] * scale) * 255.0f);
+    }
     if (E.enabled) {
         const float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
         const bool flat = dmax == dmin;
         const float range = dmax - dmin;
         for (int j = tid; j < ns; j += PT_THREADS) {
             float d = drow[s0 + j] * scale;
+            // depth-map output of this column: (depth*255).astype(uint8) wraps mod 256 (quirk Q7)
+            const int qq = s0 + j - o0;
+            if (qq >= 0 && qq < wt) dep8[qq] = csm::f32_to_u8_wrap(d * 255.0f);
             float nd = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
             float sgn = nd >= 0.0f ? 1.0f : -1.0f;
-            float pw = csm::powf_exact(fabsf(nd), A.e32, tabs);
+            float pw = csm::powf_exact_simt(fabsf(nd), A.e32, tabs);
             float cdj = (sgn * pw) * E.div32;                                     // coord_d   (:1926)
             float x = ((float)(s0 + j) + 0.5f + cdj) + E.sep32;                   // coord_x   (:1927)
             float z = fabsf(cdj);
@@ -209,11 +216,15 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
                 }
             }
             const bool is_long = p1 - p0 > 3;
-            if (p0 <= p1 && !is_long) {
-                for (int p = p0; p <= p1; p++) {
-                    unsigned idx = atomicAdd(&cnt[p - o0], 0x10000u) >> 16;
-                    if (idx < PT_KS) sgs[(p - o0) * PT_KS + idx] = (uint16_t)o;
-                    else hazard = true;
+            if (!is_long) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {  // at most 4 pixels: predicated, no divergent loop
+                    const int p = p0 + t;
+                    if (p <= p1) {
+                        unsigned idx = atomicAdd(&cnt[p - o0], 0x10000u) >> 16;
+                        if (idx < PT_KS) sgs[(p - o0) * PT_KS + idx] = (uint16_t)o;
+                        else hazard = true;
+                    }
                 }
             }
             // long segments (disocclusion bridges): the whole wave writes them, 64 pixels per step
@@ -234,14 +245,66 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
 
     if (A.dbg == 12) return;
     // ---- EVALUATE one output pixel per lane -------------------------------------------------------
+    for (int rep = 0; rep < (A.dbg == 17 ? 2 : 1); rep++)  // development: dbg 17 evaluates twice (marginal-cost probe)
     for (int q = tid; q < wt; q += PT_THREADS) {
         const int col = o0 + q;
-        uint32_t rgb;
+        uint32_t rgb = 0;
         if (!E.enabled) {
             rgb = img[col - s0];
         } else {
             const unsigned c = cnt[q];
             const int np = min((int)(c & 0xffffu), PT_KP), nsg = min((int)(c >> 16), PT_KS);
+            // per-pixel constants of the float64 ("Python float") branch of the sub-interval arithmetic
+            const double from_d = (double)col + 1e-7, to_d = (double)(col + 1) - 1e-7;
+            const double sig_dd = to_d - from_d;
+            const float ff64 = (float)from_d, tf64 = (float)to_d, center64 = (float)(from_d + 0.5 * sig_dd);
+            const float eps32 = (float)1e-7;
+
+            // ---- fastest path, decided for the whole wave: every pixel holds exactly ONE polyline point and two
+            // segments (flat and gently sloped regions).  Straight-line code, two scalar branches.  The point o,
+            // its neighbours o-1 / o+1 and the three source colours are all that is needed; the two pieces
+            // [col, x] and [x, col+1] belong to the segments (o-1 -> o) and (o -> o+1), verified below.
+            bool done = false;
+            if (!SHARP && __all(np == 1 && nsg == 2)) {
+                const int o = (int)pts[q * PT_KP];
+                const float xm = px[o - 1], x = px[o], xp = px[o + 1];
+                const int j = o - 1;  // source column (local) of point o; o-1 >= 1 and o+1 <= npts-2 checked via jok
+                const bool jok = j >= 1 && j + 1 <= ns - 1;
+                const uint32_t ia = img[jok ? j - 1 : 0], ib = img[jok ? j : 0], ic = img[jok ? j + 1 : 0];
+                // piece 0: [col, x]   (from = col + eps as Python float, to = x - eps as float32)
+                const float tf0 = x - eps32;
+                const float sig0 = tf0 - ff64;
+                const float c0 = ff64 + 0.5f * sig0;
+                // piece 1: [x, col+1] (from = x + eps if x > col else the Python-float col + eps; to = col+1-eps)
+                const bool f64_1 = !(x > (float)col);
+                const float ff1 = f64_1 ? ff64 : x + eps32;
+                const float sig1 = tf64 - ff1;
+                const float c1 = f64_1 ? center64 : ff1 + 0.5f * sig1;
+                const float sg1 = f64_1 ? (float)sig_dd : sig1;
+                const bool w0 = sig0 != 0.0f, w1 = f64_1 ? sig_dd != 0.0 : sig1 != 0.0f;
+                // chain segments forward and covering their piece, centres monotone inside the pixel
+                bool ok = jok && xm < x && x < xp;
+                ok = ok && !(c0 < (float)col) && !(c1 < c0) && !(c1 > (float)(col + 1));
+                ok = ok && (!w0 || (xm < c0 && !(x < c0))) && (!w1 || (x < c1 && !(xp < c1)));
+                if (__all(ok)) {
+                    const float ip0 = (c0 - xm) / (x - xm), ip1 = (c1 - x) / (xp - x);
+                    const float om0 = 1.0f - ip0, om1 = 1.0f - ip1;
+                    const float a0 = (float)(ia & 0xffu), a1 = (float)((ia >> 8) & 0xffu), a2 = (float)((ia >> 16) & 0xffu);
+                    const float b0 = (float)(ib & 0xffu), b1 = (float)((ib >> 8) & 0xffu), b2 = (float)((ib >> 16) & 0xffu);
+                    const float e0 = (float)(ic & 0xffu), e1 = (float)((ic >> 8) & 0xffu), e2 = (float)((ic >> 16) & 0xffu);
+                    float k0 = 0.5f, k1 = 0.5f, k2 = 0.5f;
+                    const float p0 = k0 + (a0 * om0 + b0 * ip0) * sig0, p1 = k1 + (a1 * om0 + b1 * ip0) * sig0,
+                                p2 = k2 + (a2 * om0 + b2 * ip0) * sig0;
+                    k0 = w0 ? p0 : k0; k1 = w0 ? p1 : k1; k2 = w0 ? p2 : k2;
+                    const float r0 = k0 + (b0 * om1 + e0 * ip1) * sg1, r1 = k1 + (b1 * om1 + e1 * ip1) * sg1,
+                                r2 = k2 + (b2 * om1 + e2 * ip1) * sg1;
+                    k0 = w1 ? r0 : k0; k1 = w1 ? r1 : k1; k2 = w1 ? r2 : k2;
+                    rgb = (uint32_t)csm::f32_to_u8_wrap(k0) | ((uint32_t)csm::f32_to_u8_wrap(k1) << 8) |
+                          ((uint32_t)csm::f32_to_u8_wrap(k2) << 16);
+                    done = true;
+                }
+            }
+            if (!done) {
             // wave-uniform bounds: unrolled bodies beyond them are skipped by scalar branches
             // (ballots, not shuffles: a shuffle reduction is a chain of LDS-crossbar round trips)
             int wnp = 0, wns = 0;
@@ -249,12 +312,6 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
             for (int t = 1; t <= PT_KP; t++) wnp = __any(np >= t) ? t : wnp;
 #pragma unroll
             for (int t = 1; t <= PT_KS; t++) wns = __any(nsg >= t) ? t : wns;
-            // per-pixel constants of the float64 ("Python float") branch of the sub-interval arithmetic
-            const double from_d = (double)col + 1e-7, to_d = (double)(col + 1) - 1e-7;
-            const double sig_dd = to_d - from_d;
-            const float ff64 = (float)from_d, tf64 = (float)to_d, center64 = (float)(from_d + 0.5 * sig_dd);
-            const float eps32 = (float)1e-7;
-
             // ---- fast path: "single chain" pixel -------------------------------------------------------
             // The pixel's points are CONSECUTIVE polyline points o1 .. o1+np-1 with strictly increasing x and
             // the only segments registered for the pixel are the np+1 chain segments (incoming, internal,
@@ -481,6 +538,7 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
                   ((uint32_t)csm::f32_to_u8_wrap(color2) << 16);
             }
             }
+            }  // !done
         }
         res[3 * q] = (uint8_t)rgb; res[3 * q + 1] = (uint8_t)(rgb >> 8); res[3 * q + 2] = (uint8_t)(rgb >> 16);
     }
@@ -508,16 +566,32 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
             for (int i = tid; i < 3 * wt; i += PT_THREADS) dst[i] = lut[res[i]];
         }
         float* m = A.mask + o;
-        for (int q = tid; q < wt; q += PT_THREADS)
-            m[q] = ((int)res[3 * q] + (int)res[3 * q + 1] + (int)res[3 * q + 2]) == 0 ? 1.0f : 0.0f;
-        // this eye's depth-map output for the tile ((depth*255).astype(uint8) wraps, quirk Q7)
         float* dd = (eyei == 0 ? A.depth_l : A.depth_r);
-        if (dd) {
-            dd += (rowpix + o0) * 3;
-            for (int q = tid; q < wt; q += PT_THREADS) {
-                float v = lut[csm::f32_to_u8_wrap((drow[o0 + q] * scale) * 255.0f)];
-                dd[3 * q] = v; dd[3 * q + 1] = v; dd[3 * q + 2] = v;
+        if (dd) dd += (rowpix + o0) * 3;
+        if ((wt & 3) == 0 && (w & 3) == 0) {
+            float4* m4 = reinterpret_cast<float4*>(m);
+            for (int i = tid; i < wt / 4; i += PT_THREADS) {
+                const uint8_t* r = res + 12 * i;
+                m4[i] = make_float4((r[0] | r[1] | r[2]) == 0 ? 1.0f : 0.0f, (r[3] | r[4] | r[5]) == 0 ? 1.0f : 0.0f,
+                                    (r[6] | r[7] | r[8]) == 0 ? 1.0f : 0.0f, (r[9] | r[10] | r[11]) == 0 ? 1.0f : 0.0f);
             }
+            if (dd) {
+                float4* d4 = reinterpret_cast<float4*>(dd);
+                for (int i = tid; i < (3 * wt) / 4; i += PT_THREADS) {  // 4 consecutive floats of the 3-channel row
+                    const int e = 4 * i, q0 = e / 3, r0 = e - 3 * q0;   // element e belongs to pixel e / 3
+                    const float va = lut[dep8[q0]], vb = lut[dep8[q0 + 1]];
+                    // r0 = 0: a a a b | r0 = 1: a a b b | r0 = 2: a b b b
+                    d4[i] = make_float4(va, r0 == 2 ? vb : va, r0 == 0 ? va : vb, vb);
+                }
+            }
+        } else {
+            for (int q = tid; q < wt; q += PT_THREADS)
+                m[q] = ((int)res[3 * q] + (int)res[3 * q + 1] + (int)res[3 * q + 2]) == 0 ? 1.0f : 0.0f;
+            if (dd)
+                for (int q = tid; q < wt; q += PT_THREADS) {
+                    float v = lut[dep8[q]];
+                    dd[3 * q] = v; dd[3 * q + 1] = v; dd[3 * q + 2] = v;
+                }
         }
     }
 }
@@ -526,7 +600,7 @@ static size_t polytile_lds(int S, int sharp, int PT_KP, int PT_KS) {
     int nsmax = PT_T + 2 * S + 6;
     int nptmax = (sharp ? 2 * nsmax : nsmax) + 2;
     return 1024 + align16(sizeof(csm::PowfTables)) + 2 * 4 * (size_t)((nptmax + 3) & ~3) + 4 * (size_t)((nsmax + 3) & ~3) +
-           4 * PT_T + 2 * PT_T * (PT_KP + PT_KS) + align16(3 * PT_T) + 64;
+           4 * PT_T + 2 * PT_T * (PT_KP + PT_KS) + align16(3 * PT_T) + PT_T + 64;
 }
 
 // Largest halo the tiled path accepts: beyond this the staged range dwarfs the tile and the row kernel wins.

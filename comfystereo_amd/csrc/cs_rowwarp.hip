@@ -92,7 +92,7 @@ __constant__ csm::PowfTables c_powf_tables = CS_POWF_TABLES_INIT;
 // `sign_d * (abs(d) ** e) * divergence_px` in the reference's float32 dialect.
 __device__ __forceinline__ float disparity(float d, float e32, float div32, const csm::PowfTables* T) {
     float s = d >= 0.0f ? 1.0f : -1.0f;
-    float p = csm::powf_exact(fabsf(d), e32, T);
+    float p = csm::powf_exact_simt(fabsf(d), e32, T);
     return (s * p) * div32;
 }
 
