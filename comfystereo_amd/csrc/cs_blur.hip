@@ -188,6 +188,50 @@ __global__ void __launch_bounds__(256) k_blur_apply(BlurArgs A) {
 //      chains per lane, operands fetched 8 at a time), blend, store, per-frame min/max.
 // The weight maps never exist in HBM: traffic per pixel is ~10 B read + 8 B written.
 // ---------------------------------------------------------------------------------------------
+// Edge masks of the whole frame as bit rows (2 x w/64 words per image row), one wave per 64 columns:
+// Sobel-x (6 fmaf, raster order, zero padding), the two edge tests, __ballot.  Streams the depth once.
+__global__ void __launch_bounds__(256) k_blur_edges(BlurArgs A, unsigned long long* mask_l, unsigned long long* mask_r,
+                                                    int MW) {
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, frame = blockIdx.z;
+    const int w = A.w, h = A.h;
+    const float scale = (A.stats && A.stats[frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
+    const float* d = A.depth + (size_t)frame * h * w;
+    bool le = false, re = false;
+    if (x < w) {
+        float g = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            const int yy = y + ky - 1;
+            const bool rowok = yy >= 0 && yy < h;
+            const float* r = d + (size_t)(rowok ? yy : 0) * w;
+            const float vl = (rowok && x > 0) ? r[x - 1] * scale : 0.0f;
+            const float vr = (rowok && x + 1 < w) ? r[x + 1] * scale : 0.0f;
+            const float kl = ky == 1 ? -2.0f : -1.0f, kr = ky == 1 ? 2.0f : 1.0f;
+            g = fmaf(kl, vl, g);
+            g = fmaf(kr, vr, g);
+        }
+        const float es = fminf(fmaxf(fabsf(g) / A.den, 0.0f), 1.0f);
+        le = (g > 0.0f) && (es > 0.5f);
+        re = (g < 0.0f) && (es > 0.5f);
+    }
+    const unsigned long long bl = __ballot(le), br = __ballot(re);
+    const int word = x >> 6;  // wave-uniform
+    if (lane == 0 && word < MW) {
+        mask_l[((size_t)frame * h + y) * MW + word] = bl;
+        mask_r[((size_t)frame * h + y) * MW + word] = br;
+    }
+}
+
+// 64 bits of a frame-wide bit row starting at (possibly negative / out of range) bit position `fb`
+__device__ __forceinline__ unsigned long long mask_window(const unsigned long long* row, int MW, int fb) {
+    if (fb <= -64) return 0ull;
+    if (fb < 0) return row[0] << (-fb);
+    const int wi = fb >> 6, sh = fb & 63;
+    const unsigned long long lo = wi < MW ? row[wi] : 0ull, hi = wi + 1 < MW ? row[wi + 1] : 0ull;
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+}
+
 __device__ __forceinline__ int mask_dist_left(const unsigned long long* m, int p) {
     // distance from bit p to the nearest set bit at or below p, or -1
     int wi = p >> 6;
@@ -208,17 +252,18 @@ __device__ __forceinline__ int mask_dist_right(const unsigned long long* m, int 
     }
 }
 
-__global__ void __launch_bounds__(256) k_blur_fused(BlurArgs A) {
+__global__ void __launch_bounds__(256) k_blur_fused(BlurArgs A, const unsigned long long* mask_l,
+                                                    const unsigned long long* mask_r, int MW) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = blockIdx.x * BLUR_TW, y0 = blockIdx.y * BLUR_TR, frame = blockIdx.z;
     const int w = A.w, h = A.h, v = A.vert, bs = A.bs, pad = A.bs / 2, R = A.radius;
     const int WR = BLUR_TR + 2 * v;          // weight rows: frame rows y0 - v ..
     const int EW = BLUR_TW + 2 * R;          // edge columns: frame cols x0 - R ..
-    const int DR = WR + 2, DC = EW + 2;      // depth tile: rows y0 - v - 1 .., cols x0 - R - 1 ..
+    const int DC = BLUR_TW + bs - 1;         // depth tile: rows y0 .., cols x0 - pad ..
     const int NW = (EW + 63) >> 6;           // 64-bit words per mask row
-    float* D = (float*)smem;                                   // [DR][DC]
-    float* wlt = D + ((DR * DC + 3) & ~3);                     // [WR][TW]
+    float* D = (float*)smem;                                   // [TR][DC]
+    float* wlt = D + ((BLUR_TR * DC + 3) & ~3);                // [WR][TW]
     float* wrt = wlt + WR * BLUR_TW;                           // [WR][TW]
     unsigned long long* mL = (unsigned long long*)(wrt + WR * BLUR_TW);  // [WR][NW]
     unsigned long long* mR = mL + WR * NW;                     // [WR][NW]
@@ -231,47 +276,30 @@ __global__ void __launch_bounds__(256) k_blur_fused(BlurArgs A) {
     }
     const float scale = (A.stats && A.stats[frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
     const float* d = A.depth + (size_t)frame * h * w;
-    for (int r = wave; r < DR; r += 4) {  // one wave per tile row: coalesced, no index division
-        const int yy = y0 - v - 1 + r;
-        const bool rowok = yy >= 0 && yy < h;
-        const float* drow = d + (size_t)(rowok ? yy : 0) * w;
-        for (int c = lane; c < DC; c += 64) {
-            const int xx = x0 - R - 1 + c;
-            D[r * DC + c] = (rowok && xx >= 0 && xx < w) ? drow[xx] * scale : 0.0f;
-        }
-    }
     __syncthreads();
-    if (A.dbg == 21) return;
-    // 2. edge masks, one (row, 64-column chunk) per wave step
-    for (int item = wave; item < WR * NW; item += 4) {
-        const int r = item / NW, ch = item - r * NW;
-        const int e = ch * 64 + lane;                 // edge column index, frame col x0 - R + e
-        const int yy = y0 - v + r, xx = x0 - R + e;
-        bool le = false, re = false;
-        if (e < EW && yy >= 0 && yy < h && xx >= 0 && xx < w) {
-            const float* p = D + r * DC + e;          // D row r is frame row yy - 1; column e is frame col xx - 1
-            float g = 0.0f;
-            g = fmaf(-1.0f, p[0], g); g = fmaf(1.0f, p[2], g);
-            g = fmaf(-2.0f, p[DC], g); g = fmaf(2.0f, p[DC + 2], g);
-            g = fmaf(-1.0f, p[2 * DC], g); g = fmaf(1.0f, p[2 * DC + 2], g);
-            float es = fminf(fmaxf(fabsf(g) / A.den, 0.0f), 1.0f);
-            le = (g > 0.0f) && (es > 0.5f);
-            re = (g < 0.0f) && (es > 0.5f);
+    // 2. the tile's window of the frame-wide edge bit rows (k_blur_edges): rows y0-v .., bits x0-R ..
+    const unsigned long long lastmask = (EW & 63) ? (~0ull >> (64 - (EW & 63))) : ~0ull;
+    for (int item = tid; item < WR * NW; item += 256) {
+        const int r = item / NW, k = item - r * NW;
+        const int yy = y0 - v + r;
+        unsigned long long bl = 0ull, br = 0ull;
+        if (yy >= 0 && yy < h) {
+            const size_t ro = ((size_t)frame * h + yy) * MW;
+            bl = mask_window(mask_l + ro, MW, x0 - R + 64 * k);
+            br = mask_window(mask_r + ro, MW, x0 - R + 64 * k);
+            if (k == NW - 1) { bl &= lastmask; br &= lastmask; }
         }
-        unsigned long long bl = __ballot(le), br = __ballot(re);
-        if (lane == 0) {
-            mL[item] = bl; mR[item] = br;
-            if (bl | br) *any_edge = 1;
-        }
+        mL[item] = bl; mR[item] = br;
+        if (bl | br) *any_edge = 1;
     }
     __syncthreads();
     if (*any_edge == 0 && A.fall_mode != 5) {
-        // no edge anywhere in the halo'ed tile: every weight is exactly 0, so 0*blur + (1-0)*depth == depth
+        // no edge within reach of the tile: every weight is exactly 0, so 0*blur + (1-0)*depth == depth
         float mn = INFINITY, mx = -INFINITY;
         for (int i = tid; i < BLUR_TR * BLUR_TW; i += 256) {
             const int r = i >> 6, c = i & 63, y = y0 + r, x = x0 + c;
             if (y < h && x < w) {
-                float dvv = D[(r + v + 1) * DC + c + R + 1];
+                float dvv = d[(size_t)y * w + x] * scale;
                 A.out_l[((size_t)frame * h + y) * w + x] = dvv;
                 A.out_r[((size_t)frame * h + y) * w + x] = dvv;
                 mn = fminf(mn, dvv); mx = fmaxf(mx, dvv);
@@ -284,6 +312,16 @@ __global__ void __launch_bounds__(256) k_blur_fused(BlurArgs A) {
             block_minmax_update(mn, mx, &st[ST_R_MIN], &st[ST_R_MAX], red2);
         }
         return;
+    }
+    // depth tile for the box filter (zero outside the frame == the reference's zero padding)
+    for (int r = wave; r < BLUR_TR; r += 4) {
+        const int yy = y0 + r;
+        const bool rowok = yy < h;
+        const float* drow = d + (size_t)(rowok ? yy : 0) * w;
+        for (int c = lane; c < DC; c += 64) {
+            const int xx = x0 - pad + c;
+            D[r * DC + c] = (rowok && xx >= 0 && xx < w) ? drow[xx] * scale : 0.0f;
+        }
     }
     if (A.dbg == 22) return;
     // 3. weights from the bit rows
@@ -343,10 +381,10 @@ __global__ void __launch_bounds__(256) k_blur_fused(BlurArgs A) {
         for (int j = 0; j < 8; j++) { a8[j] = wlt[(rbase + j) * BLUR_TW + tx]; b8[j] = wrt[(rbase + j) * BLUR_TW + tx]; }
     }
     if (A.dbg == 24) return;
-    // horizontal box: depth row of output row r is D row r + v + 1; tap k of column tx is D column tx + R + 1 - pad + k
+    // horizontal box: tap k of column tx is D column tx + k (the tile starts at frame column x0 - pad)
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[j] = 0.0f;
-    const float* dbase = D + (rbase + v + 1) * DC + tx + R + 1 - pad;
+    const float* dbase = D + rbase * DC + tx;
     for (int k0 = 0; k0 < bs; k0 += 8) {
         float dv[8][8];
 #pragma unroll
@@ -383,9 +421,11 @@ __global__ void __launch_bounds__(256) k_blur_fused(BlurArgs A) {
     }
 }
 
-static size_t blur_fused_lds(int v, int R) {
-    int WR = BLUR_TR + 2 * v, EW = BLUR_TW + 2 * R, DR = WR + 2, DC = EW + 2, NW = (EW + 63) >> 6;
-    return (size_t)((DR * DC + 3) & ~3) * 4 + 2 * (size_t)WR * BLUR_TW * 4 + 2 * (size_t)WR * NW * 8 + sizeof(csm::PowfTables) + 64;
+static size_t blur_fused_lds(int v, int R, int bs) {
+    int WR = BLUR_TR + 2 * v, EW = BLUR_TW + 2 * R, NW = (EW + 63) >> 6;
+    (void)EW;
+    return (size_t)((BLUR_TR * (BLUR_TW + bs - 1) + 3) & ~3) * 4 + 2 * (size_t)WR * BLUR_TW * 4 + 2 * (size_t)WR * NW * 8 +
+           sizeof(csm::PowfTables) + 64;
 }
 
 int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double falloff,
@@ -405,11 +445,17 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
     A.wl = wl; A.wr = wr; A.out_l = out_l; A.out_r = out_r;
     { const char* dbg = getenv("CS_DBG"); A.dbg = dbg ? atoi(dbg) : 0; }
     const char* nofuse = getenv("CS_BLUR_TWO_PASS");
-    size_t ldsF = blur_fused_lds(A.vert, A.radius);
+    size_t ldsF = blur_fused_lds(A.vert, A.radius, A.bs);
     if (ldsF <= 64 * 1024 && A.radius >= 1 && !(nofuse && atoi(nofuse))) {
         hipError_t e = hipFuncSetAttribute((const void*)k_blur_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
         if (e != hipSuccess) return CS_EHIP;
-        hipLaunchKernelGGL(k_blur_fused, dim3((w + BLUR_TW - 1) / BLUR_TW, (h + BLUR_TR - 1) / BLUR_TR, n), dim3(256), ldsF, stream, A);
+        // the weight scratch buffers double as the frame-wide edge bit rows (2 x ceil(w/64) words per image row)
+        const int MW = (w + 63) / 64;
+        unsigned long long* mask_l = reinterpret_cast<unsigned long long*>(wl);
+        unsigned long long* mask_r = reinterpret_cast<unsigned long long*>(wr);
+        hipLaunchKernelGGL(k_blur_edges, dim3((w + 255) / 256, h, n), dim3(256), 0, stream, A, mask_l, mask_r, MW);
+        hipLaunchKernelGGL(k_blur_fused, dim3((w + BLUR_TW - 1) / BLUR_TW, (h + BLUR_TR - 1) / BLUR_TR, n), dim3(256), ldsF, stream, A,
+                           (const unsigned long long*)mask_l, (const unsigned long long*)mask_r, MW);
         return CS_OK;
     }
     int threads = w <= 256 ? 256 : (w <= 1024 ? 512 : 1024);
