@@ -190,36 +190,40 @@ __global__ void __launch_bounds__(256) k_blur_apply(BlurArgs A) {
 // ---------------------------------------------------------------------------------------------
 // Edge masks of the whole frame as bit rows (2 x w/64 words per image row), one wave per 64 columns:
 // Sobel-x (6 fmaf, raster order, zero padding), the two edge tests, __ballot.  Streams the depth once.
+#define BLUR_ER 4  // image rows per thread of k_blur_edges (sliding 3-row window: 2 x (ER + 2) loads for ER results)
 __global__ void __launch_bounds__(256) k_blur_edges(BlurArgs A, unsigned long long* mask_l, unsigned long long* mask_r,
                                                     int MW) {
     const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, frame = blockIdx.z;
+    const int x = blockIdx.x * 256 + threadIdx.x, yb = blockIdx.y * BLUR_ER, frame = blockIdx.z;
     const int w = A.w, h = A.h;
     const float scale = (A.stats && A.stats[frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
     const float* d = A.depth + (size_t)frame * h * w;
-    bool le = false, re = false;
-    if (x < w) {
-        float g = 0.0f;
+    float vl[BLUR_ER + 2], vr[BLUR_ER + 2];
 #pragma unroll
-        for (int ky = 0; ky < 3; ky++) {
-            const int yy = y + ky - 1;
-            const bool rowok = yy >= 0 && yy < h;
-            const float* r = d + (size_t)(rowok ? yy : 0) * w;
-            const float vl = (rowok && x > 0) ? r[x - 1] * scale : 0.0f;
-            const float vr = (rowok && x + 1 < w) ? r[x + 1] * scale : 0.0f;
-            const float kl = ky == 1 ? -2.0f : -1.0f, kr = ky == 1 ? 2.0f : 1.0f;
-            g = fmaf(kl, vl, g);
-            g = fmaf(kr, vr, g);
-        }
-        const float es = fminf(fmaxf(fabsf(g) / A.den, 0.0f), 1.0f);
-        le = (g > 0.0f) && (es > 0.5f);
-        re = (g < 0.0f) && (es > 0.5f);
+    for (int i = 0; i < BLUR_ER + 2; i++) {
+        const int yy = yb - 1 + i;
+        const bool rowok = yy >= 0 && yy < h && x < w;
+        const float* r = d + (size_t)(yy >= 0 && yy < h ? yy : 0) * w;
+        vl[i] = (rowok && x > 0) ? r[x - 1] * scale : 0.0f;
+        vr[i] = (rowok && x + 1 < w) ? r[x + 1] * scale : 0.0f;
     }
-    const unsigned long long bl = __ballot(le), br = __ballot(re);
     const int word = x >> 6;  // wave-uniform
-    if (lane == 0 && word < MW) {
-        mask_l[((size_t)frame * h + y) * MW + word] = bl;
-        mask_r[((size_t)frame * h + y) * MW + word] = br;
+#pragma unroll
+    for (int j = 0; j < BLUR_ER; j++) {
+        const int y = yb + j;
+        // rows y-1, y, y+1 in raster order: (-1, +1), (-2, +2), (-1, +1); the centre taps have weight 0
+        float g = 0.0f;
+        g = fmaf(-1.0f, vl[j], g); g = fmaf(1.0f, vr[j], g);
+        g = fmaf(-2.0f, vl[j + 1], g); g = fmaf(2.0f, vr[j + 1], g);
+        g = fmaf(-1.0f, vl[j + 2], g); g = fmaf(1.0f, vr[j + 2], g);
+        const float es = fminf(fmaxf(fabsf(g) / A.den, 0.0f), 1.0f);
+        const bool le = x < w && (g > 0.0f) && (es > 0.5f);
+        const bool re = x < w && (g < 0.0f) && (es > 0.5f);
+        const unsigned long long bl = __ballot(le), br = __ballot(re);
+        if (lane == 0 && word < MW && y < h) {
+            mask_l[((size_t)frame * h + y) * MW + word] = bl;
+            mask_r[((size_t)frame * h + y) * MW + word] = br;
+        }
     }
 }
 
@@ -453,7 +457,7 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
         const int MW = (w + 63) / 64;
         unsigned long long* mask_l = reinterpret_cast<unsigned long long*>(wl);
         unsigned long long* mask_r = reinterpret_cast<unsigned long long*>(wr);
-        hipLaunchKernelGGL(k_blur_edges, dim3((w + 255) / 256, h, n), dim3(256), 0, stream, A, mask_l, mask_r, MW);
+        hipLaunchKernelGGL(k_blur_edges, dim3((w + 255) / 256, (h + BLUR_ER - 1) / BLUR_ER, n), dim3(256), 0, stream, A, mask_l, mask_r, MW);
         hipLaunchKernelGGL(k_blur_fused, dim3((w + BLUR_TW - 1) / BLUR_TW, (h + BLUR_TR - 1) / BLUR_TR, n), dim3(256), ldsF, stream, A,
                            (const unsigned long long*)mask_l, (const unsigned long long*)mask_r, MW);
         return CS_OK;

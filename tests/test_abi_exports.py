@@ -66,3 +66,19 @@ def test_null_pointers_are_rejected_before_any_device_work():
     with pytest.raises(ValueError):
         from comfystereo_amd import engine
         engine.make_params(1, 8, 8, 8, 8, 3, "none", "sideways", 1, 0, 0, 0.5, 1, False, 0, 6, 1, 0, 1)
+
+
+def test_too_wide_frames_are_rejected_with_elimit():
+    """Frames wider than the LDS-resident row kernels accept fail with CS_ELIMIT before any device work."""
+    import ctypes
+    L = _native.lib()
+    from comfystereo_amd import engine
+    wmax = L.cs_max_width(_native.FILL["gpu_warp"])
+    p = engine.make_params(1, 8, wmax + 1, 8, wmax + 1, 3, "gpu_warp", "left-right", 4.5, 0.0, 0.0, 0.5, 2.0, False, 20.0, 20.0,
+                           2.0, 6, 12)
+    fake = ctypes.c_void_p(16)
+    rc = L.cs_generate(ctypes.byref(p), fake, fake, fake, fake, fake, fake, fake, 1 << 40, None)
+    assert rc == _native.CS_ELIMIT and b"too wide" in L.cs_last_error()
+    p.w = 64
+    p.depth_w = 64
+    assert L.cs_generate(ctypes.byref(p), fake, fake, fake, fake, fake, fake, fake, 16, None) == _native.CS_EWORKSPACE

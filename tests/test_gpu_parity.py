@@ -184,3 +184,34 @@ def test_node_gpu_warp_vs_oracle_blur_on(engine):
         assert np.abs(got[0].cpu().numpy() - want[0]).max() <= 2e-6, mode
         for k in (1, 2, 3):
             assert np.array_equal(got[k].cpu().numpy(), want[k]), (mode, k)
+
+
+def test_blur_wide_kernel_takes_the_two_pass_path(engine):
+    """strength 120.5: the fused tile (halo 2 x 120 columns) does not fit in LDS -> two-pass kernels; same bits."""
+    n, h, w = 2, 96, 900
+    depth = np.stack([np.round(synth.blobs(h, w, seed=j) * 255) for j in range(n)]).astype(np.float32)
+    prm = (120.5, 6.0, 1.0, 2)
+    L, R = engine.directional_blur(cuda(depth), *prm)
+    oL, oR = oracle.blur(depth, *prm)
+    assert np.array_equal(L.cpu().numpy().view(np.uint32), oL.view(np.uint32))
+    assert np.array_equal(R.cpu().numpy().view(np.uint32), oR.view(np.uint32))
+
+
+def test_blur_two_pass_env_override(engine, monkeypatch):
+    monkeypatch.setenv("CS_BLUR_TWO_PASS", "1")
+    depth = np.round(synth.blobs(300, 517, seed=3) * 255).astype(np.float32)
+    L, R = engine.directional_blur(cuda(depth), 20, 20, 2.0, 6)
+    oL, oR = oracle.blur(depth, 20, 20, 2.0, 6)
+    assert np.array_equal(L.cpu().numpy().view(np.uint32), oL.view(np.uint32))
+    assert np.array_equal(R.cpu().numpy().view(np.uint32), oR.view(np.uint32))
+
+
+def test_polylines_row_kernel_env_override(engine, monkeypatch):
+    """CS_NO_TILE=1 forces the general row kernel for every row: same result as the tiled fast path."""
+    h, w = 24, 1500
+    img = synth.image_u8(h, w, seed=11)
+    depth = synth.blobs(h, w, seed=4) * np.float32(255)
+    a = engine.apply_stereo_divergence(cuda(img), cuda(depth), 7.0, 0.3, 2.0, "polylines_soft", 0.5).cpu().numpy()
+    monkeypatch.setenv("CS_NO_TILE", "1")
+    b = engine.apply_stereo_divergence(cuda(img), cuda(depth), 7.0, 0.3, 2.0, "polylines_soft", 0.5).cpu().numpy()
+    assert np.array_equal(a, b) and np.array_equal(a, oracle.apply_stereo_divergence(img, depth, 7.0, 0.3, 2.0, "polylines_soft", 0.5))
