@@ -97,13 +97,17 @@ def main():
     image, depth = make_inputs(torch, nloc, b0, device)
     p = engine.make_params(nloc, H, W, H, W, 3, "polylines_soft", "left-right", 8.0, 0.0, 0.0, 0.5, 2.0, blur, 20.0, 20.0,
                            2.0, 6, 12)
-    plan = engine.Plan(p, device)
+    # N > 1: shards travel over xGMI as uint8 codes (the stereoscope is k/255 exactly: 4x fewer bytes) and are
+    # expanded to float32 on every rank after the all-gather
+    plan = engine.Plan(p, device, stereo_u8=world > 1)
+    gathered8 = torch.empty((a.frames, H, 2 * W, 3), dtype=torch.uint8, device=device) if world > 1 else None
     gathered = torch.empty((a.frames, H, 2 * W, 3), dtype=torch.float32, device=device) if world > 1 else None
 
     def step():
         stereo, _, _, _ = plan.run(image, depth)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, stereo)
+            dist.all_gather_into_tensor(gathered8, stereo)
+            engine.expand_u8(gathered8, gathered)
 
     def fence():
         torch.cuda.synchronize()
@@ -154,7 +158,8 @@ def main():
             "config": {"workload": "4K 3840x2160, polylines_soft, left-right SBS, divergence 8.0, stepped depth, "
                                    f"depth blur {'on' if blur else 'off'} (widget defaults)",
                        "frames_total": a.frames, "frames_per_gpu": nloc, "sharding": "by frame, contiguous blocks",
-                       "collective": "all_gather(stereoscope) over RCCL" if world > 1 else "none"},
+                       "collective": "all_gather(stereoscope as uint8 codes) over RCCL + expand to float32 on every rank"
+                                     if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_polytile<soft> (+ k_rowwarp<polylines_soft> over the rows it flags)", "kernel_ms": kern_ms, "launches": launches.value,

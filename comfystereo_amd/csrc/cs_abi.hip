@@ -136,6 +136,19 @@ __global__ void k_finalize_stats(uint32_t* stats, int n, int group, int blur) {
     }
 }
 
+// uint8 codes -> float32 k/255 (true division through a LUT), 4 values per thread
+__global__ void __launch_bounds__(256) k_expand_u8(const uint8_t* __restrict__ in, float* __restrict__ out, size_t count) {
+    __shared__ float lut[256];
+    lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
+    __syncthreads();
+    const size_t nq = count / 4, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nq; i += stride) {
+        uint32_t pk = reinterpret_cast<const uint32_t*>(in)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(lut[pk & 0xff], lut[(pk >> 8) & 0xff], lut[(pk >> 16) & 0xff], lut[pk >> 24]);
+    }
+    for (size_t i = 4 * nq + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += stride) out[i] = lut[in[i]];
+}
+
 __global__ void k_test_powf(const float* x, float y, float* out, size_t n) {
     __shared__ csm::PowfTables T;
     const csm::PowfTables init = CS_POWF_TABLES_INIT;
@@ -312,6 +325,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     float* gray = (float*)(ws + W.gray);
     const int n = p->n, h = p->h, w = p->w, hw = h * w;
     const bool gpu_warp = p->fill == CS_FILL_GPU_WARP;
+    if (gpu_warp && (p->flags & 2)) return fail(CS_EINVAL, "gpu_warp colours are not k/255: no uint8 stereoscope output");
     const bool blur = p->depth_map_blur && (!gpu_warp || p->depth_blur_strength > 0);
 
     hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);
@@ -366,6 +380,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     A.eye[0].depth = dL; A.eye[0].st_min = ST_L_MIN; A.eye[0].st_max = ST_L_MAX;
     A.eye[1].depth = dR; A.eye[1].st_min = ST_R_MIN; A.eye[1].st_max = ST_R_MAX;
     A.stereo = stereo; A.mask = mask; A.depth_l = depth_l; A.depth_r = depth_r;
+    A.stereo_is_u8 = (p->flags & 2) ? 1 : 0;
     A.out_h = out_h; A.out_w = out_w;
     A.single = -1;
     { const char* dbg = getenv("CS_DBG"); A.dbg = dbg ? atoi(dbg) : 0; }
@@ -477,6 +492,14 @@ int cs_forward_warp(const float* image, const float* depth, int n, int h, int w,
     if (rc) return fail(rc, "gpu_warp launch failed");
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CS_OK : fail_hip(e, "cs_forward_warp");
+}
+
+int cs_expand_u8(const uint8_t* codes, float* out, size_t count, void* stream) {
+    if (!codes || !out) return fail(CS_EINVAL, "null pointer");
+    if (((uintptr_t)codes & 3) || ((uintptr_t)out & 15)) return fail(CS_EINVAL, "cs_expand_u8 needs 4-/16-byte aligned buffers");
+    hipLaunchKernelGGL(k_expand_u8, dim3(grid_for(count / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, codes, out, count);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CS_OK : fail_hip(e, "cs_expand_u8");
 }
 
 int cs_profile(int enable) {

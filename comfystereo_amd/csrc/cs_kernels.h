@@ -34,7 +34,8 @@ struct RowArgs {
     int neyes;
     // outputs
     uint8_t* out_u8;  // asd path: [n][h][w][3]
-    float* stereo;    // node path: [n][out_h][out_w][3]
+    float* stereo;    // node path: [n][out_h][out_w][3] float32 (or uint8 codes k of k/255 when stereo_is_u8)
+    int stereo_is_u8;
     float* mask;      //            [n][out_h][out_w]
     float* depth_l;   //            [n][h][w][3]
     float* depth_r;

@@ -72,6 +72,7 @@ struct PolyTileArgs {
     int neyes, single;
     uint8_t* out_u8;
     float* stereo; float* mask; float* depth_l; float* depth_r;
+    int stereo_is_u8;
     int out_h, out_w;
     uint8_t* rowflag;  // [n][h] set to 1 when the row must be redone by the general kernel
     int dbg;           // development only (env CS_DBG): 11 = stop after staging, 12 = after REGISTER, 13 = no stores
@@ -556,7 +557,14 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
     } else {
         const size_t o = ((size_t)frame * A.out_h + row + E.yoff) * A.out_w + E.xoff + o0;
         float* dst = A.stereo + o * 3;
-        if ((wt & 3) == 0 && (w & 3) == 0) {
+        if (A.stereo_is_u8) {  // compact output for the multi-GPU all-gather: the uint8 codes k (value = k / 255)
+            uint8_t* d8 = reinterpret_cast<uint8_t*>(A.stereo) + o * 3;
+            if ((wt & 3) == 0 && (w & 3) == 0)
+                for (int i = tid; i < (3 * wt) / 4; i += PT_THREADS)
+                    reinterpret_cast<uint32_t*>(d8)[i] = reinterpret_cast<const uint32_t*>(res)[i];
+            else
+                for (int i = tid; i < 3 * wt; i += PT_THREADS) d8[i] = res[i];
+        } else if ((wt & 3) == 0 && (w & 3) == 0) {
             float4* d4 = reinterpret_cast<float4*>(dst);
             for (int i = tid; i < (3 * wt) / 4; i += PT_THREADS) {
                 uint32_t pk = reinterpret_cast<const uint32_t*>(res)[i];
@@ -617,6 +625,7 @@ hipError_t launch_polytile(int sharp, const RowArgs& R, int S, uint8_t* rowflag,
     A.e32 = R.e32; A.conv32 = R.conv32;
     A.eye[0] = R.eye[0]; A.eye[1] = R.eye[1];
     A.neyes = R.neyes; A.single = R.neyes == 1 ? 0 : R.single;
+    A.stereo_is_u8 = R.stereo_is_u8;
     A.out_u8 = R.out_u8; A.stereo = R.stereo; A.mask = R.mask; A.depth_l = R.depth_l; A.depth_r = R.depth_r;
     A.out_h = R.out_h; A.out_w = R.out_w;
     A.rowflag = rowflag;

@@ -724,8 +724,13 @@ struct RowOut {
         else if (a.anaglyph == 2) { g = L->ana[2 * c]; b = L->ana[2 * c + 1]; }
         const EyeArgs& E = a.eye[eye];
         const size_t o = ((size_t)frame * a.out_h + row + E.yoff) * a.out_w + E.xoff + c;
-        float* d = a.stereo + o * 3;
-        d[0] = L->lut[r]; d[1] = L->lut[g]; d[2] = L->lut[b];
+        if (a.stereo_is_u8) {
+            uint8_t* d8 = reinterpret_cast<uint8_t*>(a.stereo) + o * 3;
+            d8[0] = r; d8[1] = g; d8[2] = b;
+        } else {
+            float* d = a.stereo + o * 3;
+            d[0] = L->lut[r]; d[1] = L->lut[g]; d[2] = L->lut[b];
+        }
         a.mask[o] = ((int)r + (int)g + (int)b) == 0 ? 1.0f : 0.0f;  // GenerateStereo.py:355-361
     }
 };
@@ -829,7 +834,10 @@ __global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
                 }
                 const int oy = row + E.yoff, ox = E.xoff;
                 float* dst = A.stereo + (((size_t)frame * A.out_h + oy) * A.out_w + ox) * 3;
-                if ((w & 3) == 0) {
+                if (A.stereo_is_u8) {
+                    uint8_t* d8 = reinterpret_cast<uint8_t*>(A.stereo) + (((size_t)frame * A.out_h + oy) * A.out_w + ox) * 3;
+                    for (int i = tid; i < 3 * w; i += nt) d8[i] = L.res[i];
+                } else if ((w & 3) == 0) {
                     float4* d4 = reinterpret_cast<float4*>(dst);
                     for (int i = tid; i < (3 * w) / 4; i += nt) {
                         uint32_t pk = reinterpret_cast<const uint32_t*>(L.res)[i];

@@ -51,12 +51,16 @@ def output_shape(p):
 class Plan:
     """Pre-allocated outputs + workspace for repeated calls of one configuration (what bench.py times)."""
 
-    def __init__(self, p, device):
+    def __init__(self, p, device, stereo_u8=False):
+        """stereo_u8: the stereoscope is produced as its uint8 codes k (value k/255, CPU techniques only) --
+        the compact form frame shards are all-gathered in; expand with `expand_u8`."""
         L = _native.lib()
         self.p = p
+        if stereo_u8:
+            p.flags |= 2
         oh, ow, mh, mw = output_shape(p)
         f32 = dict(dtype=torch.float32, device=device)
-        self.stereo = torch.empty((p.n, oh, ow, 3), **f32)
+        self.stereo = torch.empty((p.n, oh, ow, 3), dtype=torch.uint8 if stereo_u8 else torch.float32, device=device)
         self.depth_l = torch.empty((p.n, p.h, p.w, 3), **f32)
         self.depth_r = torch.empty((p.n, p.h, p.w, 3), **f32)
         self.mask = torch.empty((p.n, mh, mw), **f32)
@@ -72,6 +76,17 @@ class Plan:
     def stats(self):
         """Per-frame diagnostics words (see cs_common.h ST_*), e.g. polylines rows replayed sequentially."""
         return self.ws[: self.p.n * 64].view(torch.int32).view(self.p.n, 16).cpu()
+
+
+def expand_u8(codes, out=None):
+    """uint8 codes -> float32 k/255 on the device (true division, like the reference's np2tensor)."""
+    L = _native.lib()
+    codes = _dev(codes).contiguous()
+    assert codes.dtype == torch.uint8
+    if out is None:
+        out = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+    _native.check(L.cs_expand_u8(_ptr(codes), _ptr(out), codes.numel(), _stream()))
+    return out
 
 
 def generate(image, depth_map, divergence, separation, modes, stereo_balance, convergence_point,

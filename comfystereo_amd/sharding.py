@@ -38,10 +38,15 @@ def all_gather_frames(local, bounds, group=None):
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
 
 
-def generate_sharded(run_local, image, depth_map, fill, batch_size, group=None, gather=("stereoscope", "mask")):
+def generate_sharded(run_local, image, depth_map, fill, batch_size, group=None, gather=("stereoscope", "mask"),
+                     expand=None):
     """Run `run_local(image_block, depth_block) -> (stereo, depth_l, depth_r, mask)` on this rank's frame block
     and reassemble the requested outputs on every rank.  `image` / `depth_map` are the FULL batch (each rank
-    slices its own block; nothing is sent before compute)."""
+    slices its own block; nothing is sent before compute).
+
+    `expand`: when `run_local` returns the stereoscope in its compact uint8 form (engine.Plan(stereo_u8=True):
+    the CPU techniques' values are k/255 exactly), the shards cross xGMI as uint8 -- 4x fewer bytes -- and
+    `expand` (engine.expand_u8) turns the gathered tensor into float32 on every rank."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     n = image.shape[0]
     align = min(batch_size, n) if fill == 'gpu_warp' else 1
@@ -56,4 +61,6 @@ def generate_sharded(run_local, image, depth_map, fill, batch_size, group=None, 
     out = {}
     for name, t in zip(names, local):
         out[name] = all_gather_frames(t, bounds, group) if name in gather else t
+    if expand is not None and "stereoscope" in gather:
+        out["stereoscope"] = expand(out["stereoscope"])
     return out, bounds

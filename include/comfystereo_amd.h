@@ -79,7 +79,10 @@ typedef struct cs_params {
     int32_t depth_map_blur;     /* bool: direction-aware depth blur on/off                          */
     int32_t depth_blur_vert_smooth;
     int32_t flags;              /* bit 0: gpu_warp depth outputs are NOT clamped to 0..1 (module-level
-                                   create_stereoimages_gpu returns them unclamped, :1125-1126)      */
+                                   create_stereoimages_gpu returns them unclamped, :1125-1126)
+                                   bit 1: `stereo` receives the uint8 codes k (value = k/255) instead of
+                                   float32 -- the compact form frame shards are all-gathered in; CPU
+                                   techniques only (gpu_warp colours are genuine floats)           */
     double divergence, separation, stereo_balance, convergence_point, stereo_offset_exponent;
     double depth_blur_strength, depth_blur_edge_threshold, depth_blur_falloff;
 } cs_params;
@@ -140,6 +143,13 @@ CS_API size_t cs_warp_workspace_bytes(int n, int h, int w);
 CS_API int cs_forward_warp(const float *image, const float *depth, int n, int h, int w, double divergence_px,
                     double separation_px, double stereo_offset_exponent, double convergence_point, float *warped,
                     uint8_t *gap_mask, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * out[i] = codes[i] / 255 (float32, true division): expands a uint8 stereoscope (cs_params.flags bit 1), e.g.
+ * after the frame shards of a multi-GPU job were all-gathered in their compact form
+ * (= convertResult / np2tensor, reference GenerateStereo.py:41-44, 365-378).
+ */
+CS_API int cs_expand_u8(const uint8_t *codes, float *out, size_t count, void *stream);
 
 /*
  * Measurement hook for bench.py: while enabled, cs_generate brackets the launch of its dominant

@@ -215,3 +215,20 @@ def test_polylines_row_kernel_env_override(engine, monkeypatch):
     monkeypatch.setenv("CS_NO_TILE", "1")
     b = engine.apply_stereo_divergence(cuda(img), cuda(depth), 7.0, 0.3, 2.0, "polylines_soft", 0.5).cpu().numpy()
     assert np.array_equal(a, b) and np.array_equal(a, oracle.apply_stereo_divergence(img, depth, 7.0, 0.3, 2.0, "polylines_soft", 0.5))
+
+
+@pytest.mark.parametrize("fill,mode", [("polylines_soft", "left-right"), ("none", "red-cyan-anaglyph"), ("hybrid_edge", "top-bottom"),
+                                       ("polylines_sharp", "right-left")])
+def test_compact_u8_stereoscope_expands_to_the_float_output(engine, fill, mode):
+    """cs_params.flags bit 1 (what multi-GPU shards are gathered in) + cs_expand_u8 == the float32 output."""
+    n, h, w = 2, 40, 644
+    img = cuda(synth.image_f32(n, h, w, seed=7))
+    depth = cuda(synth.depth_batch("blobs", n, h, w, channels=3))
+    ref = engine.generate(img, depth, 6.0, 0.0, mode, 0.0, 0.5, 2.0, fill, 20.0, 20.0, False)
+    p = engine.make_params(n, h, w, h, w, 3, fill, mode, 6.0, 0.0, 0.0, 0.5, 2.0, False, 20.0, 20.0, 1.0, 0, 4)
+    plan = engine.Plan(p, img.device, stereo_u8=True)
+    out = plan.run(img, depth)
+    assert out[0].dtype == torch.uint8
+    assert torch.equal(engine.expand_u8(out[0]), ref[0])
+    for k in (1, 2, 3):
+        assert torch.equal(out[k], ref[k])
