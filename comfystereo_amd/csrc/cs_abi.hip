@@ -210,6 +210,7 @@ static void eye_setup(EyeArgs& E, double div_percent_signed, double sep_percent_
 // halo of the tiled polylines path: every source column within S of an output pixel can reach it.
 // |nd| <= max(|c|, |1-c|) because the normalised depth lies in [0, 1] (flat depth: nd = -c).
 static int poly_halo(double div_percent_a, double div_percent_b, double sep_percent, double exponent, double conv, int w) {
+    if (!(exponent >= 0.0)) return 1 << 20;  // |nd|^e is unbounded near 0 for e < 0: no finite halo
     double m = fmax(fabs(conv), fabs(1.0 - conv));
     double d = fmax(fabs(div_percent_a), fabs(div_percent_b)) / 100.0 * w;
     double s = d * pow(m, exponent) * 1.0001 + fabs(sep_percent / 100.0 * w);
