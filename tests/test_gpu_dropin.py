@@ -1,0 +1,93 @@
+"""The drop-in surface itself on the GPU: StereoImageNode.generate with CPU tensors (as ComfyUI calls it) against the
+reference's captured outputs, and the two module functions GenerateStereo.py calls.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+import synth
+from conftest import node_case_expected, node_case_inputs
+from oracle import node_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_node_generate_matches_reference_goldens(golden_node):
+    from comfystereo_amd.GenerateStereo import FILL_TECHNIQUES, StereoImageNode
+    ui = {v: k for k, v in FILL_TECHNIQUES.items()}
+    node = StereoImageNode()
+    n = 0
+    for case in golden_node.meta["cases"]:
+        if case["id"].startswith("resize/"):
+            continue
+        img, depth = node_case_inputs(golden_node, case)
+        out = node.generate(torch.from_numpy(img), torch.from_numpy(depth), case["divergence"], case["separation"], case["mode"],
+                            case["balance"], case["convergence"], case["exponent"], ui[case["fill"]], case["edge_threshold"],
+                            case["strength"], case["blur"], **case["kw"])
+        assert all(isinstance(t, torch.Tensor) and not t.is_cuda and t.dtype == torch.float32 for t in out)
+        want = node_case_expected(golden_node, case)
+        got = [t.numpy() for t in out]
+        if case["fill"] == "gpu_warp":
+            assert np.abs(got[0] - want[0]).max() <= 1e-4, case["id"]
+        else:
+            assert np.array_equal(got[0], want[0]), case["id"]
+        assert np.array_equal(got[1][..., 0], want[1]) and np.array_equal(got[2][..., 0], want[2]), case["id"]
+        assert np.array_equal(got[3], want[3]), case["id"]
+        n += 1
+    assert n >= 45
+
+
+def test_unknown_fill_string_falls_back_to_gpu_warp():
+    from comfystereo_amd.GenerateStereo import StereoImageNode
+    img = torch.from_numpy(synth.image_f32(1, 32, 64, seed=1))
+    dep = torch.from_numpy(synth.depth_batch("radial", 1, 32, 64, channels=3))
+    a = StereoImageNode().generate(img, dep, 4.5, 0, "left-right", 0, 0.5, 2, "no such technique", 20, 20, False)
+    b = StereoImageNode().generate(img, dep, 4.5, 0, "left-right", 0, 0.5, 2, "GPU Warp (Fast)", 20, 20, False)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and a[3].shape == (1, 32, 64)
+
+
+@pytest.mark.parametrize("fill", ["polylines_soft", "naive_interpolating", "hybrid_edge", "no-such-technique"])
+def test_create_stereoimages_returns_pil_like_the_reference(fill):
+    from comfystereo_amd import stereoimage_generation as sig
+    h, w = 40, 96
+    img = synth.image_f32(1, h, w, seed=2)[0]
+    depth = synth.blobs(h, w, seed=1)
+    args = dict(divergence=6.0, separation=0.5, modes=["left-right", "red-cyan-anaglyph"], stereo_balance=0.2,
+                stereo_offset_exponent=1.3, fill_technique=fill, depth_blur_strength=8.0, depth_blur_edge_threshold=6.0,
+                direction_aware_depth_blur=False, convergence_point=0.4)
+    out = sig.create_stereoimages(torch.from_numpy(img).permute(2, 0, 1), torch.from_numpy(depth), **args)
+    assert isinstance(out, tuple) and len(out) == 2  # (images, modified depth) when the blur is off
+    images, mod = out
+    assert all(isinstance(i, Image.Image) for i in images) and isinstance(mod, Image.Image)
+    assert images[0].size == (2 * w, h) and images[1].size == (w, h) and mod.size == (w, h) and mod.mode == "L"
+    okw = {k: v for k, v in args.items() if k not in ("divergence", "separation", "modes", "stereo_balance", "direction_aware_depth_blur")}
+    if fill == "no-such-technique":  # reference falls through its dispatch: both eyes are the source image
+        src = np.clip(img * np.float32(255), 0, 255).astype(np.uint8)
+        assert np.array_equal(np.array(images[0]), np.hstack([src, src]))
+        return
+    want, ml, _ = node_oracle.create_stereoimages(img.transpose(2, 0, 1), depth, 6.0, 0.5, ["left-right", "red-cyan-anaglyph"],
+                                                  0.2, direction_aware_depth_blur=False, **okw)
+    assert np.array_equal(np.array(images[0]), want[0]) and np.array_equal(np.array(images[1]), want[1])
+    assert np.array_equal(np.array(mod), ml)
+    # blur on: three return values, and return_modified_depth=False: the list only
+    out3 = sig.create_stereoimages(torch.from_numpy(img).permute(2, 0, 1), torch.from_numpy(depth), 6.0, 0.5, "left-right", 0.2, 1.3,
+                                   fill, 8.0, 6.0, True)
+    assert len(out3) == 3
+    assert isinstance(sig.create_stereoimages(torch.from_numpy(img).permute(2, 0, 1), torch.from_numpy(depth), 6.0,
+                                              return_modified_depth=False, fill_technique=fill), list)
+
+
+def test_create_stereoimages_gpu_matches_oracle():
+    from comfystereo_amd import stereoimage_generation as sig
+    b, h, w = 3, 64, 200
+    img = synth.image_f32(b, h, w, seed=3).transpose(0, 3, 1, 2).copy()
+    depth = synth.depth_batch("blobs", b, h, w, channels=1)[..., 0] * np.float32(1.7)  # > 1: already "0..255-like"
+    res, lo, ro, mask = sig.create_stereoimages_gpu(torch.from_numpy(img), torch.from_numpy(depth), 4.5, 0.2,
+                                                    ["left-right", "top-bottom"], 0.1, 2.0, 0.5, 20.0, 20.0, False)
+    want, wl, wr, wm = node_oracle.create_stereoimages_gpu(img, depth, 4.5, 0.2, ["left-right", "top-bottom"], 0.1, 2.0, 0.5, 20.0,
+                                                           20.0, False)
+    assert len(res) == 2 and res[0].is_cuda and tuple(res[0].shape) == (b, 3, h, 2 * w) and tuple(res[1].shape) == (b, 3, 2 * h, w)
+    for r, wv in zip(res, want):
+        assert np.abs(r.cpu().numpy() - wv).max() <= 2e-6
+    assert mask.dtype == torch.bool and np.array_equal(mask.cpu().numpy(), wm)
+    assert np.array_equal(lo.cpu().numpy(), wl) and np.array_equal(ro.cpu().numpy(), wr)  # unclamped, like the reference
