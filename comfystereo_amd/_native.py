@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcomfystereo_hip.so")
+# CS_LIB_PATH: development override (A/B timing of two builds of the same library in one GPU session)
+LIB_PATH = os.environ.get("CS_LIB_PATH") or os.path.join(_HERE, "libcomfystereo_hip.so")
 
 CS_OK, CS_EINVAL, CS_EWORKSPACE, CS_ELIMIT, CS_EHIP = 0, -1, -2, -3, -4
 

@@ -25,6 +25,7 @@
 #include "cs_common.h"
 #include "cs_kernels.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace cs {
 
@@ -83,6 +84,7 @@ template <int SHARP, int PT_KP, int PT_KS, int MINW>
 __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
+    if (A.dbg == 10) return;
     const int tiles = (A.w + PT_T - 1) / PT_T;
     const int tile = blockIdx.x % tiles, row = blockIdx.x / tiles, frame = blockIdx.y;
     const int eyei = A.single >= 0 ? A.single : (int)blockIdx.z;
@@ -105,8 +107,10 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
     float* pz = px + ((nptmax + 3) & ~3);                                       // [nptmax] |coord_d| of point o
     uint32_t* img = (uint32_t*)(pz + ((nptmax + 3) & ~3));                      // [nsmax] R | G<<8 | B<<16
     unsigned* cnt = (unsigned*)(img + ((nsmax + 3) & ~3));                      // [PT_T] low16: points, high16: segments
-    uint16_t* pts = (uint16_t*)(cnt + PT_T);                                    // [PT_T][PT_KP]
-    uint16_t* sgs = pts + PT_T * PT_KP;                                         // [PT_T][PT_KS]
+    uint16_t* plist = (uint16_t*)(cnt + PT_T);                                  // [PT_T] pixels the fastest path left over
+    uint16_t* pts = plist + PT_T;                                               // [PT_T][PT_KP]  (fold tiles only)
+    uint16_t* sgs = pts + PT_T * PT_KP;                                         // [PT_T][PT_KS]  (fold tiles only)
+    uint16_t* pseg = sgs;                                                       // [PT_T] monotone tiles: a segment passing through the pixel
     uint8_t* res = (uint8_t*)(sgs + PT_T * PT_KS);                              // [3*PT_T]
     uint8_t* dep8 = res + align16(3 * PT_T);                                    // [PT_T] depth-map output code of this eye
     int* flags = (int*)(dep8 + PT_T);                                           // [4]
@@ -120,7 +124,20 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
         for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += PT_THREADS) dst[i] = src[i];
     }
     for (int i = tid; i < PT_T; i += PT_THREADS) cnt[i] = 0;
-    if (tid == 0) flags[0] = 0;
+    if (tid == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
+    if (A.dbg == 9) return;
+    // the depth row of the halo'ed range: loads issued now, consumed after the image conversion (one memory round
+    // trip for both instead of two back to back)
+    constexpr int PT_PF = 3;
+    const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
+    const float dmin = E.enabled ? csm::ord2f(st[E.st_min]) : 0.0f, dmax = E.enabled ? csm::ord2f(st[E.st_max]) : 0.0f;
+    const float* drow = E.depth + rowpix;
+    float dpre[PT_PF];
+#pragma unroll
+    for (int k = 0; k < PT_PF; k++) {
+        const int j = tid + k * PT_THREADS;
+        dpre[k] = j < ns ? drow[s0 + j] : 0.0f;
+    }
     // stage the source pixels of the halo'ed range as packed uint8 RGB (reference :1508)
     if (A.image_f32) {
         const float* src = A.image_f32 + (rowpix + s0) * 3;
@@ -150,24 +167,22 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
         for (int j = tid; j < ns; j += PT_THREADS)
             img[j] = (uint32_t)src[3 * j] | ((uint32_t)src[3 * j + 1] << 8) | ((uint32_t)src[3 * j + 2] << 16);
     }
-    const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
-    const float* drow = E.depth + rowpix;
     __syncthreads();  // tables ready
+    if (A.dbg == 8) return;
     if (!E.enabled) {
         for (int q = tid; q < wt; q += PT_THREADS) dep8[q] = csm::f32_to_u8_wrap((drow[o0 + q] * scale) * 255.0f);
     }
     if (E.enabled) {
-        const float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
         const bool flat = dmax == dmin;
         const float range = dmax - dmin;
-        for (int j = tid; j < ns; j += PT_THREADS) {
-            float d = drow[s0 + j] * scale;
+        auto stage_depth = [&](int j, float draw) {
+            float d = draw * scale;
             // depth-map output of this column: (depth*255).astype(uint8) wraps mod 256 (quirk Q7)
             const int qq = s0 + j - o0;
             if (qq >= 0 && qq < wt) dep8[qq] = csm::f32_to_u8_wrap(d * 255.0f);
             float nd = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
             float sgn = nd >= 0.0f ? 1.0f : -1.0f;
-            float pw = csm::powf_exact_simt(fabsf(nd), A.e32, tabs);
+            float pw = A.dbg == 16 ? fabsf(nd) * fabsf(nd) : csm::powf_exact_simt(fabsf(nd), A.e32, tabs);
             float cdj = (sgn * pw) * E.div32;                                     // coord_d   (:1926)
             float x = ((float)(s0 + j) + 0.5f + cdj) + E.sep32;                   // coord_x   (:1927)
             float z = fabsf(cdj);
@@ -177,7 +192,13 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
             } else {
                 px[1 + j] = x; pz[1 + j] = z;
             }
+        };
+#pragma unroll
+        for (int k = 0; k < PT_PF; k++) {
+            const int j = tid + k * PT_THREADS;
+            if (j < ns) stage_depth(j, dpre[k]);
         }
+        for (int j = tid + PT_PF * PT_THREADS; j < ns; j += PT_THREADS) stage_depth(j, drow[s0 + j]);
         if (tid == 0) {
             px[0] = (float)(-1.0 * w); pz[0] = 0.0f;
             px[npts - 1] = (float)(2.0 * w); pz[npts - 1] = 0.0f;
@@ -189,18 +210,51 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
     const bool left_edge = s0 == 0, right_edge = s1 == w;
     bool hazard = false;
 
+    // ---- REGISTER ----------------------------------------------------------------------------------------
+    // Tiles whose staged polyline is strictly increasing in x (no fold: the common case away from occluding depth
+    // edges) take the MONO pass: every segment is forward and the segments over a pixel are exactly the chain around
+    // its points, which are consecutive ids -- so each pixel only needs its first and last point id, written with
+    // plain 16-bit stores by the points that see a different pixel to their left / right (cnt = first | last << 16,
+    // 0 = no point), and pseg = the segment bridging a pixel without points.  No atomics, nothing per segment.
+    // Tiles with a fold take the FULL pass: cnt = points in the pixel (low 16) | forward segments overlapping it
+    // (high 16) and the fixed-capacity id lists pts / sgs, filled through returning LDS atomics.
+    const int ofirst = left_edge ? 0 : 1, olast = right_edge ? npts - 1 : npts - 2;
     if (E.enabled) {
-        // ---- REGISTER points and forward segments into the per-pixel slot lists ------------------
-        const int ofirst = left_edge ? 0 : 1, olast = right_edge ? npts - 1 : npts - 2;
+        bool fold = false;
+        for (int o = ofirst + tid; o < olast; o += PT_THREADS) fold = fold || !(px[o] < px[o + 1]);
+        if (fold) flags[3] = 1;
+    }
+    __syncthreads();
+    const bool mono = flags[3] == 0;
+    if (E.enabled && mono) {
+        uint16_t* fl = (uint16_t*)cnt;
+        for (int o = ofirst + tid; o <= olast; o += PT_THREADS) {
+            const float x0 = px[o];
+            const float f0 = floorf(x0);
+            const float fm = floorf(px[max(o - 1, 0)]), f1 = floorf(px[min(o + 1, npts - 1)]);
+            if (x0 >= (float)o0 && x0 < (float)(o0 + wt)) {   // (never a sentinel: they lie outside the frame)
+                const int q = (int)x0 - o0;
+                if (fm != f0) fl[2 * q] = (uint16_t)o;
+                if (f1 != f0) fl[2 * q + 1] = (uint16_t)o;
+            }
+            // pixels strictly between the end pixels of segment o -> o+1 (disocclusion bridges)
+            if (o < olast && f1 - f0 >= 2.0f && !(f1 <= (float)o0 || f0 >= (float)(o0 + wt - 1))) {
+                const int pa = f0 < (float)o0 ? o0 : (int)f0 + 1;
+                const int pb = f1 > (float)(o0 + wt - 1) ? o0 + wt - 1 : (int)f1 - 1;
+                for (int p = pa; p <= pb; p++) pseg[p - o0] = (uint16_t)o;
+            }
+        }
+    } else if (E.enabled) {
         const int niter = (olast - ofirst + 1 + PT_THREADS - 1) / PT_THREADS;
         for (int it = 0; it < niter; it++) {
             const int o = ofirst + it * PT_THREADS + tid;
             const bool live = o <= olast;
             int p0 = 1, p1 = 0;
+            float f0 = 0.0f, f1 = 0.0f;
             if (live) {
                 const float x0 = px[o];
                 if (x0 >= (float)o0 && x0 < (float)(o0 + wt)) {
-                    int q = (int)x0 - o0;
+                    const int q = (int)x0 - o0;
                     unsigned idx = atomicAdd(&cnt[q], 1u) & 0xffffu;
                     if (idx < PT_KP) pts[q * PT_KP + idx] = (uint16_t)o;
                     else hazard = true;
@@ -208,7 +262,7 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
                 if (o < olast) {  // segment o -> o+1
                     const float x1 = px[o + 1];
                     if (x0 < x1) {  // reversed / degenerate segments are never active
-                        float f0 = floorf(x0), f1 = floorf(x1);
+                        f0 = floorf(x0); f1 = floorf(x1);
                         if (!(f1 < (float)o0 || f0 > (float)(o0 + wt - 1))) {
                             p0 = f0 < (float)o0 ? o0 : (int)f0;
                             p1 = f1 > (float)(o0 + wt - 1) ? o0 + wt - 1 : (int)f1;
@@ -244,30 +298,147 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
     }
     __syncthreads();
 
+    // ---- EVALUATE ----------------------------------------------------------------------------------------
+    // per-pixel constants of the float64 ("Python float") branch of the sub-interval arithmetic
+    struct PixC { double sig_dd; float ff64, tf64, center64; };
+    auto pix_consts = [](int col) {
+        PixC P;
+        const double from_d = (double)col + 1e-7, to_d = (double)(col + 1) - 1e-7;
+        P.sig_dd = to_d - from_d;
+        P.ff64 = (float)from_d; P.tf64 = (float)to_d; P.center64 = (float)(from_d + 0.5 * P.sig_dd);
+        return P;
+    };
+    const float eps32 = (float)1e-7;
+    auto put = [&](int q, uint32_t rgb) {
+        res[3 * q] = (uint8_t)rgb; res[3 * q + 1] = (uint8_t)(rgb >> 8); res[3 * q + 2] = (uint8_t)(rgb >> 16);
+    };
+    // ---- chain path: the pixel's np points are CONSECUTIVE polyline points o1 .. o1+np-1 with strictly increasing x
+    // inside the pixel and exactly np+1 forward segments overlap it -- then those are the chain segments (incoming,
+    // internal, outgoing) and sub-interval k can only be covered by chain segment k = (o1-1+k -> o1+k): two compares
+    // verify it, no list search.  np == 0: the one segment passing through.  Returns false when the pixel needs the
+    // general search.  Called by whole waves (ballots inside); `act` masks the lanes that hold a pixel.
+    auto eval_chain = [&](bool act, int q, uint32_t& rgb) -> bool {
+        const int col = o0 + q;
+        const unsigned c = cnt[q];
+        int npr, cover, o1;  // points in the pixel, forward segments over it, its smallest point id (np == 0: the segment's end)
+        if (mono) {
+            const int pf = (int)(c & 0xffffu), pl = (int)(c >> 16);
+            npr = pf ? pl - pf + 1 : 0;
+            cover = npr + 1;
+            o1 = pf ? pf : (int)pseg[q] + 1;
+        } else {
+            npr = (int)(c & 0x7fffu); cover = (int)(c >> 16);
+            int om = 0xffff;
+#pragma unroll
+            for (int k = 0; k < PT_KP; k++) om = min(om, k < npr ? (int)pts[q * PT_KP + k] : 0xffff);
+            o1 = npr ? om : (int)sgs[q * PT_KS] + 1;
+        }
+        const int np = act ? min(npr, PT_KP) : 0;
+        const PixC P = pix_consts(col);
+        const double sig_dd = P.sig_dd;
+        const float ff64 = P.ff64, tf64 = P.tf64, center64 = P.center64;
+        // wave-uniform bound: unrolled bodies beyond it are skipped by scalar branches
+        // (ballots, not shuffles: a shuffle reduction is a chain of LDS-crossbar round trips)
+        int wnp = 0;
+#pragma unroll
+        for (int t = 1; t <= PT_KP; t++) wnp = __any(np >= t) ? t : wnp;
+        bool chain = act && cover == npr + 1 && npr < PT_KP;
+        o1 = chain ? o1 : 1;
+        float cx[PT_KP + 2];     // cx[k] = x of point o1 - 1 + k, k = 0 .. np + 1
+        uint32_t cc[PT_KP + 2];  // colour of the source pixel that point refers to
+        int cj[PT_KP + 2];
+        if (__any(chain)) {
+#pragma unroll
+            for (int k = 0; k < PT_KP + 2; k++) {
+                if (k <= wnp + 1) {
+                    const int o = chain && k <= np + 1 ? o1 - 1 + k : 0;
+                    cx[k] = px[o];
+                    cj[k] = min(max(SHARP ? (o - 1) >> 1 : o - 1, 0), ns - 1);
+                    cc[k] = img[cj[k]];
+                } else { cx[k] = 0.0f; cj[k] = 0; cc[k] = 0; }
+            }
+            // every chain segment must be forward (then it is registered for this pixel, and with nsg == np + 1
+            // the registered set IS the chain: no other layer passes through the pixel)
+#pragma unroll
+            for (int k = 0; k <= PT_KP; k++)
+                if (k <= wnp) chain = chain && (k > np || cx[k] < cx[k + 1]) && (k < 1 || k > np || cx[k] < (float)(col + 1));
+            float color0 = 0.5f, color1 = 0.5f, color2 = 0.5f;
+            float prev = (float)col;
+#pragma unroll
+            for (int k = 0; k <= PT_KP; k++) {
+                if (k <= wnp) {
+                    const bool live = chain && k <= np;
+                    const float a = k == 0 ? -INFINITY : cx[k];
+                    const float b = k < np ? cx[k + 1] : INFINITY;
+                    const bool from64 = !(a > (float)col), to64 = !(b < (float)(col + 1));
+                    const bool sig64 = from64 && to64;
+                    const float ff = from64 ? ff64 : a + eps32;
+                    const float tf = to64 ? tf64 : b - eps32;
+                    const float sig_f = tf - ff;
+                    const float center = sig64 ? center64 : ff + 0.5f * sig_f;
+                    const bool work = live && (sig64 ? sig_dd != 0.0 : sig_f != 0.0f);
+                    // chain segment k must be the active one: x0 < centre <= x1, centres monotone inside the pixel
+                    const bool ok = (cx[k] < center) && !(cx[k + 1] < center) && !(center < prev) &&
+                                    !(center > (float)(col + 1));
+                    chain = chain && (!live || !work || ok) && (!live || (!(center < prev) && !(center > (float)(col + 1))));
+                    prev = live ? center : prev;
+                    const float ip_k = (center - cx[k]) / (cx[k + 1] - cx[k]);
+                    const float om = 1.0f - ip_k;
+                    const float sg = sig64 ? (float)sig_dd : sig_f;
+                    const uint32_t il = cc[k], ir = cc[k + 1];
+                    const float l0 = (float)(il & 0xffu), l1 = (float)((il >> 8) & 0xffu), l2 = (float)((il >> 16) & 0xffu);
+                    const float r0 = (float)(ir & 0xffu), r1 = (float)((ir >> 8) & 0xffu), r2 = (float)((ir >> 16) & 0xffu);
+                    float n0 = color0 + (l0 * om + r0 * ip_k) * sg;
+                    float n1 = color1 + (l1 * om + r1 * ip_k) * sg;
+                    float n2 = color2 + (l2 * om + r2 * ip_k) * sg;
+                    const bool flat = cj[k] == cj[k + 1];
+                    if (__any(work && flat)) {
+                        if (flat) {
+                            if (sig64) {
+                                n0 = (float)((double)color0 + (double)l0 * sig_dd);
+                                n1 = (float)((double)color1 + (double)l1 * sig_dd);
+                                n2 = (float)((double)color2 + (double)l2 * sig_dd);
+                            } else {
+                                n0 = color0 + l0 * sig_f;
+                                n1 = color1 + l1 * sig_f;
+                                n2 = color2 + l2 * sig_f;
+                            }
+                        }
+                    }
+                    color0 = work ? n0 : color0;
+                    color1 = work ? n1 : color1;
+                    color2 = work ? n2 : color2;
+                }
+            }
+            rgb = (uint32_t)csm::f32_to_u8_wrap(color0) | ((uint32_t)csm::f32_to_u8_wrap(color1) << 8) |
+                  ((uint32_t)csm::f32_to_u8_wrap(color2) << 16);
+        }
+        return chain;
+    };
+
     if (A.dbg == 12) return;
-    // ---- EVALUATE one output pixel per lane -------------------------------------------------------
-    for (int rep = 0; rep < (A.dbg == 17 ? 2 : 1); rep++)  // development: dbg 17 evaluates twice (marginal-cost probe)
+    // ---- pass 1, one output pixel per lane.  soft: the fastest path per lane -- exactly ONE polyline point o in
+    // the pixel and two segments over it (flat and gently sloped regions): the two pieces [col, x] and [x, col+1]
+    // belong to the segments (o-1 -> o) and (o -> o+1), verified below; straight-line code.  Every other pixel goes
+    // onto the tile's list `plist`, which pass 2 works off densely packed (a few percent of the pixels, but spread
+    // over a fifth of the waves).  sharp (two points per source pixel): the chain path directly.
     for (int q = tid; q < wt; q += PT_THREADS) {
         const int col = o0 + q;
         uint32_t rgb = 0;
-        if (!E.enabled) {
+        bool done = true;
+        if (!E.enabled || A.dbg == 15) {
             rgb = img[col - s0];
+        } else if (SHARP) {
+            done = eval_chain(true, q, rgb);
+            if (!done) { cnt[q] |= 0x8000u; flags[1] = 1; }
         } else {
             const unsigned c = cnt[q];
-            const int np = min((int)(c & 0xffffu), PT_KP), nsg = min((int)(c >> 16), PT_KS);
-            // per-pixel constants of the float64 ("Python float") branch of the sub-interval arithmetic
-            const double from_d = (double)col + 1e-7, to_d = (double)(col + 1) - 1e-7;
-            const double sig_dd = to_d - from_d;
-            const float ff64 = (float)from_d, tf64 = (float)to_d, center64 = (float)(from_d + 0.5 * sig_dd);
-            const float eps32 = (float)1e-7;
-
-            // ---- fastest path, decided for the whole wave: every pixel holds exactly ONE polyline point and two
-            // segments (flat and gently sloped regions).  Straight-line code, two scalar branches.  The point o,
-            // its neighbours o-1 / o+1 and the three source colours are all that is needed; the two pieces
-            // [col, x] and [x, col+1] belong to the segments (o-1 -> o) and (o -> o+1), verified below.
-            bool done = false;
-            if (!SHARP && __all(np == 1 && nsg == 2)) {
-                const int o = (int)pts[q * PT_KP];
+            done = mono ? (c != 0u && (c & 0xffffu) == (c >> 16)) : c == 0x20001u;
+            const PixC P = pix_consts(col);
+            const double sig_dd = P.sig_dd;
+            const float ff64 = P.ff64, tf64 = P.tf64, center64 = P.center64;
+            if (__any(done)) {
+                const int o = done ? (mono ? (int)(c & 0xffffu) : (int)pts[q * PT_KP]) : 1;
                 const float xm = px[o - 1], x = px[o], xp = px[o + 1];
                 const int j = o - 1;  // source column (local) of point o; o-1 >= 1 and o+1 <= npts-2 checked via jok
                 const bool jok = j >= 1 && j + 1 <= ns - 1;
@@ -287,133 +458,72 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
                 bool ok = jok && xm < x && x < xp;
                 ok = ok && !(c0 < (float)col) && !(c1 < c0) && !(c1 > (float)(col + 1));
                 ok = ok && (!w0 || (xm < c0 && !(x < c0))) && (!w1 || (x < c1 && !(xp < c1)));
-                if (__all(ok)) {
-                    const float ip0 = (c0 - xm) / (x - xm), ip1 = (c1 - x) / (xp - x);
-                    const float om0 = 1.0f - ip0, om1 = 1.0f - ip1;
-                    const float a0 = (float)(ia & 0xffu), a1 = (float)((ia >> 8) & 0xffu), a2 = (float)((ia >> 16) & 0xffu);
-                    const float b0 = (float)(ib & 0xffu), b1 = (float)((ib >> 8) & 0xffu), b2 = (float)((ib >> 16) & 0xffu);
-                    const float e0 = (float)(ic & 0xffu), e1 = (float)((ic >> 8) & 0xffu), e2 = (float)((ic >> 16) & 0xffu);
-                    float k0 = 0.5f, k1 = 0.5f, k2 = 0.5f;
-                    const float p0 = k0 + (a0 * om0 + b0 * ip0) * sig0, p1 = k1 + (a1 * om0 + b1 * ip0) * sig0,
-                                p2 = k2 + (a2 * om0 + b2 * ip0) * sig0;
-                    k0 = w0 ? p0 : k0; k1 = w0 ? p1 : k1; k2 = w0 ? p2 : k2;
-                    const float r0 = k0 + (b0 * om1 + e0 * ip1) * sg1, r1 = k1 + (b1 * om1 + e1 * ip1) * sg1,
-                                r2 = k2 + (b2 * om1 + e2 * ip1) * sg1;
-                    k0 = w1 ? r0 : k0; k1 = w1 ? r1 : k1; k2 = w1 ? r2 : k2;
-                    rgb = (uint32_t)csm::f32_to_u8_wrap(k0) | ((uint32_t)csm::f32_to_u8_wrap(k1) << 8) |
-                          ((uint32_t)csm::f32_to_u8_wrap(k2) << 16);
-                    done = true;
-                }
+                done = done && ok;
+                const float ip0 = (c0 - xm) / (x - xm), ip1 = (c1 - x) / (xp - x);
+                const float om0 = 1.0f - ip0, om1 = 1.0f - ip1;
+                const float a0 = (float)(ia & 0xffu), a1 = (float)((ia >> 8) & 0xffu), a2 = (float)((ia >> 16) & 0xffu);
+                const float b0 = (float)(ib & 0xffu), b1 = (float)((ib >> 8) & 0xffu), b2 = (float)((ib >> 16) & 0xffu);
+                const float e0 = (float)(ic & 0xffu), e1 = (float)((ic >> 8) & 0xffu), e2 = (float)((ic >> 16) & 0xffu);
+                float k0 = 0.5f, k1 = 0.5f, k2 = 0.5f;
+                const float p0 = k0 + (a0 * om0 + b0 * ip0) * sig0, p1 = k1 + (a1 * om0 + b1 * ip0) * sig0,
+                            p2 = k2 + (a2 * om0 + b2 * ip0) * sig0;
+                k0 = w0 ? p0 : k0; k1 = w0 ? p1 : k1; k2 = w0 ? p2 : k2;
+                const float r0 = k0 + (b0 * om1 + e0 * ip1) * sg1, r1 = k1 + (b1 * om1 + e1 * ip1) * sg1,
+                            r2 = k2 + (b2 * om1 + e2 * ip1) * sg1;
+                k0 = w1 ? r0 : k0; k1 = w1 ? r1 : k1; k2 = w1 ? r2 : k2;
+                rgb = (uint32_t)csm::f32_to_u8_wrap(k0) | ((uint32_t)csm::f32_to_u8_wrap(k1) << 8) |
+                      ((uint32_t)csm::f32_to_u8_wrap(k2) << 16);
             }
-            if (!done) {
-            // wave-uniform bounds: unrolled bodies beyond them are skipped by scalar branches
-            // (ballots, not shuffles: a shuffle reduction is a chain of LDS-crossbar round trips)
-            int wnp = 0, wns = 0;
-#pragma unroll
-            for (int t = 1; t <= PT_KP; t++) wnp = __any(np >= t) ? t : wnp;
-#pragma unroll
-            for (int t = 1; t <= PT_KS; t++) wns = __any(nsg >= t) ? t : wns;
-            // ---- fast path: "single chain" pixel -------------------------------------------------------
-            // The pixel's points are CONSECUTIVE polyline points o1 .. o1+np-1 with strictly increasing x and
-            // the only segments registered for the pixel are the np+1 chain segments (incoming, internal,
-            // outgoing).  Then sub-interval k can only be covered by chain segment k = (o1-1+k -> o1+k): two
-            // compares verify it, no list search, x's and colours are loaded once.  Anything else -> generic.
-            bool chain = nsg == np + 1 && np < PT_KP;
-            int o1;
-            {
-                int omin = 0x7fffffff, omax = -1;
-#pragma unroll
-                for (int k = 0; k < PT_KP; k++) {
-                    if (k < wnp) {
-                        int o = k < np ? (int)pts[q * PT_KP + k] : omin;
-                        omin = min(omin, o);
-                        omax = k < np ? max(omax, o) : omax;
-                    }
-                }
-                // np == 0: the single registered segment is the chain; its start point plays the role of o1 - 1
-                o1 = np == 0 ? (nsg == 1 ? (int)sgs[q * PT_KS] + 1 : 1) : omin;
-                chain = chain && (np == 0 || omax - omin == np - 1);   // distinct ids in a span of np -> consecutive
-            }
-            float cx[PT_KP + 2];     // cx[k] = x of point o1 - 1 + k, k = 0 .. np + 1
-            uint32_t cc[PT_KP + 2];  // colour of the source pixel that point refers to
-            int cj[PT_KP + 2];
-            if (__any(chain)) {
-#pragma unroll
-                for (int k = 0; k < PT_KP + 2; k++) {
-                    if (k <= wnp + 1) {
-                        const int o = chain && k <= np + 1 ? o1 - 1 + k : 0;
-                        cx[k] = px[o];
-                        cj[k] = min(max(SHARP ? (o - 1) >> 1 : o - 1, 0), ns - 1);
-                        cc[k] = img[cj[k]];
-                    } else { cx[k] = 0.0f; cj[k] = 0; cc[k] = 0; }
-                }
-                // every chain segment must be forward (then it is registered for this pixel, and with nsg == np + 1
-                // the registered set IS the chain: no other layer passes through the pixel)
-#pragma unroll
-                for (int k = 0; k <= PT_KP; k++)
-                    if (k <= wnp) chain = chain && (k > np || cx[k] < cx[k + 1]);
-                float color0 = 0.5f, color1 = 0.5f, color2 = 0.5f;
-                float prev = (float)col;
-#pragma unroll
-                for (int k = 0; k <= PT_KP; k++) {
-                    if (k <= wnp) {
-                        const bool live = chain && k <= np;
-                        const float a = k == 0 ? -INFINITY : cx[k];
-                        const float b = k < np ? cx[k + 1] : INFINITY;
-                        const bool from64 = !(a > (float)col), to64 = !(b < (float)(col + 1));
-                        const bool sig64 = from64 && to64;
-                        const float ff = from64 ? ff64 : a + eps32;
-                        const float tf = to64 ? tf64 : b - eps32;
-                        const float sig_f = tf - ff;
-                        const float center = sig64 ? center64 : ff + 0.5f * sig_f;
-                        const bool work = live && (sig64 ? sig_dd != 0.0 : sig_f != 0.0f);
-                        // chain segment k must be the active one: x0 < centre <= x1, centres monotone inside the pixel
-                        const bool ok = (cx[k] < center) && !(cx[k + 1] < center) && !(center < prev) &&
-                                        !(center > (float)(col + 1));
-                        chain = chain && (!live || !work || ok) && (!live || (!(center < prev) && !(center > (float)(col + 1))));
-                        prev = live ? center : prev;
-                        const float ip_k = (center - cx[k]) / (cx[k + 1] - cx[k]);
-                        const float om = 1.0f - ip_k;
-                        const float sg = sig64 ? (float)sig_dd : sig_f;
-                        const uint32_t il = cc[k], ir = cc[k + 1];
-                        const float l0 = (float)(il & 0xffu), l1 = (float)((il >> 8) & 0xffu), l2 = (float)((il >> 16) & 0xffu);
-                        const float r0 = (float)(ir & 0xffu), r1 = (float)((ir >> 8) & 0xffu), r2 = (float)((ir >> 16) & 0xffu);
-                        float n0 = color0 + (l0 * om + r0 * ip_k) * sg;
-                        float n1 = color1 + (l1 * om + r1 * ip_k) * sg;
-                        float n2 = color2 + (l2 * om + r2 * ip_k) * sg;
-                        const bool flat = cj[k] == cj[k + 1];
-                        if (__any(work && flat)) {
-                            if (flat) {
-                                if (sig64) {
-                                    n0 = (float)((double)color0 + (double)l0 * sig_dd);
-                                    n1 = (float)((double)color1 + (double)l1 * sig_dd);
-                                    n2 = (float)((double)color2 + (double)l2 * sig_dd);
-                                } else {
-                                    n0 = color0 + l0 * sig_f;
-                                    n1 = color1 + l1 * sig_f;
-                                    n2 = color2 + l2 * sig_f;
-                                }
-                            }
-                        }
-                        color0 = work ? n0 : color0;
-                        color1 = work ? n1 : color1;
-                        color2 = work ? n2 : color2;
-                    }
-                }
-                rgb = (uint32_t)csm::f32_to_u8_wrap(color0) | ((uint32_t)csm::f32_to_u8_wrap(color1) << 8) |
-                      ((uint32_t)csm::f32_to_u8_wrap(color2) << 16);
-            }
+            if (!done) plist[atomicAdd((unsigned*)&flags[2], 1u)] = (uint16_t)q;
+        }
+        if (done) put(q, rgb);
+    }
+    if (A.dbg == 18) return;
+    if (!SHARP) {
+        __syncthreads();
+        // ---- pass 2 (soft): the chain path over the listed pixels
+        const int nlist = flags[2];
+        for (int base = tid & ~63; base < nlist; base += PT_THREADS) {
+            const int i = base + lane;
+            const bool act = i < nlist;
+            const int q = plist[act ? i : 0];
+            uint32_t rgb = 0;
+            const bool ok = eval_chain(act, q, rgb);
+            if (ok) put(q, rgb);
+            else if (act) { cnt[q] |= 0x8000u; flags[1] = 1; }
             if (A.dbg == 14 && A.stats_rw) {  // development: how many pixels take which path
-                unsigned long long mc = __ballot(chain), mg = __ballot(!chain);
+                unsigned long long ma = __ballot(act), mg = __ballot(act && !ok);
                 if (lane == 0) {
-                    atomicAdd(&A.stats_rw[(size_t)frame * ST_WORDS + 12], (unsigned)__popcll(mc));
+                    atomicAdd(&A.stats_rw[(size_t)frame * ST_WORDS + 12], (unsigned)__popcll(ma));
                     atomicAdd(&A.stats_rw[(size_t)frame * ST_WORDS + 13], (unsigned)__popcll(mg));
                     atomicAdd(&A.stats_rw[(size_t)frame * ST_WORDS + 14], mg ? 1u : 0u);
                     atomicAdd(&A.stats_rw[(size_t)frame * ST_WORDS + 15], 1u);
                 }
             }
-            if (__any(!chain)) {
-            if (!chain) {
+        }
+    }
+    __syncthreads();
+    if (A.dbg == 19) return;
+    // ---- pass 3 (only tiles with marked pixels): search the id lists of the marked pixels --------------------
+    if (flags[1] && mono) hazard = true;  // (not seen: a monotone tile's pixel failing the chain checks) -> row redo
+    if (flags[1] && !mono) {
+        const int nwork = SHARP ? wt : flags[2];
+        for (int base = tid & ~63; base < nwork; base += PT_THREADS) {
+            const int i = base + lane;
+            const int q = SHARP ? min(i, wt - 1) : (int)plist[i < nwork ? i : 0];
+            const int col = o0 + q;
+            const bool pend = i < nwork && (cnt[q] & 0x8000u) != 0;
+            const unsigned c = pend ? cnt[q] : 0u;
+            const int np = min((int)(c & 0x7fffu), PT_KP), nsg = min((int)(c >> 16), PT_KS);
+            int wnp = 0, wns = 0;
+#pragma unroll
+            for (int t = 1; t <= PT_KP; t++) wnp = __any(np >= t) ? t : wnp;
+#pragma unroll
+            for (int t = 1; t <= PT_KS; t++) wns = __any(nsg >= t) ? t : wns;
+            if (!__any(pend)) continue;
+            const PixC P = pix_consts(col);
+            const double sig_dd = P.sig_dd;
+            const float ff64 = P.ff64, tf64 = P.tf64, center64 = P.center64;
             // the pixel's points sorted by (x, id) == the reference's stable insertion sort inside the pixel
             float xs[PT_KP];
             int os[PT_KP];
@@ -449,7 +559,7 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
             float color0 = 0.5f, color1 = 0.5f, color2 = 0.5f;
             float prev = (float)col, a = -INFINITY;
             for (int k = 0; k <= wnp; k++) {   // wave-uniform trip count; lanes with k > np idle
-                const bool live = k <= np;
+                const bool live = pend && k <= np;
                 float b = INFINITY;
 #pragma unroll
                 for (int m2 = 0; m2 < PT_KP; m2++) b = (m2 == k && k < np) ? xs[m2] : b;
@@ -535,13 +645,9 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
                 color1 = contrib ? n1 : color1;
                 color2 = contrib ? n2 : color2;
             }
-            rgb = (uint32_t)csm::f32_to_u8_wrap(color0) | ((uint32_t)csm::f32_to_u8_wrap(color1) << 8) |
-                  ((uint32_t)csm::f32_to_u8_wrap(color2) << 16);
-            }
-            }
-            }  // !done
+            if (pend) put(q, (uint32_t)csm::f32_to_u8_wrap(color0) | ((uint32_t)csm::f32_to_u8_wrap(color1) << 8) |
+                                 ((uint32_t)csm::f32_to_u8_wrap(color2) << 16));
         }
-        res[3 * q] = (uint8_t)rgb; res[3 * q + 1] = (uint8_t)(rgb >> 8); res[3 * q + 2] = (uint8_t)(rgb >> 16);
     }
     if (hazard) flags[0] = 1;
     __syncthreads();
@@ -608,7 +714,7 @@ static size_t polytile_lds(int S, int sharp, int PT_KP, int PT_KS) {
     int nsmax = PT_T + 2 * S + 6;
     int nptmax = (sharp ? 2 * nsmax : nsmax) + 2;
     return 1024 + align16(sizeof(csm::PowfTables)) + 2 * 4 * (size_t)((nptmax + 3) & ~3) + 4 * (size_t)((nsmax + 3) & ~3) +
-           4 * PT_T + 2 * PT_T * (PT_KP + PT_KS) + align16(3 * PT_T) + PT_T + 64;
+           4 * PT_T + 2 * PT_T + 2 * PT_T * (PT_KP + PT_KS) + align16(3 * PT_T) + PT_T + 64;
 }
 
 // Largest halo the tiled path accepts: beyond this the staged range dwarfs the tile and the row kernel wins.
