@@ -30,7 +30,7 @@
 namespace cs {
 
 #define PT_T 512      // output pixels per tile
-#define PT_THREADS 256
+#define PT_THREADS 256  // == the 256 entries of the byte -> float table, one per thread
 
 __constant__ csm::PowfTables c_pt_powf_tables = CS_POWF_TABLES_INIT;
 
@@ -85,10 +85,22 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     if (A.dbg == 10) return;
+    const bool rec_wg = A.dbg == 20 && blockIdx.x % 61 == 0;  // sampled: the hot atomics perturb
+    long long t_prev = rec_wg ? wall_clock64() : 0;
+    auto stamp = [&](int phase) {  // development (CS_DBG=20): per-phase latency of the workgroup, summed into frame `phase`'s spare stats word
+        if (rec_wg && A.stats_rw && threadIdx.x == 0) {
+            long long t = wall_clock64();
+            atomicAdd(&A.stats_rw[(size_t)(phase % A.n) * ST_WORDS + 12], (unsigned)(t - t_prev));
+            t_prev = t;
+        }
+    };
     const int tiles = (A.w + PT_T - 1) / PT_T;
-    const int tile = blockIdx.x % tiles, row = blockIdx.x / tiles, frame = blockIdx.y;
-    const int eyei = A.single >= 0 ? A.single : (int)blockIdx.z;
+    // (eye = slowest grid dimension: pairing the two eyes of a tile on one XCD so that the second finds the image row in
+    // that L2 was measured 13 % SLOWER -- the eyes' output streams then hit the same HBM channels at the same time)
+    const int bx = blockIdx.x, eyei = A.single >= 0 ? A.single : (int)blockIdx.z;
+    const int tile = bx % tiles, row = bx / tiles, frame = blockIdx.y;
     const EyeArgs& E = A.eye[eyei];
+    const bool eye_on = E.enabled && A.dbg != 41;  // (41: development, memory-only pass)
     const int w = A.w, h = A.h;
     const int o0 = tile * PT_T, wt = min(PT_T, w - o0);
     const int s0 = max(0, (o0 - A.S - 1) & ~3), s1 = min(w, o0 + wt + A.S + 1), ns = s1 - s0;  // s0 % 4 == 0: float4 staging
@@ -101,13 +113,14 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
     const int nptmax = (SHARP ? 2 * nsmax : nsmax) + 2;
 
     // LDS carve
-    float* lut = (float*)smem;                                                  // [256]
-    csm::PowfTables* tabs = (csm::PowfTables*)(lut + 256);
-    float* px = (float*)((char*)tabs + align16(sizeof(csm::PowfTables)));       // [nptmax] x of point o
+    float* lut = (float*)smem;                                                  // [256] k / 255, filled after the staging (shares
+    csm::PowfTables* tabs = (csm::PowfTables*)smem;                             //       its first half with the powf tables)
+    static_assert(sizeof(csm::PowfTables) <= 1024, "lut / tables overlay");
+    float* px = (float*)(smem + 1024);                                          // [nptmax] x of point o
     float* pz = px + ((nptmax + 3) & ~3);                                       // [nptmax] |coord_d| of point o
     uint32_t* img = (uint32_t*)(pz + ((nptmax + 3) & ~3));                      // [nsmax] R | G<<8 | B<<16
-    unsigned* cnt = (unsigned*)(img + ((nsmax + 3) & ~3));                      // [PT_T] low16: points, high16: segments
-    uint16_t* plist = (uint16_t*)(cnt + PT_T);                                  // [PT_T] pixels the fastest path left over
+    uint16_t* cnt = (uint16_t*)(img + ((nsmax + 3) & ~3));                      // [PT_T] per-pixel registration word (see REGISTER)
+    uint16_t* plist = cnt + PT_T;                                               // [PT_T] pixels the fastest path left over
     uint16_t* pts = plist + PT_T;                                               // [PT_T][PT_KP]  (fold tiles only)
     uint16_t* sgs = pts + PT_T * PT_KP;                                         // [PT_T][PT_KS]  (fold tiles only)
     uint16_t* pseg = sgs;                                                       // [PT_T] monotone tiles: a segment passing through the pixel
@@ -117,20 +130,10 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
 
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
     const size_t rowpix = ((size_t)frame * h + row) * w;
-    for (int i = tid; i < 256; i += PT_THREADS) lut[i] = (float)i / 255.0f;
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_pt_powf_tables);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(tabs);
-        for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += PT_THREADS) dst[i] = src[i];
-    }
-    for (int i = tid; i < PT_T; i += PT_THREADS) cnt[i] = 0;
-    if (tid == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
-    if (A.dbg == 9) return;
-    // the depth row of the halo'ed range: loads issued now, consumed after the image conversion (one memory round
-    // trip for both instead of two back to back)
+    // ---- all global loads of the tile are issued first (one memory round trip): the depth row of the halo'ed range into
+    // registers (consumed after the image conversion), the first 4-pixel group of the image row per thread; the LDS
+    // initialisation and the copy of the powf tables (another global load) follow in their shadow
     constexpr int PT_PF = 3;
-    const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
-    const float dmin = E.enabled ? csm::ord2f(st[E.st_min]) : 0.0f, dmax = E.enabled ? csm::ord2f(st[E.st_max]) : 0.0f;
     const float* drow = E.depth + rowpix;
     float dpre[PT_PF];
 #pragma unroll
@@ -138,13 +141,25 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
         const int j = tid + k * PT_THREADS;
         dpre[k] = j < ns ? drow[s0 + j] : 0.0f;
     }
+    const int nq = (A.image_f32 && (w & 3) == 0) ? ns / 4 : 0;  // (rowpix + s0) % 4 == 0 -> 16-byte aligned groups of 4 pixels
+    const float4* s4 = reinterpret_cast<const float4*>(A.image_f32 + (rowpix + s0) * 3);
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+    if (tid < nq) { q0 = s4[3 * tid]; q1 = s4[3 * tid + 1]; q2 = s4[3 * tid + 2]; }
+    const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
+    const float dmin = eye_on ? csm::ord2f(st[E.st_min]) : 0.0f, dmax = eye_on ? csm::ord2f(st[E.st_max]) : 0.0f;
+
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_pt_powf_tables);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(tabs);
+        for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += PT_THREADS) dst[i] = src[i];
+    }
+    for (int i = tid; i < PT_T / 2; i += PT_THREADS) reinterpret_cast<uint32_t*>(cnt)[i] = 0;
+    if (tid == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
+    if (A.dbg == 9) return;
     // stage the source pixels of the halo'ed range as packed uint8 RGB (reference :1508)
     if (A.image_f32) {
         const float* src = A.image_f32 + (rowpix + s0) * 3;
-        const int nq = (w & 3) == 0 ? ns / 4 : 0;  // (rowpix + s0) % 4 == 0 -> 16-byte aligned groups of 4 pixels
-        const float4* s4 = reinterpret_cast<const float4*>(src);
-        for (int i = tid; i < nq; i += PT_THREADS) {
-            float4 v0 = s4[3 * i], v1 = s4[3 * i + 1], v2 = s4[3 * i + 2];
+        auto pack4 = [&](int i, float4 v0, float4 v1, float4 v2) {
             float f[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
             uint32_t pk[4];
 #pragma unroll
@@ -155,7 +170,9 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
                 pk[k] = r | (g << 8) | (b << 16);
             }
             reinterpret_cast<uint4*>(img)[i] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        }
+        };
+        if (tid < nq) pack4(tid, q0, q1, q2);
+        for (int i = tid + PT_THREADS; i < nq; i += PT_THREADS) pack4(i, s4[3 * i], s4[3 * i + 1], s4[3 * i + 2]);
         for (int j = 4 * nq + tid; j < ns; j += PT_THREADS) {
             uint32_t r = (uint32_t)(int)fminf(fmaxf(src[3 * j] * 255.0f, 0.0f), 255.0f);
             uint32_t g = (uint32_t)(int)fminf(fmaxf(src[3 * j + 1] * 255.0f, 0.0f), 255.0f);
@@ -168,13 +185,15 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
             img[j] = (uint32_t)src[3 * j] | ((uint32_t)src[3 * j + 1] << 8) | ((uint32_t)src[3 * j + 2] << 16);
     }
     __syncthreads();  // tables ready
+    stamp(1);
     if (A.dbg == 8) return;
-    if (!E.enabled) {
+    if (!eye_on) {
         for (int q = tid; q < wt; q += PT_THREADS) dep8[q] = csm::f32_to_u8_wrap((drow[o0 + q] * scale) * 255.0f);
     }
-    if (E.enabled) {
+    if (eye_on) {
         const bool flat = dmax == dmin;
         const float range = dmax - dmin;
+        bool fold = false;
         auto stage_depth = [&](int j, float draw) {
             float d = draw * scale;
             // depth-map output of this column: (depth*255).astype(uint8) wraps mod 256 (quirk Q7)
@@ -186,11 +205,18 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
             float cdj = (sgn * pw) * E.div32;                                     // coord_d   (:1926)
             float x = ((float)(s0 + j) + 0.5f + cdj) + E.sep32;                   // coord_x   (:1927)
             float z = fabsf(cdj);
+            // fold detection (is the polyline strictly increasing in x?): the right neighbour's x sits in the next lane;
+            // the pairs across wave chunks and the sentinel pairs are checked after the barrier
+            const float xn = __shfl_down(x, 1);
+            const bool has_next = lane != 63 && j + 1 < ns;
             if (SHARP) {
-                px[1 + 2 * j] = x - (float)0.45; pz[1 + 2 * j] = z;
-                px[2 + 2 * j] = x + (float)0.45; pz[2 + 2 * j] = z;
+                const float xa = x - (float)0.45, xb = x + (float)0.45;
+                px[1 + 2 * j] = xa; pz[1 + 2 * j] = z;
+                px[2 + 2 * j] = xb; pz[2 + 2 * j] = z;
+                fold = fold || !(xa < xb) || (has_next && !(xb < xn - (float)0.45));
             } else {
                 px[1 + j] = x; pz[1 + j] = z;
+                fold = fold || (has_next && !(x < xn));
             }
         };
 #pragma unroll
@@ -203,39 +229,50 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
             px[0] = (float)(-1.0 * w); pz[0] = 0.0f;
             px[npts - 1] = (float)(2.0 * w); pz[npts - 1] = 0.0f;
         }
+        if (fold) flags[3] = 1;
     }
     __syncthreads();
+    stamp(2);
 
     if (A.dbg == 11) return;
+    lut[tid] = (float)tid / 255.0f;  // (PT_THREADS == 256) the powf tables underneath are dead now; read in the store phase
     const bool left_edge = s0 == 0, right_edge = s1 == w;
     bool hazard = false;
 
     // ---- REGISTER ----------------------------------------------------------------------------------------
     // Tiles whose staged polyline is strictly increasing in x (no fold: the common case away from occluding depth
     // edges) take the MONO pass: every segment is forward and the segments over a pixel are exactly the chain around
-    // its points, which are consecutive ids -- so each pixel only needs its first and last point id, written with
-    // plain 16-bit stores by the points that see a different pixel to their left / right (cnt = first | last << 16,
-    // 0 = no point), and pseg = the segment bridging a pixel without points.  No atomics, nothing per segment.
-    // Tiles with a fold take the FULL pass: cnt = points in the pixel (low 16) | forward segments overlapping it
-    // (high 16) and the fixed-capacity id lists pts / sgs, filled through returning LDS atomics.
+    // its points, which are consecutive ids -- so each pixel only needs its first point id and the number of points,
+    // written with one plain 16-bit store by the point that sees a different pixel to its left (cnt = first id |
+    // points << 12, 0 = no point), and pseg = the segment bridging a pixel without points.  No atomics, nothing per
+    // segment.  Tiles with a fold take the FULL pass: cnt = points in the pixel (low 8 bits) | forward segments
+    // overlapping it (high 8) and the fixed-capacity id lists pts / sgs, filled through returning LDS atomics (on the
+    // 32-bit word that holds two pixels' counters).
     const int ofirst = left_edge ? 0 : 1, olast = right_edge ? npts - 1 : npts - 2;
-    if (E.enabled) {
+    bool mono = flags[3] == 0;
+    if (eye_on) {  // the pairs the staging loop could not see; every wave computes the same answer, no barrier
+        const int nb = (ns - 1) >> 6;  // pairs (j, j+1) with j = 64 b + 63
         bool fold = false;
-        for (int o = ofirst + tid; o < olast; o += PT_THREADS) fold = fold || !(px[o] < px[o + 1]);
-        if (fold) flags[3] = 1;
+        for (int b0 = 0; b0 < nb + 2; b0 += 64) {
+            const int b = b0 + lane;
+            int o = -1;
+            if (b < nb) o = SHARP ? 2 + 2 * (64 * b + 63) : 1 + 64 * b + 63;
+            else if (b == nb && left_edge) o = 0;
+            else if (b == nb + 1 && right_edge) o = npts - 2;
+            fold = fold || (o >= 0 && !(px[o] < px[o + 1]));
+        }
+        mono = mono && !__any(fold);
     }
-    __syncthreads();
-    const bool mono = flags[3] == 0;
-    if (E.enabled && mono) {
-        uint16_t* fl = (uint16_t*)cnt;
+    if (eye_on && mono) {
         for (int o = ofirst + tid; o <= olast; o += PT_THREADS) {
             const float x0 = px[o];
             const float f0 = floorf(x0);
             const float fm = floorf(px[max(o - 1, 0)]), f1 = floorf(px[min(o + 1, npts - 1)]);
-            if (x0 >= (float)o0 && x0 < (float)(o0 + wt)) {   // (never a sentinel: they lie outside the frame)
-                const int q = (int)x0 - o0;
-                if (fm != f0) fl[2 * q] = (uint16_t)o;
-                if (f1 != f0) fl[2 * q + 1] = (uint16_t)o;
+            if (x0 >= (float)o0 && x0 < (float)(o0 + wt) && fm != f0) {   // the first point of its pixel (never a sentinel)
+                int np = 1;  // points of the pixel = the run of ids with the same floor(x); the right sentinel ends every run
+                float fn = f1;
+                while (fn == f0 && np < 15) { np++; fn = floorf(px[min(o + np, npts - 1)]); }
+                cnt[(int)x0 - o0] = (uint16_t)(o | (np << 12));   // ids < 4096: the halo limit keeps npts below that
             }
             // pixels strictly between the end pixels of segment o -> o+1 (disocclusion bridges)
             if (o < olast && f1 - f0 >= 2.0f && !(f1 <= (float)o0 || f0 >= (float)(o0 + wt - 1))) {
@@ -244,7 +281,8 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
                 for (int p = pa; p <= pb; p++) pseg[p - o0] = (uint16_t)o;
             }
         }
-    } else if (E.enabled) {
+    } else if (eye_on) {
+        unsigned* cntw = reinterpret_cast<unsigned*>(cnt);
         const int niter = (olast - ofirst + 1 + PT_THREADS - 1) / PT_THREADS;
         for (int it = 0; it < niter; it++) {
             const int o = ofirst + it * PT_THREADS + tid;
@@ -255,7 +293,7 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
                 const float x0 = px[o];
                 if (x0 >= (float)o0 && x0 < (float)(o0 + wt)) {
                     const int q = (int)x0 - o0;
-                    unsigned idx = atomicAdd(&cnt[q], 1u) & 0xffffu;
+                    unsigned idx = (atomicAdd(&cntw[q >> 1], 1u << ((q & 1) * 16)) >> ((q & 1) * 16)) & 0xffu;
                     if (idx < PT_KP) pts[q * PT_KP + idx] = (uint16_t)o;
                     else hazard = true;
                 }
@@ -276,7 +314,8 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
                 for (int t = 0; t < 4; t++) {  // at most 4 pixels: predicated, no divergent loop
                     const int p = p0 + t;
                     if (p <= p1) {
-                        unsigned idx = atomicAdd(&cnt[p - o0], 0x10000u) >> 16;
+                        const int qp = p - o0;
+                        unsigned idx = (atomicAdd(&cntw[qp >> 1], 0x100u << ((qp & 1) * 16)) >> ((qp & 1) * 16 + 8)) & 0xffu;
                         if (idx < PT_KS) sgs[(p - o0) * PT_KS + idx] = (uint16_t)o;
                         else hazard = true;
                     }
@@ -289,7 +328,8 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
                 m &= m - 1;
                 int lp0 = __shfl(p0, src), lp1 = __shfl(p1, src), lo = __shfl(o, src);
                 for (int p = lp0 + lane; p <= lp1; p += 64) {
-                    unsigned idx = atomicAdd(&cnt[p - o0], 0x10000u) >> 16;
+                    const int qp = p - o0;
+                    unsigned idx = (atomicAdd(&cntw[qp >> 1], 0x100u << ((qp & 1) * 16)) >> ((qp & 1) * 16 + 8)) & 0xffu;
                     if (idx < PT_KS) sgs[(p - o0) * PT_KS + idx] = (uint16_t)lo;
                     else hazard = true;
                 }
@@ -297,6 +337,7 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
         }
     }
     __syncthreads();
+    stamp(4);
 
     // ---- EVALUATE ----------------------------------------------------------------------------------------
     // per-pixel constants of the float64 ("Python float") branch of the sub-interval arithmetic
@@ -322,12 +363,12 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
         const unsigned c = cnt[q];
         int npr, cover, o1;  // points in the pixel, forward segments over it, its smallest point id (np == 0: the segment's end)
         if (mono) {
-            const int pf = (int)(c & 0xffffu), pl = (int)(c >> 16);
-            npr = pf ? pl - pf + 1 : 0;
+            const int pf = (int)(c & 0xfffu);
+            npr = (int)(c >> 12);
             cover = npr + 1;
-            o1 = pf ? pf : (int)pseg[q] + 1;
+            o1 = npr ? pf : (int)pseg[q] + 1;
         } else {
-            npr = (int)(c & 0x7fffu); cover = (int)(c >> 16);
+            npr = (int)(c & 0xffu); cover = (int)(c >> 8);
             int om = 0xffff;
 #pragma unroll
             for (int k = 0; k < PT_KP; k++) om = min(om, k < npr ? (int)pts[q * PT_KP + k] : 0xffff);
@@ -422,66 +463,221 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
     // belong to the segments (o-1 -> o) and (o -> o+1), verified below; straight-line code.  Every other pixel goes
     // onto the tile's list `plist`, which pass 2 works off densely packed (a few percent of the pixels, but spread
     // over a fifth of the waves).  sharp (two points per source pixel): the chain path directly.
-    for (int q = tid; q < wt; q += PT_THREADS) {
+    // ---- general search (fold tiles): the pixel's points sorted, every registered segment tested per sub-interval.
+    // Called by whole waves; `pend` masks the lanes that hold a pixel.
+    auto eval_generic = [&](bool pend, int q) {
         const int col = o0 + q;
-        uint32_t rgb = 0;
-        bool done = true;
-        if (!E.enabled || A.dbg == 15) {
-            rgb = img[col - s0];
-        } else if (SHARP) {
-            done = eval_chain(true, q, rgb);
-            if (!done) { cnt[q] |= 0x8000u; flags[1] = 1; }
-        } else {
-            const unsigned c = cnt[q];
-            done = mono ? (c != 0u && (c & 0xffffu) == (c >> 16)) : c == 0x20001u;
-            const PixC P = pix_consts(col);
-            const double sig_dd = P.sig_dd;
-            const float ff64 = P.ff64, tf64 = P.tf64, center64 = P.center64;
-            if (__any(done)) {
-                const int o = done ? (mono ? (int)(c & 0xffffu) : (int)pts[q * PT_KP]) : 1;
-                const float xm = px[o - 1], x = px[o], xp = px[o + 1];
-                const int j = o - 1;  // source column (local) of point o; o-1 >= 1 and o+1 <= npts-2 checked via jok
-                const bool jok = j >= 1 && j + 1 <= ns - 1;
-                const uint32_t ia = img[jok ? j - 1 : 0], ib = img[jok ? j : 0], ic = img[jok ? j + 1 : 0];
-                // piece 0: [col, x]   (from = col + eps as Python float, to = x - eps as float32)
-                const float tf0 = x - eps32;
-                const float sig0 = tf0 - ff64;
-                const float c0 = ff64 + 0.5f * sig0;
-                // piece 1: [x, col+1] (from = x + eps if x > col else the Python-float col + eps; to = col+1-eps)
-                const bool f64_1 = !(x > (float)col);
-                const float ff1 = f64_1 ? ff64 : x + eps32;
-                const float sig1 = tf64 - ff1;
-                const float c1 = f64_1 ? center64 : ff1 + 0.5f * sig1;
-                const float sg1 = f64_1 ? (float)sig_dd : sig1;
-                const bool w0 = sig0 != 0.0f, w1 = f64_1 ? sig_dd != 0.0 : sig1 != 0.0f;
-                // chain segments forward and covering their piece, centres monotone inside the pixel
-                bool ok = jok && xm < x && x < xp;
-                ok = ok && !(c0 < (float)col) && !(c1 < c0) && !(c1 > (float)(col + 1));
-                ok = ok && (!w0 || (xm < c0 && !(x < c0))) && (!w1 || (x < c1 && !(xp < c1)));
-                done = done && ok;
-                const float ip0 = (c0 - xm) / (x - xm), ip1 = (c1 - x) / (xp - x);
-                const float om0 = 1.0f - ip0, om1 = 1.0f - ip1;
-                const float a0 = (float)(ia & 0xffu), a1 = (float)((ia >> 8) & 0xffu), a2 = (float)((ia >> 16) & 0xffu);
-                const float b0 = (float)(ib & 0xffu), b1 = (float)((ib >> 8) & 0xffu), b2 = (float)((ib >> 16) & 0xffu);
-                const float e0 = (float)(ic & 0xffu), e1 = (float)((ic >> 8) & 0xffu), e2 = (float)((ic >> 16) & 0xffu);
-                float k0 = 0.5f, k1 = 0.5f, k2 = 0.5f;
-                const float p0 = k0 + (a0 * om0 + b0 * ip0) * sig0, p1 = k1 + (a1 * om0 + b1 * ip0) * sig0,
-                            p2 = k2 + (a2 * om0 + b2 * ip0) * sig0;
-                k0 = w0 ? p0 : k0; k1 = w0 ? p1 : k1; k2 = w0 ? p2 : k2;
-                const float r0 = k0 + (b0 * om1 + e0 * ip1) * sg1, r1 = k1 + (b1 * om1 + e1 * ip1) * sg1,
-                            r2 = k2 + (b2 * om1 + e2 * ip1) * sg1;
-                k0 = w1 ? r0 : k0; k1 = w1 ? r1 : k1; k2 = w1 ? r2 : k2;
-                rgb = (uint32_t)csm::f32_to_u8_wrap(k0) | ((uint32_t)csm::f32_to_u8_wrap(k1) << 8) |
-                      ((uint32_t)csm::f32_to_u8_wrap(k2) << 16);
+        const unsigned c = pend ? cnt[q] : 0u;
+        const int np = min((int)(c & 0xffu), PT_KP), nsg = min((int)(c >> 8), PT_KS);
+        int wnp = 0, wns = 0;
+#pragma unroll
+        for (int t = 1; t <= PT_KP; t++) wnp = __any(np >= t) ? t : wnp;
+#pragma unroll
+        for (int t = 1; t <= PT_KS; t++) wns = __any(nsg >= t) ? t : wns;
+        const PixC P = pix_consts(col);
+        const double sig_dd = P.sig_dd;
+        const float ff64 = P.ff64, tf64 = P.tf64, center64 = P.center64;
+        // the pixel's points sorted by (x, id) == the reference's stable insertion sort inside the pixel
+        float xs[PT_KP];
+        int os[PT_KP];
+#pragma unroll
+        for (int k = 0; k < PT_KP; k++) { xs[k] = INFINITY; os[k] = 0x7fffffff; }
+#pragma unroll
+        for (int k = 0; k < PT_KP; k++) {
+            if (k < wnp) {
+                int o = k < np ? (int)pts[q * PT_KP + k] : 0x7fffffff;
+                float x = k < np ? px[o] : INFINITY;
+#pragma unroll
+                for (int m2 = 0; m2 <= k; m2++) {
+                    bool lt = x < xs[m2] || (x == xs[m2] && o < os[m2]);
+                    float tx = lt ? xs[m2] : x; int to = lt ? os[m2] : o;
+                    xs[m2] = lt ? x : xs[m2]; os[m2] = lt ? o : os[m2];
+                    x = tx; o = to;
+                }
             }
-            if (!done) plist[atomicAdd((unsigned*)&flags[2], 1u)] = (uint16_t)q;
         }
-        if (done) put(q, rgb);
+        // forward segments overlapping this pixel
+        float sx0[PT_KS], sx1[PT_KS];
+        int so[PT_KS];
+#pragma unroll
+        for (int k = 0; k < PT_KS; k++) { so[k] = 0; sx0[k] = INFINITY; sx1[k] = -INFINITY; }
+#pragma unroll
+        for (int k = 0; k < PT_KS; k++) {
+            if (k < wns && k < nsg) {
+                so[k] = (int)sgs[q * PT_KS + k];
+                sx0[k] = px[so[k]];
+                sx1[k] = px[so[k] + 1];
+            }
+        }
+        float color0 = 0.5f, color1 = 0.5f, color2 = 0.5f;
+        float prev = (float)col, a = -INFINITY;
+        for (int k = 0; k <= wnp; k++) {   // wave-uniform trip count; lanes with k > np idle
+            const bool live = pend && k <= np;
+            float b = INFINITY;
+#pragma unroll
+            for (int m2 = 0; m2 < PT_KP; m2++) b = (m2 == k && k < np) ? xs[m2] : b;
+            // sub-interval [max(col, a), min(col+1, b)] shrunk by EPSILON (reference :1957-1960, D32 typing)
+            const bool from64 = !(a > (float)col), to64 = !(b < (float)(col + 1));
+            const bool sig64 = from64 && to64;
+            const float ff = from64 ? ff64 : a + eps32;
+            const float tf = to64 ? tf64 : b - eps32;
+            const float sig_f = tf - ff;
+            const float center = sig64 ? center64 : ff + 0.5f * sig_f;
+            a = live ? b : a;
+            if (live && (center < prev || center > (float)(col + 1))) hazard = true;
+            prev = live ? center : prev;
+            const bool work = live && (sig64 ? sig_dd != 0.0 : sig_f != 0.0f);  // a zero-length piece adds exactly 0
+            int nact = 0, pick = -1;
+#pragma unroll
+            for (int e = 0; e < PT_KS; e++) {
+                if (e < wns) {
+                    bool act = (sx0[e] < center) && !(sx1[e] < center);
+                    nact += act ? 1 : 0;
+                    pick = act ? e : pick;
+                }
+            }
+            if (__any(work && nact != 1)) {
+                // overlapping layers (or none): the reference picks the largest interpolated |disparity|
+                // among candidates with 0 < ip_k < 1, first one on ties -> ties are order-dependent: flag.
+                if (work && nact != 1) {
+                    int nqual = 0, best = -1;
+                    float bc = (float)(-1e-7);
+                    bool tie = false;
+#pragma unroll
+                    for (int e = 0; e < PT_KS; e++) {
+                        if (e < wns) {
+                            bool act = (sx0[e] < center) && !(sx1[e] < center);
+                            if (act) {
+                                float ip_k = (center - sx0[e]) / (sx1[e] - sx0[e]);
+                                if (0.0f < ip_k && ip_k < 1.0f) {
+                                    float cl = (1.0f - ip_k) * pz[so[e]] + ip_k * pz[so[e] + 1];
+                                    nqual++;
+                                    if (bc < cl) { bc = cl; best = e; tie = false; }
+                                    else if (cl == bc) tie = true;
+                                }
+                            }
+                        }
+                    }
+                    if (nqual == 0 || tie) hazard = true;
+                    pick = best >= 0 ? best : pick;
+                }
+            }
+            const bool contrib = work && pick >= 0;
+            // colour contribution (reference :1981-1989, D32 typing); idle lanes compute on dummy operands
+            float x0 = 0.0f, x1 = 1.0f;
+            int o = 1;
+#pragma unroll
+            for (int e = 0; e < PT_KS; e++)
+                if (e < wns) { bool hit = e == pick; x0 = hit ? sx0[e] : x0; x1 = hit ? sx1[e] : x1; o = hit ? so[e] : o; }
+            const int jl = min(max(SHARP ? (o - 1) >> 1 : o - 1, 0), ns - 1);
+            const int jr = min(max(SHARP ? o >> 1 : o, 0), ns - 1);
+            const uint32_t il = img[jl], ir = img[jr];
+            // (the compiler folds these into v_cvt_f32_ubyte0/1/2)
+            const float l0 = (float)(il & 0xffu), l1 = (float)((il >> 8) & 0xffu), l2 = (float)((il >> 16) & 0xffu);
+            const float r0 = (float)(ir & 0xffu), r1 = (float)((ir >> 8) & 0xffu), r2 = (float)((ir >> 16) & 0xffu);
+            const float ip_k = (center - x0) / (x1 - x0);
+            const float om = 1.0f - ip_k;
+            const float sg = sig64 ? (float)sig_dd : sig_f;
+            float n0 = color0 + (l0 * om + r0 * ip_k) * sg;
+            float n1 = color1 + (l1 * om + r1 * ip_k) * sg;
+            float n2 = color2 + (l2 * om + r2 * ip_k) * sg;
+            if (__any(contrib && jl == jr)) {  // segment inside one source pixel (sentinel pieces; every other 'sharp' piece)
+                if (jl == jr) {
+                    if (sig64) {
+                        n0 = (float)((double)color0 + (double)l0 * sig_dd);
+                        n1 = (float)((double)color1 + (double)l1 * sig_dd);
+                        n2 = (float)((double)color2 + (double)l2 * sig_dd);
+                    } else {
+                        n0 = color0 + l0 * sig_f;
+                        n1 = color1 + l1 * sig_f;
+                        n2 = color2 + l2 * sig_f;
+                    }
+                }
+            }
+            color0 = contrib ? n0 : color0;
+            color1 = contrib ? n1 : color1;
+            color2 = contrib ? n2 : color2;
+        }
+        if (pend) put(q, (uint32_t)csm::f32_to_u8_wrap(color0) | ((uint32_t)csm::f32_to_u8_wrap(color1) << 8) |
+                         ((uint32_t)csm::f32_to_u8_wrap(color2) << 16));
+    };
+    // straight-line code without branches or ballots: the two pixels of a lane are evaluated back to back so that the
+    // scheduler overlaps their LDS round trips
+    auto fast_px = [&](int q, bool cand, unsigned c, uint32_t& rgb) -> bool {
+        const int col = o0 + q;
+        const PixC P = pix_consts(col);
+        const double sig_dd = P.sig_dd;
+        const float ff64 = P.ff64, tf64 = P.tf64, center64 = P.center64;
+        bool done = cand;
+        const int o = cand ? (mono ? (int)(c & 0xfffu) : (int)pts[q * PT_KP]) : 1;
+        const float xm = px[o - 1], x = px[o], xp = px[o + 1];
+        const int j = o - 1;  // source column (local) of point o; o-1 >= 1 and o+1 <= npts-2 checked via jok
+        const bool jok = j >= 1 && j + 1 <= ns - 1;
+        const uint32_t ia = img[jok ? j - 1 : 0], ib = img[jok ? j : 0], ic = img[jok ? j + 1 : 0];
+        // piece 0: [col, x]   (from = col + eps as Python float, to = x - eps as float32)
+        const float tf0 = x - eps32;
+        const float sig0 = tf0 - ff64;
+        const float c0 = ff64 + 0.5f * sig0;
+        // piece 1: [x, col+1] (from = x + eps if x > col else the Python-float col + eps; to = col+1-eps)
+        const bool f64_1 = !(x > (float)col);
+        const float ff1 = f64_1 ? ff64 : x + eps32;
+        const float sig1 = tf64 - ff1;
+        const float c1 = f64_1 ? center64 : ff1 + 0.5f * sig1;
+        const float sg1 = f64_1 ? (float)sig_dd : sig1;
+        const bool w0 = sig0 != 0.0f, w1 = f64_1 ? sig_dd != 0.0 : sig1 != 0.0f;
+        // chain segments forward and covering their piece, centres monotone inside the pixel
+        bool ok = jok && xm < x && x < xp;
+        ok = ok && !(c0 < (float)col) && !(c1 < c0) && !(c1 > (float)(col + 1));
+        ok = ok && (!w0 || (xm < c0 && !(x < c0))) && (!w1 || (x < c1 && !(xp < c1)));
+        done = done && ok;
+        const float ip0 = (c0 - xm) / (x - xm), ip1 = (c1 - x) / (xp - x);
+        const float om0 = 1.0f - ip0, om1 = 1.0f - ip1;
+        const float a0 = (float)(ia & 0xffu), a1 = (float)((ia >> 8) & 0xffu), a2 = (float)((ia >> 16) & 0xffu);
+        const float b0 = (float)(ib & 0xffu), b1 = (float)((ib >> 8) & 0xffu), b2 = (float)((ib >> 16) & 0xffu);
+        const float e0 = (float)(ic & 0xffu), e1 = (float)((ic >> 8) & 0xffu), e2 = (float)((ic >> 16) & 0xffu);
+        float k0 = 0.5f, k1 = 0.5f, k2 = 0.5f;
+        const float p0 = k0 + (a0 * om0 + b0 * ip0) * sig0, p1 = k1 + (a1 * om0 + b1 * ip0) * sig0,
+                    p2 = k2 + (a2 * om0 + b2 * ip0) * sig0;
+        k0 = w0 ? p0 : k0; k1 = w0 ? p1 : k1; k2 = w0 ? p2 : k2;
+        const float r0 = k0 + (b0 * om1 + e0 * ip1) * sg1, r1 = k1 + (b1 * om1 + e1 * ip1) * sg1,
+                    r2 = k2 + (b2 * om1 + e2 * ip1) * sg1;
+        k0 = w1 ? r0 : k0; k1 = w1 ? r1 : k1; k2 = w1 ? r2 : k2;
+        rgb = (uint32_t)csm::f32_to_u8_wrap(k0) | ((uint32_t)csm::f32_to_u8_wrap(k1) << 8) |
+              ((uint32_t)csm::f32_to_u8_wrap(k2) << 16);
+        return done;
+    };
+    auto fast_cand = [&](unsigned c) { return mono ? (c >> 12) == 1u : c == 0x0201u; };
+    if (!eye_on || A.dbg == 15) {
+        for (int q = tid; q < wt; q += PT_THREADS) put(q, img[o0 + q - s0]);
+    } else if (SHARP) {
+        for (int q = tid; q < wt; q += PT_THREADS) {
+            uint32_t rgb = 0;
+            const bool ok = eval_chain(true, q, rgb);
+            if (ok) put(q, rgb);
+            if (__any(!ok)) {
+                if (mono) hazard = hazard || !ok;  // (not seen: a fold-free tile's pixel failing the chain checks) -> row redo
+                else eval_generic(!ok, q);
+            }
+        }
+    } else {
+        for (int qa = tid; qa < wt; qa += 2 * PT_THREADS) {
+            const bool vb = qa + PT_THREADS < wt;
+            const int qb = vb ? qa + PT_THREADS : qa;
+            const unsigned ca = cnt[qa], cb = cnt[qb];
+            uint32_t ra = 0, rb = 0;
+            const bool da = fast_px(qa, fast_cand(ca), ca, ra);
+            const bool db = fast_px(qb, vb && fast_cand(cb), cb, rb);
+            if (da) put(qa, ra);
+            else plist[atomicAdd((unsigned*)&flags[2], 1u)] = (uint16_t)qa;
+            if (db) put(qb, rb);
+            else if (vb) plist[atomicAdd((unsigned*)&flags[2], 1u)] = (uint16_t)qb;
+        }
     }
     if (A.dbg == 18) return;
     if (!SHARP) {
         __syncthreads();
-        // ---- pass 2 (soft): the chain path over the listed pixels
+        stamp(5);
+        // ---- pass 2 (soft): the chain path over the listed pixels, the general search for those it cannot do
         const int nlist = flags[2];
         for (int base = tid & ~63; base < nlist; base += PT_THREADS) {
             const int i = base + lane;
@@ -490,7 +686,10 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
             uint32_t rgb = 0;
             const bool ok = eval_chain(act, q, rgb);
             if (ok) put(q, rgb);
-            else if (act) { cnt[q] |= 0x8000u; flags[1] = 1; }
+            if (__any(act && !ok)) {
+                if (mono) hazard = hazard || (act && !ok);  // (not seen) -> row redo
+                else eval_generic(act && !ok, q);
+            }
             if (A.dbg == 14 && A.stats_rw) {  // development: how many pixels take which path
                 unsigned long long ma = __ballot(act), mg = __ballot(act && !ok);
                 if (lane == 0) {
@@ -502,155 +701,9 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
             }
         }
     }
-    __syncthreads();
-    if (A.dbg == 19) return;
-    // ---- pass 3 (only tiles with marked pixels): search the id lists of the marked pixels --------------------
-    if (flags[1] && mono) hazard = true;  // (not seen: a monotone tile's pixel failing the chain checks) -> row redo
-    if (flags[1] && !mono) {
-        const int nwork = SHARP ? wt : flags[2];
-        for (int base = tid & ~63; base < nwork; base += PT_THREADS) {
-            const int i = base + lane;
-            const int q = SHARP ? min(i, wt - 1) : (int)plist[i < nwork ? i : 0];
-            const int col = o0 + q;
-            const bool pend = i < nwork && (cnt[q] & 0x8000u) != 0;
-            const unsigned c = pend ? cnt[q] : 0u;
-            const int np = min((int)(c & 0x7fffu), PT_KP), nsg = min((int)(c >> 16), PT_KS);
-            int wnp = 0, wns = 0;
-#pragma unroll
-            for (int t = 1; t <= PT_KP; t++) wnp = __any(np >= t) ? t : wnp;
-#pragma unroll
-            for (int t = 1; t <= PT_KS; t++) wns = __any(nsg >= t) ? t : wns;
-            if (!__any(pend)) continue;
-            const PixC P = pix_consts(col);
-            const double sig_dd = P.sig_dd;
-            const float ff64 = P.ff64, tf64 = P.tf64, center64 = P.center64;
-            // the pixel's points sorted by (x, id) == the reference's stable insertion sort inside the pixel
-            float xs[PT_KP];
-            int os[PT_KP];
-#pragma unroll
-            for (int k = 0; k < PT_KP; k++) { xs[k] = INFINITY; os[k] = 0x7fffffff; }
-#pragma unroll
-            for (int k = 0; k < PT_KP; k++) {
-                if (k < wnp) {
-                    int o = k < np ? (int)pts[q * PT_KP + k] : 0x7fffffff;
-                    float x = k < np ? px[o] : INFINITY;
-#pragma unroll
-                    for (int m2 = 0; m2 <= k; m2++) {
-                        bool lt = x < xs[m2] || (x == xs[m2] && o < os[m2]);
-                        float tx = lt ? xs[m2] : x; int to = lt ? os[m2] : o;
-                        xs[m2] = lt ? x : xs[m2]; os[m2] = lt ? o : os[m2];
-                        x = tx; o = to;
-                    }
-                }
-            }
-            // forward segments overlapping this pixel
-            float sx0[PT_KS], sx1[PT_KS];
-            int so[PT_KS];
-#pragma unroll
-            for (int k = 0; k < PT_KS; k++) { so[k] = 0; sx0[k] = INFINITY; sx1[k] = -INFINITY; }
-#pragma unroll
-            for (int k = 0; k < PT_KS; k++) {
-                if (k < wns && k < nsg) {
-                    so[k] = (int)sgs[q * PT_KS + k];
-                    sx0[k] = px[so[k]];
-                    sx1[k] = px[so[k] + 1];
-                }
-            }
-            float color0 = 0.5f, color1 = 0.5f, color2 = 0.5f;
-            float prev = (float)col, a = -INFINITY;
-            for (int k = 0; k <= wnp; k++) {   // wave-uniform trip count; lanes with k > np idle
-                const bool live = pend && k <= np;
-                float b = INFINITY;
-#pragma unroll
-                for (int m2 = 0; m2 < PT_KP; m2++) b = (m2 == k && k < np) ? xs[m2] : b;
-                // sub-interval [max(col, a), min(col+1, b)] shrunk by EPSILON (reference :1957-1960, D32 typing)
-                const bool from64 = !(a > (float)col), to64 = !(b < (float)(col + 1));
-                const bool sig64 = from64 && to64;
-                const float ff = from64 ? ff64 : a + eps32;
-                const float tf = to64 ? tf64 : b - eps32;
-                const float sig_f = tf - ff;
-                const float center = sig64 ? center64 : ff + 0.5f * sig_f;
-                a = live ? b : a;
-                if (live && (center < prev || center > (float)(col + 1))) hazard = true;
-                prev = live ? center : prev;
-                const bool work = live && (sig64 ? sig_dd != 0.0 : sig_f != 0.0f);  // a zero-length piece adds exactly 0
-                int nact = 0, pick = -1;
-#pragma unroll
-                for (int e = 0; e < PT_KS; e++) {
-                    if (e < wns) {
-                        bool act = (sx0[e] < center) && !(sx1[e] < center);
-                        nact += act ? 1 : 0;
-                        pick = act ? e : pick;
-                    }
-                }
-                if (__any(work && nact != 1)) {
-                    // overlapping layers (or none): the reference picks the largest interpolated |disparity|
-                    // among candidates with 0 < ip_k < 1, first one on ties -> ties are order-dependent: flag.
-                    if (work && nact != 1) {
-                        int nqual = 0, best = -1;
-                        float bc = (float)(-1e-7);
-                        bool tie = false;
-#pragma unroll
-                        for (int e = 0; e < PT_KS; e++) {
-                            if (e < wns) {
-                                bool act = (sx0[e] < center) && !(sx1[e] < center);
-                                if (act) {
-                                    float ip_k = (center - sx0[e]) / (sx1[e] - sx0[e]);
-                                    if (0.0f < ip_k && ip_k < 1.0f) {
-                                        float cl = (1.0f - ip_k) * pz[so[e]] + ip_k * pz[so[e] + 1];
-                                        nqual++;
-                                        if (bc < cl) { bc = cl; best = e; tie = false; }
-                                        else if (cl == bc) tie = true;
-                                    }
-                                }
-                            }
-                        }
-                        if (nqual == 0 || tie) hazard = true;
-                        pick = best >= 0 ? best : pick;
-                    }
-                }
-                const bool contrib = work && pick >= 0;
-                // colour contribution (reference :1981-1989, D32 typing); idle lanes compute on dummy operands
-                float x0 = 0.0f, x1 = 1.0f;
-                int o = 1;
-#pragma unroll
-                for (int e = 0; e < PT_KS; e++)
-                    if (e < wns) { bool hit = e == pick; x0 = hit ? sx0[e] : x0; x1 = hit ? sx1[e] : x1; o = hit ? so[e] : o; }
-                const int jl = min(max(SHARP ? (o - 1) >> 1 : o - 1, 0), ns - 1);
-                const int jr = min(max(SHARP ? o >> 1 : o, 0), ns - 1);
-                const uint32_t il = img[jl], ir = img[jr];
-                // (the compiler folds these into v_cvt_f32_ubyte0/1/2)
-                const float l0 = (float)(il & 0xffu), l1 = (float)((il >> 8) & 0xffu), l2 = (float)((il >> 16) & 0xffu);
-                const float r0 = (float)(ir & 0xffu), r1 = (float)((ir >> 8) & 0xffu), r2 = (float)((ir >> 16) & 0xffu);
-                const float ip_k = (center - x0) / (x1 - x0);
-                const float om = 1.0f - ip_k;
-                const float sg = sig64 ? (float)sig_dd : sig_f;
-                float n0 = color0 + (l0 * om + r0 * ip_k) * sg;
-                float n1 = color1 + (l1 * om + r1 * ip_k) * sg;
-                float n2 = color2 + (l2 * om + r2 * ip_k) * sg;
-                if (__any(contrib && jl == jr)) {  // segment inside one source pixel (sentinel pieces; every other 'sharp' piece)
-                    if (jl == jr) {
-                        if (sig64) {
-                            n0 = (float)((double)color0 + (double)l0 * sig_dd);
-                            n1 = (float)((double)color1 + (double)l1 * sig_dd);
-                            n2 = (float)((double)color2 + (double)l2 * sig_dd);
-                        } else {
-                            n0 = color0 + l0 * sig_f;
-                            n1 = color1 + l1 * sig_f;
-                            n2 = color2 + l2 * sig_f;
-                        }
-                    }
-                }
-                color0 = contrib ? n0 : color0;
-                color1 = contrib ? n1 : color1;
-                color2 = contrib ? n2 : color2;
-            }
-            if (pend) put(q, (uint32_t)csm::f32_to_u8_wrap(color0) | ((uint32_t)csm::f32_to_u8_wrap(color1) << 8) |
-                                 ((uint32_t)csm::f32_to_u8_wrap(color2) << 16));
-        }
-    }
     if (hazard) flags[0] = 1;
     __syncthreads();
+    stamp(7);
     if (flags[0]) {
         // the general kernel redoes this row (both eyes) and overwrites whatever is stored below
         if (tid == 0) A.rowflag[(size_t)frame * h + row] = 1;
@@ -708,13 +761,15 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
                 }
         }
     }
+    if (rec_wg) __builtin_amdgcn_s_waitcnt(0);
+    stamp(9);
 }
 
 static size_t polytile_lds(int S, int sharp, int PT_KP, int PT_KS) {
     int nsmax = PT_T + 2 * S + 6;
     int nptmax = (sharp ? 2 * nsmax : nsmax) + 2;
-    return 1024 + align16(sizeof(csm::PowfTables)) + 2 * 4 * (size_t)((nptmax + 3) & ~3) + 4 * (size_t)((nsmax + 3) & ~3) +
-           4 * PT_T + 2 * PT_T + 2 * PT_T * (PT_KP + PT_KS) + align16(3 * PT_T) + PT_T + 64;
+    return 1024 + 2 * 4 * (size_t)((nptmax + 3) & ~3) + 4 * (size_t)((nsmax + 3) & ~3) +
+           2 * PT_T + 2 * PT_T + 2 * PT_T * (PT_KP + PT_KS) + align16(3 * PT_T) + PT_T + 64;
 }
 
 // Largest halo the tiled path accepts: beyond this the staged range dwarfs the tile and the row kernel wins.
@@ -748,10 +803,13 @@ hipError_t launch_polytile(int sharp, const RowArgs& R, int S, uint8_t* rowflag,
         if (e != hipSuccess) return e;                                                                              \
         hipLaunchKernelGGL((k_polytile<SH, KP, KS, MW>), grid, block, lds, stream, A);                              \
     }
+    // soft default: 4 points / 5 segments per pixel in the lists -> 21.6 KB of LDS at the bench halo, 72 VGPRs: 7 workgroups
+    // per CU (LDS is handed out in 2 KB granules; 6 segments would be 128 bytes over).  CS_PT_VARIANT: development.
     if (sharp) PT_LAUNCH(1, 6, 8, 4)
-    else if (variant == 1) PT_LAUNCH(0, 6, 8, 6)
-    else if (variant == 5) PT_LAUNCH(0, 3, 4, 8)
-    else PT_LAUNCH(0, 4, 6, 6)
+    else if (variant == 1) PT_LAUNCH(0, 4, 6, 6)
+    else if (variant == 2) PT_LAUNCH(0, 3, 4, 7)
+    else if (variant == 3) PT_LAUNCH(0, 6, 8, 6)
+    else PT_LAUNCH(0, 4, 5, 7)
 #undef PT_LAUNCH
     return hipGetLastError();
 }
