@@ -256,172 +256,280 @@ __device__ __forceinline__ int mask_dist_right(const unsigned long long* m, int 
     }
 }
 
-__global__ void __launch_bounds__(256) k_blur_fused(BlurArgs A, const unsigned long long* mask_l,
-                                                    const unsigned long long* mask_r, int MW) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = blockIdx.x * BLUR_TW, y0 = blockIdx.y * BLUR_TR, frame = blockIdx.z;
-    const int w = A.w, h = A.h, v = A.vert, bs = A.bs, pad = A.bs / 2, R = A.radius;
-    const int WR = BLUR_TR + 2 * v;          // weight rows: frame rows y0 - v ..
-    const int EW = BLUR_TW + 2 * R;          // edge columns: frame cols x0 - R ..
-    const int DC = BLUR_TW + bs - 1;         // depth tile: rows y0 .., cols x0 - pad ..
-    const int NW = (EW + 63) >> 6;           // 64-bit words per mask row
-    float* D = (float*)smem;                                   // [TR][DC]
-    float* wlt = D + ((BLUR_TR * DC + 3) & ~3);                // [WR][TW]
-    float* wrt = wlt + WR * BLUR_TW;                           // [WR][TW]
-    unsigned long long* mL = (unsigned long long*)(wrt + WR * BLUR_TW);  // [WR][NW]
-    unsigned long long* mR = mL + WR * NW;                     // [WR][NW]
-    csm::PowfTables* T = (csm::PowfTables*)(mR + WR * NW);
-    int* any_edge = (int*)(T + 1);
-    if (tid == 0) *any_edge = 0;
-    if (A.fall_mode == 4) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_blur_powf_tables);
-        for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += 256) reinterpret_cast<uint32_t*>(T)[i] = src[i];
+// Edges are sparse, so most 64 x 32 tiles have no edge bit within reach (+-v rows, +-R columns): every weight there is
+// exactly 0 and 0*blur + (1-0)*depth == depth -- the tile is a scaled copy.  k_blur_copy walks the frame in 256 x 32
+// pieces (four tiles) with no LDS tile and few registers (high occupancy): the depth is loaded with 16-byte accesses
+// TOGETHER with the tiles' windows of the edge bit rows (one memory round trip), edge-free tiles are stored straight
+// from the registers, and the others are appended to `worklist` for k_blur_fused.
+#define BLUR_CW 4  // tiles per k_blur_copy workgroup
+__global__ void __launch_bounds__(256) k_blur_copy(BlurArgs A, const unsigned long long* mask_l, const unsigned long long* mask_r,
+                                                   int MW, uint32_t* work_count, uint32_t* worklist) {
+    const int tid = threadIdx.x;
+    const int X0 = blockIdx.x * (BLUR_CW * BLUR_TW), y0 = blockIdx.y * BLUR_TR, frame = blockIdx.z;
+    const int w = A.w, h = A.h, v = A.vert, R = A.radius;
+    __shared__ float red[2 * 16];
+    constexpr int C4 = BLUR_CW * BLUR_TW / 4;     // float4 columns of the piece
+    constexpr int RPT = BLUR_TR * C4 / 256;       // rows per thread
+    const int c4 = tid % C4, rb = tid / C4;       // float4 column, first row (rows rb, rb + 256 / C4, ..)
+    const int x = X0 + 4 * c4;
+    float4 vv[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; i++) {
+        const int y = y0 + rb + (256 / C4) * i;
+        vv[i] = (y < h && x < w) ? *reinterpret_cast<const float4*>(A.depth + ((size_t)frame * h + y) * w + x)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const float scale = (A.stats && A.stats[frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
-    const float* d = A.depth + (size_t)frame * h * w;
-    __syncthreads();
-    // 2. the tile's window of the frame-wide edge bit rows (k_blur_edges): rows y0-v .., bits x0-R ..
+    // the tiles' windows of the edge bit rows: rows y0-v .., bits x0-R .. x0+TW+R-1 (exactly k_blur_fused's reach).
+    // No barrier between the two groups of loads: they travel together.
+    const int WR = BLUR_TR + 2 * v, EW = BLUR_TW + 2 * R, NW = (EW + 63) >> 6;
     const unsigned long long lastmask = (EW & 63) ? (~0ull >> (64 - (EW & 63))) : ~0ull;
-    for (int item = tid; item < WR * NW; item += 256) {
-        const int r = item / NW, k = item - r * NW;
-        const int yy = y0 - v + r;
-        unsigned long long bl = 0ull, br = 0ull;
-        if (yy >= 0 && yy < h) {
+    unsigned found = 0;  // bit t: an edge within reach of tile t seen by this thread
+    for (int item = tid; item < BLUR_CW * WR * NW; item += 256) {
+        const int t = item / (WR * NW), rem = item - t * (WR * NW);
+        const int r = rem / NW, k = rem - r * NW;
+        const int yy = y0 - v + r, x0 = X0 + t * BLUR_TW;
+        if (yy >= 0 && yy < h && x0 < w) {
             const size_t ro = ((size_t)frame * h + yy) * MW;
-            bl = mask_window(mask_l + ro, MW, x0 - R + 64 * k);
-            br = mask_window(mask_r + ro, MW, x0 - R + 64 * k);
-            if (k == NW - 1) { bl &= lastmask; br &= lastmask; }
-        }
-        mL[item] = bl; mR[item] = br;
-        if (bl | br) *any_edge = 1;
-    }
-    __syncthreads();
-    if (*any_edge == 0 && A.fall_mode != 5) {
-        // no edge within reach of the tile: every weight is exactly 0, so 0*blur + (1-0)*depth == depth
-        float mn = INFINITY, mx = -INFINITY;
-        for (int i = tid; i < BLUR_TR * BLUR_TW; i += 256) {
-            const int r = i >> 6, c = i & 63, y = y0 + r, x = x0 + c;
-            if (y < h && x < w) {
-                float dvv = d[(size_t)y * w + x] * scale;
-                A.out_l[((size_t)frame * h + y) * w + x] = dvv;
-                A.out_r[((size_t)frame * h + y) * w + x] = dvv;
-                mn = fminf(mn, dvv); mx = fmaxf(mx, dvv);
-            }
-        }
-        if (A.stats_rw) {
-            __shared__ float red2[2 * 16];
-            uint32_t* st = A.stats_rw + frame * ST_WORDS;
-            block_minmax_update(mn, mx, &st[ST_L_MIN], &st[ST_L_MAX], red2);
-            block_minmax_update(mn, mx, &st[ST_R_MIN], &st[ST_R_MAX], red2);
-        }
-        return;
-    }
-    // depth tile for the box filter (zero outside the frame == the reference's zero padding)
-    for (int r = wave; r < BLUR_TR; r += 4) {
-        const int yy = y0 + r;
-        const bool rowok = yy < h;
-        const float* drow = d + (size_t)(rowok ? yy : 0) * w;
-        for (int c = lane; c < DC; c += 64) {
-            const int xx = x0 - pad + c;
-            D[r * DC + c] = (rowok && xx >= 0 && xx < w) ? drow[xx] * scale : 0.0f;
+            unsigned long long bits = mask_window(mask_l + ro, MW, x0 - R + 64 * k) | mask_window(mask_r + ro, MW, x0 - R + 64 * k);
+            if (k == NW - 1) bits &= lastmask;
+            if (bits) found |= 1u << t;
         }
     }
-    if (A.dbg == 22) return;
-    // 3. weights from the bit rows
-    const float large = (float)(R + 1), rad = (float)R;
-    for (int i = tid; i < WR * BLUR_TW; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const int yy = y0 - v + r;
-        float wl = 0.0f, wr = 0.0f;
-        if (yy >= 0 && yy < h && x0 + c < w) {
-            const int p = c + R;
-            // an edge at distance >= R gives clamp(1 - d/R) == 0 exactly, like "no edge" (large = R + 1)
-            int a = mask_dist_left(mL + r * NW, p), b = mask_dist_right(mL + r * NW, NW, p);
-            int dmin = min(a >= 0 ? a : R + 1, b >= 0 ? b : R + 1);
-            float t = dmin < R ? 1.0f - (float)dmin / rad : 0.0f;
-            wl = falloff_pow(fminf(fmaxf(t, 0.0f), 1.0f), A.fall_mode, A.fall32, T);
-            a = mask_dist_left(mR + r * NW, p); b = mask_dist_right(mR + r * NW, NW, p);
-            dmin = min(a >= 0 ? a : R + 1, b >= 0 ? b : R + 1);
-            t = dmin < R ? 1.0f - (float)dmin / rad : 0.0f;
-            wr = falloff_pow(fminf(fmaxf(t, 0.0f), 1.0f), A.fall_mode, A.fall32, T);
-        }
-        wlt[i] = wl; wrt[i] = wr;
-    }
-    __syncthreads();
-    if (A.dbg == 23) return;
-    // 4. boxes + blend: lane = column tx, 8 consecutive rows
-    const int tx = tid & 63, ty = tid >> 6;
-    const int x = x0 + tx;
-    const float kb = 1.0f / (float)bs, kv = 1.0f / (float)(2 * v + 1);
-    float a8[8], b8[8], acc[8];
-    const int rbase = ty * 8;
-    if (v > 0) {
+    unsigned any = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) { a8[j] = 0.0f; b8[j] = 0.0f; }
-        const int nv = 2 * v + 1;
-        for (int k0 = 0; k0 < nv; k0 += 8) {
-            float vl[15], vr[15];
+    for (int t = 0; t < BLUR_CW; t++) any |= __syncthreads_or((found >> t) & 1u) ? 1u << t : 0u;
+    if (A.fall_mode == 5) any = (1u << BLUR_CW) - 1;
+    const int mytile = c4 / (BLUR_TW / 4);
+    const bool edge = (any >> mytile) & 1u;
+    if (tid < BLUR_CW && X0 + tid * BLUR_TW < w && ((any >> tid) & 1u))
+        worklist[atomicAdd(work_count, 1u)] = ((uint32_t)frame << 20) | ((uint32_t)blockIdx.y << 10) | (uint32_t)(blockIdx.x * BLUR_CW + tid);
+    const float scale = (A.stats && A.stats[frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
+    float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 15; i++) {
-                int rr = rbase + k0 + i;
-                bool ok = rr < WR;
-                vl[i] = ok ? wlt[rr * BLUR_TW + tx] : 0.0f;
-                vr[i] = ok ? wrt[rr * BLUR_TW + tx] : 0.0f;
-            }
-#pragma unroll
-            for (int kk = 0; kk < 8; kk++) {
-                if (k0 + kk < nv) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        a8[j] = fmaf(kv, vl[j + kk], a8[j]);
-                        b8[j] = fmaf(kv, vr[j + kk], b8[j]);
-                    }
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; j++) { a8[j] = wlt[(rbase + j) * BLUR_TW + tx]; b8[j] = wrt[(rbase + j) * BLUR_TW + tx]; }
-    }
-    if (A.dbg == 24) return;
-    // horizontal box: tap k of column tx is D column tx + k (the tile starts at frame column x0 - pad)
-#pragma unroll
-    for (int j = 0; j < 8; j++) acc[j] = 0.0f;
-    const float* dbase = D + rbase * DC + tx;
-    for (int k0 = 0; k0 < bs; k0 += 8) {
-        float dv[8][8];
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-#pragma unroll
-            for (int kk = 0; kk < 8; kk++) dv[j][kk] = (k0 + kk < bs) ? dbase[j * DC + k0 + kk] : 0.0f;
-#pragma unroll
-        for (int kk = 0; kk < 8; kk++) {
-            if (k0 + kk < bs) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) acc[j] = fmaf(kb, dv[j][kk], acc[j]);
-            }
-        }
-    }
-    float lmin = INFINITY, lmax = -INFINITY, rmin = INFINITY, rmax = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int y = y0 + rbase + j;
-        if (y < h && x < w) {
-            float dvv = dbase[j * DC + pad];
-            float ol = a8[j] * acc[j] + (1.0f - a8[j]) * dvv;
-            float orr = b8[j] * acc[j] + (1.0f - b8[j]) * dvv;
-            A.out_l[((size_t)frame * h + y) * w + x] = ol;
-            A.out_r[((size_t)frame * h + y) * w + x] = orr;
-            lmin = fminf(lmin, ol); lmax = fmaxf(lmax, ol);
-            rmin = fminf(rmin, orr); rmax = fmaxf(rmax, orr);
+    for (int i = 0; i < RPT; i++) {
+        const int y = y0 + rb + (256 / C4) * i;
+        if (!edge && y < h && x < w) {
+            float4 o = make_float4(vv[i].x * scale, vv[i].y * scale, vv[i].z * scale, vv[i].w * scale);
+            const size_t off = ((size_t)frame * h + y) * w + x;
+            *reinterpret_cast<float4*>(A.out_l + off) = o;
+            *reinterpret_cast<float4*>(A.out_r + off) = o;
+            mn = fminf(fminf(mn, fminf(o.x, o.y)), fminf(o.z, o.w));
+            mx = fmaxf(fmaxf(mx, fmaxf(o.x, o.y)), fmaxf(o.z, o.w));
         }
     }
     if (A.stats_rw) {
-        __shared__ float red[2 * 16];
         uint32_t* st = A.stats_rw + frame * ST_WORDS;
-        block_minmax_update(lmin, lmax, &st[ST_L_MIN], &st[ST_L_MAX], red);
-        block_minmax_update(rmin, rmax, &st[ST_R_MIN], &st[ST_R_MAX], red);
+        block_minmax_update(mn, mx, &st[ST_L_MIN], &st[ST_L_MAX], red);
+        block_minmax_update(mn, mx, &st[ST_R_MIN], &st[ST_R_MAX], red);
+    }
+}
+
+// k_blur_fused: persistent workgroups over the tiles of `worklist` (work_count entries, packed frame | tile row | tile
+// column); worklist == nullptr: plain grid over all tiles (blockIdx = tile).
+__global__ void __launch_bounds__(256) k_blur_fused(BlurArgs A, const unsigned long long* mask_l,
+                                                    const unsigned long long* mask_r, int MW, const uint32_t* work_count,
+                                                    const uint32_t* worklist) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        // weight as a function of the nearest-edge distance d = 0 .. R (d >= R: clamp(1 - d/R) == 0), once per workgroup
+    {
+        const int v = A.vert, R = A.radius, WR = BLUR_TR + 2 * v, NW = (BLUR_TW + 2 * R + 63) >> 6, DC = BLUR_TW + A.bs - 1;
+        float* wl0 = (float*)smem + ((BLUR_TR * DC + 3) & ~3);
+        csm::PowfTables* T = (csm::PowfTables*)((unsigned long long*)(wl0 + 2 * WR * BLUR_TW) + 2 * WR * NW);
+        float* wtab = (float*)((int*)(T + 1) + 4);
+        if (A.fall_mode == 4) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_blur_powf_tables);
+            for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += 256) reinterpret_cast<uint32_t*>(T)[i] = src[i];
+            __syncthreads();
+        }
+        const float rad = (float)R;
+        for (int dd = tid; dd <= R; dd += 256) {
+            const float t = dd < R ? 1.0f - (float)dd / rad : 0.0f;
+            wtab[dd] = falloff_pow(fminf(fmaxf(t, 0.0f), 1.0f), A.fall_mode, A.fall32, T);
+        }
+        __syncthreads();
+    }
+    auto tile = [&](const int x0, const int y0, const int frame) {
+        const int w = A.w, h = A.h, v = A.vert, bs = A.bs, pad = A.bs / 2, R = A.radius;
+        const int WR = BLUR_TR + 2 * v;          // weight rows: frame rows y0 - v ..
+        const int EW = BLUR_TW + 2 * R;          // edge columns: frame cols x0 - R ..
+        const int DC = BLUR_TW + bs - 1;         // depth tile: rows y0 .., cols x0 - pad ..
+        const int NW = (EW + 63) >> 6;           // 64-bit words per mask row
+        float* D = (float*)smem;                                   // [TR][DC]
+        float* wlt = D + ((BLUR_TR * DC + 3) & ~3);                // [WR][TW]
+        float* wrt = wlt + WR * BLUR_TW;                           // [WR][TW]
+        unsigned long long* mL = (unsigned long long*)(wrt + WR * BLUR_TW);  // [WR][NW]
+        unsigned long long* mR = mL + WR * NW;                     // [WR][NW]
+        csm::PowfTables* T = (csm::PowfTables*)(mR + WR * NW);
+        int* any_edge = (int*)(T + 1);
+        const float* wtab = (const float*)(any_edge + 4);          // [R + 1] weight of nearest-edge distance d (set up by the caller)
+        if (tid == 0) *any_edge = 0;
+        const float scale = (A.stats && A.stats[frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
+        const float* d = A.depth + (size_t)frame * h * w;
+        __syncthreads();
+        // 2. the tile's window of the frame-wide edge bit rows (k_blur_edges): rows y0-v .., bits x0-R ..
+        const unsigned long long lastmask = (EW & 63) ? (~0ull >> (64 - (EW & 63))) : ~0ull;
+        for (int item = tid; item < WR * NW; item += 256) {
+            const int r = item / NW, k = item - r * NW;
+            const int yy = y0 - v + r;
+            unsigned long long bl = 0ull, br = 0ull;
+            if (yy >= 0 && yy < h) {
+                const size_t ro = ((size_t)frame * h + yy) * MW;
+                bl = mask_window(mask_l + ro, MW, x0 - R + 64 * k);
+                br = mask_window(mask_r + ro, MW, x0 - R + 64 * k);
+                if (k == NW - 1) { bl &= lastmask; br &= lastmask; }
+            }
+            mL[item] = bl; mR[item] = br;
+            if (bl | br) *any_edge = 1;
+        }
+        __syncthreads();
+        if (A.dbg == 21) return;
+        if (*any_edge == 0 && A.fall_mode != 5) {
+            // no edge within reach of the tile: every weight is exactly 0, so 0*blur + (1-0)*depth == depth
+            float mn = INFINITY, mx = -INFINITY;
+            for (int i = tid; i < BLUR_TR * BLUR_TW; i += 256) {
+                const int r = i >> 6, c = i & 63, y = y0 + r, x = x0 + c;
+                if (y < h && x < w) {
+                    float dvv = d[(size_t)y * w + x] * scale;
+                    A.out_l[((size_t)frame * h + y) * w + x] = dvv;
+                    A.out_r[((size_t)frame * h + y) * w + x] = dvv;
+                    mn = fminf(mn, dvv); mx = fmaxf(mx, dvv);
+                }
+            }
+            if (A.stats_rw) {
+                __shared__ float red2[2 * 16];
+                uint32_t* st = A.stats_rw + frame * ST_WORDS;
+                block_minmax_update(mn, mx, &st[ST_L_MIN], &st[ST_L_MAX], red2);
+                block_minmax_update(mn, mx, &st[ST_R_MIN], &st[ST_R_MAX], red2);
+            }
+            return;
+        }
+        // depth tile for the box filter (zero outside the frame == the reference's zero padding); the loads of a chunk
+        // are all issued before the first LDS store so that a chunk costs one memory round trip, not one per element
+        {
+            constexpr int CH = 12;
+            const int total = BLUR_TR * DC;
+            for (int base = 0; base < total; base += CH * 256) {
+                float tmp[CH];
+#pragma unroll
+                for (int k = 0; k < CH; k++) {
+                    const int i = base + k * 256 + tid;
+                    const int r = i / DC, c = i - r * DC;
+                    const int yy = y0 + r, xx = x0 - pad + c;
+                    const bool ok = i < total && yy < h && xx >= 0 && xx < w;
+                    tmp[k] = ok ? d[(size_t)yy * w + xx] * scale : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < CH; k++) {
+                    const int i = base + k * 256 + tid;
+                    if (i < total) D[i] = tmp[k];
+                }
+            }
+        }
+        if (A.dbg == 22) return;
+        // 3. weights from the bit rows
+        const float large = (float)(R + 1), rad = (float)R;
+        for (int i = tid; i < WR * BLUR_TW; i += 256) {
+            const int r = i >> 6, c = i & 63;
+            const int yy = y0 - v + r;
+            float wl = 0.0f, wr = 0.0f;
+            if (yy >= 0 && yy < h && x0 + c < w) {
+                const int p = c + R;
+                // an edge at distance >= R gives clamp(1 - d/R) == 0 exactly, like "no edge" (large = R + 1)
+                int a = mask_dist_left(mL + r * NW, p), b = mask_dist_right(mL + r * NW, NW, p);
+                int dmin = min(a >= 0 ? a : R + 1, b >= 0 ? b : R + 1);
+                wl = wtab[min(dmin, R)];
+                a = mask_dist_left(mR + r * NW, p); b = mask_dist_right(mR + r * NW, NW, p);
+                dmin = min(a >= 0 ? a : R + 1, b >= 0 ? b : R + 1);
+                wr = wtab[min(dmin, R)];
+            }
+            wlt[i] = wl; wrt[i] = wr;
+        }
+        __syncthreads();
+        if (A.dbg == 23) return;
+        // 4. boxes + blend: lane = column tx, 8 consecutive rows
+        const int tx = tid & 63, ty = tid >> 6;
+        const int x = x0 + tx;
+        const float kb = 1.0f / (float)bs, kv = 1.0f / (float)(2 * v + 1);
+        float a8[8], b8[8], acc[8];
+        const int rbase = ty * 8;
+        if (v > 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { a8[j] = 0.0f; b8[j] = 0.0f; }
+            const int nv = 2 * v + 1;
+            for (int k0 = 0; k0 < nv; k0 += 8) {
+                float vl[15], vr[15];
+#pragma unroll
+                for (int i = 0; i < 15; i++) {
+                    int rr = rbase + k0 + i;
+                    bool ok = rr < WR;
+                    vl[i] = ok ? wlt[rr * BLUR_TW + tx] : 0.0f;
+                    vr[i] = ok ? wrt[rr * BLUR_TW + tx] : 0.0f;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) {
+                    if (k0 + kk < nv) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            a8[j] = fmaf(kv, vl[j + kk], a8[j]);
+                            b8[j] = fmaf(kv, vr[j + kk], b8[j]);
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { a8[j] = wlt[(rbase + j) * BLUR_TW + tx]; b8[j] = wrt[(rbase + j) * BLUR_TW + tx]; }
+        }
+        if (A.dbg == 24) return;
+        // horizontal box: tap k of column tx is D column tx + k (the tile starts at frame column x0 - pad)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = 0.0f;
+        const float* dbase = D + rbase * DC + tx;
+        for (int k0 = 0; k0 < bs; k0 += 8) {
+            float dv[8][8];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) dv[j][kk] = (k0 + kk < bs) ? dbase[j * DC + k0 + kk] : 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) {
+                if (k0 + kk < bs) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[j] = fmaf(kb, dv[j][kk], acc[j]);
+                }
+            }
+        }
+        float lmin = INFINITY, lmax = -INFINITY, rmin = INFINITY, rmax = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int y = y0 + rbase + j;
+            if (y < h && x < w) {
+                float dvv = dbase[j * DC + pad];
+                float ol = a8[j] * acc[j] + (1.0f - a8[j]) * dvv;
+                float orr = b8[j] * acc[j] + (1.0f - b8[j]) * dvv;
+                A.out_l[((size_t)frame * h + y) * w + x] = ol;
+                A.out_r[((size_t)frame * h + y) * w + x] = orr;
+                lmin = fminf(lmin, ol); lmax = fmaxf(lmax, ol);
+                rmin = fminf(rmin, orr); rmax = fmaxf(rmax, orr);
+            }
+        }
+        if (A.stats_rw) {
+            __shared__ float red[2 * 16];
+            uint32_t* st = A.stats_rw + frame * ST_WORDS;
+            block_minmax_update(lmin, lmax, &st[ST_L_MIN], &st[ST_L_MAX], red);
+            block_minmax_update(rmin, rmax, &st[ST_R_MIN], &st[ST_R_MAX], red);
+        }
+    };
+    if (!worklist) {
+        tile(blockIdx.x * BLUR_TW, blockIdx.y * BLUR_TR, blockIdx.z);
+        return;
+    }
+    const uint32_t count = *work_count;
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint32_t e = worklist[i];
+        tile((int)(e & 1023u) * BLUR_TW, (int)((e >> 10) & 1023u) * BLUR_TR, (int)(e >> 20));
+        __syncthreads();  // the tile's LDS is reused by the next one
     }
 }
 
@@ -429,7 +537,7 @@ static size_t blur_fused_lds(int v, int R, int bs) {
     int WR = BLUR_TR + 2 * v, EW = BLUR_TW + 2 * R, NW = (EW + 63) >> 6;
     (void)EW;
     return (size_t)((BLUR_TR * (BLUR_TW + bs - 1) + 3) & ~3) * 4 + 2 * (size_t)WR * BLUR_TW * 4 + 2 * (size_t)WR * NW * 8 +
-           sizeof(csm::PowfTables) + 64;
+           sizeof(csm::PowfTables) + 64 + 4 * (size_t)(R + 2);
 }
 
 int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double falloff,
@@ -458,8 +566,23 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
         unsigned long long* mask_l = reinterpret_cast<unsigned long long*>(wl);
         unsigned long long* mask_r = reinterpret_cast<unsigned long long*>(wr);
         hipLaunchKernelGGL(k_blur_edges, dim3((w + 255) / 256, (h + BLUR_ER - 1) / BLUR_ER, n), dim3(256), 0, stream, A, mask_l, mask_r, MW);
-        hipLaunchKernelGGL(k_blur_fused, dim3((w + BLUR_TW - 1) / BLUR_TW, (h + BLUR_TR - 1) / BLUR_TR, n), dim3(256), ldsF, stream, A,
-                           (const unsigned long long*)mask_l, (const unsigned long long*)mask_r, MW);
+        // edge-free tiles are copied by k_blur_copy; the others reach k_blur_fused through a worklist behind the bit rows
+        const int gy = (h + BLUR_TR - 1) / BLUR_TR, gx = (w + BLUR_TW - 1) / BLUR_TW;
+        const size_t mask_bytes = ((size_t)n * h * MW * 8 + 255) & ~(size_t)255, list_bytes = 256 + (size_t)n * gy * gx * 4;
+        if ((w & 3) == 0 && gx < 1024 && gy < 1024 && n < 4096 && mask_bytes + list_bytes <= (size_t)n * h * w * 4) {
+            uint32_t* work_count = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(wl) + mask_bytes);
+            uint32_t* worklist = work_count + 64;
+            if (hipMemsetAsync(work_count, 0, 4, stream) != hipSuccess) return CS_EHIP;
+            hipLaunchKernelGGL(k_blur_copy, dim3((gx + BLUR_CW - 1) / BLUR_CW, gy, n), dim3(256), 0, stream, A,
+                               (const unsigned long long*)mask_l, (const unsigned long long*)mask_r, MW, work_count, worklist);
+            const size_t total = (size_t)n * gy * gx;
+            const int pg = (int)(total < 2048 ? total : 2048);
+            hipLaunchKernelGGL(k_blur_fused, dim3(pg), dim3(256), ldsF, stream, A, (const unsigned long long*)mask_l,
+                               (const unsigned long long*)mask_r, MW, (const uint32_t*)work_count, (const uint32_t*)worklist);
+        } else {
+            hipLaunchKernelGGL(k_blur_fused, dim3(gx, gy, n), dim3(256), ldsF, stream, A, (const unsigned long long*)mask_l,
+                               (const unsigned long long*)mask_r, MW, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+        }
         return CS_OK;
     }
     int threads = w <= 256 ? 256 : (w <= 1024 ? 512 : 1024);
