@@ -158,6 +158,13 @@ __global__ void k_test_powf(const float* x, float y, float* out, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float a = csm::powf_exact(x[i], y, &T), b = csm::powf_exact_simt(x[i], y, &T);
         out[i] = csm::f2u(a) == csm::f2u(b) ? a : csm::u2f(0x7fc00001u);
+        // the exponent shortcuts of the tile kernel (x >= 0 only, like |nd|) must agree as well
+        if (x[i] >= 0.0f && y == 1.0f && csm::f2u(x[i]) != csm::f2u(a)) out[i] = csm::u2f(0x7fc00002u);
+        if (x[i] >= 0.0f && y == 2.0f) {
+            bool risky;
+            const float sq = csm::square_or_flag(x[i], risky);
+            if (!risky && csm::f2u(sq) != csm::f2u(a)) out[i] = csm::u2f(0x7fc00003u);
+        }
     }
 }
 

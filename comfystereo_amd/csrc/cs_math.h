@@ -154,6 +154,22 @@ __device__ __forceinline__ float powf_exact_simt(float x, float y, const PowfTab
 }
 #endif
 
+// Shortcuts of powf for the two exponents the node is used with most (the widget default 2.0, and 1.0):
+//  * powf(x, 1) == x for every finite x >= 0;
+//  * powf(x, 2) == x * x (the correctly rounded product) unless the exact product lies within 2^-9 ulp of a rounding
+//    midpoint: glibc's powf has a relative error of about 2^-35, and in an exhaustive sweep of the clone over all
+//    finite x >= 0 the largest distance from the midpoint at which the two differ is 0.0017 ulp (888704 units of
+//    2^-29 ulp; the margin used here is 2^20 units).  Outside 2^-60 <= x <= 2^60 (subnormal / overflowing products)
+//    the argument counts as risky, x == 0 is exact.  Risky arguments (0.4 %) must take the full routine.
+// tests: tests/test_oracle_math.py (criterion vs the oracle's clone), tests/test_gpu_parity.py (full binade on the GPU)
+CS_HD float square_or_flag(float ax, bool& risky) {
+    const double p2 = (double)ax * (double)ax;  // exact: 24 + 24 bits
+    int low = (int)(uint32_t)(d2u(p2) & 0x1fffffffull) - 0x10000000;
+    low = low < 0 ? -low : low;
+    risky = (low < (1 << 20) || ax < 0x1p-60f || ax > 0x1p60f) && ax != 0.0f;
+    return ax * ax;
+}
+
 // exp for |x| < 512 (pinned); larger magnitudes saturate to 0 / inf without the libm corner cases.
 // `tab` is the 256-entry {tail, scale bits} table (cs_exp_tab, or an LDS copy).
 CS_HD double exp_exact(double x, const unsigned long long* tab) {

@@ -194,17 +194,21 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
         const bool flat = dmax == dmin;
         const float range = dmax - dmin;
         bool fold = false;
-        auto stage_depth = [&](int j, float draw) {
-            float d = draw * scale;
+        // everything before the power: the depth-map output code, the normalised depth's sign and magnitude
+        auto pre = [&](int j, float draw, float& sgn, float& ax) {
+            const float d = draw * scale;
             // depth-map output of this column: (depth*255).astype(uint8) wraps mod 256 (quirk Q7)
             const int qq = s0 + j - o0;
             if (qq >= 0 && qq < wt) dep8[qq] = csm::f32_to_u8_wrap(d * 255.0f);
-            float nd = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
-            float sgn = nd >= 0.0f ? 1.0f : -1.0f;
-            float pw = A.dbg == 16 ? fabsf(nd) * fabsf(nd) : csm::powf_exact_simt(fabsf(nd), A.e32, tabs);
-            float cdj = (sgn * pw) * E.div32;                                     // coord_d   (:1926)
-            float x = ((float)(s0 + j) + 0.5f + cdj) + E.sep32;                   // coord_x   (:1927)
-            float z = fabsf(cdj);
+            const float nd = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
+            sgn = nd >= 0.0f ? 1.0f : -1.0f;
+            ax = fabsf(nd);
+        };
+        // everything after it: the point's x (and |disparity|) into LDS, fold detection
+        auto post = [&](int j, float sgn, float pw) {
+            const float cdj = (sgn * pw) * E.div32;                                     // coord_d   (:1926)
+            const float x = ((float)(s0 + j) + 0.5f + cdj) + E.sep32;                   // coord_x   (:1927)
+            const float z = fabsf(cdj);
             // fold detection (is the polyline strictly increasing in x?): the right neighbour's x sits in the next lane;
             // the pairs across wave chunks and the sentinel pairs are checked after the barrier
             const float xn = __shfl_down(x, 1);
@@ -219,12 +223,62 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
                 fold = fold || (has_next && !(x < xn));
             }
         };
+        // |nd| ** exponent, bit-exact with glibc's powf.  Exponents 2.0 (widget default) and 1.0 take the shortcuts of
+        // cs_math.h (square_or_flag): the 0.4 % "risky" arguments of the square go through the full routine, batched per
+        // wave after the loop.
+        const int pow_mode = A.dbg == 17 ? 0 : (A.e32 == 2.0f ? 2 : (A.e32 == 1.0f ? 1 : 0));
+        auto square = [&](float ax, bool& risky) { return csm::square_or_flag(ax, risky); };
+        if (pow_mode == 0) {
 #pragma unroll
-        for (int k = 0; k < PT_PF; k++) {
-            const int j = tid + k * PT_THREADS;
-            if (j < ns) stage_depth(j, dpre[k]);
+            for (int k = 0; k < PT_PF; k++) {
+                const int j = tid + k * PT_THREADS;
+                if (j < ns) {
+                    float sgn, ax;
+                    pre(j, dpre[k], sgn, ax);
+                    post(j, sgn, csm::powf_exact_simt(ax, A.e32, tabs));
+                }
+            }
+        } else {
+            float sg[PT_PF], axs[PT_PF], pw[PT_PF];
+            unsigned risk = 0;
+#pragma unroll
+            for (int k = 0; k < PT_PF; k++) {
+                const int j = tid + k * PT_THREADS;
+                sg[k] = 1.0f; axs[k] = 0.0f; pw[k] = 0.0f;
+                if (j < ns) {
+                    pre(j, dpre[k], sg[k], axs[k]);
+                    bool r = false;
+                    pw[k] = pow_mode == 1 ? axs[k] : square(axs[k], r);
+                    risk |= r ? 1u << k : 0u;
+                }
+            }
+            while (__any(risk != 0u)) {  // the full routine for the risky arguments: one pass per wave, rarely two
+                float xin = 1.0f;
+                int sel = -1;
+#pragma unroll
+                for (int k = PT_PF - 1; k >= 0; k--) if (risk & (1u << k)) { xin = axs[k]; sel = k; }
+                const float r = csm::powf_exact_simt(xin, A.e32, tabs);
+#pragma unroll
+                for (int k = 0; k < PT_PF; k++) if (sel == k) pw[k] = r;
+                risk &= risk - 1u;
+            }
+#pragma unroll
+            for (int k = 0; k < PT_PF; k++) {
+                const int j = tid + k * PT_THREADS;
+                if (j < ns) post(j, sg[k], pw[k]);
+            }
         }
-        for (int j = tid + PT_PF * PT_THREADS; j < ns; j += PT_THREADS) stage_depth(j, drow[s0 + j]);
+        for (int j = tid + PT_PF * PT_THREADS; j < ns; j += PT_THREADS) {  // (halos beyond 128 columns only)
+            float sgn, ax;
+            pre(j, drow[s0 + j], sgn, ax);
+            bool r = false;
+            float pwv = pow_mode == 1 ? ax : (pow_mode == 2 ? square(ax, r) : 0.0f);
+            if (pow_mode == 0 || __any(r)) {
+                const float full = csm::powf_exact_simt(ax, A.e32, tabs);
+                pwv = (pow_mode == 0 || r) ? full : pwv;
+            }
+            post(j, sgn, pwv);
+        }
         if (tid == 0) {
             px[0] = (float)(-1.0 * w); pz[0] = 0.0f;
             px[npts - 1] = (float)(2.0 * w); pz[npts - 1] = 0.0f;

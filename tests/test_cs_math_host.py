@@ -33,6 +33,21 @@ int main() {
         if (csm::d2u(exp(x)) != csm::d2u(csm::exp_exact(x, cs_exp_tab))) bad++;
         n++;
     }
+    // exponent shortcuts of the tile kernel: two full binades + a strided sweep of all finite x >= 0
+    long risky_n = 0;
+    auto check_sq = [&](uint32_t u) {
+        float x = csm::u2f(u);
+        bool risky;
+        float sq = csm::square_or_flag(x, risky);
+        if (risky) risky_n++;
+        else if (csm::f2u(powf(x, 2.0f)) != csm::f2u(sq)) bad++;
+        if (csm::f2u(powf(x, 1.0f)) != u) bad++;
+        n++;
+    };
+    for (uint32_t u = 0x3f000000u; u < 0x3f800000u; u++) check_sq(u);
+    if (risky_n > (1 << 23) / 200) bad++;  // the shortcut must stay a shortcut (0.4 % of a binade is flagged)
+    for (uint32_t u = 0x35800000u; u < 0x36000000u; u++) check_sq(u);
+    for (uint32_t u = 0; u < 0x7f800000u; u += 1021) check_sq(u);
     float q[] = {65025.f, 300.7f, -3.2f, 255.9f, 256.f, 1e10f};
     int want[] = {1, 44, 253, 255, 0, 0};
     for (int i = 0; i < 6; i++) if (csm::f32_to_u8_wrap(q[i]) != want[i]) bad++;
@@ -55,4 +70,4 @@ def test_device_math_header_matches_libm_on_host(tmp_path):
                            str(src), "-o", str(exe), "-lm"])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     n, bad = map(int, out.stdout.split())
-    assert out.returncode == 0 and bad == 0 and n > 9_000_000
+    assert out.returncode == 0 and bad == 0 and n > 25_000_000

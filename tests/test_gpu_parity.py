@@ -34,6 +34,25 @@ def test_device_powf_bit_exact(engine):
         assert np.array_equal(got[:: 97].view(np.uint32), want.view(np.uint32)), e
 
 
+def test_device_powf_exponent_shortcuts(engine):
+    """The tile kernel's shortcuts for exponents 2.0 (x * x unless flagged risky) and 1.0 (identity): the test kernel
+    returns a NaN marker where a shortcut disagrees with the full routine -- a whole binade, a tiny one, the stored
+    vectors where powf(x, 2) != x * x (tests/golden/powf_square.npz) and a strided sweep of all finite x >= 0."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "powf_square.npz"))
+    L = oracle.lib()
+    parts = [np.arange(0x3f000000, 0x3f800000, dtype=np.uint32), np.arange(0x35800000, 0x36000000, 3, dtype=np.uint32),
+             np.arange(0, 0x7f800000, 509, dtype=np.uint32), g["x"].view(np.uint32)]
+    x = np.concatenate(parts).view(np.float32)
+    for e in (2.0, 1.0):
+        got = engine.test_powf(cuda(x), e).cpu().numpy()
+        assert not np.isnan(got[~np.isnan(x)]).any(), e
+        idx = np.concatenate([np.arange(0, x.size, 9973), np.arange(x.size - g["x"].size, x.size)])
+        want = np.array([L.oracle_powf(float(v), e) for v in x[idx]], dtype=np.float32)
+        assert np.array_equal(got[idx].view(np.uint32), want.view(np.uint32)), e
+    assert np.array_equal(engine.test_powf(cuda(g["x"]), 2.0).cpu().numpy().view(np.uint32), g["powf_x_2"].view(np.uint32))
+
+
 def test_device_exp_bit_exact(engine):
     rng = np.random.default_rng(1)
     x = np.concatenate([-rng.random(200000) * 330.0, -(rng.random(200000, dtype=np.float32).astype(np.float64) ** 2) * 2,

@@ -46,3 +46,13 @@ def test_powf_known_answers():
     L = oracle.lib()
     assert L.oracle_powf(0.0, 2.0) == 0.0 and L.oracle_powf(1.0, 1.3) == 1.0 and L.oracle_powf(0.25, 0.5) == 0.5
     assert L.oracle_powf(0.5, 2.0) == 0.25
+
+
+def test_powf_square_vectors():
+    """tests/golden/powf_square.npz (tools/make_powf_square_vectors.py): arguments where powf(x, 2) != x * x."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "powf_square.npz"))
+    L = oracle.lib()
+    got = np.array([L.oracle_powf(float(v), 2.0) for v in g["x"]], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), g["powf_x_2"].view(np.uint32))
+    assert np.all(g["x"] * g["x"] != g["powf_x_2"])
