@@ -659,9 +659,13 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
     // scheduler overlaps their LDS round trips
     auto fast_px = [&](int q, bool cand, unsigned c, uint32_t& rgb) -> bool {
         const int col = o0 + q;
-        const PixC P = pix_consts(col);
-        const double sig_dd = P.sig_dd;
-        const float ff64 = P.ff64, tf64 = P.tf64, center64 = P.center64;
+        // the float64 ("Python float") constants of pix_consts, rounded to float32 -- closed forms, checked against the
+        // double arithmetic for every col < 2^24 (tests/test_cs_math_host.py): (float)(col + 1e-7) == col and
+        // (float)(col + 1 - 1e-7) == col + 1 from col = 2 on, the centre is col + 0.5, the length rounds to 1 - 3 * 2^-24
+        const float ff64 = col == 0 ? 0x1.ad7f2ap-24f : (col == 1 ? 0x1.000002p+0f : (float)col);
+        const float tf64 = col == 0 ? 0x1.fffffcp-1f : (col == 1 ? 0x1.fffffep+0f : (float)(col + 1));
+        const float center64 = (float)col + 0.5f;
+        const float sig_dd = 0x1.fffffap-1f;  // (float)(to - from); never zero
         bool done = cand;
         const int o = cand ? (mono ? (int)(c & 0xfffu) : (int)pts[q * PT_KP]) : 1;
         const float xm = px[o - 1], x = px[o], xp = px[o + 1];

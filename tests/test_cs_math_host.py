@@ -48,6 +48,15 @@ int main() {
     if (risky_n > (1 << 23) / 200) bad++;  // the shortcut must stay a shortcut (0.4 % of a binade is flagged)
     for (uint32_t u = 0x35800000u; u < 0x36000000u; u++) check_sq(u);
     for (uint32_t u = 0; u < 0x7f800000u; u += 1021) check_sq(u);
+    // closed forms of the per-pixel float64 constants used by the tile kernel's fast path (cs_polytile.hip, fast_px)
+    for (int col = 0; col < (1 << 24); col++) {
+        double from_d = (double)col + 1e-7, to_d = (double)(col + 1) - 1e-7, sig = to_d - from_d;
+        float ff = col == 0 ? 0x1.ad7f2ap-24f : (col == 1 ? 0x1.000002p+0f : (float)col);
+        float tf = col == 0 ? 0x1.fffffcp-1f : (col == 1 ? 0x1.fffffep+0f : (float)(col + 1));
+        if ((float)from_d != ff || (float)to_d != tf || (float)(from_d + 0.5 * sig) != (float)col + 0.5f ||
+            (float)sig != 0x1.fffffap-1f || sig == 0.0) bad++;
+        n++;
+    }
     float q[] = {65025.f, 300.7f, -3.2f, 255.9f, 256.f, 1e10f};
     int want[] = {1, 44, 253, 255, 0, 0};
     for (int i = 0; i < 6; i++) if (csm::f32_to_u8_wrap(q[i]) != want[i]) bad++;
@@ -70,4 +79,4 @@ def test_device_math_header_matches_libm_on_host(tmp_path):
                            str(src), "-o", str(exe), "-lm"])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     n, bad = map(int, out.stdout.split())
-    assert out.returncode == 0 and bad == 0 and n > 25_000_000
+    assert out.returncode == 0 and bad == 0 and n > 40_000_000

@@ -10,7 +10,7 @@ B="python3 bench.py $* --no-cpu-baseline"
 run() { # name, extra rocprof args...
   local name=$1; shift
   rm -rf /tmp/prof_$name
-  rocprofv3 "$@" -d /tmp/prof_$name -o p -- $B > $OUT/$name.log 2>&1
+  timeout 600 rocprofv3 "$@" -d /tmp/prof_$name -o p -- $B > $OUT/$name.log 2>&1
   local db=$(find /tmp/prof_$name -name '*.db' | head -1)
   if [ "$name" = trace ]; then python3 tools/prof_summary.py $db $OUT/kernel_trace.txt > /dev/null
   else python3 tools/prof_summary.py $db $OUT/$name.txt --pmc > /dev/null; fi
