@@ -91,6 +91,7 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
         if (rec_wg && A.stats_rw && threadIdx.x == 0) {
             long long t = wall_clock64();
             atomicAdd(&A.stats_rw[(size_t)(phase % A.n) * ST_WORDS + 12], (unsigned)(t - t_prev));
+            atomicAdd(&A.stats_rw[(size_t)(phase % A.n) * ST_WORDS + 13], 1u);
             t_prev = t;
         }
     };
@@ -391,7 +392,7 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
         }
     }
     __syncthreads();
-    stamp(4);
+    stamp(mono ? 4 : 3);  // fold tiles are accounted separately
 
     // ---- EVALUATE ----------------------------------------------------------------------------------------
     // per-pixel constants of the float64 ("Python float") branch of the sub-interval arithmetic
@@ -734,7 +735,7 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
     if (A.dbg == 18) return;
     if (!SHARP) {
         __syncthreads();
-        stamp(5);
+        stamp(mono ? 5 : 8);
         // ---- pass 2 (soft): the chain path over the listed pixels, the general search for those it cannot do
         const int nlist = flags[2];
         for (int base = tid & ~63; base < nlist; base += PT_THREADS) {
@@ -761,7 +762,7 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
     }
     if (hazard) flags[0] = 1;
     __syncthreads();
-    stamp(7);
+    stamp(mono ? 7 : 6);
     if (flags[0]) {
         // the general kernel redoes this row (both eyes) and overwrites whatever is stored below
         if (tid == 0) A.rowflag[(size_t)frame * h + row] = 1;

@@ -33,7 +33,9 @@ st = plan.stats()
 import os
 if os.environ.get("CS_DBG") == "20":
     nwg = 2 * a.n * ((a.h * ((a.w + 511) // 512) + 60) // 61)
-    print("mean phase latency per workgroup, us (phase = index):", [round(int(x) / nwg / 100.0, 2) for x in st[:, 12].tolist()])
+    print("mean phase latency per workgroup that recorded it, us (phase = index):",
+          [round(int(x) / max(int(c), 1) / 100.0, 2) for x, c in zip(st[:, 12].tolist(), st[:, 13].tolist())])
+    print("workgroups per phase:", [int(c) for c in st[:, 13].tolist()])
 print("chain px, generic px, waves with generic, waves:", st[:, 12].sum().item(), st[:, 13].sum().item(), st[:, 14].sum().item(), st[:, 15].sum().item())
 print("seq-fallback rows:", st[:, 10].tolist(), "tile-redo rows:", st[:, 11].tolist(), "errors:", st[:, 9].tolist())
 t0 = time.perf_counter()
