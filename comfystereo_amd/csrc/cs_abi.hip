@@ -225,16 +225,26 @@ static int poly_halo(double div_percent_a, double div_percent_b, double sep_perc
     return (int)ceil(s) + 2;
 }
 
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+// flags of the rows the tiled polylines path hands to the row kernel + their compacted list (run_rows)
+static size_t rowflag_bytes(size_t rows) { return al256(rows) + 256 + al256(rows * 4); }
+
 // polylines: tiled fast path + general row kernel over the rows it flagged; everything else: row kernel
 static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_t stream) {
     const bool poly = fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP;
     const char* no_tile = getenv("CS_NO_TILE");
     if (poly && !A.anaglyph && halo <= polytile_max_halo() && rowflag && !(no_tile && atoi(no_tile))) {
-        hipError_t e = hipMemsetAsync(rowflag, 0, (size_t)A.n * A.h, stream);
+        // workspace: [n*h flag bytes][count, padded to 256][n*h list entries]
+        const size_t rows = (size_t)A.n * A.h;
+        uint32_t* count = (uint32_t*)(rowflag + al256(rows));
+        uint32_t* list = count + 64;
+        hipError_t e = hipMemsetAsync(rowflag, 0, al256(rows) + 256, stream);
         if (e != hipSuccess) return fail_hip(e, "rowflag memset");
         e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, A, halo, rowflag, stream);
         if (e != hipSuccess) return fail_hip(e, "tiled polylines launch");
-        A.only_flagged = rowflag;
+        e = launch_collect_rows(rowflag, (int)rows, count, list, stream);
+        if (e != hipSuccess) return fail_hip(e, "flagged-row collection");
+        A.row_list = list; A.row_count = count;
     }
     hipError_t e = launch_rowwarp(fill, A, threads_for(fill, A.w), stream);
     if (e != hipSuccess) return fail_hip(e, "row kernel launch");
@@ -288,7 +298,6 @@ int cs_output_shape(const cs_params* p, int* out_h, int* out_w, int* mask_h, int
     return CS_OK;
 }
 
-static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
     size_t stats, rowflag, gray_src, gray, L, R, wl, wr, extra, total;
@@ -297,7 +306,7 @@ static WsLayout ws_layout(const cs_params* p) {
     WsLayout W;
     size_t hw = (size_t)p->h * p->w, n = p->n, o = 0;
     W.stats = o; o += al256(n * ST_WORDS * 4);
-    W.rowflag = o; o += al256(n * (size_t)p->h);
+    W.rowflag = o; o += rowflag_bytes(n * (size_t)p->h);
     bool resize = p->depth_h != p->h || p->depth_w != p->w;
     W.gray_src = o; if (resize) o += al256(n * (size_t)p->depth_h * p->depth_w * 4);
     W.gray = o; o += al256(n * hw * 4);
@@ -415,7 +424,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
 }
 
 size_t cs_asd_workspace_bytes(int n, int h, int w) {
-    return al256((size_t)n * ST_WORDS * 4) + al256((size_t)n * h) + al256(hybrid_workspace_bytes(n, h, w));
+    return al256((size_t)n * ST_WORDS * 4) + rowflag_bytes((size_t)n * h) + al256(hybrid_workspace_bytes(n, h, w));
 }
 
 int cs_apply_stereo_divergence(const uint8_t* image_u8, const float* depth, int n, int h, int w, double divergence,
@@ -444,7 +453,7 @@ int cs_apply_stereo_divergence(const uint8_t* image_u8, const float* depth, int 
     A.out_u8 = out_u8;
     A.single = -1;
     if (fill == CS_FILL_HYBRID_EDGE) {
-        int rc = launch_hybrid(A, (char*)workspace + al256((size_t)n * ST_WORDS * 4) + al256((size_t)n * h), stream);
+        int rc = launch_hybrid(A, (char*)workspace + al256((size_t)n * ST_WORDS * 4) + rowflag_bytes((size_t)n * h), stream);
         if (rc) return fail(rc, "hybrid_edge launch failed");
     } else {
         int halo = poly_halo(divergence, divergence, separation, exponent, convergence, w);

@@ -45,12 +45,14 @@ struct RowArgs {
     // hybrid_edge scratch (HBM): splat result of every eye, written by k_hybrid_splat
     uint8_t* hyb_base;  // [n][neyes][h][w][3]
     uint8_t* hyb_mask;  // [n][neyes][h][w]
-    const uint8_t* only_flagged;  // [n][h] or null: process only rows whose flag is set (tiled-path fallback)
+    const uint32_t* row_list;     // or null: process only these rows (frame * h + row), *row_count of them (tiled-path fallback)
+    const uint32_t* row_count;
     int dbg;            // development only (env CS_DBG): stop the polylines technique after phase `dbg`
 };
 
 
 // cs_rowwarp.hip
+hipError_t launch_collect_rows(const uint8_t* flag, int total, uint32_t* count, uint32_t* list, hipStream_t stream);
 hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream);
 size_t rowwarp_lds_bytes(int fill, int w);
 

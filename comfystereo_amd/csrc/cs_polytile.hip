@@ -19,7 +19,7 @@
 //      full float4 rows into the SBS/TB slot together with the mask and this eye's depth-map output.
 // Anything the fast path cannot prove order-independent -- exact closeness ties, no qualifying
 // candidate, non-monotone centres, a slot list overflowing -- flags the ROW; flagged rows are redone
-// by the general row kernel (cs_rowwarp.hip, `only_flagged`), whose results are authoritative.
+// by the general row kernel (cs_rowwarp.hip, `row_list`), whose results are authoritative.
 // The neighbours of the first/last point of a pixel never enter the arithmetic (max(col, x) and
 // min(col+1, x) discard them), which is why no global sort is needed.
 #include "cs_common.h"

@@ -736,16 +736,13 @@ struct RowOut {
 };
 
 template <int FILL>
-__global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ void rowwarp_row(const RowArgs& A, const int row, const int frame, char* smem) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int row = blockIdx.x, frame = blockIdx.y;
     const int w = A.w, h = A.h;
-    if (A.only_flagged && !A.only_flagged[(size_t)frame * h + row]) return;
     Lds L = carve(smem, FILL, w, A.anaglyph);
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
     uint32_t* st_rw = A.stats_rw ? A.stats_rw + (size_t)frame * ST_WORDS : nullptr;
-    if (A.only_flagged && st_rw && tid == 0) atomicAdd(&st_rw[ST_TILE_REDO_ROWS], 1u);
+    if (A.row_list && st_rw && tid == 0) atomicAdd(&st_rw[ST_TILE_REDO_ROWS], 1u);
     constexpr bool DIRECT = !fill_uses_res(FILL);  // the technique emits pixels itself
 
     // constants into LDS
@@ -867,10 +864,47 @@ __global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
     }
 }
 
+// One workgroup per row (both eyes); or, behind the tiled polylines path, a fixed number of workgroups working off the
+// list of rows that path flagged (`row_list`: frame * h + row) -- usually empty, so nothing the size of the batch is launched.
+template <int FILL>
+__global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (!A.row_list) {
+        rowwarp_row<FILL>(A, blockIdx.x, blockIdx.y, smem);
+        return;
+    }
+    // rows are handed out dynamically (row_count[1] = next index): a row that needs the sequential replay takes 100x
+    // longer than the others
+    const uint32_t count = A.row_count[0];
+    __shared__ uint32_t s_next;
+    while (true) {
+        if (threadIdx.x == 0) s_next = atomicAdd(const_cast<uint32_t*>(&A.row_count[1]), 1u);
+        __syncthreads();
+        const uint32_t i = s_next;
+        if (i >= count) break;
+        const uint32_t e = A.row_list[i];
+        rowwarp_row<FILL>(A, (int)(e % (uint32_t)A.h), (int)(e / (uint32_t)A.h), smem);
+        __syncthreads();  // the row's LDS (and s_next) is reused by the next one
+    }
+}
+
+// rows flagged by the tiled path -> compact list
+__global__ void __launch_bounds__(256) k_collect_rows(const uint8_t* __restrict__ flag, int total, uint32_t* count, uint32_t* list) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < total && flag[i]) list[atomicAdd(count, 1u)] = (uint32_t)i;
+}
+
+hipError_t launch_collect_rows(const uint8_t* flag, int total, uint32_t* count, uint32_t* list, hipStream_t stream) {
+    hipLaunchKernelGGL(k_collect_rows, dim3((total + 255) / 256), dim3(256), 0, stream, flag, total, count, list);
+    return hipGetLastError();
+}
+
 // host-side launcher (called from cs_abi.hip)
 hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream) {
     size_t lds = lds_common_bytes(fill, A.w, A.anaglyph) + lds_tech_bytes(fill, A.w);
+    const long long rows = (long long)A.h * A.n;
     dim3 grid(A.h, A.n), block(threads);
+    if (A.row_list) grid = dim3((unsigned)(rows < 2048 ? rows : 2048), 1);
 #define CS_LAUNCH(F)                                                                                              \
     case F: {                                                                                                     \
         hipError_t e = hipFuncSetAttribute((const void*)k_rowwarp<F>, hipFuncAttributeMaxDynamicSharedMemorySize, \
