@@ -227,6 +227,72 @@ __global__ void __launch_bounds__(256) k_blur_edges(BlurArgs A, unsigned long lo
     }
 }
 
+// The same for widths that are multiples of 4 (every real frame): FOUR columns per lane, loaded as one float4 per image
+// row (8x fewer load instructions -- the scalar version is bound by the L1 request rate, not by HBM); the two missing
+// neighbours come from the adjacent lanes (shuffles; the first / last lane of a wave loads them).  A lane's four edge bits
+// form a nibble, eight lanes' nibbles a 32-bit half word (OR over xor-shuffles), two halves a word of the bit row.
+#define BLUR_ER4 8  // image rows per thread
+__global__ void __launch_bounds__(256) k_blur_edges4(BlurArgs A, unsigned long long* mask_l, unsigned long long* mask_r, int MW) {
+    const int lane = threadIdx.x & 63;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, yb = blockIdx.y * BLUR_ER4, frame = blockIdx.z;
+    const int w = A.w, h = A.h;
+    const float scale = (A.stats && A.stats[frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
+    const float* d = A.depth + (size_t)frame * h * w;
+    float4 v[BLUR_ER4 + 2];
+    float nl[BLUR_ER4 + 2], nr[BLUR_ER4 + 2];
+#pragma unroll
+    for (int i = 0; i < BLUR_ER4 + 2; i++) {
+        const int yy = yb - 1 + i;
+        const bool rowok = yy >= 0 && yy < h;
+        const float* r = d + (size_t)(rowok ? yy : 0) * w;
+        v[i] = (rowok && x < w) ? *reinterpret_cast<const float4*>(r + x) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // columns x - 1 and x + 4: only the wave's first / last lane has to load them (zero padding outside the frame)
+        nl[i] = (lane == 0 && rowok && x > 0 && x < w) ? r[x - 1] : 0.0f;
+        nr[i] = (lane == 63 && rowok && x + 4 < w) ? r[x + 4] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < BLUR_ER4 + 2; i++) {
+        v[i].x *= scale; v[i].y *= scale; v[i].z *= scale; v[i].w *= scale;
+        const float fl = __shfl_up(v[i].w, 1), fr = __shfl_down(v[i].x, 1);
+        nl[i] = lane == 0 ? nl[i] * scale : fl;
+        nr[i] = lane == 63 ? nr[i] * scale : fr;
+        if (x + 4 >= w) nr[i] = 0.0f;  // (the neighbour lane holds zeros anyway; explicit for the frame's last column)
+    }
+    const int word = x >> 6;
+#pragma unroll
+    for (int j = 0; j < BLUR_ER4; j++) {
+        const int y = yb + j;
+        unsigned nib_l = 0, nib_r = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            // rows y-1, y, y+1 in raster order: (-1, +1), (-2, +2), (-1, +1); the centre taps have weight 0
+            float L[3], R[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const float4 q = v[j + t];
+                L[t] = c == 0 ? nl[j + t] : (c == 1 ? q.x : (c == 2 ? q.y : q.z));
+                R[t] = c == 0 ? q.y : (c == 1 ? q.z : (c == 2 ? q.w : nr[j + t]));
+            }
+            float g = 0.0f;
+            g = fmaf(-1.0f, L[0], g); g = fmaf(1.0f, R[0], g);
+            g = fmaf(-2.0f, L[1], g); g = fmaf(2.0f, R[1], g);
+            g = fmaf(-1.0f, L[2], g); g = fmaf(1.0f, R[2], g);
+            const float es = fminf(fmaxf(fabsf(g) / A.den, 0.0f), 1.0f);
+            const bool in = x + c < w;
+            nib_l |= (in && (g > 0.0f) && (es > 0.5f)) ? 1u << c : 0u;
+            nib_r |= (in && (g < 0.0f) && (es > 0.5f)) ? 1u << c : 0u;
+        }
+        unsigned hl = nib_l << (4 * (lane & 7)), hr = nib_r << (4 * (lane & 7));
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { hl |= __shfl_xor(hl, o); hr |= __shfl_xor(hr, o); }
+        const unsigned hl_hi = __shfl_down(hl, 8), hr_hi = __shfl_down(hr, 8);
+        if ((lane & 15) == 0 && word < MW && y < h) {
+            mask_l[((size_t)frame * h + y) * MW + word] = (unsigned long long)hl | ((unsigned long long)hl_hi << 32);
+            mask_r[((size_t)frame * h + y) * MW + word] = (unsigned long long)hr | ((unsigned long long)hr_hi << 32);
+        }
+    }
+}
+
 // 64 bits of a frame-wide bit row starting at (possibly negative / out of range) bit position `fb`
 __device__ __forceinline__ unsigned long long mask_window(const unsigned long long* row, int MW, int fb) {
     if (fb <= -64) return 0ull;
@@ -565,7 +631,10 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
         const int MW = (w + 63) / 64;
         unsigned long long* mask_l = reinterpret_cast<unsigned long long*>(wl);
         unsigned long long* mask_r = reinterpret_cast<unsigned long long*>(wr);
-        hipLaunchKernelGGL(k_blur_edges, dim3((w + 255) / 256, (h + BLUR_ER - 1) / BLUR_ER, n), dim3(256), 0, stream, A, mask_l, mask_r, MW);
+        if ((w & 3) == 0 && !getenv("CS_BLUR_EDGES_SCALAR"))
+            hipLaunchKernelGGL(k_blur_edges4, dim3((w + 1023) / 1024, (h + BLUR_ER4 - 1) / BLUR_ER4, n), dim3(256), 0, stream, A, mask_l, mask_r, MW);
+        else
+            hipLaunchKernelGGL(k_blur_edges, dim3((w + 255) / 256, (h + BLUR_ER - 1) / BLUR_ER, n), dim3(256), 0, stream, A, mask_l, mask_r, MW);
         // edge-free tiles are copied by k_blur_copy; the others reach k_blur_fused through a worklist behind the bit rows
         const int gy = (h + BLUR_TR - 1) / BLUR_TR, gx = (w + BLUR_TW - 1) / BLUR_TW;
         const size_t mask_bytes = ((size_t)n * h * MW * 8 + 255) & ~(size_t)255, list_bytes = 256 + (size_t)n * gy * gx * 4;
