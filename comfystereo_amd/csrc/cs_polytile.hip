@@ -30,6 +30,9 @@
 namespace cs {
 
 #define PT_T 512      // output pixels per tile
+#ifndef CS_PT_TIMESTAMPS
+#define CS_PT_TIMESTAMPS 0
+#endif
 #define PT_THREADS 256  // == the 256 entries of the byte -> float table, one per thread
 
 __constant__ csm::PowfTables c_pt_powf_tables = CS_POWF_TABLES_INIT;
@@ -81,13 +84,19 @@ struct PolyTileArgs {
 
 // PT_KP / PT_KS: polyline points / forward segments per output pixel the fast path can hold (more -> row redo)
 template <int SHARP, int PT_KP, int PT_KS, int MINW>
-__global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
+// The leading scalar arguments are the ones the first global loads depend on: with -amdgpu-kernarg-preload-count=16 they
+// arrive in SGPRs with the wave instead of through scalar-memory round trips (a by-value struct is not preloaded).
+__global__ void __launch_bounds__(PT_THREADS, MINW)
+k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
+           int hot_w, int hot_h, int hot_S, int hot_single, PolyTileArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    if (A.dbg == 10) return;
+    // development (-DCS_PT_TIMESTAMPS=1 and CS_DBG=20): per-phase latency of sampled workgroups, summed into the spare stats
+    // words of frame `phase`.  Compiled out by default: even the untaken branches delay the kernel-argument loads.
+#if CS_PT_TIMESTAMPS
     const bool rec_wg = A.dbg == 20 && blockIdx.x % 61 == 0;  // sampled: the hot atomics perturb
-    long long t_prev = rec_wg ? wall_clock64() : 0;
-    auto stamp = [&](int phase) {  // development (CS_DBG=20): per-phase latency of the workgroup, summed into frame `phase`'s spare stats word
+    long long t_prev = wall_clock64();
+    auto stamp = [&](int phase) {
         if (rec_wg && A.stats_rw && threadIdx.x == 0) {
             long long t = wall_clock64();
             atomicAdd(&A.stats_rw[(size_t)(phase % A.n) * ST_WORDS + 12], (unsigned)(t - t_prev));
@@ -95,17 +104,31 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
             t_prev = t;
         }
     };
-    const int tiles = (A.w + PT_T - 1) / PT_T;
+#else
+    constexpr bool rec_wg = false;
+    auto stamp = [](int) {};
+#endif
+    const int tiles = (hot_w + PT_T - 1) / PT_T;
     // (eye = slowest grid dimension: pairing the two eyes of a tile on one XCD so that the second finds the image row in
     // that L2 was measured 13 % SLOWER -- the eyes' output streams then hit the same HBM channels at the same time)
-    const int bx = blockIdx.x, eyei = A.single >= 0 ? A.single : (int)blockIdx.z;
+    const int bx = blockIdx.x, eyei = hot_single >= 0 ? hot_single : (int)blockIdx.z;
     const int tile = bx % tiles, row = bx / tiles, frame = blockIdx.y;
-    const EyeArgs& E = A.eye[eyei];
+    // (the eye's arguments are selected field by field: a dynamically indexed kernel-argument array costs a second,
+    // dependent scalar-memory round trip before the first global load can be issued)
+    EyeArgs E;
+    E.depth = eyei ? hot_depth1 : hot_depth0;
+    E.div32 = eyei ? A.eye[1].div32 : A.eye[0].div32;
+    E.sep32 = eyei ? A.eye[1].sep32 : A.eye[0].sep32;
+    E.enabled = eyei ? A.eye[1].enabled : A.eye[0].enabled;
+    E.st_min = eyei ? A.eye[1].st_min : A.eye[0].st_min;
+    E.st_max = eyei ? A.eye[1].st_max : A.eye[0].st_max;
+    E.xoff = eyei ? A.eye[1].xoff : A.eye[0].xoff;
+    E.yoff = eyei ? A.eye[1].yoff : A.eye[0].yoff;
     const bool eye_on = E.enabled && A.dbg != 41;  // (41: development, memory-only pass)
-    const int w = A.w, h = A.h;
+    const int w = hot_w, h = hot_h;
     const int o0 = tile * PT_T, wt = min(PT_T, w - o0);
-    const int s0 = max(0, (o0 - A.S - 1) & ~3), s1 = min(w, o0 + wt + A.S + 1), ns = s1 - s0;  // s0 % 4 == 0: float4 staging
-    const int nsmax = PT_T + 2 * A.S + 6;
+    const int s0 = max(0, (o0 - hot_S - 1) & ~3), s1 = min(w, o0 + wt + hot_S + 1), ns = s1 - s0;  // s0 % 4 == 0: float4 staging
+    const int nsmax = PT_T + 2 * hot_S + 6;
 
     // Local point ids: 0 = left sentinel (x = -w), then the points of source s0 + j in reference order
     // (soft: 1 + j; sharp: 1 + 2j and 2 + 2j), last = right sentinel (x = 2w).  The sentinels only take
@@ -142,10 +165,12 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
         const int j = tid + k * PT_THREADS;
         dpre[k] = j < ns ? drow[s0 + j] : 0.0f;
     }
-    const int nq = (A.image_f32 && (w & 3) == 0) ? ns / 4 : 0;  // (rowpix + s0) % 4 == 0 -> 16-byte aligned groups of 4 pixels
-    const float4* s4 = reinterpret_cast<const float4*>(A.image_f32 + (rowpix + s0) * 3);
+    const int nq = (hot_image && (w & 3) == 0) ? ns / 4 : 0;  // (rowpix + s0) % 4 == 0 -> 16-byte aligned groups of 4 pixels
+    const float4* s4 = reinterpret_cast<const float4*>(hot_image + (rowpix + s0) * 3);
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
     if (tid < nq) { q0 = s4[3 * tid]; q1 = s4[3 * tid + 1]; q2 = s4[3 * tid + 2]; }
+    stamp(10);  // (development) loads issued
+    if (rec_wg) { __builtin_amdgcn_s_waitcnt(0); stamp(11); }  // loads arrived
     const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
     const float dmin = eye_on ? csm::ord2f(st[E.st_min]) : 0.0f, dmax = eye_on ? csm::ord2f(st[E.st_max]) : 0.0f;
 
@@ -158,8 +183,8 @@ __global__ void __launch_bounds__(PT_THREADS, MINW) k_polytile(PolyTileArgs A) {
     if (tid == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
     if (A.dbg == 9) return;
     // stage the source pixels of the halo'ed range as packed uint8 RGB (reference :1508)
-    if (A.image_f32) {
-        const float* src = A.image_f32 + (rowpix + s0) * 3;
+    if (hot_image) {
+        const float* src = hot_image + (rowpix + s0) * 3;
         auto pack4 = [&](int i, float4 v0, float4 v1, float4 v2) {
             float f[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
             uint32_t pk[4];
@@ -860,7 +885,8 @@ hipError_t launch_polytile(int sharp, const RowArgs& R, int S, uint8_t* rowflag,
         hipError_t e = hipFuncSetAttribute((const void*)k_polytile<SH, KP, KS, MW>,                                 \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
         if (e != hipSuccess) return e;                                                                              \
-        hipLaunchKernelGGL((k_polytile<SH, KP, KS, MW>), grid, block, lds, stream, A);                              \
+        hipLaunchKernelGGL((k_polytile<SH, KP, KS, MW>), grid, block, lds, stream, A.image_f32, A.eye[0].depth,     \
+                           A.eye[1].depth, A.w, A.h, A.S, A.single, A);                              \
     }
     // soft default: 4 points / 5 segments per pixel in the lists -> 21.6 KB of LDS at the bench halo, 72 VGPRs: 7 workgroups
     // per CU (LDS is handed out in 2 KB granules; 6 segments would be 128 bytes over).  CS_PT_VARIANT: development.
