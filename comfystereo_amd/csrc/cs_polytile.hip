@@ -607,41 +607,31 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
             if (live && (center < prev || center > (float)(col + 1))) hazard = true;
             prev = live ? center : prev;
             const bool work = live && (sig64 ? sig_dd != 0.0 : sig_f != 0.0f);  // a zero-length piece adds exactly 0
-            int nact = 0, pick = -1;
+            // ONE scan of the pixel's listed segments: which are active at the centre (x0 < centre <= x1); with overlapping
+            // layers (or none) the reference picks the largest interpolated |disparity| among candidates with
+            // 0 < ip_k < 1, the first one on ties -> ties are order-dependent: flag.
+            int nact = 0, pick = -1, nqual = 0, best = -1;
+            float bc = (float)(-1e-7);
+            bool tie = false;
 #pragma unroll
             for (int e = 0; e < PT_KS; e++) {
                 if (e < wns) {
-                    bool act = (sx0[e] < center) && !(sx1[e] < center);
+                    const bool act = (sx0[e] < center) && !(sx1[e] < center);
                     nact += act ? 1 : 0;
                     pick = act ? e : pick;
+                    const float ip_e = (center - sx0[e]) / (sx1[e] - sx0[e]);
+                    const bool qual = act && 0.0f < ip_e && ip_e < 1.0f;
+                    const float cl = (1.0f - ip_e) * pz[so[e]] + ip_e * pz[so[e] + 1];
+                    nqual += qual ? 1 : 0;
+                    const bool better = qual && bc < cl;
+                    tie = better ? false : (tie || (qual && cl == bc));
+                    best = better ? e : best;
+                    bc = better ? cl : bc;
                 }
             }
-            if (__any(work && nact != 1)) {
-                // overlapping layers (or none): the reference picks the largest interpolated |disparity|
-                // among candidates with 0 < ip_k < 1, first one on ties -> ties are order-dependent: flag.
-                if (work && nact != 1) {
-                    int nqual = 0, best = -1;
-                    float bc = (float)(-1e-7);
-                    bool tie = false;
-#pragma unroll
-                    for (int e = 0; e < PT_KS; e++) {
-                        if (e < wns) {
-                            bool act = (sx0[e] < center) && !(sx1[e] < center);
-                            if (act) {
-                                float ip_k = (center - sx0[e]) / (sx1[e] - sx0[e]);
-                                if (0.0f < ip_k && ip_k < 1.0f) {
-                                    float cl = (1.0f - ip_k) * pz[so[e]] + ip_k * pz[so[e] + 1];
-                                    nqual++;
-                                    if (bc < cl) { bc = cl; best = e; tie = false; }
-                                    else if (cl == bc) tie = true;
-                                }
-                            }
-                        }
-                    }
-                    if (nqual == 0 || tie) hazard = true;
-                    pick = best >= 0 ? best : pick;
-                }
-            }
+            const bool multi = work && nact != 1;
+            if (multi && (nqual == 0 || tie)) hazard = true;
+            pick = (multi && best >= 0) ? best : pick;
             const bool contrib = work && pick >= 0;
             // colour contribution (reference :1981-1989, D32 typing); idle lanes compute on dummy operands
             float x0 = 0.0f, x1 = 1.0f;
