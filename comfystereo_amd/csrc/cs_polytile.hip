@@ -846,8 +846,10 @@ static size_t polytile_lds(int S, int sharp, int PT_KP, int PT_KS) {
            2 * PT_T + 2 * PT_T + 2 * PT_T * (PT_KP + PT_KS) + align16(3 * PT_T) + PT_T + 64;
 }
 
-// Largest halo the tiled path accepts: beyond this the staged range dwarfs the tile and the row kernel wins.
-int polytile_max_halo() { return PT_T / 2; }
+// Largest halo the tiled path accepts.  The staged range is then 3.7x the tile (LDS 37 KB soft / 55 KB sharp: 2-4
+// workgroups per CU), still several times faster than a whole row per workgroup; the 12-bit point ids of the fold-free
+// registration word allow 2 * (512 + 2 * 764 + 6) + 2 points.
+int polytile_max_halo() { return 700; }
 
 // Launch the tiled fast path for the eyes of `A0` (SBS / TB / single-eye / uint8 outputs; no anaglyph).
 // `rowflag` must be zeroed by the caller; afterwards the general kernel is run over the flagged rows.
