@@ -453,6 +453,7 @@ int cs_apply_stereo_divergence(const uint8_t* image_u8, const float* depth, int 
     A.eye[0].depth = depth; A.eye[0].st_min = ST_L_MIN; A.eye[0].st_max = ST_L_MAX;
     A.out_u8 = out_u8;
     A.single = -1;
+    { const char* dbg = getenv("CS_DBG"); A.dbg = dbg ? atoi(dbg) : 0; }
     if (fill == CS_FILL_HYBRID_EDGE) {
         int rc = launch_hybrid(A, (char*)workspace + al256((size_t)n * ST_WORDS * 4) + rowflag_bytes((size_t)n * h), stream);
         if (rc) return fail(rc, "hybrid_edge launch failed");

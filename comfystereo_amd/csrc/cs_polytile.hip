@@ -30,8 +30,20 @@
 namespace cs {
 
 #define PT_T 512      // output pixels per tile
+// -DCS_PT_TIMESTAMPS=1: development build with per-phase timestamps of sampled workgroups (CS_DBG=20).
+// PT_DEV_CUTOFF(n): CS_DBG=n returns after that phase (8 image staged, 9 LDS set up, 11 disparity staged, 12 registered,
+// 18 pass 1, 13 before the stores).  The cut-offs stay in release builds on purpose: each is one scalar compare, and the
+// basic-block boundaries they create keep the register allocator from spilling scalar state that is live across the
+// phases (measured: 8 instead of 30 spilled VGPRs, all of them then in the rare general search; 6.2 vs 6.8 ms per
+// 16 frames).  PT_DEV_IS(n): development-only behaviours (15 skips the evaluation, 41 memory-only pass).
 #ifndef CS_PT_TIMESTAMPS
 #define CS_PT_TIMESTAMPS 0
+#endif
+#define PT_DEV_CUTOFF(n) if (A.dbg == (n)) return
+#if CS_PT_TIMESTAMPS
+#define PT_DEV_IS(n) (A.dbg == (n))
+#else
+#define PT_DEV_IS(n) false
 #endif
 #define PT_THREADS 256  // == the 256 entries of the byte -> float table, one per thread
 
@@ -79,7 +91,8 @@ struct PolyTileArgs {
     int stereo_is_u8;
     int out_h, out_w;
     uint8_t* rowflag;  // [n][h] set to 1 when the row must be redone by the general kernel
-    int dbg;           // development only (env CS_DBG): 11 = stop after staging, 12 = after REGISTER, 13 = no stores
+    int dbg;           // env CS_DBG: 14 = count the pixels per evaluation path into the spare stats words, 17 = no exponent
+                       // shortcuts (tests compare the two); more in development builds, see CS_PT_TIMESTAMPS
 };
 
 // PT_KP / PT_KS: polyline points / forward segments per output pixel the fast path can hold (more -> row redo)
@@ -124,7 +137,7 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
     E.st_max = eyei ? A.eye[1].st_max : A.eye[0].st_max;
     E.xoff = eyei ? A.eye[1].xoff : A.eye[0].xoff;
     E.yoff = eyei ? A.eye[1].yoff : A.eye[0].yoff;
-    const bool eye_on = E.enabled && A.dbg != 41;  // (41: development, memory-only pass)
+    const bool eye_on = E.enabled && !PT_DEV_IS(41);
     const int w = hot_w, h = hot_h;
     const int o0 = tile * PT_T, wt = min(PT_T, w - o0);
     const int s0 = max(0, (o0 - hot_S - 1) & ~3), s1 = min(w, o0 + wt + hot_S + 1), ns = s1 - s0;  // s0 % 4 == 0: float4 staging
@@ -181,7 +194,7 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
     }
     for (int i = tid; i < PT_T / 2; i += PT_THREADS) reinterpret_cast<uint32_t*>(cnt)[i] = 0;
     if (tid == 0) { flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0; }
-    if (A.dbg == 9) return;
+    PT_DEV_CUTOFF(9);
     // stage the source pixels of the halo'ed range as packed uint8 RGB (reference :1508)
     if (hot_image) {
         const float* src = hot_image + (rowpix + s0) * 3;
@@ -212,7 +225,7 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
     }
     __syncthreads();  // tables ready
     stamp(1);
-    if (A.dbg == 8) return;
+    PT_DEV_CUTOFF(8);
     if (!eye_on) {
         for (int q = tid; q < wt; q += PT_THREADS) dep8[q] = csm::f32_to_u8_wrap((drow[o0 + q] * scale) * 255.0f);
     }
@@ -314,7 +327,7 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
     __syncthreads();
     stamp(2);
 
-    if (A.dbg == 11) return;
+    PT_DEV_CUTOFF(11);
     lut[tid] = (float)tid / 255.0f;  // (PT_THREADS == 256) the powf tables underneath are dead now; read in the store phase
     const bool left_edge = s0 == 0, right_edge = s1 == w;
     bool hazard = false;
@@ -537,7 +550,7 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
         return chain;
     };
 
-    if (A.dbg == 12) return;
+    PT_DEV_CUTOFF(12);
     // ---- pass 1, one output pixel per lane.  soft: the fastest path per lane -- exactly ONE polyline point o in
     // the pixel and two segments over it (flat and gently sloped regions): the two pieces [col, x] and [x, col+1]
     // belong to the segments (o-1 -> o) and (o -> o+1), verified below; straight-line code.  Every other pixel goes
@@ -721,7 +734,7 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
         return done;
     };
     auto fast_cand = [&](unsigned c) { return mono ? (c >> 12) == 1u : c == 0x0201u; };
-    if (!eye_on || A.dbg == 15) {
+    if (!eye_on || PT_DEV_IS(15)) {
         for (int q = tid; q < wt; q += PT_THREADS) put(q, img[o0 + q - s0]);
     } else if (SHARP) {
         for (int q = tid; q < wt; q += PT_THREADS) {
@@ -747,7 +760,7 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
             else if (vb) plist[atomicAdd((unsigned*)&flags[2], 1u)] = (uint16_t)qb;
         }
     }
-    if (A.dbg == 18) return;
+    PT_DEV_CUTOFF(18);
     if (!SHARP) {
         __syncthreads();
         stamp(mono ? 5 : 8);
@@ -782,7 +795,7 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
         // the general kernel redoes this row (both eyes) and overwrites whatever is stored below
         if (tid == 0) A.rowflag[(size_t)frame * h + row] = 1;
     }
-    if (A.dbg == 13) return;
+    PT_DEV_CUTOFF(13);
     // ---- store the tile ------------------------------------------------------------------------------
     if (A.out_u8) {
         uint8_t* dst = A.out_u8 + (rowpix + o0) * 3;

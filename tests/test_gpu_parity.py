@@ -236,6 +236,20 @@ def test_polylines_row_kernel_env_override(engine, monkeypatch):
     assert np.array_equal(a, b) and np.array_equal(a, oracle.apply_stereo_divergence(img, depth, 7.0, 0.3, 2.0, "polylines_soft", 0.5))
 
 
+@pytest.mark.parametrize("exponent", [2.0, 1.0])
+def test_polylines_exponent_shortcuts_env_override(engine, monkeypatch, exponent):
+    """CS_DBG=17 switches the tile kernel's exact shortcuts for exponents 2.0 / 1.0 off (full powf clone for every
+    pixel): identical output, and both equal the oracle."""
+    h, w = 16, 1800
+    img = synth.image_u8(h, w, seed=3)
+    depth = synth.blobs(h, w, seed=9) * np.float32(255)
+    a = engine.apply_stereo_divergence(cuda(img), cuda(depth), 6.5, 0.2, exponent, "polylines_soft", 0.4).cpu().numpy()
+    monkeypatch.setenv("CS_DBG", "17")
+    b = engine.apply_stereo_divergence(cuda(img), cuda(depth), 6.5, 0.2, exponent, "polylines_soft", 0.4).cpu().numpy()
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, oracle.apply_stereo_divergence(img, depth, 6.5, 0.2, exponent, "polylines_soft", 0.4))
+
+
 @pytest.mark.parametrize("fill,mode", [("polylines_soft", "left-right"), ("none", "red-cyan-anaglyph"), ("hybrid_edge", "top-bottom"),
                                        ("polylines_sharp", "right-left")])
 def test_compact_u8_stereoscope_expands_to_the_float_output(engine, fill, mode):
