@@ -761,8 +761,30 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
         }
     }
     PT_DEV_CUTOFF(18);
+    // this eye's depth-map output (byte code -> k/255, replicated over the three channels): depends on the staged depth only
+    auto store_depth = [&](int t0, int nthr) {
+        float* dd = (eyei == 0 ? A.depth_l : A.depth_r);
+        if (!dd || A.out_u8) return;
+        dd += (rowpix + o0) * 3;
+        if ((wt & 3) == 0 && (w & 3) == 0) {
+            float4* d4 = reinterpret_cast<float4*>(dd);
+            for (int i = t0; i < (3 * wt) / 4; i += nthr) {  // 4 consecutive floats of the 3-channel row
+                const int e = 4 * i, q0 = e / 3, r0 = e - 3 * q0;   // element e belongs to pixel e / 3
+                const float va = lut[dep8[q0]], vb = lut[dep8[q0 + 1]];
+                // r0 = 0: a a a b | r0 = 1: a a b b | r0 = 2: a b b b
+                d4[i] = make_float4(va, r0 == 2 ? vb : va, r0 == 0 ? va : vb, vb);
+            }
+        } else {
+            for (int q = t0; q < wt; q += nthr) {
+                float v = lut[dep8[q]];
+                dd[3 * q] = v; dd[3 * q + 1] = v; dd[3 * q + 2] = v;
+            }
+        }
+    };
     if (!SHARP) {
         __syncthreads();
+        // the leftovers below usually fit one wave; the other three write the depth-map output meanwhile
+        if (tid >= 64) store_depth(tid - 64, PT_THREADS - 64);
         stamp(mono ? 5 : 8);
         // ---- pass 2 (soft): the chain path over the listed pixels, the general search for those it cannot do
         const int nlist = flags[2];
@@ -820,8 +842,6 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
             for (int i = tid; i < 3 * wt; i += PT_THREADS) dst[i] = lut[res[i]];
         }
         float* m = A.mask + o;
-        float* dd = (eyei == 0 ? A.depth_l : A.depth_r);
-        if (dd) dd += (rowpix + o0) * 3;
         if ((wt & 3) == 0 && (w & 3) == 0) {
             float4* m4 = reinterpret_cast<float4*>(m);
             for (int i = tid; i < wt / 4; i += PT_THREADS) {
@@ -829,24 +849,11 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
                 m4[i] = make_float4((r[0] | r[1] | r[2]) == 0 ? 1.0f : 0.0f, (r[3] | r[4] | r[5]) == 0 ? 1.0f : 0.0f,
                                     (r[6] | r[7] | r[8]) == 0 ? 1.0f : 0.0f, (r[9] | r[10] | r[11]) == 0 ? 1.0f : 0.0f);
             }
-            if (dd) {
-                float4* d4 = reinterpret_cast<float4*>(dd);
-                for (int i = tid; i < (3 * wt) / 4; i += PT_THREADS) {  // 4 consecutive floats of the 3-channel row
-                    const int e = 4 * i, q0 = e / 3, r0 = e - 3 * q0;   // element e belongs to pixel e / 3
-                    const float va = lut[dep8[q0]], vb = lut[dep8[q0 + 1]];
-                    // r0 = 0: a a a b | r0 = 1: a a b b | r0 = 2: a b b b
-                    d4[i] = make_float4(va, r0 == 2 ? vb : va, r0 == 0 ? va : vb, vb);
-                }
-            }
         } else {
             for (int q = tid; q < wt; q += PT_THREADS)
                 m[q] = ((int)res[3 * q] + (int)res[3 * q + 1] + (int)res[3 * q + 2]) == 0 ? 1.0f : 0.0f;
-            if (dd)
-                for (int q = tid; q < wt; q += PT_THREADS) {
-                    float v = lut[dep8[q]];
-                    dd[3 * q] = v; dd[3 * q + 1] = v; dd[3 * q + 2] = v;
-                }
         }
+        if (SHARP) store_depth(tid, PT_THREADS);  // (soft: written during pass 2)
     }
     if (rec_wg) __builtin_amdgcn_s_waitcnt(0);
     stamp(9);
