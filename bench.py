@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-blur", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=10)
+    ap.add_argument("--verify", action="store_true", help="N > 1: check the reassembled float32 batch against a local float32 run")
     a = ap.parse_args()
 
     import torch
@@ -85,7 +86,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # (CS_BENCH_BACKEND=gloo: development -- exercises the N > 1 code path with several ranks on ONE GPU)
+        backend = os.environ.get("CS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % torch.cuda.device_count()
+            dist.init_process_group(backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -97,17 +104,36 @@ def main():
     image, depth = make_inputs(torch, nloc, b0, device)
     p = engine.make_params(nloc, H, W, H, W, 3, "polylines_soft", "left-right", 8.0, 0.0, 0.0, 0.5, 2.0, blur, 20.0, 20.0,
                            2.0, 6, 12)
-    # N > 1: shards travel over xGMI as uint8 codes (the stereoscope is k/255 exactly: 4x fewer bytes) and are
-    # expanded to float32 on every rank after the all-gather
-    plan = engine.Plan(p, device, stereo_u8=world > 1)
-    gathered8 = torch.empty((a.frames, H, 2 * W, 3), dtype=torch.uint8, device=device) if world > 1 else None
+    # N > 1: shards travel over xGMI as uint8 codes (the stereoscope is k/255 exactly: 4x fewer bytes) and are expanded
+    # to float32 on every rank after the all-gather.  The block of a rank is produced in chunks; the all-gather of chunk c
+    # (RCCL, its own stream) overlaps with the compute of the chunks after it, the expansion of chunk c with the
+    # all-gathers still on the wire (sharding.ChunkedGather).
     gathered = torch.empty((a.frames, H, 2 * W, 3), dtype=torch.float32, device=device) if world > 1 else None
+    n_chunks = next((k for k in (4, 2, 1) if world > 1 and sharding.ChunkedGather.usable(a.frames, world, k)), 0)
+    if world > 1 and n_chunks == 0:
+        raise SystemExit(f"--frames {a.frames} does not split evenly over {world} GPUs")
+    if world > 1:
+        cg = sharding.ChunkedGather(a.frames, n_chunks, (H, 2 * W, 3), torch.uint8, device)
+        cp = engine.make_params(cg.cf, H, W, H, W, 3, "polylines_soft", "left-right", 8.0, 0.0, 0.0, 0.5, 2.0, blur, 20.0,
+                                20.0, 2.0, 6, 12)
+        plans = [engine.Plan(cp, device, stereo_u8=True) for _ in range(n_chunks)]
+        plan = plans[0]
+    else:
+        plan = engine.Plan(p, device)
+
+    def sink(codes, first):
+        engine.expand_u8(codes, gathered[first:first + codes.shape[0]])
 
     def step():
-        stereo, _, _, _ = plan.run(image, depth)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered8, stereo)
-            engine.expand_u8(gathered8, gathered)
+        if world == 1:
+            plan.run(image, depth)
+            return
+        for c in range(n_chunks):
+            lo, hi = cg.chunk_range(c)
+            stereo, _, _, _ = plans[c].run(image[lo:hi], depth[lo:hi])
+            cg.launch(c, stereo)
+        for c in range(n_chunks):
+            cg.finish(c, sink)
 
     def fence():
         torch.cuda.synchronize()
@@ -132,14 +158,27 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    fallback_rows = int(plan.stats()[:, 10].sum())
-    tile_redo_rows = int(plan.stats()[:, 11].sum())
-    err_flags = int(plan.stats()[:, 9].sum())
+    all_plans = plans if world > 1 else [plan]
+    fallback_rows = sum(int(q.stats()[:, 10].sum()) for q in all_plans)
+    tile_redo_rows = sum(int(q.stats()[:, 11].sum()) for q in all_plans)
+    err_flags = sum(int(q.stats()[:, 9].sum()) for q in all_plans)
 
+    if a.verify and world > 1:
+        # every rank: its own block of the reassembled batch == the float32 output computed locally in one piece
+        ref = engine.Plan(p, device).run(image, depth)[0]
+        ok = torch.equal(gathered[b0:b1], ref)
+        other = (rank + 1) % world  # and one foreign frame: recompute it here
+        fi, fd = make_inputs(torch, 1, bounds[other], device)
+        p1 = engine.make_params(1, H, W, H, W, 3, "polylines_soft", "left-right", 8.0, 0.0, 0.0, 0.5, 2.0, blur, 20.0, 20.0, 2.0, 6, 12)
+        ok = ok and torch.equal(gathered[bounds[other]:bounds[other] + 1], engine.Plan(p1, device).run(fi, fd)[0])
+        print(f"[verify] rank {rank}: {'OK' if ok else 'MISMATCH'}", flush=True)
+        if not ok:
+            raise SystemExit(1)
     if rank == 0:
         fps = a.frames * a.steps / dt
         kern_ms = tot_ms.value / max(launches.value, 1)
-        alg_bytes = nloc * B_ALG_PER_PIXEL * H * W  # per launch of the dominant kernel on this rank
+        frames_per_launch = cg.cf if world > 1 else nloc
+        alg_bytes = frames_per_launch * B_ALG_PER_PIXEL * H * W  # per launch of the dominant kernel on this rank
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -148,7 +187,7 @@ def main():
                 tj = json.load(open(tpath))
                 key = f"polylines_soft_4k_blur{int(blur)}"
                 if key in tj:
-                    traffic = tj[key]["bytes_per_frame"] * nloc
+                    traffic = tj[key]["bytes_per_frame"] * frames_per_launch
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {
@@ -158,8 +197,8 @@ def main():
             "config": {"workload": "4K 3840x2160, polylines_soft, left-right SBS, divergence 8.0, stepped depth, "
                                    f"depth blur {'on' if blur else 'off'} (widget defaults)",
                        "frames_total": a.frames, "frames_per_gpu": nloc, "sharding": "by frame, contiguous blocks",
-                       "collective": "all_gather(stereoscope as uint8 codes) over RCCL + expand to float32 on every rank"
-                                     if world > 1 else "none"},
+                       "collective": f"all_gather(stereoscope as uint8 codes) over RCCL in {n_chunks} chunk(s) overlapped with compute"
+                                     " + expand to float32 on every rank" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_polytile<soft> (+ k_rowwarp<polylines_soft> over the rows it flags)", "kernel_ms": kern_ms, "launches": launches.value,

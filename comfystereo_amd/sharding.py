@@ -64,3 +64,45 @@ def generate_sharded(run_local, image, depth_map, fill, batch_size, group=None, 
     if expand is not None and "stereoscope" in gather:
         out["stereoscope"] = expand(out["stereoscope"])
     return out, bounds
+
+
+class ChunkedGather:
+    """The all-gather of a rank's frame block, cut into `n_chunks` pieces so that it overlaps with the compute of
+    the following pieces (the collective runs on the backend's own stream / thread: `async_op=True`).
+
+    Per step:   for c in range(n_chunks):  g.launch(c, local_chunk_c)      # right after chunk c was produced
+                for c in range(n_chunks):  g.finish(c, sink)               # sink(src_frames, first_frame_index)
+    `finish` waits for chunk c only and hands every rank's piece of it to `sink` together with its position in the
+    reassembled batch (rank r's frames are bounds[r] .. bounds[r+1], chunk c of them starts at bounds[r] + c * cf), so
+    the consumer (bench.py: the uint8 -> float32 expansion) already works while later chunks are still on the wire.
+    Requires equal blocks on all ranks and a block that divides into the chunks; `usable()` says whether that holds
+    (fall back to `all_gather_frames` otherwise)."""
+
+    @staticmethod
+    def usable(n_frames, world, n_chunks):
+        return n_frames % world == 0 and (n_frames // world) % n_chunks == 0 and n_frames >= world * n_chunks
+
+    def __init__(self, n_frames, n_chunks, frame_shape, dtype, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        assert self.usable(n_frames, self.world, n_chunks)
+        self.bounds = shard_bounds(n_frames, self.world)
+        self.n_chunks = n_chunks
+        self.cf = n_frames // self.world // n_chunks  # frames per chunk
+        self.staging = [torch.empty((self.world * self.cf,) + tuple(frame_shape), dtype=dtype, device=device)
+                        for _ in range(n_chunks)]
+        self.works = [None] * n_chunks
+
+    def chunk_range(self, c):
+        """Local frame range of chunk c inside this rank's block."""
+        return c * self.cf, (c + 1) * self.cf
+
+    def launch(self, c, local_chunk):
+        assert local_chunk.shape[0] == self.cf and local_chunk.is_contiguous()
+        self.works[c] = dist.all_gather_into_tensor(self.staging[c], local_chunk, group=self.group, async_op=True)
+
+    def finish(self, c, sink):
+        self.works[c].wait()
+        self.works[c] = None
+        for r in range(self.world):
+            sink(self.staging[c][r * self.cf:(r + 1) * self.cf], self.bounds[r] + c * self.cf)

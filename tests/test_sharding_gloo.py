@@ -84,3 +84,45 @@ def test_two_rank_gather_equals_unsharded(fill, n):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
+
+
+def _chunk_worker(rank, world, port, n, chunks, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shape = (3, 5)
+    full = torch.arange(n * 15, dtype=torch.int32).reshape(n, *shape).to(torch.uint8)  # frame f is recognisable
+    g = sharding.ChunkedGather(n, chunks, shape, torch.uint8, "cpu")
+    b0 = g.bounds[rank]
+    out = torch.zeros((n,) + shape, dtype=torch.float32)
+    for step in range(2):  # the staging buffers are reused step after step
+        out.zero_()
+        for c in range(chunks):
+            lo, hi = g.chunk_range(c)
+            g.launch(c, full[b0 + lo:b0 + hi].contiguous())
+
+        def sink(src, first):
+            out[first:first + src.shape[0]] = src.to(torch.float32)
+
+        for c in range(chunks):
+            g.finish(c, sink)
+        ok = torch.equal(out, full.to(torch.float32))
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,chunks", [(8, 2), (12, 3), (4, 1)])
+def test_chunked_gather_reassembles_in_frame_order(n, chunks):
+    """sharding.ChunkedGather (bench.py's N > 1 step): chunk c of every rank lands at bounds[r] + c * cf."""
+    assert sharding.ChunkedGather.usable(64, 8, 4) and not sharding.ChunkedGather.usable(10, 4, 2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, 2, port, n, chunks, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
