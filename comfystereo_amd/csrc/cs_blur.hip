@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(256) k_blur_copy(BlurArgs A, const unsigned lo
 
 // k_blur_fused: persistent workgroups over the tiles of `worklist` (work_count entries, packed frame | tile row | tile
 // column); worklist == nullptr: plain grid over all tiles (blockIdx = tile).
-__global__ void __launch_bounds__(256) k_blur_fused(BlurArgs A, const unsigned long long* mask_l,
+__global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigned long long* mask_l,
                                                     const unsigned long long* mask_r, int MW, const uint32_t* work_count,
                                                     const uint32_t* worklist) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -552,14 +552,14 @@ __global__ void __launch_bounds__(256) k_blur_fused(BlurArgs A, const unsigned l
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[j] = 0.0f;
         const float* dbase = D + rbase * DC + tx;
-        for (int k0 = 0; k0 < bs; k0 += 8) {
-            float dv[8][8];
+        for (int k0 = 0; k0 < bs; k0 += 4) {  // (4 taps x 8 rows in flight: 8 taps cost a workgroup per CU in registers)
+            float dv[8][4];
 #pragma unroll
             for (int j = 0; j < 8; j++)
 #pragma unroll
-                for (int kk = 0; kk < 8; kk++) dv[j][kk] = (k0 + kk < bs) ? dbase[j * DC + k0 + kk] : 0.0f;
+                for (int kk = 0; kk < 4; kk++) dv[j][kk] = (k0 + kk < bs) ? dbase[j * DC + k0 + kk] : 0.0f;
 #pragma unroll
-            for (int kk = 0; kk < 8; kk++) {
+            for (int kk = 0; kk < 4; kk++) {
                 if (k0 + kk < bs) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) acc[j] = fmaf(kb, dv[j][kk], acc[j]);
