@@ -60,7 +60,7 @@ __device__ __forceinline__ float torch_pow(float x, int mode, float e32, const c
     }
 }
 
-__global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
+__global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id();
     const int y = blockIdx.x, frame = blockIdx.y, w = A.w, h = A.h;
