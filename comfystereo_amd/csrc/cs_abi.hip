@@ -252,9 +252,12 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
 }
 
 static int threads_for(int fill, int w) {
-    (void)fill;
     if (w <= 256) return 256;
     if (w <= 1024) return 512;
+    // wide rows: the row kernels need 110-128 VGPRs, i.e. 16 waves per CU either way -- as two 512-thread workgroups they
+    // overlap each other's barrier phases (measured at 4K: none +7 %, inverse +9 %, naive_interpolating +43 %); naive and
+    // the polylines row kernel prefer the single 1024-thread workgroup (naive: -22 % at 512)
+    if (fill == CS_FILL_NONE || fill == CS_FILL_INVERSE || fill == CS_FILL_NAIVE_INTERPOLATING) return 512;
     return 1024;
 }
 
