@@ -1,5 +1,10 @@
 // cs_blur.hip -- direction-aware depth blur (reference stereoimage_generation.py:1171-1251,
-// `directional_motion_blur_gpu` + `_edge_distance_weight_gpu` :1131-1168), two row kernels.
+// `directional_motion_blur_gpu` + `_edge_distance_weight_gpu` :1131-1168).
+//
+// Default pipeline (further down): k_blur_edges4 (edge masks of the frame as bit rows) -> k_blur_copy (tiles without
+// an edge in reach are a scaled copy; the others go onto a worklist) -> k_blur_fused (persistent workgroups over the
+// worklist: weights from the bit rows, both boxes and the blend from one staged tile).  The two row kernels described
+// next (pass A / pass B) are the general fallback for blur kernels too wide for the fused tile.
 //
 // The parity target is the reference as CPU torch executes it: each conv2d
 // is a raster-order fmaf accumulation from 0 with zero padding, everything else is separate

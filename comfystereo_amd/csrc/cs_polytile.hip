@@ -6,17 +6,24 @@
 // source pixels within S = ceil(|divergence_px| * max(c, 1-c)^e + |separation_px|) + 1 columns
 // (c = convergence point; normalised depth lies in [0,1]).  So the row is cut into tiles of T output
 // pixels; one 256-thread workgroup owns one tile of one eye and only looks at the source columns
-// [o0-S-1, o0+T+S+1): ~20 KB of LDS, 6-8 workgroups per CU, three cheap barriers, no prefix sums:
-//   1. stage the source pixels (f32 -> u8) and coord_d = libm-exact disparity of the halo'ed range
-//   2. REGISTER: every polyline point drops its index into the (fixed-capacity) slot list of the output
-//      pixel it falls in; every forward segment drops its index into the slot lists of the pixels it
-//      overlaps (segments longer than 3 pixels -- disocclusion bridges -- are written by the whole wave,
-//      64 pixels per step, picked with a ballot)
-//   3. EVALUATE: one lane per output pixel sorts its <= KP points by (x, index) in registers (== the
-//      reference's stable insertion sort restricted to the pixel), walks the sub-intervals in order and
-//      picks the active segment with the largest interpolated |disparity| exactly like the reference
-//      (float32/float64 typing of SURVEY.md Appendix A); results are staged in LDS and written as
-//      full float4 rows into the SBS/TB slot together with the mask and this eye's depth-map output.
+// [o0-S-1, o0+T+S+1): 21.6 KB of LDS and 72 VGPRs -> 7 workgroups per CU, five barriers, no prefix sums
+// (DESIGN.md section 5 has the measurements behind each choice):
+//   1. all global loads of the tile first (depth row into registers, image row as float4), LDS set-up in their shadow
+//   2. stage the source pixels (f32 -> u8) and the libm-exact disparity of the halo'ed range -> point x's; the same
+//      loop finds out whether the polyline FOLDS anywhere in the tile (neighbour x by shuffle)
+//   3. REGISTER.  Fold-free tile: all segments are forward and the segments over a pixel are the chain around its
+//      points, so the first point of each pixel writes one 16-bit word (first id | count) -- no atomics.  Tile with
+//      a fold: every polyline point drops its index into the (fixed-capacity) slot list of the output pixel it
+//      falls in, every forward segment into the lists of the pixels it overlaps (returning LDS atomics; segments
+//      longer than 3 pixels -- disocclusion bridges -- are written by the whole wave, 64 pixels per step)
+//   4. EVALUATE pass 1: two pixels per lane; pixels with one point and two segments (~93 %) in straight-line code,
+//      the others go onto a list
+//   5. EVALUATE pass 2: the list packed onto lanes -- chain path (consecutive points, np + 1 segments: sub-interval
+//      k belongs to chain segment k, verified by two compares), else the general search: the <= KP points sorted by
+//      (x, index) in registers (== the reference's stable insertion sort restricted to the pixel), every listed
+//      segment tested per sub-interval, largest interpolated |disparity| wins exactly like the reference
+//      (float32/float64 typing of SURVEY.md Appendix A).  The idle waves write the depth-map output meanwhile.
+//   6. results staged in LDS are written as full float4 rows into the SBS/TB slot together with the mask.
 // Anything the fast path cannot prove order-independent -- exact closeness ties, no qualifying
 // candidate, non-monotone centres, a slot list overflowing -- flags the ROW; flagged rows are redone
 // by the general row kernel (cs_rowwarp.hip, `row_list`), whose results are authoritative.
