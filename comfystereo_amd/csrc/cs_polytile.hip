@@ -909,7 +909,10 @@ hipError_t launch_polytile(int sharp, const RowArgs& R, int S, uint8_t* rowflag,
     }
     // soft default: 4 points / 5 segments per pixel in the lists -> 21.6 KB of LDS at the bench halo, 72 VGPRs: 7 workgroups
     // per CU (LDS is handed out in 2 KB granules; 6 segments would be 128 bytes over).  CS_PT_VARIANT: development.
-    if (sharp) PT_LAUNCH(1, 6, 8, 4)
+    // sharp (two points per source pixel): 5 points / 7 segments per pixel (+16 % over 6 / 8 at the same redo rate on the bench)
+    if (sharp && variant == 1) PT_LAUNCH(1, 6, 8, 4)
+    else if (sharp && variant == 2) PT_LAUNCH(1, 4, 6, 5)
+    else if (sharp) PT_LAUNCH(1, 5, 7, 5)
     else if (variant == 1) PT_LAUNCH(0, 4, 6, 6)
     else if (variant == 2) PT_LAUNCH(0, 3, 4, 7)
     else if (variant == 3) PT_LAUNCH(0, 6, 8, 6)
