@@ -2,12 +2,13 @@
 460-466): same INPUT_TYPES keys / defaults / ranges, RETURN_TYPES, RETURN_NAMES and FUNCTION.
 
 `generate` hands the whole batch to the fused device path (one C-ABI call per chunk) instead of the
-reference's per-frame Python loop; results come back as CPU float32 tensors like the reference's
-(or stay on the device when the inputs already were there).
+reference's per-frame Python loop.  CPU tensors (what ComfyUI passes) go through the pinned-memory staging
+pipeline of host_pipeline.py and come back as CPU float32 tensors like the reference's; device tensors stay on
+the device.
 """
 import torch
 
-from . import engine
+from . import engine, host_pipeline
 
 try:  # ComfyUI's progress bar when running inside ComfyUI (reference GenerateStereo.py:27,110)
     from comfy.utils import ProgressBar
@@ -82,9 +83,14 @@ class StereoImageNode:
         if not torch.cuda.is_available():
             raise RuntimeError("comfystereo_amd needs an MI355X (PyTorch-ROCm `cuda` device); there is no CPU fallback")
         on_device = image.is_cuda
-        dev = image.device if on_device else torch.device("cuda", torch.cuda.current_device())
         total = len(image)
         pbar = ProgressBar(total)
+        if not on_device:  # ComfyUI's case: CPU tensors in and out -> staged through pinned memory, chunks overlapped
+            return host_pipeline.generate_host(image, depth_map, divergence, separation, modes, stereo_balance,
+                                               convergence_point, stereo_offset_exponent, fill, depth_blur_edge_threshold,
+                                               depth_blur_strength, depth_map_blur, depth_blur_falloff,
+                                               depth_blur_vert_smooth, batch_size, progress=pbar.update)
+        dev = image.device
         h, w = image.shape[1], image.shape[2]
         per_frame = 4 * h * w * (3 + depth_map.shape[3] + 6 + 6 + 2 + 5)
         chunk = max(1, min(total, CHUNK_BYTES // max(per_frame, 1)))
@@ -99,7 +105,7 @@ class StereoImageNode:
                                   depth_blur_edge_threshold, depth_blur_strength, depth_map_blur, depth_blur_falloff,
                                   depth_blur_vert_smooth, batch_size)
             for k in range(4):
-                outs[k].append(res[k] if on_device else res[k].cpu())
+                outs[k].append(res[k])
             pbar.update(b1 - b0)
         return tuple(o[0] if len(o) == 1 else torch.cat(o, dim=0) for o in outs)
 

@@ -91,3 +91,31 @@ def test_create_stereoimages_gpu_matches_oracle():
         assert np.abs(r.cpu().numpy() - wv).max() <= 2e-6
     assert mask.dtype == torch.bool and np.array_equal(mask.cpu().numpy(), wm)
     assert np.array_equal(lo.cpu().numpy(), wl) and np.array_equal(ro.cpu().numpy(), wr)  # unclamped, like the reference
+
+
+@pytest.mark.parametrize("fill,n,batch", [("polylines_soft", 7, 12), ("gpu_warp", 10, 4), ("hybrid_edge", 3, 2), ("none", 1, 1)])
+def test_host_pipeline_equals_the_whole_batch(monkeypatch, fill, n, batch):
+    """host_pipeline.generate_host (CPU tensors in/out, chunks staged through pinned memory and overlapped) ==
+    engine.generate on the whole batch at once: chunk boundaries, a shorter last chunk, buffer reuse two chunks later,
+    gpu_warp chunks aligned to the reference's sub-batches."""
+    from comfystereo_amd import engine, host_pipeline
+    from comfystereo_amd.GenerateStereo import FILL_TECHNIQUES, StereoImageNode
+    UI = {v: k for k, v in FILL_TECHNIQUES.items()}
+    NODE = StereoImageNode()
+    h, w = 40, 328
+    img = torch.from_numpy(synth.image_f32(n, h, w, seed=21))
+    dep = torch.from_numpy(synth.depth_batch("blobs", n, h, w, channels=3))
+    args = (6.0, 0.2, "left-right", 0.1, 0.5, 2.0, fill, 20.0, 20.0, True, 2.0, 3, batch)
+    ref = [t.cpu() for t in engine.generate(img.cuda(), dep.cuda(), *args)]
+    per_frame_out = 4 * (h * 2 * w * 3 + 2 * h * w * 3 + h * 2 * w)
+    monkeypatch.setattr(host_pipeline, "CHUNK_OUT_BYTES", 2 * per_frame_out + 1)  # two frames per chunk
+    seen = []
+    for pinned in (True, False):  # results written straight into pinned tensors / staged into pageable ones
+        seen.clear()
+        got = host_pipeline.generate_host(img, dep, *args, progress=seen.append, pinned_outputs=pinned)
+        assert sum(seen) == n
+        for g, r in zip(got, ref):
+            assert not g.is_cuda and g.is_pinned() == pinned and torch.equal(g, r)
+    node_out = NODE.generate(img, dep, 6.0, 0.2, "left-right", 0.1, 0.5, 2.0, UI[fill], 20.0, 20.0, True, 2.0, 3, batch)
+    for g, r in zip(node_out, ref):
+        assert torch.equal(g, r)

@@ -1,0 +1,46 @@
+"""End-to-end timing of StereoImageNode.generate with HOST tensors in and out (how ComfyUI calls the node):
+PCIe-inclusive frames/s.  Development aid; the number is quoted in DESIGN.md, never as bench.py's `value`."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import synth
+from comfystereo_amd.GenerateStereo import StereoImageNode
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=8)
+ap.add_argument("--h", type=int, default=2160)
+ap.add_argument("--w", type=int, default=3840)
+ap.add_argument("--iters", type=int, default=2)
+ap.add_argument("--fill", default="Fill - Polylines Soft")
+a = ap.parse_args()
+img = torch.from_numpy(synth.image_f32(1, a.h, a.w, seed=1)).expand(a.n, -1, -1, -1).contiguous()
+dep = torch.from_numpy(synth.depth_batch("stepped", a.n, a.h, a.w, channels=3))
+node = StereoImageNode()
+args = (8.0, 0.0, "left-right", 0.0, 0.5, 2.0, a.fill, 20.0, 20.0, True, 2.0, 6, 12)
+out = node.generate(img, dep, *args)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.iters):
+    out = node.generate(img, dep, *args)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.iters
+pinned = out[0].is_pinned()
+shapes = [tuple(t.shape) for t in out]
+nbytes = sum(t.numel() * t.element_size() for t in out)
+del out  # results released first: the next call finds their pinned blocks in PyTorch's cache
+t0 = time.perf_counter()
+for _ in range(a.iters):
+    out = node.generate(img, dep, *args)
+    del out
+torch.cuda.synchronize()
+dt_cached = (time.perf_counter() - t0) / a.iters
+gb = nbytes / 1e9 + (img.numel() + dep.numel()) * 4 / 1e9
+print(f"host tensors in/out: {a.n} frames {a.w}x{a.h}: {dt*1e3:.1f} ms -> {a.n/dt:.1f} frames/s, {gb/dt:.1f} GB/s over PCIe+host copies "
+      f"(outputs are {'pinned' if pinned else 'pageable'} CPU tensors, freshly allocated); "
+      f"with the previous results released first: {a.n/dt_cached:.1f} frames/s, {gb/dt_cached:.1f} GB/s")
