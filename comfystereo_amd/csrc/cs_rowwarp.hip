@@ -59,7 +59,8 @@ __host__ __device__ inline size_t lds_tech_bytes(int fill, int w) {
     switch (fill) {
     case CS_FILL_NONE: return align16(4 * (size_t)w);                       // winner
     case CS_FILL_NAIVE: return 3 * align16(4 * (size_t)w);                   // winner, L, R
-    case CS_FILL_NAIVE_INTERPOLATING: return align16(4 * (size_t)w) + align16((size_t)w);
+    case CS_FILL_NAIVE_INTERPOLATING:  // winner, flags, new colours, interval starts
+        return align16(4 * (size_t)w) + align16((size_t)w) + align16(3 * (size_t)w) + align16(2 * (size_t)w);
     case CS_FILL_INVERSE: return align16(8 * (size_t)w);
     case CS_FILL_HYBRID_EDGE:  // splat kernel: dest_x, bin offsets, scratch, sorted ids, exp table
         return align16(4 * (size_t)w) + 3 * align16(2 * ((size_t)w + 4)) + 2048;
@@ -169,8 +170,60 @@ __device__ void technique_forward(const Lds& L, int w, const EyeArgs& E, float e
             flags[c] = (uint8_t)((f ? 1 : 0) | (g ? 2 : 0));
         }
         __syncthreads();
+        // The reference walks a row left to right; inside an interval between two good pixels the FIRST unfilled
+        // pixel l0 triggers one linear ramp over l0 .. g-1 (g = the next good pixel, or w) from the colour left of l0 to
+        // the colour at g, in uint8 wrap arithmetic.  Every later pixel of the interval is then skipped -- unless the
+        // ramp left an unfilled pixel with channel sum 0 (mod 256), which triggers again with the freshly written
+        // left neighbour (quirk).  Parallel form: every non-good pixel finds its interval's l0 and g by a bounded walk
+        // over the immutable flags and computes its own ramp value; intervals that are too long for the walk or hit
+        // the quirk are replayed literally by the sequential code below (bit 3 of the interval start's flag).
+        uint8_t* tmpc = (uint8_t*)(L.tech + align16(4 * (size_t)w) + align16((size_t)w));                      // [3w]
+        uint16_t* istart = (uint16_t*)(L.tech + align16(4 * (size_t)w) + align16((size_t)w) + align16(3 * (size_t)w));  // [w]
+        constexpr int NI_WALK = 160;
+        auto flag_interval = [&](int s0) { atomicOr((unsigned*)flags + (s0 >> 2), 8u << ((s0 & 3) * 8)); };
+        for (int c = tid; c < w; c += nt) {
+            if (flags[c] & 2) continue;
+            // walk left to the last good pixel (or the row start), remembering the leftmost unfilled pixel on the way
+            int lg = c, l0 = -1, steps = 0;
+            while (lg >= 0 && !(flags[lg] & 2) && steps <= NI_WALK) { if (!(flags[lg] & 1)) l0 = lg; lg--; steps++; }
+            const bool left_ok = lg < 0 || (flags[lg] & 2);
+            int g = c + 1;
+            steps = 0;
+            while (g < w && !(flags[g] & 2) && steps <= NI_WALK) { g++; steps++; }
+            const bool right_ok = g >= w || (flags[g] & 2);
+            const int s0 = lg + 1;
+            if (left_ok) istart[c] = (uint16_t)s0;
+            if (!left_ok || !right_ok) {  // too long for the walk: the sequential code does this interval
+                if (left_ok) flag_interval(s0);
+                else istart[c] = 0xffff;   // start unknown: resolved below
+                continue;
+            }
+            if (l0 < 0 || c < l0) continue;  // no unfilled pixel in the interval up to here: untouched
+            uint8_t lb[3] = {0, 0, 0}, rb[3] = {0, 0, 0};
+            if (l0 > 0) { lb[0] = L.res[3 * l0 - 3]; lb[1] = L.res[3 * l0 - 2]; lb[2] = L.res[3 * l0 - 1]; }
+            if (g < w) { rb[0] = L.res[3 * g]; rb[1] = L.res[3 * g + 1]; rb[2] = L.res[3 * g + 2]; }
+            if (sum8(lb) == 0) { lb[0] = rb[0]; lb[1] = rb[1]; lb[2] = rb[2]; }
+            else if (sum8(rb) == 0) { rb[0] = lb[0]; rb[1] = lb[1]; rb[2] = lb[2]; }
+            const float total = (float)(1 + g - l0);
+            const float k = (float)(c - l0 + 1);
+            uint8_t v[3];
+            v[0] = (uint8_t)(lb[0] + csm::f32_to_u8_wrap((((float)rb[0] - (float)lb[0]) / total) * k));
+            v[1] = (uint8_t)(lb[1] + csm::f32_to_u8_wrap((((float)rb[1] - (float)lb[1]) / total) * k));
+            v[2] = (uint8_t)(lb[2] + csm::f32_to_u8_wrap((((float)rb[2] - (float)lb[2]) / total) * k));
+            tmpc[3 * c] = v[0]; tmpc[3 * c + 1] = v[1]; tmpc[3 * c + 2] = v[2];
+            atomicOr((unsigned*)flags + (c >> 2), 4u << ((c & 3) * 8));  // has a new colour (atomic: bit 3 of the same byte may be set concurrently)
+            if (c > l0 && !(flags[c] & 1) && sum8(v) == 0) flag_interval(s0);  // the quirk: re-trigger -> literal replay
+        }
+        __syncthreads();
+        for (int c = tid; c < w; c += nt) {
+            if (!(flags[c] & 4)) continue;
+            if (flags[istart[c]] & 8) continue;  // its interval is replayed below
+            L.res[3 * c] = tmpc[3 * c]; L.res[3 * c + 1] = tmpc[3 * c + 1]; L.res[3 * c + 2] = tmpc[3 * c + 2];
+        }
+        __syncthreads();
         for (int s = tid; s < w; s += nt) {
             if ((flags[s] & 2) || (s > 0 && !(flags[s - 1] & 2))) continue;  // not the start of an interval
+            if (!(flags[s] & 8)) continue;                                      // done in parallel above
             for (int l = s; l < w && !(flags[l] & 2); l++) {
                 if (sum8(&L.res[3 * l]) != 0 || (flags[l] & 1)) continue;
                 uint8_t lb[3] = {0, 0, 0}, rb[3] = {0, 0, 0};
