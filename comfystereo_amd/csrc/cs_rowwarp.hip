@@ -189,7 +189,9 @@ __device__ void technique_forward(const Lds& L, int w, const EyeArgs& E, float e
             const bool left_ok = lg < 0 || (flags[lg] & 2);
             int g = c + 1;
             steps = 0;
-            while (g < w && !(flags[g] & 2) && steps <= NI_WALK) { g++; steps++; }
+            // (one step less than the walk to the left: an interval the start pixel finds short enough on its right is
+            // then short enough for the left walk of every pixel in it -- the start pixel is the one that flags long ones)
+            while (g < w && !(flags[g] & 2) && steps < NI_WALK) { g++; steps++; }
             const bool right_ok = g >= w || (flags[g] & 2);
             const int s0 = lg + 1;
             if (left_ok) istart[c] = (uint16_t)s0;

@@ -127,3 +127,22 @@ def test_flat_and_one_channel_depth(engine):
                 assert np.abs(g.cpu().numpy() - w_).max() <= 2e-6
             else:
                 assert np.array_equal(g.cpu().numpy(), w_), (fill, k)
+
+
+@pytest.mark.parametrize("hole", [100, 159, 160, 161, 162, 163, 164, 200])
+def test_naive_interpolating_hole_lengths_around_the_walk_limit(engine, hole):
+    """naive_interpolating computes the hole ramps in parallel through walks bounded at 160 pixels and replays longer
+    intervals sequentially: holes just below / at / above the bound, ending in filled pixels with channel sum 0 (which
+    the ramp overwrites), both sweep directions."""
+    h, w = 6, 2000
+    rng = np.random.default_rng(hole)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    img[rng.random((h, w)) < 0.3] = [128, 128, 0]
+    depth = np.zeros((h, w), np.float32)
+    depth[:, w // 2:] = 255.0
+    depth[1::2, w // 3: w // 2] = 255.0  # a second geometry on the odd rows
+    for sign in (1.0, -1.0):
+        div = sign * hole * 100.0 / w
+        got = engine.apply_stereo_divergence(cuda(img), cuda(depth), div, 0.0, 1.0, "naive_interpolating", 0.0).cpu().numpy()
+        want = oracle.apply_stereo_divergence(img, depth, div, 0.0, 1.0, "naive_interpolating", 0.0)
+        assert np.array_equal(got, want), (hole, sign, int((got != want).sum()))
