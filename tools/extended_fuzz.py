@@ -18,7 +18,7 @@ from test_gpu_fuzz import FILLS, make_case
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 150.0
 t0 = time.time()
 n_asd = n_node = 0
-seed = 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 while time.time() - t0 < budget * 0.6:
     rng = np.random.default_rng(seed); seed += 1
     img, depth, div, sep, e, conv = make_case(rng)
