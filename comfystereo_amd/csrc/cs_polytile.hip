@@ -800,11 +800,18 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
             const bool act = i < nlist;
             const int q = plist[act ? i : 0];
             uint32_t rgb = 0;
-            const bool ok = eval_chain(act, q, rgb);
-            if (ok) put(q, rgb);
-            if (__any(act && !ok)) {
-                if (mono) hazard = hazard || (act && !ok);  // (not seen) -> row redo
-                else eval_generic(act && !ok, q);
+            bool ok = false;
+            if (mono) {
+                ok = eval_chain(act, q, rgb);
+                if (ok) put(q, rgb);
+                if (__any(act && !ok)) {
+                    if (mono) hazard = hazard || (act && !ok);  // (not seen) -> row redo
+                    else eval_generic(act && !ok, q);
+                }
+            } else {
+                // fold tile: the lists exist, and the general search also does the pixels the chain path could do -- one
+                // pass over the list instead of two dependent ones on the one wave the workgroup is waiting for
+                eval_generic(act, q);
             }
             if (A.dbg == 14 && A.stats_rw) {  // development: how many pixels take which path
                 unsigned long long ma = __ballot(act), mg = __ballot(act && !ok);
