@@ -596,19 +596,11 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
                 }
             }
         }
-        // forward segments overlapping this pixel
-        float sx0[PT_KS], sx1[PT_KS];
+        // forward segments overlapping this pixel: only their ids stay in registers (their end points are re-read from
+        // LDS in the scan: ten registers less, which the allocator otherwise spills to scratch on this waited-for path)
         int so[PT_KS];
 #pragma unroll
-        for (int k = 0; k < PT_KS; k++) { so[k] = 0; sx0[k] = INFINITY; sx1[k] = -INFINITY; }
-#pragma unroll
-        for (int k = 0; k < PT_KS; k++) {
-            if (k < wns && k < nsg) {
-                so[k] = (int)sgs[q * PT_KS + k];
-                sx0[k] = px[so[k]];
-                sx1[k] = px[so[k] + 1];
-            }
-        }
+        for (int k = 0; k < PT_KS; k++) so[k] = (k < wns && k < nsg) ? (int)sgs[q * PT_KS + k] : -1;
         float color0 = 0.5f, color1 = 0.5f, color2 = 0.5f;
         float prev = (float)col, a = -INFINITY;
         for (int k = 0; k <= wnp; k++) {   // wave-uniform trip count; lanes with k > np idle
@@ -636,12 +628,15 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
 #pragma unroll
             for (int e = 0; e < PT_KS; e++) {
                 if (e < wns) {
-                    const bool act = (sx0[e] < center) && !(sx1[e] < center);
+                    const bool have = so[e] >= 0;
+                    const int oe = have ? so[e] : 0;
+                    const float e0 = px[oe], e1 = px[oe + 1];
+                    const bool act = have && (e0 < center) && !(e1 < center);
                     nact += act ? 1 : 0;
                     pick = act ? e : pick;
-                    const float ip_e = (center - sx0[e]) / (sx1[e] - sx0[e]);
+                    const float ip_e = (center - e0) / (e1 - e0);
                     const bool qual = act && 0.0f < ip_e && ip_e < 1.0f;
-                    const float cl = (1.0f - ip_e) * pz[so[e]] + ip_e * pz[so[e] + 1];
+                    const float cl = (1.0f - ip_e) * pz[oe] + ip_e * pz[oe + 1];
                     nqual += qual ? 1 : 0;
                     const bool better = qual && bc < cl;
                     tie = better ? false : (tie || (qual && cl == bc));
@@ -654,11 +649,11 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
             pick = (multi && best >= 0) ? best : pick;
             const bool contrib = work && pick >= 0;
             // colour contribution (reference :1981-1989, D32 typing); idle lanes compute on dummy operands
-            float x0 = 0.0f, x1 = 1.0f;
             int o = 1;
 #pragma unroll
             for (int e = 0; e < PT_KS; e++)
-                if (e < wns) { bool hit = e == pick; x0 = hit ? sx0[e] : x0; x1 = hit ? sx1[e] : x1; o = hit ? so[e] : o; }
+                if (e < wns) o = (e == pick && so[e] >= 0) ? so[e] : o;
+            const float x0 = contrib ? px[o] : 0.0f, x1 = contrib ? px[o + 1] : 1.0f;
             const int jl = min(max(SHARP ? (o - 1) >> 1 : o - 1, 0), ns - 1);
             const int jr = min(max(SHARP ? o >> 1 : o, 0), ns - 1);
             const uint32_t il = img[jl], ir = img[jr];
@@ -835,7 +830,11 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
     // ---- store the tile ------------------------------------------------------------------------------
     if (A.out_u8) {
         uint8_t* dst = A.out_u8 + (rowpix + o0) * 3;
-        for (int i = tid; i < 3 * wt; i += PT_THREADS) dst[i] = res[i];
+        if ((wt & 3) == 0 && (w & 3) == 0)  // (rowpix + o0) * 3 is then a multiple of 4
+            for (int i = tid; i < (3 * wt) / 4; i += PT_THREADS)
+                reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(res)[i];
+        else
+            for (int i = tid; i < 3 * wt; i += PT_THREADS) dst[i] = res[i];
     } else {
         const size_t o = ((size_t)frame * A.out_h + row + E.yoff) * A.out_w + E.xoff + o0;
         float* dst = A.stereo + o * 3;
