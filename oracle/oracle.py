@@ -22,6 +22,9 @@ FILLS = {
     "polylines_sharp": 4,
     "inverse": 5,
     "hybrid_edge": 6,
+    "none_post": 8,
+    "inverse_post": 9,
+    "hybrid_edge_plus": 10,
 }
 
 _lib = None

@@ -34,6 +34,7 @@ enum {
     FILL_POLY_SHARP = 4,
     FILL_INVERSE = 5,
     FILL_HYBRID_EDGE = 6,
+    FILL_NONE_POST = 8, FILL_INVERSE_POST = 9, FILL_HYBRID_EDGE_PLUS = 10, /* UI-unreachable (reference :1605-1610) */
 };
 
 EXPORT float oracle_powf(float x, float y) { return om_powf(x, y); }
@@ -389,6 +390,110 @@ EXPORT void oracle_hybrid_edge(const uint8_t *img, const float *nd, int h, int w
 }
 
 /* -------------------------------------------------------------------------------------------
+ * The UI-unreachable techniques of the dispatcher (reference :1605-1610).
+ *
+ * post_interp: the row-wise np.interp of apply_stereo_divergence_naive_post / _inverse_post (:1804-1833): for every
+ * row with at least one valid pixel and every channel, output = np.interp(arange(w), valid, base[valid]) -- float64
+ * inside numpy (slope = (fp[j+1]-fp[j]) / (xp[j+1]-xp[j]); slope * (x - xp[j]) + fp[j]; the sample itself when
+ * x == xp[j]; the end values outside), stored into a float32 array and truncated by astype(uint8).
+ * ------------------------------------------------------------------------------------------- */
+static void post_interp(uint8_t *img, const uint8_t *mask, int h, int w) {
+    int *valid = (int *)malloc(sizeof(int) * (size_t)w);
+    uint8_t *rowout = (uint8_t *)malloc((size_t)w * 3);
+    for (int row = 0; row < h; row++) {
+        uint8_t *r = &img[(size_t)row * w * 3];
+        int nv = 0;
+        for (int x = 0; x < w; x++) if (mask[(size_t)row * w + x]) valid[nv++] = x;
+        if (nv == 0) continue;
+        for (int ch = 0; ch < 3; ch++) {
+            int j = 0;
+            for (int x = 0; x < w; x++) {
+                double res;
+                if (x < valid[0]) res = (double)r[valid[0] * 3 + ch];
+                else if (x > valid[nv - 1]) res = (double)r[valid[nv - 1] * 3 + ch];
+                else {
+                    while (j + 1 < nv && valid[j + 1] <= x) j++;
+                    if (j == nv - 1 || valid[j] == x) res = (double)r[valid[j] * 3 + ch];
+                    else {
+                        double y0 = (double)r[valid[j] * 3 + ch], y1 = (double)r[valid[j + 1] * 3 + ch];
+                        double slope = (y1 - y0) / ((double)valid[j + 1] - (double)valid[j]);
+                        res = slope * ((double)x - (double)valid[j]) + y0;
+                    }
+                }
+                rowout[x * 3 + ch] = (uint8_t)(float)res; /* float64 -> float32 array -> astype(uint8) */
+            }
+        }
+        memcpy(r, rowout, (size_t)w * 3);
+    }
+    free(valid); free(rowout);
+}
+
+/* apply_stereo_divergence_naive_post (:1804-1817) = naive_mapping_with_mask (:1665-1686: the 'none' forward map and
+ * its filled mask) + post_interp */
+EXPORT void oracle_naive_post(const uint8_t *img, const float *nd, int h, int w, double div_px, double sep_px,
+                              double exponent, uint8_t *out) {
+    float e32 = (float)exponent, div32 = (float)div_px, sep32 = (float)sep_px;
+    uint8_t *filled = (uint8_t *)calloc((size_t)h * w, 1);
+    memset(out, 0, (size_t)h * w * 3);
+    for (int row = 0; row < h; row++) {
+        int asc = div_px < 0;
+        for (int n = 0; n < w; n++) {
+            int col = asc ? n : w - 1 - n;
+            float off = disparity_f32(nd[(size_t)row * w + col], e32, div32) + sep32; /* :1679 */
+            int col_d = col + (int)off;
+            if (0 <= col_d && col_d < w) {
+                memcpy(&out[((size_t)row * w + col_d) * 3], &img[((size_t)row * w + col) * 3], 3);
+                filled[(size_t)row * w + col_d] = 1;
+            }
+        }
+    }
+    post_interp(out, filled, h, w);
+    free(filled);
+}
+
+/* apply_stereo_divergence_inverse_post (:1820-1833) = inverse_mapping_with_mask (:1689-1713) + post_interp */
+EXPORT void oracle_inverse_post(const uint8_t *img, const float *nd, int h, int w, double div_px, double sep_px,
+                                double exponent, uint8_t *out) {
+    float e32 = (float)exponent, div32 = (float)div_px, sep32 = (float)sep_px;
+    float *zb = (float *)malloc(sizeof(float) * w);
+    uint8_t *mask = (uint8_t *)calloc((size_t)h * w, 1);
+    memset(out, 0, (size_t)h * w * 3);
+    for (int row = 0; row < h; row++) {
+        for (int x = 0; x < w; x++) zb[x] = -1.0f;
+        for (int x = 0; x < w; x++) {
+            float d = nd[(size_t)row * w + x];
+            float off = disparity_f32(d, e32, div32);
+            float dest_x = ((float)(x + 0.5) + off) + sep32;
+            long j = (long)floorf(dest_x);
+            for (int t = 0; t < 2; t++) {
+                long jj = j + t;
+                if (0 <= jj && jj < w && d > zb[jj]) {
+                    memcpy(&out[((size_t)row * w + jj) * 3], &img[((size_t)row * w + x) * 3], 3);
+                    zb[jj] = d;
+                    mask[(size_t)row * w + jj] = 1;
+                }
+            }
+        }
+    }
+    post_interp(out, mask, h, w);
+    free(zb); free(mask);
+}
+
+/* apply_stereo_divergence_hybrid_edge_plus (:1778-1802): hybrid_edge, then every pixel that is still black takes the
+ * polylines_soft pixel */
+EXPORT int oracle_hybrid_edge_plus(const uint8_t *img, const float *nd, int h, int w, double div_px, double sep_px,
+                                   double exponent, uint8_t *out) {
+    size_t hw = (size_t)h * w;
+    uint8_t *poly = (uint8_t *)malloc(hw * 3);
+    oracle_hybrid_edge(img, nd, h, w, div_px, sep_px, exponent, out, NULL);
+    int rc = oracle_polylines(img, nd, h, w, div_px, sep_px, exponent, 0, poly);
+    for (size_t i = 0; i < hw; i++)
+        if (out[3 * i] == 0 && out[3 * i + 1] == 0 && out[3 * i + 2] == 0) memcpy(&out[3 * i], &poly[3 * i], 3);
+    free(poly);
+    return rc;
+}
+
+/* -------------------------------------------------------------------------------------------
  * apply_stereo_divergence (reference :1576-1620): per-image min/max normalisation, convergence
  * shift, percent -> pixels, dispatch.  depth: [h][w] float32.  Returns 0 / -1 (csg overflow) /
  * -2 (unknown fill: the reference returns the image unchanged -- mirrored here).
@@ -423,6 +528,12 @@ EXPORT int oracle_apply_stereo_divergence(const uint8_t *img, const float *depth
         oracle_inverse(img, nd, h, w, div_px, sep_px, exponent, out); break;
     case FILL_HYBRID_EDGE:
         oracle_hybrid_edge(img, nd, h, w, div_px, sep_px, exponent, out, NULL); break;
+    case FILL_NONE_POST:
+        oracle_naive_post(img, nd, h, w, div_px, sep_px, exponent, out); break;
+    case FILL_INVERSE_POST:
+        oracle_inverse_post(img, nd, h, w, div_px, sep_px, exponent, out); break;
+    case FILL_HYBRID_EDGE_PLUS:
+        rc = oracle_hybrid_edge_plus(img, nd, h, w, div_px, sep_px, exponent, out); break;
     default:
         memcpy(out, img, hw * 3); rc = -2; break;
     }

@@ -37,6 +37,12 @@ def golden_asd():
 
 
 @pytest.fixture(scope="session")
+def golden_hidden():
+    """The UI-unreachable techniques (none_post, inverse_post, hybrid_edge_plus) on the inputs of golden_asd."""
+    return Golden("apply_stereo_divergence_hidden.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_blur():
     return Golden("blur.npz")
 

@@ -40,6 +40,25 @@ def test_apply_stereo_divergence_digests(golden_asd):
             assert sha(got) == want, (d["kind"], fill)
 
 
+def test_hidden_techniques_bit_exact(golden_asd, golden_hidden):
+    """none_post / inverse_post / hybrid_edge_plus (reference dispatcher :1605-1610) against the captured outputs."""
+    g, n = golden_hidden, 0
+    for case in g.meta["cases"]:
+        cid = case["id"]
+        for fill in g.meta["fills"]:
+            got = oracle.apply_stereo_divergence(golden_asd[f"{cid}/img"], golden_asd[f"{cid}/depth"], case["divergence"],
+                                                 case["separation"], case["exponent"], fill, case["convergence"])
+            assert np.array_equal(got, g[f"{cid}/out/{fill}"]), (cid, fill)
+            n += 1
+    assert n == len(g.meta["cases"]) * 3
+    for d in g.meta["digests"]:
+        img = synth.image_u8(d["h"], d["w"], seed=d["img_seed"])
+        depth = synth.DEPTHS[d["kind"]](d["h"], d["w"]) * np.float32(255.0)
+        for fill, want in d["out"].items():
+            assert sha(oracle.apply_stereo_divergence(img, depth, d["divergence"], d["separation"], d["exponent"], fill,
+                                                      d["convergence"])) == want, (d["kind"], fill)
+
+
 def test_blur_bit_exact(golden_blur):
     g = golden_blur
     for case in g.meta["cases"]:

@@ -83,6 +83,35 @@ def gen_apply_stereo_divergence(sig):
     print("apply_stereo_divergence:", len(cases), "cases x", len(FILLS), "fills +", len(digests), "digest cases")
 
 
+HIDDEN_FILLS = ["none_post", "inverse_post", "hybrid_edge_plus"]  # dispatcher branches no UI string reaches (:1605-1610)
+
+
+def gen_hidden(sig):
+    """The UI-unreachable techniques on the inputs of apply_stereo_divergence.npz (outputs only) + digests."""
+    base = np.load(os.path.join(OUT, "apply_stereo_divergence.npz"))
+    meta = json.loads(str(base["meta"]))
+    arrays = {}
+    for case in meta["cases"]:
+        cid = case["id"]
+        for fill in HIDDEN_FILLS:
+            arrays[f"{cid}/out/{fill}"] = sig.apply_stereo_divergence(base[f"{cid}/img"], base[f"{cid}/depth"], case["divergence"],
+                                                                      case["separation"], case["exponent"], fill, case["convergence"])
+    digests = []
+    for d in meta["digests"]:
+        img = synth.image_u8(d["h"], d["w"], seed=d["img_seed"])
+        depth = synth.DEPTHS[d["kind"]](d["h"], d["w"]) * np.float32(255.0)
+        assert sha(img) == d["img_sha"] and sha(depth) == d["depth_sha"]
+        e = dict(d, out={})
+        for fill in HIDDEN_FILLS:
+            e["out"][fill] = sha(sig.apply_stereo_divergence(img, depth, d["divergence"], d["separation"], d["exponent"], fill,
+                                                             d["convergence"]))
+        digests.append(e)
+    np.savez_compressed(os.path.join(OUT, "apply_stereo_divergence_hidden.npz"),
+                        meta=json.dumps(dict(cases=meta["cases"], fills=HIDDEN_FILLS, digests=digests,
+                                             inputs="apply_stereo_divergence.npz")), **arrays)
+    print("hidden techniques:", len(meta["cases"]), "cases x", len(HIDDEN_FILLS), "fills +", len(digests), "digest cases")
+
+
 def gen_blur(sig):
     """Fixture for directional_motion_blur_gpu (reference :1171-1251) on CPU torch."""
     arrays, cases = {}, []
@@ -225,7 +254,11 @@ def main():
                     glibc=platform.libc_ver()[1], machine=platform.machine(),
                     reference="Dobidop/ComfyStereo v2.1.3 @ /root/reference (read-only)",
                     generator="tools/make_goldens.py")
+    if "--only-hidden" in sys.argv:  # (added after the first fixtures were committed: leaves them untouched)
+        gen_hidden(sig)
+        return
     gen_apply_stereo_divergence(sig)
+    gen_hidden(sig)
     gen_blur(sig)
     gen_forward_warp(sig)
     gen_node(gs)
