@@ -15,6 +15,8 @@ CS_OK, CS_EINVAL, CS_EWORKSPACE, CS_ELIMIT, CS_EHIP = 0, -1, -2, -3, -4
 FILL = {
     "none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3, "polylines_sharp": 4, "inverse": 5,
     "hybrid_edge": 6, "gpu_warp": 7,
+    # branches of the reference dispatcher no UI string reaches (stereoimage_generation.py:1605-1610)
+    "none_post": 8, "inverse_post": 9, "hybrid_edge_plus": 10,
 }
 MODE = {
     "left-right": 0, "right-left": 1, "top-bottom": 2, "bottom-top": 3, "red-cyan-anaglyph": 4, "left-only": 5,

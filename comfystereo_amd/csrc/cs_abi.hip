@@ -257,7 +257,9 @@ static int threads_for(int fill, int w) {
     // wide rows: the row kernels need 110-128 VGPRs, i.e. 16 waves per CU either way -- as two 512-thread workgroups they
     // overlap each other's barrier phases (measured at 4K: none +7 %, inverse +9 %, naive_interpolating +43 %); naive and
     // the polylines row kernel prefer the single 1024-thread workgroup (naive: -22 % at 512)
-    if (fill == CS_FILL_NONE || fill == CS_FILL_INVERSE || fill == CS_FILL_NAIVE_INTERPOLATING) return 512;
+    if (fill == CS_FILL_NONE || fill == CS_FILL_INVERSE || fill == CS_FILL_NAIVE_INTERPOLATING || fill == CS_FILL_NONE_POST ||
+        fill == CS_FILL_INVERSE_POST)
+        return 512;
     return 1024;
 }
 
@@ -273,6 +275,7 @@ const char* cs_last_error(void) { return g_err; }
 int cs_max_width(int fill) {
     if (fill == CS_FILL_GPU_WARP) return gpuwarp_max_width();
     if (fill == CS_FILL_HYBRID_EDGE) return hybrid_max_width();
+    if (fill < 0 || fill > CS_FILL_HYBRID_EDGE_PLUS) return 0;
     int lo = 0, hi = 1 << 16;
     while (lo < hi) {
         int mid = (lo + hi + 1) / 2;
@@ -319,7 +322,7 @@ static WsLayout ws_layout(const cs_params* p) {
     W.wl = o; if (blur) o += al256(n * hw * 4);
     W.wr = o; if (blur) o += al256(n * hw * 4);
     W.extra = o;
-    if (p->fill == CS_FILL_HYBRID_EDGE) o += al256(hybrid_workspace_bytes(p->n, p->h, p->w));
+    if (p->fill == CS_FILL_HYBRID_EDGE || p->fill == CS_FILL_HYBRID_EDGE_PLUS) o += al256(hybrid_workspace_bytes(p->n, p->h, p->w));
     if (p->fill == CS_FILL_GPU_WARP) o += al256(gpuwarp_workspace_bytes(p->n, p->h, p->w));
     W.total = o;
     return W;
@@ -333,7 +336,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     if (!p || !image || !depth || !stereo || !depth_l || !depth_r || !mask || !workspace) return fail(CS_EINVAL, "null pointer");
     if (p->n <= 0 || p->h <= 0 || p->w <= 0 || p->depth_h <= 0 || p->depth_w <= 0 || p->depth_c <= 0)
         return fail(CS_EINVAL, "non-positive size");
-    if (p->fill < 0 || p->fill > CS_FILL_GPU_WARP) return fail(CS_EINVAL, "unknown fill technique");
+    if (p->fill < 0 || p->fill > CS_FILL_HYBRID_EDGE_PLUS) return fail(CS_EINVAL, "unknown fill technique");
     int out_h, out_w, mask_h, mask_w;
     int rc = cs_output_shape(p, &out_h, &out_w, &mask_h, &mask_w);
     if (rc) return rc;
@@ -415,8 +418,8 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     case CS_MODE_LEFT_ONLY: A.single = 0; break;
     case CS_MODE_ONLY_RIGHT: A.single = 1; break;
     }
-    if (p->fill == CS_FILL_HYBRID_EDGE) {
-        rc = launch_hybrid(A, ws + W.extra, stream);
+    if (p->fill == CS_FILL_HYBRID_EDGE || p->fill == CS_FILL_HYBRID_EDGE_PLUS) {
+        rc = launch_hybrid(A, ws + W.extra, stream, p->fill == CS_FILL_HYBRID_EDGE_PLUS);
         if (rc) return fail(rc, "hybrid_edge launch failed");
     } else {
         int halo = poly_halo(left_div, right_div, p->separation, p->stereo_offset_exponent, p->convergence_point, w);
@@ -437,7 +440,7 @@ int cs_apply_stereo_divergence(const uint8_t* image_u8, const float* depth, int 
     hipStream_t stream = (hipStream_t)stream_;
     if (!image_u8 || !depth || !out_u8 || !workspace) return fail(CS_EINVAL, "null pointer");
     if (n <= 0 || h <= 0 || w <= 0) return fail(CS_EINVAL, "non-positive size");
-    if (fill < 0 || fill > CS_FILL_HYBRID_EDGE) return fail(CS_EINVAL, "unknown fill technique");
+    if (fill < 0 || fill > CS_FILL_HYBRID_EDGE_PLUS || fill == CS_FILL_GPU_WARP) return fail(CS_EINVAL, "unknown fill technique");
     if (w > cs_max_width(fill)) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
     if (workspace_bytes < cs_asd_workspace_bytes(n, h, w)) return fail(CS_EWORKSPACE, "workspace too small");
     uint32_t* stats = (uint32_t*)workspace;
@@ -457,8 +460,9 @@ int cs_apply_stereo_divergence(const uint8_t* image_u8, const float* depth, int 
     A.out_u8 = out_u8;
     A.single = -1;
     { const char* dbg = getenv("CS_DBG"); A.dbg = dbg ? atoi(dbg) : 0; }
-    if (fill == CS_FILL_HYBRID_EDGE) {
-        int rc = launch_hybrid(A, (char*)workspace + al256((size_t)n * ST_WORDS * 4) + rowflag_bytes((size_t)n * h), stream);
+    if (fill == CS_FILL_HYBRID_EDGE || fill == CS_FILL_HYBRID_EDGE_PLUS) {
+        int rc = launch_hybrid(A, (char*)workspace + al256((size_t)n * ST_WORDS * 4) + rowflag_bytes((size_t)n * h), stream,
+                               fill == CS_FILL_HYBRID_EDGE_PLUS);
         if (rc) return fail(rc, "hybrid_edge launch failed");
     } else {
         int halo = poly_halo(divergence, divergence, separation, exponent, convergence, w);

@@ -69,7 +69,7 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
 // cs_hybrid.hip
 size_t hybrid_workspace_bytes(int n, int h, int w);
 int hybrid_max_width();
-int launch_hybrid(const RowArgs& A, void* workspace, hipStream_t stream);
+int launch_hybrid(const RowArgs& A, void* workspace, hipStream_t stream, int plus = 0);  // plus: hybrid_edge_plus
 
 // cs_gpuwarp.hip
 size_t gpuwarp_workspace_bytes(int n, int h, int w);

@@ -62,8 +62,14 @@ __host__ __device__ inline size_t lds_tech_bytes(int fill, int w) {
     case CS_FILL_NAIVE_INTERPOLATING:  // winner, flags, new colours, interval starts
         return align16(4 * (size_t)w) + align16((size_t)w) + align16(3 * (size_t)w) + align16(2 * (size_t)w);
     case CS_FILL_INVERSE: return align16(8 * (size_t)w);
+    case CS_FILL_NONE_POST: return 3 * align16(4 * (size_t)w);                       // winner, L, R
+    case CS_FILL_INVERSE_POST: return align16(8 * (size_t)w) + 2 * align16(4 * (size_t)w);  // keys, L, R
     case CS_FILL_HYBRID_EDGE:  // splat kernel: dest_x, bin offsets, scratch, sorted ids, exp table
         return align16(4 * (size_t)w) + 3 * align16(2 * ((size_t)w + 4)) + 2048;
+    case CS_FILL_HYBRID_EDGE_PLUS: {  // the hybrid fill pass, then the polylines row technique (same region), + its pixels
+        size_t a = lds_tech_bytes(CS_FILL_HYBRID_EDGE, w), b = lds_tech_bytes(CS_FILL_POLYLINES_SOFT, w);
+        return (a > b ? a : b) + align16(3 * (size_t)w);
+    }
     case CS_FILL_POLYLINES_SOFT:
     case CS_FILL_POLYLINES_SHARP: {
         int sharp = fill == CS_FILL_POLYLINES_SHARP;
@@ -254,6 +260,44 @@ __device__ void technique_forward(const Lds& L, int w, const EyeArgs& E, float e
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// none_post / inverse_post (reference :1804-1833): after the mapping, every row that has a valid pixel is
+// np.interp'ed channel by channel over its valid pixels: float64 inside numpy -- slope = (y1 - y0) / (x1 - x0),
+// slope * (x - x0) + y0, the sample itself on a valid pixel, the end values outside -- then stored into a float32
+// array and truncated by astype(uint8).  Nearest valid pixel to the left / right = prefix-max / suffix-min scans.
+// ---------------------------------------------------------------------------------------------
+template <class Valid>
+__device__ void technique_post_interp(const Lds& L, int w, int* Lf, int* Rf, const Valid& valid) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int BIG = 1 << 29;
+    for (int c = tid; c < w; c += nt) {
+        const bool f = valid(c);
+        Lf[c] = f ? c : -BIG;
+        Rf[c] = f ? c : BIG;
+    }
+    __syncthreads();
+    block_scan_inclusive(Lf, w, -BIG, OpMax(), L.misc + 8);
+    block_scan_inclusive(Rf, w, BIG, OpMin(), L.misc + 8, true);
+    for (int c = tid; c < w; c += nt) {
+        const int l = Lf[c], r = Rf[c];
+        if (l == c || (l < 0 && r >= BIG)) continue;  // valid pixel keeps its value; a row without valid pixels stays black
+        // (sources are valid pixels, which this loop never modifies)
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            double res;
+            if (l < 0) res = (double)L.res[3 * r + ch];
+            else if (r >= BIG) res = (double)L.res[3 * l + ch];
+            else {
+                const double y0 = (double)L.res[3 * l + ch], y1 = (double)L.res[3 * r + ch];
+                const double slope = (y1 - y0) / ((double)r - (double)l);
+                res = slope * ((double)c - (double)l) + y0;
+            }
+            L.res[3 * c + ch] = (uint8_t)(int)(float)res;
+        }
+    }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -851,7 +895,7 @@ __device__ void rowwarp_row(const RowArgs& A, const int row, const int frame, ch
             const float* drow = E.depth + rowpix;
             const bool flat = dmax == dmin;
             const float range = dmax - dmin;
-            if (FILL != CS_FILL_HYBRID_EDGE) {
+            if (FILL != CS_FILL_HYBRID_EDGE && FILL != CS_FILL_HYBRID_EDGE_PLUS) {
                 for (int c = tid; c < w; c += nt) {
                     float d = drow[c] * scale;
                     L.nd[c] = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
@@ -860,10 +904,42 @@ __device__ void rowwarp_row(const RowArgs& A, const int row, const int frame, ch
             }
             if (FILL == CS_FILL_NONE || FILL == CS_FILL_NAIVE || FILL == CS_FILL_NAIVE_INTERPOLATING)
                 technique_forward<FILL>(L, w, E, A.e32);
-            else if (FILL == CS_FILL_INVERSE) technique_inverse(L, w, E, A.e32);
+            else if (FILL == CS_FILL_NONE_POST) {
+                technique_forward<CS_FILL_NONE>(L, w, E, A.e32);
+                const int* winner = (const int*)L.tech;
+                const int init = E.asc ? -1 : 0x7fffffff;
+                technique_post_interp(L, w, (int*)(L.tech + align16(4 * (size_t)w)), (int*)(L.tech + 2 * align16(4 * (size_t)w)),
+                                      [=](int c) { return winner[c] != init; });
+            } else if (FILL == CS_FILL_INVERSE_POST) {
+                technique_inverse(L, w, E, A.e32);
+                const unsigned long long* key = (const unsigned long long*)L.tech;
+                const unsigned long long init = ((unsigned long long)csm::f2ord(-1.0f) << 32) | 0xffffffffull;
+                technique_post_interp(L, w, (int*)(L.tech + align16(8 * (size_t)w)),
+                                      (int*)(L.tech + align16(8 * (size_t)w) + align16(4 * (size_t)w)),
+                                      [=](int c) { return key[c] > init; });
+            } else if (FILL == CS_FILL_INVERSE) technique_inverse(L, w, E, A.e32);
             else if (FILL == CS_FILL_POLYLINES_SOFT) technique_polylines<0>(L, w, E, A.e32, st_rw, out, A.dbg);
             else if (FILL == CS_FILL_POLYLINES_SHARP) technique_polylines<1>(L, w, E, A.e32, st_rw, out, A.dbg);
             else if (FILL == CS_FILL_HYBRID_EDGE) technique_hybrid_fill(L, A, frame, row, e);
+            else if (FILL == CS_FILL_HYBRID_EDGE_PLUS) {
+                // hybrid_edge into `res`, then the polylines_soft row into `alt`; pixels that stayed black take the latter
+                technique_hybrid_fill(L, A, frame, row, e);
+                size_t ta = lds_tech_bytes(CS_FILL_HYBRID_EDGE, w), tb = lds_tech_bytes(CS_FILL_POLYLINES_SOFT, w);
+                uint8_t* alt = (uint8_t*)(L.tech + (ta > tb ? ta : tb));
+                for (int c = tid; c < w; c += nt) {
+                    float d = drow[c] * scale;
+                    L.nd[c] = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
+                }
+                __syncthreads();
+                auto into_alt = [=](int c, uint8_t r, uint8_t g, uint8_t b) { alt[3 * c] = r; alt[3 * c + 1] = g; alt[3 * c + 2] = b; };
+                technique_polylines<0>(L, w, E, A.e32, st_rw, into_alt, A.dbg);
+                __syncthreads();
+                for (int c = tid; c < w; c += nt)
+                    if (L.res[3 * c] == 0 && L.res[3 * c + 1] == 0 && L.res[3 * c + 2] == 0) {
+                        L.res[3 * c] = alt[3 * c]; L.res[3 * c + 1] = alt[3 * c + 1]; L.res[3 * c + 2] = alt[3 * c + 2];
+                    }
+                __syncthreads();
+            }
         } else if (DIRECT) {
             for (int c = tid; c < w; c += nt) out(c, L.img[3 * c], L.img[3 * c + 1], L.img[3 * c + 2]);
         } else {
@@ -977,6 +1053,9 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
         CS_LAUNCH(CS_FILL_POLYLINES_SHARP)
         CS_LAUNCH(CS_FILL_INVERSE)
         CS_LAUNCH(CS_FILL_HYBRID_EDGE)
+        CS_LAUNCH(CS_FILL_NONE_POST)
+        CS_LAUNCH(CS_FILL_INVERSE_POST)
+        CS_LAUNCH(CS_FILL_HYBRID_EDGE_PLUS)
     default: return hipErrorInvalidValue;
     }
 #undef CS_LAUNCH
@@ -994,7 +1073,7 @@ int hybrid_max_width() {
     }
     return lo;
 }
-int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream) {
+int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int plus) {
     RowArgs A = A0;
     A.hyb_base = (uint8_t*)workspace;
     A.hyb_mask = A.hyb_base + (size_t)A.n * A.neyes * A.h * A.w * 3;
@@ -1004,7 +1083,7 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute((const void*)k_hybrid_splat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return CS_EHIP;
     hipLaunchKernelGGL(k_hybrid_splat, dim3(A.h, A.n, A.neyes), dim3(threads), lds, stream, A);
-    e = launch_rowwarp(CS_FILL_HYBRID_EDGE, A, threads2, stream);
+    e = launch_rowwarp(plus ? CS_FILL_HYBRID_EDGE_PLUS : CS_FILL_HYBRID_EDGE, A, plus ? threads : threads2, stream);
     return e == hipSuccess ? CS_OK : CS_EHIP;
 }
 

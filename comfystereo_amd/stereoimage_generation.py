@@ -15,8 +15,8 @@ from PIL import Image
 
 from . import engine
 
-_CPU_FILLS = ('none', 'naive', 'naive_interpolating', 'polylines_soft', 'polylines_sharp', 'inverse', 'hybrid_edge')
-_UNPORTED = ('none_post', 'inverse_post', 'hybrid_edge_plus')  # UI-unreachable in the reference
+_CPU_FILLS = ('none', 'naive', 'naive_interpolating', 'polylines_soft', 'polylines_sharp', 'inverse', 'hybrid_edge',
+              'none_post', 'inverse_post', 'hybrid_edge_plus')  # the last three: no UI string reaches them (:1605-1610)
 _MODES = ('left-right', 'right-left', 'top-bottom', 'bottom-top', 'red-cyan-anaglyph', 'left-only', 'only-right',
           'cyan-red-reverseanaglyph')
 
@@ -51,8 +51,6 @@ def create_stereoimages(original_image, depthmap, divergence, separation=0.0, mo
     if not (isinstance(depthmap, torch.Tensor) and isinstance(original_image, torch.Tensor)):
         raise NotImplementedError("numpy/PIL inputs take the reference's scipy blur path (reflect borders), which "
                                   "the node never uses; pass torch tensors")
-    if fill_technique in _UNPORTED:
-        raise NotImplementedError(f"fill_technique '{fill_technique}' is UI-unreachable in the reference and not ported yet")
     for m in modes:
         if m not in _MODES:
             raise Exception('Unknown mode')
@@ -124,8 +122,6 @@ def apply_stereo_divergence(original_image, depth, divergence, separation, stere
     img = torch.as_tensor(np.asarray(original_image) if not isinstance(original_image, torch.Tensor) else original_image)
     dep = torch.as_tensor(np.asarray(depth) if not isinstance(depth, torch.Tensor) else depth)
     assert tuple(img.shape[:2]) == tuple(dep.shape), 'Depthmap and the image must have the same size'
-    if fill_technique in _UNPORTED:
-        raise NotImplementedError(f"fill_technique '{fill_technique}' is not ported yet")
     if fill_technique not in _CPU_FILLS:
         return img.cpu().numpy()  # reference fallback (:1620)
     out = engine.apply_stereo_divergence(img.to(dev, torch.uint8), dep.to(dev, torch.float32), divergence, separation,

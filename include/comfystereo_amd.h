@@ -52,7 +52,11 @@ enum cs_fill {
     CS_FILL_POLYLINES_SHARP = 4,     /* 'polylines_sharp'      :1912-1992 */
     CS_FILL_INVERSE = 5,             /* 'inverse'              :1715-1737 */
     CS_FILL_HYBRID_EDGE = 6,         /* 'hybrid_edge'          :1837-1848 */
-    CS_FILL_GPU_WARP = 7             /* 'gpu_warp'             forward_warp_gpu :277-450 */
+    CS_FILL_GPU_WARP = 7,            /* 'gpu_warp'             forward_warp_gpu :277-450 */
+    /* branches of the dispatcher that no UI string reaches (reference :1605-1610); not valid for gpu paths */
+    CS_FILL_NONE_POST = 8,           /* 'none_post'            :1804-1817 (forward map + row-wise np.interp) */
+    CS_FILL_INVERSE_POST = 9,        /* 'inverse_post'         :1820-1833 */
+    CS_FILL_HYBRID_EDGE_PLUS = 10    /* 'hybrid_edge_plus'     :1778-1802 (hybrid_edge, black pixels from polylines_soft) */
 };
 
 /* output modes of reference stereoimage_generation.py:1543-1562 / :1093-1120 */

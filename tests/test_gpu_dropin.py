@@ -46,7 +46,8 @@ def test_unknown_fill_string_falls_back_to_gpu_warp():
     assert all(torch.equal(x, y) for x, y in zip(a, b)) and a[3].shape == (1, 32, 64)
 
 
-@pytest.mark.parametrize("fill", ["polylines_soft", "naive_interpolating", "hybrid_edge", "no-such-technique"])
+@pytest.mark.parametrize("fill", ["polylines_soft", "naive_interpolating", "hybrid_edge", "no-such-technique", "none_post",
+                                  "inverse_post", "hybrid_edge_plus"])
 def test_create_stereoimages_returns_pil_like_the_reference(fill):
     from comfystereo_amd import stereoimage_generation as sig
     h, w = 40, 96

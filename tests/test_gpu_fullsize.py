@@ -84,11 +84,11 @@ def test_4k_tiny_divergence_passes_the_image_through(engine):
 
 @pytest.mark.parametrize("shape", [(1, 7), (3, 2), (5, 33), (17, 130), (9, 515), (4, 1030), (2, 3841)])
 @pytest.mark.parametrize("fill", ["none", "naive", "naive_interpolating", "polylines_soft", "polylines_sharp", "inverse",
-                                  "hybrid_edge"])
+                                  "hybrid_edge", "none_post", "inverse_post", "hybrid_edge_plus"])
 def test_ragged_shapes_vs_oracle(engine, shape, fill):
     """Widths that are not multiples of 4 / 64 / the tile, single rows, 4K+1: every technique, both signs."""
     h, w = shape
-    if w > 3000 and fill in ("polylines_soft", "polylines_sharp", "hybrid_edge"):
+    if w > 3000 and fill in ("polylines_soft", "polylines_sharp", "hybrid_edge", "hybrid_edge_plus"):
         h = 1
     img = synth.image_u8(h, w, seed=h * 1000 + w, hazards=True)
     depth = synth.noisy_ramp(h, w, seed=w, amp=0.02) * np.float32(255)

@@ -8,7 +8,8 @@ import torch
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
-FILLS = ["none", "naive", "naive_interpolating", "polylines_soft", "polylines_sharp", "inverse", "hybrid_edge"]
+FILLS = ["none", "naive", "naive_interpolating", "polylines_soft", "polylines_sharp", "inverse", "hybrid_edge", "none_post",
+         "inverse_post", "hybrid_edge_plus"]
 
 
 @pytest.fixture(scope="module")

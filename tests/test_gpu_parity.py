@@ -10,6 +10,7 @@ from oracle import node_oracle, oracle
 pytestmark = pytest.mark.gpu
 
 CPU_FILLS = ["none", "naive", "naive_interpolating", "polylines_soft", "polylines_sharp", "inverse", "hybrid_edge"]
+HIDDEN_FILLS = ["none_post", "inverse_post", "hybrid_edge_plus"]  # dispatcher branches no UI string reaches (:1605-1610)
 GPU_WARP_COLOUR_TOL = 1e-4
 
 
@@ -74,14 +75,24 @@ def test_apply_stereo_divergence_goldens(engine, golden_asd, fill):
         assert np.array_equal(got.cpu().numpy(), g[f"{cid}/out/{fill}"]), (cid, fill)
 
 
-@pytest.mark.parametrize("fill", CPU_FILLS)
+@pytest.mark.parametrize("fill", HIDDEN_FILLS)
+def test_hidden_techniques_goldens(engine, golden_asd, golden_hidden, fill):
+    """none_post / inverse_post / hybrid_edge_plus: bit-exact against the outputs captured from the reference."""
+    for case in golden_hidden.meta["cases"]:
+        cid = case["id"]
+        got = engine.apply_stereo_divergence(cuda(golden_asd[f"{cid}/img"]), cuda(golden_asd[f"{cid}/depth"]), case["divergence"],
+                                             case["separation"], case["exponent"], fill, case["convergence"])
+        assert np.array_equal(got.cpu().numpy(), golden_hidden[f"{cid}/out/{fill}"]), (cid, fill)
+
+
+@pytest.mark.parametrize("fill", CPU_FILLS + HIDDEN_FILLS)
 @pytest.mark.parametrize("kind", ["blobs", "stepped", "noisy_ramp", "radial", "random8"])
 def test_apply_stereo_divergence_vs_oracle(engine, fill, kind):
     """Seeded inputs at sizes the oracle finishes in seconds, batch of frames, both signs, exponents, separation."""
     h, w, n = 40, 640, 3
     params = [(6.0, 0.0, 2.0, 0.5), (-6.0, 0.4, 1.3, 0.4), (3.0, -0.8, 0.5, 0.0), (-9.0, 0.0, 1.0, 1.0)]
     for pi, (div, sep, e, conv) in enumerate(params):
-        if kind == "random8" and fill.startswith("poly"):
+        if kind == "random8" and (fill.startswith("poly") or fill == "hybrid_edge_plus"):
             div = 1.2 if div > 0 else -1.2
         img = np.stack([synth.image_u8(h, w, seed=10 * pi + j) for j in range(n)])
         depth = np.stack([synth.DEPTHS[kind](h, w, **({"cx": w / 2 + 31 * j} if kind in ("radial", "stepped") else {"seed": j}))
