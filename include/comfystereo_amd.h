@@ -43,7 +43,8 @@ enum cs_status {
     CS_EHIP = -4       /* a HIP runtime call failed */
 };
 
-/* fill_technique keys of reference GenerateStereo.py:88-100 (the UI-reachable ones) */
+/* fill_technique keys: 0..7 are the UI-reachable ones of reference GenerateStereo.py:88-100; 8..10 are the remaining
+ * branches of the dispatcher stereoimage_generation.py:1605-1610, reachable through its module functions only */
 enum cs_fill {
     CS_FILL_NONE = 0,                /* 'none'                 stereoimage_generation.py:1850-1910 */
     CS_FILL_NAIVE = 1,               /* 'naive'                :1893-1908 */
