@@ -74,3 +74,8 @@ def test_fails_loudly_without_a_gpu():
         gs.StereoImageNode().generate(img, dep, 4.5, 0, "left-right", 0, 0.5, 2, "Fill - Polylines Soft", 20, 20, True)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         sig.create_stereoimages(img[0].permute(2, 0, 1), dep[0, :, :, 0], 5.0)
+    from comfystereo_amd import host_pipeline
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        host_pipeline.generate_host(img, dep, 4.5, 0, "left-right", 0, 0.5, 2, "polylines_soft", 20, 20, True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):  # the techniques no UI string reaches included
+        sig.apply_stereo_divergence(torch.zeros(4, 4, 3, dtype=torch.uint8), dep[0, :, :, 0], 5.0, 0.0, 2.0, "none_post")
