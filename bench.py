@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- the headline metric of BASELINE.json on MI355X.
+"""bench.py -- the headline metric of BASELINE.json on MI355X (and, with --config, its other configurations).
 
   metric : SBS frames/s (+ achieved HBM GB/s) for 4K (3840x2160) forward warp + polylines_soft hole fill,
            divergence 8.0, left-right side-by-side, stepped synthetic depth, widget defaults otherwise
            (direction-aware depth blur ON: strength 20, threshold 20, falloff 2.0, vert 6).
   step   : one pass of the whole hot path (cs_generate: gray depth + min/max, depth blur, warp + fill +
-           SBS/mask/depth-map assembly) over the batch of N_FRAMES frames, inputs resident in HBM;
+           SBS/mask/depth-map assembly) over the batch of frames, inputs resident in HBM;
            with --gpus N > 1 the batch is sharded by frame (strong scaling: total work fixed) and the step
            ends with the RCCL all-gather that reassembles the stereoscope tensor on every rank.
 
-  python bench.py [--gpus N --steps K --warmup W] [--frames F] [--no-blur] [--no-cpu-baseline]
+  python bench.py [--gpus N --steps K --warmup W] [--config metric|cfg2|cfg3|cfg4|cfg5] [--frames F] [--no-blur]
+                  [--no-cpu-baseline] [--verify]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline     : dominant kernel (k_polytile: warp + polylines fill + assembly) -- algorithmic bytes per launch / its mean
-                 duration measured with HIP events on the launch stream inside the timed region
-  cpu_baseline : the CPU oracle (C port of the reference's D32 arithmetic, 1 thread) on a bounded sample
+Prints ONE JSON line on rank 0 (contract in the task description) with extra objects:
+  roofline     : dominant kernel of the configuration -- algorithmic bytes per launch / its mean duration measured with HIP
+                 events on the launch stream inside the timed region
+  cpu_baseline : the CPU oracle (C port of the reference's D32 arithmetic) on a bounded sample of the same workload:
+                 1 thread, and all host cores (OpenMP over rows = the analogue of the reference's numba prange)
+  value_blur_off (metric config, N = 1): the same workload with the depth blur switched off
+  split        (N > 1): kernels only / kernels + all-gather / end to end
 """
 import argparse
 import ctypes
@@ -28,13 +32,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-H, W = 2160, 3840
-B_ALG_PER_PIXEL = 80  # float32 node boundary, SBS, CPU-technique mask
 HBM_PEAK_GBS = 8000.0
 
+# BASELINE.json configs.  bytes_px: algorithmic bytes per source pixel at the float32 node boundary
+# (80: SBS + output-shaped mask, 76: gpu_warp SBS with the eye-shaped mask, 64: anaglyph).
+CONFIGS = {
+    "metric": dict(h=2160, w=3840, frames=64, fill="polylines_soft", mode="left-right", div=8.0, depth="stepped", bytes_px=80,
+                   name="SBS frames/sec, 4K warp+polylines_soft", kernel="k_polytile<soft> (+ k_rowwarp<polylines_soft> over the rows it flags)",
+                   what="4K 3840x2160, polylines_soft, left-right SBS, divergence 8.0, stepped depth"),
+    "cfg2": dict(h=1080, w=1920, frames=32, fill="polylines_soft", mode="left-right", div=3.5, depth="stepped", bytes_px=80,
+                 name="SBS frames/sec, 1080p warp+polylines_soft (BASELINE cfg 2)", kernel="k_polytile<soft>",
+                 what="BASELINE.json configs[1]: 1080p, divergence 3.5, polylines_soft, left-right SBS, stepped depth, batch of 32 frames"),
+    "cfg3": dict(h=2160, w=3840, frames=16, fill="hybrid_edge", mode="left-right", div=8.0, depth="stepped", bytes_px=80,
+                 name="SBS frames/sec, 4K hybrid_edge + depth blur (BASELINE cfg 3)", kernel="k_hybrid_splat + k_rowwarp<hybrid_edge>",
+                 what="BASELINE.json configs[2]: 4K, divergence 8.0, hybrid_edge fill + edge-aware depth blur, batch of 16 frames"),
+    "cfg4": dict(h=1080, w=1920, frames=256, fill="gpu_warp", mode="left-right", div=4.5, depth="radial", bytes_px=76,
+                 name="SBS frames/sec, 256x1080p gpu_warp (BASELINE cfg 4)", kernel="k_gpuwarp",
+                 what="BASELINE.json configs[3]: batch of 256 1080p frames, gpu_warp fill, left-right SBS, radial depth with a moving centre"),
+    "cfg5": dict(h=2160, w=3840, frames=64, fill="none", mode="red-cyan-anaglyph", div=8.0, depth="stepped", bytes_px=64,
+                 name="anaglyph frames/sec, 64x4K no-fill + mask (BASELINE cfg 5)", kernel="k_rowwarp<none>",
+                 what="BASELINE.json configs[4]: batch of 64 4K frames, red-cyan-anaglyph + no_fill mask output, stepped depth"),
+}
+UI_FILL = {"polylines_soft": "Fill - Polylines Soft", "hybrid_edge": "Imperfect fill - Hybrid Edge", "gpu_warp": "GPU Warp (Fast)",
+           "none": "No fill"}
 
-def make_inputs(torch, frames, first, device):
-    """Synthetic batch on the device: 8-bit-origin random RGB; stepped radial depth with a moving centre."""
+
+def make_inputs(torch, cfg, frames, first, device):
+    """Synthetic batch on the device: 8-bit-origin random RGB; radial / stepped depth with a moving centre."""
+    H, W = cfg["h"], cfg["w"]
     g = torch.Generator(device=device)
     imgs, deps = [], []
     yy, xx = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float64),
@@ -44,25 +69,42 @@ def make_inputs(torch, frames, first, device):
         imgs.append(torch.randint(0, 256, (H, W, 3), generator=g, device=device, dtype=torch.int32).to(torch.float32) / 255.0)
         cx, cy = W / 2 + (17 * i) % (W // 4), H / 2 + (11 * i) % (H // 4)
         r = torch.sqrt((yy - cy) ** 2 + (xx - cx) ** 2)
-        d = torch.floor((1.0 - r / r.max()) * 6) / 6
+        d = 1.0 - r / r.max()
+        if cfg["depth"] == "stepped":
+            d = torch.floor(d * 6) / 6
         deps.append(d.to(torch.float32)[..., None].expand(H, W, 3))
     return torch.stack(imgs).contiguous(), torch.stack(deps).contiguous()
 
 
-def cpu_baseline(frames_sample, blur):
-    """The oracle (test infrastructure) timed as the reported CPU baseline: full node path, 1 thread."""
-    import numpy as np
+def cpu_baseline(cfg, frames_sample, blur, seconds_budget=12.0):
+    """The oracle (test infrastructure) timed as the reported CPU baseline on the host cores of the GPU box: the full node
+    path on a bounded sample of the same workload, first on one thread, then on all cores (rows in parallel)."""
     import synth
-    from oracle import node_oracle
+    from oracle import node_oracle, oracle
+    H, W = cfg["h"], cfg["w"]
     img = synth.image_f32(frames_sample, H, W, seed=1)
-    depth = synth.depth_batch("stepped", frames_sample, H, W, channels=3)
-    t0 = time.perf_counter()
-    node_oracle.generate(img, depth, 8.0, 0.0, "left-right", 0.0, 0.5, 2.0, "Fill - Polylines Soft", 20.0, 20.0, blur,
-                         depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
-    dt = time.perf_counter() - t0
-    return {"value": frames_sample / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{frames_sample} frame(s) of the same workload (4K, both eyes, full node path) through the C oracle, "
-                      f"{dt:.1f} s on {os.cpu_count()} visible host cores (1 used)"}
+    depth = synth.depth_batch(cfg["depth"], frames_sample, H, W, channels=3)
+
+    def run(n):
+        t0 = time.perf_counter()
+        node_oracle.generate(img[:n], depth[:n], cfg["div"], 0.0, cfg["mode"], 0.0, 0.5, 2.0, UI_FILL[cfg["fill"]], 20.0, 20.0, blur,
+                             depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+        return time.perf_counter() - t0
+
+    oracle.set_threads(1)
+    t_one = run(1)
+    n1 = max(1, min(frames_sample, int(seconds_budget / max(t_one, 1e-3))))
+    dt1 = run(n1) if n1 > 1 else t_one
+    cores = oracle.set_threads(os.cpu_count() or 1)
+    nall = frames_sample
+    dta = run(nall)
+    oracle.set_threads(1)
+    return {"value": n1 / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n1} frame(s) of the same workload (both eyes, full node path) through the C oracle, {dt1:.1f} s on 1 of "
+                      f"{os.cpu_count()} visible host cores",
+            "all_cores": {"value": nall / dta, "unit": "frames/s", "cores": cores,
+                          "sample": f"{nall} frame(s), rows of the warp and of the blur on {cores} OpenMP threads (the analogue of "
+                                    f"the reference's numba prange; gray / conversions stay single-threaded numpy), {dta:.1f} s"}}
 
 
 def main():
@@ -70,12 +112,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=64, help="total frames in the batch (sharded over the GPUs)")
+    ap.add_argument("--config", default="metric", choices=sorted(CONFIGS))
+    ap.add_argument("--frames", type=int, default=0, help="total frames in the batch (sharded over the GPUs); 0 = the config's")
     ap.add_argument("--no-blur", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=10)
+    ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--verify", action="store_true", help="N > 1: check the reassembled float32 batch against a local float32 run")
     a = ap.parse_args()
+    cfg = dict(CONFIGS[a.config])
+    frames = a.frames or cfg["frames"]
+    H, W = cfg["h"], cfg["w"]
 
     import torch
     import torch.distributed as dist
@@ -86,7 +132,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # (CS_BENCH_BACKEND=gloo: development -- exercises the N > 1 code path with several ranks on ONE GPU)
+        # (CS_BENCH_BACKEND=gloo: development / tests -- exercises the N > 1 code path with several ranks on ONE GPU)
         backend = os.environ.get("CS_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -97,43 +143,49 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     blur = not a.no_blur
+    gpu_warp = cfg["fill"] == "gpu_warp"
+    batch_size = 12
 
-    bounds = sharding.shard_bounds(a.frames, world)
+    def params(n, blur_on=blur):
+        return engine.make_params(n, H, W, H, W, 3, cfg["fill"], cfg["mode"], cfg["div"], 0.0, 0.0, 0.5, 2.0, blur_on, 20.0, 20.0,
+                                  2.0, 6, batch_size)
+
+    bounds = sharding.shard_bounds(frames, world, min(batch_size, frames) if gpu_warp else 1)
     b0, b1 = bounds[rank], bounds[rank + 1]
     nloc = b1 - b0
-    image, depth = make_inputs(torch, nloc, b0, device)
-    p = engine.make_params(nloc, H, W, H, W, 3, "polylines_soft", "left-right", 8.0, 0.0, 0.0, 0.5, 2.0, blur, 20.0, 20.0,
-                           2.0, 6, 12)
-    # N > 1: shards travel over xGMI as uint8 codes (the stereoscope is k/255 exactly: 4x fewer bytes) and are expanded
-    # to float32 on every rank after the all-gather.  The block of a rank is produced in chunks; the all-gather of chunk c
-    # (RCCL, its own stream) overlaps with the compute of the chunks after it, the expansion of chunk c with the
-    # all-gathers still on the wire (sharding.ChunkedGather).
-    gathered = torch.empty((a.frames, H, 2 * W, 3), dtype=torch.float32, device=device) if world > 1 else None
-    n_chunks = next((k for k in (4, 2, 1) if world > 1 and sharding.ChunkedGather.usable(a.frames, world, k)), 0)
-    if world > 1 and n_chunks == 0:
-        raise SystemExit(f"--frames {a.frames} does not split evenly over {world} GPUs")
-    if world > 1:
-        cg = sharding.ChunkedGather(a.frames, n_chunks, (H, 2 * W, 3), torch.uint8, device)
-        cp = engine.make_params(cg.cf, H, W, H, W, 3, "polylines_soft", "left-right", 8.0, 0.0, 0.0, 0.5, 2.0, blur, 20.0,
-                                20.0, 2.0, 6, 12)
-        plans = [engine.Plan(cp, device, stereo_u8=True) for _ in range(n_chunks)]
-        plan = plans[0]
+    image, depth = make_inputs(torch, cfg, nloc, b0, device)
+    out_h, out_w = engine.output_shape(params(1))[:2]
+
+    # N > 1, CPU techniques: shards travel over xGMI as uint8 codes (the stereoscope is k/255 exactly: 4x fewer bytes), the
+    # block of a rank is produced in chunks whose all-gathers overlap with the following compute, and every gathered chunk
+    # is expanded to float32 on every rank (sharding.ShardedStereoJob).  gpu_warp colours are genuine floats: one float32
+    # all-gather of the rank's block.
+    job = None
+    if world > 1 and not gpu_warp:
+        job = sharding.ShardedStereoJob(params, frames, (out_h, out_w, 3), device)
+        plans = job.plans
     else:
-        plan = engine.Plan(p, device)
+        plan = engine.Plan(params(nloc), device)
+        plans = [plan]
+        if world > 1:
+            sizes = {bounds[r + 1] - bounds[r] for r in range(world)}
+            if len(sizes) != 1:
+                raise SystemExit(f"--frames {frames} does not split into equal sub-batch-aligned blocks over {world} GPUs")
+    gathered_f32 = [None]
 
-    def sink(codes, first):
-        engine.expand_u8(codes, gathered[first:first + codes.shape[0]])
+    def compute_only():
+        if job is not None:
+            job.compute(image, depth)
+        else:
+            plan.run(image, depth)
 
-    def step():
+    def step(expand=True):
         if world == 1:
             plan.run(image, depth)
-            return
-        for c in range(n_chunks):
-            lo, hi = cg.chunk_range(c)
-            stereo, _, _, _ = plans[c].run(image[lo:hi], depth[lo:hi])
-            cg.launch(c, stereo)
-        for c in range(n_chunks):
-            cg.finish(c, sink)
+        elif job is not None:
+            job.step(image, depth, expand=expand)
+        else:
+            gathered_f32[0] = sharding.all_gather_frames(plan.run(image, depth)[0], bounds)
 
     def fence():
         torch.cuda.synchronize()
@@ -141,74 +193,104 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(fn, steps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     L = _native.lib()
     for _ in range(a.warmup):
         step()
     fence()
     L.cs_profile(1)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt = timed(step, a.steps)
     tot_ms, launches = ctypes.c_double(), ctypes.c_int()
     _native.check(L.cs_profile_read(ctypes.byref(tot_ms), ctypes.byref(launches)))
     L.cs_profile(0)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    all_plans = plans if world > 1 else [plan]
-    fallback_rows = sum(int(q.stats()[:, 10].sum()) for q in all_plans)
-    tile_redo_rows = sum(int(q.stats()[:, 11].sum()) for q in all_plans)
-    err_flags = sum(int(q.stats()[:, 9].sum()) for q in all_plans)
+    fallback_rows = sum(int(q.stats()[:, 10].sum()) for q in plans)
+    tile_redo_rows = sum(int(q.stats()[:, 11].sum()) for q in plans)
+    err_flags = sum(int(q.stats()[:, 9].sum()) for q in plans)
+
+    split = None
+    if world > 1:  # kernels only / + all-gather / end to end, each timed like the headline
+        dt_k = timed(compute_only, a.steps)
+        dt_g = timed((lambda: step(expand=False)), a.steps) if job is not None else dt
+        split = {"kernels_only_fps": frames * a.steps / dt_k, "kernels_plus_allgather_fps": frames * a.steps / dt_g,
+                 "end_to_end_fps": frames * a.steps / dt,
+                 "note": "end to end = kernels + all-gather + uint8->float32 expansion on every rank (device-resident inputs)"
+                         if job is not None else "gpu_warp: float32 all-gather, no expansion step"}
+
+    value_blur_off = None
+    if world == 1 and a.config == "metric" and blur:
+        plan_off = engine.Plan(params(nloc, False), device)
+        plan_off.run(image, depth)
+        value_blur_off = frames * a.steps / timed(lambda: plan_off.run(image, depth), a.steps)
+        del plan_off
 
     if a.verify and world > 1:
         # every rank: its own block of the reassembled batch == the float32 output computed locally in one piece
-        ref = engine.Plan(p, device).run(image, depth)[0]
-        ok = torch.equal(gathered[b0:b1], ref)
-        other = (rank + 1) % world  # and one foreign frame: recompute it here
-        fi, fd = make_inputs(torch, 1, bounds[other], device)
-        p1 = engine.make_params(1, H, W, H, W, 3, "polylines_soft", "left-right", 8.0, 0.0, 0.0, 0.5, 2.0, blur, 20.0, 20.0, 2.0, 6, 12)
-        ok = ok and torch.equal(gathered[bounds[other]:bounds[other] + 1], engine.Plan(p1, device).run(fi, fd)[0])
+        full = job.gathered if job is not None else gathered_f32[0]
+        ref = engine.Plan(params(nloc), device).run(image, depth)[0]
+        ok = torch.equal(full[b0:b1], ref)
+        other = (rank + 1) % world  # and one foreign sub-batch: recompute it here
+        no = min(batch_size, bounds[other + 1] - bounds[other]) if gpu_warp else 1
+        fi, fd = make_inputs(torch, cfg, no, bounds[other], device)
+        ok = ok and torch.equal(full[bounds[other]:bounds[other] + no], engine.Plan(params(no), device).run(fi, fd)[0])
         print(f"[verify] rank {rank}: {'OK' if ok else 'MISMATCH'}", flush=True)
         if not ok:
             raise SystemExit(1)
     if rank == 0:
-        fps = a.frames * a.steps / dt
+        fps = frames * a.steps / dt
         kern_ms = tot_ms.value / max(launches.value, 1)
-        frames_per_launch = cg.cf if world > 1 else nloc
-        alg_bytes = frames_per_launch * B_ALG_PER_PIXEL * H * W  # per launch of the dominant kernel on this rank
+        frames_per_launch = job.cg.cf if job is not None else nloc
+        alg_bytes = frames_per_launch * cfg["bytes_px"] * H * W  # per launch of the dominant kernel on this rank
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = f"polylines_soft_4k_blur{int(blur)}"
+                key = f"{cfg['fill']}_{'4k' if H == 2160 else '1080p'}_blur{int(blur)}" if a.config != "metric" else f"polylines_soft_4k_blur{int(blur)}"
                 if key in tj:
                     traffic = tj[key]["bytes_per_frame"] * frames_per_launch
+                    traffic_source = f"profiles/pmc_traffic.json[{key}] (PMC passes of {tj[key].get('profile', 'the committed profile')}, not measured in this run)"
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {
-            "metric": "SBS frames/sec, 4K warp+polylines_soft", "value": fps, "unit": "frames/s", "n_gpus": world,
+            "metric": cfg["name"], "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "4K 3840x2160, polylines_soft, left-right SBS, divergence 8.0, stepped depth, "
-                                   f"depth blur {'on' if blur else 'off'} (widget defaults)",
-                       "frames_total": a.frames, "frames_per_gpu": nloc, "sharding": "by frame, contiguous blocks",
-                       "collective": f"all_gather(stereoscope as uint8 codes) over RCCL in {n_chunks} chunk(s) overlapped with compute"
-                                     " + expand to float32 on every rank" if world > 1 else "none"},
+            "config": {"workload": f"{cfg['what']}, depth blur {'on' if blur else 'off'} (widget defaults)",
+                       "frames_total": frames, "frames_per_gpu": nloc, "sharding": "by frame, contiguous blocks",
+                       "collective": "none" if world == 1 else (
+                           f"all_gather(stereoscope as uint8 codes) over RCCL in {job.n_chunks} chunk(s) overlapped with compute"
+                           " + expand to float32 on every rank" if job is not None else "all_gather(stereoscope float32) over RCCL")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_polytile<soft> (+ k_rowwarp<polylines_soft> over the rows it flags)", "kernel_ms": kern_ms, "launches": launches.value,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": cfg["kernel"], "kernel_ms": kern_ms, "launches": launches.value,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "pipeline_achieved": a.frames * a.steps * B_ALG_PER_PIXEL * H * W / dt / 1e9 / world},
+                         "algorithmic_bytes_note": f"{cfg['bytes_px']} B per source pixel = every input read once and every output written "
+                                                   "once at the float32 node boundary (SURVEY.md 8d); the dominant kernel itself does not "
+                                                   "read the 12 B/px RGB depth input (the gray / blur pre-pass does): kernel-own bytes = "
+                                                   f"{cfg['bytes_px'] - 12 + (8 if blur else 4)} B/px",
+                         "pipeline_achieved": frames * a.steps * cfg["bytes_px"] * H * W / dt / 1e9 / world},
             "diagnostics": {"rows_redone_by_general_kernel": tile_redo_rows, "rows_replayed_sequentially": fallback_rows,
                             "kernel_error_flags": err_flags},
         }
+        if value_blur_off is not None:
+            line["value_blur_off"] = value_blur_off
+        if split is not None:
+            line["split"] = split
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(a.cpu_frames, blur)
+            line["cpu_baseline"] = cpu_baseline(cfg, a.cpu_frames, blur)
         elif not a.no_cpu_baseline:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

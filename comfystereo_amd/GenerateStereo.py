@@ -20,7 +20,7 @@ except Exception:  # noqa: BLE001 - standalone use
         def update(self, k):
             self.current += k
 
-FILL_TECHNIQUES = {
+FILL_TECHNIQUES = {  # the combo entries of the widget (reference GenerateStereo.py:52-61)
     'GPU Warp (Fast)': 'gpu_warp',
     'No fill': 'none',
     'No fill - Reverse projection': 'inverse',
@@ -30,6 +30,13 @@ FILL_TECHNIQUES = {
     'Fill - Polylines Soft': 'polylines_soft',
     'Fill - Polylines Sharp': 'polylines_sharp',
 }
+# generate() also maps the three strings the reference keeps out of its combo list (commented out at :56-57) but still
+# translates at :97-99 -- an API workflow may pass them
+FILL_TECHNIQUE_MAPPING = dict(FILL_TECHNIQUES, **{
+    'Fill - Post-fill': 'none_post',
+    'Fill - Reverse projection with Post-fill': 'inverse_post',
+    'Fill - Hybrid Edge with fill': 'hybrid_edge_plus',
+})
 
 # frames handed to one cs_generate call: bounded by a byte budget, not by the widget's batch_size
 # (288 GB of HBM3E: a chunk of 64 4K frames needs ~55 GB including outputs)
@@ -79,7 +86,7 @@ class StereoImageNode:
     def generate(self, image, depth_map, divergence, separation, modes,
                  stereo_balance, convergence_point, stereo_offset_exponent, fill_technique, depth_blur_edge_threshold,
                  depth_blur_strength, depth_map_blur, depth_blur_falloff=1.0, depth_blur_vert_smooth=0, batch_size=4):
-        fill = FILL_TECHNIQUES.get(fill_technique, 'gpu_warp')  # unknown strings fall back like the reference (:102)
+        fill = FILL_TECHNIQUE_MAPPING.get(fill_technique, 'gpu_warp')  # unknown strings fall back like the reference (:102)
         if not torch.cuda.is_available():
             raise RuntimeError("comfystereo_amd needs an MI355X (PyTorch-ROCm `cuda` device); there is no CPU fallback")
         on_device = image.is_cuda

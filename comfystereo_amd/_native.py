@@ -26,9 +26,12 @@ MODE = {
 EXPORTS = [
     "cs_version", "cs_last_error", "cs_max_width", "cs_output_shape", "cs_workspace_bytes", "cs_generate",
     "cs_asd_workspace_bytes", "cs_apply_stereo_divergence", "cs_blur_workspace_bytes", "cs_directional_blur",
-    "cs_warp_workspace_bytes", "cs_forward_warp", "cs_expand_u8", "cs_profile", "cs_profile_read", "cs_test_powf",
-    "cs_test_exp",
+    "cs_warp_workspace_bytes", "cs_forward_warp", "cs_expand_u8", "cs_profile", "cs_profile_read", "cs_debug_set",
+    "cs_test_powf", "cs_test_exp",
 ]
+
+# enum cs_debug_key (development switches; tests and profiling tools only)
+DEBUG = {"dbg": 0, "no_tile": 1, "pt_variant": 2, "blur_two_pass": 3, "blur_edges_scalar": 4}
 
 
 class Params(ctypes.Structure):
@@ -86,7 +89,8 @@ def lib():
     L.cs_blur_workspace_bytes.restype = c_size
     L.cs_blur_workspace_bytes.argtypes = [c_int, c_int, c_int]
     L.cs_directional_blur.restype = c_int
-    L.cs_directional_blur.argtypes = [vp, c_int, c_int, c_int, c_double, c_double, c_double, c_int, vp, vp, vp, c_size, vp]
+    L.cs_directional_blur.argtypes = [vp, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int, vp, vp, vp,
+                                      c_size, vp]
     L.cs_warp_workspace_bytes.restype = c_size
     L.cs_warp_workspace_bytes.argtypes = [c_int, c_int, c_int]
     L.cs_forward_warp.restype = c_int
@@ -97,12 +101,19 @@ def lib():
     L.cs_profile.argtypes = [c_int]
     L.cs_profile_read.restype = c_int
     L.cs_profile_read.argtypes = [ctypes.POINTER(c_double), ip]
+    L.cs_debug_set.restype = c_int
+    L.cs_debug_set.argtypes = [c_int, c_int]
     L.cs_test_powf.restype = c_int
     L.cs_test_powf.argtypes = [vp, ctypes.c_float, vp, c_size, vp]
     L.cs_test_exp.restype = c_int
     L.cs_test_exp.argtypes = [vp, vp, c_size, vp]
     _lib = L
     return L
+
+
+def debug_set(key, value):
+    """cs_debug_set: development switch `key` (see DEBUG) := value.  Process-wide; reset it to 0 afterwards."""
+    check(lib().cs_debug_set(DEBUG[key], int(value)))
 
 
 def check(rc):

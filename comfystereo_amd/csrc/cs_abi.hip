@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <math.h>
 #include <string.h>
+#include <atomic>
+#include <mutex>
 
 #include "cs_common.h"
 #include "cs_kernels.h"
@@ -20,6 +22,10 @@ static int fail_hip(hipError_t e, const char* where) {
     snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
     return CS_EHIP;
 }
+
+// development switches: explicit state set through cs_debug_set (never the environment)
+static std::atomic<int> g_dev[CS_DEBUG_KEYS];
+int dev_switch(int key) { return (key >= 0 && key < CS_DEBUG_KEYS) ? g_dev[key].load(std::memory_order_relaxed) : 0; }
 
 // ---------------------------------------------------------------------------------------------
 // streaming kernels
@@ -176,14 +182,19 @@ __global__ void k_test_exp(const double* x, double* out, size_t n) {
 }
 
 // ---- measurement hook (cs_profile / cs_profile_read) ------------------------------------------
+// The event pool is process-wide opt-in state (cs_profile); every access holds g_prof_mu, so concurrent cs_generate
+// calls on different streams / threads may record into it.
 static const int PROF_MAX = 4096;
-static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static std::atomic<bool> g_prof_on{false};
 static hipEvent_t g_prof_ev[2 * PROF_MAX];
 static int g_prof_made = 0, g_prof_used = 0;
 struct ProfScope {
     hipStream_t s; int slot;
     explicit ProfScope(hipStream_t stream) : s(stream), slot(-1) {
-        if (!g_prof_on || g_prof_used >= PROF_MAX) return;
+        if (!g_prof_on.load(std::memory_order_relaxed)) return;
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        if (g_prof_used >= PROF_MAX) return;
         while (g_prof_made <= g_prof_used) {
             if (hipEventCreate(&g_prof_ev[2 * g_prof_made]) != hipSuccess) return;
             if (hipEventCreate(&g_prof_ev[2 * g_prof_made + 1]) != hipSuccess) return;
@@ -192,7 +203,11 @@ struct ProfScope {
         slot = g_prof_used++;
         (void)hipEventRecord(g_prof_ev[2 * slot], s);
     }
-    ~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof_ev[2 * slot + 1], s); }
+    ~ProfScope() {
+        if (slot < 0) return;
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        (void)hipEventRecord(g_prof_ev[2 * slot + 1], s);
+    }
 };
 
 static int threads_for(int fill, int w);
@@ -232,8 +247,7 @@ static size_t rowflag_bytes(size_t rows) { return al256(rows) + 256 + al256(rows
 // polylines: tiled fast path + general row kernel over the rows it flagged; everything else: row kernel
 static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_t stream) {
     const bool poly = fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP;
-    const char* no_tile = getenv("CS_NO_TILE");
-    if (poly && !A.anaglyph && halo <= polytile_max_halo() && rowflag && !(no_tile && atoi(no_tile))) {
+    if (poly && !A.anaglyph && halo <= polytile_max_halo() && rowflag && !dev_switch(CS_DEBUG_NO_TILE)) {
         // workspace: [n*h flag bytes][count, padded to 256][n*h list entries]
         const size_t rows = (size_t)A.n * A.h;
         uint32_t* count = (uint32_t*)(rowflag + al256(rows));
@@ -316,7 +330,7 @@ static WsLayout ws_layout(const cs_params* p) {
     bool resize = p->depth_h != p->h || p->depth_w != p->w;
     W.gray_src = o; if (resize) o += al256(n * (size_t)p->depth_h * p->depth_w * 4);
     W.gray = o; o += al256(n * hw * 4);
-    bool blur = p->depth_map_blur && (p->fill != CS_FILL_GPU_WARP || p->depth_blur_strength > 0);
+    bool blur = p->depth_map_blur && p->depth_blur_strength > 0;  // strength <= 0: the reference returns the depth as is (:1194)
     W.L = o; if (blur) o += al256(n * hw * 4);
     W.R = o; if (blur) o += al256(n * hw * 4);
     W.wl = o; if (blur) o += al256(n * hw * 4);
@@ -349,7 +363,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     const int n = p->n, h = p->h, w = p->w, hw = h * w;
     const bool gpu_warp = p->fill == CS_FILL_GPU_WARP;
     if (gpu_warp && (p->flags & 2)) return fail(CS_EINVAL, "gpu_warp colours are not k/255: no uint8 stereoscope output");
-    const bool blur = p->depth_map_blur && (!gpu_warp || p->depth_blur_strength > 0);
+    const bool blur = p->depth_map_blur && p->depth_blur_strength > 0;  // strength <= 0 == blur off (reference :1194, :1050)
 
     hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);
     const bool resize = p->depth_h != h || p->depth_w != w;
@@ -370,7 +384,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     if (blur) {
         float* L = (float*)(ws + W.L);
         float* R = (float*)(ws + W.R);
-        rc = launch_blur(gray, n, h, w, p->depth_blur_strength, p->depth_blur_edge_threshold, p->depth_blur_falloff,
+        rc = launch_blur(gray, n, h, w, p->depth_blur_strength, p->depth_blur_edge_threshold, p->depth_blur_strength, p->depth_blur_falloff,
                          p->depth_blur_vert_smooth, L, R, (float*)(ws + W.wl), (float*)(ws + W.wr), stats, 1, stream);
         if (rc) return fail(rc, "depth blur: unsupported parameters (strength must round to >= 1)");
         dL = L; dR = R;
@@ -407,7 +421,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     A.stereo_is_u8 = (p->flags & 2) ? 1 : 0;
     A.out_h = out_h; A.out_w = out_w;
     A.single = -1;
-    { const char* dbg = getenv("CS_DBG"); A.dbg = dbg ? atoi(dbg) : 0; }
+    A.dbg = dev_switch(CS_DEBUG_DBG);
     switch (p->mode) {
     case CS_MODE_LEFT_RIGHT: A.eye[1].xoff = w; break;
     case CS_MODE_RIGHT_LEFT: A.eye[0].xoff = w; break;
@@ -459,7 +473,7 @@ int cs_apply_stereo_divergence(const uint8_t* image_u8, const float* depth, int 
     A.eye[0].depth = depth; A.eye[0].st_min = ST_L_MIN; A.eye[0].st_max = ST_L_MAX;
     A.out_u8 = out_u8;
     A.single = -1;
-    { const char* dbg = getenv("CS_DBG"); A.dbg = dbg ? atoi(dbg) : 0; }
+    A.dbg = dev_switch(CS_DEBUG_DBG);
     if (fill == CS_FILL_HYBRID_EDGE || fill == CS_FILL_HYBRID_EDGE_PLUS) {
         int rc = launch_hybrid(A, (char*)workspace + al256((size_t)n * ST_WORDS * 4) + rowflag_bytes((size_t)n * h), stream,
                                fill == CS_FILL_HYBRID_EDGE_PLUS);
@@ -476,7 +490,7 @@ int cs_apply_stereo_divergence(const uint8_t* image_u8, const float* depth, int 
 size_t cs_blur_workspace_bytes(int n, int h, int w) { return al256((size_t)n * ST_WORDS * 4) + 2 * al256((size_t)n * h * w * 4); }
 
 int cs_directional_blur(const float* depth, int n, int h, int w, double blur_strength, double edge_threshold,
-                        double falloff_exponent, int vert_smooth_px, float* out_l, float* out_r, void* workspace,
+                        double blur_mask_width, double falloff_exponent, int vert_smooth_px, float* out_l, float* out_r, void* workspace,
                         size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!depth || !out_l || !out_r || !workspace) return fail(CS_EINVAL, "null pointer");
@@ -493,7 +507,7 @@ int cs_directional_blur(const float* depth, int n, int h, int w, double blur_str
     float* wl = (float*)(ws + al256((size_t)n * ST_WORDS * 4));
     float* wr = wl + al256(n * hw * 4) / 4;
     hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);
-    int rc = launch_blur(depth, n, h, w, blur_strength, edge_threshold, falloff_exponent, vert_smooth_px, out_l, out_r, wl,
+    int rc = launch_blur(depth, n, h, w, blur_strength, edge_threshold, blur_mask_width, falloff_exponent, vert_smooth_px, out_l, out_r, wl,
                          wr, stats, 0, stream);
     if (rc) return fail(rc, "depth blur: unsupported parameters (strength must round to >= 1)");
     hipError_t e = hipGetLastError();
@@ -529,12 +543,24 @@ int cs_expand_u8(const uint8_t* codes, float* out, size_t count, void* stream) {
 }
 
 int cs_profile(int enable) {
-    g_prof_on = enable != 0;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    g_prof_on.store(enable != 0);
     if (enable) g_prof_used = 0;
     return CS_OK;
 }
 
+int cs_debug_set(int key, int value) {
+    if (key < 0 || key >= CS_DEBUG_KEYS) return fail(CS_EINVAL, "cs_debug_set: unknown key");
+#ifndef CS_DEV
+    if (key == CS_DEBUG_DBG && value != 0 && value != 14 && value != 17)
+        return fail(CS_EINVAL, "cs_debug_set: this CS_DEBUG_DBG value needs a -DCS_DEV build (phase cut-offs leave outputs unwritten)");
+#endif
+    g_dev[key].store(value, std::memory_order_relaxed);
+    return CS_OK;
+}
+
 int cs_profile_read(double* total_ms, int* launches) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     double tot = 0.0;
     for (int i = 0; i < g_prof_used; i++) {
         hipError_t e = hipEventSynchronize(g_prof_ev[2 * i + 1]);

@@ -611,8 +611,8 @@ static size_t blur_fused_lds(int v, int R, int bs) {
            sizeof(csm::PowfTables) + 64 + 4 * (size_t)(R + 2);
 }
 
-int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double falloff,
-                int vert, float* out_l, float* out_r, float* wl, float* wr, uint32_t* stats, int node_path,
+int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double mask_width,
+                double falloff, int vert, float* out_l, float* out_r, float* wl, float* wr, uint32_t* stats, int node_path,
                 hipStream_t stream) {
     BlurArgs A;
     A.depth = depth; A.n = n; A.h = h; A.w = w;
@@ -620,23 +620,23 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
     A.stats_rw = node_path ? stats : nullptr;
     A.den = (float)(10.0 * edge_threshold);
     A.bs = (int)nearbyint(strength);  // Python round(): half to even
-    A.radius = (int)strength;
+    A.radius = (int)mask_width;  // mask_radius = int(blur_mask_width), reference :1209
     A.vert = vert > 0 ? vert : 0;
     if (A.bs < 1) return CS_EINVAL;  // torch raises on a zero-width kernel
     A.fall32 = (float)falloff;
     A.fall_mode = falloff == 1.0 ? 0 : falloff == 0.5 ? 1 : falloff == 2.0 ? 2 : falloff == 3.0 ? 3 : falloff == 0.0 ? 5 : 4;
     A.wl = wl; A.wr = wr; A.out_l = out_l; A.out_r = out_r;
-    { const char* dbg = getenv("CS_DBG"); A.dbg = dbg ? atoi(dbg) : 0; }
-    const char* nofuse = getenv("CS_BLUR_TWO_PASS");
+    A.dbg = dev_switch(CS_DEBUG_DBG);
+    const int nofuse = dev_switch(CS_DEBUG_BLUR_TWO_PASS);
     size_t ldsF = blur_fused_lds(A.vert, A.radius, A.bs);
-    if (ldsF <= 64 * 1024 && A.radius >= 1 && !(nofuse && atoi(nofuse))) {
+    if (ldsF <= 64 * 1024 && A.radius >= 1 && !nofuse) {
         hipError_t e = hipFuncSetAttribute((const void*)k_blur_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
         if (e != hipSuccess) return CS_EHIP;
         // the weight scratch buffers double as the frame-wide edge bit rows (2 x ceil(w/64) words per image row)
         const int MW = (w + 63) / 64;
         unsigned long long* mask_l = reinterpret_cast<unsigned long long*>(wl);
         unsigned long long* mask_r = reinterpret_cast<unsigned long long*>(wr);
-        if ((w & 3) == 0 && !getenv("CS_BLUR_EDGES_SCALAR"))
+        if ((w & 3) == 0 && !dev_switch(CS_DEBUG_BLUR_EDGES_SCALAR))
             hipLaunchKernelGGL(k_blur_edges4, dim3((w + 1023) / 1024, (h + BLUR_ER4 - 1) / BLUR_ER4, n), dim3(256), 0, stream, A, mask_l, mask_r, MW);
         else
             hipLaunchKernelGGL(k_blur_edges, dim3((w + 255) / 256, (h + BLUR_ER - 1) / BLUR_ER, n), dim3(256), 0, stream, A, mask_l, mask_r, MW);

@@ -47,8 +47,14 @@ struct RowArgs {
     uint8_t* hyb_mask;  // [n][neyes][h][w]
     const uint32_t* row_list;     // or null: process only these rows (frame * h + row), *row_count of them (tiled-path fallback)
     const uint32_t* row_count;
-    int dbg;            // development only (env CS_DBG): stop the polylines technique after phase `dbg`
+    int dbg;            // development only (cs_debug_set(CS_DEBUG_DBG, n)): see dev_switch() below
 };
+
+// Development switches (cs_debug_set, include/comfystereo_amd.h).  Release builds never read the environment; the
+// switches are explicit process-wide state that only tests and profiling tools set.  In a release build CS_DEBUG_DBG
+// only accepts the values that leave every output intact (14: count pixels per evaluation path, 17: no exponent
+// shortcuts); the phase cut-offs of the tile and blur kernels need a -DCS_DEV build.
+int dev_switch(int key);
 
 
 // cs_rowwarp.hip
@@ -62,11 +68,11 @@ int polytile_max_halo();
 
 // cs_blur.hip: directional depth blur; if `scale_from_stats`, the input is multiplied by 255 for frames
 // whose stats say so, and the per-frame min/max of both outputs are accumulated into stats.
-int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double falloff,
-                int vert, float* out_l, float* out_r, float* wl, float* wr, uint32_t* stats, int node_path,
+int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double mask_width,
+                double falloff, int vert, float* out_l, float* out_r, float* wl, float* wr, uint32_t* stats, int node_path,
                 hipStream_t stream);
 
-// cs_hybrid.hip
+// cs_rowwarp.hip (hybrid_edge: k_hybrid_splat + the fill pass of k_rowwarp)
 size_t hybrid_workspace_bytes(int n, int h, int w);
 int hybrid_max_width();
 int launch_hybrid(const RowArgs& A, void* workspace, hipStream_t stream, int plus = 0);  // plus: hybrid_edge_plus

@@ -902,8 +902,7 @@ hipError_t launch_polytile(int sharp, const RowArgs& R, int S, uint8_t* rowflag,
     A.dbg = R.dbg;
     const int tiles = (A.w + PT_T - 1) / PT_T;
     dim3 grid(tiles * A.h, A.n, A.single >= 0 ? 1 : 2), block(PT_THREADS);
-    const char* ev = getenv("CS_PT_VARIANT");
-    const int variant = ev ? atoi(ev) : 0;
+    const int variant = dev_switch(CS_DEBUG_PT_VARIANT);
 #define PT_LAUNCH(SH, KP, KS, MW)                                                                                   \
     {                                                                                                               \
         size_t lds = polytile_lds(S, SH, KP, KS);                                                                   \

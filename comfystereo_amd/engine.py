@@ -123,8 +123,9 @@ def apply_stereo_divergence(image_u8, depth, divergence, separation, stereo_offs
     return out[0] if squeeze else out
 
 
-def directional_blur(depth, blur_strength, edge_threshold, falloff_exponent=1.0, vert_smooth_px=0):
-    """reference stereoimage_generation.py:1171-1251 for a [N,H,W] (or [H,W]) float32 device tensor, 0..255 scale."""
+def directional_blur(depth, blur_strength, edge_threshold, falloff_exponent=1.0, vert_smooth_px=0, blur_mask_width=None):
+    """reference stereoimage_generation.py:1171-1251 for a [N,H,W] (or [H,W]) float32 device tensor, 0..255 scale.
+    blur_mask_width: reach of the blur weights from an edge (default: the blur strength, like the reference's callers)."""
     L = _native.lib()
     depth = _dev(depth).contiguous().float()
     shp = depth.shape
@@ -133,7 +134,8 @@ def directional_blur(depth, blur_strength, edge_threshold, falloff_exponent=1.0,
     out_l, out_r = torch.empty_like(d3), torch.empty_like(d3)
     nb = L.cs_blur_workspace_bytes(n, h, w)
     ws = torch.empty((max(nb, 256),), dtype=torch.uint8, device=depth.device)
-    _native.check(L.cs_directional_blur(_ptr(d3), n, h, w, float(blur_strength), float(edge_threshold),
+    mw = float(blur_strength if blur_mask_width is None else blur_mask_width)
+    _native.check(L.cs_directional_blur(_ptr(d3), n, h, w, float(blur_strength), float(edge_threshold), mw,
                                         float(falloff_exponent), int(vert_smooth_px), _ptr(out_l), _ptr(out_r), _ptr(ws),
                                         nb, _stream()))
     return out_l.reshape(shp), out_r.reshape(shp)

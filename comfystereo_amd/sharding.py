@@ -21,8 +21,16 @@ def shard_bounds(n_frames, world_size, align=1):
     return bounds
 
 
+def _host_staged(t, group=None):
+    """gloo cannot all-gather device tensors: with that backend (CPU tests, several ranks sharing one GPU in the -m gpu
+    tests) device tensors take a round trip through host memory.  RCCL ("nccl") gathers device memory directly."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def all_gather_frames(local, bounds, group=None):
     """All-gather tensors whose dim 0 is this rank's frame block -> the full [N, ...] tensor on every rank."""
+    if _host_staged(local, group):
+        return all_gather_frames(local.cpu(), bounds, group).to(local.device)
     world = dist.get_world_size(group)
     sizes = [bounds[r + 1] - bounds[r] for r in range(world)]
     n = bounds[-1]
@@ -92,6 +100,12 @@ class ChunkedGather:
         self.staging = [torch.empty((self.world * self.cf,) + tuple(frame_shape), dtype=dtype, device=device)
                         for _ in range(n_chunks)]
         self.works = [None] * n_chunks
+        # gloo + device tensors (several ranks on one GPU in the tests): the chunks cross the wire from pinned host copies
+        self.host = torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
+        if self.host:
+            self.h_local = [torch.empty((self.cf,) + tuple(frame_shape), dtype=dtype).pin_memory() for _ in range(n_chunks)]
+            self.h_all = [torch.empty((self.world * self.cf,) + tuple(frame_shape), dtype=dtype).pin_memory()
+                          for _ in range(n_chunks)]
 
     def chunk_range(self, c):
         """Local frame range of chunk c inside this rank's block."""
@@ -99,10 +113,58 @@ class ChunkedGather:
 
     def launch(self, c, local_chunk):
         assert local_chunk.shape[0] == self.cf and local_chunk.is_contiguous()
+        if self.host:
+            self.h_local[c].copy_(local_chunk, non_blocking=True)
+            torch.cuda.current_stream().synchronize()  # the host copy must be complete before gloo reads it
+            self.works[c] = dist.all_gather_into_tensor(self.h_all[c], self.h_local[c], group=self.group, async_op=True)
+            return
         self.works[c] = dist.all_gather_into_tensor(self.staging[c], local_chunk, group=self.group, async_op=True)
 
     def finish(self, c, sink):
         self.works[c].wait()
         self.works[c] = None
+        if self.host:
+            self.staging[c].copy_(self.h_all[c], non_blocking=True)
         for r in range(self.world):
             sink(self.staging[c][r * self.cf:(r + 1) * self.cf], self.bounds[r] + c * self.cf)
+
+
+class ShardedStereoJob:
+    """One rank's part of a frame-sharded batch for the CPU techniques (what `bench.py --gpus N` times and the -m gpu
+    sharding tests check): the rank's block is produced chunk by chunk with the stereoscope in its compact uint8 form
+    (engine.Plan(stereo_u8=True): every value is k/255 exactly), chunk c is all-gathered (RCCL over xGMI; its own
+    stream) while the chunks after it are computed, and each gathered chunk is expanded to float32 (cs_expand_u8) into
+    the reassembled batch while later chunks are still on the wire.
+
+    make_params(n_frames) -> engine params for a chunk of that many frames.  step(image_block, depth_block) returns the
+    reassembled float32 stereoscope [N, out_h, out_w, 3] (the same tensor every step)."""
+
+    def __init__(self, make_params, n_frames, out_shape, device, group=None, chunk_options=(4, 2, 1)):
+        from . import engine
+        self.engine = engine
+        world = dist.get_world_size(group)
+        self.n_chunks = next((k for k in chunk_options if ChunkedGather.usable(n_frames, world, k)), 0)
+        if self.n_chunks == 0:
+            raise ValueError(f"{n_frames} frames do not split evenly over {world} ranks")
+        self.cg = ChunkedGather(n_frames, self.n_chunks, tuple(out_shape), torch.uint8, device, group)
+        self.plans = [engine.Plan(make_params(self.cg.cf), device, stereo_u8=True) for _ in range(self.n_chunks)]
+        self.gathered = torch.empty((n_frames,) + tuple(out_shape), dtype=torch.float32, device=device)
+        self.bounds = self.cg.bounds
+
+    def _sink(self, codes, first):
+        self.engine.expand_u8(codes, self.gathered[first:first + codes.shape[0]])
+
+    def compute(self, image_block, depth_block):
+        """The kernels only (no collective): every chunk of this rank's block."""
+        for c in range(self.n_chunks):
+            lo, hi = self.cg.chunk_range(c)
+            self.plans[c].run(image_block[lo:hi], depth_block[lo:hi])
+
+    def step(self, image_block, depth_block, expand=True):
+        for c in range(self.n_chunks):
+            lo, hi = self.cg.chunk_range(c)
+            stereo, _, _, _ = self.plans[c].run(image_block[lo:hi], depth_block[lo:hi])
+            self.cg.launch(c, stereo)
+        for c in range(self.n_chunks):
+            self.cg.finish(c, self._sink if expand else (lambda codes, first: None))
+        return self.gathered

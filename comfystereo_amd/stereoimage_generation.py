@@ -131,14 +131,11 @@ def apply_stereo_divergence(original_image, depth, divergence, separation, stere
 
 def directional_motion_blur_gpu(depth_tensor, blur_strength, edge_threshold, blur_mask_width=5,
                                 falloff_exponent=1.0, vert_smooth_px=0):
-    """[H,W] or [B,H,W] depth on the 0..255 scale -> (left, right) device tensors (reference :1171-1251).
-    The reference always passes blur_mask_width = blur_strength (:1051-1054, :1479-1482); so does the kernel."""
+    """[H,W] or [B,H,W] depth on the 0..255 scale -> (left, right) device tensors (reference :1171-1251)."""
     if blur_strength <= 0:
         return depth_tensor, depth_tensor
-    if float(blur_mask_width) != float(blur_strength):
-        raise NotImplementedError("blur_mask_width != blur_strength is never used by the reference's callers")
     return engine.directional_blur(depth_tensor.to(_device(), torch.float32), blur_strength, edge_threshold,
-                                   falloff_exponent, vert_smooth_px)
+                                   falloff_exponent, vert_smooth_px, blur_mask_width=blur_mask_width)
 
 
 def forward_warp_gpu(image_tensor, depth_tensor, divergence_px, separation_px, stereo_offset_exponent,

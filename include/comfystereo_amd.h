@@ -15,7 +15,8 @@
  *     message for the last failing call
  *   - scalar parameters are doubles because they are Python floats in the reference, which rounds
  *     them to float32 at specific points of the arithmetic
- *   - re-entrant per stream as long as each concurrent call gets its own workspace
+ *   - re-entrant per stream as long as each concurrent call gets its own workspace; the only process-wide state
+ *     is opt-in (cs_profile's event pool, guarded by a mutex; cs_debug_set's development switches)
  */
 #ifndef COMFYSTEREO_AMD_H
 #define COMFYSTEREO_AMD_H
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 1
+#define CS_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define CS_API __attribute__((visibility("default")))
@@ -130,13 +131,14 @@ CS_API int cs_apply_stereo_divergence(const uint8_t *image_u8, const float *dept
                                uint8_t *out_u8, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
- * directional_motion_blur_gpu (reference stereoimage_generation.py:1171-1251, called with
- * blur_mask_width = blur_strength as at :1051-1054 / :1479-1482).  depth, out_l, out_r: [n][h][w]
- * float32 on the 0..255 scale.  workspace: cs_blur_workspace_bytes(n, h, w).
+ * directional_motion_blur_gpu (reference stereoimage_generation.py:1171-1251; its own callers pass
+ * blur_mask_width = blur_strength, :1051-1054 / :1479-1482).  depth, out_l, out_r: [n][h][w]
+ * float32 on the 0..255 scale.  blur_strength <= 0 copies the input (:1194).
+ * workspace: cs_blur_workspace_bytes(n, h, w).
  */
 CS_API size_t cs_blur_workspace_bytes(int n, int h, int w);
 CS_API int cs_directional_blur(const float *depth, int n, int h, int w, double blur_strength, double edge_threshold,
-                        double falloff_exponent, int vert_smooth_px, float *out_l, float *out_r, void *workspace,
+                        double blur_mask_width, double falloff_exponent, int vert_smooth_px, float *out_l, float *out_r, void *workspace,
                         size_t workspace_bytes, void *stream);
 
 /*
@@ -164,6 +166,22 @@ CS_API int cs_expand_u8(const uint8_t *codes, float *out, size_t count, void *st
  */
 CS_API int cs_profile(int enable);
 CS_API int cs_profile_read(double *total_ms, int *launches);
+
+/*
+ * Development switches for the parity tests and profiling tools (compare two code paths of the same kernel,
+ * count pixels per evaluation path).  Explicit, process-wide, opt-in state like cs_profile; the library never reads
+ * the environment.  Release builds reject CS_DEBUG_DBG values that would leave outputs unwritten (phase cut-offs
+ * exist in -DCS_DEV builds only).  No reference counterpart.
+ */
+enum cs_debug_key {
+    CS_DEBUG_DBG = 0,               /* 14: count pixels per evaluation path into spare stats words; 17: no exponent shortcuts */
+    CS_DEBUG_NO_TILE = 1,           /* polylines: general row kernel for every row instead of the tiled path */
+    CS_DEBUG_PT_VARIANT = 2,        /* tile kernel: other list capacities / the previous kernel generation */
+    CS_DEBUG_BLUR_TWO_PASS = 3,     /* depth blur: two-pass row kernels */
+    CS_DEBUG_BLUR_EDGES_SCALAR = 4, /* depth blur: one-column-per-lane edge kernel */
+    CS_DEBUG_KEYS = 8
+};
+CS_API int cs_debug_set(int key, int value);
 
 /* Device self-tests of the libm-exact scalar routines (used by the parity tests):
  * out[i] = powf(x[i], y) / out[i] = exp(x[i]) evaluated by the same device code the kernels use. */

@@ -18,6 +18,9 @@ FILL_KEYS = {
     'Imperfect fill - Hybrid Edge': 'hybrid_edge', 'Fill - Naive': 'naive',
     'Fill - Naive interpolating': 'naive_interpolating', 'Fill - Polylines Soft': 'polylines_soft',
     'Fill - Polylines Sharp': 'polylines_sharp',
+    # mapped by the reference (GenerateStereo.py:97-99) although its combo list leaves them out (:56-57)
+    'Fill - Post-fill': 'none_post', 'Fill - Reverse projection with Post-fill': 'inverse_post',
+    'Fill - Hybrid Edge with fill': 'hybrid_edge_plus',
 }
 
 

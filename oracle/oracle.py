@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libstereo_oracle.so")
+# CS_ORACLE_LIB: another build of the checker, e.g. the AddressSanitizer one (`make -C oracle asan`)
+_LIB_PATH = os.environ.get("CS_ORACLE_LIB") or os.path.join(_HERE, "libstereo_oracle.so")
 
 FILLS = {
     "none": 0,
@@ -47,6 +48,10 @@ def lib():
         L = ctypes.CDLL(_LIB_PATH)
         u8p, f32p = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_float)
         c_int, c_double = ctypes.c_int, ctypes.c_double
+        L.oracle_set_threads.restype = None
+        L.oracle_set_threads.argtypes = [c_int]
+        L.oracle_max_threads.restype = c_int
+        L.oracle_set_threads(1)  # single-threaded unless a caller (bench.py's cpu_baseline) asks for more
         L.oracle_powf.restype = ctypes.c_float
         L.oracle_powf.argtypes = [ctypes.c_float, ctypes.c_float]
         L.oracle_exp.restype = c_double
@@ -65,6 +70,8 @@ def lib():
         if hasattr(L, "oracle_blur"):
             L.oracle_blur.restype = None
             L.oracle_blur.argtypes = [f32p, c_int, c_int, c_int, c_double, c_double, c_double, c_int, f32p, f32p]
+            L.oracle_blur2.restype = None
+            L.oracle_blur2.argtypes = [f32p, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int, f32p, f32p]
         if hasattr(L, "oracle_forward_warp_gpu"):
             L.oracle_forward_warp_gpu.restype = None
             L.oracle_forward_warp_gpu.argtypes = [f32p, f32p, c_int, c_int, c_int, c_double, c_double, c_double,
@@ -85,6 +92,14 @@ def powf(x, y):
     return float(lib().oracle_powf(float(x), float(y)))
 
 
+def set_threads(n):
+    """Rows of the polylines technique and of the depth blur run on `n` OpenMP threads (the analogue of the reference's
+    numba `prange`); 1 = the default.  Returns the number of host cores OpenMP sees."""
+    L = lib()
+    L.oracle_set_threads(int(n))
+    return L.oracle_max_threads()
+
+
 def apply_stereo_divergence(img_u8_hwc, depth_f32_hw, divergence, separation, exponent, fill, convergence=0.5,
                             return_nd=False):
     """reference stereoimage_generation.py:1576-1620 (`apply_stereo_divergence`)."""
@@ -101,15 +116,16 @@ def apply_stereo_divergence(img_u8_hwc, depth_f32_hw, divergence, separation, ex
     return (out, nd) if return_nd else out
 
 
-def blur(depth_f32, strength, edge_threshold, falloff=1.0, vert_smooth=0):
-    """reference stereoimage_generation.py:1171-1251 (`directional_motion_blur_gpu`), depth [B,H,W] or [H,W]."""
+def blur(depth_f32, strength, edge_threshold, falloff=1.0, vert_smooth=0, mask_width=None):
+    """reference stereoimage_generation.py:1171-1251 (`directional_motion_blur_gpu`), depth [B,H,W] or [H,W].
+    mask_width: `blur_mask_width` (the reference's callers pass the blur strength, the default here)."""
     d = np.ascontiguousarray(depth_f32, dtype=np.float32)
     shp = d.shape
     d3 = d.reshape((-1,) + shp[-2:])
     L = np.empty_like(d3)
     R = np.empty_like(d3)
-    lib().oracle_blur(_f32(d3), d3.shape[0], d3.shape[1], d3.shape[2], float(strength), float(edge_threshold),
-                      float(falloff), int(vert_smooth), _f32(L), _f32(R))
+    lib().oracle_blur2(_f32(d3), d3.shape[0], d3.shape[1], d3.shape[2], float(strength), float(edge_threshold),
+                       float(strength if mask_width is None else mask_width), float(falloff), int(vert_smooth), _f32(L), _f32(R))
     return L.reshape(shp), R.reshape(shp)
 
 

@@ -37,6 +37,15 @@ enum {
     FILL_NONE_POST = 8, FILL_INVERSE_POST = 9, FILL_HYBRID_EDGE_PLUS = 10, /* UI-unreachable (reference :1605-1610) */
 };
 
+#ifdef _OPENMP
+#include <omp.h>
+EXPORT void oracle_set_threads(int n) { omp_set_num_threads(n < 1 ? 1 : n); }
+EXPORT int oracle_max_threads(void) { return omp_get_num_procs(); }
+#else
+EXPORT void oracle_set_threads(int n) { (void)n; }
+EXPORT int oracle_max_threads(void) { return 1; }
+#endif
+
 EXPORT float oracle_powf(float x, float y) { return om_powf(x, y); }
 EXPORT double oracle_exp(double x) { return om_exp(x); }
 
@@ -162,12 +171,24 @@ EXPORT int oracle_polylines(const uint8_t *img, const float *nd, int h, int w, d
     float e32 = (float)exponent, div32 = (float)div_px, sep32 = (float)sep_px;
     float half32 = (float)0.45;
     int npt_max = 5 + 2 * w;
+    int csg_cap = 5 * (int)fabs(div_px) + 25;
+    int rc_all = 0;
+    /* rows are independent (the reference's `prange(h)`, :1918): the cpu_baseline leg of bench.py runs them on all
+     * cores through OpenMP; oracle_set_threads(1) (the default) keeps every test single-threaded */
+#pragma omp parallel
+    {
     pt_t *pt = (pt_t *)malloc(sizeof(pt_t) * npt_max);
     sg_t *sg = (sg_t *)malloc(sizeof(sg_t) * npt_max);
-    int csg_cap = 5 * (int)fabs(div_px) + 25;
     sg_t *csg = (sg_t *)malloc(sizeof(sg_t) * csg_cap);
-    int rc = 0;
-    for (int row = 0; row < h && rc == 0; row++) {
+#pragma omp for schedule(dynamic, 4)
+    for (int row = 0; row < h; row++) {
+        int rc = 0;
+        {
+            int seen;
+#pragma omp atomic read
+            seen = rc_all;
+            if (seen) continue; /* the reference raises at the first overflow */
+        }
         const uint8_t *irow = &img[(size_t)row * w * 3];
         memset(pt, 0, sizeof(pt_t) * npt_max);
         int pt_end = 0;
@@ -269,9 +290,14 @@ EXPORT int oracle_polylines(const uint8_t *img, const float *nd, int h, int w, d
             }
             for (int c = 0; c < 3; c++) out[((size_t)row * w + col) * 3 + c] = f32_to_u8_wrap(color[c]);
         }
+        if (rc) {
+#pragma omp atomic write
+            rc_all = rc;
+        }
     }
     free(pt); free(sg); free(csg);
-    return rc;
+    }
+    return rc_all;
 }
 
 /* -------------------------------------------------------------------------------------------
@@ -579,8 +605,8 @@ static void edge_distance_weight(const uint8_t *edge, int W, int radius, double 
     }
 }
 
-EXPORT void oracle_blur(const float *depth, int B, int H, int W, double strength, double edge_threshold,
-                        double falloff, int vert, float *outL, float *outR) {
+EXPORT void oracle_blur2(const float *depth, int B, int H, int W, double strength, double edge_threshold,
+                         double mask_width, double falloff, int vert, float *outL, float *outR) {
     size_t hw = (size_t)H * W;
     if (strength <= 0) { /* :1194 */
         memcpy(outL, depth, sizeof(float) * hw * B);
@@ -588,15 +614,17 @@ EXPORT void oracle_blur(const float *depth, int B, int H, int W, double strength
         return;
     }
     int bs = (int)nearbyint(strength); /* Python round(): half to even */
-    int radius = (int)strength;        /* int(blur_mask_width) */
+    int radius = (int)mask_width;      /* mask_radius = int(blur_mask_width) :1209 */
     float den = (float)(10.0 * edge_threshold);
     float *wl = (float *)malloc(sizeof(float) * hw), *wr = (float *)malloc(sizeof(float) * hw);
     float *tl = (float *)malloc(sizeof(float) * hw), *tr = (float *)malloc(sizeof(float) * hw);
-    uint8_t *el = (uint8_t *)malloc(W), *er = (uint8_t *)malloc(W);
     static const float SOB[3][3] = {{-1, 0, 1}, {-2, 0, 2}, {-1, 0, 1}};
     for (int b = 0; b < B; b++) {
         const float *d = depth + hw * b;
+        /* (rows in parallel when oracle_set_threads(n > 1): every output value depends on its own row band only) */
+#pragma omp parallel for schedule(static)
         for (int y = 0; y < H; y++) {
+            uint8_t *el = (uint8_t *)malloc(W), *er = (uint8_t *)malloc(W);
             for (int x = 0; x < W; x++) {
                 float g = 0.0f;
                 for (int ky = 0; ky < 3; ky++)
@@ -612,9 +640,11 @@ EXPORT void oracle_blur(const float *depth, int B, int H, int W, double strength
             }
             edge_distance_weight(el, W, radius, falloff, wl + (size_t)y * W);
             edge_distance_weight(er, W, radius, falloff, wr + (size_t)y * W);
+            free(el); free(er);
         }
         if (vert > 0) { /* :1229-1233 vertical box on the weights, zero padding */
             float kv = 1.0f / (float)(2 * vert + 1);
+#pragma omp parallel for schedule(static)
             for (int y = 0; y < H; y++)
                 for (int x = 0; x < W; x++) {
                     float a = 0.0f, c = 0.0f;
@@ -633,6 +663,7 @@ EXPORT void oracle_blur(const float *depth, int B, int H, int W, double strength
         }
         float kb = 1.0f / (float)bs;
         int pad = bs / 2;
+#pragma omp parallel for schedule(static)
         for (int y = 0; y < H; y++)
             for (int x = 0; x < W; x++) {
                 float acc = 0.0f;
@@ -647,7 +678,13 @@ EXPORT void oracle_blur(const float *depth, int B, int H, int W, double strength
                 outR[hw * b + o] = wr[o] * acc + (1.0f - wr[o]) * dv; /* :1244 */
             }
     }
-    free(wl); free(wr); free(tl); free(tr); free(el); free(er);
+    free(wl); free(wr); free(tl); free(tr);
+}
+
+/* the reference's own call sites pass blur_mask_width = blur_strength (:1051-1054, :1479-1482) */
+EXPORT void oracle_blur(const float *depth, int B, int H, int W, double strength, double edge_threshold,
+                        double falloff, int vert, float *outL, float *outR) {
+    oracle_blur2(depth, B, H, W, strength, edge_threshold, strength, falloff, vert, outL, outR);
 }
 
 /* -------------------------------------------------------------------------------------------

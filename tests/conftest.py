@@ -79,3 +79,18 @@ def node_case_expected(g, case):
     mshape = case["shapes"]["mask"]
     mask = np.unpackbits(g[f"{cid}/mask"])[: int(np.prod(mshape))].reshape(mshape).astype(np.float32)
     return stereo, dl, dr, mask
+
+
+@pytest.fixture
+def dev_switch():
+    """Set development switches of the library (cs_debug_set) for one test; all of them are reset afterwards."""
+    from comfystereo_amd import _native
+    touched = []
+
+    def set_(key, value):
+        touched.append(key)
+        _native.debug_set(key, value)
+
+    yield set_
+    for key in touched:
+        _native.debug_set(key, 0)

@@ -22,7 +22,7 @@ def test_library_is_built_and_exports_every_declared_symbol():
     assert len(syms) >= 14 and set(syms) == set(_native.EXPORTS)
     for s in syms:
         assert hasattr(L, s), s
-    assert L.cs_version() == 1
+    assert L.cs_version() == 2
 
 
 def test_enums_match_header():
@@ -62,7 +62,7 @@ def test_host_side_queries_without_gpu():
 def test_null_pointers_are_rejected_before_any_device_work():
     L = _native.lib()
     assert L.cs_apply_stereo_divergence(None, None, 1, 8, 8, 1.0, 0.0, 1.0, 0, 0.5, None, None, 0, None) == _native.CS_EINVAL
-    assert L.cs_directional_blur(None, 1, 8, 8, 5.0, 6.0, 1.0, 0, None, None, None, 0, None) == _native.CS_EINVAL
+    assert L.cs_directional_blur(None, 1, 8, 8, 5.0, 6.0, 5.0, 1.0, 0, None, None, None, 0, None) == _native.CS_EINVAL
     with pytest.raises(ValueError):
         from comfystereo_amd import engine
         engine.make_params(1, 8, 8, 8, 8, 3, "none", "sideways", 1, 0, 0, 0.5, 1, False, 0, 6, 1, 0, 1)
@@ -82,3 +82,17 @@ def test_too_wide_frames_are_rejected_with_elimit():
     p.w = 64
     p.depth_w = 64
     assert L.cs_generate(ctypes.byref(p), fake, fake, fake, fake, fake, fake, fake, 16, None) == _native.CS_EWORKSPACE
+
+
+def test_debug_switches_are_explicit_and_release_builds_reject_the_phase_cutoffs():
+    """cs_debug_set is the only way to reach the development switches (the library never reads the environment); a
+    release build refuses the CS_DEBUG_DBG values that would leave outputs unwritten."""
+    L = _native.lib()
+    assert L.cs_debug_set(_native.DEBUG["dbg"], 17) == _native.CS_OK
+    assert L.cs_debug_set(_native.DEBUG["dbg"], 0) == _native.CS_OK
+    assert L.cs_debug_set(_native.DEBUG["dbg"], 12) == _native.CS_EINVAL and b"CS_DEV" in L.cs_last_error()
+    assert L.cs_debug_set(99, 1) == _native.CS_EINVAL
+    src = os.path.join(ROOT, "comfystereo_amd", "csrc")
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(src, f)).read(), f

@@ -120,3 +120,54 @@ def test_host_pipeline_equals_the_whole_batch(monkeypatch, fill, n, batch):
     node_out = NODE.generate(img, dep, 6.0, 0.2, "left-right", 0.1, 0.5, 2.0, UI[fill], 20.0, 20.0, True, 2.0, 3, batch)
     for g, r in zip(node_out, ref):
         assert torch.equal(g, r)
+
+
+@pytest.mark.parametrize("ui,key", [("Fill - Post-fill", "none_post"),
+                                    ("Fill - Reverse projection with Post-fill", "inverse_post"),
+                                    ("Fill - Hybrid Edge with fill", "hybrid_edge_plus")])
+def test_node_maps_the_strings_the_reference_keeps_out_of_its_combo_list(ui, key):
+    """reference GenerateStereo.py:97-99 still translates three strings whose combo entries are commented out (:56-57):
+    an API workflow passing them must get those techniques, not the gpu_warp fallback of unknown strings (:102)."""
+    from comfystereo_amd.GenerateStereo import FILL_TECHNIQUES, FILL_TECHNIQUE_MAPPING, StereoImageNode
+    from oracle import node_oracle
+    assert ui not in FILL_TECHNIQUES and FILL_TECHNIQUE_MAPPING[ui] == key
+    assert ui not in StereoImageNode.INPUT_TYPES()["required"]["fill_technique"][0]
+    n, h, w = 2, 40, 200
+    img = synth.image_f32(n, h, w, seed=5)
+    dep = synth.depth_batch("blobs", n, h, w, channels=3)
+    args = (6.0, 0.2, "left-right", 0.1, 0.5, 2.0)
+    got = StereoImageNode().generate(torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), *args, ui, 20.0, 20.0, False,
+                                     2.0, 6, 12)
+    want = node_oracle.generate(img, dep, *args, ui, 20.0, 20.0, False, depth_blur_falloff=2.0, depth_blur_vert_smooth=6,
+                                batch_size=12)
+    for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+        assert np.array_equal(g.cpu().numpy(), w_), name
+    unknown = StereoImageNode().generate(torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), *args, "no such fill",
+                                         20.0, 20.0, False, 2.0, 6, 12)
+    assert unknown[3].shape == (n, h, w)  # gpu_warp: eye-shaped mask
+
+
+def test_blur_with_zero_strength_is_blur_off():
+    """reference :1194 / :1050: direction-aware blur with strength <= 0 returns the depth unchanged."""
+    from comfystereo_amd import engine
+    n, h, w = 1, 32, 160
+    img = torch.from_numpy(synth.image_f32(n, h, w, seed=8)).cuda()
+    dep = torch.from_numpy(synth.depth_batch("blobs", n, h, w, channels=3)).cuda()
+    for fill in ("polylines_soft", "gpu_warp"):
+        a = engine.generate(img, dep, 5.0, 0.0, "left-right", 0.0, 0.5, 2.0, fill, 20.0, 0.0, True, 2.0, 6, 4)
+        b = engine.generate(img, dep, 5.0, 0.0, "left-right", 0.0, 0.5, 2.0, fill, 20.0, 20.0, False, 2.0, 6, 4)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), fill
+
+
+def test_blur_mask_width_is_independent_of_the_strength():
+    """directional_motion_blur_gpu(depth, strength, threshold, blur_mask_width, ...): the weights reach
+    int(blur_mask_width) pixels from an edge whatever the box width is (reference :1208-1209)."""
+    from comfystereo_amd import stereoimage_generation as sig
+    from oracle import oracle
+    depth = np.round(synth.blobs(270, 480, seed=1) * 255).astype(np.float32)
+    for s, t, mw, f, v in [(20, 20, 5, 2.0, 3), (20, 20, 33.7, 1.0, 0), (7.4, 6, 12, 2.0, 6)]:
+        L, R = sig.directional_motion_blur_gpu(torch.from_numpy(depth), s, t, mw, falloff_exponent=f, vert_smooth_px=v)
+        oL, oR = oracle.blur(depth, s, t, f, v, mask_width=mw)
+        assert np.array_equal(L.cpu().numpy().view(np.uint32), oL.view(np.uint32))
+        assert np.array_equal(R.cpu().numpy().view(np.uint32), oR.view(np.uint32))

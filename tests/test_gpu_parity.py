@@ -227,8 +227,8 @@ def test_blur_wide_kernel_takes_the_two_pass_path(engine):
     assert np.array_equal(R.cpu().numpy().view(np.uint32), oR.view(np.uint32))
 
 
-def test_blur_two_pass_env_override(engine, monkeypatch):
-    monkeypatch.setenv("CS_BLUR_TWO_PASS", "1")
+def test_blur_two_pass_switch(engine, dev_switch):
+    dev_switch("blur_two_pass", 1)
     depth = np.round(synth.blobs(300, 517, seed=3) * 255).astype(np.float32)
     L, R = engine.directional_blur(cuda(depth), 20, 20, 2.0, 6)
     oL, oR = oracle.blur(depth, 20, 20, 2.0, 6)
@@ -236,26 +236,26 @@ def test_blur_two_pass_env_override(engine, monkeypatch):
     assert np.array_equal(R.cpu().numpy().view(np.uint32), oR.view(np.uint32))
 
 
-def test_polylines_row_kernel_env_override(engine, monkeypatch):
-    """CS_NO_TILE=1 forces the general row kernel for every row: same result as the tiled fast path."""
+def test_polylines_row_kernel_switch(engine, dev_switch):
+    """cs_debug_set(CS_DEBUG_NO_TILE, 1) forces the general row kernel for every row: same result as the tiled fast path."""
     h, w = 24, 1500
     img = synth.image_u8(h, w, seed=11)
     depth = synth.blobs(h, w, seed=4) * np.float32(255)
     a = engine.apply_stereo_divergence(cuda(img), cuda(depth), 7.0, 0.3, 2.0, "polylines_soft", 0.5).cpu().numpy()
-    monkeypatch.setenv("CS_NO_TILE", "1")
+    dev_switch("no_tile", 1)
     b = engine.apply_stereo_divergence(cuda(img), cuda(depth), 7.0, 0.3, 2.0, "polylines_soft", 0.5).cpu().numpy()
     assert np.array_equal(a, b) and np.array_equal(a, oracle.apply_stereo_divergence(img, depth, 7.0, 0.3, 2.0, "polylines_soft", 0.5))
 
 
 @pytest.mark.parametrize("exponent", [2.0, 1.0])
-def test_polylines_exponent_shortcuts_env_override(engine, monkeypatch, exponent):
-    """CS_DBG=17 switches the tile kernel's exact shortcuts for exponents 2.0 / 1.0 off (full powf clone for every
+def test_polylines_exponent_shortcuts_switch(engine, dev_switch, exponent):
+    """cs_debug_set(CS_DEBUG_DBG, 17) switches the tile kernel's exact shortcuts for exponents 2.0 / 1.0 off (full powf clone for every
     pixel): identical output, and both equal the oracle."""
     h, w = 16, 1800
     img = synth.image_u8(h, w, seed=3)
     depth = synth.blobs(h, w, seed=9) * np.float32(255)
     a = engine.apply_stereo_divergence(cuda(img), cuda(depth), 6.5, 0.2, exponent, "polylines_soft", 0.4).cpu().numpy()
-    monkeypatch.setenv("CS_DBG", "17")
+    dev_switch("dbg", 17)
     b = engine.apply_stereo_divergence(cuda(img), cuda(depth), 6.5, 0.2, exponent, "polylines_soft", 0.4).cpu().numpy()
     assert np.array_equal(a, b)
     assert np.array_equal(a, oracle.apply_stereo_divergence(img, depth, 6.5, 0.2, exponent, "polylines_soft", 0.4))

@@ -1,6 +1,7 @@
 """Ad-hoc timing of the fused batch path (development aid; bench.py is the contract)."""
 import argparse
-import sys, os
+import os
+import sys
 import time
 
 import numpy as np
@@ -9,7 +10,13 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import synth
-from comfystereo_amd import engine
+from comfystereo_amd import engine, _native
+
+# development switches from the environment (tools only: the library itself never reads the environment)
+for _env, _key in (("CS_DBG", "dbg"), ("CS_NO_TILE", "no_tile"), ("CS_PT_VARIANT", "pt_variant"),
+                   ("CS_BLUR_TWO_PASS", "blur_two_pass"), ("CS_BLUR_EDGES_SCALAR", "blur_edges_scalar")):
+    if os.environ.get(_env):
+        _native.debug_set(_key, int(os.environ[_env]))
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=4)
