@@ -254,7 +254,12 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         uint32_t* list = count + 64;
         hipError_t e = hipMemsetAsync(rowflag, 0, al256(rows) + 256, stream);
         if (e != hipSuccess) return fail_hip(e, "rowflag memset");
-        e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, A, halo, rowflag, stream);
+        // soft: the point-owner kernel (cs_polypoint.hip) unless the halo is too wide for it or the development switch
+        // CS_DEBUG_PT_VARIANT >= 1 asks for the first generation (cs_polytile.hip); sharp: first generation
+        if (fill == CS_FILL_POLYLINES_SOFT && halo <= polypoint_max_halo() && dev_switch(CS_DEBUG_PT_VARIANT) == 0)
+            e = launch_polypoint(A, halo, rowflag, stream);
+        else
+            e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, A, halo, rowflag, stream);
         if (e != hipSuccess) return fail_hip(e, "tiled polylines launch");
         e = launch_collect_rows(rowflag, (int)rows, count, list, stream);
         if (e != hipSuccess) return fail_hip(e, "flagged-row collection");

@@ -66,6 +66,10 @@ size_t rowwarp_lds_bytes(int fill, int w);
 hipError_t launch_polytile(int sharp, const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream);
 int polytile_max_halo();
 
+// cs_polypoint.hip: second generation of the tiled path (polylines_soft): one lane per polyline point
+hipError_t launch_polypoint(const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream);
+int polypoint_max_halo();
+
 // cs_blur.hip: directional depth blur; if `scale_from_stats`, the input is multiplied by 255 for frames
 // whose stats say so, and the per-frame min/max of both outputs are accumulated into stats.
 int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double mask_width,

@@ -919,6 +919,7 @@ hipError_t launch_polytile(int sharp, const RowArgs& R, int S, uint8_t* rowflag,
     else if (sharp && variant == 2) PT_LAUNCH(1, 4, 6, 5)
     else if (sharp) PT_LAUNCH(1, 5, 7, 5)
     else if (variant == 1) PT_LAUNCH(0, 4, 6, 6)
+    else if (variant == 9) PT_LAUNCH(0, 4, 5, 7)
     else if (variant == 2) PT_LAUNCH(0, 3, 4, 7)
     else if (variant == 3) PT_LAUNCH(0, 6, 8, 6)
     else PT_LAUNCH(0, 4, 5, 7)
