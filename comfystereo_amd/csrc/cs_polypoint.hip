@@ -37,13 +37,23 @@ namespace cs {
 // registration, 34: no pass 2, 35: no general search).  Release builds compile the tests away.
 #ifdef CS_DEV
 #define PP_DEV_IS(n) (A.dbg == (n))
+// (development) why a row was handed to the general kernel: reason bits OR-ed into the frame's spare stats word 12
+#define PP_HAZARD(code) do { hazard = true; if (A.stats_rw) atomicOr(&A.stats_rw[(size_t)frame * ST_WORDS + 12], (unsigned)(code)); } while (0)
 #else
 #define PP_DEV_IS(n) false
+#define PP_HAZARD(code) do { hazard = true; } while (0)
 #endif
 #define PP_DCAP 128          // pixels under reversed segments a tile can hold in its lists (more -> row redo)
 #define PP_DIRTY 0x80u       // dflag: pixel lies under a reversed segment; low 7 bits = its list slot
 
 __constant__ csm::PowfTables c_pp_powf_tables = CS_POWF_TABLES_INIT;
+// k / 255 by true division (convertResult / np2tensor, reference GenerateStereo.py:41-44): evaluated by the compiler in IEEE
+// float32, copied to LDS by every workgroup
+struct Lut255 {
+    float v[256];
+    constexpr Lut255() : v() { for (int i = 0; i < 256; i++) v[i] = (float)i / 255.0f; }
+};
+__constant__ Lut255 c_pp_lut255 = Lut255();
 
 struct PolyPointArgs {
     int n, h, w, S, T;
@@ -57,7 +67,6 @@ struct PolyPointArgs {
     int single;
     uint8_t* out_u8;
     float* stereo; float* mask; float* depth_l; float* depth_r;
-    int stereo_is_u8;
     int out_h, out_w;
     uint8_t* rowflag;
     int dbg;
@@ -94,10 +103,11 @@ __device__ __forceinline__ float div_with(float a, float b, float y1) {
     return __builtin_fmaf(r1, y1, q1);
 }
 
-// lane i receives lane i + 1's value (lane 63: undefined) -- one DPP move instead of a ds_bpermute round trip
+// lane i receives lane i + 1's value, lane 63 +inf -- one DPP move instead of a ds_bpermute round trip
 __device__ __forceinline__ float wave_next(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x7f800000, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
 }
+__device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 
 // per-pixel constants of the float64 ("Python float") branch of the sub-interval arithmetic (reference :1957-1960)
 struct PixC { double sig_dd; float ff64, tf64, center64; };
@@ -109,20 +119,26 @@ __device__ __forceinline__ PixC pix_consts(int col) {
     return P;
 }
 
-enum { PF_HAZARD = 0, PF_NLIST = 1, PF_NDIRTY = 2, PF_DLO = 3, PF_DHI = 4, PF_WORDS = 8 };
+enum { PF_HAZARD = 0, PF_NLIST = 1, PF_NDIRTY = 2, PF_DLO = 3, PF_DHI = 4, PF_JLO = 5, PF_JHI = 6, PF_WORDS = 8 };
+// output forms: float32 node outputs / the uint8 codes of the stereoscope (cs_params.flags bit 1) / apply_stereo_divergence
+// (uint8 image in, uint8 image out, nothing else)
+enum { PO_F32 = 0, PO_U8 = 1, PO_ASD = 2 };
 // list entries: kind << 28 | point id << 12 | pixel (tile-local)
 enum { PK_CHAIN = 0u, PK_BRIDGE = 1u };
 
-template <int SLOTS, int PT_KP, int PT_KS, int MINW>
+template <int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW>
 __global__ void __launch_bounds__(PP_THREADS, MINW)
 k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
             int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, PolyPointArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = hot_T;
-    const int tiles = (hot_w + T - 1) / T;
-    const int bx = blockIdx.x, eyei = hot_single >= 0 ? hot_single : (int)blockIdx.z;
-    const int tile = bx % tiles, row = bx / tiles, frame = blockIdx.y;
+    // grid = (tiles, rows, frames x eyes): no integer division in the prologue (a scalar division costs ~30 SALU instructions,
+    // and the scalar unit is as busy as the vector units in this kernel)
+    const int tile = blockIdx.x, row = blockIdx.y;
+    const int zi = blockIdx.z;
+    const int eyei = hot_single >= 0 ? hot_single : (zi >= A.n ? 1 : 0);
+    const int frame = zi >= A.n ? zi - A.n : zi;
     EyeArgs E;
     E.depth = eyei ? hot_depth1 : hot_depth0;
     E.div32 = eyei ? A.eye[1].div32 : A.eye[0].div32;
@@ -136,20 +152,21 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     const int w = hot_w, h = hot_h;
     const int o0 = tile * T, wt = min(T, w - o0);
     const int s0 = max(0, o0 - hot_S - 1), s1 = min(w, o0 + wt + hot_S + 1), ns = s1 - s0;
-    const int nsmax = T + 2 * hot_S + 2;
     // local point ids: 0 = left sentinel (x = -w), 1 + j = source column s0 + j, ns + 1 = right sentinel (x = 2w); the
-    // sentinels only exist when the staged range touches the frame border
-    const int npts = ns + 2, nptmax = nsmax + 2;
+    // sentinels only matter when the staged range touches the frame border.  Every lane stages SLOTS points j = tid + 256 k;
+    // slots beyond the row end re-read the last column and get x = 2w + (j - ns): slot ns IS the right sentinel.
+    const int npts = ns + 2;
+    constexpr int NPT = SLOTS * PP_THREADS + 4;
     const bool left_edge = s0 == 0, right_edge = s1 == w;
 
     // ---- LDS carve ----
     float* lut = (float*)smem;                                                    // [256] k / 255
-    float4* P = (float4*)(smem + 1024);                                           // [nptmax] {x, R, G, B} of point o
-    float* pz = (float*)(P + nptmax);                                             // [nptmax] |coord_d| (fold tiles only)
-    csm::PowfTables* tabs = (csm::PowfTables*)pz;                                 //   (the powf tables until barrier 1)
+    float4* P = (float4*)(smem + 1024);                                           // [NPT] {R, G, B, x} of point o
+    float* pz = (float*)(P + NPT);                                                // [NPT] |coord_d|
+    uint32_t* plist = (uint32_t*)(pz + NPT);                                      // [max(T, 128)] pixels evaluated in pass 2
+    csm::PowfTables* tabs = (csm::PowfTables*)plist;                              //   (until barrier 1: the powf tables, 512 bytes)
     static_assert(sizeof(csm::PowfTables) == 512, "tables overlay");
-    uint32_t* plist = (uint32_t*)(pz + max((nptmax + 3) & ~3, 128));              // [T] pixels evaluated in pass 2
-    uint8_t* dflag = (uint8_t*)(plist + T);                                       // [T] PP_DIRTY | slot
+    uint8_t* dflag = (uint8_t*)(plist + max(T, 128));                             // [T] PP_DIRTY | slot
     uint16_t* dcnt = (uint16_t*)(dflag + ((T + 3) & ~3));                         // [DCAP] points (low 8) | segments (high 8)
     uint16_t* dpix = dcnt + PP_DCAP;                                              // [DCAP] pixel of the slot
     uint16_t* pts = dpix + PP_DCAP;                                               // [DCAP][PT_KP]
@@ -157,44 +174,43 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     int* flags = (int*)(sgs + PP_DCAP * PT_KS);                                   // [PF_WORDS]
 
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
-    const size_t rowpix = ((size_t)frame * h + row) * w;
-    // ---- all global loads first: depth and image of the lane's points ----
-    const float* drow = E.depth + rowpix;
+    const uint32_t rowpix = ((uint32_t)frame * (uint32_t)h + (uint32_t)row) * (uint32_t)w;   // pixel index < 2^31 (checked on the host)
+    // ---- all global loads first: depth and image of the lane's points (clamped to the staged range: no branches) ----
+    const float* drow = E.depth + rowpix + s0;
     float dpre[SLOTS];
     F3 cpre[SLOTS];
+    B3 cpre8[SLOTS];
     const F3* irow = reinterpret_cast<const F3*>(hot_image) + rowpix + s0;
     const B3* irow8 = reinterpret_cast<const B3*>(A.image_u8) + rowpix + s0;
 #pragma unroll
     for (int k = 0; k < SLOTS; k++) {
-        const int j = tid + k * PP_THREADS;
-        dpre[k] = j < ns ? drow[s0 + j] : 0.0f;
-        cpre[k] = F3{0.f, 0.f, 0.f};
-        if (j < ns) {
-            if (hot_image) cpre[k] = irow[j];
-            else { const B3 b = irow8[j]; cpre[k] = F3{(float)b.x, (float)b.y, (float)b.z}; }
-        }
+        const int jc = min(tid + k * PP_THREADS, ns - 1);
+        dpre[k] = drow[jc];
+        if (OUT == PO_ASD) cpre8[k] = irow8[jc];
+        else cpre[k] = irow[jc];
     }
     const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
-    const float dmin = eye_on ? csm::ord2f(st[E.st_min]) : 0.0f, dmax = eye_on ? csm::ord2f(st[E.st_max]) : 0.0f;
+    const float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
+    // depth * 255 inside the int32 range everywhere in this frame?  (else: the exact x86 conversion for the depth-map codes)
+    const bool code_wraps = !(fmaxf(fabsf(dmin), fabsf(dmax)) < 8.0e6f);
 
     // LDS set-up in the shadow of the loads
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_pp_powf_tables);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(tabs);
-        if (tid < (int)(sizeof(csm::PowfTables) / 4)) dst[tid] = src[tid];
-    }
-    lut[tid] = (float)tid / 255.0f;  // PP_THREADS == 256
-    for (int i = tid; i < (T + 3) / 4; i += PP_THREADS) reinterpret_cast<uint32_t*>(dflag)[i] = 0;
+    if (tid < (int)(sizeof(csm::PowfTables) / 4))
+        reinterpret_cast<uint32_t*>(tabs)[tid] = reinterpret_cast<const uint32_t*>(&c_pp_powf_tables)[tid];
+    lut[tid] = c_pp_lut255.v[tid];  // PP_THREADS == 256
+    if (tid < (T + 3) / 4) reinterpret_cast<uint32_t*>(dflag)[tid] = 0;   // T <= 1024
     if (tid < PP_DCAP / 2) reinterpret_cast<uint32_t*>(dcnt)[tid] = 0;
-    if (tid < PF_WORDS) flags[tid] = tid == PF_DLO ? 0x7fffffff : (tid == PF_DHI ? -1 : 0);
-    __syncthreads();  // tables, flags
+    if (tid < PF_WORDS) {   // minima start at INT_MAX, maxima at -1, counters at 0
+        constexpr unsigned is_min = (1u << PF_DLO) | (1u << PF_JLO), is_max = (1u << PF_DHI) | (1u << PF_JHI);
+        flags[tid] = (int)(0x7fffffffu * ((is_min >> tid) & 1u)) | -(int)((is_max >> tid) & 1u);
+    }
+    __syncthreads();  // barrier 0: tables, flags
 
     const float o0f = (float)o0, o1f = (float)(o0 + wt);   // tile = [o0f, o1f)
     bool hazard = false;
     // ---- pixels under the reversed segment (xa -> xb), xb <= xa: slots in the tile's lists.  Called by whole waves.
-    auto mark_reversed = [&](bool rev, float xa, float xb) {
-        unsigned long long m = __ballot(rev);
-        if (!m) return;
+    auto mark_reversed = [&](unsigned long long m, float xa, float xb) {
+        const bool rev = (m >> lane) & 1ull;
         int lo = 0, n = 0, base = 0;
         if (rev) {
             const float fl = fmaxf(floorf(xb), o0f), fh = fminf(floorf(xa), o1f - 1.0f);
@@ -214,57 +230,106 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             for (int i = lane; i < ln; i += 64) {
                 const int s = lbase + i;
                 if (s < PP_DCAP) { dflag[llo + i] = (uint8_t)(PP_DIRTY | s); dpix[s] = (uint16_t)(llo + i); }
-                else hazard = true;
+                else PP_HAZARD(2);
             }
         }
+    };
+    // ---- output rows of this tile: 32-bit offsets from wave-uniform bases ----
+    const uint32_t obase = OUT == PO_ASD ? (rowpix + (uint32_t)o0)
+                                         : (((uint32_t)frame * (uint32_t)A.out_h + (uint32_t)(row + E.yoff)) * (uint32_t)A.out_w + (uint32_t)(E.xoff + o0));
+    char* const st_row = OUT == PO_ASD ? (char*)A.out_u8 + (size_t)obase * 3 : (OUT == PO_U8 ? (char*)A.stereo + (size_t)obase * 3 : (char*)A.stereo + (size_t)obase * 12);
+    char* const mk_row = OUT == PO_ASD ? nullptr : (char*)A.mask + (size_t)obase * 4;
+    auto emit = [&](int q, int r, int g, int b) {   // colour codes 0..255 of tile pixel q
+        const uint32_t uq = (uint32_t)q;
+        if (OUT == PO_F32) *reinterpret_cast<F3*>(st_row + 12u * uq) = F3{lut[r], lut[g], lut[b]};
+        else *reinterpret_cast<B3*>(st_row + 3u * uq) = B3{(uint8_t)r, (uint8_t)g, (uint8_t)b};
+        if (OUT != PO_ASD) *reinterpret_cast<float*>(mk_row + 4u * uq) = (r | g | b) == 0 ? 1.0f : 0.0f;
     };
 
     // =====================================================================================================
     // phase B: stage the lane's points: colour codes as floats, the libm-exact disparity -> x, reversed segments
     // =====================================================================================================
-    float px_[SLOTS], pzv[SLOTS], cr[SLOTS], cg[SLOTS], cb[SLOTS];
-    int dcode[SLOTS];
-#pragma unroll
-    for (int k = 0; k < SLOTS; k++) { px_[k] = 0.f; pzv[k] = 0.f; cr[k] = cg[k] = cb[k] = 0.f; dcode[k] = 0; }
-    // colour: np.clip(x * 255, 0, 255).astype(uint8) (reference :1508) as the float value of the code
+    // colour: np.clip(x * 255, 0, 255).astype(uint8) (reference :1508) as the float value of the code -> P[o].rgb right away
+    // (slots beyond the row end hold the last column's colour: slot ns is the right sentinel, :1935)
+    const int qoff = s0 - o0;
 #pragma unroll
     for (int k = 0; k < SLOTS; k++) {
-        if (hot_image) {
-            cr[k] = truncf(__builtin_amdgcn_fmed3f(cpre[k].x * 255.0f, 0.0f, 255.0f));
-            cg[k] = truncf(__builtin_amdgcn_fmed3f(cpre[k].y * 255.0f, 0.0f, 255.0f));
-            cb[k] = truncf(__builtin_amdgcn_fmed3f(cpre[k].z * 255.0f, 0.0f, 255.0f));
-        } else { cr[k] = cpre[k].x; cg[k] = cpre[k].y; cb[k] = cpre[k].z; }
+        F3 c;
+        if (OUT == PO_ASD) c = F3{(float)cpre8[k].x, (float)cpre8[k].y, (float)cpre8[k].z};
+        else c = F3{truncf(__builtin_amdgcn_fmed3f(cpre[k].x * 255.0f, 0.0f, 255.0f)),
+                    truncf(__builtin_amdgcn_fmed3f(cpre[k].y * 255.0f, 0.0f, 255.0f)),
+                    truncf(__builtin_amdgcn_fmed3f(cpre[k].z * 255.0f, 0.0f, 255.0f))};
+        *reinterpret_cast<F3*>(P + 1 + tid + k * PP_THREADS) = c;
+        if (k == 0 && tid == 0) *reinterpret_cast<F3*>(P) = c;   // left sentinel (:1921): the first column's colour
     }
-    if (eye_on) {
+    // this eye's depth-map output: (depth * 255).astype(uint8) wraps mod 256 (quirk Q7), value code / 255 on three channels
+    if (OUT != PO_ASD) {
+        float* const dd = eyei == 0 ? A.depth_l : A.depth_r;
+        char* const dd_row = (char*)dd + (size_t)(rowpix + (uint32_t)o0) * 12;
+        int code[SLOTS];
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) code[k] = (int)((dpre[k] * scale) * 255.0f) & 0xff;
+        if (code_wraps) {
+#pragma unroll
+            for (int k = 0; k < SLOTS; k++) code[k] = (int)csm::f32_to_u8_wrap((dpre[k] * scale) * 255.0f);
+        }
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) {
+            const int q = tid + k * PP_THREADS + qoff;   // tile pixel of this source column
+            if ((unsigned)q < (unsigned)wt) {
+                const float v = lut[code[k]];
+                *reinterpret_cast<F3*>(dd_row + 12u * (uint32_t)q) = F3{v, v, v};
+            }
+        }
+    }
+    if (!eye_on) {   // divergence < 0.001 for this eye: the source image (quirk Q10); rare, kept out of the hot path
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) {
+            const int q = tid + k * PP_THREADS + qoff;
+            const float4 c = P[1 + tid + k * PP_THREADS];
+            if ((unsigned)q < (unsigned)wt) emit(q, (int)c.x, (int)c.y, (int)c.z);
+        }
+        return;
+    }
+    {
         const bool flat = dmax == dmin;
         const float range = dmax - dmin;
-        // (d - dmin) / range with the refined reciprocal of the frame's range computed once; ranges near the float32 limits
-        // (never seen: depth maps are 0..255) take the plain division
+        // (d - dmin) / range through the refined reciprocal of the frame's range, computed once.  The residual steps need
+        // numerators that are 0 or >= 2^-60 and a range within 2^+-40 (depth maps are 0..255); otherwise: plain division.
         const bool range_ok = range > 0x1p-40f && range < 0x1p40f;
         const float yr = range_ok ? rcp_refined(range) : 0.0f;
         const int pow_mode = A.dbg == 17 ? 0 : (A.e32 == 2.0f ? 2 : (A.e32 == 1.0f ? 1 : 0));
-        float sg[SLOTS], axs[SLOTS], pw[SLOTS];
-        unsigned risk = 0;
+        float sg[SLOTS], axs[SLOTS], pw[SLOTS], av[SLOTS];
+        uint32_t amin = 0xffffffffu;
 #pragma unroll
         for (int k = 0; k < SLOTS; k++) {
-            const int j = tid + k * PP_THREADS;
-            const float d = dpre[k] * scale;
-            // depth-map output code of this column: (depth * 255).astype(uint8) wraps mod 256 (quirk Q7)
-            dcode[k] = csm::f32_to_u8_wrap(d * 255.0f);
-            const float a = d - dmin;
-            // (numerators below 2^-60 other than 0 -- differences of denormal-sized depths -- would round inside the residuals)
-            float nq = div_with(a, range, yr);
-            if (__any(j < ns && !(range_ok && (a == 0.0f || (a >= 0x1p-60f && a < 0x1p60f))))) {
-                asm volatile("" ::: "memory");  // (keeps the compiler from speculating the slow division into the hot path)
-                nq = a / range;
-            }
-            const float nd = flat ? 0.0f - A.conv32 : nq - A.conv32;
+            av[k] = dpre[k] * scale - dmin;
+            amin = min(amin, __builtin_bit_cast(uint32_t, av[k]) - 1u);   // 0 -> 0xffffffff; negative (never) -> huge
+        }
+        const bool slow_div = __any(amin < 0x21800000u - 1u) || !range_ok;   // some 0 < a < 2^-60
+        unsigned risk = 0;
+        float nqv[SLOTS];
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) nqv[k] = div_with(av[k], range, yr);
+        if (slow_div) {
+            asm volatile("" ::: "memory");  // (keeps the compiler from speculating the slow division into the hot path)
+#pragma unroll
+            for (int k = 0; k < SLOTS; k++) nqv[k] = av[k] / range;
+        }
+        if (flat) {
+#pragma unroll
+            for (int k = 0; k < SLOTS; k++) nqv[k] = 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) {
+            const float nd = nqv[k] - A.conv32;
             sg[k] = nd >= 0.0f ? 1.0f : -1.0f;
             axs[k] = fabsf(nd);
             bool r = false;
             pw[k] = pow_mode == 1 ? axs[k] : (pow_mode == 2 ? csm::square_or_flag(axs[k], r) : 0.0f);
             if (pow_mode == 0) r = true;
-            risk |= (r && j < ns) ? 1u << k : 0u;
+            risk |= r ? 1u << k : 0u;
         }
         while (__any(risk != 0u)) {  // the full powf clone for the risky arguments (all of them for other exponents)
             float xin = 1.0f;
@@ -276,78 +341,53 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             for (int k = 0; k < SLOTS; k++) if (sel == k) pw[k] = r;
             risk &= risk - 1u;
         }
-        const float jf0 = (float)(s0 + tid) + 0.5f;  // exact: integers + 0.5 below 2^23
+        const float tidf = (float)tid;
+        const float jf0 = (float)s0 + tidf + 0.5f;  // exact: integers + 0.5 below 2^23
+        int wjlo = 0x7fffffff, wjhi = -1;
+        float* const Pxw = reinterpret_cast<float*>(P + 1 + tid) + 3;
+        float* const pzw = pz + 1 + tid;
 #pragma unroll
         for (int k = 0; k < SLOTS; k++) {
             const int j = tid + k * PP_THREADS;
             const float cdj = (sg[k] * pw[k]) * E.div32;                                   // coord_d   (:1926)
-            const float x = ((jf0 + (float)(k * PP_THREADS)) + cdj) + E.sep32;             // coord_x   (:1927)
-            px_[k] = x;
-            pzv[k] = fabsf(cdj);
-            if (j < ns) P[1 + j] = make_float4(x, cr[k], cg[k], cb[k]);
-            // reversed segment (j -> j+1)?  The right neighbour sits in the next lane; the pairs across wave chunks and the
-            // sentinel pairs are checked after the barrier.
+            float x = ((jf0 + (float)(k * PP_THREADS)) + cdj) + E.sep32;                   // coord_x   (:1927)
+            // slots beyond the staged range: x = 2w + (j - ns), strictly increasing, slot ns = the right sentinel (:1935)
+            x = j < ns ? x : tidf + (float)(2 * w - ns + k * PP_THREADS);
+            Pxw[4 * k * PP_THREADS] = x;
+            pzw[k * PP_THREADS] = fabsf(cdj);
+            // reversed segment (j -> j+1)?  The right neighbour sits in the next lane (lane 63: +inf; the pairs across wave
+            // chunks and the left sentinel's pair are checked after the barrier).
             const float xn = wave_next(x);
-            const bool rev = lane != 63 && j + 1 < ns && !(x < xn);
-            mark_reversed(rev, x, xn);
+            const unsigned long long mrev = __ballot(!(x < xn));
+            if (mrev) mark_reversed(mrev, x, xn);
+            // the range of points that can lie in the tile: first j with x >= o0, last j with x < o0 + wt (wave-uniform
+            // candidates from ballots; one pair of atomics per wave below)
+            const unsigned long long m1 = __ballot(x >= o0f), m2 = __ballot(x < o1f);
+            const int base = k * PP_THREADS + wave * 64;
+            wjlo = min(wjlo, m1 ? base + __ffsll((long long)m1) - 1 : 0x7fffffff);
+            wjhi = max(wjhi, m2 ? base + 63 - __clzll((long long)m2) : -1);
         }
-        if (tid == 0) {  // sentinels (:1921, :1935): they refer to the first / last source column
-            if (left_edge) P[0] = make_float4((float)(-1.0 * w), cr[0], cg[0], cb[0]);
-        }
-        if (right_edge) {
-#pragma unroll
-            for (int k = 0; k < SLOTS; k++)
-                if (tid + k * PP_THREADS == ns - 1) P[npts - 1] = make_float4((float)(2.0 * w), cr[k], cg[k], cb[k]);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < SLOTS; k++) dcode[k] = csm::f32_to_u8_wrap((dpre[k] * scale) * 255.0f);
+        if (lane == 0) { atomicMin(&flags[PF_JLO], wjlo); atomicMax(&flags[PF_JHI], wjhi); }
+        if (tid == 0) P[0].w = (float)(-1.0 * w);   // left sentinel (:1921) at the frame border
     }
     __syncthreads();  // barrier 1: points staged, in-wave reversed segments marked
     if (PP_DEV_IS(31)) return;
 
-    // ---- output helpers -------------------------------------------------------------------------------
-    const size_t obase = A.out_u8 ? (rowpix + o0) : (((size_t)frame * A.out_h + row + E.yoff) * A.out_w + E.xoff + o0);
-    auto emit = [&](int q, int r, int g, int b) {   // colour codes 0..255 of tile pixel q
-        if (A.out_u8) {
-            reinterpret_cast<B3*>(A.out_u8)[obase + q] = B3{(uint8_t)r, (uint8_t)g, (uint8_t)b};
-        } else {
-            if (A.stereo_is_u8) reinterpret_cast<B3*>(A.stereo)[obase + q] = B3{(uint8_t)r, (uint8_t)g, (uint8_t)b};
-            else reinterpret_cast<F3*>(A.stereo)[obase + q] = F3{lut[r], lut[g], lut[b]};
-            A.mask[obase + q] = (r | g | b) == 0 ? 1.0f : 0.0f;
-        }
-    };
-    // this eye's depth-map output (code -> k / 255 on the three channels) and, for a disabled eye, the source image
-    {
-        float* dd = A.out_u8 ? nullptr : (eyei == 0 ? A.depth_l : A.depth_r);
-#pragma unroll
-        for (int k = 0; k < SLOTS; k++) {
-            const int j = tid + k * PP_THREADS;
-            const int q = s0 + j - o0;
-            if (j < ns && q >= 0 && q < wt) {
-                if (dd) { const float v = lut[dcode[k] & 0xff]; reinterpret_cast<F3*>(dd)[rowpix + o0 + q] = F3{v, v, v}; }
-                if (!eye_on) emit(q, (int)cr[k], (int)cg[k], (int)cb[k]);
-            }
-        }
-    }
-    if (!eye_on) return;
-
-    // ---- the segment pairs the staging loop could not see (lane 63 of every chunk, the sentinel pairs): every wave
+    // ---- the segment pairs the staging loop could not see (lane 63 of every chunk, the left sentinel's pair): every wave
     // computes the same answer; wave 0 marks, and only then a barrier is needed (rare)
     {
         const int nb = (ns - 1) >> 6;  // pairs (j, j+1) with j = 64 b + 63
         bool any = false;
-        for (int b0 = 0; b0 < nb + 2; b0 += 64) {
+        for (int b0 = 0; b0 < nb + 1; b0 += 64) {
             const int b = b0 + lane;
             int o = -1;
             if (b < nb) o = 1 + 64 * b + 63;
             else if (b == nb && left_edge) o = 0;
-            else if (b == nb + 1 && right_edge) o = npts - 2;
-            const float xa = o >= 0 ? P[o].x : 0.0f, xb = o >= 0 ? P[o + 1].x : 1.0f;
-            const bool rev = o >= 0 && !(xa < xb);
-            if (__any(rev)) {
+            const float xa = o >= 0 ? P[o].w : 0.0f, xb = o >= 0 ? P[o + 1].w : 1.0f;
+            const unsigned long long mrev = __ballot(o >= 0 && !(xa < xb));
+            if (mrev) {
                 any = true;
-                if (wave == 0) mark_reversed(rev, xa, xb);
+                if (wave == 0) mark_reversed(mrev, xa, xb);
             }
         }
         if (any) __syncthreads();
@@ -355,126 +395,112 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     const int ndirty = min(flags[PF_NDIRTY], PP_DCAP);
     const bool fold_tile = flags[PF_NDIRTY] > 0;
     const int dlo = flags[PF_DLO], dhi = flags[PF_DHI];
-    if (flags[PF_NDIRTY] > PP_DCAP) hazard = true;
-
+    if (flags[PF_NDIRTY] > PP_DCAP) PP_HAZARD(1);
+    // points that can lie in the tile, plus the one before them (its segment may bridge into the tile); sentinels excluded
+    const int jlo = max(flags[PF_JLO] - 1, 0), jhi = min(flags[PF_JHI], ns - 1);
+    if (tid == 0) { pz[0] = 0.0f; pz[npts - 1] = 0.0f; }   // sentinels (:1921, :1935); read after barrier 2
     if (PP_DEV_IS(32)) return;
+
     auto list_push = [&](uint32_t kind, int o, int q) {
         const unsigned idx = atomicAdd((unsigned*)&flags[PF_NLIST], 1u);
         if (idx < (unsigned)T) plist[idx] = (kind << 28) | ((uint32_t)o << 12) | (uint32_t)q;
-        else hazard = true;
+        else PP_HAZARD(4);
     };
     const float eps32 = (float)1e-7;
     const float sig_whole = 0x1.fffffap-1f;  // (float)((col + 1 - 1e-7) - (col + 1e-7)) for every col >= 2 (tests/test_cs_math_host.py)
+    const float tlo = o0f - 0.5f, thi = o1f - 0.5f;
+    const bool edge_tile = left_edge || right_edge;
 
     // =====================================================================================================
-    // phase C: every point looks at its pixel
+    // phase C: every point that can lie in the tile looks at its pixel (lanes densely packed over [jlo, jhi])
     // =====================================================================================================
-#pragma unroll
-    for (int k = 0; k < SLOTS; k++) {
-        const int j = tid + k * PP_THREADS;
+    for (int jb = jlo; jb <= jhi; jb += PP_THREADS) {
+        // (every lane runs the body -- the cooperative loops below need whole waves -- lanes beyond jhi re-read point jhi
+        // and are kept from acting by `act`)
+        const bool act = jb + tid <= jhi;
+        const int j = min(jb + tid, jhi);
         const int o = 1 + j;
-        const bool valid = j < ns;
-        const float x = px_[k];
-        const float4 pm = P[valid ? o - 1 : 0], pp = P[valid ? o + 1 : 0];
-        if (fold_tile && valid) pz[o] = pzv[k];
-        if (fold_tile && k == 0 && tid == 0) { pz[0] = 0.0f; pz[npts - 1] = 0.0f; }   // sentinels (:1921, :1935)
-        const float xm = pm.x, xp = pp.x;
-        const float f0 = floorf(x), f0p1 = f0 + 1.0f;
-        const bool has_m = valid && (j >= 1 || left_edge), has_p = valid && (j + 1 < ns || right_edge);
-        const bool in_tile = valid && f0 >= o0f && f0 < o1f;
-        const int q = in_tile ? (int)f0 - o0 : 0;
-        // is this point the first one of its pixel / the only one?  (a pixel under a reversed segment is nobody's)
-        const bool first = in_tile && has_m && xm < f0;
-        const bool single = has_p && !(xp < f0p1);
+        const float4 pm = P[o - 1], pc = P[o], pp = P[o + 1];
+        const float x = pc.w, xm = pm.w, xp = pp.w;
+        const float f0 = floorf(x), f1 = floorf(xp), f0p1 = f0 + 1.0f;
+        // ---- the fast path: one point in the pixel, two pieces [col, x] and [x, col+1] on the segments (o-1 -> o),
+        // (o -> o+1).  Piece 0: from = col + eps (-> col in float32 for col >= 2), to = x - eps; piece 1: from = x + eps,
+        // to = col + 1 - eps (-> col + 1).
+        const float tf0 = x - eps32, sig0 = tf0 - f0, c0 = f0 + 0.5f * sig0;
+        const float ff1 = x + eps32, sig1 = f0p1 - ff1, c1 = ff1 + 0.5f * sig1;
+        const float den0 = x - xm, den1 = xp - x;
+        // Conditions as positive margins (a < b <=> b - a > 0 for finite floats), merged by min:
+        //   first point of a pixel of this tile:  xm < col, o0 <= col < o0 + wt
+        //   the only one:                         floor(xp) > col
+        //   both chain segments forward:          xm < x < xp
+        //   col >= 2 (closed-form float64 constants), x > col (else piece 1 starts at the Python-float col + eps), and
+        //   piece 1's centre right of x (its segment is active there); everything else the reference checks follows:
+        //   col <= c0 <= x - eps, c1 <= col + 1 <= xp  (monotone rounding of exact sums).
+        const float g_first = fmin3(f0 - xm, f0 - tlo, thi - f0);
+        float g = fmin3(fmin3(den0, den1, (f1 - f0) - 0.5f), fmin3(sig0, f0 - 1.5f, c1 - x), g_first);
+        // a sentinel neighbour makes a "flat" piece (other typing): frame-border tiles only
+        if (edge_tile) g = fminf(g, fminf((float)j - 0.5f, (float)(ns - 1 - j) - 0.5f));
+        const int q = (int)f0 - o0;
         bool dirty = false;
-        if (fold_tile) dirty = in_tile && (dflag[q] & PP_DIRTY) != 0;
-        // ---- the fast path: one point, two pieces [col, x] and [x, col+1] on the segments (o-1 -> o), (o -> o+1).
-        // Needs real neighbours (a sentinel piece is "flat": other typing), col >= 2 (closed-form float64 constants) and
-        // x > col (else the second piece starts at the Python-float col + eps).
-        bool fast = first && single && !dirty && j >= 1 && j + 1 < ns && f0 >= 2.0f && x > f0;
+        if (fold_tile) dirty = g_first > 0.0f && (dflag[q] & PP_DIRTY) != 0;
+        const bool fast = g > 0.0f && !dirty && act;
         {
-            const float tf0 = x - eps32;                // piece 0: from = col + eps (-> col as float32), to = x - eps
-            const float sig0 = tf0 - f0;
-            const float c0 = f0 + 0.5f * sig0;
-            const float ff1 = x + eps32;                // piece 1: from = x + eps, to = col + 1 - eps (-> col + 1)
-            const float sig1 = f0p1 - ff1;
-            const float c1 = ff1 + 0.5f * sig1;
-            const bool w0 = sig0 != 0.0f, w1 = sig1 != 0.0f;
-            // the two chain segments are forward and active at their piece's centre, centres monotone inside the pixel
-            bool ok = xm < x && x < xp;
-            ok = ok && !(c0 < f0) && !(c1 < c0) && !(c1 > f0p1);
-            ok = ok && (!w0 || (xm < c0 && !(x < c0))) && (!w1 || (x < c1 && !(xp < c1)));
-            const bool listed = first && !dirty && !(fast && ok);   // several points / special typing -> pass 2
-            fast = fast && ok;
-            if (__any(fast)) {
-                const float ip0 = div_core(c0 - xm, x - xm), ip1 = div_core(c1 - x, xp - x);
-                const float om0 = 1.0f - ip0, om1 = 1.0f - ip1;
-                // (a piece of length zero adds exactly 0: no select needed; the lerp operands are finite)
-                float k0 = 0.5f + (pm.y * om0 + cr[k] * ip0) * sig0;
-                float k1 = 0.5f + (pm.z * om0 + cg[k] * ip0) * sig0;
-                float k2 = 0.5f + (pm.w * om0 + cb[k] * ip0) * sig0;
-                k0 = k0 + (cr[k] * om1 + pp.y * ip1) * sig1;
-                k1 = k1 + (cg[k] * om1 + pp.z * ip1) * sig1;
-                k2 = k2 + (cb[k] * om1 + pp.w * ip1) * sig1;
-                if (fast) emit(q, (int)k0 & 0xff, (int)k1 & 0xff, (int)k2 & 0xff);
-            }
-            if (__any(listed)) { if (listed) list_push(PK_CHAIN, o, q); }
+            const float ip0 = div_core(c0 - xm, den0), ip1 = div_core(c1 - x, den1);
+            const float om0 = 1.0f - ip0, om1 = 1.0f - ip1;
+            // (both pieces have positive length here; the lerp operands are finite)
+            float k0 = 0.5f + (pm.x * om0 + pc.x * ip0) * sig0;
+            float k1 = 0.5f + (pm.y * om0 + pc.y * ip0) * sig0;
+            float k2 = 0.5f + (pm.z * om0 + pc.z * ip0) * sig0;
+            k0 = k0 + (pc.x * om1 + pp.x * ip1) * sig1;
+            k1 = k1 + (pc.y * om1 + pp.y * ip1) * sig1;
+            k2 = k2 + (pc.z * om1 + pp.z * ip1) * sig1;
+            if (fast) emit(q, (int)k0 & 0xff, (int)k1 & 0xff, (int)k2 & 0xff);
         }
-        // ---- pixels strictly between the end pixels of the forward segment (o -> o+1): disocclusion bridges, one piece
-        // each; appended to the list (a run of up to 3 pixels by its lane, longer ones by the whole wave)
-        if (!PP_DEV_IS(33)) {
-            const float f1 = floorf(xp);
-            const bool fwd = has_p && x < xp;
+        // the first point of a pixel that is not done yet: several points / special typing -> pass 2 (chain path)
+        if (g_first > 0.0f && !fast && !dirty && act) list_push(PK_CHAIN, o, q);
+        // ---- pixels strictly between the end pixels of the forward segment (o -> o+1): disocclusion bridges, one
+        // piece each, appended to the list (a run of up to 3 pixels by its lane, longer ones by the whole wave)
+        const float nbr = fmin3(den1, (f1 - f0) - 1.5f, fminf(f1 - o0f - 0.5f, (o1f - 1.5f) - f0));
+        const bool has_seg = act && (j + 1 < ns || right_edge);   // the segment (o -> o+1) exists and is this lane's
+        const bool has_bridge = nbr > 0.0f && has_seg && !PP_DEV_IS(33);
+        if (__any(has_bridge)) {
             int pa = 1, pb = 0;
-            if (fwd && f1 - f0 >= 2.0f && !(f1 <= o0f || f0 >= o1f - 1.0f)) {
+            if (has_bridge) {
                 pa = f0 < o0f ? 0 : (int)f0 + 1 - o0;
                 pb = f1 > o1f - 1.0f ? wt - 1 : (int)f1 - 1 - o0;
             }
-            // the left sentinel's segment (0 -> 1) belongs to the lane of point 1
-            int sa = 1, sb = 0;
-            if (left_edge && j == 0 && valid) {
-                const float fs = floorf(x);  // pixels 0 .. floor(x1) - 1 lie under the sentinel segment: this tile's share
-                if (fs - 1.0f >= o0f) { sa = 0; sb = min((int)fs - 1 - o0, wt - 1); }
-            }
-            const int nrun = pb - pa + 1, nsen = sb - sa + 1;
-            if (__any(nrun > 0 || nsen > 0)) {
-                const bool is_long = nrun > 3;
-                if (nrun > 0 && !is_long) {
+            const bool is_long = pb - pa + 1 > 3;
+            if (pb >= pa && !is_long) {
 #pragma unroll
-                    for (int t = 0; t < 3; t++) {
-                        const int p = pa + t;
-                        if (p <= pb && !(fold_tile && (dflag[p] & PP_DIRTY))) list_push(PK_BRIDGE, o, p);
-                    }
+                for (int t = 0; t < 3; t++) {
+                    const int p = pa + t;
+                    if (p <= pb && !(fold_tile && (dflag[p] & PP_DIRTY))) list_push(PK_BRIDGE, o, p);
                 }
-                unsigned long long m = __ballot(is_long);
-                while (m) {
-                    const int src = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const int lpa = __builtin_amdgcn_readlane(pa, src), lpb = __builtin_amdgcn_readlane(pb, src),
-                              lo = __builtin_amdgcn_readlane(o, src);
-                    for (int p = lpa + lane; p <= lpb; p += 64)
-                        if (!(fold_tile && (dflag[p] & PP_DIRTY))) list_push(PK_BRIDGE, lo, p);
-                }
-                for (int p = sa; p <= sb; p++)   // (frame border only) sentinel pieces: the chain path knows their typing
-                    if (!(fold_tile && (dflag[p] & PP_DIRTY))) list_push(PK_BRIDGE, 0, p);
+            }
+            unsigned long long m = __ballot(is_long);
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int lpa = __builtin_amdgcn_readlane(pa, src), lpb = __builtin_amdgcn_readlane(pb, src),
+                          lo = __builtin_amdgcn_readlane(o, src);
+                for (int p = lpa + lane; p <= lpb; p += 64)
+                    if (!(fold_tile && (dflag[p] & PP_DIRTY))) list_push(PK_BRIDGE, lo, p);
             }
         }
         // ---- fold tiles: points and forward segments over the pixels under reversed segments go into those pixels' lists
         if (fold_tile && !PP_DEV_IS(33)) {
-            if (dirty) {
+            const bool in_tile = fminf(f0 - tlo, thi - f0) > 0.0f && act;
+            if (in_tile && (dflag[q] & PP_DIRTY)) {
                 const int s = dflag[q] & 0x7f;
                 const unsigned idx = atomic_add_u16(dcnt, s, 1u) & 0xffu;
                 if (idx < PT_KP) pts[s * PT_KP + idx] = (uint16_t)o;
-                else hazard = true;
+                else PP_HAZARD(8);
             }
             int p0 = 1, p1 = 0;
-            if (has_p && x < xp) {
-                const float f1 = floorf(xp);
-                if (!(f1 < o0f || f0 > o1f - 1.0f)) {
-                    p0 = f0 < o0f ? 0 : (int)f0 - o0;
-                    p1 = f1 > o1f - 1.0f ? wt - 1 : (int)f1 - o0;
-                    p0 = max(p0, dlo); p1 = min(p1, dhi);   // only the dirty stretch of the tile matters
-                }
+            if (den1 > 0.0f && has_seg && !(f1 < o0f || f0 > o1f - 1.0f)) {
+                p0 = f0 < o0f ? 0 : (int)f0 - o0;
+                p1 = f1 > o1f - 1.0f ? wt - 1 : (int)f1 - o0;
+                p0 = max(p0, dlo); p1 = min(p1, dhi);   // only the dirty stretch of the tile matters
             }
             auto reg_seg = [&](int p, int oo) {
                 const unsigned fl = dflag[p];
@@ -482,7 +508,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
                     const int s = fl & 0x7f;
                     const unsigned idx = (atomic_add_u16(dcnt, s, 0x100u) >> 8) & 0xffu;
                     if (idx < PT_KS) sgs[s * PT_KS + idx] = (uint16_t)oo;
-                    else hazard = true;
+                    else PP_HAZARD(16);
                 }
             };
             const bool seg_long = p1 - p0 > 3;
@@ -500,10 +526,28 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
                     for (int p = lp0 + lane; p <= lp1; p += 64) reg_seg(p, lo);
                 }
             }
-            // the left sentinel's segment
-            if (left_edge && j == 0 && valid && (float)(-1.0 * w) < x) {
-                const int e1 = min(min((int)floorf(x) - o0, wt - 1), dhi);
-                if (!(floorf(x) < o0f)) for (int p = max(0, dlo); p <= e1; p++) reg_seg(p, 0);
+        }
+    }
+    // ---- the left sentinel's segment (0 -> 1), frame border only: the pixels 0 .. floor(x1) - 1 under it take the chain path
+    // (their piece is "flat"); in fold tiles it is a listed segment like the others
+    if (left_edge && tid == 0) {
+        const float x1 = P[1].w, fs = floorf(x1);
+        if ((float)(-1.0 * w) < x1) {
+            const int e1 = min((int)fs - 1 - o0, wt - 1);
+            if (fs - 1.0f >= o0f)
+                for (int p = 0; p <= e1; p++)
+                    if (!(fold_tile && (dflag[p] & PP_DIRTY))) list_push(PK_BRIDGE, 0, p);
+            if (fold_tile && !(fs < o0f)) {
+                const int e2 = min(min((int)fs - o0, wt - 1), dhi);
+                for (int p = max(0, dlo); p <= e2; p++) {
+                    const unsigned fl = dflag[p];
+                    if (fl & PP_DIRTY) {
+                        const int s = fl & 0x7f;
+                        const unsigned idx = (atomic_add_u16(dcnt, s, 0x100u) >> 8) & 0xffu;
+                        if (idx < PT_KS) sgs[s * PT_KS + idx] = (uint16_t)0;
+                        else PP_HAZARD(16);
+                    }
+                }
             }
         }
     }
@@ -525,7 +569,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         int npr = 0;
         if (act && !bridge) {
             npr = 1;
-            while (npr <= PT_KP && floorf(P[min(o1in + npr, npts - 1)].x) == colf) npr++;
+            while (npr <= PT_KP && floorf(P[min(o1in + npr, npts - 1)].w) == colf) npr++;
         }
         const int o1 = bridge ? o1in + 1 : o1in;   // np == 0: the segment's END point
         const int np = act ? min(npr, PT_KP) : 0;
@@ -543,7 +587,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             if (k <= wnp + 1) {
                 const int o = chain && k <= np + 1 ? o1 - 1 + k : 0;
                 const float4 v = P[o];
-                cx[k] = v.x; c0[k] = v.y; c1[k] = v.z; c2[k] = v.w;
+                cx[k] = v.w; c0[k] = v.x; c1[k] = v.y; c2[k] = v.z;
                 cj[k] = min(max(o - 1, 0), ns - 1);
             } else { cx[k] = 0.0f; c0[k] = c1[k] = c2[k] = 0.0f; cj[k] = 0; }
         }
@@ -615,10 +659,10 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             const float4 a = P[lean ? o : 1], b = P[lean ? o + 1 : 2];
             const float colf = (float)(o0 + q);
             const float center = colf + 0.5f;
-            const float ip = div_core(center - a.x, b.x - a.x), om = 1.0f - ip;
-            const float k0 = 0.5f + (a.y * om + b.y * ip) * sig_whole;
-            const float k1 = 0.5f + (a.z * om + b.z * ip) * sig_whole;
-            const float k2 = 0.5f + (a.w * om + b.w * ip) * sig_whole;
+            const float ip = div_core(center - a.w, b.w - a.w), om = 1.0f - ip;
+            const float k0 = 0.5f + (a.x * om + b.x * ip) * sig_whole;
+            const float k1 = 0.5f + (a.y * om + b.y * ip) * sig_whole;
+            const float k2 = 0.5f + (a.z * om + b.z * ip) * sig_whole;
             // the segment is forward, starts left of the pixel and ends right of it (checked when it was listed)
             if (lean) emit(q, (int)k0 & 0xff, (int)k1 & 0xff, (int)k2 & 0xff);
         }
@@ -627,7 +671,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             int r8 = 0, g8 = 0, b8 = 0;
             const bool ok = eval_chain(rest, q, o, bridge, r8, g8, b8);
             if (rest && ok) emit(q, r8, g8, b8);
-            hazard = hazard || (rest && !ok);
+            if (rest && !ok) PP_HAZARD(32);
         }
     }
     // ---- general search over the pixels under reversed segments (first generation, eval_generic): the pixel's points
@@ -641,7 +685,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         pend = pend && dflag[q] == (uint8_t)(PP_DIRTY | s);   // (a slot that lost its pixel to an overlapping reversed segment)
         const int col = o0 + q;
         const unsigned c = pend ? dcnt[s] : 0u;
-        if ((c & 0xffu) > PT_KP || (c >> 8) > PT_KS) hazard = true;
+        if ((c & 0xffu) > PT_KP || (c >> 8) > PT_KS) PP_HAZARD(256);
         const int np = min((int)(c & 0xffu), PT_KP), nsg = min((int)(c >> 8), PT_KS);
         int wnp = 0, wns = 0;
 #pragma unroll
@@ -658,7 +702,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         for (int k = 0; k < PT_KP; k++) {
             if (k < wnp) {
                 int o = k < np ? (int)pts[s * PT_KP + k] : 0x7fffffff;
-                float x = k < np ? P[o].x : INFINITY;
+                float x = k < np ? P[o].w : INFINITY;
 #pragma unroll
                 for (int m2 = 0; m2 <= k; m2++) {
                     const bool lt = x < xs[m2] || (x == xs[m2] && o < os[m2]);
@@ -685,7 +729,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             const float sig_f = tf - ff;
             const float center = sig64 ? C.center64 : ff + 0.5f * sig_f;
             a = live ? b : a;
-            if (live && (center < prev || center > colp1)) hazard = true;
+            if (live && (center < prev || center > colp1)) PP_HAZARD(64);
             prev = live ? center : prev;
             const bool work = live && (sig64 ? C.sig_dd != 0.0 : sig_f != 0.0f);
             int nact = 0, pick = -1, nqual = 0, best = -1;
@@ -696,7 +740,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
                 if (e < wns) {
                     const bool have = so[e] >= 0;
                     const int oe = have ? so[e] : 0;
-                    const float e0 = P[oe].x, e1 = P[oe + 1].x;
+                    const float e0 = P[oe].w, e1 = P[oe + 1].w;
                     const bool actv = have && (e0 < center) && !(e1 < center);
                     nact += actv ? 1 : 0;
                     pick = actv ? e : pick;
@@ -711,7 +755,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
                 }
             }
             const bool multi = work && nact != 1;
-            if (multi && (nqual == 0 || tie)) hazard = true;
+            if (multi && (nqual == 0 || tie)) PP_HAZARD(128);
             pick = (multi && best >= 0) ? best : pick;
             const bool contrib = work && pick >= 0;
             int o = 1;
@@ -719,24 +763,24 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             for (int e = 0; e < PT_KS; e++)
                 if (e < wns) o = (e == pick && so[e] >= 0) ? so[e] : o;
             const float4 pl = P[contrib ? o : 1], pr = P[contrib ? o + 1 : 2];
-            const float x0 = contrib ? pl.x : 0.0f, x1 = contrib ? pr.x : 1.0f;
+            const float x0 = contrib ? pl.w : 0.0f, x1 = contrib ? pr.w : 1.0f;
             const int jl = min(max(o - 1, 0), ns - 1), jr = min(max(o, 0), ns - 1);
             const float ip_k = (center - x0) / (x1 - x0);
             const float om = 1.0f - ip_k;
             const float sgm = sig64 ? (float)C.sig_dd : sig_f;
-            float n0 = color0 + (pl.y * om + pr.y * ip_k) * sgm;
-            float n1 = color1 + (pl.z * om + pr.z * ip_k) * sgm;
-            float n2 = color2 + (pl.w * om + pr.w * ip_k) * sgm;
+            float n0 = color0 + (pl.x * om + pr.x * ip_k) * sgm;
+            float n1 = color1 + (pl.y * om + pr.y * ip_k) * sgm;
+            float n2 = color2 + (pl.z * om + pr.z * ip_k) * sgm;
             if (__any(contrib && jl == jr)) {  // segment inside one source pixel (sentinel pieces)
                 if (jl == jr) {
                     if (sig64) {
-                        n0 = (float)((double)color0 + (double)pl.y * C.sig_dd);
-                        n1 = (float)((double)color1 + (double)pl.z * C.sig_dd);
-                        n2 = (float)((double)color2 + (double)pl.w * C.sig_dd);
+                        n0 = (float)((double)color0 + (double)pl.x * C.sig_dd);
+                        n1 = (float)((double)color1 + (double)pl.y * C.sig_dd);
+                        n2 = (float)((double)color2 + (double)pl.z * C.sig_dd);
                     } else {
-                        n0 = color0 + pl.y * sig_f;
-                        n1 = color1 + pl.z * sig_f;
-                        n2 = color2 + pl.w * sig_f;
+                        n0 = color0 + pl.x * sig_f;
+                        n1 = color1 + pl.y * sig_f;
+                        n2 = color2 + pl.z * sig_f;
                     }
                 }
             }
@@ -746,20 +790,20 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         }
         if (pend) emit(q, csm::f32_to_u8_wrap(color0), csm::f32_to_u8_wrap(color1), csm::f32_to_u8_wrap(color2));
     }
-    if (hazard) A.rowflag[(size_t)frame * h + row] = 1;  // the general kernel redoes this row (both eyes)
+    if (hazard) A.rowflag[(uint32_t)frame * (uint32_t)h + (uint32_t)row] = 1;  // the general kernel redoes this row (both eyes)
 }
 
-static size_t polypoint_lds(int S, int T, int KP, int KS) {
-    const int nptmax = T + 2 * S + 4;
-    const int npz = ((nptmax + 3) & ~3) > 128 ? ((nptmax + 3) & ~3) : 128;  // (the powf tables overlay pz: 512 bytes at least)
-    return 1024 + 16 * (size_t)nptmax + 4 * (size_t)npz + 4 * (size_t)T + (size_t)((T + 3) & ~3) +
-           2 * PP_DCAP * (2 + (size_t)KP + KS) + 4 * PF_WORDS + 64;
+static size_t polypoint_lds(int slots, int T, int KP, int KS) {
+    const size_t npt = (size_t)slots * PP_THREADS + 4;
+    return 1024 + 16 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((T + 3) & ~3) + 2 * PP_DCAP * (2 + (size_t)KP + KS) +
+           4 * PF_WORDS + 64;
 }
 
-// Tile width for a row of `w` pixels with halo S: the staged range (T + 2S + 2 points) must fit the SLOTS * 256 point
-// slots of a workgroup; equal tiles, multiples of 4.  0: the halo is too wide for this kernel.
+// Tile width for a row of `w` pixels with halo S: the staged range (T + 2S + 2 points) plus the right sentinel must fit the
+// SLOTS * 256 point slots of a workgroup; equal tiles, multiples of 4.  0: the halo is too wide for this kernel.
 static int polypoint_tile(int w, int S, int slots) {
-    int tmax = (slots * PP_THREADS - 2 * S - 2) & ~3;
+    if (slots * PP_THREADS + 1 >= 4096) return 0;  // 12-bit point field of the list entries
+    int tmax = (slots * PP_THREADS - 2 * S - 4) & ~3;
     if (tmax > 4092) tmax = 4092;  // 12-bit pixel field of the list entries
     if (tmax < 64) return 0;
     const int tiles = (w + tmax - 1) / tmax;
@@ -767,34 +811,56 @@ static int polypoint_tile(int w, int S, int slots) {
     return t < 4 ? 4 : t;
 }
 
-int polypoint_max_halo() { return (3 * PP_THREADS - 2 - 64) / 2; }
+int polypoint_max_halo() { return (4 * PP_THREADS - 4 - 64) / 2; }
 
 // Launch for the eyes of `R` (SBS / TB / single-eye / uint8 outputs; no anaglyph).  `rowflag` must be zeroed by the caller;
 // afterwards the general kernel is run over the flagged rows.
 hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream_t stream) {
-    constexpr int SLOTS = 3, KP = 4, KS = 5;
+    constexpr int KP = 4, KS = 5;
+    // point slots per lane: 3 (768 per workgroup, 7 workgroups per CU at the bench halo) or 4 (1024: wider tiles, less halo
+    // per output pixel, 5 workgroups per CU); development switch CS_DEBUG_PT_VARIANT 3 / 4 forces one
+    const int forced = dev_switch(CS_DEBUG_PT_VARIANT);
+    int slots = (forced == 3 || forced == 4) ? forced : 3;
+    if (polypoint_tile(R.w, S, slots) == 0 && slots == 3) slots = 4;
     PolyPointArgs A;
     A.n = R.n; A.h = R.h; A.w = R.w; A.S = S;
-    A.T = polypoint_tile(R.w, S, SLOTS);
-    if (A.T == 0 || A.T + 2 * S + 2 > SLOTS * PP_THREADS - 0 || A.T + 2 * S + 4 >= 4096) return hipErrorInvalidValue;
+    A.T = polypoint_tile(R.w, S, slots);
+    if (A.T == 0 || A.T + 2 * S + 3 > slots * PP_THREADS) return hipErrorInvalidValue;
     A.image_f32 = R.image_f32; A.image_u8 = R.image_u8;
     A.stats = R.stats; A.stats_rw = R.stats_rw;
     A.scale_from_stats = R.scale_from_stats;
     A.e32 = R.e32; A.conv32 = R.conv32;
     A.eye[0] = R.eye[0]; A.eye[1] = R.eye[1];
     A.single = R.neyes == 1 ? 0 : R.single;
-    A.stereo_is_u8 = R.stereo_is_u8;
     A.out_u8 = R.out_u8; A.stereo = R.stereo; A.mask = R.mask; A.depth_l = R.depth_l; A.depth_r = R.depth_r;
     A.out_h = R.out_h; A.out_w = R.out_w;
     A.rowflag = rowflag;
     A.dbg = R.dbg;
+    const int out = R.out_u8 ? PO_ASD : (R.stereo_is_u8 ? PO_U8 : PO_F32);
+    if ((out == PO_ASD) != (R.image_u8 != nullptr)) return hipErrorInvalidValue;  // uint8 image in <=> uint8 image out
     const int tiles = (A.w + A.T - 1) / A.T;
-    dim3 grid(tiles * A.h, A.n, A.single >= 0 ? 1 : 2), block(PP_THREADS);
-    const size_t lds = polypoint_lds(S, A.T, KP, KS);
-    hipError_t e = hipFuncSetAttribute((const void*)k_polypoint<SLOTS, KP, KS, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_polypoint<SLOTS, KP, KS, 7>), grid, block, lds, stream, A.image_f32, A.eye[0].depth, A.eye[1].depth,
-                       A.w, A.h, A.S, A.T, A.single, A);
+    if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31) || A.h > 65535 || 2 * A.n > 65535)
+        return hipErrorInvalidValue;   // 32-bit pixel indices, grid limits
+    dim3 grid(tiles, A.h, A.single >= 0 ? A.n : 2 * A.n), block(PP_THREADS);
+    const size_t lds = polypoint_lds(slots, A.T, KP, KS);
+#define PP_LAUNCH(SL, O, MW)                                                                                                \
+    {                                                                                                                       \
+        hipError_t e = hipFuncSetAttribute((const void*)k_polypoint<SL, O, KP, KS, MW>,                                     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+        if (e != hipSuccess) return e;                                                                                      \
+        hipLaunchKernelGGL((k_polypoint<SL, O, KP, KS, MW>), grid, block, lds, stream, A.image_f32, A.eye[0].depth,         \
+                           A.eye[1].depth, A.w, A.h, A.S, A.T, A.single, A);                                                \
+    }
+    if (slots == 3) {
+        if (out == PO_F32) PP_LAUNCH(3, PO_F32, 7)
+        else if (out == PO_U8) PP_LAUNCH(3, PO_U8, 7)
+        else PP_LAUNCH(3, PO_ASD, 7)
+    } else {
+        if (out == PO_F32) PP_LAUNCH(4, PO_F32, 5)
+        else if (out == PO_U8) PP_LAUNCH(4, PO_U8, 5)
+        else PP_LAUNCH(4, PO_ASD, 5)
+    }
+#undef PP_LAUNCH
     return hipGetLastError();
 }
 

@@ -921,7 +921,7 @@ hipError_t launch_polytile(int sharp, const RowArgs& R, int S, uint8_t* rowflag,
     else if (variant == 1) PT_LAUNCH(0, 4, 6, 6)
     else if (variant == 9) PT_LAUNCH(0, 4, 5, 7)
     else if (variant == 2) PT_LAUNCH(0, 3, 4, 7)
-    else if (variant == 3) PT_LAUNCH(0, 6, 8, 6)
+    else if (variant == 13) PT_LAUNCH(0, 6, 8, 6)
     else PT_LAUNCH(0, 4, 5, 7)
 #undef PT_LAUNCH
     return hipGetLastError();

@@ -1,10 +1,13 @@
 #!/bin/bash
-# development aid: build libcs_<name>.so with cs_polytile.hip taken from a git revision (A/B timing)
-#   tools/build_variant.sh HEAD base   ->  comfystereo_amd/libcs_base.so
+# development aid: build comfystereo_amd/libcs_<name>.so with extra compiler flags on one translation unit (A/B timing with
+# CS_LIB_PATH):   tools/build_variant.sh noslp cs_polypoint "-fno-slp-vectorize"
 set -e
 cd "$(dirname "$0")/../comfystereo_amd/csrc"
-rev=$1; name=$2
-git show "$rev:comfystereo_amd/csrc/cs_polytile.hip" > /tmp/cs_polytile_$name.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -fvisibility=hidden -mllvm -amdgpu-kernarg-preload-count=16 -I. -c -x hip /tmp/cs_polytile_$name.hip -o /tmp/cs_polytile_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libcs_$name.so cs_abi.o cs_blur.o cs_gpuwarp.o cs_rowwarp.o /tmp/cs_polytile_$name.o
+name=$1; unit=$2; extra=$3
+make -s
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -fvisibility=hidden -mllvm -amdgpu-kernarg-preload-count=16"
+/opt/rocm/bin/hipcc $FLAGS $extra -c $unit.hip -o /tmp/${unit}_$name.o
+objs=""
+for o in cs_*.o; do if [ "$o" = "$unit.o" ]; then objs="$objs /tmp/${unit}_$name.o"; else objs="$objs $o"; fi; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libcs_$name.so $objs
 ls -la ../libcs_$name.so

@@ -70,6 +70,17 @@ for kind, blur in (("stepped", True), ("blobs", False), ("radial", True)):
                                 depth_blur_vert_smooth=3, batch_size=12)
     res = [int((g.cpu().numpy() != wv).sum()) for g, wv in zip(got, want)]
     print("node", kind, "blur", blur, "mismatching values (stereo, dl, dr, mask):", res)
+    if res[0]:
+        gs = np.round(got[0].cpu().numpy() * 255).astype(int)
+        ws = np.round(want[0] * 255).astype(int)
+        bad = np.argwhere((gs != ws).any(-1))
+        rows = sorted(set((int(f), int(r)) for f, r, c in bad))
+        print(f"     {len(bad)} pixels in {len(rows)} rows; first rows {rows[:6]}")
+        for f, r, c in bad[:8]:
+            print(f"     frame {f} row {r} eye {c // w} col {c % w}: got {gs[f, r, c].tolist()} want {ws[f, r, c].tolist()}")
+        f, r = rows[0]
+        cols = sorted(int(c) for ff, rr, c in bad if ff == f and rr == r)
+        print(f"     row ({f},{r}) bad cols: {cols[:40]}")
     bad_total += sum(res)
 print("TOTAL mismatches:", bad_total)
 sys.exit(1 if bad_total else 0)

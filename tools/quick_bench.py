@@ -44,6 +44,7 @@ if os.environ.get("CS_DBG") == "20":
           [round(int(x) / max(int(c), 1) / 100.0, 2) for x, c in zip(st[:, 12].tolist(), st[:, 13].tolist())])
     print("workgroups per phase:", [int(c) for c in st[:, 13].tolist()])
 print("chain px, generic px, waves with generic, waves:", st[:, 12].sum().item(), st[:, 13].sum().item(), st[:, 14].sum().item(), st[:, 15].sum().item())
+print("stats word 12 (dev builds: hazard reason bits):", [hex(int(v)) for v in st[:, 12].tolist()])
 print("seq-fallback rows:", st[:, 10].tolist(), "tile-redo rows:", st[:, 11].tolist(), "errors:", st[:, 9].tolist())
 t0 = time.perf_counter()
 for _ in range(a.iters):
