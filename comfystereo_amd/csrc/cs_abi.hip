@@ -257,7 +257,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         // soft: the point-owner kernel (cs_polypoint.hip) unless the halo is too wide for it or the development switch
         // CS_DEBUG_PT_VARIANT >= 1 asks for the first generation (cs_polytile.hip); sharp: first generation
         const int variant = dev_switch(CS_DEBUG_PT_VARIANT);   // 0 / 3 / 4: point-owner kernel; other values: first generation
-        if (fill == CS_FILL_POLYLINES_SOFT && halo <= polypoint_max_halo() && (variant == 0 || variant == 3 || variant == 4))
+        if (fill == CS_FILL_POLYLINES_SOFT && halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 6)))
             e = launch_polypoint(A, halo, rowflag, stream);
         else
             e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, A, halo, rowflag, stream);

@@ -126,8 +126,8 @@ enum { PO_F32 = 0, PO_U8 = 1, PO_ASD = 2 };
 // list entries: kind << 28 | point id << 12 | pixel (tile-local)
 enum { PK_CHAIN = 0u, PK_BRIDGE = 1u };
 
-template <int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW>
-__global__ void __launch_bounds__(PP_THREADS, MINW)
+template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW>
+__global__ void __launch_bounds__(NT, MINW)
 k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
             int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, PolyPointArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -156,7 +156,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // sentinels only matter when the staged range touches the frame border.  Every lane stages SLOTS points j = tid + 256 k;
     // slots beyond the row end re-read the last column and get x = 2w + (j - ns): slot ns IS the right sentinel.
     const int npts = ns + 2;
-    constexpr int NPT = SLOTS * PP_THREADS + 4;
+    constexpr int NPT = SLOTS * NT + 4;
     const bool left_edge = s0 == 0, right_edge = s1 == w;
 
     // ---- LDS carve ----
@@ -184,7 +184,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     const B3* irow8 = reinterpret_cast<const B3*>(A.image_u8) + rowpix + s0;
 #pragma unroll
     for (int k = 0; k < SLOTS; k++) {
-        const int jc = min(tid + k * PP_THREADS, ns - 1);
+        const int jc = min(tid + k * NT, ns - 1);
         dpre[k] = drow[jc];
         if (OUT == PO_ASD) cpre8[k] = irow8[jc];
         else cpre[k] = irow[jc];
@@ -197,8 +197,8 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // LDS set-up in the shadow of the loads
     if (tid < (int)(sizeof(csm::PowfTables) / 4))
         reinterpret_cast<uint32_t*>(tabs)[tid] = reinterpret_cast<const uint32_t*>(&c_pp_powf_tables)[tid];
-    lut[tid] = c_pp_lut255.v[tid];  // PP_THREADS == 256
-    if (tid < (T + 3) / 4) reinterpret_cast<uint32_t*>(dflag)[tid] = 0;   // T <= 1024
+    if (tid < 256) lut[tid] = c_pp_lut255.v[tid];
+    if (tid < (T + 3) / 4) reinterpret_cast<uint32_t*>(dflag)[tid] = 0;   // T <= 4 NT (checked on the host)
     if (tid < PP_DCAP / 2) reinterpret_cast<uint32_t*>(dcnt)[tid] = 0;
     if (tid < PF_WORDS) {   // minima start at INT_MAX, maxima at -1, counters at 0
         constexpr unsigned is_min = (1u << PF_DLO) | (1u << PF_JLO), is_max = (1u << PF_DHI) | (1u << PF_JHI);
@@ -259,7 +259,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         else c = F3{truncf(__builtin_amdgcn_fmed3f(cpre[k].x * 255.0f, 0.0f, 255.0f)),
                     truncf(__builtin_amdgcn_fmed3f(cpre[k].y * 255.0f, 0.0f, 255.0f)),
                     truncf(__builtin_amdgcn_fmed3f(cpre[k].z * 255.0f, 0.0f, 255.0f))};
-        *reinterpret_cast<F3*>(P + 1 + tid + k * PP_THREADS) = c;
+        *reinterpret_cast<F3*>(P + 1 + tid + k * NT) = c;
         if (k == 0 && tid == 0) *reinterpret_cast<F3*>(P) = c;   // left sentinel (:1921): the first column's colour
     }
     // this eye's depth-map output: (depth * 255).astype(uint8) wraps mod 256 (quirk Q7), value code / 255 on three channels
@@ -275,7 +275,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         }
 #pragma unroll
         for (int k = 0; k < SLOTS; k++) {
-            const int q = tid + k * PP_THREADS + qoff;   // tile pixel of this source column
+            const int q = tid + k * NT + qoff;   // tile pixel of this source column
             if ((unsigned)q < (unsigned)wt) {
                 const float v = lut[code[k]];
                 *reinterpret_cast<F3*>(dd_row + 12u * (uint32_t)q) = F3{v, v, v};
@@ -286,8 +286,8 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < SLOTS; k++) {
-            const int q = tid + k * PP_THREADS + qoff;
-            const float4 c = P[1 + tid + k * PP_THREADS];
+            const int q = tid + k * NT + qoff;
+            const float4 c = P[1 + tid + k * NT];
             if ((unsigned)q < (unsigned)wt) emit(q, (int)c.x, (int)c.y, (int)c.z);
         }
         return;
@@ -348,13 +348,13 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         float* const pzw = pz + 1 + tid;
 #pragma unroll
         for (int k = 0; k < SLOTS; k++) {
-            const int j = tid + k * PP_THREADS;
+            const int j = tid + k * NT;
             const float cdj = (sg[k] * pw[k]) * E.div32;                                   // coord_d   (:1926)
-            float x = ((jf0 + (float)(k * PP_THREADS)) + cdj) + E.sep32;                   // coord_x   (:1927)
+            float x = ((jf0 + (float)(k * NT)) + cdj) + E.sep32;                   // coord_x   (:1927)
             // slots beyond the staged range: x = 2w + (j - ns), strictly increasing, slot ns = the right sentinel (:1935)
-            x = j < ns ? x : tidf + (float)(2 * w - ns + k * PP_THREADS);
-            Pxw[4 * k * PP_THREADS] = x;
-            pzw[k * PP_THREADS] = fabsf(cdj);
+            x = j < ns ? x : tidf + (float)(2 * w - ns + k * NT);
+            Pxw[4 * k * NT] = x;
+            pzw[k * NT] = fabsf(cdj);
             // reversed segment (j -> j+1)?  The right neighbour sits in the next lane (lane 63: +inf; the pairs across wave
             // chunks and the left sentinel's pair are checked after the barrier).
             const float xn = wave_next(x);
@@ -363,7 +363,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             // the range of points that can lie in the tile: first j with x >= o0, last j with x < o0 + wt (wave-uniform
             // candidates from ballots; one pair of atomics per wave below)
             const unsigned long long m1 = __ballot(x >= o0f), m2 = __ballot(x < o1f);
-            const int base = k * PP_THREADS + wave * 64;
+            const int base = k * NT + wave * 64;
             wjlo = min(wjlo, m1 ? base + __ffsll((long long)m1) - 1 : 0x7fffffff);
             wjhi = max(wjhi, m2 ? base + 63 - __clzll((long long)m2) : -1);
         }
@@ -414,9 +414,10 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // =====================================================================================================
     // phase C: every point that can lie in the tile looks at its pixel (lanes densely packed over [jlo, jhi])
     // =====================================================================================================
-    for (int jb = jlo; jb <= jhi; jb += PP_THREADS) {
+    for (int jb = jlo; jb <= jhi; jb += NT) {
         // (every lane runs the body -- the cooperative loops below need whole waves -- lanes beyond jhi re-read point jhi
         // and are kept from acting by `act`)
+        if (jb + wave * 64 > jhi) continue;   // (a wave without a point left has nothing to do or to cooperate on)
         const bool act = jb + tid <= jhi;
         const int j = min(jb + tid, jhi);
         const int o = 1 + j;
@@ -647,7 +648,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         r8 = csm::f32_to_u8_wrap(color0); g8 = csm::f32_to_u8_wrap(color1); b8 = csm::f32_to_u8_wrap(color2);
         return chain;
     };
-    for (int base = wave * 64; base < nlist; base += PP_THREADS) {
+    for (int base = wave * 64; base < nlist; base += NT) {
         const int i = base + lane;
         const bool act = i < nlist;
         const uint32_t e = plist[act ? i : 0];
@@ -678,7 +679,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // sorted by (x, id) == the reference's stable insertion sort inside the pixel; every listed segment tested per
     // sub-interval; with several (or no) active segments the largest interpolated |disparity| with 0 < ip < 1 wins,
     // ties are order-dependent -> row redo.
-    for (int base = (3 - wave) * 64; base < (PP_DEV_IS(35) ? 0 : ndirty); base += PP_THREADS) {
+    for (int base = (NT / 64 - 1 - wave) * 64; base < (PP_DEV_IS(35) ? 0 : ndirty); base += NT) {
         const int s = base + lane;
         bool pend = s < ndirty;
         const int q = dpix[pend ? s : 0];
@@ -793,39 +794,62 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     if (hazard) A.rowflag[(uint32_t)frame * (uint32_t)h + (uint32_t)row] = 1;  // the general kernel redoes this row (both eyes)
 }
 
-static size_t polypoint_lds(int slots, int T, int KP, int KS) {
-    const size_t npt = (size_t)slots * PP_THREADS + 4;
+static size_t polypoint_lds(int nt, int slots, int T, int KP, int KS) {
+    const size_t npt = (size_t)slots * nt + 4;
     return 1024 + 16 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((T + 3) & ~3) + 2 * PP_DCAP * (2 + (size_t)KP + KS) +
            4 * PF_WORDS + 64;
 }
 
 // Tile width for a row of `w` pixels with halo S: the staged range (T + 2S + 2 points) plus the right sentinel must fit the
-// SLOTS * 256 point slots of a workgroup; equal tiles, multiples of 4.  0: the halo is too wide for this kernel.
-static int polypoint_tile(int w, int S, int slots) {
-    if (slots * PP_THREADS + 1 >= 4096) return 0;  // 12-bit point field of the list entries
-    int tmax = (slots * PP_THREADS - 2 * S - 4) & ~3;
-    if (tmax > 4092) tmax = 4092;  // 12-bit pixel field of the list entries
+// `nslots` point slots of a workgroup; equal tiles, multiples of 4.  0: the halo is too wide for this geometry.
+static int polypoint_tile(int w, int S, int nslots, int nt) {
+    if (nslots + 1 >= 4096) return 0;  // 12-bit point field of the list entries
+    int tmax = (nslots - 2 * S - 4) & ~3;
+    if (tmax > 4 * nt) tmax = 4 * nt;  // one pass zeroes the per-pixel flags
     if (tmax < 64) return 0;
     const int tiles = (w + tmax - 1) / tmax;
     int t = ((w + tiles - 1) / tiles + 3) & ~3;
     return t < 4 ? 4 : t;
 }
 
-int polypoint_max_halo() { return (4 * PP_THREADS - 4 - 64) / 2; }
+int polypoint_max_halo() { return (3 * 384 - 4 - 64) / 2; }
+
+template <int NT, int SLOTS, int MINW>
+static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream) {
+    constexpr int KP = 4, KS = 5;
+    const int tiles = (A.w + A.T - 1) / A.T;
+    dim3 grid(tiles, A.h, A.single >= 0 ? A.n : 2 * A.n), block(NT);
+    const size_t lds = polypoint_lds(NT, SLOTS, A.T, KP, KS);
+#define PP_LAUNCH(O)                                                                                                         \
+    {                                                                                                                        \
+        hipError_t e = hipFuncSetAttribute((const void*)k_polypoint<NT, SLOTS, O, KP, KS, MINW>,                             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        if (e != hipSuccess) return e;                                                                                       \
+        hipLaunchKernelGGL((k_polypoint<NT, SLOTS, O, KP, KS, MINW>), grid, block, lds, stream, A.image_f32, A.eye[0].depth, \
+                           A.eye[1].depth, A.w, A.h, A.S, A.T, A.single, A);                                                 \
+    }
+    if (out == PO_F32) PP_LAUNCH(PO_F32)
+    else if (out == PO_U8) PP_LAUNCH(PO_U8)
+    else PP_LAUNCH(PO_ASD)
+#undef PP_LAUNCH
+    return hipGetLastError();
+}
 
 // Launch for the eyes of `R` (SBS / TB / single-eye / uint8 outputs; no anaglyph).  `rowflag` must be zeroed by the caller;
 // afterwards the general kernel is run over the flagged rows.
 hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream_t stream) {
-    constexpr int KP = 4, KS = 5;
-    // point slots per lane: 3 (768 per workgroup, 7 workgroups per CU at the bench halo) or 4 (1024: wider tiles, less halo
-    // per output pixel, 5 workgroups per CU); development switch CS_DEBUG_PT_VARIANT 3 / 4 forces one
+    // workgroup geometry: threads x point slots per lane.  256 x 3 (7 workgroups per CU at the bench halo) is the default;
+    // development switch CS_DEBUG_PT_VARIANT: 3 = 256 x 3, 4 = 256 x 4, 5 = 384 x 3, 6 = 320 x 3
     const int forced = dev_switch(CS_DEBUG_PT_VARIANT);
-    int slots = (forced == 3 || forced == 4) ? forced : 3;
-    if (polypoint_tile(R.w, S, slots) == 0 && slots == 3) slots = 4;
+    int geo = (forced >= 3 && forced <= 6) ? forced : 3;
+    auto nt_of = [](int g) { return g == 5 ? 384 : (g == 6 ? 320 : 256); };
+    auto sl_of = [](int g) { return g == 4 ? 4 : 3; };
+    if (polypoint_tile(R.w, S, nt_of(geo) * sl_of(geo), nt_of(geo)) == 0 && geo == 3) geo = 5;
+    const int nt = nt_of(geo), slots = sl_of(geo);
     PolyPointArgs A;
     A.n = R.n; A.h = R.h; A.w = R.w; A.S = S;
-    A.T = polypoint_tile(R.w, S, slots);
-    if (A.T == 0 || A.T + 2 * S + 3 > slots * PP_THREADS) return hipErrorInvalidValue;
+    A.T = polypoint_tile(R.w, S, nt * slots, nt);
+    if (A.T == 0 || A.T + 2 * S + 3 > nt * slots) return hipErrorInvalidValue;
     A.image_f32 = R.image_f32; A.image_u8 = R.image_u8;
     A.stats = R.stats; A.stats_rw = R.stats_rw;
     A.scale_from_stats = R.scale_from_stats;
@@ -838,30 +862,14 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     A.dbg = R.dbg;
     const int out = R.out_u8 ? PO_ASD : (R.stereo_is_u8 ? PO_U8 : PO_F32);
     if ((out == PO_ASD) != (R.image_u8 != nullptr)) return hipErrorInvalidValue;  // uint8 image in <=> uint8 image out
-    const int tiles = (A.w + A.T - 1) / A.T;
     if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31) || A.h > 65535 || 2 * A.n > 65535)
         return hipErrorInvalidValue;   // 32-bit pixel indices, grid limits
-    dim3 grid(tiles, A.h, A.single >= 0 ? A.n : 2 * A.n), block(PP_THREADS);
-    const size_t lds = polypoint_lds(slots, A.T, KP, KS);
-#define PP_LAUNCH(SL, O, MW)                                                                                                \
-    {                                                                                                                       \
-        hipError_t e = hipFuncSetAttribute((const void*)k_polypoint<SL, O, KP, KS, MW>,                                     \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
-        if (e != hipSuccess) return e;                                                                                      \
-        hipLaunchKernelGGL((k_polypoint<SL, O, KP, KS, MW>), grid, block, lds, stream, A.image_f32, A.eye[0].depth,         \
-                           A.eye[1].depth, A.w, A.h, A.S, A.T, A.single, A);                                                \
+    switch (geo) {
+    case 4: return polypoint_launch<256, 4, 5>(A, out, stream);
+    case 5: return polypoint_launch<384, 3, 7>(A, out, stream);
+    case 6: return polypoint_launch<320, 3, 6>(A, out, stream);
+    default: return polypoint_launch<256, 3, 7>(A, out, stream);
     }
-    if (slots == 3) {
-        if (out == PO_F32) PP_LAUNCH(3, PO_F32, 7)
-        else if (out == PO_U8) PP_LAUNCH(3, PO_U8, 7)
-        else PP_LAUNCH(3, PO_ASD, 7)
-    } else {
-        if (out == PO_F32) PP_LAUNCH(4, PO_F32, 5)
-        else if (out == PO_U8) PP_LAUNCH(4, PO_U8, 5)
-        else PP_LAUNCH(4, PO_ASD, 5)
-    }
-#undef PP_LAUNCH
-    return hipGetLastError();
 }
 
 }  // namespace cs
