@@ -137,8 +137,8 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // and the scalar unit is as busy as the vector units in this kernel)
     const int tile = blockIdx.x, row = blockIdx.y;
     const int zi = blockIdx.z;
-    const int eyei = hot_single >= 0 ? hot_single : (zi >= A.n ? 1 : 0);
-    const int frame = zi >= A.n ? zi - A.n : zi;
+    const int eyei = hot_single >= 0 ? hot_single : (zi & 1);
+    const int frame = hot_single >= 0 ? zi : (zi >> 1);
     EyeArgs E;
     E.depth = eyei ? hot_depth1 : hot_depth0;
     E.div32 = eyei ? A.eye[1].div32 : A.eye[0].div32;

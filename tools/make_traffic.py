@@ -7,6 +7,7 @@ import re
 import sys
 
 run, frames, key = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+kernel = sys.argv[4] if len(sys.argv) > 4 else "k_polypoint"
 
 
 def mean(path, kernel, counter):
@@ -16,14 +17,14 @@ def mean(path, kernel, counter):
     raise SystemExit(f"{counter} of {kernel} not found in {path}")
 
 
-fetch_kib = mean(f"{run}/pmc_fetch.txt", "k_polytile", "FETCH_SIZE")
-write_kib = mean(f"{run}/pmc_write.txt", "k_polytile", "WRITE_SIZE")
+fetch_kib = mean(f"{run}/pmc_fetch.txt", kernel, "FETCH_SIZE")
+write_kib = mean(f"{run}/pmc_write.txt", kernel, "WRITE_SIZE")
 out = "profiles/pmc_traffic.json"
 try:
     d = json.load(open(out))
 except Exception:  # noqa: BLE001
     d = {}
 d[key] = {"bytes_per_frame": (2 * fetch_kib + write_kib) * 1024 / frames, "fetch_kib_raw_per_dispatch": fetch_kib,
-          "write_kib_per_dispatch": write_kib, "frames_per_dispatch": frames, "read_correction": 2.0, "source": run}
+          "write_kib_per_dispatch": write_kib, "frames_per_dispatch": frames, "read_correction": 2.0, "source": run, "profile": run, "kernel": kernel}
 json.dump(d, open(out, "w"), indent=1)
 print(d[key])
