@@ -92,24 +92,40 @@ __global__ void __launch_bounds__(256) k_minmax(const float* __restrict__ a, int
     block_minmax_commit(mn, mx, &stats[frame * ST_WORDS + wmin], &stats[frame * ST_WORDS + wmax]);
 }
 
-// F.interpolate(mode='bilinear', align_corners=False) of the gray depth (GenerateStereo.py:141-148,
-// 214-220) + min/max of the result.
+// F.interpolate(mode='bilinear', align_corners=False) of the gray depth (GenerateStereo.py:141-148, 214-220) + min/max of the
+// result, bit for bit as CPU torch 2.10 computes it (probed against torch in the build container, tests/golden/resize.npz):
+//   source index = fma(scale, dst + 0.5, -0.5) clamped at 0 (scale = (float)in / out; the compiler contracts the expression),
+//   lambda1 = index - floor, lambda0 = 1 - lambda1, second tap = first + 1 unless at the border;
+//   outputs with out_h + out_w > 128 take the separable loop  fma(t0, wy0, t1 * wy1), t = fma(a, wx0, b * wx1);
+//   smaller ones the four-tap loop over weight products  fma(d, wy1*wx1, fma(c, wy1*wx0, fma(a, wy0*wx0, b * (wy0*wx1))))
+//   (which of its two loops torch's TensorIterator picks depends on out_h + out_w only: scanned for 3 <= out_h <= 300 and every
+//   out_w up to 4200 pixels per frame, independent of the input size, the batch and the thread count).
 __global__ void __launch_bounds__(256) k_resize_bilinear(const float* __restrict__ in, int ih, int iw,
                                                          float* __restrict__ out, int oh, int ow, uint32_t* stats) {
     const int frame = blockIdx.y;
     const float* src = in + (size_t)frame * ih * iw;
     float* dst = out + (size_t)frame * oh * ow;
     const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
+    const bool small = oh + ow <= 128;
     float mn = INFINITY, mx = -INFINITY;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < oh * ow; i += gridDim.x * blockDim.x) {
-        int y = i / ow, x = i - y * ow;
-        float fy = fmaxf(sy * ((float)y + 0.5f) - 0.5f, 0.0f), fx = fmaxf(sx * ((float)x + 0.5f) - 0.5f, 0.0f);
-        int y0 = min((int)fy, ih - 1), x0 = min((int)fx, iw - 1);
-        int y1 = min(y0 + 1, ih - 1), x1 = min(x0 + 1, iw - 1);
-        float ly = fy - (float)y0, lx = fx - (float)x0;
-        float hy = 1.0f - ly, hx = 1.0f - lx;
-        float v = hy * (hx * src[y0 * iw + x0] + lx * src[y0 * iw + x1]) +
-                  ly * (hx * src[y1 * iw + x0] + lx * src[y1 * iw + x1]);
+        const int y = i / ow, x = i - y * ow;
+        const float fy = fmaxf(fmaf(sy, (float)y + 0.5f, -0.5f), 0.0f), fx = fmaxf(fmaf(sx, (float)x + 0.5f, -0.5f), 0.0f);
+        const int y0 = min((int)fy, ih - 1), x0 = min((int)fx, iw - 1);
+        const int y1 = y0 + (y0 < ih - 1 ? 1 : 0), x1 = x0 + (x0 < iw - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float hy = 1.0f - ly, hx = 1.0f - lx;
+        const float a = src[y0 * iw + x0], b = src[y0 * iw + x1], c = src[y1 * iw + x0], d = src[y1 * iw + x1];
+        float v;
+        if (small) {
+            v = b * (hy * lx);
+            v = fmaf(a, hy * hx, v);
+            v = fmaf(c, ly * hx, v);
+            v = fmaf(d, ly * lx, v);
+        } else {
+            const float t0 = fmaf(a, hx, b * lx), t1 = fmaf(c, hx, d * lx);
+            v = fmaf(t0, hy, t1 * ly);
+        }
         dst[i] = v;
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
@@ -153,6 +169,51 @@ __global__ void __launch_bounds__(256) k_expand_u8(const uint8_t* __restrict__ i
         reinterpret_cast<float4*>(out)[i] = make_float4(lut[pk & 0xff], lut[(pk >> 8) & 0xff], lut[(pk >> 16) & 0xff], lut[pk >> 24]);
     }
     for (size_t i = 4 * nq + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += stride) out[i] = lut[in[i]];
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// stereo_shift_torch (reference stereo_utils.py:15-88): the `none` forward map on a float payload (latents [b][c][h][w]).
+// One workgroup per (row, batch item): winner source column per destination by LDS atomics (the reference's sweep makes the
+// largest source column win for a negative shift and the smallest for a positive one, :56-67), then a gather of all channels.
+// The depth is normalised with the GLOBAL min / max of the whole depth tensor (:36-45), unfilled destinations stay 0.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_stereo_shift(const float* __restrict__ in, const float* __restrict__ depth, int c, int h,
+                                                      int w, const uint32_t* stats, float scale_px32, int asc, int pow_mode,
+                                                      float e32, float* __restrict__ out) {
+    extern __shared__ int win[];   // [w] winning source column per destination, -1 = none
+    __shared__ csm::PowfTables T;
+    const int row = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (tid == 0) { const csm::PowfTables init = CS_POWF_TABLES_INIT; T = init; }
+    for (int x = tid; x < w; x += blockDim.x) win[x] = asc ? -1 : 0x7fffffff;
+    __syncthreads();
+    const float mn = csm::ord2f(stats[ST_L_MIN]), mx = csm::ord2f(stats[ST_L_MAX]);
+    const float rng = mx - mn;
+    const bool flat = !(rng > 1.1920929e-07f);   // torch.finfo(float32).eps (:40)
+    const float* drow = depth + ((size_t)b * h + row) * w;
+    for (int col = tid; col < w; col += blockDim.x) {
+        const float nd = flat ? 0.0f : (1.0f * (drow[col] - mn)) / rng;
+        float dv;
+        if (pow_mode == 1) dv = nd;                      // torch.pow special-cases 1, 2 and 0.5
+        else if (pow_mode == 2) dv = nd * nd;
+        else if (pow_mode == 3) dv = sqrtf(nd);
+        else dv = csm::powf_exact(nd, e32, &T);          // (other exponents: libm powf; torch's scalar pow may differ in the last ulp)
+        const float prod = dv * scale_px32;
+        if (fabsf(prod) < 1.0e9f) {
+            const int cd = col + (int)prod;              // int() truncates toward zero (:64)
+            if (cd >= 0 && cd < w) {
+                if (asc) atomicMax(&win[cd], col);
+                else atomicMin(&win[cd], col);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < c * w; i += blockDim.x) {
+        const int ch = i / w, x = i - ch * w;
+        const int src = win[x];
+        const size_t base = (((size_t)b * c + ch) * h + row) * w;
+        out[base + x] = (src >= 0 && src < w) ? in[base + src] : 0.0f;
+    }
 }
 
 __global__ void k_test_powf(const float* x, float y, float* out, size_t n) {
@@ -262,6 +323,15 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         else
             e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, A, halo, rowflag, stream);
         if (e != hipSuccess) return fail_hip(e, "tiled polylines launch");
+        // single-eye modes (left-only / only-right): the tile kernels visit one eye, both depth maps are outputs all the same
+        if (A.neyes == 2 && A.single >= 0 && !A.out_u8) {
+            const int other = 1 - A.single;
+            float* dd = other == 0 ? A.depth_l : A.depth_r;
+            if (dd) {
+                e = launch_depth_codes(A.eye[other].depth, A.n, A.h, A.w, A.stats, A.scale_from_stats, dd, stream);
+                if (e != hipSuccess) return fail_hip(e, "depth-map output launch");
+            }
+        }
         e = launch_collect_rows(rowflag, (int)rows, count, list, stream);
         if (e != hipSuccess) return fail_hip(e, "flagged-row collection");
         A.row_list = list; A.row_count = count;
@@ -546,6 +616,42 @@ int cs_expand_u8(const uint8_t* codes, float* out, size_t count, void* stream) {
     hipLaunchKernelGGL(k_expand_u8, dim3(grid_for(count / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, codes, out, count);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CS_OK : fail_hip(e, "cs_expand_u8");
+}
+
+
+size_t cs_stereo_shift_workspace_bytes(void) { return al256(ST_WORDS * 4); }
+
+int cs_stereo_shift(const float* input, const float* depth, int b, int c, int h, int w, double scale_factor, int shift_both,
+                    double stereo_offset_exponent, float* out, void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!input || !depth || !out || !workspace) return fail(CS_EINVAL, "null pointer");
+    if (b <= 0 || c <= 0 || h <= 0 || w <= 0) return fail(CS_EINVAL, "non-positive size");
+    if ((size_t)w * 4 > 64 * 1024) return fail(CS_ELIMIT, "row too wide for the LDS-resident winner table");
+    if (workspace_bytes < cs_stereo_shift_workspace_bytes()) return fail(CS_EWORKSPACE, "workspace too small");
+    uint32_t* stats = (uint32_t*)workspace;
+    hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(256), 0, stream, stats, 1);
+    // one "frame" = the whole depth tensor: the reference normalises with its global min / max (stereo_utils.py:36-45)
+    const size_t total = (size_t)b * h * w;
+    if (total >= (1ull << 31)) return fail(CS_ELIMIT, "depth tensor too large");
+    hipLaunchKernelGGL(k_minmax, dim3(grid_for(total, 256), 1), dim3(256), 0, stream, depth, (int)total, stats, ST_L_MIN, ST_L_MAX);
+    const double e = stereo_offset_exponent;
+    const int pow_mode = e == 1.0 ? 1 : (e == 2.0 ? 2 : (e == 0.5 ? 3 : 0));
+    const size_t half = (size_t)b * c * h * w;
+    const double balance = shift_both ? 0.5 : 0.0;
+    for (int eye = 0; eye < 2; eye++) {
+        float* dst = out + eye * half;
+        if (eye == 0 && !shift_both) {   // left = input (:75-77)
+            hipError_t e1 = hipMemcpyAsync(dst, input, half * 4, hipMemcpyDeviceToDevice, stream);
+            if (e1 != hipSuccess) return fail_hip(e1, "cs_stereo_shift");
+            continue;
+        }
+        const double sf = eye == 0 ? +1 * scale_factor * balance : -1 * scale_factor * (1 - balance);
+        const double scale_px = (sf / 100.0) * (double)w;   // (:54)
+        hipLaunchKernelGGL(k_stereo_shift, dim3(h, b), dim3(256), (size_t)w * 4, stream, input, depth, c, h, w, stats,
+                           (float)scale_px, scale_px < 0 ? 1 : 0, pow_mode, (float)e, dst);
+    }
+    hipError_t er = hipGetLastError();
+    return er == hipSuccess ? CS_OK : fail_hip(er, "cs_stereo_shift");
 }
 
 int cs_profile(int enable) {

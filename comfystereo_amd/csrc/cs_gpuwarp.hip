@@ -80,11 +80,12 @@ __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
     const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
     for (int x = tid; x < w; x += nt) gap[x] = 0;
     __syncthreads();
-    // torch.linspace(-1, 1, H)[y] (symmetric two-sided fill) and its unnormalisation
+    // torch.linspace(-1, 1, H)[y] (symmetric two-sided fill, each value one fused multiply-add: bit-equal to CPU torch for
+    // every H probed, 48 .. 2160) and its unnormalisation
     float gy;
     {
         float step = h > 1 ? 2.0f / (float)(h - 1) : 0.0f;
-        gy = y < h / 2 ? -1.0f + step * (float)y : 1.0f - step * (float)(h - y - 1);
+        gy = y < h / 2 ? fmaf(step, (float)y, -1.0f) : fmaf(-step, (float)(h - y - 1), 1.0f);
     }
     float yy = (gy + 1.0f) * ((float)(h - 1) / 2.0f);
     yy = fminf(fmaxf(yy, 0.0f), (float)(h - 1));

@@ -69,6 +69,9 @@ int polytile_max_halo();
 // cs_polypoint.hip: second generation of the tiled path (polylines_soft): one lane per polyline point
 hipError_t launch_polypoint(const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream);
 int polypoint_max_halo();
+// depth-map output (code / 255 on three channels) of an eye the tile kernels do not visit (single-eye modes)
+hipError_t launch_depth_codes(const float* depth, int n, int h, int w, const uint32_t* stats, int scale_from_stats, float* out,
+                              hipStream_t stream);
 
 // cs_blur.hip: directional depth blur; if `scale_from_stats`, the input is multiplied by 255 for frames
 // whose stats say so, and the per-frame min/max of both outputs are accumulated into stats.

@@ -794,6 +794,32 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     if (hazard) A.rowflag[(uint32_t)frame * (uint32_t)h + (uint32_t)row] = 1;  // the general kernel redoes this row (both eyes)
 }
 
+// Depth-map output of an eye the tile kernel does not visit (modes left-only / only-right still return both depth maps,
+// reference stereoimage_generation.py:1511-1516): (depth * 255).astype(uint8) wraps mod 256 (quirk Q7), value code / 255.
+__global__ void __launch_bounds__(256) k_depth_codes(const float* __restrict__ depth, int hw, const uint32_t* stats,
+                                                     int scale_from_stats, float* __restrict__ out) {
+    __shared__ float lut[256];
+    lut[threadIdx.x] = c_pp_lut255.v[threadIdx.x];
+    __syncthreads();
+    const int frame = blockIdx.y;
+    const float scale = (scale_from_stats && stats[frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
+    const float* d = depth + (size_t)frame * hw;
+    F3* o = reinterpret_cast<F3*>(out) + (size_t)frame * hw;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+        const float v = lut[csm::f32_to_u8_wrap((d[i] * scale) * 255.0f)];
+        o[i] = F3{v, v, v};
+    }
+}
+
+hipError_t launch_depth_codes(const float* depth, int n, int h, int w, const uint32_t* stats, int scale_from_stats, float* out,
+                              hipStream_t stream) {
+    const int hw = h * w;
+    const int gx = (hw + 256 * 8 - 1) / (256 * 8);
+    hipLaunchKernelGGL(k_depth_codes, dim3(gx < 1 ? 1 : (gx > 4096 ? 4096 : gx), n), dim3(256), 0, stream, depth, hw, stats,
+                       scale_from_stats, out);
+    return hipGetLastError();
+}
+
 static size_t polypoint_lds(int nt, int slots, int T, int KP, int KS) {
     const size_t npt = (size_t)slots * nt + 4;
     return 1024 + 16 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((T + 3) & ~3) + 2 * PP_DCAP * (2 + (size_t)KP + KS) +

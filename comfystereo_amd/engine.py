@@ -158,6 +158,21 @@ def forward_warp(image, depth, divergence_px, separation_px, stereo_offset_expon
     return warped, mask.bool()
 
 
+def stereo_shift(input_images, depthmaps, scale_factor=8.0, shift_both=False, stereo_offset_exponent=1.0):
+    """reference stereo_utils.py:15-88 for device tensors: input [B,C,H,W], depth [B,H,W] float32 -> [2B,C,H,W]."""
+    L = _native.lib()
+    x = _dev(input_images).contiguous().float()
+    d = _dev(depthmaps).contiguous().float()
+    b, c, h, w = x.shape
+    assert tuple(d.shape) == (b, h, w)
+    out = torch.empty((2 * b, c, h, w), dtype=torch.float32, device=x.device)
+    nb = L.cs_stereo_shift_workspace_bytes()
+    ws = torch.empty((max(nb, 256),), dtype=torch.uint8, device=x.device)
+    _native.check(L.cs_stereo_shift(_ptr(x), _ptr(d), b, c, h, w, float(scale_factor), int(bool(shift_both)),
+                                    float(stereo_offset_exponent), _ptr(out), _ptr(ws), nb, _stream()))
+    return out
+
+
 def test_powf(x, y):
     L = _native.lib()
     x = _dev(x).contiguous().float()

@@ -159,6 +159,18 @@ CS_API int cs_forward_warp(const float *image, const float *depth, int n, int h,
 CS_API int cs_expand_u8(const uint8_t *codes, float *out, size_t count, void *stream);
 
 /*
+ * stereo_shift_torch (reference stereo_utils.py:15-88; callers stereodiffusion_nodes.py:650, :664): the depth-driven
+ * forward shift of the `none` technique on a float payload -- diffusion latents.  input [b][c][h][w] float32, depth
+ * [b][h][w] float32 (normalised with its global min / max like the reference, :36-45) -> out [2b][c][h][w]: the left
+ * views (the input itself unless shift_both) followed by the right views; destinations nothing lands on stay 0.
+ * torch.pow is exact for exponents 1 (the callers' value), 2 and 0.5; other exponents go through libm powf.
+ */
+CS_API size_t cs_stereo_shift_workspace_bytes(void);
+CS_API int cs_stereo_shift(const float *input, const float *depth, int b, int c, int h, int w, double scale_factor,
+                    int shift_both, double stereo_offset_exponent, float *out, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
+/*
  * Measurement hook for bench.py: while enabled, cs_generate brackets the launch of its dominant
  * kernel (the row warp + fill kernel of the selected technique) with HIP events on the caller's
  * stream.  cs_profile_read waits for the recorded events, returns the summed kernel time in

@@ -709,12 +709,13 @@ EXPORT void oracle_forward_warp_gpu(const float *image, const float *depth, int 
     float *nz = (float *)malloc(sizeof(float) * W), *ns = (float *)malloc(sizeof(float) * W);
     long *cs = (long *)malloc(sizeof(long) * W);
     float sx = (float)(W - 1);
-    /* torch.linspace(-1, 1, H): symmetric fill, float32 (gpu_warp tolerance) */
+    /* torch.linspace(-1, 1, H): symmetric fill in float32, each value ONE fused multiply-add (probed against CPU torch 2.10
+     * for H = 48 .. 2160: every value bit-equal; with separate roundings 40 % of the rows are off by an ulp) */
     float *gy = (float *)malloc(sizeof(float) * H);
     {
         float step = H > 1 ? (1.0f - (-1.0f)) / (float)(H - 1) : 0.0f;
         int half = H / 2;
-        for (int i = 0; i < H; i++) gy[i] = i < half ? -1.0f + step * (float)i : 1.0f - step * (float)(H - i - 1);
+        for (int i = 0; i < H; i++) gy[i] = i < half ? fmaf(step, (float)i, -1.0f) : fmaf(-step, (float)(H - i - 1), 1.0f);
     }
     for (int b = 0; b < B; b++) {
         const float *db = depth + hw * b;

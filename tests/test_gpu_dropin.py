@@ -18,8 +18,6 @@ def test_node_generate_matches_reference_goldens(golden_node):
     node = StereoImageNode()
     n = 0
     for case in golden_node.meta["cases"]:
-        if case["id"].startswith("resize/"):
-            continue
         img, depth = node_case_inputs(golden_node, case)
         out = node.generate(torch.from_numpy(img), torch.from_numpy(depth), case["divergence"], case["separation"], case["mode"],
                             case["balance"], case["convergence"], case["exponent"], ui[case["fill"]], case["edge_threshold"],
@@ -171,3 +169,24 @@ def test_blur_mask_width_is_independent_of_the_strength():
         oL, oR = oracle.blur(depth, s, t, f, v, mask_width=mw)
         assert np.array_equal(L.cpu().numpy().view(np.uint32), oL.view(np.uint32))
         assert np.array_equal(R.cpu().numpy().view(np.uint32), oR.view(np.uint32))
+
+
+def test_stereo_shift_torch_matches_reference_vectors_and_oracle():
+    """comfystereo_amd.stereo_utils.stereo_shift_torch (cs_stereo_shift) == the reference's captured outputs, bit for bit;
+    larger random cases against the oracle."""
+    from conftest import Golden
+    from comfystereo_amd.stereo_utils import stereo_shift_torch
+    from oracle import stereo_shift_oracle as so
+    g = Golden("stereo_shift.npz")
+    for case in g.meta["cases"]:
+        cid = case["id"]
+        x, d = torch.from_numpy(g[f"{cid}/x"]), torch.from_numpy(g[f"{cid}/d"])
+        got = stereo_shift_torch(x, d, case["scale_factor"], case["shift_both"], case["exponent"])
+        assert not got.is_cuda and got.dtype == torch.float32   # CPU tensors in -> CPU tensor out, like the reference
+        assert np.array_equal(got.numpy(), g[f"{cid}/out"]), cid
+    rng = np.random.default_rng(3)
+    for (b, c, h, w, sf, both, e) in [(2, 4, 96, 160, 10.0, True, 1.0), (1, 8, 33, 257, -14.0, False, 2.0)]:
+        x = rng.standard_normal((b, c, h, w)).astype(np.float32)
+        d = rng.random((b, h, w)).astype(np.float32)
+        got = stereo_shift_torch(torch.from_numpy(x).cuda(), torch.from_numpy(d).cuda(), sf, both, e)
+        assert got.is_cuda and np.array_equal(got.cpu().numpy(), so.stereo_shift(x, d, sf, both, e))

@@ -146,3 +146,47 @@ def test_naive_interpolating_hole_lengths_around_the_walk_limit(engine, hole):
         got = engine.apply_stereo_divergence(cuda(img), cuda(depth), div, 0.0, 1.0, "naive_interpolating", 0.0).cpu().numpy()
         want = oracle.apply_stereo_divergence(img, depth, div, 0.0, 1.0, "naive_interpolating", 0.0)
         assert np.array_equal(got, want), (hole, sign, int((got != want).sum()))
+
+
+def test_digests_at_baseline_sizes_on_the_gpu():
+    """cfg 1 (512 x 512 naive_interpolating), cfg 2 (1080p polylines_soft), cfg 3 at a quarter (1080p hybrid_edge), depth blur
+    on: the HIP path against SHA-256 digests of the reference's own outputs (tests/golden/digests.json)."""
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN
+    from comfystereo_amd import engine
+    from comfystereo_amd.GenerateStereo import FILL_TECHNIQUE_MAPPING
+    dig = json.load(open(os.path.join(GOLDEN, "digests.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    for cid, c in dig.items():
+        img = synth.image_u8(c["h"], c["w"], seed=c["image_seed"], hazards=False)[None].astype(np.float32) / np.float32(255.0)
+        depth = synth.depth_batch(c["kind"], 1, c["h"], c["w"], channels=3)
+        got = engine.generate(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda(), c["divergence"], 0.0, c["mode"], 0.0,
+                              0.5, 2.0, FILL_TECHNIQUE_MAPPING[c["fill_ui"]], 20.0, 20.0, c["blur"], depth_blur_falloff=2.0,
+                              depth_blur_vert_smooth=6, batch_size=12)
+        got = [t.cpu().numpy() for t in got]
+        k = [np.round(a * 255.0).astype(np.uint8) for a in (got[0], got[1][..., 0], got[2][..., 0])]
+        assert sha(k[0]) == c["stereo_u8"], cid
+        assert sha(k[1]) == c["dl_u8"] and sha(k[2]) == c["dr_u8"], cid
+        assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"], cid
+
+
+def test_forward_warp_1080p_rows_on_the_gpu():
+    """forward_warp_gpu at 1080p against rows captured from the reference (gap mask exact; colours to the last ulps outside
+    the gaps, <= 1e-4 for the few gap pixels whose torch.sqrt weight is not correctly rounded)."""
+    from conftest import Golden, assert_warp_colours
+    from comfystereo_amd import engine
+    g = Golden("forward_warp_1080p.npz")
+    for case in g.meta["cases"]:
+        cid = case["id"]
+        h, w = case["h"], case["w"]
+        img = synth.image_f32(1, h, w, seed=case["image_seed"]).transpose(0, 3, 1, 2).copy()
+        depth = synth.stepped(h, w)[None] * np.float32(255.0)
+        warped, mask = engine.forward_warp(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda(), case["divergence_px"],
+                                           case["separation_px"], case["exponent"], case["convergence"])
+        warped, mask = warped.cpu().numpy(), mask.cpu().numpy()
+        want_mask = np.unpackbits(g[f"{cid}/mask"])[: mask.size].reshape(mask.shape).astype(bool)
+        assert np.array_equal(mask, want_mask), cid
+        rows = case["rows"]
+        assert_warp_colours(warped[:, :, rows, :], g[f"{cid}/rows"], want_mask[:, rows, :], cid)

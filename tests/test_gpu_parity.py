@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import synth
-from conftest import node_case_expected, node_case_inputs
+from conftest import assert_warp_colours, node_case_expected, node_case_inputs
 from oracle import node_oracle, oracle
 
 pytestmark = pytest.mark.gpu
@@ -118,9 +118,6 @@ def test_node_goldens(engine, golden_node):
         want = node_case_expected(g, case)
         cid = case["id"]
         assert list(got[0].shape) == case["shapes"]["stereo"] and list(got[3].shape) == case["shapes"]["mask"], cid
-        if cid.startswith("resize/"):
-            assert np.mean(got[0] != want[0]) < 0.02, cid  # bilinear resize: tolerance (different float order)
-            continue
         if case["fill"] == "gpu_warp":
             assert np.abs(got[0] - want[0]).max() <= GPU_WARP_COLOUR_TOL, (cid, np.abs(got[0] - want[0]).max())
         else:
@@ -129,7 +126,33 @@ def test_node_goldens(engine, golden_node):
         assert np.array_equal(got[1][..., 0], got[1][..., 2]), cid
         assert np.array_equal(got[3], want[3]), cid
         ran += 1
-    assert ran >= 45
+    assert ran >= 46
+
+
+def test_node_goldens_round2(engine, golden_node_extra):
+    """The second node fixture: API-only modes (reference stereoimage_generation.py:1543-1562, :1094-1120), the fill strings
+    outside the combo list (GenerateStereo.py:97-99) through the node class, and depth maps of another size -- the bilinear
+    resize (GenerateStereo.py:141-148, 214-220) is bit-exact, so depth maps and mask are asserted as well."""
+    from conftest import extra_case_expected, extra_case_inputs
+    from comfystereo_amd.GenerateStereo import StereoImageNode
+    g = golden_node_extra
+    node = StereoImageNode()
+    for case in g.meta["cases"]:
+        img, depth = extra_case_inputs(g, case)
+        out = node.generate(cuda(img), cuda(depth), case["divergence"], case["separation"], case["mode"], case["balance"],
+                            case["convergence"], case["exponent"], case["fill_ui"], case["edge_threshold"], case["strength"],
+                            case["blur"], **case["kw"])
+        got = [t.cpu().numpy() for t in out]
+        want = extra_case_expected(g, case)
+        cid = case["id"]
+        assert list(got[0].shape) == case["shapes"]["stereo"] and list(got[3].shape) == case["shapes"]["mask"], cid
+        if case["gpu"]:
+            assert np.abs(got[0] - want[0]).max() <= GPU_WARP_COLOUR_TOL, (cid, np.abs(got[0] - want[0]).max())
+            assert np.abs(got[1][..., 0] - want[1]).max() <= 1e-6 and np.abs(got[2][..., 0] - want[2]).max() <= 1e-6, cid
+        else:
+            assert np.array_equal(got[0], want[0]), (cid, int((got[0] != want[0]).sum()))
+            assert np.array_equal(got[1][..., 0], want[1]) and np.array_equal(got[2][..., 0], want[2]), cid
+        assert np.array_equal(got[3], want[3]), cid
 
 
 @pytest.mark.parametrize("fill,mode", [("polylines_soft", "left-right"), ("none", "red-cyan-anaglyph"),
@@ -183,7 +206,7 @@ def test_forward_warp_goldens(engine, golden_warp):
         err = np.abs(warped - g[f"{cid}/warped"])
         if case["exponent"] in (2.0, 1.0, 0.5):
             assert np.array_equal(mask, want_mask), cid
-            assert err.max() <= GPU_WARP_COLOUR_TOL, (cid, err.max())
+            assert_warp_colours(warped, g[f"{cid}/warped"], want_mask, cid)
         else:
             assert (mask != want_mask).mean() <= 1e-3 and np.quantile(err, 0.999) <= 1e-3, cid
 

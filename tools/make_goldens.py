@@ -243,6 +243,124 @@ def gen_node(gs):
     print("node_generate:", len(cases), "cases")
 
 
+def gen_node_extra(gs):
+    """Second node fixture (added in round 2, leaves node_generate.npz untouched): the three modes only an API workflow can
+    pass (left-only, only-right, cyan-red-reverseanaglyph: reference stereoimage_generation.py:1543-1562, :1094-1120), the three
+    fill strings the combo list leaves out (GenerateStereo.py:97-99), and depth maps whose size differs from the image's
+    (bilinear resize, GenerateStereo.py:141-148 / 214-220) on both of torch's resize loops (<= 4096 output pixels and more)."""
+    node = gs.StereoImageNode()
+    arrays, cases = {}, []
+
+    def run(cid, grp, fill_ui, mode, div=6.0, sep=0.2, bal=0.1, conv=0.5, e=2.0, thr=20.0, st=20.0, blur=False, **kw):
+        image = torch.from_numpy(arrays[f"{grp}/img_u8"].astype(np.float32) / np.float32(255.0))
+        depth = torch.from_numpy(arrays[f"{grp}/depth"])
+        outs = node.generate(image, depth, div, sep, mode, bal, conv, e, fill_ui, thr, st, blur, **kw)
+        stereo, dl, dr, mask = [o.numpy() for o in outs]
+        gpu = fill_ui == "GPU Warp (Fast)"
+        if gpu:
+            arrays[f"{cid}/stereo"], arrays[f"{cid}/dl"], arrays[f"{cid}/dr"] = stereo, dl[..., 0].copy(), dr[..., 0].copy()
+        else:
+            for name, a in (("stereo", stereo), ("dl", dl[..., 0]), ("dr", dr[..., 0])):
+                k = np.round(a * 255.0).astype(np.uint8)
+                assert np.array_equal(k.astype(np.float32) / np.float32(255.0), a)
+                arrays[f"{cid}/{name}_u8"] = k
+        arrays[f"{cid}/mask"] = np.packbits(mask.astype(bool))
+        cases.append(dict(id=cid, group=grp, fill_ui=fill_ui, gpu=gpu, mode=mode, divergence=div, separation=sep, balance=bal,
+                          convergence=conv, exponent=e, edge_threshold=thr, strength=st, blur=blur, kw=kw,
+                          shapes=dict(stereo=list(stereo.shape), depth=list(dl.shape), mask=list(mask.shape))))
+
+    arrays["api/img_u8"] = np.stack([synth.image_u8(32, 72, seed=s) for s in (11, 12)])
+    arrays["api/depth"] = synth.depth_batch("blobs", 2, 32, 72, channels=3)
+    for mode in ("left-only", "only-right", "cyan-red-reverseanaglyph"):
+        for ui in ("No fill", "Fill - Polylines Soft", "Imperfect fill - Hybrid Edge", "GPU Warp (Fast)"):
+            run(f"api/{mode}/{ui}", "api", ui, mode, batch_size=12)
+    for ui in ("Fill - Post-fill", "Fill - Reverse projection with Post-fill", "Fill - Hybrid Edge with fill"):
+        run(f"api/hidden/{ui}", "api", ui, "left-right", batch_size=12)
+    # resize: (group, image h x w, depth h x w, channels)
+    for grp, (h, w), (dh, dw), ch in (("rs_small_up", (32, 64), (20, 36), 3), ("rs_big_up", (96, 160), (48, 64), 3),
+                                      ("rs_big_down", (72, 96), (108, 160), 1), ("rs_odd", (45, 91), (33, 57), 3)):
+        arrays[f"{grp}/img_u8"] = np.stack([synth.image_u8(h, w, seed=s) for s in (21, 22, 23)])
+        arrays[f"{grp}/depth"] = synth.depth_batch("radial" if grp != "rs_big_up" else "blobs", 3, dh, dw, channels=ch)
+        for ui, mode in (("No fill", "left-right"), ("Fill - Polylines Soft", "top-bottom"), ("GPU Warp (Fast)", "left-right")):
+            run(f"{grp}/{ui}", grp, ui, mode, div=5.0, batch_size=2)
+    np.savez_compressed(os.path.join(OUT, "node_extra.npz"), meta=json.dumps(dict(cases=cases)), **arrays)
+    print("node_extra:", len(cases), "cases")
+
+
+def gen_digests(gs):
+    """SHA-256 digests of the reference's node outputs at BASELINE.json sizes: inputs come from tools/synth.py
+    (seeded), so only the digests are committed.  Minutes of pure-Python reference time per case."""
+    node = gs.StereoImageNode()
+    out = {}
+    for cid, (h, w, kind, ui, mode, div, blur) in {
+            "cfg1_512_naive_interpolating": (512, 512, "radial", "Fill - Naive interpolating", "left-right", 4.5, True),
+            "cfg2_1080p_polylines_soft": (1080, 1920, "stepped", "Fill - Polylines Soft", "left-right", 3.5, True),
+            "cfg3q_1080p_hybrid_edge": (1080, 1920, "stepped", "Imperfect fill - Hybrid Edge", "left-right", 8.0, True)}.items():
+        img8 = synth.image_u8(h, w, seed=1000, hazards=False)[None]
+        depth = synth.depth_batch(kind, 1, h, w, channels=3)
+        image = torch.from_numpy(img8.astype(np.float32) / np.float32(255.0))
+        outs = node.generate(image, torch.from_numpy(depth), div, 0.0, mode, 0.0, 0.5, 2.0, ui, 20.0, 20.0, blur,
+                             depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+        stereo, dl, dr, mask = [o.numpy() for o in outs]
+        k = [np.round(a * 255.0).astype(np.uint8) for a in (stereo, dl[..., 0], dr[..., 0])]
+        out[cid] = dict(h=h, w=w, kind=kind, fill_ui=ui, mode=mode, divergence=div, blur=blur, image_seed=1000,
+                        stereo_u8=sha(k[0]), dl_u8=sha(k[1]), dr_u8=sha(k[2]), mask=sha(np.packbits(mask.astype(bool))),
+                        mask_sum=int(mask.sum()))
+        print("digest", cid, out[cid]["stereo_u8"][:16])
+    with open(os.path.join(OUT, "digests.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+WARP_1080P_ROWS = [0, 1, 110, 128, 129, 257, 332, 539, 540, 746, 822, 951, 1078, 1079]
+
+
+def gen_warp_1080p(sig):
+    """forward_warp_gpu at 1080p (where the [-1, 1] coordinate round trip costs most, SURVEY B-16): inputs come from
+    tools/synth.py (seeded); committed are the full gap mask (bit-packed) and a handful of output rows."""
+    h, w = 1080, 1920
+    img = synth.image_f32(1, h, w, seed=6).transpose(0, 3, 1, 2).copy()
+    depth = synth.stepped(h, w)[None] * np.float32(255.0)
+    arrays, cases = {}, []
+    for cid, (dpx, spx, e, conv) in enumerate([(67.2, 1.5, 2.0, 0.5), (-40.0, 0.0, 1.0, 0.3)]):
+        warped, mask = sig.forward_warp_gpu(torch.from_numpy(img), torch.from_numpy(depth), dpx, spx, e, conv)
+        arrays[f"{cid}/rows"] = warped.numpy()[:, :, WARP_1080P_ROWS, :].copy()
+        arrays[f"{cid}/mask"] = np.packbits(mask.numpy())
+        cases.append(dict(id=str(cid), divergence_px=dpx, separation_px=spx, exponent=e, convergence=conv, rows=WARP_1080P_ROWS,
+                          h=h, w=w, image_seed=6, depth="stepped * 255"))
+    np.savez_compressed(os.path.join(OUT, "forward_warp_1080p.npz"), meta=json.dumps(dict(cases=cases)), **arrays)
+    print("forward_warp_1080p:", len(cases), "cases")
+
+
+def load_stereo_utils():
+    """stereo_utils.py of the reference alone (torch, einops)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_stereo_utils", refload.REF + "/stereo_utils.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def gen_stereo_shift():
+    """Fixture for stereo_shift_torch (reference stereo_utils.py:15-88) on latent-shaped inputs."""
+    su = load_stereo_utils()
+    rng = np.random.default_rng(77)
+    arrays, cases = {}, []
+    for cid, (b, c, h, w, sf, both, e) in enumerate([(1, 4, 64, 64, 8.0, False, 1.0), (1, 4, 128, 128, 8.0, False, 1.0),
+                                                      (2, 4, 64, 64, 12.0, True, 1.0), (1, 4, 48, 80, -9.0, False, 2.0),
+                                                      (1, 3, 40, 56, 6.0, True, 0.5), (1, 4, 32, 40, 15.0, False, 1.0),
+                                                      (1, 4, 16, 24, 8.0, False, 1.0)]):
+        x = rng.standard_normal((b, c, h, w)).astype(np.float32)
+        yy, xx = np.mgrid[0:h, 0:w]
+        d = (np.sin(xx / 7.0) + np.cos(yy / 5.0) + 0.3 * rng.random((b, h, w))).astype(np.float32)
+        if cid == 6:
+            d[:] = 0.25  # flat depth: the reference normalises it to zeros (:40-43)
+        out = su.stereo_shift_torch(torch.from_numpy(x), torch.from_numpy(d), sf, both, e).numpy()
+        arrays[f"{cid}/x"], arrays[f"{cid}/d"], arrays[f"{cid}/out"] = x, d, out
+        cases.append(dict(id=str(cid), scale_factor=sf, shift_both=both, exponent=e))
+    np.savez_compressed(os.path.join(OUT, "stereo_shift.npz"), meta=json.dumps(dict(cases=cases)), **arrays)
+    print("stereo_shift:", len(cases), "cases")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     refload.quiet()
@@ -257,11 +375,27 @@ def main():
     if "--only-hidden" in sys.argv:  # (added after the first fixtures were committed: leaves them untouched)
         gen_hidden(sig)
         return
+    if "--only-stereo-shift" in sys.argv:
+        gen_stereo_shift()
+        return
+    if "--only-node-extra" in sys.argv:
+        gen_node_extra(gs)
+        return
+    if "--only-warp-1080p" in sys.argv:
+        gen_warp_1080p(sig)
+        return
+    if "--only-digests" in sys.argv:
+        gen_digests(gs)
+        return
     gen_apply_stereo_divergence(sig)
     gen_hidden(sig)
     gen_blur(sig)
     gen_forward_warp(sig)
     gen_node(gs)
+    gen_stereo_shift()
+    gen_node_extra(gs)
+    gen_warp_1080p(sig)
+    gen_digests(gs)
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
