@@ -34,7 +34,7 @@ namespace cs {
 #define PP_THREADS 256
 // -DCS_DEV builds (make -C comfystereo_amd/csrc dev): cs_debug_set(CS_DEBUG_DBG, n) cuts the kernel short so that hardware
 // counters can be attributed to its phases (31: after staging, 32: before phase C, 33: phase C without bridges and fold
-// registration, 34: no pass 2, 35: no general search).  Release builds compile the tests away.
+// registration, 34: no pass 2, 35: no general search, 36: no powf for the risky squares, 37: no depth-map output).  Release builds compile the tests away.
 #ifdef CS_DEV
 #define PP_DEV_IS(n) (A.dbg == (n))
 // (development) why a row was handed to the general kernel: reason bits OR-ed into the frame's spare stats word 12
@@ -133,9 +133,17 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = hot_T;
-    // grid = (tiles, rows, frames x eyes): no integer division in the prologue (a scalar division costs ~30 SALU instructions,
-    // and the scalar unit is as busy as the vector units in this kernel)
-    const int tile = blockIdx.x, row = blockIdx.y;
+    // grid = (tiles x 8 rows, rows / 8, frames x eyes), decoded with shifts (a scalar division costs ~30 SALU instructions, and
+    // the scalar unit is as busy as the vector units in this kernel).  Workgroup b runs on XCD b % 8 (observed dispatch order,
+    // MI355X_MICROARCH.md; a speed assumption only): with blockIdx.x = tile * 8 + (row & 7) all tiles of a row land on one
+    // XCD, back to back, and the halo columns two neighbouring tiles share come from that XCD's L2 the second time instead
+    // of from HBM (FETCH_SIZE -21 %).  Putting the two eyes of a tile next to each other as well takes the image row out of
+    // HBM for the second eye (FETCH_SIZE -60 %) and is 4 % SLOWER (measured, r02c): the kernel is bound by instruction
+    // issue, not by HBM, and the eyes then compete for the same L1 lines.
+    const int xi = blockIdx.x;
+    const int row = blockIdx.y * 8 + (xi & 7);
+    if (row >= hot_h) return;
+    const int tile = xi >> 3;
     const int zi = blockIdx.z;
     const int eyei = hot_single >= 0 ? hot_single : (zi & 1);
     const int frame = hot_single >= 0 ? zi : (zi >> 1);
@@ -176,18 +184,19 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
     const uint32_t rowpix = ((uint32_t)frame * (uint32_t)h + (uint32_t)row) * (uint32_t)w;   // pixel index < 2^31 (checked on the host)
     // ---- all global loads first: depth and image of the lane's points (clamped to the staged range: no branches) ----
-    const float* drow = E.depth + rowpix + s0;
+    // (32-bit byte offsets from wave-uniform row bases: one address instruction per load)
+    const char* const drow = reinterpret_cast<const char*>(E.depth + rowpix + s0);
+    const char* const irow = reinterpret_cast<const char*>(reinterpret_cast<const F3*>(hot_image) + rowpix + s0);
+    const char* const irow8 = reinterpret_cast<const char*>(reinterpret_cast<const B3*>(A.image_u8) + rowpix + s0);
     float dpre[SLOTS];
     F3 cpre[SLOTS];
     B3 cpre8[SLOTS];
-    const F3* irow = reinterpret_cast<const F3*>(hot_image) + rowpix + s0;
-    const B3* irow8 = reinterpret_cast<const B3*>(A.image_u8) + rowpix + s0;
 #pragma unroll
     for (int k = 0; k < SLOTS; k++) {
-        const int jc = min(tid + k * NT, ns - 1);
-        dpre[k] = drow[jc];
-        if (OUT == PO_ASD) cpre8[k] = irow8[jc];
-        else cpre[k] = irow[jc];
+        const uint32_t jc = (uint32_t)min(tid + k * NT, ns - 1);
+        dpre[k] = *reinterpret_cast<const float*>(drow + 4u * jc);
+        if (OUT == PO_ASD) cpre8[k] = *reinterpret_cast<const B3*>(irow8 + 3u * jc);
+        else cpre[k] = *reinterpret_cast<const F3*>(irow + 12u * jc);
     }
     const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
     const float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
@@ -263,7 +272,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         if (k == 0 && tid == 0) *reinterpret_cast<F3*>(P) = c;   // left sentinel (:1921): the first column's colour
     }
     // this eye's depth-map output: (depth * 255).astype(uint8) wraps mod 256 (quirk Q7), value code / 255 on three channels
-    if (OUT != PO_ASD) {
+    if (OUT != PO_ASD && !PP_DEV_IS(37)) {
         float* const dd = eyei == 0 ? A.depth_l : A.depth_r;
         char* const dd_row = (char*)dd + (size_t)(rowpix + (uint32_t)o0) * 12;
         int code[SLOTS];
@@ -331,6 +340,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             if (pow_mode == 0) r = true;
             risk |= r ? 1u << k : 0u;
         }
+        if (PP_DEV_IS(36)) risk = 0;
         while (__any(risk != 0u)) {  // the full powf clone for the risky arguments (all of them for other exponents)
             float xin = 1.0f;
             int sel = -1;
@@ -844,7 +854,7 @@ template <int NT, int SLOTS, int MINW>
 static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream) {
     constexpr int KP = 4, KS = 5;
     const int tiles = (A.w + A.T - 1) / A.T;
-    dim3 grid(tiles, A.h, A.single >= 0 ? A.n : 2 * A.n), block(NT);
+    dim3 grid(tiles * 8, (A.h + 7) / 8, A.single >= 0 ? A.n : 2 * A.n), block(NT);   // (see the kernel's prologue)
     const size_t lds = polypoint_lds(NT, SLOTS, A.T, KP, KS);
 #define PP_LAUNCH(O)                                                                                                         \
     {                                                                                                                        \
@@ -888,7 +898,7 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     A.dbg = R.dbg;
     const int out = R.out_u8 ? PO_ASD : (R.stereo_is_u8 ? PO_U8 : PO_F32);
     if ((out == PO_ASD) != (R.image_u8 != nullptr)) return hipErrorInvalidValue;  // uint8 image in <=> uint8 image out
-    if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31) || A.h > 65535 || 2 * A.n > 65535)
+    if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31) || A.h > 8 * 65535 || 2 * A.n > 65535)
         return hipErrorInvalidValue;   // 32-bit pixel indices, grid limits
     switch (geo) {
     case 4: return polypoint_launch<256, 4, 5>(A, out, stream);
