@@ -108,6 +108,7 @@ __device__ __forceinline__ float wave_next(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x7f800000, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
 }
 __device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+using csm::code_over_255;
 
 // per-pixel constants of the float64 ("Python float") branch of the sub-interval arithmetic (reference :1957-1960)
 struct PixC { double sig_dd; float ff64, tf64, center64; };
@@ -168,8 +169,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     const bool left_edge = s0 == 0, right_edge = s1 == w;
 
     // ---- LDS carve ----
-    float* lut = (float*)smem;                                                    // [256] k / 255
-    float4* P = (float4*)(smem + 1024);                                           // [NPT] {R, G, B, x} of point o
+    float4* P = (float4*)smem;                                                    // [NPT] {R, G, B, x} of point o
     float* pz = (float*)(P + NPT);                                                // [NPT] |coord_d|
     uint32_t* plist = (uint32_t*)(pz + NPT);                                      // [max(T, 128)] pixels evaluated in pass 2
     csm::PowfTables* tabs = (csm::PowfTables*)plist;                              //   (until barrier 1: the powf tables, 512 bytes)
@@ -206,7 +206,6 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // LDS set-up in the shadow of the loads
     if (tid < (int)(sizeof(csm::PowfTables) / 4))
         reinterpret_cast<uint32_t*>(tabs)[tid] = reinterpret_cast<const uint32_t*>(&c_pp_powf_tables)[tid];
-    if (tid < 256) lut[tid] = c_pp_lut255.v[tid];
     if (tid < (T + 3) / 4) reinterpret_cast<uint32_t*>(dflag)[tid] = 0;   // T <= 4 NT (checked on the host)
     if (tid < PP_DCAP / 2) reinterpret_cast<uint32_t*>(dcnt)[tid] = 0;
     if (tid < PF_WORDS) {   // minima start at INT_MAX, maxima at -1, counters at 0
@@ -248,12 +247,14 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
                                          : (((uint32_t)frame * (uint32_t)A.out_h + (uint32_t)(row + E.yoff)) * (uint32_t)A.out_w + (uint32_t)(E.xoff + o0));
     char* const st_row = OUT == PO_ASD ? (char*)A.out_u8 + (size_t)obase * 3 : (OUT == PO_U8 ? (char*)A.stereo + (size_t)obase * 3 : (char*)A.stereo + (size_t)obase * 12);
     char* const mk_row = OUT == PO_ASD ? nullptr : (char*)A.mask + (size_t)obase * 4;
-    auto emit = [&](int q, int r, int g, int b) {   // colour codes 0..255 of tile pixel q
+    // colour codes of tile pixel q as integer-valued floats 0..255
+    auto emit_f = [&](int q, float r, float g, float b) {
         const uint32_t uq = (uint32_t)q;
-        if (OUT == PO_F32) *reinterpret_cast<F3*>(st_row + 12u * uq) = F3{lut[r], lut[g], lut[b]};
-        else *reinterpret_cast<B3*>(st_row + 3u * uq) = B3{(uint8_t)r, (uint8_t)g, (uint8_t)b};
-        if (OUT != PO_ASD) *reinterpret_cast<float*>(mk_row + 4u * uq) = (r | g | b) == 0 ? 1.0f : 0.0f;
+        if (OUT == PO_F32) *reinterpret_cast<F3*>(st_row + 12u * uq) = F3{code_over_255(r), code_over_255(g), code_over_255(b)};
+        else *reinterpret_cast<B3*>(st_row + 3u * uq) = B3{(uint8_t)(int)r, (uint8_t)(int)g, (uint8_t)(int)b};
+        if (OUT != PO_ASD) *reinterpret_cast<float*>(mk_row + 4u * uq) = __builtin_fmaxf(__builtin_fmaxf(r, g), b) == 0.0f ? 1.0f : 0.0f;
     };
+    auto emit = [&](int q, int r, int g, int b) { emit_f(q, (float)r, (float)g, (float)b); };   // the same from integer codes
 
     // =====================================================================================================
     // phase B: stage the lane's points: colour codes as floats, the libm-exact disparity -> x, reversed segments
@@ -277,7 +278,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         char* const dd_row = (char*)dd + (size_t)(rowpix + (uint32_t)o0) * 12;
         int code[SLOTS];
 #pragma unroll
-        for (int k = 0; k < SLOTS; k++) code[k] = (int)((dpre[k] * scale) * 255.0f) & 0xff;
+        for (int k = 0; k < SLOTS; k++) code[k] = (int)((dpre[k] * scale) * 255.0f);   // (the low byte is taken below)
         if (code_wraps) {
 #pragma unroll
             for (int k = 0; k < SLOTS; k++) code[k] = (int)csm::f32_to_u8_wrap((dpre[k] * scale) * 255.0f);
@@ -286,7 +287,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         for (int k = 0; k < SLOTS; k++) {
             const int q = tid + k * NT + qoff;   // tile pixel of this source column
             if ((unsigned)q < (unsigned)wt) {
-                const float v = lut[code[k]];
+                const float v = code_over_255((float)(code[k] & 0xff));
                 *reinterpret_cast<F3*>(dd_row + 12u * (uint32_t)q) = F3{v, v, v};
             }
         }
@@ -297,7 +298,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         for (int k = 0; k < SLOTS; k++) {
             const int q = tid + k * NT + qoff;
             const float4 c = P[1 + tid + k * NT];
-            if ((unsigned)q < (unsigned)wt) emit(q, (int)c.x, (int)c.y, (int)c.z);
+            if ((unsigned)q < (unsigned)wt) emit_f(q, c.x, c.y, c.z);
         }
         return;
     }
@@ -465,7 +466,8 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             k0 = k0 + (pc.x * om1 + pp.x * ip1) * sig1;
             k1 = k1 + (pc.y * om1 + pp.y * ip1) * sig1;
             k2 = k2 + (pc.z * om1 + pp.z * ip1) * sig1;
-            if (fast) emit(q, (int)k0 & 0xff, (int)k1 & 0xff, (int)k2 & 0xff);
+            // (0.5 <= k < 255.5: the lerp operands are codes 0..255, the piece lengths sum to less than 1)
+            if (fast) emit_f(q, truncf(k0), truncf(k1), truncf(k2));
         }
         // the first point of a pixel that is not done yet: several points / special typing -> pass 2 (chain path)
         if (g_first > 0.0f && !fast && !dirty && act) list_push(PK_CHAIN, o, q);
@@ -675,7 +677,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             const float k1 = 0.5f + (a.y * om + b.y * ip) * sig_whole;
             const float k2 = 0.5f + (a.z * om + b.z * ip) * sig_whole;
             // the segment is forward, starts left of the pixel and ends right of it (checked when it was listed)
-            if (lean) emit(q, (int)k0 & 0xff, (int)k1 & 0xff, (int)k2 & 0xff);
+            if (lean) emit_f(q, truncf(k0), truncf(k1), truncf(k2));
         }
         const bool rest = act && !lean;
         if (__any(rest)) {
@@ -832,7 +834,7 @@ hipError_t launch_depth_codes(const float* depth, int n, int h, int w, const uin
 
 static size_t polypoint_lds(int nt, int slots, int T, int KP, int KS) {
     const size_t npt = (size_t)slots * nt + 4;
-    return 1024 + 16 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((T + 3) & ~3) + 2 * PP_DCAP * (2 + (size_t)KP + KS) +
+    return 16 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((T + 3) & ~3) + 2 * PP_DCAP * (2 + (size_t)KP + KS) +
            4 * PF_WORDS + 64;
 }
 

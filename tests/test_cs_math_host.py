@@ -57,6 +57,7 @@ int main() {
             (float)sig != 0x1.fffffap-1f || sig == 0.0) bad++;
         n++;
     }
+    for (int k = 0; k < 256; k++) { if (csm::f2u(csm::code_over_255((float)k)) != csm::f2u((float)k / 255.0f)) bad++; n++; }
     float q[] = {65025.f, 300.7f, -3.2f, 255.9f, 256.f, 1e10f};
     int want[] = {1, 44, 253, 255, 0, 0};
     for (int i = 0; i < 6; i++) if (csm::f32_to_u8_wrap(q[i]) != want[i]) bad++;
