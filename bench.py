@@ -38,10 +38,10 @@ HBM_PEAK_GBS = 8000.0
 # (80: SBS + output-shaped mask, 76: gpu_warp SBS with the eye-shaped mask, 64: anaglyph).
 CONFIGS = {
     "metric": dict(h=2160, w=3840, frames=64, fill="polylines_soft", mode="left-right", div=8.0, depth="stepped", bytes_px=80,
-                   name="SBS frames/sec, 4K warp+polylines_soft", kernel="k_polytile<soft> (+ k_rowwarp<polylines_soft> over the rows it flags)",
+                   name="SBS frames/sec, 4K warp+polylines_soft", kernel="k_polypoint (+ k_rowwarp<polylines_soft> over the rows it flags)",
                    what="4K 3840x2160, polylines_soft, left-right SBS, divergence 8.0, stepped depth"),
     "cfg2": dict(h=1080, w=1920, frames=32, fill="polylines_soft", mode="left-right", div=3.5, depth="stepped", bytes_px=80,
-                 name="SBS frames/sec, 1080p warp+polylines_soft (BASELINE cfg 2)", kernel="k_polytile<soft>",
+                 name="SBS frames/sec, 1080p warp+polylines_soft (BASELINE cfg 2)", kernel="k_polypoint",
                  what="BASELINE.json configs[1]: 1080p, divergence 3.5, polylines_soft, left-right SBS, stepped depth, batch of 32 frames"),
     "cfg3": dict(h=2160, w=3840, frames=16, fill="hybrid_edge", mode="left-right", div=8.0, depth="stepped", bytes_px=80,
                  name="SBS frames/sec, 4K hybrid_edge + depth blur (BASELINE cfg 3)", kernel="k_hybrid_splat + k_rowwarp<hybrid_edge>",
