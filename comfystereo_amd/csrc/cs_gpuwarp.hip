@@ -4,10 +4,10 @@
 // The reference issues ~1000 full-frame ATen launches per eye pair (8 gather/scatter rounds, two
 // cummax scans, grid_sample).  Here one workgroup owns one image row and keeps the whole state of
 // the row (normalised depth, pixel offsets, z-buffer, inverse source map) in LDS:
-//   * each of the 8 rounds: every adjacent pixel pair proposes a target column; torch's CPU
-//     scatter_ is sequential, so the HIGHEST pair index targeting a column decides it, and a
-//     non-improving winner writes back what it gathered (quirk Q3).  -> LDS atomicMax over pair
-//     indices picks the deciding pair, which alone updates (z, src) of its column.
+//   * the 8 rounds: every adjacent pixel pair proposes a target column per round; torch's CPU scatter_ is sequential, so
+//     the HIGHEST pair index targeting a column decides it, and a non-improving winner writes back what it gathered
+//     (quirk Q3).  The deciding pair of column c in round k is the highest pair with floor(min(dl, dr)) == c - k: one LDS
+//     atomicMax pass over the pairs serves all rounds, then one lane per column replays its 8 z-tests from registers.
 //   * gap fill: "left nearest" = prefix-max scan; "right nearest" is the row's RIGHTMOST filled
 //     column (quirk Q2) = one block-wide max.
 //   * sampling: the bilinear grid_sample through the [-1,1] coordinate round trip (both axes), read
@@ -47,6 +47,8 @@ struct GwArgs {
     int noclamp;
 };
 
+struct Px3 { float x, y, z; };
+
 __constant__ csm::PowfTables c_gw_powf_tables = CS_POWF_TABLES_INIT;
 
 __device__ __forceinline__ float torch_pow(float x, int mode, float e32, const csm::PowfTables* T) {
@@ -64,12 +66,15 @@ __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id();
     const int y = blockIdx.x, frame = blockIdx.y, w = A.w, h = A.h;
-    float* ndn = (float*)smem;     // normalised depth (not convergence-shifted)
+    float* ndn = (float*)smem;     // normalised depth (not convergence-shifted); after the column pass: the left-nearest scan
     float* po = ndn + w;           // pixel offset
     float* zb = po + w;            // z-buffer
     float* sm = zb + w;            // source map
-    int* winner = (int*)(sm + w);  // deciding pair per column; later: left-nearest scan
-    uint8_t* gap = (uint8_t*)(winner + w);
+    int* M = (int*)(sm + w);       // [w + 8] highest pair index per floor(min(dl, dr)) = -7 .. w-2
+    int* W0 = M + w + 8;           // [8] per round: highest pair index clamped to column 0
+    int* W1 = W0 + 8;              // [8] per round: highest pair index clamped to column w-1
+    int* winner = (int*)ndn;
+    uint8_t* gap = (uint8_t*)(W1 + 8);
     int* ws = (int*)(gap + align16((size_t)w));
     csm::PowfTables* T = (csm::PowfTables*)(ws + 32);
     if (A.pow_mode == 4) {
@@ -93,6 +98,7 @@ __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
     const float wn = yy - yn, wsth = 1.0f - wn;
     const int iy0 = (int)yn, iy1 = min(iy0 + 1, h - 1);
     const float sxw = (float)(w - 1);
+    const bool interleaved = A.img_sc == 1 && A.img_sx == 3 && A.out_sc == 1 && A.out_sx == 3;
 
     for (int e = 0; e < A.neyes; e++) {
         const GwEye& E = A.eye[e];
@@ -122,56 +128,77 @@ __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
             float sg = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
             float od = sg * torch_pow(fabsf(s), A.pow_mode, A.e32, T);
             po[x] = od * E.div32 + E.sep32;
-            zb[x] = -1.0f;
-            sm[x] = -1.0f;
         }
+        for (int x = tid; x < w + 8 + 16; x += nt) M[x] = -1;   // (M, W0, W1 are contiguous)
         __syncthreads();
-        for (int k = 0; k < 8; k++) {
-            for (int x = tid; x < w; x += nt) winner[x] = -1;
-            __syncthreads();
-            for (int i = tid; i < w - 1; i += nt) {
-                float dl = (float)i + po[i], dr = (float)(i + 1) + po[i + 1];
-                float fs = floorf(fminf(dl, dr));
-                float cf = fminf(fmaxf(fs + (float)k, 0.0f), sxw);  // clamp(c, 0, W-1)
-                atomicMax(&winner[(int)cf], i);
-            }
-            __syncthreads();
-            for (int i = tid; i < w - 1; i += nt) {
-                float dl = (float)i + po[i], dr = (float)(i + 1) + po[i + 1];
-                float fs = floorf(fminf(dl, dr));
-                float cfl = fs + (float)k;  // exact: |fs| << 2^24
-                int cs_ = (int)fminf(fmaxf(cfl, 0.0f), sxw);
-                if (winner[cs_] != i) continue;
-                bool connected = fabsf(po[i + 1] - po[i]) < 1.5f;
-                float sw = dr - dl;
-                float safe = fabsf(sw) < (float)1e-4 ? 1.0f : sw;
-                float frac = (cfl - dl) / safe;
-                bool valid = connected && cfl >= 0.0f && cfl < (float)w && frac >= 0.0f && frac < 1.0f;
-                float iz = ndn[i] * (1.0f - frac) + ndn[i + 1] * frac;
-                if (valid && iz > zb[cs_] + (float)1e-6) {
-                    zb[cs_] = iz;
-                    sm[cs_] = (float)i + frac;
+        // ---- the 8 scatter rounds (:330-391).  In round k the pair (i, i+1) targets column clamp(fs_i + k, 0, w-1),
+        // fs_i = floor(min(dl, dr)); the HIGHEST pair index targeting a column decides it (sequential scatter_), and only
+        // that pair's z-test can change the column.  Columns are independent of each other, and the deciding pair of an
+        // interior column c in round k is the highest i with fs_i == c - k, whatever k: ONE atomic pass builds
+        // M[v] = max{i : fs_i == v}; columns 0 and w-1 collect the clamped pairs per round (W0 / W1).  Then one lane per
+        // column replays its 8 rounds in order out of registers -- no barrier between rounds.
+        for (int i = tid; i < w - 1; i += nt) {
+            const float dl = (float)i + po[i], dr = (float)(i + 1) + po[i + 1];
+            const float fs = floorf(fminf(dl, dr));
+            if (fs >= -7.0f && fs <= (float)(w - 2)) atomicMax(&M[(int)fs + 7], i);
+            if (!(fs > 0.0f) || fs + 7.0f >= sxw) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const float cfl = fs + (float)k;
+                    if (!(cfl > 0.0f)) atomicMax(&W0[k], i);          // fmaxf(NaN, 0) == 0 as well
+                    else if (cfl >= sxw) atomicMax(&W1[k], i);
                 }
             }
-            __syncthreads();
         }
-        // gap fill (:393-438)
+        __syncthreads();
         int myright = -1;
         for (int x = tid; x < w; x += nt) {
-            bool filled = !(sm[x] < 0.0f);
-            winner[x] = filled ? x : -1;
+            float z = -1.0f, src = -1.0f;
+            // Only rounds 0..3 can pass the z-test: a valid proposal needs connected (|po[i+1] - po[i]| < 1.5, so
+            // dr - dl < 2.51) and 0 <= frac < 1, i.e. dl <= fs + k < dr -- with fs >= dl - 1 that leaves k <= 3; a
+            // deciding pair that is not valid changes nothing (it writes back what it gathered, quirk Q3).
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = x == 0 ? W0[k] : (x == w - 1 ? W1[k] : M[x - k + 7]);
+                if (i < 0) continue;
+                const float po0 = po[i], po1 = po[i + 1];
+                const float dl = (float)i + po0, dr = (float)(i + 1) + po1;
+                const float fs = floorf(fminf(dl, dr));
+                const float cfl = fs + (float)k;  // exact: |fs| << 2^24
+                const bool connected = fabsf(po1 - po0) < 1.5f;
+                const float sw = dr - dl;
+                const float safe = fabsf(sw) < (float)1e-4 ? 1.0f : sw;
+                const float num = cfl - dl;
+                // (the quotient of operands of opposite sign is negative, and |num| >= 1.001 |safe| rounds to >= 1: such a
+                // proposal fails `frac >= 0 && frac < 1` whatever the rounding -- three of four do, no division for them)
+                const bool maybe = connected && cfl >= 0.0f && cfl < (float)w &&
+                                   !((num < 0.0f && safe > 0.0f) || (num > 0.0f && safe < 0.0f) || fabsf(num) >= 1.001f * fabsf(safe));
+                if (!maybe) continue;
+                const float frac = num / safe;
+                const bool valid = frac >= 0.0f && frac < 1.0f;
+                const float iz = ndn[i] * (1.0f - frac) + ndn[i + 1] * frac;
+                if (valid && iz > z + (float)1e-6) {
+                    z = iz;
+                    src = (float)i + frac;
+                }
+            }
+            zb[x] = z;
+            sm[x] = src;
+            const bool filled = !(src < 0.0f);
             if (filled) myright = max(myright, x);
             if (!filled) gap[x] = 1;
         }
+        // gap fill (:393-438): "left nearest" = prefix max of the filled columns, "right nearest" = the row's RIGHTMOST
+        // filled column (quirk Q2)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) myright = max(myright, __shfl_xor(myright, off));
         if (lane == 0) ws[16 + wave] = myright;
-        __syncthreads();
+        __syncthreads();   // (ndn is dead from here on: its storage holds the scan)
         int rightmost = -1;
         for (int i = 0; i < (nt >> 6); i++) rightmost = max(rightmost, ws[16 + i]);
+        for (int x = tid; x < w; x += nt) winner[x] = !(sm[x] < 0.0f) ? x : -1;
         __syncthreads();
         block_scan_inclusive(winner, w, -1, OpMax(), ws);
-        // po is dead now: reuse it for the final source positions
         for (int x = tid; x < w; x += nt) {
             float s = sm[x];
             if (s < 0.0f) {
@@ -189,12 +216,9 @@ __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
                 float g = lsrc * (1.0f - tb) + rsrc * tb;
                 if (hl || hr) s = g;
             }
-            po[x] = fminf(fmaxf(s, 0.0f), sxw);
-        }
-        __syncthreads();
-        // bilinear sample through the grid_sample coordinate round trip (:440-448)
-        for (int x = tid; x < w; x += nt) {
-            float gx = po[x] * 2.0f / sxw - 1.0f;
+            const float pos = fminf(fmaxf(s, 0.0f), sxw);
+            // bilinear sample through the grid_sample coordinate round trip (:440-448)
+            float gx = pos * 2.0f / sxw - 1.0f;
             float xx = (gx + 1.0f) * (sxw / 2.0f);
             xx = fminf(fmaxf(xx, 0.0f), sxw);
             float xw = floorf(xx);
@@ -206,11 +230,21 @@ __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
             const float* p10 = A.image + frame * A.img_sf + iy1 * A.img_sy + ix0 * A.img_sx;
             const float* p11 = A.image + frame * A.img_sf + iy1 * A.img_sy + ix1 * A.img_sx;
             float* o = A.out + frame * A.out_sf + (y + E.yoff) * A.out_sy + (x + E.xoff) * A.out_sx;
+            if (interleaved && E.chan_mask == 7) {   // node layout, all channels: 12-byte accesses
+                const Px3 a = *reinterpret_cast<const Px3*>(p00), b = *reinterpret_cast<const Px3*>(p01),
+                          c2 = *reinterpret_cast<const Px3*>(p10), d = *reinterpret_cast<const Px3*>(p11);
+                Px3 r;
+                r.x = a.x * nw + b.x * ne + c2.x * sw2 + d.x * se;
+                r.y = a.y * nw + b.y * ne + c2.y * sw2 + d.y * se;
+                r.z = a.z * nw + b.z * ne + c2.z * sw2 + d.z * se;
+                *reinterpret_cast<Px3*>(o) = r;
+            } else {
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                if (!(E.chan_mask & (1 << c))) continue;
-                float v = p00[c * A.img_sc] * nw + p01[c * A.img_sc] * ne + p10[c * A.img_sc] * sw2 + p11[c * A.img_sc] * se;
-                o[c * A.out_sc] = v;
+                for (int c = 0; c < 3; c++) {
+                    if (!(E.chan_mask & (1 << c))) continue;
+                    float v = p00[c * A.img_sc] * nw + p01[c * A.img_sc] * ne + p10[c * A.img_sc] * sw2 + p11[c * A.img_sc] * se;
+                    o[c * A.out_sc] = v;
+                }
             }
         }
         __syncthreads();
@@ -230,7 +264,7 @@ __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
                 float v = drow[x] * scale;
                 if (div255) v = v / 255.0f;
                 if (!A.noclamp) v = fminf(fmaxf(v, 0.0f), 1.0f);
-                dst[3 * x] = v; dst[3 * x + 1] = v; dst[3 * x + 2] = v;
+                *reinterpret_cast<Px3*>(dst + 3 * x) = Px3{v, v, v};
             }
         }
     }
@@ -252,7 +286,7 @@ __global__ void k_gpuwarp_flags(uint32_t* stats, int n, int group) {
 }
 
 static size_t gw_lds_bytes(int w) {
-    return 5 * (size_t)w * 4 + align16((size_t)w) + 32 * 4 + sizeof(csm::PowfTables) + 64;
+    return 5 * (size_t)w * 4 + 24 * 4 + align16((size_t)w) + 32 * 4 + sizeof(csm::PowfTables) + 64;
 }
 size_t gpuwarp_workspace_bytes(int, int, int) { return 256; }
 int gpuwarp_max_width() {
