@@ -62,20 +62,36 @@ __device__ __forceinline__ float torch_pow(float x, int mode, float e32, const c
     }
 }
 
+// a / b, correctly rounded: the FMA core of the IEEE expansion hipcc emits for `a / b` without its range scaling
+// (v_div_scale / v_div_fixup), which only acts near the range limits.  Callers guarantee a == 0 or 2^-60 <= |a| < 2^60
+// and 2^-40 <= |b| <= 2^40 (checked on the GPU over random operands by tools/ubench/issue_rate.hip).
+__device__ __forceinline__ float gw_div_core(float a, float b) {
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e0 = __builtin_fmaf(-b, y0, 1.0f);
+    const float y1 = __builtin_fmaf(e0, y0, y0);
+    const float q0 = a * y1;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(r0, y1, q0);
+    const float r1 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(r1, y1, q1);
+}
+__device__ __forceinline__ bool gw_core_ok(float a) { const float m = fabsf(a); return a == 0.0f || (m >= 0x1p-60f && m < 0x1p60f); }
+
 __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id();
     const int y = blockIdx.x, frame = blockIdx.y, w = A.w, h = A.h;
     float* ndn = (float*)smem;     // normalised depth (not convergence-shifted); after the column pass: the left-nearest scan
-    float* po = ndn + w;           // pixel offset
-    float* zb = po + w;            // z-buffer
-    float* sm = zb + w;            // source map
-    int* M = (int*)(sm + w);       // [w + 8] highest pair index per floor(min(dl, dr)) = -7 .. w-2
+    float* po = ndn + w;           // pixel offset; from the column pass on: the source map
+    float* D = po + w;             // x + offset = dl of pair x = dr of pair x-1
+    float* zb = D + w;             // z-buffer
+    int* M = (int*)(zb + w);       // [w + 8] highest pair index per floor(min(dl, dr)) = -7 .. w-2
     int* W0 = M + w + 8;           // [8] per round: highest pair index clamped to column 0
     int* W1 = W0 + 8;              // [8] per round: highest pair index clamped to column w-1
     int* winner = (int*)ndn;
-    uint8_t* gap = (uint8_t*)(W1 + 8);
-    int* ws = (int*)(gap + align16((size_t)w));
+    float* sm = po;
+    uint8_t* flags = (uint8_t*)(W1 + 8);   // bit 0: gap in some eye (the mask output); bit 1: pair x is connected (this eye)
+    int* ws = (int*)(flags + align16((size_t)w));
     csm::PowfTables* T = (csm::PowfTables*)(ws + 32);
     if (A.pow_mode == 4) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_gw_powf_tables);
@@ -83,7 +99,7 @@ __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
     }
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
     const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
-    for (int x = tid; x < w; x += nt) gap[x] = 0;
+    for (int x = tid; x < w; x += nt) flags[x] = 0;
     __syncthreads();
     // torch.linspace(-1, 1, H)[y] (symmetric two-sided fill, each value one fused multiply-add: bit-equal to CPU torch for
     // every H probed, 48 .. 2160) and its unnormalisation
@@ -98,6 +114,7 @@ __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
     const float wn = yy - yn, wsth = 1.0f - wn;
     const int iy0 = (int)yn, iy1 = min(iy0 + 1, h - 1);
     const float sxw = (float)(w - 1);
+    const bool sxw_ok = w >= 2 && w <= (1 << 20);   // the division core's denominator range
     const bool interleaved = A.img_sc == 1 && A.img_sx == 3 && A.out_sc == 1 && A.out_sx == 3;
 
     for (int e = 0; e < A.neyes; e++) {
@@ -118,16 +135,27 @@ __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
         const float range = dmax - dmin;
         const float crange = fmaxf(range, (float)1e-6);
         const bool has_range = range > (float)1e-6;
+        const bool crange_ok = crange < 0x1p40f;   // (>= 1e-6 by construction)
+        const float* const img_row0 = A.image + frame * A.img_sf + iy0 * A.img_sy;
+        const float* const img_row1 = A.image + frame * A.img_sf + iy1 * A.img_sy;
+        float* const out_row = A.out + frame * A.out_sf + (y + E.yoff) * A.out_sy + E.xoff * A.out_sx;
         const float* drow = E.depth + ((size_t)frame * h + y) * w;
+        // ---- pass 1: normalised depth, pixel offset, x + offset (:300-328)
         for (int x = tid; x < w; x += nt) {
-            float v = drow[x] * scale;
-            if (div255) v = v / 255.0f;
-            float nrm = has_range ? (v - dmin) / crange : 0.0f;
-            ndn[x] = nrm;
-            float s = nrm - A.conv32;
-            float sg = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
-            float od = sg * torch_pow(fabsf(s), A.pow_mode, A.e32, T);
-            po[x] = od * E.div32 + E.sep32;
+            {
+                float v = drow[x] * scale;
+                if (div255) v = v / 255.0f;
+                const float num = v - dmin;
+                float nrm = (crange_ok && gw_core_ok(num)) ? gw_div_core(num, crange) : num / crange;
+                nrm = has_range ? nrm : 0.0f;
+                ndn[x] = nrm;
+                const float s = nrm - A.conv32;
+                const float sg = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
+                const float od = sg * torch_pow(fabsf(s), A.pow_mode, A.e32, T);
+                const float p = od * E.div32 + E.sep32;
+                po[x] = p;
+                D[x] = (float)x + p;
+            }
         }
         for (int x = tid; x < w + 8 + 16; x += nt) M[x] = -1;   // (M, W0, W1 are contiguous)
         __syncthreads();
@@ -136,67 +164,84 @@ __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
         // that pair's z-test can change the column.  Columns are independent of each other, and the deciding pair of an
         // interior column c in round k is the highest i with fs_i == c - k, whatever k: ONE atomic pass builds
         // M[v] = max{i : fs_i == v}; columns 0 and w-1 collect the clamped pairs per round (W0 / W1).  Then one lane per
-        // column replays its 8 rounds in order out of registers -- no barrier between rounds.
+        // column replays its rounds in order out of registers -- no barrier between rounds.
         for (int i = tid; i < w - 1; i += nt) {
-            const float dl = (float)i + po[i], dr = (float)(i + 1) + po[i + 1];
-            const float fs = floorf(fminf(dl, dr));
-            if (fs >= -7.0f && fs <= (float)(w - 2)) atomicMax(&M[(int)fs + 7], i);
-            if (!(fs > 0.0f) || fs + 7.0f >= sxw) {
+            {
+                const float dl = D[i], dr = D[i + 1];
+                const float fs = floorf(fminf(dl, dr));
+                const bool connected = fabsf(po[i + 1] - po[i]) < 1.5f;
+                flags[i] = (uint8_t)((flags[i] & 1u) | (connected ? 2u : 0u));
+                if (fs >= -7.0f && fs <= (float)(w - 2)) atomicMax(&M[(int)fs + 7], i);
+                if (!(fs > 0.0f) || fs + 7.0f >= sxw) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const float cfl = fs + (float)k;
-                    if (!(cfl > 0.0f)) atomicMax(&W0[k], i);          // fmaxf(NaN, 0) == 0 as well
-                    else if (cfl >= sxw) atomicMax(&W1[k], i);
+                    for (int k = 0; k < 8; k++) {
+                        const float cfl = fs + (float)k;
+                        if (!(cfl > 0.0f)) atomicMax(&W0[k], i);          // fmaxf(NaN, 0) == 0 as well
+                        else if (cfl >= sxw) atomicMax(&W1[k], i);
+                    }
                 }
             }
         }
         __syncthreads();
+        // Only rounds 0..3 can pass the z-test: a valid proposal needs connected (|po[i+1] - po[i]| < 1.5, so
+        // dr - dl < 2.51) and 0 <= frac < 1, i.e. dl <= fs + k < dr -- with fs >= dl - 1 that leaves k <= 3; a
+        // deciding pair that is not valid changes nothing (it writes back what it gathered, quirk Q3).
+        // One proposal: pair i for the column value cfl (== fs_i + k).
+        auto propose = [&](int i, float cfl, float& z, float& src) {
+            const float dl = D[i], dr = D[i + 1];
+            const float sw = dr - dl;
+            const float safe = fabsf(sw) < (float)1e-4 ? 1.0f : sw;
+            const float num = cfl - dl;
+            // (the quotient of operands of opposite sign is negative, and |num| >= 1.001 |safe| rounds to >= 1: such a
+            // proposal fails `frac >= 0 && frac < 1` whatever the rounding -- three of four do, no division for them)
+            const bool maybe = (flags[i] & 2u) && cfl >= 0.0f && cfl < (float)w &&
+                               !((num < 0.0f && safe > 0.0f) || (num > 0.0f && safe < 0.0f) || fabsf(num) >= 1.001f * fabsf(safe));
+            if (!maybe) return;
+            // (here 1e-4 <= |safe| < 2.51 and |num| < 2.6: inside the division core's range unless num is tiny)
+            const float frac = gw_core_ok(num) ? gw_div_core(num, safe) : num / safe;
+            const bool valid = frac >= 0.0f && frac < 1.0f;
+            const float iz = ndn[i] * (1.0f - frac) + ndn[i + 1] * frac;
+            if (valid && iz > z + (float)1e-6) {
+                z = iz;
+                src = (float)i + frac;
+            }
+        };
         int myright = -1;
         for (int x = tid; x < w; x += nt) {
             float z = -1.0f, src = -1.0f;
-            // Only rounds 0..3 can pass the z-test: a valid proposal needs connected (|po[i+1] - po[i]| < 1.5, so
-            // dr - dl < 2.51) and 0 <= frac < 1, i.e. dl <= fs + k < dr -- with fs >= dl - 1 that leaves k <= 3; a
-            // deciding pair that is not valid changes nothing (it writes back what it gathered, quirk Q3).
+            if (x > 0 && x < w - 1) {
+                // interior column: the deciding pair of round k has fs == x - k, so its column value is x itself
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int i = x == 0 ? W0[k] : (x == w - 1 ? W1[k] : M[x - k + 7]);
-                if (i < 0) continue;
-                const float po0 = po[i], po1 = po[i + 1];
-                const float dl = (float)i + po0, dr = (float)(i + 1) + po1;
-                const float fs = floorf(fminf(dl, dr));
-                const float cfl = fs + (float)k;  // exact: |fs| << 2^24
-                const bool connected = fabsf(po1 - po0) < 1.5f;
-                const float sw = dr - dl;
-                const float safe = fabsf(sw) < (float)1e-4 ? 1.0f : sw;
-                const float num = cfl - dl;
-                // (the quotient of operands of opposite sign is negative, and |num| >= 1.001 |safe| rounds to >= 1: such a
-                // proposal fails `frac >= 0 && frac < 1` whatever the rounding -- three of four do, no division for them)
-                const bool maybe = connected && cfl >= 0.0f && cfl < (float)w &&
-                                   !((num < 0.0f && safe > 0.0f) || (num > 0.0f && safe < 0.0f) || fabsf(num) >= 1.001f * fabsf(safe));
-                if (!maybe) continue;
-                const float frac = num / safe;
-                const bool valid = frac >= 0.0f && frac < 1.0f;
-                const float iz = ndn[i] * (1.0f - frac) + ndn[i + 1] * frac;
-                if (valid && iz > z + (float)1e-6) {
-                    z = iz;
-                    src = (float)i + frac;
+                for (int k = 0; k < 4; k++) {
+                    const int i = M[x - k + 7];
+                    if (i >= 0) propose(i, (float)x, z, src);
+                }
+            } else {
+                // the clamped columns: the deciding pair's own fs + k decides whether it is in range at all
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = x == 0 ? W0[k] : W1[k];
+                    if (i >= 0) propose(i, floorf(fminf(D[i], D[i + 1])) + (float)k, z, src);
                 }
             }
-            zb[x] = z;
-            sm[x] = src;
             const bool filled = !(src < 0.0f);
             if (filled) myright = max(myright, x);
-            if (!filled) gap[x] = 1;
+            zb[x] = z;
+            sm[x] = src;   // (po's storage: the offsets were last read by the pair pass)
         }
         // gap fill (:393-438): "left nearest" = prefix max of the filled columns, "right nearest" = the row's RIGHTMOST
         // filled column (quirk Q2)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) myright = max(myright, __shfl_xor(myright, off));
         if (lane == 0) ws[16 + wave] = myright;
-        __syncthreads();   // (ndn is dead from here on: its storage holds the scan)
+        __syncthreads();   // (every read of ndn is done: its storage takes the scan)
         int rightmost = -1;
         for (int i = 0; i < (nt >> 6); i++) rightmost = max(rightmost, ws[16 + i]);
-        for (int x = tid; x < w; x += nt) winner[x] = !(sm[x] < 0.0f) ? x : -1;
+        for (int x = tid; x < w; x += nt) {
+            const bool filled = !(sm[x] < 0.0f);
+            winner[x] = filled ? x : -1;
+            if (!filled) flags[x] |= 1u;
+        }
         __syncthreads();
         block_scan_inclusive(winner, w, -1, OpMax(), ws);
         for (int x = tid; x < w; x += nt) {
@@ -218,27 +263,31 @@ __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
             }
             const float pos = fminf(fmaxf(s, 0.0f), sxw);
             // bilinear sample through the grid_sample coordinate round trip (:440-448)
-            float gx = pos * 2.0f / sxw - 1.0f;
+            const float p2 = pos * 2.0f;
+            float gx = ((sxw_ok && gw_core_ok(p2)) ? gw_div_core(p2, sxw) : p2 / sxw) - 1.0f;
             float xx = (gx + 1.0f) * (sxw / 2.0f);
             xx = fminf(fmaxf(xx, 0.0f), sxw);
             float xw = floorf(xx);
             float ww = xx - xw, we = 1.0f - ww;
             int ix0 = (int)xw, ix1 = min(ix0 + 1, w - 1);
             float nw = wsth * we, ne = wsth * ww, sw2 = wn * we, se = wn * ww;
-            const float* p00 = A.image + frame * A.img_sf + iy0 * A.img_sy + ix0 * A.img_sx;
-            const float* p01 = A.image + frame * A.img_sf + iy0 * A.img_sy + ix1 * A.img_sx;
-            const float* p10 = A.image + frame * A.img_sf + iy1 * A.img_sy + ix0 * A.img_sx;
-            const float* p11 = A.image + frame * A.img_sf + iy1 * A.img_sy + ix1 * A.img_sx;
-            float* o = A.out + frame * A.out_sf + (y + E.yoff) * A.out_sy + (x + E.xoff) * A.out_sx;
-            if (interleaved && E.chan_mask == 7) {   // node layout, all channels: 12-byte accesses
-                const Px3 a = *reinterpret_cast<const Px3*>(p00), b = *reinterpret_cast<const Px3*>(p01),
-                          c2 = *reinterpret_cast<const Px3*>(p10), d = *reinterpret_cast<const Px3*>(p11);
+            if (interleaved && E.chan_mask == 7) {   // node layout, all channels: 12-byte accesses, 32-bit offsets
+                const char* const r0 = reinterpret_cast<const char*>(img_row0);
+                const char* const r1 = reinterpret_cast<const char*>(img_row1);
+                const uint32_t o0 = 12u * (uint32_t)ix0, o1 = 12u * (uint32_t)ix1;
+                const Px3 a = *reinterpret_cast<const Px3*>(r0 + o0), b = *reinterpret_cast<const Px3*>(r0 + o1),
+                          c2 = *reinterpret_cast<const Px3*>(r1 + o0), d = *reinterpret_cast<const Px3*>(r1 + o1);
                 Px3 r;
                 r.x = a.x * nw + b.x * ne + c2.x * sw2 + d.x * se;
                 r.y = a.y * nw + b.y * ne + c2.y * sw2 + d.y * se;
                 r.z = a.z * nw + b.z * ne + c2.z * sw2 + d.z * se;
-                *reinterpret_cast<Px3*>(o) = r;
+                *reinterpret_cast<Px3*>(reinterpret_cast<char*>(out_row) + 12u * (uint32_t)x) = r;
             } else {
+                const float* p00 = img_row0 + (size_t)ix0 * A.img_sx;
+                const float* p01 = img_row0 + (size_t)ix1 * A.img_sx;
+                const float* p10 = img_row1 + (size_t)ix0 * A.img_sx;
+                const float* p11 = img_row1 + (size_t)ix1 * A.img_sx;
+                float* o = out_row + (size_t)x * A.out_sx;
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     if (!(E.chan_mask & (1 << c))) continue;
@@ -250,9 +299,9 @@ __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
         __syncthreads();
     }
     if (A.mask_u8)
-        for (int x = tid; x < w; x += nt) A.mask_u8[((size_t)frame * h + y) * w + x] = gap[x];
+        for (int x = tid; x < w; x += nt) A.mask_u8[((size_t)frame * h + y) * w + x] = flags[x] & 1u;
     if (A.mask_f32)
-        for (int x = tid; x < w; x += nt) A.mask_f32[((size_t)frame * h + y) * w + x] = gap[x] ? 1.0f : 0.0f;
+        for (int x = tid; x < w; x += nt) A.mask_f32[((size_t)frame * h + y) * w + x] = (flags[x] & 1u) ? 1.0f : 0.0f;
     if (A.depth_l) {
         // left_depth / 255 if its (sub-batch) max > 1 (:1125-1126), clamp(0,1), 3 channels (GenerateStereo.py:165-168)
         for (int e = 0; e < 2; e++) {
@@ -301,7 +350,12 @@ static int pow_mode_of(double e) { return e == 1.0 ? 0 : e == 0.5 ? 1 : e == 2.0
 
 static int gw_launch(GwArgs& A, hipStream_t stream) {
     size_t lds = gw_lds_bytes(A.w);
-    int threads = A.w <= 256 ? 256 : (A.w <= 1024 ? 512 : 1024);
+    // workgroup size: about 4 columns per thread (measured at 1080p: 512 threads 2.30 ms per 32 frames, 1024: 2.71, 256: 2.94)
+    int threads = A.w <= 1024 ? 256 : (A.w <= 2048 ? 512 : 1024);
+    const int forced = dev_switch(CS_DEBUG_PT_VARIANT);   // (development: workgroup size)
+    if (forced == 21 && A.w <= 4 * 512) threads = 512;
+    if (forced == 22 && A.w <= 4 * 256) threads = 256;
+    if (forced == 23) threads = 1024;
     hipError_t e = hipFuncSetAttribute((const void*)k_gpuwarp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return CS_EHIP;
     hipLaunchKernelGGL(k_gpuwarp, dim3(A.h, A.n), dim3(threads), lds, stream, A);
