@@ -26,7 +26,7 @@ MODE = {
 EXPORTS = [
     "cs_version", "cs_last_error", "cs_max_width", "cs_output_shape", "cs_workspace_bytes", "cs_generate",
     "cs_asd_workspace_bytes", "cs_apply_stereo_divergence", "cs_blur_workspace_bytes", "cs_directional_blur",
-    "cs_warp_workspace_bytes", "cs_forward_warp", "cs_expand_u8", "cs_stereo_shift_workspace_bytes", "cs_stereo_shift", "cs_profile", "cs_profile_read", "cs_debug_set",
+    "cs_warp_workspace_bytes", "cs_forward_warp", "cs_warp_mesh_workspace_bytes", "cs_forward_warp_mesh", "cs_expand_u8", "cs_stereo_shift_workspace_bytes", "cs_stereo_shift", "cs_profile", "cs_profile_read", "cs_debug_set",
     "cs_test_powf", "cs_test_exp",
 ]
 
@@ -93,6 +93,10 @@ def lib():
                                       c_size, vp]
     L.cs_warp_workspace_bytes.restype = c_size
     L.cs_warp_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    L.cs_warp_mesh_workspace_bytes.restype = c_size
+    L.cs_warp_mesh_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    L.cs_forward_warp_mesh.restype = c_int
+    L.cs_forward_warp_mesh.argtypes = [vp, vp, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_double, vp, vp, vp, c_size, vp]
     L.cs_forward_warp.restype = c_int
     L.cs_forward_warp.argtypes = [vp, vp, c_int, c_int, c_int, c_double, c_double, c_double, c_double, vp, vp, vp, c_size, vp]
     L.cs_stereo_shift_workspace_bytes.restype = c_size

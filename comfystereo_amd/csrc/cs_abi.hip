@@ -363,7 +363,7 @@ int cs_version(void) { return CS_ABI_VERSION; }
 const char* cs_last_error(void) { return g_err; }
 
 int cs_max_width(int fill) {
-    if (fill == CS_FILL_GPU_WARP) return gpuwarp_max_width();
+    if (fill == CS_FILL_GPU_WARP) return gpuwarp_max_width();   // (the mesh-quality variant, cs_params.flags bit 2: cs_forward_warp_mesh's limit)
     if (fill == CS_FILL_HYBRID_EDGE) return hybrid_max_width();
     if (fill < 0 || fill > CS_FILL_HYBRID_EDGE_PLUS) return 0;
     int lo = 0, hi = 1 << 16;
@@ -413,7 +413,7 @@ static WsLayout ws_layout(const cs_params* p) {
     W.wr = o; if (blur) o += al256(n * hw * 4);
     W.extra = o;
     if (p->fill == CS_FILL_HYBRID_EDGE || p->fill == CS_FILL_HYBRID_EDGE_PLUS) o += al256(hybrid_workspace_bytes(p->n, p->h, p->w));
-    if (p->fill == CS_FILL_GPU_WARP) o += al256(gpuwarp_workspace_bytes(p->n, p->h, p->w));
+    if (p->fill == CS_FILL_GPU_WARP) o += al256(gpuwarp_workspace_bytes(p->n, p->h, p->w, p->batch_size, p->flags & 4));
     W.total = o;
     return W;
 }
@@ -590,24 +590,41 @@ int cs_directional_blur(const float* depth, int n, int h, int w, double blur_str
     return e == hipSuccess ? CS_OK : fail_hip(e, "cs_directional_blur");
 }
 
-size_t cs_warp_workspace_bytes(int n, int h, int w) { return al256((size_t)n * ST_WORDS * 4) + al256(gpuwarp_workspace_bytes(n, h, w)); }
+size_t cs_warp_workspace_bytes(int n, int h, int w) { return al256((size_t)n * ST_WORDS * 4) + al256(gpuwarp_workspace_bytes(n, h, w, n, 0)); }
+size_t cs_warp_mesh_workspace_bytes(int n, int h, int w) { return al256((size_t)n * ST_WORDS * 4) + al256(gpuwarp_workspace_bytes(n, h, w, n, 1)); }
 
-int cs_forward_warp(const float* image, const float* depth, int n, int h, int w, double divergence_px,
-                    double separation_px, double exponent, double convergence, float* warped, uint8_t* gap_mask,
-                    void* workspace, size_t workspace_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int forward_warp_common(const float* image, const float* depth, int n, int h, int w, double divergence_px,
+                               double separation_px, double exponent, double convergence, int mesh, double grad_thr,
+                               float* warped, uint8_t* gap_mask, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!image || !depth || !warped || !gap_mask || !workspace) return fail(CS_EINVAL, "null pointer");
     if (n <= 0 || h <= 0 || w <= 0) return fail(CS_EINVAL, "non-positive size");
-    if (w > gpuwarp_max_width()) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
-    if (workspace_bytes < cs_warp_workspace_bytes(n, h, w)) return fail(CS_EWORKSPACE, "workspace too small");
+    if (mesh && (h < 2 || w < 2)) return fail(CS_EINVAL, "the mesh warp needs at least 2 x 2 pixels");
+    if (mesh && !(grad_thr >= 0.0)) return fail(CS_EINVAL, "gradient_threshold must be >= 0");
+    if (w > (mesh ? meshwarp_max_width() : gpuwarp_max_width())) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
+    if (workspace_bytes < (mesh ? cs_warp_mesh_workspace_bytes(n, h, w) : cs_warp_workspace_bytes(n, h, w)))
+        return fail(CS_EWORKSPACE, "workspace too small");
     uint32_t* stats = (uint32_t*)workspace;
     hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);
     hipLaunchKernelGGL(k_minmax, dim3(grid_for((size_t)h * w, 256), n), dim3(256), 0, stream, depth, h * w, stats, ST_L_MIN, ST_L_MAX);
     int rc = launch_gpuwarp_plain(image, depth, n, h, w, divergence_px, separation_px, exponent, convergence, warped,
-                                  gap_mask, stats, (char*)workspace + al256((size_t)n * ST_WORDS * 4), stream);
+                                  gap_mask, stats, (char*)workspace + al256((size_t)n * ST_WORDS * 4), stream, mesh, grad_thr);
     if (rc) return fail(rc, "gpu_warp launch failed");
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CS_OK : fail_hip(e, "cs_forward_warp");
+}
+
+int cs_forward_warp(const float* image, const float* depth, int n, int h, int w, double divergence_px,
+                    double separation_px, double exponent, double convergence, float* warped, uint8_t* gap_mask,
+                    void* workspace, size_t workspace_bytes, void* stream_) {
+    return forward_warp_common(image, depth, n, h, w, divergence_px, separation_px, exponent, convergence, 0, 1.5, warped,
+                               gap_mask, workspace, workspace_bytes, (hipStream_t)stream_);
+}
+
+int cs_forward_warp_mesh(const float* image, const float* depth, int n, int h, int w, double divergence_px,
+                         double separation_px, double exponent, double convergence, double gradient_threshold,
+                         float* warped, uint8_t* gap_mask, void* workspace, size_t workspace_bytes, void* stream_) {
+    return forward_warp_common(image, depth, n, h, w, divergence_px, separation_px, exponent, convergence, 1,
+                               gradient_threshold, warped, gap_mask, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
 int cs_expand_u8(const uint8_t* codes, float* out, size_t count, void* stream) {

@@ -45,6 +45,10 @@ struct GwArgs {
     float* mask_f32;   // node:  [n][h][w] (left | right)
     float* depth_l; float* depth_r;  // node: [n][h][w][3]
     int noclamp;
+    int mesh;          // 1: mesh-quality warp (k_meshwarp) instead of forward_warp_gpu's scatter rounds
+    float grad_thr;    // mesh: gradient_threshold of the triangle culling (reference :455, 1.5)
+    uint8_t* keep;     // mesh: [neyes][groups][h-1][w-1] keep bits (bit 0 triangle A, bit 1 triangle B)
+    int group;         // mesh: frames per group (the tensor forward_warp_mesh is handed)
 };
 
 struct Px3 { float x, y, z; };
@@ -319,6 +323,216 @@ __global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Mesh-quality warp: forward_warp_mesh (reference stereoimage_generation.py:453-689), what the reference runs whenever
+// `moderngl` is importable (:1068-1071).  The reference hands a triangle mesh to OpenGL; here the rasteriser is written
+// out.  Vertices move horizontally only, so output row k is one scanline through ONE row of quads (r = floor(wy),
+// wy = (k + .5)(H-1)/H under the reference's clip-space mapping): a workgroup stages the offsets and depths of mesh rows
+// r and r+1, every kept triangle scatters the pixels of its span into a 64-bit LDS z-buffer (interpolated depth | draw
+// order: '<' on clip_z with the first-drawn triangle winning ties), and one lane per output pixel recomputes the winning
+// triangle's interpolation for the colour.  Gaps take the nearest covered pixel on the side the eye's divergence names
+// (:664-687).  The implementation-defined parts of OpenGL rasterisation are fixed as in oracle/stereo_oracle.c
+// (`oracle_forward_warp_mesh`, the specification this kernel is tested against; no fixture of the reference can exist
+// without an OpenGL context).
+// ---------------------------------------------------------------------------------------------------------------------
+// normalised depth and pixel offset of one mesh row (the same arithmetic as pass 1 of k_gpuwarp)
+__device__ void mesh_stage_row(const GwArgs& A, const GwEye& E, const uint32_t* st, float scale, int frame, int y, float* nd,
+                               float* po, const csm::PowfTables* T) {
+    const int w = A.w;
+    const bool div255 = st[E.st_div] != 0;
+    float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
+    if (div255) { dmin = dmin / 255.0f; dmax = dmax / 255.0f; }
+    const float range = dmax - dmin;
+    const float crange = fmaxf(range, (float)1e-6);
+    const bool has_range = range > (float)1e-6;
+    const float* drow = E.depth + ((size_t)frame * A.h + y) * w;
+    for (int x = threadIdx.x; x < w; x += blockDim.x) {
+        float v = drow[x] * scale;
+        if (div255) v = v / 255.0f;
+        const float nrm = has_range ? (v - dmin) / crange : 0.0f;
+        nd[x] = nrm;
+        const float s = nrm - A.conv32;
+        const float sg = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
+        po[x] = (sg * torch_pow(fabsf(s), A.pow_mode, A.e32, T)) * E.div32 + E.sep32;
+    }
+}
+
+__device__ __forceinline__ unsigned mesh_keep_bits(float o00, float o10, float o01, float o11, float thr) {
+    const float da = fmaxf(fmaxf(fabsf(o00 - o10), fabsf(o00 - o01)), fabsf(o10 - o01));
+    const float db = fmaxf(fmaxf(fabsf(o11 - o10), fabsf(o11 - o01)), fabsf(o10 - o01));
+    return (da < thr ? 1u : 0u) | (db < thr ? 2u : 0u);
+}
+
+// keep bits of quad row r for one eye, OR-ed over the frames of a group ("keep triangle if it passes in ANY batch item")
+__global__ void __launch_bounds__(512) k_mesh_keep(GwArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int r = blockIdx.x, grp = blockIdx.y, e = blockIdx.z, w = A.w, h = A.h;
+    float* nd = (float*)smem;      // (unused here, staged by the shared helper)
+    float* o0 = nd + w;
+    float* o1 = o0 + w;
+    uint8_t* acc = (uint8_t*)(o1 + w);
+    csm::PowfTables* T = (csm::PowfTables*)(acc + align16((size_t)w));
+    const GwEye& E = A.eye[e];
+    if (!E.enabled) return;
+    if (A.pow_mode == 4) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_gw_powf_tables);
+        for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += nt) reinterpret_cast<uint32_t*>(T)[i] = src[i];
+    }
+    for (int x = tid; x < w; x += nt) acc[x] = 0;
+    __syncthreads();
+    const int f0 = grp * A.group, f1 = min(f0 + A.group, A.n);
+    for (int f = f0; f < f1; f++) {
+        const uint32_t* st = A.stats + (size_t)f * ST_WORDS;
+        const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
+        mesh_stage_row(A, E, st, scale, f, r, nd, o0, T);
+        __syncthreads();
+        mesh_stage_row(A, E, st, scale, f, r + 1, nd, o1, T);
+        __syncthreads();
+        for (int x = tid; x < w - 1; x += nt) acc[x] |= (uint8_t)mesh_keep_bits(o0[x], o0[x + 1], o1[x], o1[x + 1], A.grad_thr);
+        __syncthreads();
+    }
+    const int ngroups = (A.n + A.group - 1) / A.group;
+    uint8_t* dst = A.keep + (((size_t)e * ngroups + grp) * (h - 1) + r) * (size_t)(w - 1);
+    for (int x = tid; x < w - 1; x += nt) dst[x] = acc[x];
+}
+
+__global__ void __launch_bounds__(1024, 8) k_meshwarp(GwArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id();
+    const int k = blockIdx.x, frame = blockIdx.y, w = A.w, h = A.h;
+    unsigned long long* key = (unsigned long long*)smem;   // [w] ordered depth << 32 | ~draw index; 0 = uncovered
+    float* n0 = (float*)(key + w);   // normalised depth, mesh rows r / r+1
+    float* n1 = n0 + w;
+    float* o0 = n1 + w;              // pixel offset, mesh rows r / r+1
+    float* o1 = o0 + w;
+    int* fillcol = (int*)(o1 + w);   // nearest covered pixel (scan)
+    uint8_t* flags = (uint8_t*)(fillcol + w);   // gap in some eye
+    int* ws = (int*)(flags + align16((size_t)w));
+    csm::PowfTables* T = (csm::PowfTables*)(ws + 32);
+    if (A.pow_mode == 4) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_gw_powf_tables);
+        for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += nt) reinterpret_cast<uint32_t*>(T)[i] = src[i];
+    }
+    const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
+    const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
+    for (int x = tid; x < w; x += nt) flags[x] = 0;
+    // the scanline of output row k in mesh coordinates
+    const float sc = (float)(w - 1) / (float)w, isc = (float)w / (float)(w - 1), scy = (float)(h - 1) / (float)h;
+    const float wy = ((float)k + 0.5f) * scy;
+    const int r = (int)floorf(wy);
+    const float t = wy - (float)r, omt = 1.0f - t;
+    const int ngroups = (A.n + A.group - 1) / A.group, grp = frame / A.group;
+    const int BIG = 1 << 29;
+    __syncthreads();
+
+    for (int e = 0; e < A.neyes; e++) {
+        const GwEye& E = A.eye[e];
+        if (!E.enabled) {
+            if (A.out)
+                for (int x = tid; x < w; x += nt)
+                    for (int c = 0; c < 3; c++)
+                        if (E.chan_mask & (1 << c))
+                            A.out[frame * A.out_sf + (k + E.yoff) * A.out_sy + (x + E.xoff) * A.out_sx + c * A.out_sc] =
+                                A.image[frame * A.img_sf + k * A.img_sy + x * A.img_sx + c * A.img_sc];
+            continue;
+        }
+        mesh_stage_row(A, E, st, scale, frame, r, n0, o0, T);
+        mesh_stage_row(A, E, st, scale, frame, r + 1, n1, o1, T);
+        for (int x = tid; x < w; x += nt) key[x] = 0ull;
+        __syncthreads();
+        const uint8_t* keep = A.keep + (((size_t)e * ngroups + grp) * (h - 1) + r) * (size_t)(w - 1);
+        // the span of triangle `type` of quad x on the scanline: end points a -> e2 (x), their depths
+        auto span = [&](int x, int type, float& a, float& e2, float& za, float& ze) {
+            const float P00 = (float)x + o0[x], P10 = (float)(x + 1) + o0[x + 1], P01 = (float)x + o1[x],
+                        P11 = (float)(x + 1) + o1[x + 1];
+            const float xl = omt * P00 + t * P01, xd = omt * P10 + t * P01, xr = omt * P10 + t * P11;
+            const float zl = omt * n0[x] + t * n1[x], zd = omt * n0[x + 1] + t * n1[x], zr = omt * n0[x + 1] + t * n1[x + 1];
+            a = type ? xd : xl; e2 = type ? xr : xd;
+            za = type ? zd : zl; ze = type ? zr : zd;
+        };
+        // ---- scatter: every kept triangle into the pixels of its span
+        for (int x = tid; x < w - 1; x += nt) {
+            const unsigned kb = keep[x];
+#pragma unroll
+            for (int type = 0; type < 2; type++) {
+                if (!(kb & (1u << type))) continue;
+                float a, e2, za, ze;
+                span(x, type, a, e2, za, ze);
+                const float lo = fminf(a, e2), hi = fmaxf(a, e2);
+                if (!(lo < hi)) continue;
+                float f0 = floorf(lo * isc) - 1.0f, f1 = floorf(hi * isc) + 1.0f;
+                f0 = fmaxf(f0, 0.0f); f1 = fminf(f1, (float)(w - 1));
+                if (!(f0 <= f1)) continue;
+                const unsigned order = 0xffffffffu - (unsigned)(type * (w - 1) + x);
+                for (int px = (int)f0; px <= (int)f1; px++) {
+                    const float u = ((float)px + 0.5f) * sc;
+                    if (!(lo <= u && u < hi)) continue;
+                    const float s = (u - a) / (e2 - a);
+                    const float z = (1.0f - s) * za + s * ze;
+                    atomicMax(&key[px], ((unsigned long long)csm::f2ord(z) << 32) | order);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- covered pixels; nearest covered pixel on the side this eye fills from
+        const bool from_left = !(E.div32 < 0.0f);
+        for (int x = tid; x < w; x += nt) {
+            const bool covered = key[x] != 0ull;
+            fillcol[x] = covered ? x : (from_left ? -1 : BIG);
+            if (!covered) flags[x] = 1;
+        }
+        __syncthreads();
+        if (from_left) block_scan_inclusive(fillcol, w, -1, OpMax(), ws);
+        else block_scan_inclusive(fillcol, w, BIG, OpMin(), ws, true);
+        // ---- colours
+        const float* const img_r0 = A.image + frame * A.img_sf + r * A.img_sy;
+        const float* const img_r1 = img_r0 + A.img_sy;
+        float* const out_row = A.out + frame * A.out_sf + (k + E.yoff) * A.out_sy + E.xoff * A.out_sx;
+        for (int px = tid; px < w; px += nt) {
+            const int f = fillcol[px];
+            float c3[3] = {0.0f, 0.0f, 0.0f};
+            if (f >= 0 && f < w) {   // (the pixel itself when it is covered)
+                const unsigned draw = 0xffffffffu - (unsigned)(key[f] & 0xffffffffull);
+                const int type = draw >= (unsigned)(w - 1) ? 1 : 0, x = (int)draw - type * (w - 1);
+                float a, e2, za, ze;
+                span(x, type, a, e2, za, ze);
+                const float u = ((float)f + 0.5f) * sc;
+                const float s = (u - a) / (e2 - a), oms = 1.0f - s;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float c00 = img_r0[(size_t)x * A.img_sx + c * A.img_sc], c10 = img_r0[(size_t)(x + 1) * A.img_sx + c * A.img_sc],
+                                c01 = img_r1[(size_t)x * A.img_sx + c * A.img_sc], c11 = img_r1[(size_t)(x + 1) * A.img_sx + c * A.img_sc];
+                    const float cl = omt * c00 + t * c01, cd = omt * c10 + t * c01, cr = omt * c10 + t * c11;
+                    c3[c] = oms * (type ? cd : cl) + s * (type ? cr : cd);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                if (E.chan_mask & (1 << c)) out_row[(size_t)px * A.out_sx + c * A.out_sc] = c3[c];
+        }
+        __syncthreads();
+    }
+    if (A.mask_u8)
+        for (int x = tid; x < w; x += nt) A.mask_u8[((size_t)frame * h + k) * w + x] = flags[x];
+    if (A.mask_f32)
+        for (int x = tid; x < w; x += nt) A.mask_f32[((size_t)frame * h + k) * w + x] = flags[x] ? 1.0f : 0.0f;
+    if (A.depth_l) {
+        for (int e = 0; e < 2; e++) {
+            const GwEye& E = A.eye[e];
+            const bool div255 = st[E.st_div] != 0;
+            const float* drow = E.depth + ((size_t)frame * h + k) * w;
+            float* dst = (e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + k) * w) * 3;
+            for (int x = tid; x < w; x += nt) {
+                float v = drow[x] * scale;
+                if (div255) v = v / 255.0f;
+                if (!A.noclamp) v = fminf(fmaxf(v, 0.0f), 1.0f);
+                *reinterpret_cast<Px3*>(dst + 3 * x) = Px3{v, v, v};
+            }
+        }
+    }
+}
+
 // forward_warp_gpu's `if (d_max_all > 1.0).any(): d = d / 255.0` is global over the tensor it is handed,
 // i.e. over one reference sub-batch (`group` frames).
 __global__ void k_gpuwarp_flags(uint32_t* stats, int n, int group) {
@@ -337,7 +551,22 @@ __global__ void k_gpuwarp_flags(uint32_t* stats, int n, int group) {
 static size_t gw_lds_bytes(int w) {
     return 5 * (size_t)w * 4 + 24 * 4 + align16((size_t)w) + 32 * 4 + sizeof(csm::PowfTables) + 64;
 }
-size_t gpuwarp_workspace_bytes(int, int, int) { return 256; }
+static size_t mesh_lds_bytes(int w) { return 8 * (size_t)w + 5 * (size_t)w * 4 + align16((size_t)w) + 32 * 4 + sizeof(csm::PowfTables) + 64; }
+static size_t mesh_keep_lds_bytes(int w) { return 3 * (size_t)w * 4 + align16((size_t)w) + sizeof(csm::PowfTables) + 64; }
+// (the mesh variant's keep bits: 2 eyes x groups x (h-1)(w-1) bytes)
+size_t gpuwarp_workspace_bytes(int n, int h, int w, int group, int mesh) {
+    if (!mesh) return 256;
+    const int g = group > 0 && group < n ? group : n;
+    return 256 + 2 * (size_t)((n + g - 1) / g) * h * w;
+}
+int meshwarp_max_width() {
+    int lo = 2, hi = 1 << 15;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) / 2;
+        if (mesh_lds_bytes(mid) <= CS_LDS_BYTES) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
 int gpuwarp_max_width() {
     int lo = 2, hi = 1 << 15;
     while (lo < hi) {
@@ -349,6 +578,20 @@ int gpuwarp_max_width() {
 static int pow_mode_of(double e) { return e == 1.0 ? 0 : e == 0.5 ? 1 : e == 2.0 ? 2 : e == 3.0 ? 3 : e == 0.0 ? 5 : 4; }
 
 static int gw_launch(GwArgs& A, hipStream_t stream) {
+    if (A.mesh) {
+        if (A.h < 2 || A.w < 2) return CS_EINVAL;   // the reference divides by H - 1 and W - 1
+        if (A.w > meshwarp_max_width()) return CS_ELIMIT;
+        const int ngroups = (A.n + A.group - 1) / A.group;
+        const int threads = A.w <= 1024 ? 256 : (A.w <= 2048 ? 512 : 1024);
+        size_t lk = mesh_keep_lds_bytes(A.w), lm = mesh_lds_bytes(A.w);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mesh_keep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lk);
+        if (e != hipSuccess) return CS_EHIP;
+        e = hipFuncSetAttribute((const void*)k_meshwarp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
+        if (e != hipSuccess) return CS_EHIP;
+        hipLaunchKernelGGL(k_mesh_keep, dim3(A.h - 1, ngroups, A.neyes), dim3(threads > 512 ? 512 : threads), lk, stream, A);
+        hipLaunchKernelGGL(k_meshwarp, dim3(A.h, A.n), dim3(threads), lm, stream, A);
+        return CS_OK;
+    }
     size_t lds = gw_lds_bytes(A.w);
     // workgroup size: about 4 columns per thread (measured at 1080p: 512 threads 2.30 ms per 32 frames, 1024: 2.71, 256: 2.94)
     int threads = A.w <= 1024 ? 256 : (A.w <= 2048 ? 512 : 1024);
@@ -364,7 +607,7 @@ static int gw_launch(GwArgs& A, hipStream_t stream) {
 
 int launch_gpuwarp_plain(const float* image, const float* depth, int n, int h, int w, double div_px, double sep_px,
                          double exponent, double convergence, float* warped, uint8_t* gap_mask, uint32_t* stats,
-                         void*, hipStream_t stream) {
+                         void* extra, hipStream_t stream, int mesh, double grad_thr) {
     hipLaunchKernelGGL(k_gpuwarp_flags, dim3((n + 63) / 64), dim3(64), 0, stream, stats, n, n);
     GwArgs A;
     memset(&A, 0, sizeof(A));
@@ -384,12 +627,13 @@ int launch_gpuwarp_plain(const float* image, const float* depth, int n, int h, i
     A.out = warped;
     A.out_sf = A.img_sf; A.out_sc = A.img_sc; A.out_sy = w; A.out_sx = 1;
     A.mask_u8 = gap_mask;
+    A.mesh = mesh; A.grad_thr = (float)grad_thr; A.keep = (uint8_t*)extra + 256; A.group = n;
     return gw_launch(A, stream);
 }
 
 int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL, const float* dR, int scale_from_stats,
                         uint32_t* stats, float* stereo, float* depth_l, float* depth_r, float* mask, int out_h,
-                        int out_w, void*, hipStream_t stream) {
+                        int out_w, void* extra, hipStream_t stream) {
     const int n = p->n, h = p->h, w = p->w;
     int group = p->batch_size > 0 ? (p->batch_size < n ? p->batch_size : n) : n;
     hipLaunchKernelGGL(k_gpuwarp_flags, dim3((n + 63) / 64), dim3(64), 0, stream, stats, n, group);
@@ -427,6 +671,7 @@ int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL,
     A.mask_f32 = mask;
     A.depth_l = depth_l; A.depth_r = depth_r;
     A.noclamp = p->flags & 1;
+    A.mesh = (p->flags & 4) ? 1 : 0; A.grad_thr = 1.5f; A.keep = (uint8_t*)extra + 256; A.group = group;
     return gw_launch(A, stream);
 }
 

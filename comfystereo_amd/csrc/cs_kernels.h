@@ -85,11 +85,13 @@ int hybrid_max_width();
 int launch_hybrid(const RowArgs& A, void* workspace, hipStream_t stream, int plus = 0);  // plus: hybrid_edge_plus
 
 // cs_gpuwarp.hip
-size_t gpuwarp_workspace_bytes(int n, int h, int w);
+size_t gpuwarp_workspace_bytes(int n, int h, int w, int group, int mesh);   // group: frames per reference sub-batch
 int gpuwarp_max_width();
+int meshwarp_max_width();
+// mesh != 0: forward_warp_mesh (mesh-quality rasteriser) instead of forward_warp_gpu
 int launch_gpuwarp_plain(const float* image, const float* depth, int n, int h, int w, double div_px, double sep_px,
                          double exponent, double convergence, float* warped, uint8_t* gap_mask, uint32_t* stats,
-                         void* workspace, hipStream_t stream);
+                         void* workspace, hipStream_t stream, int mesh = 0, double grad_thr = 1.5);
 int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL, const float* dR, int scale_from_stats,
                         uint32_t* stats, float* stereo, float* depth_l, float* depth_r, float* mask, int out_h,
                         int out_w, void* workspace, hipStream_t stream);

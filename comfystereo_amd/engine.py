@@ -25,6 +25,12 @@ def _dev(t):
     return t
 
 
+# The reference picks its gpu_warp implementation at import time: forward_warp_mesh when `moderngl` is importable,
+# forward_warp_gpu otherwise (stereoimage_generation.py:18-24, :1068-1071).  Here both are HIP kernels and the choice is
+# this switch (cs_params.flags bit 2): False = forward_warp_gpu semantics (the parity-pinned default), True = mesh quality.
+MESH_WARP = False
+
+
 def make_params(n, h, w, depth_h, depth_w, depth_c, fill, mode, divergence, separation, stereo_balance,
                 convergence_point, stereo_offset_exponent, depth_map_blur, depth_blur_strength,
                 depth_blur_edge_threshold, depth_blur_falloff, depth_blur_vert_smooth, batch_size):
@@ -38,6 +44,8 @@ def make_params(n, h, w, depth_h, depth_w, depth_c, fill, mode, divergence, sepa
     p.convergence_point, p.stereo_offset_exponent = float(convergence_point), float(stereo_offset_exponent)
     p.depth_blur_strength, p.depth_blur_edge_threshold = float(depth_blur_strength), float(depth_blur_edge_threshold)
     p.depth_blur_falloff = float(depth_blur_falloff)
+    if MESH_WARP and fill == 'gpu_warp':
+        p.flags |= 4
     return p
 
 
@@ -155,6 +163,25 @@ def forward_warp(image, depth, divergence_px, separation_px, stereo_offset_expon
     _native.check(L.cs_forward_warp(_ptr(image), _ptr(depth), b, h, w, float(divergence_px), float(separation_px),
                                     float(stereo_offset_exponent), float(convergence_point), _ptr(warped), _ptr(mask),
                                     _ptr(ws), nb, _stream()))
+    return warped, mask.bool()
+
+
+def forward_warp_mesh(image, depth, divergence_px, separation_px, stereo_offset_exponent, convergence_point=0.5,
+                      gradient_threshold=1.5):
+    """reference stereoimage_generation.py:453-689 (the mesh-quality warp): image [B,3,H,W], depth [B,H,W] ->
+    (warped, gap mask bool)."""
+    L = _native.lib()
+    image = _dev(image).contiguous().float()
+    depth = _dev(depth).contiguous().float()
+    b, c, h, w = image.shape
+    assert c == 3
+    warped = torch.empty_like(image)
+    mask = torch.empty((b, h, w), dtype=torch.uint8, device=image.device)
+    nb = L.cs_warp_mesh_workspace_bytes(b, h, w)
+    ws = torch.empty((max(nb, 256),), dtype=torch.uint8, device=image.device)
+    _native.check(L.cs_forward_warp_mesh(_ptr(image), _ptr(depth), b, h, w, float(divergence_px), float(separation_px),
+                                         float(stereo_offset_exponent), float(convergence_point), float(gradient_threshold),
+                                         _ptr(warped), _ptr(mask), _ptr(ws), nb, _stream()))
     return warped, mask.bool()
 
 

@@ -7,7 +7,7 @@
 Same names, argument order, defaults, return types and error behaviour; the arithmetic runs in the
 HIP kernels behind the C ABI (there is no CPU fallback: without a GPU these functions raise).
 Extras kept for callers of the reference's building blocks: apply_stereo_divergence (:1576-1620),
-directional_motion_blur_gpu (:1171-1251), forward_warp_gpu (:277-450).
+directional_motion_blur_gpu (:1171-1251), forward_warp_gpu (:277-450), forward_warp_mesh (:453-689).
 """
 import numpy as np
 import torch
@@ -19,6 +19,12 @@ _CPU_FILLS = ('none', 'naive', 'naive_interpolating', 'polylines_soft', 'polylin
               'none_post', 'inverse_post', 'hybrid_edge_plus')  # the last three: no UI string reaches them (:1605-1610)
 _MODES = ('left-right', 'right-left', 'top-bottom', 'bottom-top', 'red-cyan-anaglyph', 'left-only', 'only-right',
           'cyan-red-reverseanaglyph')
+
+
+# The reference's import-time switch (:18-24): True makes create_stereoimages_gpu warp through forward_warp_mesh, the
+# mesh-quality rasteriser, instead of forward_warp_gpu (:1068-1071).  Both are HIP kernels here; False (the default) is the
+# parity-pinned path.  engine.MESH_WARP is the same switch for the node.
+MODERNGL_AVAILABLE = False
 
 
 def _device():
@@ -108,7 +114,9 @@ def create_stereoimages_gpu(image_tensor, depth_tensor, divergence, separation=0
         p = engine.make_params(b, h, w, h, w, 1, 'gpu_warp', m, divergence, separation, stereo_balance, convergence_point,
                                stereo_offset_exponent, direction_aware_depth_blur, depth_blur_strength,
                                depth_blur_edge_threshold, depth_blur_falloff, depth_blur_vert_smooth, b)
-        p.flags = 1  # module-level depth outputs are not clamped (the node clamps them afterwards)
+        p.flags |= 1  # module-level depth outputs are not clamped (the node clamps them afterwards)
+        if MODERNGL_AVAILABLE:
+            p.flags |= 4
         stereo, dl, dr, mk = engine.Plan(p, dev).run(img, dep)
         results.append(stereo.permute(0, 3, 1, 2))
         lo, ro, mask = dl[..., 0], dr[..., 0], mk > 0.5
@@ -146,3 +154,11 @@ def forward_warp_gpu(image_tensor, depth_tensor, divergence_px, separation_px, s
     dev = _device()
     return engine.forward_warp(image_tensor.to(dev, torch.float32), depth_tensor.to(dev, torch.float32), divergence_px,
                                separation_px, stereo_offset_exponent, convergence_point)
+
+
+def forward_warp_mesh(image_tensor, depth_tensor, divergence_px, separation_px, stereo_offset_exponent,
+                      convergence_point=0.5, gradient_threshold=1.5, max_stretch=8):
+    """reference :453-689 -> (warped [B,C,H,W], gap_mask bool [B,H,W]); `max_stretch` is unused there as well."""
+    dev = _device()
+    return engine.forward_warp_mesh(image_tensor.to(dev, torch.float32), depth_tensor.to(dev, torch.float32), divergence_px,
+                                    separation_px, stereo_offset_exponent, convergence_point, gradient_threshold)

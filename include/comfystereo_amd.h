@@ -88,7 +88,10 @@ typedef struct cs_params {
                                    create_stereoimages_gpu returns them unclamped, :1125-1126)
                                    bit 1: `stereo` receives the uint8 codes k (value = k/255) instead of
                                    float32 -- the compact form frame shards are all-gathered in; CPU
-                                   techniques only (gpu_warp colours are genuine floats)           */
+                                   techniques only (gpu_warp colours are genuine floats)
+                                   bit 2: fill gpu_warp runs the mesh-quality warp (forward_warp_mesh,
+                                   :453-689 -- what the reference does when moderngl is importable,
+                                   :1068-1071) instead of forward_warp_gpu; see cs_forward_warp_mesh */
     double divergence, separation, stereo_balance, convergence_point, stereo_offset_exponent;
     double depth_blur_strength, depth_blur_edge_threshold, depth_blur_falloff;
 } cs_params;
@@ -150,6 +153,20 @@ CS_API size_t cs_warp_workspace_bytes(int n, int h, int w);
 CS_API int cs_forward_warp(const float *image, const float *depth, int n, int h, int w, double divergence_px,
                     double separation_px, double stereo_offset_exponent, double convergence_point, float *warped,
                     uint8_t *gap_mask, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * forward_warp_mesh (reference stereoimage_generation.py:453-689), the mesh-quality warp the reference uses whenever
+ * `moderngl` is importable (:1068-1071): same tensors as cs_forward_warp plus the culling threshold (reference
+ * default 1.5).  The reference rasterises through OpenGL; the parts OpenGL leaves to the implementation are fixed as
+ * documented in oracle/stereo_oracle.c (oracle_forward_warp_mesh) -- no bit parity with a particular GL driver is
+ * claimed.  Needs h >= 2 and w >= 2.  Through cs_generate the same warp is selected by cs_params.flags bit 2 with
+ * fill CS_FILL_GPU_WARP.  workspace: cs_warp_mesh_workspace_bytes(n, h, w).
+ */
+CS_API size_t cs_warp_mesh_workspace_bytes(int n, int h, int w);
+CS_API int cs_forward_warp_mesh(const float *image, const float *depth, int n, int h, int w, double divergence_px,
+                         double separation_px, double stereo_offset_exponent, double convergence_point,
+                         double gradient_threshold, float *warped, uint8_t *gap_mask, void *workspace,
+                         size_t workspace_bytes, void *stream);
 
 /*
  * out[i] = codes[i] / 255 (float32, true division): expands a uint8 stereoscope (cs_params.flags bit 1), e.g.

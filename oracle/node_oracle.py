@@ -103,8 +103,9 @@ def create_stereoimages(img_chw, depth_hw, divergence, separation=0.0, modes=Non
 def create_stereoimages_gpu(img_bchw, depth_bhw, divergence, separation=0.0, modes=None, stereo_balance=0.0,
                             stereo_offset_exponent=1.0, convergence_point=0.5, depth_blur_strength=0.0,
                             depth_blur_edge_threshold=6.0, direction_aware_depth_blur=False, depth_blur_falloff=1.0,
-                            depth_blur_vert_smooth=0):
-    """-> (list of float32 [B,3,H',W'], left_depth [B,H,W], right_depth [B,H,W], mask bool [B,H,W])."""
+                            depth_blur_vert_smooth=0, mesh=False):
+    """-> (list of float32 [B,3,H',W'], left_depth [B,H,W], right_depth [B,H,W], mask bool [B,H,W]).
+    mesh: warp_fn = forward_warp_mesh (the reference's choice when moderngl is importable, :1068-1071)."""
     modes = ['left-right'] if modes is None else (modes if isinstance(modes, list) else [modes])
     img = np.ascontiguousarray(img_bchw, dtype=F32)
     depth = np.ascontiguousarray(depth_bhw, dtype=F32)
@@ -121,10 +122,11 @@ def create_stereoimages_gpu(img_bchw, depth_bhw, divergence, separation=0.0, mod
     left_px, right_px, sep_px = (left_div / 100.0) * W, (right_div / 100.0) * W, (separation / 100.0) * W
     lmask = rmask = np.zeros((B, H, W), dtype=bool)
     left_eye = right_eye = img
+    warp_fn = oracle.forward_warp_mesh if mesh else oracle.forward_warp_gpu
     if not left_div < 0.001:
-        left_eye, lmask = oracle.forward_warp_gpu(img, left_d, +left_px, -sep_px, stereo_offset_exponent, convergence_point)
+        left_eye, lmask = warp_fn(img, left_d, +left_px, -sep_px, stereo_offset_exponent, convergence_point)
     if not right_div < 0.001:
-        right_eye, rmask = oracle.forward_warp_gpu(img, right_d, -right_px, sep_px, stereo_offset_exponent, convergence_point)
+        right_eye, rmask = warp_fn(img, right_d, -right_px, sep_px, stereo_offset_exponent, convergence_point)
     results = [assemble(left_eye, right_eye, m, 1, 3, 2) for m in modes]
     lo = left_d / F32(255.0) if left_d.max() > 1.0 else left_d
     ro = right_d / F32(255.0) if right_d.max() > 1.0 else right_d
@@ -133,7 +135,7 @@ def create_stereoimages_gpu(img_bchw, depth_bhw, divergence, separation=0.0, mod
 
 def generate(image, depth_map, divergence, separation, modes, stereo_balance, convergence_point, stereo_offset_exponent,
              fill_technique, depth_blur_edge_threshold, depth_blur_strength, depth_map_blur, depth_blur_falloff=1.0,
-             depth_blur_vert_smooth=0, batch_size=4):
+             depth_blur_vert_smooth=0, batch_size=4, mesh=False):
     """-> (stereoscope [N,H',W',3], depth_left [N,H,W,3], depth_right [N,H,W,3], mask [N,H',W' | H,W]) float32."""
     image = np.asarray(image, dtype=F32)
     depth_map = np.asarray(depth_map, dtype=F32)
@@ -151,7 +153,7 @@ def generate(image, depth_map, divergence, separation, modes, stereo_balance, co
                                                      stereo_offset_exponent, convergence_point, depth_blur_strength,
                                                      depth_blur_edge_threshold, depth_map_blur,
                                                      depth_blur_falloff=depth_blur_falloff,
-                                                     depth_blur_vert_smooth=depth_blur_vert_smooth)
+                                                     depth_blur_vert_smooth=depth_blur_vert_smooth, mesh=mesh)
             stereo.append(res[0].transpose(0, 2, 3, 1))
             dls.append(np.repeat(np.clip(lo, 0, 1)[..., None], 3, -1))
             drs.append(np.repeat(np.clip(ro, 0, 1)[..., None], 3, -1))

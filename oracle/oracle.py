@@ -76,6 +76,10 @@ def lib():
             L.oracle_forward_warp_gpu.restype = None
             L.oracle_forward_warp_gpu.argtypes = [f32p, f32p, c_int, c_int, c_int, c_double, c_double, c_double,
                                                   c_double, f32p, u8p]
+        if hasattr(L, "oracle_forward_warp_mesh"):
+            L.oracle_forward_warp_mesh.restype = None
+            L.oracle_forward_warp_mesh.argtypes = [f32p, f32p, c_int, c_int, c_int, c_double, c_double, c_double,
+                                                   c_double, c_double, f32p, u8p]
         _lib = L
     return _lib
 
@@ -139,4 +143,19 @@ def forward_warp_gpu(image_f32_bchw, depth_f32_bhw, divergence_px, separation_px
     mask = np.empty((b, h, w), dtype=np.uint8)
     lib().oracle_forward_warp_gpu(_f32(img), _f32(dep), b, h, w, float(divergence_px), float(separation_px),
                                   float(exponent), float(convergence), _f32(out), _u8(mask))
+    return out, mask.astype(bool)
+
+
+def forward_warp_mesh(image_f32_bchw, depth_f32_bhw, divergence_px, separation_px, exponent, convergence=0.5,
+                      gradient_threshold=1.5):
+    """The mesh-quality warp (reference stereoimage_generation.py:453-689, `forward_warp_mesh`) as specified in
+    stereo_oracle.c -- PARITY UNPINNED (no moderngl / OpenGL here) -> (warped [B,C,H,W] f32, gap mask bool)."""
+    img = np.ascontiguousarray(image_f32_bchw, dtype=np.float32)
+    dep = np.ascontiguousarray(depth_f32_bhw, dtype=np.float32)
+    b, c, h, w = img.shape
+    assert c == 3 and dep.shape == (b, h, w)
+    out = np.empty_like(img)
+    mask = np.empty((b, h, w), dtype=np.uint8)
+    lib().oracle_forward_warp_mesh(_f32(img), _f32(dep), b, h, w, float(divergence_px), float(separation_px),
+                                   float(exponent), float(convergence), float(gradient_threshold), _f32(out), _u8(mask))
     return out, mask.astype(bool)

@@ -810,3 +810,146 @@ EXPORT void oracle_forward_warp_gpu(const float *image, const float *depth, int 
     }
     free(nd); free(po); free(dest); free(src); free(zb); free(nz); free(ns); free(cs); free(gy);
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * forward_warp_mesh (reference stereoimage_generation.py:453-689): the mesh-quality warp the reference runs whenever
+ * `moderngl` is importable (:1068-1071).  PARITY UNPINNED: moderngl / an OpenGL context do not exist in this image, the
+ * reference's rasteriser (sub-pixel snapping, interpolation precision, 24-bit depth buffer) is implementation-defined,
+ * so no fixture of the reference can be produced here.  This function is the SPECIFICATION the HIP kernel
+ * (cs_gpuwarp.hip, k_meshwarp) is tested against; it follows the reference's geometry exactly and fixes the
+ * implementation-defined parts:
+ *   - vertices: pixel (y, x) at (x + pixel_offset, y); quad (y, x) = triangles A (v00, v10, v01) and B (v11, v10, v01),
+ *     all A's drawn before all B's, each in row-major order (:507-520)
+ *   - a triangle is kept when the largest pairwise |offset difference| of its vertices is < gradient_threshold in ANY
+ *     frame of the tensor (:523-535)
+ *   - window mapping of the clip coordinates (:546-548): vertex x * W/(W-1), vertex row * H/(H-1); the fragment of
+ *     output pixel (k, px) sits at its centre, i.e. at mesh coordinates u = (px + .5)(W-1)/W, wy = (k + .5)(H-1)/H
+ *   - coverage: half-open spans [lo, hi) of the scanline wy through the triangle; attributes interpolated along the
+ *     scanline between the two edge points (equal to barycentric interpolation in exact arithmetic), float32
+ *   - depth test '<' on clip_z == '>' on the interpolated normalised depth; equal depth: the triangle drawn first wins
+ *   - gap fill (:664-687): nearest covered pixel to the left (divergence >= 0) or to the right (< 0); uncovered pixels
+ *     without one stay 0 (the cleared framebuffer)
+ * ------------------------------------------------------------------------------------------------------------------- */
+EXPORT void oracle_forward_warp_mesh(const float *image, const float *depth, int B, int H, int W, double div_px,
+                                     double sep_px, double exponent, double convergence, double grad_thr, float *out,
+                                     uint8_t *mask) {
+    size_t hw = (size_t)H * W;
+    int any_gt1 = 0;
+    for (size_t i = 0; i < hw * B; i++)
+        if (depth[i] > 1.0f) { any_gt1 = 1; break; }
+    float div32 = (float)div_px, sep32 = (float)sep_px, conv32 = (float)convergence, thr = (float)grad_thr;
+    float *nd = (float *)malloc(sizeof(float) * hw * B), *po = (float *)malloc(sizeof(float) * hw * B);
+    for (int b = 0; b < B; b++) {
+        const float *db = depth + hw * b;
+        float dmin = INFINITY, dmax = -INFINITY;
+        for (size_t i = 0; i < hw; i++) {
+            float v = any_gt1 ? db[i] / 255.0f : db[i];
+            if (v < dmin) dmin = v;
+            if (v > dmax) dmax = v;
+        }
+        float range = dmax - dmin;
+        float crange = range < (float)1e-6 ? (float)1e-6 : range;
+        for (size_t i = 0; i < hw; i++) {
+            float v = any_gt1 ? db[i] / 255.0f : db[i];
+            float n = range > (float)1e-6 ? (v - dmin) / crange : 0.0f;
+            nd[hw * b + i] = n;
+            float s = n - conv32;
+            float sg = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
+            po[hw * b + i] = (sg * torch_pow_scalar(fabsf(s), exponent)) * div32 + sep32;
+        }
+    }
+    /* keep bits: bit 0 triangle A, bit 1 triangle B of quad (r, x); OR over the frames */
+    uint8_t *keep = (uint8_t *)calloc((size_t)(H > 1 ? H - 1 : 0) * (W > 1 ? W - 1 : 0) + 1, 1);
+    for (int b = 0; b < B; b++)
+        for (int r = 0; r + 1 < H; r++)
+            for (int x = 0; x + 1 < W; x++) {
+                const float *o = po + hw * b;
+                float o00 = o[(size_t)r * W + x], o10 = o[(size_t)r * W + x + 1], o01 = o[(size_t)(r + 1) * W + x],
+                      o11 = o[(size_t)(r + 1) * W + x + 1];
+                float da = fmaxf(fmaxf(fabsf(o00 - o10), fabsf(o00 - o01)), fabsf(o10 - o01));
+                float dbb = fmaxf(fmaxf(fabsf(o11 - o10), fabsf(o11 - o01)), fabsf(o10 - o01));
+                keep[(size_t)r * (W - 1) + x] |= (uint8_t)((da < thr ? 1 : 0) | (dbb < thr ? 2 : 0));
+            }
+    const float sc = (float)(W - 1) / (float)W, isc = (float)W / (float)(W - 1), scy = (float)(H - 1) / (float)H;
+    float *zb = (float *)malloc(sizeof(float) * W);
+    long *win = (long *)malloc(sizeof(long) * W);   /* winning triangle: draw index, -1 = none */
+    float *col = (float *)malloc(sizeof(float) * 3 * W);
+    for (int b = 0; b < B; b++) {
+        const float *nb = nd + hw * b, *ob = po + hw * b;
+        const float *img = image + 3 * hw * b;
+        for (int k = 0; k < H; k++) {
+            float *orow[3] = {out + (3 * (size_t)b + 0) * hw + (size_t)k * W, out + (3 * (size_t)b + 1) * hw + (size_t)k * W,
+                              out + (3 * (size_t)b + 2) * hw + (size_t)k * W};
+            uint8_t *mrow = mask + hw * b + (size_t)k * W;
+            for (int x = 0; x < W; x++) { win[x] = -1; zb[x] = 0.0f; }
+            if (H >= 2 && W >= 2) {
+                const float wy = ((float)k + 0.5f) * scy;
+                const int r = (int)floorf(wy);
+                const float t = wy - (float)r, omt = 1.0f - t;
+                const float *o0 = ob + (size_t)r * W, *o1 = ob + (size_t)(r + 1) * W;
+                const float *n0 = nb + (size_t)r * W, *n1 = nb + (size_t)(r + 1) * W;
+                for (int type = 0; type < 2; type++)
+                    for (int x = 0; x + 1 < W; x++) {
+                        if (!(keep[(size_t)r * (W - 1) + x] & (1 << type))) continue;
+                        const float P00 = (float)x + o0[x], P10 = (float)(x + 1) + o0[x + 1], P01 = (float)x + o1[x],
+                                    P11 = (float)(x + 1) + o1[x + 1];
+                        const float xl = omt * P00 + t * P01, xd = omt * P10 + t * P01, xr = omt * P10 + t * P11;
+                        const float zl = omt * n0[x] + t * n1[x], zd = omt * n0[x + 1] + t * n1[x], zr = omt * n0[x + 1] + t * n1[x + 1];
+                        const float a = type ? xd : xl, e = type ? xr : xd;
+                        const float za = type ? zd : zl, ze = type ? zr : zd;
+                        const float lo = fminf(a, e), hi = fmaxf(a, e);
+                        if (!(lo < hi)) continue;
+                        float f0 = floorf(lo * isc) - 1.0f, f1 = floorf(hi * isc) + 1.0f;
+                        if (f0 < 0.0f) f0 = 0.0f;
+                        if (f1 > (float)(W - 1)) f1 = (float)(W - 1);
+                        if (!(f0 <= f1)) continue;
+                        for (int px = (int)f0; px <= (int)f1; px++) {
+                            const float u = ((float)px + 0.5f) * sc;
+                            if (!(lo <= u && u < hi)) continue;
+                            const float s = (u - a) / (e - a);
+                            const float z = (1.0f - s) * za + s * ze;
+                            if (win[px] < 0 || z > zb[px]) { zb[px] = z; win[px] = (long)type * (W - 1) + x; }
+                        }
+                    }
+                /* colours of the covered pixels */
+                for (int px = 0; px < W; px++) {
+                    col[3 * px] = col[3 * px + 1] = col[3 * px + 2] = 0.0f;
+                    if (win[px] < 0) continue;
+                    const int type = win[px] >= W - 1, x = (int)(win[px] - (long)type * (W - 1));
+                    const float P00 = (float)x + o0[x], P10 = (float)(x + 1) + o0[x + 1], P01 = (float)x + o1[x],
+                                P11 = (float)(x + 1) + o1[x + 1];
+                    const float xl = omt * P00 + t * P01, xd = omt * P10 + t * P01, xr = omt * P10 + t * P11;
+                    const float a = type ? xd : xl, e = type ? xr : xd;
+                    const float u = ((float)px + 0.5f) * sc;
+                    const float s = (u - a) / (e - a);
+                    for (int c = 0; c < 3; c++) {
+                        const float *p0 = img + (size_t)c * hw + (size_t)r * W, *p1 = p0 + W;
+                        const float cl = omt * p0[x] + t * p1[x], cd = omt * p0[x + 1] + t * p1[x], cr = omt * p0[x + 1] + t * p1[x + 1];
+                        const float ca = type ? cd : cl, ce = type ? cr : cd;
+                        col[3 * px + c] = (1.0f - s) * ca + s * ce;
+                    }
+                }
+            } else {
+                for (int px = 0; px < 3 * W; px++) col[px] = 0.0f;
+            }
+            /* gap mask + directional smear */
+            for (int px = 0; px < W; px++) mrow[px] = win[px] < 0;
+            if (div_px >= 0) {
+                long f = -1;
+                for (int px = 0; px < W; px++) {
+                    if (!mrow[px]) f = px;
+                    const long srcp = mrow[px] && f >= 0 ? f : px;
+                    for (int c = 0; c < 3; c++) orow[c][px] = col[3 * srcp + c];
+                }
+            } else {
+                long f = -1;
+                for (int px = W - 1; px >= 0; px--) {
+                    if (!mrow[px]) f = px;
+                    const long srcp = mrow[px] && f >= 0 ? f : px;
+                    for (int c = 0; c < 3; c++) orow[c][px] = col[3 * srcp + c];
+                }
+            }
+        }
+    }
+    free(nd); free(po); free(keep); free(zb); free(win); free(col);
+}

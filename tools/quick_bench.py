@@ -18,6 +18,8 @@ for _env, _key in (("CS_DBG", "dbg"), ("CS_NO_TILE", "no_tile"), ("CS_PT_VARIANT
     if os.environ.get(_env):
         _native.debug_set(_key, int(os.environ[_env]))
 
+if os.environ.get("CS_MESH"):
+    engine.MESH_WARP = True   # gpu_warp as the mesh-quality rasteriser (cs_params.flags bit 2)
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=4)
 ap.add_argument("--h", type=int, default=2160)
