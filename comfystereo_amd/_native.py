@@ -25,7 +25,7 @@ MODE = {
 
 EXPORTS = [
     "cs_version", "cs_last_error", "cs_max_width", "cs_output_shape", "cs_workspace_bytes", "cs_generate",
-    "cs_asd_workspace_bytes", "cs_apply_stereo_divergence", "cs_blur_workspace_bytes", "cs_directional_blur",
+    "cs_asd_workspace_bytes", "cs_apply_stereo_divergence", "cs_apply_stereo_divergence2", "cs_blur_workspace_bytes", "cs_directional_blur",
     "cs_warp_workspace_bytes", "cs_forward_warp", "cs_warp_mesh_workspace_bytes", "cs_forward_warp_mesh", "cs_expand_u8", "cs_stereo_shift_workspace_bytes", "cs_stereo_shift", "cs_profile", "cs_profile_read", "cs_debug_set",
     "cs_test_powf", "cs_test_exp",
 ]
@@ -83,6 +83,9 @@ def lib():
     L.cs_generate.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, c_size, vp]
     L.cs_asd_workspace_bytes.restype = c_size
     L.cs_asd_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    L.cs_apply_stereo_divergence2.restype = c_int
+    L.cs_apply_stereo_divergence2.argtypes = [vp, vp, c_int, c_int, c_int, c_double, c_double, c_double, c_int, c_double, c_int,
+                                              vp, vp, c_size, vp]
     L.cs_apply_stereo_divergence.restype = c_int
     L.cs_apply_stereo_divergence.argtypes = [vp, vp, c_int, c_int, c_int, c_double, c_double, c_double, c_int, c_double,
                                              vp, vp, c_size, vp]

@@ -283,6 +283,8 @@ static void eye_setup(EyeArgs& E, double div_percent_signed, double sep_percent_
     double sep_px = (sep_percent_signed / 100.0) * (double)w;
     E.div32 = (float)div_px;
     E.sep32 = (float)sep_px;
+    E.div64 = div_px;
+    E.sep64 = sep_px;
     E.asc = div_px < 0 ? 1 : 0;
     E.naive_lim = abs((int)div_px) + 2;
     E.csg_cap = 5 * (int)fabs(div_px) + 25;
@@ -302,6 +304,10 @@ static int poly_halo(double div_percent_a, double div_percent_b, double sep_perc
 }
 
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+// techniques with a D64 (numba typing) instantiation: the forward-map family and the z-buffered inverse map
+static bool dialect_d64_ok(int fill) {
+    return fill == CS_FILL_NONE || fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING || fill == CS_FILL_INVERSE;
+}
 // flags of the rows the tiled polylines path hands to the row kernel + their compacted list (run_rows)
 static size_t rowflag_bytes(size_t rows) { return al256(rows) + 256 + al256(rows * 4); }
 
@@ -439,6 +445,8 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     const int n = p->n, h = p->h, w = p->w, hw = h * w;
     const bool gpu_warp = p->fill == CS_FILL_GPU_WARP;
     if (gpu_warp && (p->flags & 2)) return fail(CS_EINVAL, "gpu_warp colours are not k/255: no uint8 stereoscope output");
+    if ((p->flags & 24) && !dialect_d64_ok(p->fill))
+        return fail(CS_EINVAL, "dialect D64 (flags bits 3/4) exists for none / naive / naive_interpolating / inverse only");
     const bool blur = p->depth_map_blur && p->depth_blur_strength > 0;  // strength <= 0 == blur off (reference :1194, :1050)
 
     hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);
@@ -486,6 +494,8 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     A.scale_from_stats = scale_from_stats;
     A.e32 = (float)p->stereo_offset_exponent;
     A.conv32 = (float)p->convergence_point;
+    A.e64 = p->stereo_offset_exponent;
+    A.d64 = (p->flags >> 3) & 3;
     A.neyes = 2;
     eye_setup(A.eye[0], +1 * left_div, -1 * p->separation, w);
     eye_setup(A.eye[1], -1 * right_div, p->separation, w);
@@ -527,6 +537,16 @@ size_t cs_asd_workspace_bytes(int n, int h, int w) {
 int cs_apply_stereo_divergence(const uint8_t* image_u8, const float* depth, int n, int h, int w, double divergence,
                                double separation, double exponent, int fill, double convergence, uint8_t* out_u8,
                                void* workspace, size_t workspace_bytes, void* stream_) {
+    return cs_apply_stereo_divergence2(image_u8, depth, n, h, w, divergence, separation, exponent, fill, convergence, 0, out_u8,
+                                       workspace, workspace_bytes, stream_);
+}
+
+int cs_apply_stereo_divergence2(const uint8_t* image_u8, const float* depth, int n, int h, int w, double divergence,
+                                double separation, double exponent, int fill, double convergence, int dialect,
+                                uint8_t* out_u8, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (dialect < 0 || dialect > 3) return fail(CS_EINVAL, "dialect: 0 (D32), 1 (float64 disparities), 2 (int64 sums), 3 (D64)");
+    if (dialect && !dialect_d64_ok(fill))
+        return fail(CS_EINVAL, "dialect D64 exists for none / naive / naive_interpolating / inverse only");
     hipStream_t stream = (hipStream_t)stream_;
     if (!image_u8 || !depth || !out_u8 || !workspace) return fail(CS_EINVAL, "null pointer");
     if (n <= 0 || h <= 0 || w <= 0) return fail(CS_EINVAL, "non-positive size");
@@ -544,6 +564,8 @@ int cs_apply_stereo_divergence(const uint8_t* image_u8, const float* depth, int 
     A.scale_from_stats = 0;
     A.e32 = (float)exponent;
     A.conv32 = (float)convergence;
+    A.e64 = exponent;
+    A.d64 = dialect;
     A.neyes = 1;
     eye_setup(A.eye[0], divergence, separation, w);
     A.eye[0].depth = depth; A.eye[0].st_min = ST_L_MIN; A.eye[0].st_max = ST_L_MAX;

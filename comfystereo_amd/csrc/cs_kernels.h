@@ -14,6 +14,7 @@ __host__ __device__ inline int poly_npt(int w, int sharp) { return (sharp ? 2 * 
 struct EyeArgs {
     const float* depth;  // [n][h][w] depth this eye warps with (unscaled when scale_from_stats)
     float div32, sep32;  // (float)divergence_px, (float)separation_px -- signed
+    double div64, sep64; // the Python floats themselves (dialect D64)
     int enabled;         // 0: eye = source image (divergence < 0.001, quirk Q10)
     int asc;             // divergence_px < 0: sweep ascending (max source column wins)
     int naive_lim;       // abs(int(divergence_px)) + 2
@@ -30,6 +31,8 @@ struct RowArgs {
     uint32_t* stats_rw;
     int scale_from_stats;     // depth rows are multiplied by 255 when stats[ST_SCALE255]
     float e32, conv32;
+    double e64;               // the exponent as the Python float (dialect D64)
+    int d64;                  // dialect bits (cs_params.flags bits 3 / 4): 1 = float64 disparity chain, 2 = int64 pixel sums
     EyeArgs eye[2];
     int neyes;
     // outputs

@@ -104,18 +104,32 @@ __device__ __forceinline__ float disparity(float d, float e32, float div32, cons
     return (s * p) * div32;
 }
 
+// The same in dialect D64 (numba typing, SURVEY.md Appendix A -- what the reference computes when numba is installed):
+// the float32 depth meets the float64 exponent, so `abs(d) ** e`, the products and the sums run in float64.  `pow` is the
+// device library's (<= 1 ulp from libm's; the callers only take int() / floor() of the result plus a pixel coordinate).
+__device__ __forceinline__ double disparity64(float d, double e64, double div64) {
+    const double s = d >= 0.0f ? 1.0 : -1.0;
+    return (s * pow((double)fabsf(d), e64)) * div64;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward map shared by none / naive / naive_interpolating
 // ---------------------------------------------------------------------------------------------
-__device__ void forward_map(const Lds& L, int w, const EyeArgs& E, float e32, int* winner) {
+__device__ void forward_map(const Lds& L, int w, const EyeArgs& E, float e32, int* winner, int d64 = 0, double e64 = 0.0) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int init = E.asc ? -1 : 0x7fffffff;
     for (int c = tid; c < w; c += nt) winner[c] = init;
     __syncthreads();
     for (int c = tid; c < w; c += nt) {
-        float off = disparity(L.nd[c], e32, E.div32, L.tabs) + E.sep32;
-        // int(): truncation toward zero; keep the conversion defined for absurd offsets
-        int io = off >= 2147483520.0f ? 0x7fffff00 : (off <= -2147483520.0f ? -0x7fffff00 : (int)off);
+        int io;
+        if (d64 & 1) {
+            const double off = disparity64(L.nd[c], e64, E.div64) + E.sep64;
+            io = off >= 2147483520.0 ? 0x7fffff00 : (off <= -2147483520.0 ? -0x7fffff00 : (int)off);
+        } else {
+            const float off = disparity(L.nd[c], e32, E.div32, L.tabs) + E.sep32;
+            // int(): truncation toward zero; keep the conversion defined for absurd offsets
+            io = off >= 2147483520.0f ? 0x7fffff00 : (off <= -2147483520.0f ? -0x7fffff00 : (int)off);
+        }
         long long cd = (long long)c + io;
         if (cd >= 0 && cd < w) {
             if (E.asc) atomicMax(&winner[(int)cd], c);
@@ -133,14 +147,16 @@ __device__ void forward_map(const Lds& L, int w, const EyeArgs& E, float e32, in
     __syncthreads();
 }
 
-__device__ __forceinline__ unsigned sum8(const uint8_t* p) { return (unsigned)(p[0] + p[1] + p[2]) & 0xffu; }
+// sum() of a uint8 pixel: wraps mod 256 in dialect D32 (quirk Q5), int64 under numba (D64)
+__device__ __forceinline__ unsigned sum8(const uint8_t* p, unsigned mask = 0xffu) { return (unsigned)(p[0] + p[1] + p[2]) & mask; }
 
 template <int FILL>
-__device__ void technique_forward(const Lds& L, int w, const EyeArgs& E, float e32) {
+__device__ void technique_forward(const Lds& L, int w, const EyeArgs& E, float e32, int d64 = 0, double e64 = 0.0) {
     const int tid = threadIdx.x, nt = blockDim.x;
     int* winner = (int*)L.tech;
     const int init = E.asc ? -1 : 0x7fffffff;
-    forward_map(L, w, E, e32, winner);
+    const unsigned smask = (d64 & 2) ? 0xffffu : 0xffu;
+    forward_map(L, w, E, e32, winner, d64, e64);
     if (FILL == CS_FILL_NAIVE) {
         // nearest filled pixel: Lf[c] = last filled <= c, Rf[c] = first filled >= c
         int* Lf = (int*)(L.tech + align16(4 * (size_t)w));
@@ -172,7 +188,7 @@ __device__ void technique_forward(const Lds& L, int w, const EyeArgs& E, float e
         uint8_t* flags = (uint8_t*)(L.tech + align16(4 * (size_t)w));  // bit0 filled, bit1 good
         for (int c = tid; c < w; c += nt) {
             bool f = winner[c] != init;
-            bool g = f && sum8(&L.res[3 * c]) != 0;
+            bool g = f && sum8(&L.res[3 * c], smask) != 0;
             flags[c] = (uint8_t)((f ? 1 : 0) | (g ? 2 : 0));
         }
         __syncthreads();
@@ -210,8 +226,8 @@ __device__ void technique_forward(const Lds& L, int w, const EyeArgs& E, float e
             uint8_t lb[3] = {0, 0, 0}, rb[3] = {0, 0, 0};
             if (l0 > 0) { lb[0] = L.res[3 * l0 - 3]; lb[1] = L.res[3 * l0 - 2]; lb[2] = L.res[3 * l0 - 1]; }
             if (g < w) { rb[0] = L.res[3 * g]; rb[1] = L.res[3 * g + 1]; rb[2] = L.res[3 * g + 2]; }
-            if (sum8(lb) == 0) { lb[0] = rb[0]; lb[1] = rb[1]; lb[2] = rb[2]; }
-            else if (sum8(rb) == 0) { rb[0] = lb[0]; rb[1] = lb[1]; rb[2] = lb[2]; }
+            if (sum8(lb, smask) == 0) { lb[0] = rb[0]; lb[1] = rb[1]; lb[2] = rb[2]; }
+            else if (sum8(rb, smask) == 0) { rb[0] = lb[0]; rb[1] = lb[1]; rb[2] = lb[2]; }
             const float total = (float)(1 + g - l0);
             const float k = (float)(c - l0 + 1);
             uint8_t v[3];
@@ -220,7 +236,7 @@ __device__ void technique_forward(const Lds& L, int w, const EyeArgs& E, float e
             v[2] = (uint8_t)(lb[2] + csm::f32_to_u8_wrap((((float)rb[2] - (float)lb[2]) / total) * k));
             tmpc[3 * c] = v[0]; tmpc[3 * c + 1] = v[1]; tmpc[3 * c + 2] = v[2];
             atomicOr((unsigned*)flags + (c >> 2), 4u << ((c & 3) * 8));  // has a new colour (atomic: bit 3 of the same byte may be set concurrently)
-            if (c > l0 && !(flags[c] & 1) && sum8(v) == 0) flag_interval(s0);  // the quirk: re-trigger -> literal replay
+            if (c > l0 && !(flags[c] & 1) && sum8(v, smask) == 0) flag_interval(s0);  // the quirk: re-trigger -> literal replay
         }
         __syncthreads();
         for (int c = tid; c < w; c += nt) {
@@ -233,19 +249,19 @@ __device__ void technique_forward(const Lds& L, int w, const EyeArgs& E, float e
             if ((flags[s] & 2) || (s > 0 && !(flags[s - 1] & 2))) continue;  // not the start of an interval
             if (!(flags[s] & 8)) continue;                                      // done in parallel above
             for (int l = s; l < w && !(flags[l] & 2); l++) {
-                if (sum8(&L.res[3 * l]) != 0 || (flags[l] & 1)) continue;
+                if (sum8(&L.res[3 * l], smask) != 0 || (flags[l] & 1)) continue;
                 uint8_t lb[3] = {0, 0, 0}, rb[3] = {0, 0, 0};
                 if (l > 0) { lb[0] = L.res[3 * l - 3]; lb[1] = L.res[3 * l - 2]; lb[2] = L.res[3 * l - 1]; }
                 int r = l + 1;
                 while (r < w) {
-                    if (sum8(&L.res[3 * r]) != 0 && (flags[r] & 1)) {
+                    if (sum8(&L.res[3 * r], smask) != 0 && (flags[r] & 1)) {
                         rb[0] = L.res[3 * r]; rb[1] = L.res[3 * r + 1]; rb[2] = L.res[3 * r + 2];
                         break;
                     }
                     r++;
                 }
-                if (sum8(lb) == 0) { lb[0] = rb[0]; lb[1] = rb[1]; lb[2] = rb[2]; }
-                else if (sum8(rb) == 0) { rb[0] = lb[0]; rb[1] = lb[1]; rb[2] = lb[2]; }
+                if (sum8(lb, smask) == 0) { lb[0] = rb[0]; lb[1] = rb[1]; lb[2] = rb[2]; }
+                else if (sum8(rb, smask) == 0) { rb[0] = lb[0]; rb[1] = lb[1]; rb[2] = lb[2]; }
                 float total = (float)(1 + r - l);
                 float st0 = ((float)rb[0] - (float)lb[0]) / total;
                 float st1 = ((float)rb[1] - (float)lb[1]) / total;
@@ -303,7 +319,7 @@ __device__ void technique_post_interp(const Lds& L, int w, int* Lf, int* Rf, con
 // ---------------------------------------------------------------------------------------------
 // inverse: two-column z-buffered splat
 // ---------------------------------------------------------------------------------------------
-__device__ void technique_inverse(const Lds& L, int w, const EyeArgs& E, float e32) {
+__device__ void technique_inverse(const Lds& L, int w, const EyeArgs& E, float e32, int d64 = 0, double e64 = 0.0) {
     const int tid = threadIdx.x, nt = blockDim.x;
     unsigned long long* key = (unsigned long long*)L.tech;
     const unsigned long long init = ((unsigned long long)csm::f2ord(-1.0f) << 32) | 0xffffffffull;
@@ -311,9 +327,13 @@ __device__ void technique_inverse(const Lds& L, int w, const EyeArgs& E, float e
     __syncthreads();
     for (int x = tid; x < w; x += nt) {
         float d = L.nd[x];
-        float off = disparity(d, e32, E.div32, L.tabs);
-        float dest = ((float)x + 0.5f + off) + E.sep32;
-        float fl = floorf(dest);
+        float fl;
+        if (d64 & 1) fl = (float)floor((((double)x + 0.5) + disparity64(d, e64, E.div64)) + E.sep64);   // (only the range test and int() use it)
+        else {
+            float off = disparity(d, e32, E.div32, L.tabs);
+            float dest = ((float)x + 0.5f + off) + E.sep32;
+            fl = floorf(dest);
+        }
         if (!(fl >= -2.0f && fl <= (float)w)) continue;
         int j = (int)fl;
         unsigned long long k = ((unsigned long long)csm::f2ord(d) << 32) | (unsigned long long)(0xffffffffu - (unsigned)x);
@@ -903,21 +923,21 @@ __device__ void rowwarp_row(const RowArgs& A, const int row, const int frame, ch
                 __syncthreads();
             }
             if (FILL == CS_FILL_NONE || FILL == CS_FILL_NAIVE || FILL == CS_FILL_NAIVE_INTERPOLATING)
-                technique_forward<FILL>(L, w, E, A.e32);
+                technique_forward<FILL>(L, w, E, A.e32, A.d64, A.e64);
             else if (FILL == CS_FILL_NONE_POST) {
-                technique_forward<CS_FILL_NONE>(L, w, E, A.e32);
+                technique_forward<CS_FILL_NONE>(L, w, E, A.e32, A.d64, A.e64);
                 const int* winner = (const int*)L.tech;
                 const int init = E.asc ? -1 : 0x7fffffff;
                 technique_post_interp(L, w, (int*)(L.tech + align16(4 * (size_t)w)), (int*)(L.tech + 2 * align16(4 * (size_t)w)),
                                       [=](int c) { return winner[c] != init; });
             } else if (FILL == CS_FILL_INVERSE_POST) {
-                technique_inverse(L, w, E, A.e32);
+                technique_inverse(L, w, E, A.e32, A.d64, A.e64);
                 const unsigned long long* key = (const unsigned long long*)L.tech;
                 const unsigned long long init = ((unsigned long long)csm::f2ord(-1.0f) << 32) | 0xffffffffull;
                 technique_post_interp(L, w, (int*)(L.tech + align16(8 * (size_t)w)),
                                       (int*)(L.tech + align16(8 * (size_t)w) + align16(4 * (size_t)w)),
                                       [=](int c) { return key[c] > init; });
-            } else if (FILL == CS_FILL_INVERSE) technique_inverse(L, w, E, A.e32);
+            } else if (FILL == CS_FILL_INVERSE) technique_inverse(L, w, E, A.e32, A.d64, A.e64);
             else if (FILL == CS_FILL_POLYLINES_SOFT) technique_polylines<0>(L, w, E, A.e32, st_rw, out, A.dbg);
             else if (FILL == CS_FILL_POLYLINES_SHARP) technique_polylines<1>(L, w, E, A.e32, st_rw, out, A.dbg);
             else if (FILL == CS_FILL_HYBRID_EDGE) technique_hybrid_fill(L, A, frame, row, e);

@@ -29,6 +29,11 @@ def _dev(t):
 # forward_warp_gpu otherwise (stereoimage_generation.py:18-24, :1068-1071).  Here both are HIP kernels and the choice is
 # this switch (cs_params.flags bit 2): False = forward_warp_gpu semantics (the parity-pinned default), True = mesh quality.
 MESH_WARP = False
+# Arithmetic dialect of the CPU techniques (cs_params.flags bits 3 / 4): "D32" = the reference as it runs WITHOUT numba
+# (float32 disparities, wrapping uint8 pixel sums) -- what the goldens pin; "D64" = the typing numba gives the same
+# source lines (float64 disparities, int64 sums), available for none / naive /
+# naive_interpolating / inverse.
+DIALECT = "D32"
 
 
 def make_params(n, h, w, depth_h, depth_w, depth_c, fill, mode, divergence, separation, stereo_balance,
@@ -46,6 +51,8 @@ def make_params(n, h, w, depth_h, depth_w, depth_c, fill, mode, divergence, sepa
     p.depth_blur_falloff = float(depth_blur_falloff)
     if MESH_WARP and fill == 'gpu_warp':
         p.flags |= 4
+    if DIALECT != "D32":
+        p.flags |= DIALECTS[DIALECT] << 3   # (cs_generate refuses techniques without a D64 instantiation)
     return p
 
 
@@ -112,8 +119,14 @@ def generate(image, depth_map, divergence, separation, modes, stereo_balance, co
     return Plan(p, image.device).run(image, depth_map)
 
 
-def apply_stereo_divergence(image_u8, depth, divergence, separation, stereo_offset_exponent, fill, convergence_point=0.5):
-    """reference stereoimage_generation.py:1576-1620 for [N,H,W,3] uint8 + [N,H,W] float32 device tensors."""
+DIALECTS = {"D32": 0, "D64": 3, "f64-disparity": 1, "int64-sum": 2}
+
+
+def apply_stereo_divergence(image_u8, depth, divergence, separation, stereo_offset_exponent, fill, convergence_point=0.5,
+                            dialect="D32"):
+    """reference stereoimage_generation.py:1576-1620 for [N,H,W,3] uint8 + [N,H,W] float32 device tensors.
+    dialect: "D32" = the reference without numba (the pinned contract); "D64" = numba's typing (float64 disparities,
+    int64 pixel sums; none / naive / naive_interpolating / inverse only)."""
     L = _native.lib()
     image_u8 = _dev(image_u8).contiguous()
     depth = _dev(depth).contiguous().float()
@@ -125,9 +138,9 @@ def apply_stereo_divergence(image_u8, depth, divergence, separation, stereo_offs
     out = torch.empty_like(image_u8)
     nb = L.cs_asd_workspace_bytes(n, h, w)
     ws = torch.empty((max(nb, 256),), dtype=torch.uint8, device=image_u8.device)
-    _native.check(L.cs_apply_stereo_divergence(_ptr(image_u8), _ptr(depth), n, h, w, float(divergence), float(separation),
-                                               float(stereo_offset_exponent), FILL[fill], float(convergence_point),
-                                               _ptr(out), _ptr(ws), nb, _stream()))
+    _native.check(L.cs_apply_stereo_divergence2(_ptr(image_u8), _ptr(depth), n, h, w, float(divergence), float(separation),
+                                                float(stereo_offset_exponent), FILL[fill], float(convergence_point),
+                                                DIALECTS[dialect], _ptr(out), _ptr(ws), nb, _stream()))
     return out[0] if squeeze else out
 
 

@@ -91,7 +91,13 @@ typedef struct cs_params {
                                    techniques only (gpu_warp colours are genuine floats)
                                    bit 2: fill gpu_warp runs the mesh-quality warp (forward_warp_mesh,
                                    :453-689 -- what the reference does when moderngl is importable,
-                                   :1068-1071) instead of forward_warp_gpu; see cs_forward_warp_mesh */
+                                   :1068-1071) instead of forward_warp_gpu; see cs_forward_warp_mesh
+                                   bits 3, 4: arithmetic dialect.  0 = D32, the reference WITHOUT numba
+                                   (float32 disparities, uint8 pixel sums that wrap) -- the pinned
+                                   contract.  bit 3: float64 disparity chain, bit 4: int64 pixel
+                                   sums; both = D64, the typing numba gives the reference's kernels
+                                   (derived).  none / naive /
+                                   naive_interpolating / inverse only, else CS_EINVAL              */
     double divergence, separation, stereo_balance, convergence_point, stereo_offset_exponent;
     double depth_blur_strength, depth_blur_edge_threshold, depth_blur_falloff;
 } cs_params;
@@ -132,6 +138,11 @@ CS_API size_t cs_asd_workspace_bytes(int n, int h, int w);
 CS_API int cs_apply_stereo_divergence(const uint8_t *image_u8, const float *depth, int n, int h, int w, double divergence,
                                double separation, double stereo_offset_exponent, int fill, double convergence_point,
                                uint8_t *out_u8, void *workspace, size_t workspace_bytes, void *stream);
+/* The same with the arithmetic dialect named: 0 = D32 (as above), 1 = float64 disparity chain, 2 = int64 pixel sums,
+ * 3 = both = D64 (cs_params.flags bits 3 / 4). */
+CS_API int cs_apply_stereo_divergence2(const uint8_t *image_u8, const float *depth, int n, int h, int w, double divergence,
+                                double separation, double stereo_offset_exponent, int fill, double convergence_point,
+                                int dialect, uint8_t *out_u8, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * directional_motion_blur_gpu (reference stereoimage_generation.py:1171-1251; its own callers pass

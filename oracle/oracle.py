@@ -76,12 +76,20 @@ def lib():
             L.oracle_forward_warp_gpu.restype = None
             L.oracle_forward_warp_gpu.argtypes = [f32p, f32p, c_int, c_int, c_int, c_double, c_double, c_double,
                                                   c_double, f32p, u8p]
+        if hasattr(L, "oracle_set_dialect"):
+            L.oracle_set_dialect.restype = None
+            L.oracle_set_dialect.argtypes = [c_int]
         if hasattr(L, "oracle_forward_warp_mesh"):
             L.oracle_forward_warp_mesh.restype = None
             L.oracle_forward_warp_mesh.argtypes = [f32p, f32p, c_int, c_int, c_int, c_double, c_double, c_double,
                                                    c_double, c_double, f32p, u8p]
         _lib = L
     return _lib
+
+
+def set_dialect(name):
+    """"D32" (default, pinned) | "f64-disparity" | "int64-sum" | "D64": see stereo_oracle.c (g_dialect)."""
+    lib().oracle_set_dialect({"D32": 0, "f64-disparity": 1, "int64-sum": 2, "D64": 3}[name])
 
 
 def _u8(a):

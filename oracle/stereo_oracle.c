@@ -58,6 +58,17 @@ static inline uint8_t f32_to_u8_wrap(float v) {
     return (uint8_t)(uint32_t)i;
 }
 
+/* Arithmetic dialect: bit 0 = float64 disparity chain, bit 1 = int64 pixel sums.  0 = D32, the
+ * reference without numba (pinned by the goldens); 3 = D64, the typing numba gives the same lines (derived).  The
+ * float64 disparity chain alone is pinned indirectly: tests/golden/dialect_f64.npz holds what the reference's own inner
+ * functions return when they are handed normalized_depth.astype(float64). */
+static int g_dialect = 0;
+EXPORT void oracle_set_dialect(int d) { g_dialect = d & 3; }
+static inline double disparity_f64(float d, double e, double div_px) {
+    double sign = d >= 0.0f ? 1.0 : -1.0;
+    return (sign * pow((double)fabsf(d), e)) * div_px;
+}
+
 /* `sign_d * (abs(d) ** e) * divergence_px` in D32: powf, then two float32 multiplies
  * (reference :1637,1677,1698,1724,1865,1926; Appendix A rows 2-3). */
 static inline float disparity_f32(float d, float e32, float div32) {
@@ -84,8 +95,12 @@ EXPORT void oracle_naive(const uint8_t *img, const float *nd, int h, int w, doub
         for (int n = 0; n < w; n++) {
             int col = asc ? n : w - 1 - n;
             float d = nd[(size_t)row * w + col];
-            float off = disparity_f32(d, e32, div32) + sep32; /* :1865 */
-            int col_d = col + (int)off;                        /* int(): trunc toward zero */
+            int col_d;
+            if (g_dialect & 1) col_d = col + (int)(disparity_f64(d, exponent, div_px) + sep_px);
+            else {
+                float off = disparity_f32(d, e32, div32) + sep32; /* :1865 */
+                col_d = col + (int)off;                            /* int(): trunc toward zero */
+            }
             if (0 <= col_d && col_d < w) {
                 memcpy(&derived[((size_t)row * w + col_d) * 3], &img[((size_t)row * w + col) * 3], 3);
                 filled[(size_t)row * w + col_d] = 1;
@@ -97,7 +112,7 @@ EXPORT void oracle_naive(const uint8_t *img, const float *nd, int h, int w, doub
         for (int row = 0; row < h; row++) {
             uint8_t *drow = &derived[(size_t)row * w * 3];
             const uint8_t *frow = &filled[(size_t)row * w];
-#define SUM8(p) ((uint8_t)((p)[0] + (p)[1] + (p)[2]))
+#define SUM8(p) ((g_dialect & 2) ? (int)((p)[0] + (p)[1] + (p)[2]) : (int)(uint8_t)((p)[0] + (p)[1] + (p)[2]))
             for (int l = 0; l < w; l++) {
                 if (SUM8(&drow[l * 3]) != 0 || frow[l]) continue;
                 uint8_t lb[3] = {0, 0, 0}, rb[3] = {0, 0, 0};
@@ -312,10 +327,14 @@ EXPORT void oracle_inverse(const uint8_t *img, const float *nd, int h, int w, do
         for (int x = 0; x < w; x++) zb[x] = -1.0f;
         for (int x = 0; x < w; x++) {
             float d = nd[(size_t)row * w + x];
-            float off = disparity_f32(d, e32, div32);
-            float dest_x = ((float)(x + 0.5) + off) + sep32; /* :1725 */
-            float fl = floorf(dest_x);
-            long j = (long)fl;
+            long j;
+            if (g_dialect & 1) j = (long)floor((((double)x + 0.5) + disparity_f64(d, exponent, div_px)) + sep_px);
+            else {
+                float off = disparity_f32(d, e32, div32);
+                float dest_x = ((float)(x + 0.5) + off) + sep32; /* :1725 */
+                float fl = floorf(dest_x);
+                j = (long)fl;
+            }
             for (int t = 0; t < 2; t++) {
                 long jj = j + t;
                 if (0 <= jj && jj < w && d > zb[jj]) {

@@ -1,0 +1,64 @@
+"""Dialect D64 (numba typing) -- the part of it that can be pinned here: the float64 disparity chain.
+tests/golden/dialect_f64.npz holds what the reference's own inner functions return for normalized_depth.astype(float64)
+(tools/make_goldens.py --only-dialect); pixel sums there still wrap (no numba in this image), so the fixture corresponds to
+the oracle's "f64-disparity" setting; the int64 pixel sums of full D64 are derived from numba's typing rules and only
+checked for what they must change.  Runs without a GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "dialect_f64.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    z = np.load(GOLD)
+    return z, json.loads(str(z["meta"]))["cases"]
+
+
+def _run(z, c, fill, dialect):
+    oracle.set_dialect(dialect)
+    try:
+        return oracle.apply_stereo_divergence(z[f"{c['id']}/img"], z[f"{c['id']}/depth"], c["divergence"], c["separation"],
+                                              c["exponent"], fill, c["convergence"])
+    finally:
+        oracle.set_dialect("D32")
+
+
+def test_f64_disparity_chain_matches_the_reference_inner_functions(gold):
+    z, cases = gold
+    for c in cases:
+        for fill in ("none", "naive", "naive_interpolating", "inverse"):
+            np.testing.assert_array_equal(_run(z, c, fill, "f64-disparity"), z[f"{c['id']}/{fill}"], err_msg=f"{c['id']}/{fill}")
+
+
+def test_where_the_dialects_diverge(gold):
+    """Report (and bound) the divergence: ordinary depth maps give identical frames -- a float32 disparity only truncates
+    differently when it lies within an ulp of an integer -- the searched near-integer case differs in a fifth of its pixels."""
+    z, cases = gold
+    for c in cases:
+        d32, f64 = _run(z, c, "none", "D32"), _run(z, c, "none", "f64-disparity")
+        n = int((d32 != f64).any(-1).sum())
+        assert n == c["pixels_differing_from_d32"]
+        assert (n > 500) == (c["kind"] == "near-integer")
+
+
+def test_int64_sums_only_change_pixels_whose_channels_sum_to_a_multiple_of_256(gold):
+    z, cases = gold
+    changed = 0
+    for c in cases:
+        a, b = _run(z, c, "naive_interpolating", "f64-disparity"), _run(z, c, "naive_interpolating", "D64")
+        none = _run(z, c, "none", "D64")
+        # with int64 sums a (128,128,0) pixel is not "black": rows without such pixels (and without true holes next to
+        # them) are untouched by the change of the sum
+        rows_with_hazard = ((none.astype(np.int64).sum(-1) % 256 == 0) & (none.astype(np.int64).sum(-1) > 0)).any(1)
+        assert (a[~rows_with_hazard] == b[~rows_with_hazard]).all()
+        changed += int((a != b).any(-1).sum())
+    assert changed > 0
+    # the forward map itself has no sums
+    for c in cases[:2]:
+        np.testing.assert_array_equal(_run(z, c, "none", "f64-disparity"), _run(z, c, "none", "D64"))

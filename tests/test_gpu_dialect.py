@@ -1,0 +1,81 @@
+"""Dialect D64 on the GPU (cs_apply_stereo_divergence2 / cs_params.flags bits 3, 4): the float64 disparity chain against the
+fixture generated from the reference's inner functions (tests/golden/dialect_f64.npz) and full D64 against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import node_oracle, oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "dialect_f64.npz")
+FILLS = ("none", "naive", "naive_interpolating", "inverse")
+
+
+def _gpu(img, depth, c, fill, dialect):
+    from comfystereo_amd import engine
+    return engine.apply_stereo_divergence(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda(), c["divergence"],
+                                          c["separation"], c["exponent"], fill, c["convergence"], dialect=dialect).cpu().numpy()
+
+
+def test_f64_disparity_chain_matches_the_reference_fixture():
+    z = np.load(GOLD)
+    for c in json.loads(str(z["meta"]))["cases"]:
+        for fill in FILLS:
+            got = _gpu(z[f"{c['id']}/img"], z[f"{c['id']}/depth"], c, fill, "f64-disparity")
+            np.testing.assert_array_equal(got, z[f"{c['id']}/{fill}"], err_msg=f"{c['id']}/{fill}")
+
+
+def test_d64_matches_the_oracle_and_differs_from_d32_where_it_should():
+    z = np.load(GOLD)
+    cases = json.loads(str(z["meta"]))["cases"]
+    for c in cases:
+        img, depth = z[f"{c['id']}/img"], z[f"{c['id']}/depth"]
+        for fill in FILLS:
+            oracle.set_dialect("D64")
+            try:
+                want = oracle.apply_stereo_divergence(img, depth, c["divergence"], c["separation"], c["exponent"], fill, c["convergence"])
+            finally:
+                oracle.set_dialect("D32")
+            np.testing.assert_array_equal(_gpu(img, depth, c, fill, "D64"), want, err_msg=f"{c['id']}/{fill}")
+    c = cases[-1]   # the near-integer case: the dialects disagree on many pixels
+    a, b = _gpu(z["5/img"], z["5/depth"], c, "none", "D32"), _gpu(z["5/img"], z["5/depth"], c, "none", "D64")
+    assert int((a != b).any(-1).sum()) == c["pixels_differing_from_d32"]
+
+
+def test_other_techniques_refuse_the_dialect():
+    from comfystereo_amd import engine
+    img = torch.zeros((1, 16, 32, 3), dtype=torch.uint8, device="cuda")
+    dep = torch.rand((1, 16, 32), device="cuda")
+    for fill in ("polylines_soft", "polylines_sharp", "hybrid_edge"):
+        with pytest.raises(RuntimeError, match="D64"):
+            engine.apply_stereo_divergence(img, dep, 3.0, 0.0, 1.0, fill, 0.5, dialect="D64")
+
+
+def test_node_path_with_the_dialect_switch():
+    """engine.DIALECT -> cs_params.flags bits 3 / 4 through cs_generate (SBS + anaglyph, uint8-origin image with hazards)."""
+    from comfystereo_amd import engine
+    n, h, w = 2, 40, 96
+    img = synth.image_f32(n, h, w, seed=9)
+    depth = synth.depth_batch("random8", n, h, w, channels=3)
+    engine.DIALECT = "D64"
+    oracle.set_dialect("D64")
+    try:
+        for ui, mode in (("Fill - Naive interpolating", "left-right"), ("No fill - Reverse projection", "red-cyan-anaglyph"),
+                         ("Fill - Naive", "top-bottom")):
+            fill = node_oracle.FILL_KEYS[ui]
+            p = engine.make_params(n, h, w, h, w, 3, fill, mode, 7.0, 0.5, 0.0, 0.5, 1.3, False, 6.0, 6.0, 1.0, 0, 4)
+            assert (p.flags >> 3) & 3 == 3
+            got = [t.cpu().numpy() for t in engine.Plan(p, torch.device("cuda")).run(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda())]
+            want = node_oracle.generate(img, depth, 7.0, 0.5, mode, 0.0, 0.5, 1.3, ui, 6.0, 6.0, False)
+            for g, wv in zip(got, want):
+                np.testing.assert_array_equal(g, wv)
+        with pytest.raises(RuntimeError, match="D64"):
+            p = engine.make_params(n, h, w, h, w, 3, "polylines_soft", "left-right", 7.0, 0.5, 0.0, 0.5, 1.3, False, 6.0, 6.0, 1.0, 0, 4)
+            engine.Plan(p, torch.device("cuda")).run(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda())
+    finally:
+        engine.DIALECT = "D32"
+        oracle.set_dialect("D32")

@@ -361,6 +361,59 @@ def gen_stereo_shift():
     print("stereo_shift:", len(cases), "cases")
 
 
+def gen_dialect_f64(sig):
+    """Indirect pin of the float64 disparity chain of dialect D64: the reference's inner functions
+    (apply_stereo_divergence_naive :1850-1910, apply_stereo_divergence_inverse :1715-1737) handed
+    normalized_depth.astype(float64) -- `abs(d) ** e`, the products and int() / floor() then run in float64 as under numba,
+    while sum() of a uint8 pixel still wraps (no numba here).  Depth maps span exactly 0..1, so the reference's own
+    normalisation (:1587-1600) is the identity and the driver reproduces the same normalized_depth from them."""
+    rng = np.random.default_rng(4242)
+    arrays, cases = {}, []
+    h, w = 40, 112
+    for cid, (kind, div, sep, e, conv) in enumerate([("stepped", 6.0, 0.0, 2.0, 0.5), ("radial", -7.5, 1.0, 1.3, 0.4),
+                                                     ("random8", 9.0, -0.5, 0.7, 0.5), ("noisy_ramp", 12.5, 0.0, 1.0, 0.6),
+                                                     ("blobs", 3.3, 2.0, 0.1, 0.3), ("near-integer", 7.3, 0.0, 1.0, 0.0)]):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        img[rng.random((h, w)) < 0.03] = (128, 128, 0)   # channel sum 256: black under the wrapping sum only
+        img[rng.random((h, w)) < 0.03] = 0
+        if kind == "near-integer":
+            # offsets within a few float32 ulps of an integer: where the float32 and the float64 chain truncate differently
+            # (searched, not constructed: the candidates are depth values whose float32 chain lands on the other side of
+            # the integer than the float64 chain does)
+            dpx, c32 = (div / 100.0) * w, np.float32(conv)
+            base = (rng.integers(1, 6, (h, w)) / dpx).astype(np.float32) + c32
+            depth = base.copy()
+            for idx in np.ndindex(h, w):
+                if rng.random() < 0.5:
+                    continue
+                for k in range(-48, 49):
+                    cand = (base[idx].view(np.int32) + np.int32(k)).view(np.float32)
+                    ndc = cand - c32
+                    i32 = int(1.0 * (abs(ndc) ** e) * dpx + 0.0)
+                    i64 = int(1.0 * (abs(np.float64(ndc)) ** e) * dpx + 0.0)
+                    if i32 != i64:
+                        depth[idx] = cand
+                        break
+        else:
+            depth = synth.depth_batch(kind, 1, h, w, channels=1)[0, ..., 0].astype(np.float32)
+            depth = (depth - depth.min()) / (depth.max() - depth.min())
+        depth[0, 0], depth[0, 1] = 0.0, 1.0
+        depth = depth.astype(np.float32)
+        nd32 = depth - np.float32(conv)
+        nd64 = nd32.astype(np.float64)
+        div_px, sep_px = (div / 100.0) * w, (sep / 100.0) * w
+        arrays[f"{cid}/img"], arrays[f"{cid}/depth"] = img, depth
+        for fill in ("none", "naive", "naive_interpolating"):
+            arrays[f"{cid}/{fill}"] = sig.apply_stereo_divergence_naive(img, nd64, div_px, sep_px, e, fill)
+        arrays[f"{cid}/inverse"] = sig.apply_stereo_divergence_inverse(img, nd64, div_px, sep_px, e)
+        # how often the two dialects disagree on this case (reported by the tests)
+        d32 = sig.apply_stereo_divergence_naive(img, nd32, div_px, sep_px, e, "none")
+        cases.append(dict(id=str(cid), kind=kind, divergence=div, separation=sep, exponent=e, convergence=conv,
+                          pixels_differing_from_d32=int((d32 != arrays[f"{cid}/none"]).any(-1).sum())))
+    np.savez_compressed(os.path.join(OUT, "dialect_f64.npz"), meta=json.dumps(dict(cases=cases)), **arrays)
+    print("dialect_f64:", len(cases), "cases;", [c["pixels_differing_from_d32"] for c in cases], "pixels differ from D32 ('none')")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     refload.quiet()
@@ -387,6 +440,9 @@ def main():
     if "--only-digests" in sys.argv:
         gen_digests(gs)
         return
+    if "--only-dialect" in sys.argv:
+        gen_dialect_f64(sig)
+        return
     gen_apply_stereo_divergence(sig)
     gen_hidden(sig)
     gen_blur(sig)
@@ -396,6 +452,7 @@ def main():
     gen_node_extra(gs)
     gen_warp_1080p(sig)
     gen_digests(gs)
+    gen_dialect_f64(sig)
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
