@@ -819,6 +819,93 @@ __device__ void technique_hybrid_fill(const Lds& L, const RowArgs& A, int frame,
     __syncthreads();
 }
 
+// hybrid_edge, second pass as a plain elementwise kernel (the row kernel's LDS staging, scans and barriers buy nothing
+// here: edge_aware_gap_fill only reads the splat result around the pixel).  One lane per source column of one row: both
+// eyes of the pixel, the layout / anaglyph composition of RowOut, the no-fill mask and both depth-map outputs.
+struct Px3f { float x, y, z; };
+struct Px3b { uint8_t x, y, z; };
+
+__device__ __forceinline__ void hybrid_fill_px(const RowArgs& A, const unsigned long long* etab, int frame, int eyei, int row, int j,
+                                               uint8_t out[3]) {
+    const int w = A.w, h = A.h;
+    const uint8_t* base = A.hyb_base + (((size_t)frame * A.neyes + eyei) * h) * (size_t)w * 3;
+    const uint8_t* mask = A.hyb_mask + (((size_t)frame * A.neyes + eyei) * h) * (size_t)w;
+    const uint8_t* b = base + ((size_t)row * w + j) * 3;
+    float r0 = (float)b[0], r1 = (float)b[1], r2 = (float)b[2];
+    if (mask[(size_t)row * w + j] == 0) {
+        float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
+        double wt = 0.0;
+        double g0 = 0.0;
+        bool have_g0 = false;
+        for (int di = -1; di <= 1; di++)
+            for (int dj = -1; dj <= 1; dj++) {
+                int ni = row + di, nj = j + dj;
+                if (ni < 0 || ni >= h || nj < 0 || nj >= w) continue;
+                if (mask[(size_t)ni * w + nj] == 0) continue;
+                if (!have_g0) { g0 = hyb_guidance(A, frame, row, j); have_g0 = true; }
+                int dsq = di * di + dj * dj;
+                double w_s = csm::exp_exact(-(double)dsq / 2.0, etab);
+                double diff = g0 - hyb_guidance(A, frame, ni, nj);
+                double w_r = csm::exp_exact(-(diff * diff) / 200.0, etab);
+                double wg = w_s * w_r;
+                float wg32 = (float)wg;
+                const uint8_t* nb = base + ((size_t)ni * w + nj) * 3;
+                n0 = n0 + (float)nb[0] * wg32;
+                n1 = n1 + (float)nb[1] * wg32;
+                n2 = n2 + (float)nb[2] * wg32;
+                wt += wg;
+            }
+        if (wt > 0.0) {
+            float wt32 = (float)wt;
+            r0 = n0 / wt32; r1 = n1 / wt32; r2 = n2 / wt32;
+        }
+    }
+    r0 = fminf(fmaxf(r0, 0.0f), 255.0f); r1 = fminf(fmaxf(r1, 0.0f), 255.0f); r2 = fminf(fmaxf(r2, 0.0f), 255.0f);
+    out[0] = (uint8_t)(int)r0; out[1] = (uint8_t)(int)r1; out[2] = (uint8_t)(int)r2;
+}
+
+__global__ void __launch_bounds__(256) k_hybrid_fill(RowArgs A) {
+    __shared__ unsigned long long etab[256];
+    etab[threadIdx.x] = d_hyb_exp_tab[threadIdx.x];
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y, frame = blockIdx.z;
+    const int w = A.w, h = A.h;
+    if (j >= w) return;
+    const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
+    const size_t pix = ((size_t)frame * h + row) * w + j;
+    uint8_t px[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    for (int e = 0; e < A.neyes; e++) {
+        if (A.single >= 0 && A.single != e) continue;
+        if (A.eye[e].enabled) hybrid_fill_px(A, etab, frame, e, row, j, px[e]);
+        else { px[e][0] = src_u8(A, frame, row, j, 0); px[e][1] = src_u8(A, frame, row, j, 1); px[e][2] = src_u8(A, frame, row, j, 2); }
+    }
+    auto store = [&](int e, uint8_t r, uint8_t g, uint8_t b) {   // (RowOut's destination arithmetic)
+        const EyeArgs& E = A.eye[e];
+        const size_t o = ((size_t)frame * A.out_h + row + E.yoff) * A.out_w + E.xoff + j;
+        if (A.stereo_is_u8) *reinterpret_cast<Px3b*>(reinterpret_cast<uint8_t*>(A.stereo) + o * 3) = Px3b{r, g, b};
+        else *reinterpret_cast<Px3f*>(A.stereo + o * 3) = Px3f{csm::code_over_255((float)r), csm::code_over_255((float)g), csm::code_over_255((float)b)};
+        A.mask[o] = ((int)r + (int)g + (int)b) == 0 ? 1.0f : 0.0f;  // GenerateStereo.py:355-361
+    };
+    if (A.out_u8) {
+        *reinterpret_cast<Px3b*>(A.out_u8 + pix * 3) = Px3b{px[0][0], px[0][1], px[0][2]};
+    } else if (A.anaglyph == 1) store(1, px[0][0], px[1][1], px[1][2]);       // R from eye 0, GB from eye 1 (:1996-2010)
+    else if (A.anaglyph == 2) store(1, px[1][0], px[0][1], px[0][2]);
+    else {
+        for (int e = 0; e < A.neyes; e++) {
+            if (A.single >= 0 && A.single != e) continue;
+            store(e, px[e][0], px[e][1], px[e][2]);
+        }
+    }
+    // depth-map outputs: (depth*255).astype(uint8) wraps mod 256 (quirk Q7), then /255, 3 channels
+    if (A.depth_l) {
+        const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
+        for (int e = 0; e < 2; e++) {
+            const float v = csm::code_over_255((float)csm::f32_to_u8_wrap((A.eye[e].depth[pix] * scale) * 255.0f));
+            *reinterpret_cast<Px3f*>((e == 0 ? A.depth_l : A.depth_r) + pix * 3) = Px3f{v, v, v};
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // the row kernel
 // ---------------------------------------------------------------------------------------------
@@ -1103,7 +1190,12 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int pl
     hipError_t e = hipFuncSetAttribute((const void*)k_hybrid_splat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return CS_EHIP;
     hipLaunchKernelGGL(k_hybrid_splat, dim3(A.h, A.n, A.neyes), dim3(threads), lds, stream, A);
-    e = launch_rowwarp(plus ? CS_FILL_HYBRID_EDGE_PLUS : CS_FILL_HYBRID_EDGE, A, plus ? threads : threads2, stream);
+    if (plus) e = launch_rowwarp(CS_FILL_HYBRID_EDGE_PLUS, A, threads, stream);
+    else if (dev_switch(CS_DEBUG_PT_VARIANT) == 31) e = launch_rowwarp(CS_FILL_HYBRID_EDGE, A, threads2, stream);   // (development: the row kernel's fill pass)
+    else {
+        hipLaunchKernelGGL(k_hybrid_fill, dim3((A.w + 255) / 256, A.h, A.n), dim3(256), 0, stream, A);
+        e = hipGetLastError();
+    }
     return e == hipSuccess ? CS_OK : CS_EHIP;
 }
 
