@@ -832,7 +832,7 @@ __device__ __forceinline__ void hybrid_fill_px(const RowArgs& A, const unsigned 
     const uint8_t* mask = A.hyb_mask + (((size_t)frame * A.neyes + eyei) * h) * (size_t)w;
     const uint8_t* b = base + ((size_t)row * w + j) * 3;
     float r0 = (float)b[0], r1 = (float)b[1], r2 = (float)b[2];
-    if (mask[(size_t)row * w + j] == 0) {
+    if (mask[(size_t)row * w + j] == 0 && A.dbg != 41) {
         float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
         double wt = 0.0;
         double g0 = 0.0;
