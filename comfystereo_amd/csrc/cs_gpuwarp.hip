@@ -81,7 +81,10 @@ __device__ __forceinline__ float gw_div_core(float a, float b) {
 }
 __device__ __forceinline__ bool gw_core_ok(float a) { const float m = fabsf(a); return a == 0.0f || (m >= 0x1p-60f && m < 0x1p60f); }
 
-__global__ void __launch_bounds__(1024, 8) k_gpuwarp(GwArgs A) {
+// MINW: waves per SIMD the register budget is sized for -- 8 (64 VGPRs, 8 spilled) lets two 1024-thread workgroups share a
+// CU at 4K; the 512-thread workgroups of narrower frames run 6 per SIMD without spills (+5 % at 1080p)
+template <int MINW>
+__global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id();
     const int y = blockIdx.x, frame = blockIdx.y, w = A.w, h = A.h;
@@ -599,9 +602,12 @@ static int gw_launch(GwArgs& A, hipStream_t stream) {
     if (forced == 21 && A.w <= 4 * 512) threads = 512;
     if (forced == 22 && A.w <= 4 * 256) threads = 256;
     if (forced == 23) threads = 1024;
-    hipError_t e = hipFuncSetAttribute((const void*)k_gpuwarp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool wide = threads > 512;
+    hipError_t e = hipFuncSetAttribute(wide ? (const void*)k_gpuwarp<8> : (const void*)k_gpuwarp<6>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return CS_EHIP;
-    hipLaunchKernelGGL(k_gpuwarp, dim3(A.h, A.n), dim3(threads), lds, stream, A);
+    if (wide) hipLaunchKernelGGL(k_gpuwarp<8>, dim3(A.h, A.n), dim3(threads), lds, stream, A);
+    else hipLaunchKernelGGL(k_gpuwarp<6>, dim3(A.h, A.n), dim3(threads), lds, stream, A);
     return CS_OK;
 }
 
