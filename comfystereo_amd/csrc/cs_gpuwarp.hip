@@ -400,7 +400,8 @@ __global__ void __launch_bounds__(512) k_mesh_keep(GwArgs A) {
     for (int x = tid; x < w - 1; x += nt) dst[x] = acc[x];
 }
 
-__global__ void __launch_bounds__(1024, 8) k_meshwarp(GwArgs A) {
+template <int MINW>   // (as for k_gpuwarp)
+__global__ void __launch_bounds__(1024, MINW) k_meshwarp(GwArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id();
     const int k = blockIdx.x, frame = blockIdx.y, w = A.w, h = A.h;
@@ -589,10 +590,12 @@ static int gw_launch(GwArgs& A, hipStream_t stream) {
         size_t lk = mesh_keep_lds_bytes(A.w), lm = mesh_lds_bytes(A.w);
         hipError_t e = hipFuncSetAttribute((const void*)k_mesh_keep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lk);
         if (e != hipSuccess) return CS_EHIP;
-        e = hipFuncSetAttribute((const void*)k_meshwarp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
+        e = hipFuncSetAttribute(threads > 512 ? (const void*)k_meshwarp<8> : (const void*)k_meshwarp<6>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
         if (e != hipSuccess) return CS_EHIP;
         hipLaunchKernelGGL(k_mesh_keep, dim3(A.h - 1, ngroups, A.neyes), dim3(threads > 512 ? 512 : threads), lk, stream, A);
-        hipLaunchKernelGGL(k_meshwarp, dim3(A.h, A.n), dim3(threads), lm, stream, A);
+        if (threads > 512) hipLaunchKernelGGL(k_meshwarp<8>, dim3(A.h, A.n), dim3(threads), lm, stream, A);
+        else hipLaunchKernelGGL(k_meshwarp<6>, dim3(A.h, A.n), dim3(threads), lm, stream, A);
         return CS_OK;
     }
     size_t lds = gw_lds_bytes(A.w);
