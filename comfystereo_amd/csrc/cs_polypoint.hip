@@ -342,15 +342,20 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             risk |= r ? 1u << k : 0u;
         }
         if (PP_DEV_IS(36)) risk = 0;
-        while (__any(risk != 0u)) {  // the full powf clone for the risky arguments (all of them for other exponents)
-            float xin = 1.0f;
-            int sel = -1;
+        // the full powf clone for the risky arguments (all of them for other exponents).  Behind its own branch: the compiler
+        // otherwise hoists the clone's ~55 constant set-up instructions in front of the loop test, where every wave pays them.
+        if (__any(risk != 0u)) {
+            asm volatile("" ::: "memory");
+            do {
+                float xin = 1.0f;
+                int sel = -1;
 #pragma unroll
-            for (int k = SLOTS - 1; k >= 0; k--) if (risk & (1u << k)) { xin = axs[k]; sel = k; }
-            const float r = csm::powf_exact_simt(xin, A.e32, tabs);
+                for (int k = SLOTS - 1; k >= 0; k--) if (risk & (1u << k)) { xin = axs[k]; sel = k; }
+                const float r = csm::powf_exact_simt(xin, A.e32, tabs);
 #pragma unroll
-            for (int k = 0; k < SLOTS; k++) if (sel == k) pw[k] = r;
-            risk &= risk - 1u;
+                for (int k = 0; k < SLOTS; k++) if (sel == k) pw[k] = r;
+                risk &= risk - 1u;
+            } while (__any(risk != 0u));
         }
         const float tidf = (float)tid;
         const float jf0 = (float)s0 + tidf + 0.5f;  // exact: integers + 0.5 below 2^23
