@@ -172,7 +172,11 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     float4* P = (float4*)smem;                                                    // [NPT] {R, G, B, x} of point o
     float* pz = (float*)(P + NPT);                                                // [NPT] |coord_d|
     uint32_t* plist = (uint32_t*)(pz + NPT);                                      // [max(T, 128)] pixels evaluated in pass 2
-    csm::PowfTables* tabs = (csm::PowfTables*)plist;                              //   (until barrier 1: the powf tables, 512 bytes)
+    // The powf tables: exponents 1 and 2 only run the clone for the 0.4 % risky squares and read the tables where they are,
+    // in constant memory (512 bytes, L1-resident: no copy, nothing to wait for before barrier 0: +2 %); any other exponent
+    // sends every point through the clone, and the tables are copied into LDS (overlaying plist until barrier 1: +6 % there)
+    csm::PowfTables* const tabs_lds = (csm::PowfTables*)plist;
+    const bool all_powf = A.dbg == 17 || !(A.e32 == 2.0f || A.e32 == 1.0f);
     static_assert(sizeof(csm::PowfTables) == 512, "tables overlay");
     uint8_t* dflag = (uint8_t*)(plist + max(T, 128));                             // [T] PP_DIRTY | slot
     uint16_t* dcnt = (uint16_t*)(dflag + ((T + 3) & ~3));                         // [DCAP] points (low 8) | segments (high 8)
@@ -204,8 +208,8 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     const bool code_wraps = !(fmaxf(fabsf(dmin), fabsf(dmax)) < 8.0e6f);
 
     // LDS set-up in the shadow of the loads
-    if (tid < (int)(sizeof(csm::PowfTables) / 4))
-        reinterpret_cast<uint32_t*>(tabs)[tid] = reinterpret_cast<const uint32_t*>(&c_pp_powf_tables)[tid];
+    if (all_powf && tid < (int)(sizeof(csm::PowfTables) / 4))
+        reinterpret_cast<uint32_t*>(tabs_lds)[tid] = reinterpret_cast<const uint32_t*>(&c_pp_powf_tables)[tid];
     if (tid < (T + 3) / 4) reinterpret_cast<uint32_t*>(dflag)[tid] = 0;   // T <= 4 NT (checked on the host)
     if (tid < PP_DCAP / 2) reinterpret_cast<uint32_t*>(dcnt)[tid] = 0;
     if (tid < PF_WORDS) {   // minima start at INT_MAX, maxima at -1, counters at 0
@@ -309,7 +313,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         // numerators that are 0 or >= 2^-60 and a range within 2^+-40 (depth maps are 0..255); otherwise: plain division.
         const bool range_ok = range > 0x1p-40f && range < 0x1p40f;
         const float yr = range_ok ? rcp_refined(range) : 0.0f;
-        const int pow_mode = A.dbg == 17 ? 0 : (A.e32 == 2.0f ? 2 : (A.e32 == 1.0f ? 1 : 0));
+        const int pow_mode = all_powf ? 0 : (A.e32 == 2.0f ? 2 : 1);
         float sg[SLOTS], axs[SLOTS], pw[SLOTS], av[SLOTS];
         uint32_t amin = 0xffffffffu;
 #pragma unroll
@@ -351,7 +355,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
                 int sel = -1;
 #pragma unroll
                 for (int k = SLOTS - 1; k >= 0; k--) if (risk & (1u << k)) { xin = axs[k]; sel = k; }
-                const float r = csm::powf_exact_simt(xin, A.e32, tabs);
+                const float r = all_powf ? csm::powf_exact_simt(xin, A.e32, tabs_lds) : csm::powf_exact_simt(xin, A.e32, &c_pp_powf_tables);
 #pragma unroll
                 for (int k = 0; k < SLOTS; k++) if (sel == k) pw[k] = r;
                 risk &= risk - 1u;
