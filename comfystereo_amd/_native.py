@@ -24,7 +24,7 @@ MODE = {
 }
 
 EXPORTS = [
-    "cs_version", "cs_last_error", "cs_max_width", "cs_output_shape", "cs_workspace_bytes", "cs_generate",
+    "cs_version", "cs_last_error", "cs_max_width", "cs_max_width_mode", "cs_output_shape", "cs_workspace_bytes", "cs_generate",
     "cs_asd_workspace_bytes", "cs_apply_stereo_divergence", "cs_apply_stereo_divergence2", "cs_blur_workspace_bytes", "cs_directional_blur",
     "cs_warp_workspace_bytes", "cs_forward_warp", "cs_warp_mesh_workspace_bytes", "cs_forward_warp_mesh", "cs_expand_u8", "cs_stereo_shift_workspace_bytes", "cs_stereo_shift", "cs_profile", "cs_profile_read", "cs_debug_set",
     "cs_test_powf", "cs_test_exp",
@@ -73,6 +73,8 @@ def lib():
     L.cs_version.argtypes = []
     L.cs_last_error.restype = ctypes.c_char_p
     L.cs_last_error.argtypes = []
+    L.cs_max_width_mode.restype = c_int
+    L.cs_max_width_mode.argtypes = [c_int, c_int]
     L.cs_max_width.restype = c_int
     L.cs_max_width.argtypes = [c_int]
     L.cs_output_shape.restype = c_int

@@ -368,17 +368,22 @@ extern "C" {
 int cs_version(void) { return CS_ABI_VERSION; }
 const char* cs_last_error(void) { return g_err; }
 
-int cs_max_width(int fill) {
+// widest frame the LDS-resident row kernels take; anaglyph modes keep two channels of the first eye per pixel as well
+static int max_width_for(int fill, int anaglyph) {
     if (fill == CS_FILL_GPU_WARP) return gpuwarp_max_width();   // (the mesh-quality variant, cs_params.flags bit 2: cs_forward_warp_mesh's limit)
     if (fill == CS_FILL_HYBRID_EDGE) return hybrid_max_width();
     if (fill < 0 || fill > CS_FILL_HYBRID_EDGE_PLUS) return 0;
     int lo = 0, hi = 1 << 16;
     while (lo < hi) {
         int mid = (lo + hi + 1) / 2;
-        if (rowwarp_lds_bytes(fill, mid) <= CS_LDS_BYTES && poly_npt(mid, 1) < 65535) lo = mid;
+        if (rowwarp_lds_bytes(fill, mid, anaglyph) <= CS_LDS_BYTES && poly_npt(mid, 1) < 65535) lo = mid;
         else hi = mid - 1;
     }
     return lo;
+}
+int cs_max_width(int fill) { return max_width_for(fill, 1); }
+int cs_max_width_mode(int fill, int mode) {
+    return max_width_for(fill, mode == CS_MODE_RED_CYAN_ANAGLYPH || mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH);
 }
 
 int cs_output_shape(const cs_params* p, int* out_h, int* out_w, int* mask_h, int* mask_w) {
@@ -436,7 +441,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     int out_h, out_w, mask_h, mask_w;
     int rc = cs_output_shape(p, &out_h, &out_w, &mask_h, &mask_w);
     if (rc) return rc;
-    if (p->w > cs_max_width(p->fill)) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
+    if (p->w > cs_max_width_mode(p->fill, p->mode)) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
     WsLayout W = ws_layout(p);
     if (workspace_bytes < W.total) return fail(CS_EWORKSPACE, "workspace too small");
     char* ws = (char*)workspace;
@@ -551,7 +556,7 @@ int cs_apply_stereo_divergence2(const uint8_t* image_u8, const float* depth, int
     if (!image_u8 || !depth || !out_u8 || !workspace) return fail(CS_EINVAL, "null pointer");
     if (n <= 0 || h <= 0 || w <= 0) return fail(CS_EINVAL, "non-positive size");
     if (fill < 0 || fill > CS_FILL_HYBRID_EDGE_PLUS || fill == CS_FILL_GPU_WARP) return fail(CS_EINVAL, "unknown fill technique");
-    if (w > cs_max_width(fill)) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
+    if (w > max_width_for(fill, 0)) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
     if (workspace_bytes < cs_asd_workspace_bytes(n, h, w)) return fail(CS_EWORKSPACE, "workspace too small");
     uint32_t* stats = (uint32_t*)workspace;
     hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);

@@ -63,7 +63,7 @@ int dev_switch(int key);
 // cs_rowwarp.hip
 hipError_t launch_collect_rows(const uint8_t* flag, int total, uint32_t* count, uint32_t* list, hipStream_t stream);
 hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream);
-size_t rowwarp_lds_bytes(int fill, int w);
+size_t rowwarp_lds_bytes(int fill, int w, int anaglyph = 1);   // anaglyph modes stash two channels of the first eye (2 B per pixel)
 
 // cs_polytile.hip: tiled fast path of polylines; flags rows it cannot do for the general kernel
 hipError_t launch_polytile(int sharp, const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream);

@@ -1169,14 +1169,14 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
     return hipGetLastError();
 }
 
-size_t rowwarp_lds_bytes(int fill, int w) { return lds_common_bytes(fill, w, 1) + lds_tech_bytes(fill, w); }
+size_t rowwarp_lds_bytes(int fill, int w, int anaglyph) { return lds_common_bytes(fill, w, anaglyph) + lds_tech_bytes(fill, w); }
 
 size_t hybrid_workspace_bytes(int n, int h, int w) { return (size_t)n * 2 * h * w * 4 + 256; }
 int hybrid_max_width() {
     int lo = 0, hi = 1 << 15;
     while (lo < hi) {
         int mid = (lo + hi + 1) / 2;
-        if (rowwarp_lds_bytes(CS_FILL_HYBRID_EDGE, mid) <= CS_LDS_BYTES) lo = mid; else hi = mid - 1;
+        if (rowwarp_lds_bytes(CS_FILL_HYBRID_EDGE, mid, 1) <= CS_LDS_BYTES) lo = mid; else hi = mid - 1;
     }
     return lo;
 }
@@ -1184,7 +1184,7 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int pl
     RowArgs A = A0;
     A.hyb_base = (uint8_t*)workspace;
     A.hyb_mask = A.hyb_base + (size_t)A.n * A.neyes * A.h * A.w * 3;
-    size_t lds = rowwarp_lds_bytes(CS_FILL_HYBRID_EDGE, A.w);
+    size_t lds = rowwarp_lds_bytes(CS_FILL_HYBRID_EDGE, A.w, 1);
     int threads = A.w <= 256 ? 256 : (A.w <= 1024 ? 512 : 1024);
     const int threads2 = A.w > 1024 ? 512 : threads;  // the fill pass: two workgroups per CU at wide rows (+4.5 % at 4K)
     hipError_t e = hipFuncSetAttribute((const void*)k_hybrid_splat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -107,6 +107,9 @@ CS_API const char *cs_last_error(void);
 
 /* Largest frame width the LDS-resident row kernels accept for `fill` (160 KiB LDS per CU). */
 CS_API int cs_max_width(int fill);
+/* The same for one output mode: the side-by-side / top-bottom / single-eye modes need 2 bytes less LDS per pixel than the
+ * anaglyphs (cs_max_width is the anaglyph, i.e. smallest, limit). */
+CS_API int cs_max_width_mode(int fill, int mode);
 
 /* Shape of the outputs of cs_generate for `p`: stereoscope [n][*out_h][*out_w][3],
  * mask [n][*mask_h][*mask_w] (output-shaped for the CPU techniques, eye-shaped for gpu_warp). */

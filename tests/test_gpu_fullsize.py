@@ -190,3 +190,35 @@ def test_forward_warp_1080p_rows_on_the_gpu():
         assert np.array_equal(mask, want_mask), cid
         rows = case["rows"]
         assert_warp_colours(warped[:, :, rows, :], g[f"{cid}/rows"], want_mask[:, rows, :], cid)
+
+
+UI = {"none": "No fill", "naive_interpolating": "Fill - Naive interpolating", "polylines_soft": "Fill - Polylines Soft",
+      "inverse": "No fill - Reverse projection", "gpu_warp": "GPU Warp (Fast)"}
+
+
+@pytest.mark.parametrize("fill", sorted(UI))
+def test_8k_wide_rows_side_by_side(engine, fill):
+    """7680-pixel rows (an 8K frame is 7680 wide) through the node path, SBS: the techniques whose row state fits the LDS at
+    that width (cs_max_width_mode; the anaglyph modes need 2 more bytes per pixel and stay below 8K for some of them)."""
+    from comfystereo_amd import _native
+    L = _native.lib()
+    h, w = 6, 7680
+    assert L.cs_max_width_mode(engine.FILL[fill], engine.MODE["left-right"]) >= w
+    img = synth.image_f32(1, h, w, seed=8)
+    depth = synth.depth_batch("stepped", 1, h, w, channels=3)
+    got = gen(engine, img, depth, fill, "left-right", blur=False, div=3.0)
+    want = node_oracle.generate(img, depth, 3.0, 0.0, "left-right", 0.0, 0.5, 2.0, UI[fill], 20.0, 20.0, False, batch_size=12)
+    if fill == "gpu_warp":
+        assert np.array_equal(got[3], want[3])
+        assert np.abs(got[0] - want[0]).max() <= 1e-4
+    else:
+        for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+            assert np.array_equal(g, w_), name
+
+
+def test_too_wide_frames_are_refused_not_truncated(engine):
+    h, w = 4, 7680
+    img = synth.image_f32(1, h, w, seed=8)
+    depth = synth.depth_batch("stepped", 1, h, w, channels=3)
+    with pytest.raises(RuntimeError, match="too wide"):
+        gen(engine, img, depth, "polylines_sharp", "left-right", blur=False, div=3.0)
