@@ -47,7 +47,8 @@ struct Lds {
 
 
 __host__ __device__ constexpr bool fill_uses_res(int fill) {
-    return fill != CS_FILL_POLYLINES_SOFT && fill != CS_FILL_POLYLINES_SHARP;  // polylines emits pixels directly
+    // polylines emits pixels directly; hybrid_edge's LDS kernel is the splat only (its fill pass is k_hybrid_fill)
+    return fill != CS_FILL_POLYLINES_SOFT && fill != CS_FILL_POLYLINES_SHARP && fill != CS_FILL_HYBRID_EDGE;
 }
 __host__ __device__ inline size_t lds_common_bytes(int fill, int w, int anaglyph) {
     return 1024 + align16(sizeof(csm::PowfTables)) + 128 + align16(3 * (size_t)w) +
@@ -58,7 +59,7 @@ __host__ __device__ inline int poly_cap(int w, int sharp) { return (sharp ? 4 : 
 __host__ __device__ inline size_t lds_tech_bytes(int fill, int w) {
     switch (fill) {
     case CS_FILL_NONE: return align16(4 * (size_t)w);                       // winner
-    case CS_FILL_NAIVE: return 3 * align16(4 * (size_t)w);                   // winner, L, R
+    case CS_FILL_NAIVE: return align16(4 * (size_t)w) + 2 * align16(2 * (size_t)w);   // winner, L, R (16-bit columns)
     case CS_FILL_NAIVE_INTERPOLATING:  // winner, flags, new colours, interval starts
         return align16(4 * (size_t)w) + align16((size_t)w) + align16(3 * (size_t)w) + align16(2 * (size_t)w);
     case CS_FILL_INVERSE: return align16(8 * (size_t)w);
@@ -158,24 +159,26 @@ __device__ void technique_forward(const Lds& L, int w, const EyeArgs& E, float e
     const unsigned smask = (d64 & 2) ? 0xffffu : 0xffu;
     forward_map(L, w, E, e32, winner, d64, e64);
     if (FILL == CS_FILL_NAIVE) {
-        // nearest filled pixel: Lf[c] = last filled <= c, Rf[c] = first filled >= c
-        int* Lf = (int*)(L.tech + align16(4 * (size_t)w));
-        int* Rf = (int*)(L.tech + 2 * align16(4 * (size_t)w));
-        const int BIG = 1 << 29;
+        // nearest filled pixel: Lf[c] = last filled <= c (-1: none), Rf[c] = first filled >= c (0x7fff: none); 16-bit
+        // columns (w < 32767 is far beyond what fits the LDS anyway) keep 8K-wide rows inside the 160 KB
+        int16_t* Lf = (int16_t*)(L.tech + align16(4 * (size_t)w));
+        int16_t* Rf = (int16_t*)(L.tech + align16(4 * (size_t)w) + align16(2 * (size_t)w));
+        const int NONE_R = 0x7fff, BIG = 1 << 29;
         for (int c = tid; c < w; c += nt) {
             bool f = winner[c] != init;
-            Lf[c] = f ? c : -BIG;
-            Rf[c] = f ? c : BIG;
+            Lf[c] = (int16_t)(f ? c : -1);
+            Rf[c] = (int16_t)(f ? c : NONE_R);
         }
         __syncthreads();
-        block_scan_inclusive(Lf, w, -BIG, OpMax(), L.misc + 8);
-        block_scan_inclusive(Rf, w, BIG, OpMin(), L.misc + 8, true);
+        block_scan_inclusive(Lf, w, -1, OpMax(), L.misc + 8);
+        block_scan_inclusive(Rf, w, NONE_R, OpMin(), L.misc + 8, true);
         for (int c = tid; c < w; c += nt) {
             if (winner[c] != init) continue;
-            int dr = Rf[c] - c, dl = c - Lf[c];
+            const int r = Rf[c], l = Lf[c];
+            int dr = r == NONE_R ? BIG : r - c, dl = l < 0 ? BIG : c - l;
             int src = -1;
-            if (dr <= dl) { if (dr < E.naive_lim) src = Rf[c]; }
-            else if (dl < E.naive_lim) src = Lf[c];
+            if (dr <= dl) { if (dr < E.naive_lim) src = r; }
+            else if (dl < E.naive_lim) src = l;
             if (src >= 0) {  // sources are filled pixels, which this loop never modifies
                 L.res[3 * c + 0] = L.res[3 * src + 0];
                 L.res[3 * c + 1] = L.res[3 * src + 1];
@@ -678,7 +681,7 @@ __global__ void __launch_bounds__(1024) k_hybrid_splat(RowArgs A) {
     const int row = blockIdx.x, frame = blockIdx.y, eyei = blockIdx.z;
     const int w = A.w, h = A.h;
     const EyeArgs& E = A.eye[eyei];
-    Lds L = carve(smem, CS_FILL_HYBRID_EDGE, w, 1);
+    Lds L = carve(smem, CS_FILL_HYBRID_EDGE, w, 0);
     char* t = L.tech;
     float* destx = (float*)t; t += align16(4 * (size_t)w);
     uint16_t* binoff = (uint16_t*)t; t += align16(2 * ((size_t)w + 4));   // bin b = j_c + 1, b in [0, w+1]
@@ -1027,7 +1030,6 @@ __device__ void rowwarp_row(const RowArgs& A, const int row, const int frame, ch
             } else if (FILL == CS_FILL_INVERSE) technique_inverse(L, w, E, A.e32, A.d64, A.e64);
             else if (FILL == CS_FILL_POLYLINES_SOFT) technique_polylines<0>(L, w, E, A.e32, st_rw, out, A.dbg);
             else if (FILL == CS_FILL_POLYLINES_SHARP) technique_polylines<1>(L, w, E, A.e32, st_rw, out, A.dbg);
-            else if (FILL == CS_FILL_HYBRID_EDGE) technique_hybrid_fill(L, A, frame, row, e);
             else if (FILL == CS_FILL_HYBRID_EDGE_PLUS) {
                 // hybrid_edge into `res`, then the polylines_soft row into `alt`; pixels that stayed black take the latter
                 technique_hybrid_fill(L, A, frame, row, e);
@@ -1159,7 +1161,6 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
         CS_LAUNCH(CS_FILL_POLYLINES_SOFT)
         CS_LAUNCH(CS_FILL_POLYLINES_SHARP)
         CS_LAUNCH(CS_FILL_INVERSE)
-        CS_LAUNCH(CS_FILL_HYBRID_EDGE)
         CS_LAUNCH(CS_FILL_NONE_POST)
         CS_LAUNCH(CS_FILL_INVERSE_POST)
         CS_LAUNCH(CS_FILL_HYBRID_EDGE_PLUS)
@@ -1176,7 +1177,7 @@ int hybrid_max_width() {
     int lo = 0, hi = 1 << 15;
     while (lo < hi) {
         int mid = (lo + hi + 1) / 2;
-        if (rowwarp_lds_bytes(CS_FILL_HYBRID_EDGE, mid, 1) <= CS_LDS_BYTES) lo = mid; else hi = mid - 1;
+        if (rowwarp_lds_bytes(CS_FILL_HYBRID_EDGE, mid, 0) <= CS_LDS_BYTES) lo = mid; else hi = mid - 1;
     }
     return lo;
 }
@@ -1184,14 +1185,12 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int pl
     RowArgs A = A0;
     A.hyb_base = (uint8_t*)workspace;
     A.hyb_mask = A.hyb_base + (size_t)A.n * A.neyes * A.h * A.w * 3;
-    size_t lds = rowwarp_lds_bytes(CS_FILL_HYBRID_EDGE, A.w, 1);
+    size_t lds = rowwarp_lds_bytes(CS_FILL_HYBRID_EDGE, A.w, 0);
     int threads = A.w <= 256 ? 256 : (A.w <= 1024 ? 512 : 1024);
-    const int threads2 = A.w > 1024 ? 512 : threads;  // the fill pass: two workgroups per CU at wide rows (+4.5 % at 4K)
     hipError_t e = hipFuncSetAttribute((const void*)k_hybrid_splat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return CS_EHIP;
     hipLaunchKernelGGL(k_hybrid_splat, dim3(A.h, A.n, A.neyes), dim3(threads), lds, stream, A);
     if (plus) e = launch_rowwarp(CS_FILL_HYBRID_EDGE_PLUS, A, threads, stream);
-    else if (dev_switch(CS_DEBUG_PT_VARIANT) == 31) e = launch_rowwarp(CS_FILL_HYBRID_EDGE, A, threads2, stream);   // (development: the row kernel's fill pass)
     else {
         hipLaunchKernelGGL(k_hybrid_fill, dim3((A.w + 255) / 256, A.h, A.n), dim3(256), 0, stream, A);
         e = hipGetLastError();

@@ -192,8 +192,9 @@ def test_forward_warp_1080p_rows_on_the_gpu():
         assert_warp_colours(warped[:, :, rows, :], g[f"{cid}/rows"], want_mask[:, rows, :], cid)
 
 
-UI = {"none": "No fill", "naive_interpolating": "Fill - Naive interpolating", "polylines_soft": "Fill - Polylines Soft",
-      "inverse": "No fill - Reverse projection", "gpu_warp": "GPU Warp (Fast)"}
+UI = {"none": "No fill", "naive": "Fill - Naive", "naive_interpolating": "Fill - Naive interpolating",
+      "polylines_soft": "Fill - Polylines Soft", "inverse": "No fill - Reverse projection",
+      "hybrid_edge": "Imperfect fill - Hybrid Edge", "gpu_warp": "GPU Warp (Fast)"}
 
 
 @pytest.mark.parametrize("fill", sorted(UI))
