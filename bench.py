@@ -50,7 +50,7 @@ CONFIGS = {
                  name="SBS frames/sec, 256x1080p gpu_warp (BASELINE cfg 4)", kernel="k_gpuwarp",
                  what="BASELINE.json configs[3]: batch of 256 1080p frames, gpu_warp fill, left-right SBS, radial depth with a moving centre"),
     "cfg5": dict(h=2160, w=3840, frames=64, fill="none", mode="red-cyan-anaglyph", div=8.0, depth="stepped", bytes_px=64,
-                 name="anaglyph frames/sec, 64x4K no-fill + mask (BASELINE cfg 5)", kernel="k_rowwarp<none>",
+                 name="anaglyph frames/sec, 64x4K no-fill + mask (BASELINE cfg 5)", kernel="k_fwdtile (halo-tile forward map, both eyes per workgroup)",
                  what="BASELINE.json configs[4]: batch of 64 4K frames, red-cyan-anaglyph + no_fill mask output, stepped depth"),
 }
 UI_FILL = {"polylines_soft": "Fill - Polylines Soft", "hybrid_edge": "Imperfect fill - Hybrid Edge", "gpu_warp": "GPU Warp (Fast)",

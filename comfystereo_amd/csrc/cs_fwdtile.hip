@@ -1,0 +1,217 @@
+// cs_fwdtile.hip -- fill technique 'none' (reference stereoimage_generation.py:1850-1867, the forward map of
+// apply_stereo_divergence_naive) as a halo-tile kernel: the node path's float32 image in, both eyes of a tile out.
+//
+// The general row kernel (cs_rowwarp.hip) keeps a whole row of one frame in LDS (60 KB at 4K: two workgroups per CU,
+// five barriers, every pixel through the full powf clone).  The forward map only moves a pixel by int(offset) columns,
+// |offset| <= S = |div_px| max(c, 1-c)^e + |sep_px| (normalised depth in [0, 1]), so an output tile [o0, o0 + T) only
+// needs the source columns [o0 - S, o0 + T + S): a 256-thread workgroup stages them three per lane, converts the
+// colours once for BOTH eyes (packed uint8 codes in LDS), and per eye
+//   * every source pixel proposes itself for its destination column: "later write wins" of the reference's sweep ==
+//     the highest (divergence < 0) or lowest source column per destination -> LDS atomicMax / atomicMin,
+//   * every output column looks up its winner's colour (0 = hole) and keeps it in a register,
+// then the eyes are written straight into their slots of the SBS / top-bottom layout or composed into the anaglyph
+// (:1996-2010), together with the no-fill mask (GenerateStereo.py:355-361) and both depth-map outputs (:1511-1516).
+// Dialect D32 only (other dialects, uint8 images and anaglyph-free single calls of apply_stereo_divergence take the row
+// kernel).  Arithmetic as in cs_rowwarp.hip: (d - min) / range - conv, sign * powf(|nd|, e) * div + sep in float32 with
+// the libm-exact powf (exponents 2 and 1 through the exact shortcuts of cs_math.h), int() truncation.
+#include "cs_common.h"
+#include "cs_kernels.h"
+
+namespace cs {
+
+__constant__ csm::PowfTables c_fw_powf_tables = CS_POWF_TABLES_INIT;
+
+struct FwdTileArgs {
+    int n, h, w, S, T;
+    const float* image;
+    const uint32_t* stats;
+    int scale_from_stats;
+    float e32, conv32;
+    EyeArgs eye[2];
+    int single, anaglyph;
+    float* stereo; int stereo_is_u8;
+    float* mask; float* depth_l; float* depth_r;
+    int out_h, out_w;
+    int dbg;
+};
+
+struct FwF3 { float x, y, z; };
+struct FwB3 { uint8_t x, y, z; };
+
+template <int NT, int SLOTS>
+__global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    // grid = (tiles x 8 rows, rows / 8, frames): all tiles of a row on one XCD (see cs_polypoint.hip)
+    const int xi = blockIdx.x;
+    const int row = blockIdx.y * 8 + (xi & 7);
+    if (row >= A.h) return;
+    const int tile = xi >> 3, frame = blockIdx.z;
+    const int w = A.w, h = A.h, T = A.T;
+    const int o0 = tile * T, wt = min(T, w - o0);
+    const int s0 = max(0, o0 - A.S), s1 = min(w, o0 + wt + A.S), ns = s1 - s0;
+    constexpr int NPT = NT * SLOTS;
+    uint32_t* img = (uint32_t*)smem;        // [NPT] colour codes r | g << 8 | b << 16 of source column s0 + j
+    int* winner = (int*)(img + NPT);        // [T] winning source column (local index) per output column of the tile
+
+    const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
+    const uint32_t rowpix = ((uint32_t)frame * (uint32_t)h + (uint32_t)row) * (uint32_t)w;
+    const char* const irow = reinterpret_cast<const char*>(reinterpret_cast<const FwF3*>(A.image) + rowpix + s0);
+    const char* const drow0 = reinterpret_cast<const char*>(A.eye[0].depth + rowpix + s0);
+    const char* const drow1 = reinterpret_cast<const char*>(A.eye[1].depth + rowpix + s0);
+    FwF3 cpre[SLOTS];
+    float dpre[2][SLOTS];
+#pragma unroll
+    for (int k = 0; k < SLOTS; k++) {
+        const uint32_t jc = (uint32_t)min(tid + k * NT, ns - 1);
+        cpre[k] = *reinterpret_cast<const FwF3*>(irow + 12u * jc);
+        dpre[0][k] = *reinterpret_cast<const float*>(drow0 + 4u * jc);
+        dpre[1][k] = *reinterpret_cast<const float*>(drow1 + 4u * jc);
+    }
+    const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
+    // colours: np.clip(x * 255, 0, 255).astype(uint8) (reference :1508), once for both eyes
+#pragma unroll
+    for (int k = 0; k < SLOTS; k++) {
+        const uint32_t r = (uint32_t)(int)__builtin_amdgcn_fmed3f(cpre[k].x * 255.0f, 0.0f, 255.0f);
+        const uint32_t g = (uint32_t)(int)__builtin_amdgcn_fmed3f(cpre[k].y * 255.0f, 0.0f, 255.0f);
+        const uint32_t b = (uint32_t)(int)__builtin_amdgcn_fmed3f(cpre[k].z * 255.0f, 0.0f, 255.0f);
+        img[tid + k * NT] = r | g << 8 | b << 16;
+    }
+    constexpr int OUTS = SLOTS;   // output columns per lane: T <= NT * SLOTS
+    uint32_t res[2][OUTS];
+    const int pow_mode = A.dbg == 17 ? 0 : (A.e32 == 2.0f ? 2 : (A.e32 == 1.0f ? 1 : 0));
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+#pragma unroll
+        for (int m = 0; m < OUTS; m++) res[e][m] = 0;
+        if (A.single >= 0 && A.single != e) continue;
+        const EyeArgs& E = A.eye[e];
+        if (!E.enabled) {   // divergence < 0.001: the eye is the source image (quirk Q10)
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < OUTS; m++) {
+                const int q = tid + m * NT;
+                if (q < wt) res[e][m] = img[q + o0 - s0];
+            }
+            continue;
+        }
+        const int init = E.asc ? -1 : 0x7fffffff;
+#pragma unroll
+        for (int m = 0; m < OUTS; m++) if (tid + m * NT < T) winner[tid + m * NT] = init;
+        __syncthreads();   // (also: img complete)
+        const float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
+        const bool flat = dmax == dmin;
+        const float range = dmax - dmin;
+        float nd[SLOTS], pw[SLOTS];
+        unsigned risk = 0;
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) {
+            const float d = dpre[e][k] * scale;
+            nd[k] = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;   // (:1587-1600)
+            const float ax = fabsf(nd[k]);
+            bool r = pow_mode == 0;
+            pw[k] = pow_mode == 1 ? ax : (pow_mode == 2 ? csm::square_or_flag(ax, r) : 0.0f);
+            risk |= r ? 1u << k : 0u;
+        }
+        if (__any(risk != 0u)) {   // the full powf clone for the risky squares / for every point at other exponents
+            asm volatile("" ::: "memory");
+            do {
+                float xin = 1.0f;
+                int sel = -1;
+#pragma unroll
+                for (int k = SLOTS - 1; k >= 0; k--) if (risk & (1u << k)) { xin = fabsf(nd[k]); sel = k; }
+                const float r = csm::powf_exact_simt(xin, A.e32, &c_fw_powf_tables);
+#pragma unroll
+                for (int k = 0; k < SLOTS; k++) if (sel == k) pw[k] = r;
+                risk &= risk - 1u;
+            } while (__any(risk != 0u));
+        }
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) {
+            const int j = tid + k * NT;
+            const float sg = nd[k] >= 0.0f ? 1.0f : -1.0f;
+            const float off = ((sg * pw[k]) * E.div32) + E.sep32;                  // (:1865)
+            // int(): truncation toward zero; keep the conversion defined for absurd offsets
+            const int io = off >= 2147483520.0f ? 0x7fffff00 : (off <= -2147483520.0f ? -0x7fffff00 : (int)off);
+            const long long q = (long long)(s0 + j - o0) + io;
+            if (j < ns && q >= 0 && q < wt) {
+                if (E.asc) atomicMax(&winner[(int)q], j);
+                else atomicMin(&winner[(int)q], j);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < OUTS; m++) {
+            const int q = tid + m * NT;
+            if (q < wt) {
+                const int s = winner[q];
+                res[e][m] = s != init ? img[s] : 0u;
+            }
+        }
+        __syncthreads();   // (winner is re-initialised for the next eye)
+    }
+    // ---- outputs: eyes into their slots / the anaglyph composition, the no-fill mask, both depth-map outputs
+    auto store = [&](int e, int q, uint32_t c) {
+        const EyeArgs& E = A.eye[e];
+        const uint32_t o = ((uint32_t)frame * (uint32_t)A.out_h + (uint32_t)(row + E.yoff)) * (uint32_t)A.out_w + (uint32_t)(E.xoff + o0 + q);
+        const uint32_t r = c & 0xffu, g = (c >> 8) & 0xffu, b = (c >> 16) & 0xffu;
+        if (A.stereo_is_u8) *reinterpret_cast<FwB3*>(reinterpret_cast<uint8_t*>(A.stereo) + (size_t)o * 3) = FwB3{(uint8_t)r, (uint8_t)g, (uint8_t)b};
+        else *reinterpret_cast<FwF3*>(A.stereo + (size_t)o * 3) = FwF3{csm::code_over_255((float)r), csm::code_over_255((float)g), csm::code_over_255((float)b)};
+        A.mask[o] = (c & 0xffffffu) == 0u ? 1.0f : 0.0f;   // sum of the channels == 0 (GenerateStereo.py:355-361)
+    };
+#pragma unroll
+    for (int m = 0; m < OUTS; m++) {
+        const int q = tid + m * NT;
+        if (q >= wt) continue;
+        if (A.anaglyph == 1) store(1, q, (res[0][m] & 0xffu) | (res[1][m] & 0xffff00u));        // R from eye 0, GB from eye 1
+        else if (A.anaglyph == 2) store(1, q, (res[1][m] & 0xffu) | (res[0][m] & 0xffff00u));
+        else {
+            if (A.single < 0 || A.single == 0) store(0, q, res[0][m]);
+            if (A.single < 0 || A.single == 1) store(1, q, res[1][m]);
+        }
+    }
+    // depth-map outputs: (depth * 255).astype(uint8) wraps mod 256 (quirk Q7), value code / 255 on three channels
+    const int qoff = s0 - o0;
+#pragma unroll
+    for (int k = 0; k < SLOTS; k++) {
+        const int q = tid + k * NT + qoff;   // tile pixel of this source column
+        if ((unsigned)q < (unsigned)wt) {
+            const size_t p = (size_t)(rowpix + (uint32_t)(o0 + q)) * 3;
+            const float v0 = csm::code_over_255((float)csm::f32_to_u8_wrap((dpre[0][k] * scale) * 255.0f));
+            const float v1 = csm::code_over_255((float)csm::f32_to_u8_wrap((dpre[1][k] * scale) * 255.0f));
+            *reinterpret_cast<FwF3*>(A.depth_l + p) = FwF3{v0, v0, v0};
+            *reinterpret_cast<FwF3*>(A.depth_r + p) = FwF3{v1, v1, v1};
+        }
+    }
+}
+
+// Largest halo the tile kernel takes (beyond it: the row kernel)
+int fwdtile_max_halo() { return (256 * 3 - 64) / 2; }
+
+// `none` through the tile kernel.  Returns hipErrorNotSupported when the call is not one of its cases (the caller then
+// launches the row kernel).
+hipError_t launch_fwdtile(const RowArgs& R, int S, hipStream_t stream) {
+    constexpr int NT = 256, SLOTS = 3;
+    if (!R.image_f32 || R.out_u8 || R.d64 || R.neyes != 2 || !R.depth_l || !R.depth_r || R.row_list) return hipErrorNotSupported;
+    if (S > fwdtile_max_halo()) return hipErrorNotSupported;
+    if ((size_t)R.n * R.h * R.w >= (1ull << 31) || (size_t)R.n * R.out_h * R.out_w >= (1ull << 31) || R.n > 65535) return hipErrorNotSupported;
+    FwdTileArgs A;
+    A.n = R.n; A.h = R.h; A.w = R.w; A.S = S;
+    int tmax = (NT * SLOTS - 2 * S) & ~3;
+    const int tiles = (R.w + tmax - 1) / tmax;
+    A.T = ((R.w + tiles - 1) / tiles + 3) & ~3;
+    if (A.T + 2 * S > NT * SLOTS) return hipErrorNotSupported;
+    A.image = R.image_f32; A.stats = R.stats; A.scale_from_stats = R.scale_from_stats;
+    A.e32 = R.e32; A.conv32 = R.conv32;
+    A.eye[0] = R.eye[0]; A.eye[1] = R.eye[1];
+    A.single = R.single; A.anaglyph = R.anaglyph;
+    A.stereo = R.stereo; A.stereo_is_u8 = R.stereo_is_u8; A.mask = R.mask; A.depth_l = R.depth_l; A.depth_r = R.depth_r;
+    A.out_h = R.out_h; A.out_w = R.out_w;
+    A.dbg = R.dbg;
+    const int ntiles = (R.w + A.T - 1) / A.T;
+    const size_t lds = (size_t)NT * SLOTS * 4 + (size_t)A.T * 4 + 64;
+    hipLaunchKernelGGL((k_fwdtile<NT, SLOTS>), dim3(ntiles * 8, (R.h + 7) / 8, R.n), dim3(NT), lds, stream, A);
+    return hipGetLastError();
+}
+
+}  // namespace cs
