@@ -342,8 +342,8 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         if (e != hipSuccess) return fail_hip(e, "flagged-row collection");
         A.row_list = list; A.row_count = count;
     }
-    if (fill == CS_FILL_NONE && !dev_switch(CS_DEBUG_NO_TILE)) {   // the halo-tile kernel where it applies
-        hipError_t e = launch_fwdtile(A, halo, stream);
+    if ((fill == CS_FILL_NONE || fill == CS_FILL_INVERSE) && !dev_switch(CS_DEBUG_NO_TILE)) {   // the halo-tile kernel where it applies
+        hipError_t e = launch_fwdtile(fill, A, halo, stream);
         if (e == hipSuccess) return CS_OK;
         if (e != hipErrorNotSupported) return fail_hip(e, "forward tile kernel launch");
     }

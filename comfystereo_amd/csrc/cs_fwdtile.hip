@@ -1,5 +1,6 @@
-// cs_fwdtile.hip -- fill technique 'none' (reference stereoimage_generation.py:1850-1867, the forward map of
-// apply_stereo_divergence_naive) as a halo-tile kernel: the node path's float32 image in, both eyes of a tile out.
+// cs_fwdtile.hip -- fill techniques 'none' (reference stereoimage_generation.py:1850-1867, the forward map of
+// apply_stereo_divergence_naive) and 'inverse' (:1715-1737, the z-buffered two-column splat) as a halo-tile kernel: the
+// node path's float32 image in, both eyes of a tile out.
 //
 // The general row kernel (cs_rowwarp.hip) keeps a whole row of one frame in LDS (60 KB at 4K: two workgroups per CU,
 // five barriers, every pixel through the full powf clone).  The forward map only moves a pixel by int(offset) columns,
@@ -7,7 +8,9 @@
 // needs the source columns [o0 - S, o0 + T + S): a 256-thread workgroup stages them three per lane, converts the
 // colours once for BOTH eyes (packed uint8 codes in LDS), and per eye
 //   * every source pixel proposes itself for its destination column: "later write wins" of the reference's sweep ==
-//     the highest (divergence < 0) or lowest source column per destination -> LDS atomicMax / atomicMin,
+//     the highest (divergence < 0) or lowest source column per destination -> LDS atomicMax / atomicMin ('none'); the
+//     z-buffer with strict '>' and ascending x == the maximum over (closeness, -x) of the two columns a pixel lands on
+//     -> 64-bit LDS atomicMax ('inverse'),
 //   * every output column looks up its winner's colour (0 = hole) and keeps it in a register,
 // then the eyes are written straight into their slots of the SBS / top-bottom layout or composed into the anaglyph
 // (:1996-2010), together with the no-fill mask (GenerateStereo.py:355-361) and both depth-map outputs (:1511-1516).
@@ -38,7 +41,7 @@ struct FwdTileArgs {
 struct FwF3 { float x, y, z; };
 struct FwB3 { uint8_t x, y, z; };
 
-template <int NT, int SLOTS>
+template <int NT, int SLOTS, int FILL>
 __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -52,7 +55,9 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
     const int s0 = max(0, o0 - A.S), s1 = min(w, o0 + wt + A.S), ns = s1 - s0;
     constexpr int NPT = NT * SLOTS;
     uint32_t* img = (uint32_t*)smem;        // [NPT] colour codes r | g << 8 | b << 16 of source column s0 + j
-    int* winner = (int*)(img + NPT);        // [T] winning source column (local index) per output column of the tile
+    int* winner = (int*)(img + NPT);        // [T] winning source column (local index) per output column of the tile ('none')
+    unsigned long long* key = (unsigned long long*)(img + NPT);   // [T] closeness << 32 | ~source index ('inverse')
+    const unsigned long long key_init = ((unsigned long long)csm::f2ord(-1.0f) << 32) | 0xffffffffull;
 
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
     const uint32_t rowpix = ((uint32_t)frame * (uint32_t)h + (uint32_t)row) * (uint32_t)w;
@@ -97,7 +102,11 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
         }
         const int init = E.asc ? -1 : 0x7fffffff;
 #pragma unroll
-        for (int m = 0; m < OUTS; m++) if (tid + m * NT < T) winner[tid + m * NT] = init;
+        for (int m = 0; m < OUTS; m++)
+            if (tid + m * NT < T) {
+                if (FILL == CS_FILL_INVERSE) key[tid + m * NT] = key_init;
+                else winner[tid + m * NT] = init;
+            }
         __syncthreads();   // (also: img complete)
         const float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
         const bool flat = dmax == dmin;
@@ -130,13 +139,25 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
         for (int k = 0; k < SLOTS; k++) {
             const int j = tid + k * NT;
             const float sg = nd[k] >= 0.0f ? 1.0f : -1.0f;
-            const float off = ((sg * pw[k]) * E.div32) + E.sep32;                  // (:1865)
-            // int(): truncation toward zero; keep the conversion defined for absurd offsets
-            const int io = off >= 2147483520.0f ? 0x7fffff00 : (off <= -2147483520.0f ? -0x7fffff00 : (int)off);
-            const long long q = (long long)(s0 + j - o0) + io;
-            if (j < ns && q >= 0 && q < wt) {
-                if (E.asc) atomicMax(&winner[(int)q], j);
-                else atomicMin(&winner[(int)q], j);
+            if (FILL == CS_FILL_INVERSE) {
+                const float off = (sg * pw[k]) * E.div32;
+                const float dest = ((float)(s0 + j) + 0.5f + off) + E.sep32;   // (:1725)
+                const float fl = floorf(dest);
+                if (j < ns && fl >= -2.0f && fl <= (float)w) {
+                    const int q = (int)fl - o0;
+                    const unsigned long long kk = ((unsigned long long)csm::f2ord(nd[k]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)j);
+                    if (q >= 0 && q < wt) atomicMax(&key[q], kk);
+                    if (q + 1 >= 0 && q + 1 < wt) atomicMax(&key[q + 1], kk);
+                }
+            } else {
+                const float off = ((sg * pw[k]) * E.div32) + E.sep32;                  // (:1865)
+                // int(): truncation toward zero; keep the conversion defined for absurd offsets
+                const int io = off >= 2147483520.0f ? 0x7fffff00 : (off <= -2147483520.0f ? -0x7fffff00 : (int)off);
+                const long long q = (long long)(s0 + j - o0) + io;
+                if (j < ns && q >= 0 && q < wt) {
+                    if (E.asc) atomicMax(&winner[(int)q], j);
+                    else atomicMin(&winner[(int)q], j);
+                }
             }
         }
         __syncthreads();
@@ -144,8 +165,13 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
         for (int m = 0; m < OUTS; m++) {
             const int q = tid + m * NT;
             if (q < wt) {
-                const int s = winner[q];
-                res[e][m] = s != init ? img[s] : 0u;
+                if (FILL == CS_FILL_INVERSE) {
+                    const unsigned long long kk = key[q];
+                    res[e][m] = kk > key_init ? img[0xffffffffu - (unsigned)(kk & 0xffffffffull)] : 0u;
+                } else {
+                    const int s = winner[q];
+                    res[e][m] = s != init ? img[s] : 0u;
+                }
             }
         }
         __syncthreads();   // (winner is re-initialised for the next eye)
@@ -188,10 +214,12 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
 // Largest halo the tile kernel takes (beyond it: the row kernel)
 int fwdtile_max_halo() { return (256 * 3 - 64) / 2; }
 
-// `none` through the tile kernel.  Returns hipErrorNotSupported when the call is not one of its cases (the caller then
+// `none` / `inverse` through the tile kernel.  Returns hipErrorNotSupported when the call is not one of its cases (the caller then
 // launches the row kernel).
-hipError_t launch_fwdtile(const RowArgs& R, int S, hipStream_t stream) {
+hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, hipStream_t stream) {
+    const int S = S0 + (fill == CS_FILL_INVERSE ? 2 : 0);   // (the splat also touches the column right of floor(dest))
     constexpr int NT = 256, SLOTS = 3;
+    if (fill != CS_FILL_NONE && fill != CS_FILL_INVERSE) return hipErrorNotSupported;
     if (!R.image_f32 || R.out_u8 || R.d64 || R.neyes != 2 || !R.depth_l || !R.depth_r || R.row_list) return hipErrorNotSupported;
     if (S > fwdtile_max_halo()) return hipErrorNotSupported;
     if ((size_t)R.n * R.h * R.w >= (1ull << 31) || (size_t)R.n * R.out_h * R.out_w >= (1ull << 31) || R.n > 65535) return hipErrorNotSupported;
@@ -209,8 +237,9 @@ hipError_t launch_fwdtile(const RowArgs& R, int S, hipStream_t stream) {
     A.out_h = R.out_h; A.out_w = R.out_w;
     A.dbg = R.dbg;
     const int ntiles = (R.w + A.T - 1) / A.T;
-    const size_t lds = (size_t)NT * SLOTS * 4 + (size_t)A.T * 4 + 64;
-    hipLaunchKernelGGL((k_fwdtile<NT, SLOTS>), dim3(ntiles * 8, (R.h + 7) / 8, R.n), dim3(NT), lds, stream, A);
+    const size_t lds = (size_t)NT * SLOTS * 4 + (size_t)A.T * 8 + 64;
+    if (fill == CS_FILL_INVERSE) hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_INVERSE>), dim3(ntiles * 8, (R.h + 7) / 8, R.n), dim3(NT), lds, stream, A);
+    else hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_NONE>), dim3(ntiles * 8, (R.h + 7) / 8, R.n), dim3(NT), lds, stream, A);
     return hipGetLastError();
 }
 
