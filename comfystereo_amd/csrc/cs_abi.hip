@@ -529,7 +529,8 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     case CS_MODE_ONLY_RIGHT: A.single = 1; break;
     }
     if (p->fill == CS_FILL_HYBRID_EDGE || p->fill == CS_FILL_HYBRID_EDGE_PLUS) {
-        rc = launch_hybrid(A, ws + W.extra, stream, p->fill == CS_FILL_HYBRID_EDGE_PLUS);
+        rc = launch_hybrid(A, ws + W.extra, stream, p->fill == CS_FILL_HYBRID_EDGE_PLUS,
+                           poly_halo(left_div, right_div, p->separation, p->stereo_offset_exponent, p->convergence_point, w));
         if (rc) return fail(rc, "hybrid_edge launch failed");
     } else {
         int halo = poly_halo(left_div, right_div, p->separation, p->stereo_offset_exponent, p->convergence_point, w);

@@ -89,7 +89,7 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
 // cs_rowwarp.hip (hybrid_edge: k_hybrid_splat + the fill pass of k_rowwarp)
 size_t hybrid_workspace_bytes(int n, int h, int w);
 int hybrid_max_width();
-int launch_hybrid(const RowArgs& A, void* workspace, hipStream_t stream, int plus = 0);  // plus: hybrid_edge_plus
+int launch_hybrid(const RowArgs& A, void* workspace, hipStream_t stream, int plus = 0, int halo = -1);  // plus: hybrid_edge_plus; halo >= 0: bound of |offset| (tile splat)
 
 // cs_gpuwarp.hip
 size_t gpuwarp_workspace_bytes(int n, int h, int w, int group, int mesh);   // group: frames per reference sub-batch

@@ -773,6 +773,128 @@ __global__ void __launch_bounds__(1024) k_hybrid_splat(RowArgs A) {
     }
 }
 
+// The same splat for an output TILE of one eye row (node path, float32 image): only the sources within S + 2 columns of
+// the tile can touch it, so a 256-thread workgroup stages them three per lane and runs the counting sort, the in-bin
+// ranking and the 3-way merge on ~770 sources out of 14 KB of LDS (8 workgroups per CU) instead of on a whole row out of
+// 50 KB (2 per CU).  Exponents 2 / 1 take the exact shortcuts of cs_math.h.  Results identical to k_hybrid_splat's.
+#define HYT_NT 256
+#define HYT_SLOTS 3
+#define HYT_NPT (HYT_NT * HYT_SLOTS)
+__global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, int T) {
+    __shared__ unsigned long long etab[256];
+    __shared__ uint32_t img[HYT_NPT];          // colour codes r | g << 8 | b << 16 of source s0 + j
+    __shared__ float destx[HYT_NPT];
+    __shared__ short bin[HYT_NPT];             // bin of source j: j_c - (o0 - 1), -1: cannot touch the tile
+    __shared__ uint16_t binoff[HYT_NPT + 8];   // [T + 3]
+    __shared__ uint16_t scratch[HYT_NPT];
+    __shared__ uint16_t sorted[HYT_NPT];
+    __shared__ int scan_ws[32];
+    const int tid = threadIdx.x;
+    const int xi = blockIdx.x;
+    const int row = blockIdx.y * 8 + (xi & 7);
+    if (row >= A.h) return;
+    const int tile = xi >> 3;
+    const int frame = blockIdx.z / A.neyes, eyei = blockIdx.z - frame * A.neyes;
+    const int w = A.w, h = A.h;
+    const EyeArgs& E = A.eye[eyei];
+    if (!E.enabled) return;  // eye = source image; the fill pass never reads this slot
+    const int o0 = tile * T, wt = min(T, w - o0);
+    const int s0 = max(0, o0 - S - 2), s1 = min(w, o0 + wt + S + 2), ns = s1 - s0;
+    const int nbin = wt + 2;   // j_c = o0 - 1 .. o0 + wt
+    etab[tid] = d_hyb_exp_tab[tid];
+    for (int i = tid; i < (nbin + 4) / 2 + 1; i += HYT_NT) ((unsigned*)binoff)[i] = 0;
+    const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
+    const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
+    const float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
+    const bool flat = dmax == dmin;
+    const float range = dmax - dmin;
+    const size_t rowpix = ((size_t)frame * h + row) * w;
+    const float* drow = E.depth + rowpix;
+    const int pow_mode = A.dbg == 17 ? 0 : (A.e32 == 2.0f ? 2 : (A.e32 == 1.0f ? 1 : 0));
+    __syncthreads();
+    for (int j = tid; j < ns; j += HYT_NT) {
+        const int x = s0 + j;
+        const float* px = A.image_f32 + (rowpix + x) * 3;
+        const uint32_t r = (uint32_t)(int)fminf(fmaxf(px[0] * 255.0f, 0.0f), 255.0f);
+        const uint32_t g = (uint32_t)(int)fminf(fmaxf(px[1] * 255.0f, 0.0f), 255.0f);
+        const uint32_t b = (uint32_t)(int)fminf(fmaxf(px[2] * 255.0f, 0.0f), 255.0f);
+        img[j] = r | g << 8 | b << 16;
+        const float d = drow[x] * scale;
+        const float nd = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
+        const float ax = fabsf(nd);
+        float p;
+        bool risky = pow_mode == 0;
+        if (pow_mode == 1) p = ax;
+        else if (pow_mode == 2) p = csm::square_or_flag(ax, risky);
+        else p = 0.0f;
+        if (risky) p = csm::powf_exact(ax, A.e32, &c_powf_tables);
+        const float off = ((nd >= 0.0f ? 1.0f : -1.0f) * p) * E.div32;
+        const float dx = ((float)x + 0.5f + off) + E.sep32;
+        destx[j] = dx;
+        const float fl = floorf(dx);
+        int b_ = -1;
+        if (fl >= (float)(o0 - 1) && fl <= (float)(o0 + wt)) b_ = (int)fl - (o0 - 1);   // j_c in [o0 - 1, o0 + wt] can touch a tile column
+        bin[j] = (short)b_;
+        if (b_ >= 0) atomic_add_u16(binoff, b_ + 1, 1);
+    }
+    __syncthreads();
+    block_scan_inclusive(binoff, nbin + 1, 0, OpAdd(), scan_ws);
+    for (int j = tid; j < ns; j += HYT_NT) {
+        const int b_ = bin[j];
+        if (b_ >= 0) scratch[atomic_add_u16(binoff, b_, 1)] = (uint16_t)j;
+    }
+    __syncthreads();
+    const int total = binoff[nbin - 1];
+    for (int k = tid; k < total; k += HYT_NT) {
+        const int j = scratch[k];
+        const int b_ = bin[j];
+        const int bs = b_ > 0 ? binoff[b_ - 1] : 0, be = binoff[b_];
+        int r = 0;
+        for (int t = bs; t < be; t++) r += scratch[t] < j ? 1 : 0;
+        sorted[bs + r] = (uint16_t)j;
+    }
+    __syncthreads();
+    uint8_t* base = A.hyb_base + ((((size_t)frame * A.neyes + eyei) * h + row) * w) * 3;
+    uint8_t* maskrow = A.hyb_mask + (((size_t)frame * A.neyes + eyei) * h + row) * w;
+    for (int q = tid; q < wt; q += HYT_NT) {
+        const int jcol = o0 + q;
+        // bins of j_c = jcol-1, jcol, jcol+1  ->  local bins q, q+1, q+2
+        int p0 = q > 0 ? binoff[q - 1] : 0, e0 = binoff[q];
+        int p1 = e0, e1 = binoff[q + 1];
+        int p2 = e1, e2 = binoff[q + 2];
+        float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, ws = 0.0f;
+        bool touched = false;
+        while (p0 < e0 || p1 < e1 || p2 < e2) {
+            const int x0 = p0 < e0 ? sorted[p0] : 0x7fffffff;
+            const int x1 = p1 < e1 ? sorted[p1] : 0x7fffffff;
+            const int x2 = p2 < e2 ? sorted[p2] : 0x7fffffff;
+            int j;
+            if (x0 < x1 && x0 < x2) { j = x0; p0++; }
+            else if (x1 < x2) { j = x1; p1++; }
+            else { j = x2; p2++; }
+            const float diff = destx[j] - (float)jcol;
+            const float arg = -(diff * diff) / 2.0f;
+            const double wg = csm::exp_exact((double)arg, etab);
+            const uint32_t c = img[j];
+            acc0 = (float)((double)acc0 + (double)(c & 0xffu) * wg);
+            acc1 = (float)((double)acc1 + (double)((c >> 8) & 0xffu) * wg);
+            acc2 = (float)((double)acc2 + (double)((c >> 16) & 0xffu) * wg);
+            ws = ws + (float)wg;
+            touched = true;
+        }
+        uint8_t v[3] = {0, 0, 0};
+        if (ws > 0.0f) {
+            float v0 = acc0 / ws, v1 = acc1 / ws, v2 = acc2 / ws;
+            v0 = v0 < 0.0f ? 0.0f : (v0 > 255.0f ? 255.0f : v0);
+            v1 = v1 < 0.0f ? 0.0f : (v1 > 255.0f ? 255.0f : v1);
+            v2 = v2 < 0.0f ? 0.0f : (v2 > 255.0f ? 255.0f : v2);
+            v[0] = (uint8_t)(int)v0; v[1] = (uint8_t)(int)v1; v[2] = (uint8_t)(int)v2;
+        }
+        base[3 * jcol + 0] = v[0]; base[3 * jcol + 1] = v[1]; base[3 * jcol + 2] = v[2];
+        maskrow[jcol] = touched ? 1 : 0;
+    }
+}
+
 __device__ __forceinline__ double hyb_guidance(const RowArgs& A, int frame, int y, int x) {
     return (0.299 * (double)src_u8(A, frame, y, x, 0) + 0.587 * (double)src_u8(A, frame, y, x, 1)) +
            0.114 * (double)src_u8(A, frame, y, x, 2);
@@ -1181,7 +1303,7 @@ int hybrid_max_width() {
     }
     return lo;
 }
-int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int plus) {
+int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int plus, int halo) {
     RowArgs A = A0;
     A.hyb_base = (uint8_t*)workspace;
     A.hyb_mask = A.hyb_base + (size_t)A.n * A.neyes * A.h * A.w * 3;
@@ -1189,7 +1311,14 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int pl
     int threads = A.w <= 256 ? 256 : (A.w <= 1024 ? 512 : 1024);
     hipError_t e = hipFuncSetAttribute((const void*)k_hybrid_splat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return CS_EHIP;
-    hipLaunchKernelGGL(k_hybrid_splat, dim3(A.h, A.n, A.neyes), dim3(threads), lds, stream, A);
+    // the tile form of the splat for the node path (float32 image) when a tile fits next to its halo
+    const int tmax = (HYT_NPT - 2 * (halo + 2) - 8) & ~3;
+    if (halo >= 0 && A.image_f32 && tmax >= 128 && !dev_switch(CS_DEBUG_NO_TILE) && (size_t)A.n * A.neyes <= 65535) {
+        const int tiles = (A.w + tmax - 1) / tmax;
+        const int T = ((A.w + tiles - 1) / tiles + 3) & ~3;
+        hipLaunchKernelGGL(k_hybrid_splat_tile, dim3(((A.w + T - 1) / T) * 8, (A.h + 7) / 8, A.n * A.neyes), dim3(HYT_NT), 0, stream, A, halo, T);
+    } else
+        hipLaunchKernelGGL(k_hybrid_splat, dim3(A.h, A.n, A.neyes), dim3(threads), lds, stream, A);
     if (plus) e = launch_rowwarp(CS_FILL_HYBRID_EDGE_PLUS, A, threads, stream);
     else {
         hipLaunchKernelGGL(k_hybrid_fill, dim3((A.w + 255) / 256, A.h, A.n), dim3(256), 0, stream, A);
