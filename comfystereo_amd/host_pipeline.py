@@ -57,12 +57,24 @@ class _Stage:
         self.range = None
 
 
+def result_shapes(image_shape, modes, fill="polylines_soft"):
+    """Shapes of the four results for an image batch [N,H,W,3]: (stereoscope, depth_left, depth_right, mask)."""
+    n, h, w = int(image_shape[0]), int(image_shape[1]), int(image_shape[2])
+    p = engine.make_params(1, h, w, h, w, 1, fill, modes, 1.0, 0.0, 0.0, 0.5, 1.0, False, 0.0, 0.0, 1.0, 0, 1)
+    oh, ow, mh, mw = engine.output_shape(p)
+    return (n, oh, ow, 3), (n, h, w, 3), (n, h, w, 3), (n, mh, mw)
+
+
 def generate_host(image, depth_map, divergence, separation, modes, stereo_balance, convergence_point,
                   stereo_offset_exponent, fill, depth_blur_edge_threshold, depth_blur_strength, depth_map_blur,
                   depth_blur_falloff=1.0, depth_blur_vert_smooth=0, batch_size=4, device=None, progress=None,
-                  pinned_outputs=True):
+                  pinned_outputs=True, out=None):
     """CPU tensors in (image [N,H,W,3], depth_map [N,H',W',C], float32) -> four CPU float32 tensors, like
-    StereoImageNode.generate returns them.  `progress(k)` is called with the number of frames finished."""
+    StereoImageNode.generate returns them.  `progress(k)` is called with the number of frames finished.
+    out: (stereoscope, depth_left, depth_right, mask) CPU float32 tensors of the result shapes (`result_shapes`) to write
+    into: a caller that keeps PINNED result tensors across calls (`tensor.pin_memory()` once) takes the
+    pinned allocation -- 24 GB/s of page faulting and locking, the bound of the default path -- off the critical path;
+    pageable tensors work too (through the pinned staging buffers)."""
     if not torch.cuda.is_available():
         raise RuntimeError("comfystereo_amd needs an MI355X (PyTorch-ROCm `cuda` device); there is no CPU fallback")
     device = device or torch.device("cuda", torch.cuda.current_device())
@@ -84,14 +96,23 @@ def generate_host(image, depth_map, divergence, separation, modes, stereo_balanc
     chunk = _chunk_frames(total, per_frame_out, fill, batch_size)
     shapes = ((total, oh, ow, 3), (total, h, w, 3), (total, h, w, 3), (total, mh, mw))
     final = None
-    if pinned_outputs:
+    if out is not None:
+        out = tuple(out)
+        if len(out) != 4:
+            raise ValueError("out: (stereoscope, depth_left, depth_right, mask)")
+        for t, sh in zip(out, shapes):
+            if t.device.type != "cpu" or t.dtype != torch.float32 or tuple(t.shape) != sh or not t.is_contiguous():
+                raise ValueError(f"out tensors must be contiguous CPU float32 tensors of shapes {shapes}")
+        if all(t.is_pinned() for t in out):
+            final = out
+    if final is None and out is None and pinned_outputs:
         try:
             final = tuple(torch.empty(sh, dtype=torch.float32, pin_memory=True) for sh in shapes)
         except RuntimeError:  # not enough lockable memory: fall back to pageable results through staging buffers
             final = None
     direct = final is not None
     if not direct:
-        final = tuple(torch.empty(sh, dtype=torch.float32) for sh in shapes)
+        final = out if out is not None else tuple(torch.empty(sh, dtype=torch.float32) for sh in shapes)
     ranges = [(b0, min(b0 + chunk, total)) for b0 in range(0, total, chunk)]
     slots = [_Stage(params(chunk), dshape, device, not direct) for _ in range(min(2, len(ranges)))]
     tail = None  # a shorter last chunk gets its own (smaller) slot

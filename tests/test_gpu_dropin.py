@@ -115,6 +115,15 @@ def test_host_pipeline_equals_the_whole_batch(monkeypatch, fill, n, batch):
         assert sum(seen) == n
         for g, r in zip(got, ref):
             assert not g.is_cuda and g.is_pinned() == pinned and torch.equal(g, r)
+    # caller-provided result tensors: pinned ones are written directly, pageable ones through the staging
+    shapes = host_pipeline.result_shapes(img.shape, "left-right", fill)
+    for pin in (True, False):
+        outs = tuple(torch.full(sh, -7.0).pin_memory() if pin else torch.full(sh, -7.0) for sh in shapes)
+        got = host_pipeline.generate_host(img, dep, *args, out=outs)
+        for g, o, r in zip(got, outs, ref):
+            assert g.data_ptr() == o.data_ptr() and torch.equal(o, r)
+    with pytest.raises(ValueError):
+        host_pipeline.generate_host(img, dep, *args, out=(torch.empty(1),) * 4)
     node_out = NODE.generate(img, dep, 6.0, 0.2, "left-right", 0.1, 0.5, 2.0, UI[fill], 20.0, 20.0, True, 2.0, 3, batch)
     for g, r in zip(node_out, ref):
         assert torch.equal(g, r)

@@ -44,3 +44,17 @@ gb = nbytes / 1e9 + (img.numel() + dep.numel()) * 4 / 1e9
 print(f"host tensors in/out: {a.n} frames {a.w}x{a.h}: {dt*1e3:.1f} ms -> {a.n/dt:.1f} frames/s, {gb/dt:.1f} GB/s over PCIe+host copies "
       f"(outputs are {'pinned' if pinned else 'pageable'} CPU tensors, freshly allocated); "
       f"with the previous results released first: {a.n/dt_cached:.1f} frames/s, {gb/dt_cached:.1f} GB/s")
+# caller-provided pinned result tensors, kept across calls (host_pipeline.generate_host(..., out=...))
+from comfystereo_amd import host_pipeline
+from comfystereo_amd.GenerateStereo import FILL_TECHNIQUE_MAPPING
+fill = FILL_TECHNIQUE_MAPPING[a.fill]
+outs = tuple(torch.empty(sh, dtype=torch.float32).pin_memory() for sh in host_pipeline.result_shapes(img.shape, "left-right", fill))
+hargs = (8.0, 0.0, "left-right", 0.0, 0.5, 2.0, fill, 20.0, 20.0, True, 2.0, 6, 12)
+host_pipeline.generate_host(img, dep, *hargs, out=outs)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.iters):
+    host_pipeline.generate_host(img, dep, *hargs, out=outs)
+torch.cuda.synchronize()
+dt_out = (time.perf_counter() - t0) / a.iters
+print(f"results into caller-provided pinned tensors (out=): {a.n/dt_out:.1f} frames/s, {gb/dt_out:.1f} GB/s")
