@@ -282,6 +282,8 @@ def main():
                                                    "once at the float32 node boundary (SURVEY.md 8d); the dominant kernel itself does not "
                                                    "read the 12 B/px RGB depth input (the gray / blur pre-pass does): kernel-own bytes = "
                                                    f"{cfg['bytes_px'] - 12 + (8 if blur else 4)} B/px",
+                         # the same with the kernel's OWN algorithmic bytes (its depth input is the gray / blurred depth, not RGB)
+                         "frac_kernel_own": achieved / HBM_PEAK_GBS * (cfg["bytes_px"] - 12 + (8 if blur else 4)) / cfg["bytes_px"],
                          "pipeline_achieved": frames * a.steps * cfg["bytes_px"] * H * W / dt / 1e9 / world},
             "diagnostics": {"rows_redone_by_general_kernel": tile_redo_rows, "rows_replayed_sequentially": fallback_rows,
                             "kernel_error_flags": err_flags},
