@@ -45,6 +45,7 @@ struct GwArgs {
     float* mask_f32;   // node:  [n][h][w] (left | right)
     float* depth_l; float* depth_r;  // node: [n][h][w][3]
     int noclamp;
+    int dbg;           // development (-DCS_DEV builds): phase cut-offs 51-54 of k_gpuwarp
     int mesh;          // 1: mesh-quality warp (k_meshwarp) instead of forward_warp_gpu's scatter rounds
     float grad_thr;    // mesh: gradient_threshold of the triangle culling (reference :455, 1.5)
     uint8_t* keep;     // mesh: [neyes][groups][h-1][w-1] keep bits (bit 0 triangle A, bit 1 triangle B)
@@ -52,6 +53,11 @@ struct GwArgs {
 };
 
 struct Px3 { float x, y, z; };
+#ifdef CS_DEV
+#define GW_DEV_IS(n) (A.dbg == (n))
+#else
+#define GW_DEV_IS(n) false
+#endif
 
 __constant__ csm::PowfTables c_gw_powf_tables = CS_POWF_TABLES_INIT;
 
@@ -79,11 +85,23 @@ __device__ __forceinline__ float gw_div_core(float a, float b) {
     const float r1 = __builtin_fmaf(-b, q1, a);
     return __builtin_fmaf(r1, y1, q1);
 }
+__device__ __forceinline__ float gw_rcp_refined(float b) {
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, y0, 1.0f), y0, y0);
+}
+__device__ __forceinline__ float gw_div_with(float a, float b, float y1) {   // gw_div_core with the refined reciprocal of b supplied
+    const float q0 = a * y1;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(r0, y1, q0);
+    const float r1 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(r1, y1, q1);
+}
 __device__ __forceinline__ bool gw_core_ok(float a) { const float m = fabsf(a); return a == 0.0f || (m >= 0x1p-60f && m < 0x1p60f); }
 
 // MINW: waves per SIMD the register budget is sized for -- 8 (64 VGPRs, 8 spilled) lets two 1024-thread workgroups share a
 // CU at 4K; the 512-thread workgroups of narrower frames run 6 per SIMD without spills (+5 % at 1080p)
-template <int MINW>
+// POW: 2 = exponent 2 compiled in (the widget default: x * x, no mode dispatch per pixel), -1 = A.pow_mode at run time
+template <int MINW, int POW>
 __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id();
@@ -122,6 +140,7 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
     const int iy0 = (int)yn, iy1 = min(iy0 + 1, h - 1);
     const float sxw = (float)(w - 1);
     const bool sxw_ok = w >= 2 && w <= (1 << 20);   // the division core's denominator range
+    const float ysx = sxw_ok ? gw_rcp_refined(sxw) : 0.0f;
     const bool interleaved = A.img_sc == 1 && A.img_sx == 3 && A.out_sc == 1 && A.out_sx == 3;
 
     for (int e = 0; e < A.neyes; e++) {
@@ -147,18 +166,29 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
         const float* const img_row1 = A.image + frame * A.img_sf + iy1 * A.img_sy;
         float* const out_row = A.out + frame * A.out_sf + (y + E.yoff) * A.out_sy + E.xoff * A.out_sx;
         const float* drow = E.depth + ((size_t)frame * h + y) * w;
-        // ---- pass 1: normalised depth, pixel offset, x + offset (:300-328)
-        for (int x = tid; x < w; x += nt) {
-            {
-                float v = drow[x] * scale;
-                if (div255) v = v / 255.0f;
+        // ---- pass 1: normalised depth, pixel offset, x + offset (:300-328); four columns per thread with their loads first
+        const float yr = crange_ok ? gw_rcp_refined(crange) : 0.0f;   // several numerators over one denominator
+        for (int xb = tid; xb < w; xb += 4 * nt) {
+            float dv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) dv[u] = xb + u * nt < w ? drow[xb + u * nt] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int x = xb + u * nt;
+                if (x >= w) continue;
+                float v = dv[u] * scale;
+                if (div255) {
+                    asm volatile("" ::: "memory");   // (a real branch: the division is not worth speculating)
+                    v = v / 255.0f;
+                }
                 const float num = v - dmin;
-                float nrm = (crange_ok && gw_core_ok(num)) ? gw_div_core(num, crange) : num / crange;
+                float nrm = (crange_ok && gw_core_ok(num)) ? gw_div_with(num, crange, yr) : num / crange;
                 nrm = has_range ? nrm : 0.0f;
                 ndn[x] = nrm;
                 const float s = nrm - A.conv32;
                 const float sg = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
-                const float od = sg * torch_pow(fabsf(s), A.pow_mode, A.e32, T);
+                const float ax = fabsf(s);
+                const float od = sg * (POW == 2 ? ax * ax : torch_pow(ax, A.pow_mode, A.e32, T));
                 const float p = od * E.div32 + E.sep32;
                 po[x] = p;
                 D[x] = (float)x + p;
@@ -166,6 +196,7 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
         }
         for (int x = tid; x < w + 8 + 16; x += nt) M[x] = -1;   // (M, W0, W1 are contiguous)
         __syncthreads();
+        if (GW_DEV_IS(51)) continue;
         // ---- the 8 scatter rounds (:330-391).  In round k the pair (i, i+1) targets column clamp(fs_i + k, 0, w-1),
         // fs_i = floor(min(dl, dr)); the HIGHEST pair index targeting a column decides it (sequential scatter_), and only
         // that pair's z-test can change the column.  Columns are independent of each other, and the deciding pair of an
@@ -190,6 +221,7 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
             }
         }
         __syncthreads();
+        if (GW_DEV_IS(52)) continue;
         // Only rounds 0..3 can pass the z-test: a valid proposal needs connected (|po[i+1] - po[i]| < 1.5, so
         // dr - dl < 2.51) and 0 <= frac < 1, i.e. dl <= fs + k < dr -- with fs >= dl - 1 that leaves k <= 3; a
         // deciding pair that is not valid changes nothing (it writes back what it gathered, quirk Q3).
@@ -236,6 +268,7 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
             zb[x] = z;
             sm[x] = src;   // (po's storage: the offsets were last read by the pair pass)
         }
+        if (GW_DEV_IS(53)) { __syncthreads(); continue; }
         // gap fill (:393-438): "left nearest" = prefix max of the filled columns, "right nearest" = the row's RIGHTMOST
         // filled column (quirk Q2)
 #pragma unroll
@@ -251,6 +284,7 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
         }
         __syncthreads();
         block_scan_inclusive(winner, w, -1, OpMax(), ws);
+        if (GW_DEV_IS(54)) { __syncthreads(); continue; }
         for (int x = tid; x < w; x += nt) {
             float s = sm[x];
             if (s < 0.0f) {
@@ -271,7 +305,7 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
             const float pos = fminf(fmaxf(s, 0.0f), sxw);
             // bilinear sample through the grid_sample coordinate round trip (:440-448)
             const float p2 = pos * 2.0f;
-            float gx = ((sxw_ok && gw_core_ok(p2)) ? gw_div_core(p2, sxw) : p2 / sxw) - 1.0f;
+            float gx = ((sxw_ok && gw_core_ok(p2)) ? gw_div_with(p2, sxw, ysx) : p2 / sxw) - 1.0f;
             float xx = (gx + 1.0f) * (sxw / 2.0f);
             xx = fminf(fmaxf(xx, 0.0f), sxw);
             float xw = floorf(xx);
@@ -605,12 +639,16 @@ static int gw_launch(GwArgs& A, hipStream_t stream) {
     if (forced == 21 && A.w <= 4 * 512) threads = 512;
     if (forced == 22 && A.w <= 4 * 256) threads = 256;
     if (forced == 23) threads = 1024;
-    const bool wide = threads > 512;
-    hipError_t e = hipFuncSetAttribute(wide ? (const void*)k_gpuwarp<8> : (const void*)k_gpuwarp<6>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool wide = threads > 512, pow2 = A.pow_mode == 2;
+    const void* fn = wide ? (pow2 ? (const void*)k_gpuwarp<8, 2> : (const void*)k_gpuwarp<8, -1>)
+                          : (pow2 ? (const void*)k_gpuwarp<6, 2> : (const void*)k_gpuwarp<6, -1>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return CS_EHIP;
-    if (wide) hipLaunchKernelGGL(k_gpuwarp<8>, dim3(A.h, A.n), dim3(threads), lds, stream, A);
-    else hipLaunchKernelGGL(k_gpuwarp<6>, dim3(A.h, A.n), dim3(threads), lds, stream, A);
+    const dim3 grid(A.h, A.n), block(threads);
+    if (wide && pow2) hipLaunchKernelGGL((k_gpuwarp<8, 2>), grid, block, lds, stream, A);
+    else if (wide) hipLaunchKernelGGL((k_gpuwarp<8, -1>), grid, block, lds, stream, A);
+    else if (pow2) hipLaunchKernelGGL((k_gpuwarp<6, 2>), grid, block, lds, stream, A);
+    else hipLaunchKernelGGL((k_gpuwarp<6, -1>), grid, block, lds, stream, A);
     return CS_OK;
 }
 
@@ -636,6 +674,7 @@ int launch_gpuwarp_plain(const float* image, const float* depth, int n, int h, i
     A.out = warped;
     A.out_sf = A.img_sf; A.out_sc = A.img_sc; A.out_sy = w; A.out_sx = 1;
     A.mask_u8 = gap_mask;
+    A.dbg = dev_switch(CS_DEBUG_DBG);
     A.mesh = mesh; A.grad_thr = (float)grad_thr; A.keep = (uint8_t*)extra + 256; A.group = n;
     return gw_launch(A, stream);
 }
@@ -680,6 +719,7 @@ int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL,
     A.mask_f32 = mask;
     A.depth_l = depth_l; A.depth_r = depth_r;
     A.noclamp = p->flags & 1;
+    A.dbg = dev_switch(CS_DEBUG_DBG);
     A.mesh = (p->flags & 4) ? 1 : 0; A.grad_thr = 1.5f; A.keep = (uint8_t*)extra + 256; A.group = group;
     return gw_launch(A, stream);
 }
