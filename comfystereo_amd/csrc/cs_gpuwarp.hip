@@ -53,6 +53,7 @@ struct GwArgs {
 };
 
 struct Px3 { float x, y, z; };
+#define GW_WALK 48
 #ifdef CS_DEV
 #define GW_DEV_IS(n) (A.dbg == (n))
 #else
@@ -277,15 +278,28 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
         __syncthreads();   // (every read of ndn is done: its storage takes the scan)
         int rightmost = -1;
         for (int i = 0; i < (nt >> 6); i++) rightmost = max(rightmost, ws[16 + i]);
+        // "left nearest filled" of the gap pixels: gaps are a few percent of a row and a few pixels wide, so every gap pixel
+        // walks left over the (final) source map, at most GW_WALK columns; only when some gap is wider than that does the
+        // workgroup run the prefix-max scan over the whole row (adversarial depth: long runs of disconnected pairs)
+        bool unresolved = false;
         for (int x = tid; x < w; x += nt) {
-            const bool filled = !(sm[x] < 0.0f);
-            winner[x] = filled ? x : -1;
-            if (!filled) flags[x] |= 1u;
+            if (sm[x] < 0.0f) {
+                flags[x] |= 1u;
+                int l = x - 1, steps = 0;
+                while (l >= 0 && sm[l] < 0.0f && steps < GW_WALK) { l--; steps++; }
+                if (l >= 0 && sm[l] < 0.0f) unresolved = true;
+                winner[x] = l;   // (-1: no filled column to the left)
+            }
         }
-        __syncthreads();
-        block_scan_inclusive(winner, w, -1, OpMax(), ws);
+        if (__syncthreads_or(unresolved)) {
+            for (int x = tid; x < w; x += nt) winner[x] = !(sm[x] < 0.0f) ? x : -1;
+            __syncthreads();
+            block_scan_inclusive(winner, w, -1, OpMax(), ws);
+        }
         if (GW_DEV_IS(54)) { __syncthreads(); continue; }
-        for (int x = tid; x < w; x += nt) {
+        // final source position of column x (gap fill :393-438), then the bilinear taps of the grid_sample round trip (:440-448)
+        struct Taps { int ix0, ix1; float nw, ne, sw2, se; };
+        auto taps_of = [&](int x) {
             float s = sm[x];
             if (s < 0.0f) {
                 int left = winner[x];
@@ -303,37 +317,54 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
                 if (hl || hr) s = g;
             }
             const float pos = fminf(fmaxf(s, 0.0f), sxw);
-            // bilinear sample through the grid_sample coordinate round trip (:440-448)
             const float p2 = pos * 2.0f;
             float gx = ((sxw_ok && gw_core_ok(p2)) ? gw_div_with(p2, sxw, ysx) : p2 / sxw) - 1.0f;
             float xx = (gx + 1.0f) * (sxw / 2.0f);
             xx = fminf(fmaxf(xx, 0.0f), sxw);
-            float xw = floorf(xx);
-            float ww = xx - xw, we = 1.0f - ww;
-            int ix0 = (int)xw, ix1 = min(ix0 + 1, w - 1);
-            float nw = wsth * we, ne = wsth * ww, sw2 = wn * we, se = wn * ww;
-            if (interleaved && E.chan_mask == 7) {   // node layout, all channels: 12-byte accesses, 32-bit offsets
-                const char* const r0 = reinterpret_cast<const char*>(img_row0);
-                const char* const r1 = reinterpret_cast<const char*>(img_row1);
-                const uint32_t o0 = 12u * (uint32_t)ix0, o1 = 12u * (uint32_t)ix1;
-                const Px3 a = *reinterpret_cast<const Px3*>(r0 + o0), b = *reinterpret_cast<const Px3*>(r0 + o1),
-                          c2 = *reinterpret_cast<const Px3*>(r1 + o0), d = *reinterpret_cast<const Px3*>(r1 + o1);
+            const float xw = floorf(xx);
+            const float ww = xx - xw, we = 1.0f - ww;
+            Taps t;
+            t.ix0 = (int)xw; t.ix1 = min(t.ix0 + 1, w - 1);
+            t.nw = wsth * we; t.ne = wsth * ww; t.sw2 = wn * we; t.se = wn * ww;
+            return t;
+        };
+        if (interleaved && E.chan_mask == 7) {   // node layout, all channels: 12-byte accesses, 32-bit offsets, two columns
+            const char* const r0 = reinterpret_cast<const char*>(img_row0);   // per step so that eight loads are in flight
+            const char* const r1 = reinterpret_cast<const char*>(img_row1);
+            constexpr bool TWO = MINW < 8;   // (the 64-register instantiation spills with two columns in flight: -3 % at 4K)
+            for (int xb = tid; xb < w; xb += (TWO ? 2 : 1) * nt) {
+                const int x1 = xb + nt;
+                const bool two = TWO && x1 < w;
+                const Taps t0 = taps_of(xb), t1 = taps_of(two ? x1 : xb);
+                const uint32_t a0 = 12u * (uint32_t)t0.ix0, a1 = 12u * (uint32_t)t0.ix1, b0 = 12u * (uint32_t)t1.ix0, b1 = 12u * (uint32_t)t1.ix1;
+                const Px3 pa = *reinterpret_cast<const Px3*>(r0 + a0), pb = *reinterpret_cast<const Px3*>(r0 + a1),
+                          pc = *reinterpret_cast<const Px3*>(r1 + a0), pd = *reinterpret_cast<const Px3*>(r1 + a1);
+                const Px3 qa = *reinterpret_cast<const Px3*>(r0 + b0), qb = *reinterpret_cast<const Px3*>(r0 + b1),
+                          qc = *reinterpret_cast<const Px3*>(r1 + b0), qd = *reinterpret_cast<const Px3*>(r1 + b1);
                 Px3 r;
-                r.x = a.x * nw + b.x * ne + c2.x * sw2 + d.x * se;
-                r.y = a.y * nw + b.y * ne + c2.y * sw2 + d.y * se;
-                r.z = a.z * nw + b.z * ne + c2.z * sw2 + d.z * se;
-                *reinterpret_cast<Px3*>(reinterpret_cast<char*>(out_row) + 12u * (uint32_t)x) = r;
-            } else {
-                const float* p00 = img_row0 + (size_t)ix0 * A.img_sx;
-                const float* p01 = img_row0 + (size_t)ix1 * A.img_sx;
-                const float* p10 = img_row1 + (size_t)ix0 * A.img_sx;
-                const float* p11 = img_row1 + (size_t)ix1 * A.img_sx;
+                r.x = pa.x * t0.nw + pb.x * t0.ne + pc.x * t0.sw2 + pd.x * t0.se;
+                r.y = pa.y * t0.nw + pb.y * t0.ne + pc.y * t0.sw2 + pd.y * t0.se;
+                r.z = pa.z * t0.nw + pb.z * t0.ne + pc.z * t0.sw2 + pd.z * t0.se;
+                *reinterpret_cast<Px3*>(reinterpret_cast<char*>(out_row) + 12u * (uint32_t)xb) = r;
+                if (two) {
+                    r.x = qa.x * t1.nw + qb.x * t1.ne + qc.x * t1.sw2 + qd.x * t1.se;
+                    r.y = qa.y * t1.nw + qb.y * t1.ne + qc.y * t1.sw2 + qd.y * t1.se;
+                    r.z = qa.z * t1.nw + qb.z * t1.ne + qc.z * t1.sw2 + qd.z * t1.se;
+                    *reinterpret_cast<Px3*>(reinterpret_cast<char*>(out_row) + 12u * (uint32_t)x1) = r;
+                }
+            }
+        } else {
+            for (int x = tid; x < w; x += nt) {
+                const Taps t = taps_of(x);
+                const float* p00 = img_row0 + (size_t)t.ix0 * A.img_sx;
+                const float* p01 = img_row0 + (size_t)t.ix1 * A.img_sx;
+                const float* p10 = img_row1 + (size_t)t.ix0 * A.img_sx;
+                const float* p11 = img_row1 + (size_t)t.ix1 * A.img_sx;
                 float* o = out_row + (size_t)x * A.out_sx;
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     if (!(E.chan_mask & (1 << c))) continue;
-                    float v = p00[c * A.img_sc] * nw + p01[c * A.img_sc] * ne + p10[c * A.img_sc] * sw2 + p11[c * A.img_sc] * se;
-                    o[c * A.out_sc] = v;
+                    o[c * A.out_sc] = p00[c * A.img_sc] * t.nw + p01[c * A.img_sc] * t.ne + p10[c * A.img_sc] * t.sw2 + p11[c * A.img_sc] * t.se;
                 }
             }
         }
@@ -350,11 +381,22 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
             const bool div255 = st[E.st_div] != 0;
             const float* drow = E.depth + ((size_t)frame * h + y) * w;
             float* dst = (e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + y) * w) * 3;
-            for (int x = tid; x < w; x += nt) {
-                float v = drow[x] * scale;
-                if (div255) v = v / 255.0f;
-                if (!A.noclamp) v = fminf(fmaxf(v, 0.0f), 1.0f);
-                *reinterpret_cast<Px3*>(dst + 3 * x) = Px3{v, v, v};
+            for (int xb = tid; xb < w; xb += 4 * nt) {   // (loads first; /255 behind a real branch)
+                float dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) dv[u] = xb + u * nt < w ? drow[xb + u * nt] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int x = xb + u * nt;
+                    if (x >= w) continue;
+                    float v = dv[u] * scale;
+                    if (div255) {
+                        asm volatile("" ::: "memory");
+                        v = v / 255.0f;
+                    }
+                    if (!A.noclamp) v = fminf(fmaxf(v, 0.0f), 1.0f);
+                    *reinterpret_cast<Px3*>(dst + 3 * x) = Px3{v, v, v};
+                }
             }
         }
     }
