@@ -64,3 +64,48 @@ def test_fuzz_all_fills(engine, seed):
                                                  fill, conv).cpu().numpy()
             bad = np.argwhere(got != want)
             assert bad.size == 0, (seed, fill, img.shape, div, sep, e, conv, len(bad), bad[:3].tolist())
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_dialect_d64(engine, seed):
+    """The same corner-case generator under dialect D64 (float64 disparity chain + int64 pixel sums): HIP vs the oracle in the
+    same dialect, bit for bit, for the techniques that have the instantiation."""
+    rng = np.random.default_rng(12000 + seed)
+    oracle.set_dialect("D64")
+    try:
+        for _ in range(12):
+            img, depth, div, sep, e, conv = make_case(rng)
+            for fill in ("none", "naive", "naive_interpolating", "inverse"):
+                want = oracle.apply_stereo_divergence(img, depth, div, sep, e, fill, conv)
+                got = engine.apply_stereo_divergence(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda(), div, sep, e,
+                                                     fill, conv, dialect="D64").cpu().numpy()
+                bad = np.argwhere(got != want)
+                assert bad.size == 0, (seed, fill, img.shape, div, sep, e, conv, len(bad), bad[:3].tolist())
+    finally:
+        oracle.set_dialect("D32")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_mesh_warp(engine, seed):
+    """forward_warp_mesh on the same hostile depth maps (plateaus, spikes, noise), batches of 1-3 frames (the any-frame
+    culling rule), both signs of the divergence: HIP vs its specification in the oracle."""
+    rng = np.random.default_rng(15000 + seed)
+    for _ in range(6):
+        b = int(rng.integers(1, 4))
+        cases = [make_case(rng) for _ in range(b)]
+        h = max(2, min(c[1].shape[0] for c in cases) + 1)
+        w = min(c[1].shape[1] for c in cases)
+        dep = np.stack([np.resize(c[1][:, :w], (h, w)) for c in cases]).astype(np.float32)
+        img = rng.random((b, 3, h, w), dtype=np.float32)
+        _, _, div, sep, e, conv = cases[0]
+        div_px, sep_px = div / 100.0 * w, sep / 100.0 * w
+        want, wmask = oracle.forward_warp_mesh(img, dep, div_px, sep_px, e, conv)
+        got, gmask = engine.forward_warp_mesh(torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), div_px, sep_px, e, conv)
+        gmask = gmask.cpu().numpy()
+        # (a pixel centre within rounding of a triangle edge may be covered on one side only: float32 spans on both sides,
+        # but the exponent path differs -- torch.pow semantics on the device, libm on the host -- for e not in {0.5, 1, 2})
+        tol = 2e-3 if e in (0.5, 1.0, 2.0) else 2e-2
+        assert (gmask != wmask).mean() <= tol, (seed, img.shape, div, sep, e, conv, float((gmask != wmask).mean()))
+        same = (gmask == wmask)[:, None].repeat(3, 1)
+        diff = np.abs(got.cpu().numpy() - want)
+        assert (diff[same] > 1e-5).mean() <= 5 * tol, (seed, img.shape, float(diff[same].max()))
