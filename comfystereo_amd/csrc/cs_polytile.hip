@@ -131,8 +131,15 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
     const int tiles = (hot_w + PT_T - 1) / PT_T;
     // (eye = slowest grid dimension: pairing the two eyes of a tile on one XCD so that the second finds the image row in
     // that L2 was measured 13 % SLOWER -- the eyes' output streams then hit the same HBM channels at the same time)
-    const int bx = blockIdx.x, eyei = hot_single >= 0 ? hot_single : (int)blockIdx.z;
-    const int tile = bx % tiles, row = bx / tiles, frame = blockIdx.y;
+    // grid = (tiles x 8 rows, rows / 8, frames x eyes), decoded with shifts: no integer division (~30 scalar instructions),
+    // and all tiles of a row run on one XCD (workgroup b -> XCD b % 8), so the halo columns neighbouring tiles share come
+    // from that L2 (cs_polypoint.hip has the measurements)
+    const int bx = blockIdx.x;
+    const int row = blockIdx.y * 8 + (bx & 7);
+    if (row >= hot_h) return;
+    const int tile = bx >> 3;
+    const int eyei = hot_single >= 0 ? hot_single : (int)(blockIdx.z & 1);
+    const int frame = hot_single >= 0 ? (int)blockIdx.z : (int)(blockIdx.z >> 1);
     // (the eye's arguments are selected field by field: a dynamically indexed kernel-argument array costs a second,
     // dependent scalar-memory round trip before the first global load can be issued)
     EyeArgs E;
@@ -194,7 +201,10 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
     const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
     const float dmin = eye_on ? csm::ord2f(st[E.st_min]) : 0.0f, dmax = eye_on ? csm::ord2f(st[E.st_max]) : 0.0f;
 
-    {
+    // the powf tables go to LDS only when every point needs the clone (exponents other than 1 and 2); the 0.4 % risky
+    // squares read them from constant memory (cs_polypoint.hip: +2 % / +6 %)
+    const bool all_powf = A.dbg == 17 || !(A.e32 == 2.0f || A.e32 == 1.0f);
+    if (all_powf) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_pt_powf_tables);
         uint32_t* dst = reinterpret_cast<uint32_t*>(tabs);
         for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += PT_THREADS) dst[i] = src[i];
@@ -272,7 +282,7 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
         // |nd| ** exponent, bit-exact with glibc's powf.  Exponents 2.0 (widget default) and 1.0 take the shortcuts of
         // cs_math.h (square_or_flag): the 0.4 % "risky" arguments of the square go through the full routine, batched per
         // wave after the loop.
-        const int pow_mode = A.dbg == 17 ? 0 : (A.e32 == 2.0f ? 2 : (A.e32 == 1.0f ? 1 : 0));
+        const int pow_mode = all_powf ? 0 : (A.e32 == 2.0f ? 2 : 1);
         auto square = [&](float ax, bool& risky) { return csm::square_or_flag(ax, risky); };
         if (pow_mode == 0) {
 #pragma unroll
@@ -298,15 +308,18 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
                     risk |= r ? 1u << k : 0u;
                 }
             }
-            while (__any(risk != 0u)) {  // the full routine for the risky arguments: one pass per wave, rarely two
-                float xin = 1.0f;
-                int sel = -1;
+            if (__any(risk != 0u)) {  // the full routine for the risky arguments: one pass per wave, rarely two (behind its own
+                asm volatile("" ::: "memory");   // branch: its constant set-up is otherwise hoisted in front of the test)
+                do {
+                    float xin = 1.0f;
+                    int sel = -1;
 #pragma unroll
-                for (int k = PT_PF - 1; k >= 0; k--) if (risk & (1u << k)) { xin = axs[k]; sel = k; }
-                const float r = csm::powf_exact_simt(xin, A.e32, tabs);
+                    for (int k = PT_PF - 1; k >= 0; k--) if (risk & (1u << k)) { xin = axs[k]; sel = k; }
+                    const float r = csm::powf_exact_simt(xin, A.e32, &c_pt_powf_tables);
 #pragma unroll
-                for (int k = 0; k < PT_PF; k++) if (sel == k) pw[k] = r;
-                risk &= risk - 1u;
+                    for (int k = 0; k < PT_PF; k++) if (sel == k) pw[k] = r;
+                    risk &= risk - 1u;
+                } while (__any(risk != 0u));
             }
 #pragma unroll
             for (int k = 0; k < PT_PF; k++) {
@@ -320,7 +333,7 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
             bool r = false;
             float pwv = pow_mode == 1 ? ax : (pow_mode == 2 ? square(ax, r) : 0.0f);
             if (pow_mode == 0 || __any(r)) {
-                const float full = csm::powf_exact_simt(ax, A.e32, tabs);
+                const float full = pow_mode == 0 ? csm::powf_exact_simt(ax, A.e32, tabs) : csm::powf_exact_simt(ax, A.e32, &c_pt_powf_tables);
                 pwv = (pow_mode == 0 || r) ? full : pwv;
             }
             post(j, sgn, pwv);
@@ -901,7 +914,7 @@ hipError_t launch_polytile(int sharp, const RowArgs& R, int S, uint8_t* rowflag,
     A.rowflag = rowflag;
     A.dbg = R.dbg;
     const int tiles = (A.w + PT_T - 1) / PT_T;
-    dim3 grid(tiles * A.h, A.n, A.single >= 0 ? 1 : 2), block(PT_THREADS);
+    dim3 grid(tiles * 8, (A.h + 7) / 8, A.single >= 0 ? A.n : 2 * A.n), block(PT_THREADS);
     const int variant = dev_switch(CS_DEBUG_PT_VARIANT);
 #define PT_LAUNCH(SH, KP, KS, MW)                                                                                   \
     {                                                                                                               \
