@@ -342,10 +342,23 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         if (e != hipSuccess) return fail_hip(e, "flagged-row collection");
         A.row_list = list; A.row_count = count;
     }
-    if ((fill == CS_FILL_NONE || fill == CS_FILL_INVERSE) && !dev_switch(CS_DEBUG_NO_TILE)) {   // the halo-tile kernel where it applies
-        hipError_t e = launch_fwdtile(fill, A, halo, stream);
-        if (e == hipSuccess) return CS_OK;
-        if (e != hipErrorNotSupported) return fail_hip(e, "forward tile kernel launch");
+    if ((fill == CS_FILL_NONE || fill == CS_FILL_INVERSE || fill == CS_FILL_NAIVE) && !dev_switch(CS_DEBUG_NO_TILE)) {
+        // the halo-tile kernel where it applies; 'naive' hands the rows it cannot decide to the row kernel
+        const bool flagging = fill == CS_FILL_NAIVE && rowflag;
+        const size_t rows = (size_t)A.n * A.h;
+        if (flagging) {
+            hipError_t e = hipMemsetAsync(rowflag, 0, al256(rows) + 256, stream);
+            if (e != hipSuccess) return fail_hip(e, "rowflag memset");
+        }
+        hipError_t e = launch_fwdtile(fill, A, halo, flagging ? rowflag : nullptr, stream);
+        if (e == hipSuccess) {
+            if (!flagging) return CS_OK;
+            uint32_t* count = (uint32_t*)(rowflag + al256(rows));
+            uint32_t* list = count + 64;
+            e = launch_collect_rows(rowflag, (int)rows, count, list, stream);
+            if (e != hipSuccess) return fail_hip(e, "flagged-row collection");
+            A.row_list = list; A.row_count = count;
+        } else if (e != hipErrorNotSupported) return fail_hip(e, "forward tile kernel launch");
     }
     hipError_t e = launch_rowwarp(fill, A, threads_for(fill, A.w), stream);
     if (e != hipSuccess) return fail_hip(e, "row kernel launch");

@@ -1,6 +1,7 @@
 // cs_fwdtile.hip -- fill techniques 'none' (reference stereoimage_generation.py:1850-1867, the forward map of
-// apply_stereo_divergence_naive) and 'inverse' (:1715-1737, the z-buffered two-column splat) as a halo-tile kernel: the
-// node path's float32 image in, both eyes of a tile out.
+// apply_stereo_divergence_naive), 'naive' (:1893-1908, holes take the nearest filled pixel, right before left) and
+// 'inverse' (:1715-1737, the z-buffered two-column splat) as a halo-tile kernel: the node path's float32 image in, both
+// eyes of a tile out.
 //
 // The general row kernel (cs_rowwarp.hip) keeps a whole row of one frame in LDS (60 KB at 4K: two workgroups per CU,
 // five barriers, every pixel through the full powf clone).  The forward map only moves a pixel by int(offset) columns,
@@ -11,7 +12,10 @@
 //     the highest (divergence < 0) or lowest source column per destination -> LDS atomicMax / atomicMin ('none'); the
 //     z-buffer with strict '>' and ascending x == the maximum over (closeness, -x) of the two columns a pixel lands on
 //     -> 64-bit LDS atomicMax ('inverse'),
-//   * every output column looks up its winner's colour (0 = hole) and keeps it in a register,
+//   * every output column looks up its winner's colour (0 = hole) and keeps it in a register; 'naive': the forward map is
+//     computed for R more columns on either side of the tile, the filled flags become bit rows (wave ballots), and a hole
+//     finds its nearest filled neighbours with clz / ctz.  A hole that the window cannot decide (nothing filled within
+//     its reach although the search limit |int(div_px)| + 1 goes further) flags the ROW for the row kernel,
 // then the eyes are written straight into their slots of the SBS / top-bottom layout or composed into the anaglyph
 // (:1996-2010), together with the no-fill mask (GenerateStereo.py:355-361) and both depth-map outputs (:1511-1516).
 // Dialect D32 only (other dialects, uint8 images and anaglyph-free single calls of apply_stereo_divergence take the row
@@ -26,6 +30,8 @@ __constant__ csm::PowfTables c_fw_powf_tables = CS_POWF_TABLES_INIT;
 
 struct FwdTileArgs {
     int n, h, w, S, T;
+    int R;                // 'naive': columns of the forward map computed beyond either end of the tile
+    uint8_t* rowflag;     // 'naive': rows handed to the row kernel
     const float* image;
     const uint32_t* stats;
     int scale_from_stats;
@@ -52,12 +58,15 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
     const int tile = xi >> 3, frame = blockIdx.z;
     const int w = A.w, h = A.h, T = A.T;
     const int o0 = tile * T, wt = min(T, w - o0);
-    const int s0 = max(0, o0 - A.S), s1 = min(w, o0 + wt + A.S), ns = s1 - s0;
+    const int c0 = max(0, o0 - A.R), c1 = min(w, o0 + wt + A.R), nwin = c1 - c0;   // columns of the forward map (the tile + R)
+    const int s0 = max(0, c0 - A.S), s1 = min(w, c1 + A.S), ns = s1 - s0;
     constexpr int NPT = NT * SLOTS;
     uint32_t* img = (uint32_t*)smem;        // [NPT] colour codes r | g << 8 | b << 16 of source column s0 + j
-    int* winner = (int*)(img + NPT);        // [T] winning source column (local index) per output column of the tile ('none')
+    int* winner = (int*)(img + NPT);        // [nwin] winning source column (local index) per column of the window ('none', 'naive')
     unsigned long long* key = (unsigned long long*)(img + NPT);   // [T] closeness << 32 | ~source index ('inverse')
     const unsigned long long key_init = ((unsigned long long)csm::f2ord(-1.0f) << 32) | 0xffffffffull;
+    unsigned long long* fm = key + NPT;     // [NPT / 64] filled flags of the window as bit rows ('naive')
+    bool giveup = false;
 
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
     const uint32_t rowpix = ((uint32_t)frame * (uint32_t)h + (uint32_t)row) * (uint32_t)w;
@@ -101,12 +110,10 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
             continue;
         }
         const int init = E.asc ? -1 : 0x7fffffff;
-#pragma unroll
-        for (int m = 0; m < OUTS; m++)
-            if (tid + m * NT < T) {
-                if (FILL == CS_FILL_INVERSE) key[tid + m * NT] = key_init;
-                else winner[tid + m * NT] = init;
-            }
+        for (int p = tid; p < nwin; p += NT) {
+            if (FILL == CS_FILL_INVERSE) key[p] = key_init;
+            else winner[p] = init;
+        }
         __syncthreads();   // (also: img complete)
         const float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
         const bool flat = dmax == dmin;
@@ -153,14 +160,23 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
                 const float off = ((sg * pw[k]) * E.div32) + E.sep32;                  // (:1865)
                 // int(): truncation toward zero; keep the conversion defined for absurd offsets
                 const int io = off >= 2147483520.0f ? 0x7fffff00 : (off <= -2147483520.0f ? -0x7fffff00 : (int)off);
-                const long long q = (long long)(s0 + j - o0) + io;
-                if (j < ns && q >= 0 && q < wt) {
+                const long long q = (long long)(s0 + j - c0) + io;
+                if (j < ns && q >= 0 && q < nwin) {
                     if (E.asc) atomicMax(&winner[(int)q], j);
                     else atomicMin(&winner[(int)q], j);
                 }
             }
         }
         __syncthreads();
+        if (FILL == CS_FILL_NAIVE) {
+            // filled flags of the window as bit rows: one ballot per 64 columns
+            for (int pb = (tid >> 6) * 64; pb < nwin; pb += NT) {
+                const int p = pb + (tid & 63);
+                const unsigned long long bits = __ballot(p < nwin && winner[p] != init);
+                if ((tid & 63) == 0) fm[pb >> 6] = bits;
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int m = 0; m < OUTS; m++) {
             const int q = tid + m * NT;
@@ -169,13 +185,47 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
                     const unsigned long long kk = key[q];
                     res[e][m] = kk > key_init ? img[0xffffffffu - (unsigned)(kk & 0xffffffffull)] : 0u;
                 } else {
-                    const int s = winner[q];
+                    const int p = q + (o0 - c0);
+                    int s = winner[p];
+                    if (FILL == CS_FILL_NAIVE && s == init) {
+                        // nearest filled column to the right (dr) and to the left (dl) inside the window, BIG: none there
+                        const int BIG = 1 << 29, nw = (nwin + 63) >> 6;
+                        int dr = BIG, dl = BIG;
+                        {
+                            int wi = (p + 1) >> 6;
+                            unsigned long long cur = wi < nw ? fm[wi] & (~0ull << ((p + 1) & 63)) : 0ull;
+                            while (wi < nw) {
+                                if (cur) { dr = wi * 64 + __ffsll((long long)cur) - 1 - p; break; }
+                                if (++wi < nw) cur = fm[wi];
+                            }
+                        }
+                        if (p > 0) {
+                            int wi = (p - 1) >> 6;
+                            unsigned long long cur = fm[wi] & (~0ull >> (63 - ((p - 1) & 63)));
+                            while (true) {
+                                if (cur) { dl = p - (wi * 64 + 63 - __clzll((long long)cur)); break; }
+                                if (--wi < 0) break;
+                                cur = fm[wi];
+                            }
+                        }
+                        // (:1899-1907) for o = 1 .. lim - 1: the right neighbour at distance o, else the left one.  What the window
+                        // did not examine -- beyond its ends, unless they are the frame's -- must not be able to change the answer.
+                        const int lim1 = E.naive_lim - 1;
+                        const int cov_r = c1 == w ? BIG : nwin - 1 - p, cov_l = c0 == 0 ? BIG : p;
+                        const int a = dr <= lim1 ? dr : BIG, b = dl <= lim1 ? dl : BIG;
+                        if ((dr == BIG && cov_r < min(b, lim1)) || (dl == BIG && cov_l < min(a - 1, lim1))) giveup = true;
+                        int sp = -1;
+                        if (a <= b) { if (a != BIG) sp = p + a; }
+                        else sp = p - b;
+                        s = sp >= 0 ? winner[sp] : init;
+                    }
                     res[e][m] = s != init ? img[s] : 0u;
                 }
             }
         }
         __syncthreads();   // (winner is re-initialised for the next eye)
     }
+    if (FILL == CS_FILL_NAIVE && giveup) A.rowflag[(uint32_t)frame * (uint32_t)h + (uint32_t)row] = 1;   // the row kernel redoes it
     // ---- outputs: eyes into their slots / the anaglyph composition, the no-fill mask, both depth-map outputs
     auto store = [&](int e, int q, uint32_t c) {
         const EyeArgs& E = A.eye[e];
@@ -214,21 +264,30 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
 // Largest halo the tile kernel takes (beyond it: the row kernel)
 int fwdtile_max_halo() { return (256 * 3 - 64) / 2; }
 
-// `none` / `inverse` through the tile kernel.  Returns hipErrorNotSupported when the call is not one of its cases (the caller then
+// `none` / `naive` / `inverse` through the tile kernel (`naive`: rows it flags in `rowflag` must be redone by the row kernel).  Returns hipErrorNotSupported when the call is not one of its cases (the caller then
 // launches the row kernel).
-hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, hipStream_t stream) {
-    const int S = S0 + (fill == CS_FILL_INVERSE ? 2 : 0);   // (the splat also touches the column right of floor(dest))
+hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, uint8_t* rowflag, hipStream_t stream) {
     constexpr int NT = 256, SLOTS = 3;
-    if (fill != CS_FILL_NONE && fill != CS_FILL_INVERSE) return hipErrorNotSupported;
+    if (fill != CS_FILL_NONE && fill != CS_FILL_INVERSE && fill != CS_FILL_NAIVE) return hipErrorNotSupported;
     if (!R.image_f32 || R.out_u8 || R.d64 || R.neyes != 2 || !R.depth_l || !R.depth_r || R.row_list) return hipErrorNotSupported;
+    const int S = S0 + (fill == CS_FILL_INVERSE ? 2 : 0);   // (the splat also touches the column right of floor(dest))
     if (S > fwdtile_max_halo()) return hipErrorNotSupported;
     if ((size_t)R.n * R.h * R.w >= (1ull << 31) || (size_t)R.n * R.out_h * R.out_w >= (1ull << 31) || R.n > 65535) return hipErrorNotSupported;
     FwdTileArgs A;
     A.n = R.n; A.h = R.h; A.w = R.w; A.S = S;
-    int tmax = (NT * SLOTS - 2 * S) & ~3;
+    // 'naive': the source of column c lands within S of it, so a hole's nearest filled pixel is within S + 1 -- except next
+    // to the frame borders, where the kernel flags what it cannot decide
+    A.R = 0; A.rowflag = rowflag;
+    if (fill == CS_FILL_NAIVE) {
+        if (!rowflag) return hipErrorNotSupported;
+        const int lim1 = max(R.eye[0].naive_lim, R.eye[1].naive_lim) - 1;
+        A.R = min(S + 1, lim1 > 0 ? lim1 : 0);
+    }
+    int tmax = (NT * SLOTS - 2 * S - 2 * A.R) & ~3;
+    if (tmax < 128) return hipErrorNotSupported;
     const int tiles = (R.w + tmax - 1) / tmax;
     A.T = ((R.w + tiles - 1) / tiles + 3) & ~3;
-    if (A.T + 2 * S > NT * SLOTS) return hipErrorNotSupported;
+    if (A.T + 2 * S + 2 * A.R > NT * SLOTS) return hipErrorNotSupported;
     A.image = R.image_f32; A.stats = R.stats; A.scale_from_stats = R.scale_from_stats;
     A.e32 = R.e32; A.conv32 = R.conv32;
     A.eye[0] = R.eye[0]; A.eye[1] = R.eye[1];
@@ -237,9 +296,11 @@ hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, hipStream_t stream
     A.out_h = R.out_h; A.out_w = R.out_w;
     A.dbg = R.dbg;
     const int ntiles = (R.w + A.T - 1) / A.T;
-    const size_t lds = (size_t)NT * SLOTS * 4 + (size_t)A.T * 8 + 64;
-    if (fill == CS_FILL_INVERSE) hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_INVERSE>), dim3(ntiles * 8, (R.h + 7) / 8, R.n), dim3(NT), lds, stream, A);
-    else hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_NONE>), dim3(ntiles * 8, (R.h + 7) / 8, R.n), dim3(NT), lds, stream, A);
+    const size_t lds = (size_t)NT * SLOTS * 4 + (size_t)NT * SLOTS * 8 + (size_t)(NT * SLOTS / 64) * 8 + 64;
+    const dim3 grid(ntiles * 8, (R.h + 7) / 8, R.n), block(NT);
+    if (fill == CS_FILL_INVERSE) hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_INVERSE>), grid, block, lds, stream, A);
+    else if (fill == CS_FILL_NAIVE) hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_NAIVE>), grid, block, lds, stream, A);
+    else hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_NONE>), grid, block, lds, stream, A);
     return hipGetLastError();
 }
 

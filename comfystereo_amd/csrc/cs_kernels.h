@@ -69,8 +69,9 @@ size_t rowwarp_lds_bytes(int fill, int w, int anaglyph = 1);   // anaglyph modes
 hipError_t launch_polytile(int sharp, const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream);
 int polytile_max_halo();
 
-// cs_fwdtile.hip: fills 'none' / 'inverse' as a halo-tile kernel (node path); hipErrorNotSupported: not one of its cases
-hipError_t launch_fwdtile(int fill, const RowArgs& A, int S, hipStream_t stream);
+// cs_fwdtile.hip: fills 'none' / 'naive' / 'inverse' as a halo-tile kernel (node path); hipErrorNotSupported: not one of its
+// cases.  'naive' flags the rows it cannot finish in `rowflag` (zeroed by the caller) for the row kernel.
+hipError_t launch_fwdtile(int fill, const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream);
 int fwdtile_max_halo();
 
 // cs_polypoint.hip: second generation of the tiled path (polylines_soft): one lane per polyline point
