@@ -489,6 +489,124 @@ __device__ int poly_sequential(const Poly& P, const Lds& L, int csg_cap_ref, con
     return 0;
 }
 
+// The same replay by a whole WAVE.  The sweep itself is sequential (the active list carries its order from column to
+// column), but the work inside a step is not: with noisy depth the list holds tens to hundreds of segments and the single
+// lane spends its time in dependent LDS reads over it (4K, random 8-bit depth: 0.8 frames/s).  Here the 64 lanes share
+// every step:
+//   * removal.  The reference's scan `if dead(csg[ci]): csg[ci] = csg[end-1]; end -= 1 else ci += 1` has a closed form:
+//     survivors in the first (end - removed) slots stay where they are, and the dead slots among those are filled, in
+//     ascending order, by the survivors of the tail taken from the END backwards (a dead element moved into a hole is
+//     re-tested and dropped again).  Dead flags by ballot, ranks by population counts, one LDS hand-over.
+//   * selection: `best < closeness` with a strict compare keeps the FIRST maximum -> wave maximum, lowest lane that holds it.
+// Returns 0, -1 (the reference's list would overflow) or -2 (more holes than the scratch holds: the single-lane replay runs).
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <class Emit>
+__device__ int poly_sequential_wave(const Poly& P, const Lds& L, int csg_cap_ref, const Emit& emit, const float* pxs) {
+    const int lane = threadIdx.x & 63;
+    const int w = P.w, sg_end = P.npt - 1;
+    uint16_t* csg = P.entries;
+    unsigned long long* deadw = (unsigned long long*)P.longs;   // [64] dead flags of list chunk ch (P.longs is idle here)
+    uint16_t* holepos = P.longs + 256;                          // [768] dead slots of the surviving prefix, ascending
+    const int cap_ref = min(csg_cap_ref, P.cap), cap = min(cap_ref, 64 * 64);
+    // `pxs` (soft only: npt = w + 2 floats fit the idle bin / segment offset arrays): x of every point, filled by the caller --
+    // one LDS read instead of coord_d + arithmetic on every use
+    auto PX = [&](int o) { return pxs ? pxs[o] : poly_x(P, o); };
+    int csg_end = 0, sg_pointer = 0, pt_i = 0;
+    for (int col = 0; col < w; col++) {
+        float color[3] = {0.5f, 0.5f, 0.5f};
+        while (PX(P.perm[pt_i]) < (float)col) pt_i++;
+        pt_i--;
+        while (PX(P.perm[pt_i]) < (float)(col + 1)) {
+            const SubInt s = poly_subinterval(col, PX(P.perm[pt_i]), PX(P.perm[pt_i + 1]));
+            while (sg_pointer < sg_end && PX(P.perm[sg_pointer]) < s.center) {
+                if (csg_end >= cap) return cap == cap_ref ? -1 : -2;
+                if (lane == 0) csg[csg_end] = P.perm[sg_pointer];
+                csg_end++; sg_pointer++;
+            }
+            wave_lds_sync();
+            // ---- removal
+            const int n = csg_end, nch = (n + 63) >> 6;
+            int removed = 0;
+            for (int ch = 0; ch < nch; ch++) {
+                const int i = ch * 64 + lane;
+                const bool dead = i < n && PX((int)csg[i] + 1) < s.center;
+                const unsigned long long m = __ballot(dead);
+                if (lane == 0) deadw[ch] = m;
+                removed += __popcll(m);
+            }
+            if (removed) {
+                wave_lds_sync();
+                const int ns = n - removed;
+                int before = 0, nholes = 0;   // dead slots among the first ns, in ascending order
+                for (int ch = 0; ch * 64 < ns; ch++) {
+                    const unsigned long long m = deadw[ch];
+                    const int i = ch * 64 + lane;
+                    const bool hole = i < ns && ((m >> lane) & 1ull);
+                    const int r = before + __popcll(m & ((1ull << lane) - 1ull));
+                    if (hole) { if (r < 768) holepos[r] = (uint16_t)i; }
+                    const unsigned long long inpref = (ch + 1) * 64 <= ns ? ~0ull : ((1ull << (ns - ch * 64)) - 1ull);
+                    before += __popcll(m & inpref);
+                }
+                nholes = before;
+                if (nholes > 768) return -2;
+                wave_lds_sync();
+                int after = 0;   // survivors behind the current chunk (towards the end of the list)
+                for (int ch = nch - 1; ch >= 0 && ch * 64 + 63 >= ns; ch--) {
+                    const unsigned long long m = deadw[ch];
+                    const int i = ch * 64 + lane;
+                    const unsigned long long valid = (ch + 1) * 64 <= n ? ~0ull : ((1ull << (n - ch * 64)) - 1ull);
+                    const unsigned long long tail = ch * 64 >= ns ? ~0ull : ~((1ull << (ns - ch * 64)) - 1ull);
+                    const unsigned long long surv = ~m & valid & tail;
+                    const bool mine = (surv >> lane) & 1ull;
+                    const int r = after + __popcll(lane == 63 ? 0ull : (surv >> (lane + 1)));
+                    if (mine) csg[holepos[r]] = csg[i];
+                    after += __popcll(surv);
+                }
+                csg_end = ns;
+                wave_lds_sync();
+            }
+            // ---- selection: the reference's scan over the list, with its strict compare, over the lanes that can still win
+            int best = 0;
+            if (csg_end != 1) {
+                float bc = (float)(-1e-7);
+                for (int ch = 0; ch * 64 < csg_end; ch++) {
+                    const int i = ch * 64 + lane;
+                    float cl = -INFINITY;
+                    if (i < csg_end) {
+                        const int o = csg[i];
+                        const float x0 = PX(o), x1 = PX(o + 1);
+                        const float ip_k = (s.center - x0) / (x1 - x0);
+                        const float c = (1.0f - ip_k) * poly_z(P, o) + ip_k * poly_z(P, o + 1);
+                        if (0.0f < ip_k && ip_k < 1.0f) cl = c;
+                    }
+                    unsigned long long m = __ballot(bc < cl);
+                    if (__popcll(m) <= 6) {
+                        while (m) {   // (usually one to three candidates: a scalar pass over them beats six cross-lane steps)
+                            const int b = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cl), b));
+                            if (bc < v) { bc = v; best = ch * 64 + b; }
+                        }
+                    } else {          // wave maximum, lowest lane that holds it (strict compare == first maximum)
+                        float mx = cl;
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+                        if (bc < mx) {
+                            bc = mx;
+                            best = ch * 64 + __ffsll((long long)__ballot(cl == mx)) - 1;
+                        }
+                    }
+                }
+            }
+            // csg_end == 0 cannot happen (the polyline is connected from -w to 2w); slot 0 then still holds a valid (stale) id
+            poly_accumulate(P, L.img, csg[best], s.center, s.sig64, s.sig_d, s.sig_f, color);
+            pt_i++;
+        }
+        if (lane == 0) emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
+    }
+    return 0;
+}
+
 // rasterise the forward segments into per-pixel lists; PASS 0 counts, PASS 1 fills
 template <int PASS>
 __device__ __forceinline__ void poly_seg_pixels(const Poly& P, int o, int& p0, int& p1) {
@@ -641,10 +759,18 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
     }
     __syncthreads();
     if (overflow || *flag_hazard) {
-        // order-dependent row: replay the reference sweep literally on one lane
-        if (tid == 0) {
-            int rc = poly_sequential(P, L, E.csg_cap, emit);
-            if (stats_rw) {
+        // order-dependent row: replay the reference sweep literally -- by the first wave (its 64 lanes share the list work
+        // of every step), or by one lane when the wave form runs out of scratch
+        float* pxs = nullptr;
+        if (!SHARP && (size_t)((char*)P.entries - (char*)P.binoff) >= 4 * (size_t)npt) {   // (bin / segment offsets are dead here)
+            pxs = (float*)P.binoff;
+            for (int o = tid; o < npt; o += nt) pxs[o] = poly_x(P, o);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int rc = dbg == 26 ? -2 : poly_sequential_wave(P, L, E.csg_cap, emit, pxs);
+            if (rc == -2 && tid == 0) rc = poly_sequential(P, L, E.csg_cap, emit);
+            if (stats_rw && tid == 0) {
                 atomicAdd(&stats_rw[ST_FALLBACK_ROWS], 1u);
                 if (rc) atomicOr(&stats_rw[ST_ERROR], 1u);
             }

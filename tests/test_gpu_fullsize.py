@@ -223,3 +223,21 @@ def test_too_wide_frames_are_refused_not_truncated(engine):
     depth = synth.depth_batch("stepped", 1, h, w, channels=3)
     with pytest.raises(RuntimeError, match="too wide"):
         gen(engine, img, depth, "polylines_sharp", "left-right", blur=False, div=3.0)
+
+
+def test_order_dependent_rows_take_the_wave_replay(engine):
+    """Noise depth on 8-bit levels ties everywhere (equal |disparity| on overlapping layers): every row is order-dependent
+    and goes through the sequential replay of the reference's active list -- done by a whole wave since round 2.  Bit-exact
+    against the oracle, at a width that spans several tiles, both polylines variants, plus the single-lane form (the wave
+    form's fallback) through its development switch where the build allows it."""
+    h, w = 24, 1540
+    img = synth.image_f32(1, h, w, seed=12)
+    depth = synth.depth_batch("random8", 1, h, w, channels=3)
+    for fill, ui in (("polylines_soft", "Fill - Polylines Soft"), ("polylines_sharp", "Fill - Polylines Sharp")):
+        want = node_oracle.generate(img, depth, 6.0, 0.0, "left-right", 0.0, 0.5, 2.0, ui, 20.0, 20.0, False, batch_size=12)
+        p = engine.make_params(1, h, w, h, w, 3, fill, "left-right", 6.0, 0.0, 0.0, 0.5, 2.0, False, 20.0, 20.0, 1.0, 0, 12)
+        plan = engine.Plan(p, torch.device("cuda"))
+        got = [t.cpu().numpy() for t in plan.run(cuda(img), cuda(depth))]
+        assert int(plan.stats()[:, 10].sum()) > 0   # rows replayed sequentially
+        for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+            assert np.array_equal(g, w_), (fill, name)
