@@ -425,14 +425,31 @@ __device__ void mesh_stage_row(const GwArgs& A, const GwEye& E, const uint32_t* 
     const float crange = fmaxf(range, (float)1e-6);
     const bool has_range = range > (float)1e-6;
     const float* drow = E.depth + ((size_t)frame * A.h + y) * w;
-    for (int x = threadIdx.x; x < w; x += blockDim.x) {
-        float v = drow[x] * scale;
-        if (div255) v = v / 255.0f;
-        const float nrm = has_range ? (v - dmin) / crange : 0.0f;
-        nd[x] = nrm;
-        const float s = nrm - A.conv32;
-        const float sg = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
-        po[x] = (sg * torch_pow(fabsf(s), A.pow_mode, A.e32, T)) * E.div32 + E.sep32;
+    const bool crange_ok = crange < 0x1p40f;
+    const float yr = crange_ok ? gw_rcp_refined(crange) : 0.0f;
+    const int nt = blockDim.x;
+    for (int xb = threadIdx.x; xb < w; xb += 4 * nt) {   // (four columns per thread with their loads first, as in k_gpuwarp)
+        float dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) dv[u] = xb + u * nt < w ? drow[xb + u * nt] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int x = xb + u * nt;
+            if (x >= w) continue;
+            float v = dv[u] * scale;
+            if (div255) {
+                asm volatile("" ::: "memory");
+                v = v / 255.0f;
+            }
+            const float num = v - dmin;
+            float nrm = (crange_ok && gw_core_ok(num)) ? gw_div_with(num, crange, yr) : num / crange;
+            nrm = has_range ? nrm : 0.0f;
+            nd[x] = nrm;
+            const float s = nrm - A.conv32;
+            const float sg = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
+            const float ax = fabsf(s);
+            po[x] = (sg * (A.pow_mode == 2 ? ax * ax : torch_pow(ax, A.pow_mode, A.e32, T))) * E.div32 + E.sep32;
+        }
     }
 }
 
