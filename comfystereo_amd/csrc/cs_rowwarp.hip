@@ -792,6 +792,8 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
 //     result, so it is embarrassingly parallel.
 // ---------------------------------------------------------------------------------------------
 __device__ const unsigned long long d_hyb_exp_tab[256] = {CS_EXP_TAB_VALUES};
+#define CS_EXP_M05 0x1.368b2fc6f960ap-1   // exp(-0.5)
+#define CS_EXP_M10 0x1.78b56362cef38p-2   // exp(-1.0)
 
 __device__ __forceinline__ uint8_t src_u8(const RowArgs& A, int frame, int y, int x, int c) {
     size_t o = (((size_t)frame * A.h + y) * A.w + x) * 3 + c;
@@ -1048,7 +1050,9 @@ __device__ void technique_hybrid_fill(const Lds& L, const RowArgs& A, int frame,
                     if (mask[(size_t)ni * w + nj] == 0) continue;
                     if (!have_g0) { g0 = hyb_guidance(A, frame, row, j); have_g0 = true; }
                     int dsq = di * di + dj * dj;
-                    double w_s = csm::exp_exact(-(double)dsq / 2.0, etab);
+                    // math.exp(-dsq / 2) for dsq = 1, 2 (the centre is never a touched neighbour): the two values of glibc's exp,
+                // i.e. of csm::exp_exact (tests/test_cs_math_host.py compares) -- no need to evaluate them per neighbour
+                const double w_s = dsq == 1 ? CS_EXP_M05 : CS_EXP_M10;
                     double diff = g0 - hyb_guidance(A, frame, ni, nj);
                     double w_r = csm::exp_exact(-(diff * diff) / 200.0, etab);
                     double wg = w_s * w_r;
@@ -1095,7 +1099,9 @@ __device__ __forceinline__ void hybrid_fill_px(const RowArgs& A, const unsigned 
                 if (mask[(size_t)ni * w + nj] == 0) continue;
                 if (!have_g0) { g0 = hyb_guidance(A, frame, row, j); have_g0 = true; }
                 int dsq = di * di + dj * dj;
-                double w_s = csm::exp_exact(-(double)dsq / 2.0, etab);
+                // math.exp(-dsq / 2) for dsq = 1, 2 (the centre is never a touched neighbour): the two values of glibc's exp,
+                // i.e. of csm::exp_exact (tests/test_cs_math_host.py compares) -- no need to evaluate them per neighbour
+                const double w_s = dsq == 1 ? CS_EXP_M05 : CS_EXP_M10;
                 double diff = g0 - hyb_guidance(A, frame, ni, nj);
                 double w_r = csm::exp_exact(-(diff * diff) / 200.0, etab);
                 double wg = w_s * w_r;

@@ -33,6 +33,9 @@ int main() {
         if (csm::d2u(exp(x)) != csm::d2u(csm::exp_exact(x, cs_exp_tab))) bad++;
         n++;
     }
+    // the two spatial weights of edge_aware_gap_fill hard-coded in cs_rowwarp.hip (CS_EXP_M05, CS_EXP_M10)
+    if (csm::d2u(csm::exp_exact(-0.5, cs_exp_tab)) != csm::d2u(0x1.368b2fc6f960ap-1) || csm::d2u(exp(-0.5)) != csm::d2u(0x1.368b2fc6f960ap-1)) bad++;
+    if (csm::d2u(csm::exp_exact(-1.0, cs_exp_tab)) != csm::d2u(0x1.78b56362cef38p-2) || csm::d2u(exp(-1.0)) != csm::d2u(0x1.78b56362cef38p-2)) bad++;
     // exponent shortcuts of the tile kernel: two full binades + a strided sweep of all finite x >= 0
     long risky_n = 0;
     auto check_sq = [&](uint32_t u) {
