@@ -498,21 +498,32 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
             }
         }
         if (A.dbg == 22) return;
-        // 3. weights from the bit rows
-        const float large = (float)(R + 1), rad = (float)R;
+        // 3. weights from the bit rows.  Only edges within R columns give a non-zero weight, so a pixel looks at the 2R + 1
+        // bits around its own column: one funnel shift puts them into a 64-bit word (R <= 31), the nearest set bit on
+        // either side is a clz / ctz of its two halves.  (Wider masks: word-by-word searches over the whole window.)
+        const bool narrow = 2 * R + 1 <= 63;
+        auto nearest = [&](const unsigned long long* m, int c) -> int {   // min(distance to the nearest edge, R + 1)
+            if (narrow) {
+                const unsigned long long lo = m[0], hi = NW > 1 ? m[1] : 0ull;
+                unsigned long long W = c ? (lo >> c) | (hi << (64 - c)) : lo;   // bit k = window bit c + k: the pixel sits at bit R
+                W &= (2ull << (2 * R)) - 1ull;
+                const unsigned long long left = W & ((2ull << R) - 1ull), right = W >> R;
+                const int dl = left ? R - (63 - __clzll((long long)left)) : R + 1;
+                const int dr = right ? __ffsll((long long)right) - 1 : R + 1;
+                return min(dl, dr);
+            }
+            const int p = c + R;
+            const int a = mask_dist_left(m, p), b = mask_dist_right(m, NW, p);
+            return min(a >= 0 ? a : R + 1, b >= 0 ? b : R + 1);
+        };
         for (int i = tid; i < WR * BLUR_TW; i += 256) {
             const int r = i >> 6, c = i & 63;
             const int yy = y0 - v + r;
             float wl = 0.0f, wr = 0.0f;
             if (yy >= 0 && yy < h && x0 + c < w) {
-                const int p = c + R;
-                // an edge at distance >= R gives clamp(1 - d/R) == 0 exactly, like "no edge" (large = R + 1)
-                int a = mask_dist_left(mL + r * NW, p), b = mask_dist_right(mL + r * NW, NW, p);
-                int dmin = min(a >= 0 ? a : R + 1, b >= 0 ? b : R + 1);
-                wl = wtab[min(dmin, R)];
-                a = mask_dist_left(mR + r * NW, p); b = mask_dist_right(mR + r * NW, NW, p);
-                dmin = min(a >= 0 ? a : R + 1, b >= 0 ? b : R + 1);
-                wr = wtab[min(dmin, R)];
+                // an edge at distance >= R gives clamp(1 - d/R) == 0 exactly, like "no edge"
+                wl = wtab[min(nearest(mL + r * NW, c), R)];
+                wr = wtab[min(nearest(mR + r * NW, c), R)];
             }
             wlt[i] = wl; wrt[i] = wr;
         }
