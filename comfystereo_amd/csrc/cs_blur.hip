@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         // weight as a function of the nearest-edge distance d = 0 .. R (d >= R: clamp(1 - d/R) == 0), once per workgroup
     {
-        const int v = A.vert, R = A.radius, WR = BLUR_TR + 2 * v, NW = (BLUR_TW + 2 * R + 63) >> 6, DC = BLUR_TW + A.bs - 1;
+        const int v = A.vert, R = A.radius, WR = BLUR_TR + 2 * v, NW = (BLUR_TW + 2 * R + 63) >> 6, DC = (BLUR_TW + A.bs - 1 + 3) & ~3;
         float* wl0 = (float*)smem + ((BLUR_TR * DC + 3) & ~3);
         csm::PowfTables* T = (csm::PowfTables*)((unsigned long long*)(wl0 + 2 * WR * BLUR_TW) + 2 * WR * NW);
         float* wtab = (float*)((int*)(T + 1) + 4);
@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
         const int w = A.w, h = A.h, v = A.vert, bs = A.bs, pad = A.bs / 2, R = A.radius;
         const int WR = BLUR_TR + 2 * v;          // weight rows: frame rows y0 - v ..
         const int EW = BLUR_TW + 2 * R;          // edge columns: frame cols x0 - R ..
-        const int DC = BLUR_TW + bs - 1;         // depth tile: rows y0 .., cols x0 - pad ..
+        const int DC = (BLUR_TW + bs - 1 + 3) & ~3;   // depth tile: rows y0 .., cols x0 - pad .. (row stride: a multiple of 4)
         const int NW = (EW + 63) >> 6;           // 64-bit words per mask row
         float* D = (float*)smem;                                   // [TR][DC]
         float* wlt = D + ((BLUR_TR * DC + 3) & ~3);                // [WR][TW]
@@ -529,71 +529,84 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
         }
         __syncthreads();
         if (A.dbg == 23) return;
-        // 4. boxes + blend: lane = column tx, 8 consecutive rows
-        const int tx = tid & 63, ty = tid >> 6;
-        const int x = x0 + tx;
+        // 4. boxes + blend: a thread owns 4 consecutive columns of 2 consecutive rows and reads its operands as float4 --
+        // 13x fewer LDS instructions than one column per lane (the phase was bound by LDS issue, not by the fmaf chains);
+        // every chain keeps the reference's order (taps ascending from an accumulator of 0)
+        const int cx = 4 * (tid & 15), r0 = 2 * (tid >> 4);
         const float kb = 1.0f / (float)bs, kv = 1.0f / (float)(2 * v + 1);
-        float a8[8], b8[8], acc[8];
-        const int rbase = ty * 8;
+        float wa[2][4], wb[2][4], acc[2][4];
         if (v > 0) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) { a8[j] = 0.0f; b8[j] = 0.0f; }
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) { wa[j][c] = 0.0f; wb[j][c] = 0.0f; }
             const int nv = 2 * v + 1;
-            for (int k0 = 0; k0 < nv; k0 += 8) {
-                float vl[15], vr[15];
+            for (int kk = 0; kk <= nv; kk++) {   // weight row r0 + kk is tap kk of output row r0 and tap kk - 1 of row r0 + 1
+                const int rr = min(r0 + kk, WR - 1);
+                const float4 l4 = *reinterpret_cast<const float4*>(wlt + rr * BLUR_TW + cx);
+                const float4 r4 = *reinterpret_cast<const float4*>(wrt + rr * BLUR_TW + cx);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+                if (kk < nv) {
 #pragma unroll
-                for (int i = 0; i < 15; i++) {
-                    int rr = rbase + k0 + i;
-                    bool ok = rr < WR;
-                    vl[i] = ok ? wlt[rr * BLUR_TW + tx] : 0.0f;
-                    vr[i] = ok ? wrt[rr * BLUR_TW + tx] : 0.0f;
+                    for (int c = 0; c < 4; c++) { wa[0][c] = fmaf(kv, lv[c], wa[0][c]); wb[0][c] = fmaf(kv, rv[c], wb[0][c]); }
                 }
+                if (kk >= 1) {
 #pragma unroll
-                for (int kk = 0; kk < 8; kk++) {
-                    if (k0 + kk < nv) {
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            a8[j] = fmaf(kv, vl[j + kk], a8[j]);
-                            b8[j] = fmaf(kv, vr[j + kk], b8[j]);
-                        }
-                    }
+                    for (int c = 0; c < 4; c++) { wa[1][c] = fmaf(kv, lv[c], wa[1][c]); wb[1][c] = fmaf(kv, rv[c], wb[1][c]); }
                 }
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; j++) { a8[j] = wlt[(rbase + j) * BLUR_TW + tx]; b8[j] = wrt[(rbase + j) * BLUR_TW + tx]; }
-        }
-        if (A.dbg == 24) return;
-        // horizontal box: tap k of column tx is D column tx + k (the tile starts at frame column x0 - pad)
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[j] = 0.0f;
-        const float* dbase = D + rbase * DC + tx;
-        for (int k0 = 0; k0 < bs; k0 += 4) {  // (4 taps x 8 rows in flight: 8 taps cost a workgroup per CU in registers)
-            float dv[8][4];
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) dv[j][kk] = (k0 + kk < bs) ? dbase[j * DC + k0 + kk] : 0.0f;
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                if (k0 + kk < bs) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) acc[j] = fmaf(kb, dv[j][kk], acc[j]);
-                }
+            for (int j = 0; j < 2; j++) {
+                const float4 l4 = *reinterpret_cast<const float4*>(wlt + (r0 + j) * BLUR_TW + cx);
+                const float4 r4 = *reinterpret_cast<const float4*>(wrt + (r0 + j) * BLUR_TW + cx);
+                wa[j][0] = l4.x; wa[j][1] = l4.y; wa[j][2] = l4.z; wa[j][3] = l4.w;
+                wb[j][0] = r4.x; wb[j][1] = r4.y; wb[j][2] = r4.z; wb[j][3] = r4.w;
             }
         }
+        if (A.dbg == 24) return;
+        // horizontal box: tap k of column c is D column c + k (the tile starts at frame column x0 - pad)
         float lmin = INFINITY, lmax = -INFINITY, rmin = INFINITY, rmax = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int y = y0 + rbase + j;
+        for (int j = 0; j < 2; j++) {
+            const float* drow = D + (r0 + j) * DC + cx;
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[j][c] = 0.0f;
+            float4 nx = *reinterpret_cast<const float4*>(drow);
+            for (int k0 = 0; k0 < bs; k0 += 4) {
+                const float4 cur = nx;
+                nx = *reinterpret_cast<const float4*>(drow + k0 + 4);   // (the last chunk may read past the row: unused, in bounds)
+                const float d8[8] = {cur.x, cur.y, cur.z, cur.w, nx.x, nx.y, nx.z, nx.w};
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    if (k0 + kk < bs) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) acc[j][c] = fmaf(kb, d8[c + kk], acc[j][c]);
+                    }
+                }
+            }
+            const int y = y0 + r0 + j, x = x0 + cx;
             if (y < h && x < w) {
-                float dvv = dbase[j * DC + pad];
-                float ol = a8[j] * acc[j] + (1.0f - a8[j]) * dvv;
-                float orr = b8[j] * acc[j] + (1.0f - b8[j]) * dvv;
-                A.out_l[((size_t)frame * h + y) * w + x] = ol;
-                A.out_r[((size_t)frame * h + y) * w + x] = orr;
-                lmin = fminf(lmin, ol); lmax = fmaxf(lmax, ol);
-                rmin = fminf(rmin, orr); rmax = fmaxf(rmax, orr);
+                float ol[4], orr[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float dvv = drow[c + pad];
+                    ol[c] = wa[j][c] * acc[j][c] + (1.0f - wa[j][c]) * dvv;
+                    orr[c] = wb[j][c] * acc[j][c] + (1.0f - wb[j][c]) * dvv;
+                }
+                const size_t off = ((size_t)frame * h + y) * w + x;
+                if (x + 3 < w && (w & 3) == 0) {
+                    *reinterpret_cast<float4*>(A.out_l + off) = make_float4(ol[0], ol[1], ol[2], ol[3]);
+                    *reinterpret_cast<float4*>(A.out_r + off) = make_float4(orr[0], orr[1], orr[2], orr[3]);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (x + c < w) {
+                        if (!(x + 3 < w && (w & 3) == 0)) { A.out_l[off + c] = ol[c]; A.out_r[off + c] = orr[c]; }
+                        lmin = fminf(lmin, ol[c]); lmax = fmaxf(lmax, ol[c]);
+                        rmin = fminf(rmin, orr[c]); rmax = fmaxf(rmax, orr[c]);
+                    }
+                }
             }
         }
         if (A.stats_rw) {
@@ -618,7 +631,7 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
 static size_t blur_fused_lds(int v, int R, int bs) {
     int WR = BLUR_TR + 2 * v, EW = BLUR_TW + 2 * R, NW = (EW + 63) >> 6;
     (void)EW;
-    return (size_t)((BLUR_TR * (BLUR_TW + bs - 1) + 3) & ~3) * 4 + 2 * (size_t)WR * BLUR_TW * 4 + 2 * (size_t)WR * NW * 8 +
+    return (size_t)(BLUR_TR * ((BLUR_TW + bs - 1 + 3) & ~3)) * 4 + 2 * (size_t)WR * BLUR_TW * 4 + 2 * (size_t)WR * NW * 8 +
            sizeof(csm::PowfTables) + 64 + 4 * (size_t)(R + 2);
 }
 
