@@ -352,18 +352,27 @@ __global__ void __launch_bounds__(256) k_blur_copy(BlurArgs A, const unsigned lo
     }
     // the tiles' windows of the edge bit rows: rows y0-v .., bits x0-R .. x0+TW+R-1 (exactly k_blur_fused's reach).
     // No barrier between the two groups of loads: they travel together.
-    const int WR = BLUR_TR + 2 * v, EW = BLUR_TW + 2 * R, NW = (EW + 63) >> 6;
-    const unsigned long long lastmask = (EW & 63) ? (~0ull >> (64 - (EW & 63))) : ~0ull;
+    // Every word of the bit rows that overlaps the piece's reach is loaded ONCE (the two masks OR-ed) and tested against
+    // the reach of each of the four tiles -- 2.7x fewer loads than a window per tile.
+    const int WR = BLUR_TR + 2 * v;
+    const int WB = ((BLUR_CW * BLUR_TW + 2 * R + 63) >> 6) + 1;   // words that can overlap [X0 - R, X0 + 256 + R)
+    const int w0 = (X0 - R) >> 6;                                   // (arithmetic shift: floor for the negative start)
     unsigned found = 0;  // bit t: an edge within reach of tile t seen by this thread
-    for (int item = tid; item < BLUR_CW * WR * NW; item += 256) {
-        const int t = item / (WR * NW), rem = item - t * (WR * NW);
-        const int r = rem / NW, k = rem - r * NW;
-        const int yy = y0 - v + r, x0 = X0 + t * BLUR_TW;
-        if (yy >= 0 && yy < h && x0 < w) {
-            const size_t ro = ((size_t)frame * h + yy) * MW;
-            unsigned long long bits = mask_window(mask_l + ro, MW, x0 - R + 64 * k) | mask_window(mask_r + ro, MW, x0 - R + 64 * k);
-            if (k == NW - 1) bits &= lastmask;
-            if (bits) found |= 1u << t;
+    for (int item = tid; item < WR * WB; item += 256) {
+        const int r = item / WB, k = item - r * WB;
+        const int yy = y0 - v + r, wi = w0 + k;
+        if (yy >= 0 && yy < h && wi >= 0 && wi < MW) {
+            const size_t ro = ((size_t)frame * h + yy) * MW + wi;
+            const unsigned long long bits = mask_l[ro] | mask_r[ro];
+            if (bits) {
+                const int b0 = wi * 64;   // frame column of bit 0
+#pragma unroll
+                for (int t = 0; t < BLUR_CW; t++) {
+                    const int x0 = X0 + t * BLUR_TW;
+                    const int lo = max(x0 - R, b0), hi = min(x0 + BLUR_TW - 1 + R, b0 + 63);
+                    if (x0 < w && lo <= hi && (bits & (~0ull >> (63 - (hi - b0))) & (~0ull << (lo - b0)))) found |= 1u << t;
+                }
+            }
         }
     }
     unsigned any = 0;
