@@ -342,9 +342,10 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         if (e != hipSuccess) return fail_hip(e, "flagged-row collection");
         A.row_list = list; A.row_count = count;
     }
-    if ((fill == CS_FILL_NONE || fill == CS_FILL_INVERSE || fill == CS_FILL_NAIVE) && !dev_switch(CS_DEBUG_NO_TILE)) {
+    if ((fill == CS_FILL_NONE || fill == CS_FILL_INVERSE || fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING) &&
+        !dev_switch(CS_DEBUG_NO_TILE)) {
         // the halo-tile kernel where it applies; 'naive' hands the rows it cannot decide to the row kernel
-        const bool flagging = fill == CS_FILL_NAIVE && rowflag;
+        const bool flagging = (fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING) && rowflag;
         const size_t rows = (size_t)A.n * A.h;
         if (flagging) {
             hipError_t e = hipMemsetAsync(rowflag, 0, al256(rows) + 256, stream);

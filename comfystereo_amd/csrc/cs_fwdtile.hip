@@ -1,6 +1,7 @@
 // cs_fwdtile.hip -- fill techniques 'none' (reference stereoimage_generation.py:1850-1867, the forward map of
-// apply_stereo_divergence_naive), 'naive' (:1893-1908, holes take the nearest filled pixel, right before left) and
-// 'inverse' (:1715-1737, the z-buffered two-column splat) as a halo-tile kernel: the node path's float32 image in, both
+// apply_stereo_divergence_naive), 'naive' (:1893-1908, holes take the nearest filled pixel, right before left),
+// 'naive_interpolating' (:1871-1892, linear ramps over the holes) and 'inverse' (:1715-1737, the z-buffered two-column
+// splat) as a halo-tile kernel: the node path's float32 image in, both
 // eyes of a tile out.
 //
 // The general row kernel (cs_rowwarp.hip) keeps a whole row of one frame in LDS (60 KB at 4K: two workgroups per CU,
@@ -15,7 +16,10 @@
 //   * every output column looks up its winner's colour (0 = hole) and keeps it in a register; 'naive': the forward map is
 //     computed for R more columns on either side of the tile, the filled flags become bit rows (wave ballots), and a hole
 //     finds its nearest filled neighbours with clz / ctz.  A hole that the window cannot decide (nothing filled within
-//     its reach although the search limit |int(div_px)| + 1 goes further) flags the ROW for the row kernel,
+//     its reach although the search limit |int(div_px)| + 1 goes further) flags the ROW for the row kernel;
+//     'naive_interpolating': the row kernel's formulation (cs_rowwarp.hip: every pixel of an interval between two "good"
+//     pixels finds the interval by walking the flags and computes its own ramp value; intervals that hit the re-trigger
+//     quirk are replayed literally by one lane) on the window -- intervals that leave the window flag the row,
 // then the eyes are written straight into their slots of the SBS / top-bottom layout or composed into the anaglyph
 // (:1996-2010), together with the no-fill mask (GenerateStereo.py:355-361) and both depth-map outputs (:1511-1516).
 // Dialect D32 only (other dialects, uint8 images and anaglyph-free single calls of apply_stereo_divergence take the row
@@ -66,7 +70,14 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
     unsigned long long* key = (unsigned long long*)(img + NPT);   // [T] closeness << 32 | ~source index ('inverse')
     const unsigned long long key_init = ((unsigned long long)csm::f2ord(-1.0f) << 32) | 0xffffffffull;
     unsigned long long* fm = key + NPT;     // [NPT / 64] filled flags of the window as bit rows ('naive')
+    // 'naive_interpolating': colours of the window (modified in place like the reference's derived_image), ramp values, the
+    // interval start of a pixel, per-pixel flags (1 filled, 2 good, 4 has a ramp value, 8 interval needs the replay, 16 unresolved)
+    uint32_t* colw = (uint32_t*)(fm + NPT / 64);
+    uint32_t* tmpv = colw + NPT;
+    uint16_t* istart = (uint16_t*)(tmpv + NPT);
+    uint8_t* fl = (uint8_t*)(istart + NPT);
     bool giveup = false;
+    auto sum8 = [](uint32_t c) { return ((c & 0xffu) + ((c >> 8) & 0xffu) + ((c >> 16) & 0xffu)) & 0xffu; };   // uint8 sum: wraps (quirk Q5)
 
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
     const uint32_t rowpix = ((uint32_t)frame * (uint32_t)h + (uint32_t)row) * (uint32_t)w;
@@ -168,6 +179,65 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
             }
         }
         __syncthreads();
+        if (FILL == CS_FILL_NAIVE_INTERPOLATING) {
+            for (int p = tid; p < nwin; p += NT) {
+                const int s = winner[p];
+                const bool f = s != init;
+                const uint32_t c = f ? img[s] : 0u;
+                colw[p] = c;
+                fl[p] = (uint8_t)((f ? 1 : 0) | ((f && sum8(c) != 0u) ? 2 : 0));
+            }
+            __syncthreads();
+            auto flag_or = [&](int p, unsigned bit) { atomicOr((unsigned*)fl + (p >> 2), bit << ((p & 3) * 8)); };
+            auto ramp = [&](uint32_t lb, uint32_t rb, float total, float k) {   // l_border + (step * k).astype(uint8), per channel
+                uint32_t v = 0;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const float a = (float)((lb >> (8 * ch)) & 0xffu), b = (float)((rb >> (8 * ch)) & 0xffu);
+                    v |= (uint32_t)(uint8_t)(((lb >> (8 * ch)) & 0xffu) + csm::f32_to_u8_wrap(((b - a) / total) * k)) << (8 * ch);
+                }
+                return v;
+            };
+            for (int p = tid; p < nwin; p += NT) {
+                if (fl[p] & 2) continue;
+                int lg = p, l0 = -1;
+                while (lg >= 0 && !(fl[lg] & 2)) { if (!(fl[lg] & 1)) l0 = lg; lg--; }
+                int g = p + 1;
+                while (g < nwin && !(fl[g] & 2)) g++;
+                if ((lg < 0 && c0 > 0) || (g >= nwin && c1 < w)) { flag_or(p, 16u); continue; }   // the interval leaves the window
+                const int s0i = lg + 1;
+                istart[p] = (uint16_t)s0i;
+                if (l0 < 0 || p < l0) continue;   // no unfilled pixel in the interval up to here: untouched
+                uint32_t lb = l0 > 0 ? colw[l0 - 1] : 0u, rb = g < nwin ? colw[g] : 0u;   // (l0 == 0 only at the frame's first column)
+                if (sum8(lb) == 0u) lb = rb;
+                else if (sum8(rb) == 0u) rb = lb;
+                const uint32_t v = ramp(lb, rb, (float)(1 + g - l0), (float)(p - l0 + 1));
+                tmpv[p] = v;
+                flag_or(p, 4u);
+                if (p > l0 && !(fl[p] & 1) && sum8(v) == 0u) flag_or(s0i, 8u);   // the quirk: re-trigger -> literal replay
+            }
+            __syncthreads();
+            for (int p = tid; p < nwin; p += NT)
+                if ((fl[p] & 4) && !(fl[istart[p]] & 8)) colw[p] = tmpv[p];
+            __syncthreads();
+            for (int s = tid; s < nwin; s += NT) {   // literal replay of the flagged intervals, one lane each
+                if ((fl[s] & 2) || (s > 0 && !(fl[s - 1] & 2)) || !(fl[s] & 8)) continue;
+                for (int l = s; l < nwin && !(fl[l] & 2); l++) {
+                    if (sum8(colw[l]) != 0u || (fl[l] & 1)) continue;
+                    uint32_t lb = l > 0 ? colw[l - 1] : 0u, rb = 0u;
+                    int r = l + 1;
+                    while (r < nwin) {
+                        if (sum8(colw[r]) != 0u && (fl[r] & 1)) { rb = colw[r]; break; }
+                        r++;
+                    }
+                    if (sum8(lb) == 0u) lb = rb;
+                    else if (sum8(rb) == 0u) rb = lb;
+                    const float total = (float)(1 + r - l);
+                    for (int c = l; c < r; c++) colw[c] = ramp(lb, rb, total, (float)(c - l + 1));
+                }
+            }
+            __syncthreads();
+        }
         if (FILL == CS_FILL_NAIVE) {
             // filled flags of the window as bit rows: one ballot per 64 columns
             for (int pb = (tid >> 6) * 64; pb < nwin; pb += NT) {
@@ -186,6 +256,11 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
                     res[e][m] = kk > key_init ? img[0xffffffffu - (unsigned)(kk & 0xffffffffull)] : 0u;
                 } else {
                     const int p = q + (o0 - c0);
+                    if (FILL == CS_FILL_NAIVE_INTERPOLATING) {
+                        if (fl[p] & 16) giveup = true;
+                        res[e][m] = colw[p];
+                        continue;
+                    }
                     int s = winner[p];
                     if (FILL == CS_FILL_NAIVE && s == init) {
                         // nearest filled column to the right (dr) and to the left (dl) inside the window, BIG: none there
@@ -225,7 +300,7 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
         }
         __syncthreads();   // (winner is re-initialised for the next eye)
     }
-    if (FILL == CS_FILL_NAIVE && giveup) A.rowflag[(uint32_t)frame * (uint32_t)h + (uint32_t)row] = 1;   // the row kernel redoes it
+    if ((FILL == CS_FILL_NAIVE || FILL == CS_FILL_NAIVE_INTERPOLATING) && giveup) A.rowflag[(uint32_t)frame * (uint32_t)h + (uint32_t)row] = 1;   // the row kernel redoes it
     // ---- outputs: eyes into their slots / the anaglyph composition, the no-fill mask, both depth-map outputs
     auto store = [&](int e, int q, uint32_t c) {
         const EyeArgs& E = A.eye[e];
@@ -268,7 +343,7 @@ int fwdtile_max_halo() { return (256 * 3 - 64) / 2; }
 // launches the row kernel).
 hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, uint8_t* rowflag, hipStream_t stream) {
     constexpr int NT = 256, SLOTS = 3;
-    if (fill != CS_FILL_NONE && fill != CS_FILL_INVERSE && fill != CS_FILL_NAIVE) return hipErrorNotSupported;
+    if (fill != CS_FILL_NONE && fill != CS_FILL_INVERSE && fill != CS_FILL_NAIVE && fill != CS_FILL_NAIVE_INTERPOLATING) return hipErrorNotSupported;
     if (!R.image_f32 || R.out_u8 || R.d64 || R.neyes != 2 || !R.depth_l || !R.depth_r || R.row_list) return hipErrorNotSupported;
     const int S = S0 + (fill == CS_FILL_INVERSE ? 2 : 0);   // (the splat also touches the column right of floor(dest))
     if (S > fwdtile_max_halo()) return hipErrorNotSupported;
@@ -283,6 +358,13 @@ hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, uint8_t* rowflag, 
         const int lim1 = max(R.eye[0].naive_lim, R.eye[1].naive_lim) - 1;
         A.R = min(S + 1, lim1 > 0 ? lim1 : 0);
     }
+    // 'naive_interpolating': an interval runs from the good pixel before a hole to the good pixel after it; holes are at most
+    // 2S wide but usually far narrower -- a window of S + 8 on either side, the rest (and intervals lengthened by black
+    // pixels) goes to the row kernel
+    if (fill == CS_FILL_NAIVE_INTERPOLATING) {
+        if (!rowflag) return hipErrorNotSupported;
+        A.R = S + 8;
+    }
     int tmax = (NT * SLOTS - 2 * S - 2 * A.R) & ~3;
     if (tmax < 128) return hipErrorNotSupported;
     const int tiles = (R.w + tmax - 1) / tmax;
@@ -296,10 +378,12 @@ hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, uint8_t* rowflag, 
     A.out_h = R.out_h; A.out_w = R.out_w;
     A.dbg = R.dbg;
     const int ntiles = (R.w + A.T - 1) / A.T;
-    const size_t lds = (size_t)NT * SLOTS * 4 + (size_t)NT * SLOTS * 8 + (size_t)(NT * SLOTS / 64) * 8 + 64;
+    const size_t npt = (size_t)NT * SLOTS;
+    const size_t lds = npt * 4 + npt * 8 + (npt / 64) * 8 + (fill == CS_FILL_NAIVE_INTERPOLATING ? npt * (4 + 4 + 2 + 1) : 0) + 64;
     const dim3 grid(ntiles * 8, (R.h + 7) / 8, R.n), block(NT);
     if (fill == CS_FILL_INVERSE) hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_INVERSE>), grid, block, lds, stream, A);
     else if (fill == CS_FILL_NAIVE) hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_NAIVE>), grid, block, lds, stream, A);
+    else if (fill == CS_FILL_NAIVE_INTERPOLATING) hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_NAIVE_INTERPOLATING>), grid, block, lds, stream, A);
     else hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_NONE>), grid, block, lds, stream, A);
     return hipGetLastError();
 }
