@@ -312,9 +312,13 @@ static bool dialect_d64_ok(int fill) {
 static size_t rowflag_bytes(size_t rows) { return al256(rows) + 256 + al256(rows * 4); }
 
 // polylines: tiled fast path + general row kernel over the rows it flagged; everything else: row kernel
-static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_t stream) {
+// anaglyph scratch of the tiled polylines path: both eyes as uint8 codes side by side
+static size_t poly_anaglyph_bytes(int n, int h, int w) { return al256((size_t)n * h * 2 * w * 3); }
+
+static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_t stream, uint8_t* ana_sbs = nullptr) {
     const bool poly = fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP;
-    if (poly && !A.anaglyph && halo <= polytile_max_halo() && rowflag && !dev_switch(CS_DEBUG_NO_TILE)) {
+    if (poly && (!A.anaglyph || (ana_sbs && A.image_f32 && !A.out_u8)) && halo <= polytile_max_halo() && rowflag &&
+        !dev_switch(CS_DEBUG_NO_TILE)) {
         // workspace: [n*h flag bytes][count, padded to 256][n*h list entries]
         const size_t rows = (size_t)A.n * A.h;
         uint32_t* count = (uint32_t*)(rowflag + al256(rows));
@@ -324,11 +328,24 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         // soft: the point-owner kernel (cs_polypoint.hip) unless the halo is too wide for it or the development switch
         // CS_DEBUG_PT_VARIANT >= 1 asks for the first generation (cs_polytile.hip); sharp: first generation
         const int variant = dev_switch(CS_DEBUG_PT_VARIANT);   // 0 / 3 / 4: point-owner kernel; other values: first generation
+        // anaglyph modes: the tile kernels write the two eyes as uint8 codes side by side into scratch (no mask), the rows they
+        // flag are redone by the row kernel in final form, k_anaglyph_compose makes the composite of the others
+        RowArgs T = A;
+        if (A.anaglyph) {
+            T.anaglyph = 0; T.single = -1;
+            T.stereo = reinterpret_cast<float*>(ana_sbs); T.stereo_is_u8 = 1; T.no_mask = 1; T.mask = nullptr;
+            T.out_h = A.h; T.out_w = 2 * A.w;
+            T.eye[0].xoff = 0; T.eye[0].yoff = 0; T.eye[1].xoff = A.w; T.eye[1].yoff = 0;
+        }
         if (fill == CS_FILL_POLYLINES_SOFT && halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 6)))
-            e = launch_polypoint(A, halo, rowflag, stream);
+            e = launch_polypoint(T, halo, rowflag, stream);
         else
-            e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, A, halo, rowflag, stream);
+            e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, T, halo, rowflag, stream);
         if (e != hipSuccess) return fail_hip(e, "tiled polylines launch");
+        if (A.anaglyph) {
+            e = launch_anaglyph_compose(ana_sbs, rowflag, A.n, A.h, A.w, A.anaglyph, A.stereo, A.stereo_is_u8, A.mask, stream);
+            if (e != hipSuccess) return fail_hip(e, "anaglyph composition launch");
+        }
         // single-eye modes (left-only / only-right): the tile kernels visit one eye, both depth maps are outputs all the same
         if (A.neyes == 2 && A.single >= 0 && !A.out_u8) {
             const int other = 1 - A.single;
@@ -444,6 +461,9 @@ static WsLayout ws_layout(const cs_params* p) {
     W.extra = o;
     if (p->fill == CS_FILL_HYBRID_EDGE || p->fill == CS_FILL_HYBRID_EDGE_PLUS) o += al256(hybrid_workspace_bytes(p->n, p->h, p->w));
     if (p->fill == CS_FILL_GPU_WARP) o += al256(gpuwarp_workspace_bytes(p->n, p->h, p->w, p->batch_size, p->flags & 4));
+    if ((p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP) &&
+        (p->mode == CS_MODE_RED_CYAN_ANAGLYPH || p->mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH))
+        o += poly_anaglyph_bytes(p->n, p->h, p->w);
     W.total = o;
     return W;
 }
@@ -548,7 +568,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
         if (rc) return fail(rc, "hybrid_edge launch failed");
     } else {
         int halo = poly_halo(left_div, right_div, p->separation, p->stereo_offset_exponent, p->convergence_point, w);
-        rc = run_rows(p->fill, A, halo, (uint8_t*)(ws + W.rowflag), stream);
+        rc = run_rows(p->fill, A, halo, (uint8_t*)(ws + W.rowflag), stream, A.anaglyph ? (uint8_t*)(ws + W.extra) : nullptr);
         if (rc) return rc;
     }
     hipError_t e = hipGetLastError();

@@ -39,6 +39,7 @@ struct RowArgs {
     uint8_t* out_u8;  // asd path: [n][h][w][3]
     float* stereo;    // node path: [n][out_h][out_w][3] float32 (or uint8 codes k of k/255 when stereo_is_u8)
     int stereo_is_u8;
+    int no_mask;      // (tile kernels, with stereo_is_u8) no mask output: the per-eye intermediate of the anaglyph modes
     float* mask;      //            [n][out_h][out_w]
     float* depth_l;   //            [n][h][w][3]
     float* depth_r;
@@ -77,6 +78,9 @@ int fwdtile_max_halo();
 // cs_polypoint.hip: second generation of the tiled path (polylines_soft): one lane per polyline point
 hipError_t launch_polypoint(const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream);
 int polypoint_max_halo();
+// anaglyph modes behind the tile kernel: the eyes as uint8 codes side by side -> the composite (rows flagged in rowflag excepted)
+hipError_t launch_anaglyph_compose(const uint8_t* sbs, const uint8_t* rowflag, int n, int h, int w, int anaglyph, float* stereo,
+                                   int stereo_is_u8, float* mask, hipStream_t stream);
 // depth-map output (code / 255 on three channels) of an eye the tile kernels do not visit (single-eye modes)
 hipError_t launch_depth_codes(const float* depth, int n, int h, int w, const uint32_t* stats, int scale_from_stats, float* out,
                               hipStream_t stream);

@@ -123,7 +123,8 @@ __device__ __forceinline__ PixC pix_consts(int col) {
 enum { PF_HAZARD = 0, PF_NLIST = 1, PF_NDIRTY = 2, PF_DLO = 3, PF_DHI = 4, PF_JLO = 5, PF_JHI = 6, PF_WORDS = 8 };
 // output forms: float32 node outputs / the uint8 codes of the stereoscope (cs_params.flags bit 1) / apply_stereo_divergence
 // (uint8 image in, uint8 image out, nothing else)
-enum { PO_F32 = 0, PO_U8 = 1, PO_ASD = 2 };
+// (PO_U8NM: uint8 codes without the mask -- the per-eye intermediate of the anaglyph modes, composed by k_anaglyph_compose)
+enum { PO_F32 = 0, PO_U8 = 1, PO_ASD = 2, PO_U8NM = 3 };
 // list entries: kind << 28 | point id << 12 | pixel (tile-local)
 enum { PK_CHAIN = 0u, PK_BRIDGE = 1u };
 
@@ -249,14 +250,14 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // ---- output rows of this tile: 32-bit offsets from wave-uniform bases ----
     const uint32_t obase = OUT == PO_ASD ? (rowpix + (uint32_t)o0)
                                          : (((uint32_t)frame * (uint32_t)A.out_h + (uint32_t)(row + E.yoff)) * (uint32_t)A.out_w + (uint32_t)(E.xoff + o0));
-    char* const st_row = OUT == PO_ASD ? (char*)A.out_u8 + (size_t)obase * 3 : (OUT == PO_U8 ? (char*)A.stereo + (size_t)obase * 3 : (char*)A.stereo + (size_t)obase * 12);
-    char* const mk_row = OUT == PO_ASD ? nullptr : (char*)A.mask + (size_t)obase * 4;
+    char* const st_row = OUT == PO_ASD ? (char*)A.out_u8 + (size_t)obase * 3 : ((OUT == PO_U8 || OUT == PO_U8NM) ? (char*)A.stereo + (size_t)obase * 3 : (char*)A.stereo + (size_t)obase * 12);
+    char* const mk_row = (OUT == PO_ASD || OUT == PO_U8NM) ? nullptr : (char*)A.mask + (size_t)obase * 4;
     // colour codes of tile pixel q as integer-valued floats 0..255
     auto emit_f = [&](int q, float r, float g, float b) {
         const uint32_t uq = (uint32_t)q;
         if (OUT == PO_F32) *reinterpret_cast<F3*>(st_row + 12u * uq) = F3{code_over_255(r), code_over_255(g), code_over_255(b)};
         else *reinterpret_cast<B3*>(st_row + 3u * uq) = B3{(uint8_t)(int)r, (uint8_t)(int)g, (uint8_t)(int)b};
-        if (OUT != PO_ASD) *reinterpret_cast<float*>(mk_row + 4u * uq) = __builtin_fmaxf(__builtin_fmaxf(r, g), b) == 0.0f ? 1.0f : 0.0f;
+        if (OUT != PO_ASD && OUT != PO_U8NM) *reinterpret_cast<float*>(mk_row + 4u * uq) = __builtin_fmaxf(__builtin_fmaxf(r, g), b) == 0.0f ? 1.0f : 0.0f;
     };
     auto emit = [&](int q, int r, int g, int b) { emit_f(q, (float)r, (float)g, (float)b); };   // the same from integer codes
 
@@ -841,6 +842,30 @@ hipError_t launch_depth_codes(const float* depth, int n, int h, int w, const uin
     return hipGetLastError();
 }
 
+// Anaglyph composition of the two eyes the tile kernel wrote as uint8 codes side by side ([n][h][2w][3]): R from one eye,
+// G and B from the other (overlap_red_cyan, reference :1996-2010), k / 255, the no-fill mask of the composite
+// (GenerateStereo.py:355-361).  Rows the tile kernel flagged are skipped: the row kernel writes them in final form.
+__global__ void __launch_bounds__(256) k_anaglyph_compose(const uint8_t* __restrict__ sbs, const uint8_t* __restrict__ rowflag, int w,
+                                                          int anaglyph, float* stereo, int stereo_is_u8, float* mask) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t row = blockIdx.y;   // frame * h + row
+    if (x >= w || rowflag[row]) return;
+    const B3 l = *reinterpret_cast<const B3*>(sbs + ((size_t)row * 2 * w + x) * 3);
+    const B3 r = *reinterpret_cast<const B3*>(sbs + ((size_t)row * 2 * w + w + x) * 3);
+    const B3 c = anaglyph == 1 ? B3{l.x, r.y, r.z} : B3{r.x, l.y, l.z};
+    const size_t o = (size_t)row * w + x;
+    if (stereo_is_u8) *reinterpret_cast<B3*>(reinterpret_cast<uint8_t*>(stereo) + o * 3) = c;
+    else *reinterpret_cast<F3*>(stereo + o * 3) = F3{code_over_255((float)c.x), code_over_255((float)c.y), code_over_255((float)c.z)};
+    mask[o] = ((int)c.x + (int)c.y + (int)c.z) == 0 ? 1.0f : 0.0f;
+}
+
+hipError_t launch_anaglyph_compose(const uint8_t* sbs, const uint8_t* rowflag, int n, int h, int w, int anaglyph, float* stereo,
+                                   int stereo_is_u8, float* mask, hipStream_t stream) {
+    hipLaunchKernelGGL(k_anaglyph_compose, dim3((w + 255) / 256, n * h), dim3(256), 0, stream, sbs, rowflag, w, anaglyph, stereo,
+                       stereo_is_u8, mask);
+    return hipGetLastError();
+}
+
 static size_t polypoint_lds(int nt, int slots, int T, int KP, int KS) {
     const size_t npt = (size_t)slots * nt + 4;
     return 16 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((T + 3) & ~3) + 2 * PP_DCAP * (2 + (size_t)KP + KS) +
@@ -877,6 +902,7 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
     }
     if (out == PO_F32) PP_LAUNCH(PO_F32)
     else if (out == PO_U8) PP_LAUNCH(PO_U8)
+    else if (out == PO_U8NM) PP_LAUNCH(PO_U8NM)
     else PP_LAUNCH(PO_ASD)
 #undef PP_LAUNCH
     return hipGetLastError();
@@ -907,7 +933,7 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     A.out_h = R.out_h; A.out_w = R.out_w;
     A.rowflag = rowflag;
     A.dbg = R.dbg;
-    const int out = R.out_u8 ? PO_ASD : (R.stereo_is_u8 ? PO_U8 : PO_F32);
+    const int out = R.out_u8 ? PO_ASD : (R.stereo_is_u8 ? (R.no_mask ? PO_U8NM : PO_U8) : PO_F32);
     if ((out == PO_ASD) != (R.image_u8 != nullptr)) return hipErrorInvalidValue;  // uint8 image in <=> uint8 image out
     if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31) || A.h > 8 * 65535 || 2 * A.n > 65535)
         return hipErrorInvalidValue;   // 32-bit pixel indices, grid limits

@@ -868,7 +868,8 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
             for (int i = tid; i < 3 * wt; i += PT_THREADS) dst[i] = lut[res[i]];
         }
         float* m = A.mask + o;
-        if ((wt & 3) == 0 && (w & 3) == 0) {
+        if (!A.mask) {   // (the per-eye intermediate of the anaglyph modes has no mask: k_anaglyph_compose writes the composite's)
+        } else if ((wt & 3) == 0 && (w & 3) == 0) {
             float4* m4 = reinterpret_cast<float4*>(m);
             for (int i = tid; i < wt / 4; i += PT_THREADS) {
                 const uint8_t* r = res + 12 * i;

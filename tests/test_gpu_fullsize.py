@@ -234,10 +234,31 @@ def test_order_dependent_rows_take_the_wave_replay(engine):
     img = synth.image_f32(1, h, w, seed=12)
     depth = synth.depth_batch("random8", 1, h, w, channels=3)
     for fill, ui in (("polylines_soft", "Fill - Polylines Soft"), ("polylines_sharp", "Fill - Polylines Sharp")):
-        want = node_oracle.generate(img, depth, 6.0, 0.0, "left-right", 0.0, 0.5, 2.0, ui, 20.0, 20.0, False, batch_size=12)
-        p = engine.make_params(1, h, w, h, w, 3, fill, "left-right", 6.0, 0.0, 0.0, 0.5, 2.0, False, 20.0, 20.0, 1.0, 0, 12)
+        # (anaglyph: the tile kernels write the eyes into scratch, the flagged rows are written in final form by the row kernel
+        # and skipped by the composition)
+        for mode in ("left-right", "red-cyan-anaglyph"):
+            want = node_oracle.generate(img, depth, 6.0, 0.0, mode, 0.0, 0.5, 2.0, ui, 20.0, 20.0, False, batch_size=12)
+            p = engine.make_params(1, h, w, h, w, 3, fill, mode, 6.0, 0.0, 0.0, 0.5, 2.0, False, 20.0, 20.0, 1.0, 0, 12)
+            plan = engine.Plan(p, torch.device("cuda"))
+            got = [t.cpu().numpy() for t in plan.run(cuda(img), cuda(depth))]
+            assert int(plan.stats()[:, 10].sum()) > 0   # rows replayed sequentially
+            for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+                assert np.array_equal(g, w_), (fill, mode, name)
+
+
+def test_anaglyph_through_the_tile_kernels_mixes_flagged_and_composed_rows(engine):
+    """Anaglyph polylines: a frame whose upper half ties everywhere (rows redone by the row kernel, final form) and whose
+    lower half is smooth (eyes composed from the tile kernels' scratch)."""
+    h, w = 32, 1028
+    img = synth.image_f32(1, h, w, seed=13)
+    depth = synth.depth_batch("blobs", 1, h, w, channels=3)
+    depth[:, : h // 2] = synth.depth_batch("random8", 1, h // 2, w, channels=3)
+    for mode in ("red-cyan-anaglyph", "cyan-red-reverseanaglyph"):
+        want = node_oracle.generate(img, depth, 5.0, 0.5, mode, 0.1, 0.5, 2.0, "Fill - Polylines Soft", 20.0, 20.0, False, batch_size=12)
+        p = engine.make_params(1, h, w, h, w, 3, "polylines_soft", mode, 5.0, 0.5, 0.1, 0.5, 2.0, False, 20.0, 20.0, 1.0, 0, 12)
         plan = engine.Plan(p, torch.device("cuda"))
         got = [t.cpu().numpy() for t in plan.run(cuda(img), cuda(depth))]
-        assert int(plan.stats()[:, 10].sum()) > 0   # rows replayed sequentially
+        redone = int(plan.stats()[:, 11].sum())
+        assert 0 < redone < 2 * h
         for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
-            assert np.array_equal(g, w_), (fill, name)
+            assert np.array_equal(g, w_), (mode, name)
