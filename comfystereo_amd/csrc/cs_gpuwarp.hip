@@ -695,7 +695,7 @@ static int gw_launch(GwArgs& A, hipStream_t stream) {
     // workgroup size: about 4 columns per thread (measured at 1080p: 512 threads 2.30 ms per 32 frames, 1024: 2.71, 256: 2.94)
     int threads = A.w <= 1024 ? 256 : (A.w <= 2048 ? 512 : 1024);
     const int forced = dev_switch(CS_DEBUG_PT_VARIANT);   // (development: workgroup size)
-    if (forced == 21 && A.w <= 4 * 512) threads = 512;
+    if (forced == 21) threads = 512;
     if (forced == 22 && A.w <= 4 * 256) threads = 256;
     if (forced == 23) threads = 1024;
     const bool wide = threads > 512, pow2 = A.pow_mode == 2;
