@@ -748,27 +748,72 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
               ((uint32_t)csm::f32_to_u8_wrap(k2) << 16);
         return done;
     };
-    auto fast_cand = [&](unsigned c) { return mono ? (c >> 12) == 1u : c == 0x0201u; };
+    // sharp: two points per source pixel, so the common pixel holds exactly TWO consecutive points o, o+1 and three
+    // pieces [col, x_o] [x_o, x_o+1] [x_o+1, col+1] on the chain segments (o-1 -> o) (o -> o+1) (o+1 -> o+2), alternately
+    // flat (inside one source pixel: colour * length) and interpolating.  Same checks as the chain path, straight-line.
+    auto fast_px2 = [&](int q, bool cand, unsigned c, uint32_t& rgb) -> bool {
+        const int col = o0 + q;
+        const float ff64 = col == 0 ? 0x1.ad7f2ap-24f : (col == 1 ? 0x1.000002p+0f : (float)col);
+        const float tf64 = col == 0 ? 0x1.fffffcp-1f : (col == 1 ? 0x1.fffffep+0f : (float)(col + 1));
+        int o = 1;
+        bool ok = cand;
+        if (mono) o = cand ? (int)(c & 0xfffu) : 1;
+        else {
+            const int pa = pts[q * PT_KP], pb = pts[q * PT_KP + 1];
+            o = cand ? min(pa, pb) : 1;
+            ok = ok && max(pa, pb) == o + 1;
+        }
+        ok = ok && o >= 1 && o + 2 <= npts - 1;
+        o = ok ? o : 1;
+        const float x0 = px[o - 1], x1 = px[o], x2 = px[o + 1], x3 = px[o + 2];
+        const int j0 = min(max((o - 2) >> 1, 0), ns - 1), j1 = min((o - 1) >> 1, ns - 1);
+        const int j2 = min(o >> 1, ns - 1), j3 = min((o + 1) >> 1, ns - 1);
+        const uint32_t i0 = img[j0], i1 = img[j1], i2 = img[j2], i3 = img[j3];
+        const float colf = (float)col, col1 = (float)(col + 1);
+        ok = ok && x0 < x1 && x1 < x2 && x2 < x3 && x1 < col1 && x2 < col1 && x2 > colf;
+        float k0 = 0.5f, k1 = 0.5f, k2 = 0.5f, prev = colf;
+        auto piece = [&](float xa, float xb, uint32_t ia, uint32_t ib, bool flat, float ff, float tf) {
+            const float sig = tf - ff;
+            const float cen = ff + 0.5f * sig;
+            const bool work = sig != 0.0f;
+            ok = ok && (!work || (xa < cen && !(xb < cen))) && !(cen < prev) && !(cen > col1);
+            prev = cen;
+            const float ip = (cen - xa) / (xb - xa);
+            const float om = 1.0f - ip;
+            const float l0 = (float)(ia & 0xffu), l1 = (float)((ia >> 8) & 0xffu), l2 = (float)((ia >> 16) & 0xffu);
+            const float r0 = (float)(ib & 0xffu), r1 = (float)((ib >> 8) & 0xffu), r2 = (float)((ib >> 16) & 0xffu);
+            const float m0 = flat ? l0 : l0 * om + r0 * ip, m1 = flat ? l1 : l1 * om + r1 * ip,
+                        m2 = flat ? l2 : l2 * om + r2 * ip;
+            const float n0 = k0 + m0 * sig, n1 = k1 + m1 * sig, n2 = k2 + m2 * sig;
+            k0 = work ? n0 : k0; k1 = work ? n1 : k1; k2 = work ? n2 : k2;
+        };
+        piece(x0, x1, i0, i1, j0 == j1, ff64, x1 - eps32);
+        piece(x1, x2, i1, i2, j1 == j2, !(x1 > colf) ? ff64 : x1 + eps32, x2 - eps32);
+        piece(x2, x3, i2, i3, j2 == j3, x2 + eps32, tf64);
+        rgb = (uint32_t)csm::f32_to_u8_wrap(k0) | ((uint32_t)csm::f32_to_u8_wrap(k1) << 8) |
+              ((uint32_t)csm::f32_to_u8_wrap(k2) << 16);
+        return ok;
+    };
+    auto fast_cand = [&](unsigned c) {
+        if (SHARP) return mono ? (c >> 12) == 2u : c == 0x0302u;
+        return mono ? (c >> 12) == 1u : c == 0x0201u;
+    };
     if (!eye_on || PT_DEV_IS(15)) {
         for (int q = tid; q < wt; q += PT_THREADS) put(q, img[o0 + q - s0]);
-    } else if (SHARP) {
-        for (int q = tid; q < wt; q += PT_THREADS) {
-            uint32_t rgb = 0;
-            const bool ok = eval_chain(true, q, rgb);
-            if (ok) put(q, rgb);
-            if (__any(!ok)) {
-                if (mono) hazard = hazard || !ok;  // (not seen: a fold-free tile's pixel failing the chain checks) -> row redo
-                else eval_generic(!ok, q);
-            }
-        }
     } else {
         for (int qa = tid; qa < wt; qa += 2 * PT_THREADS) {
             const bool vb = qa + PT_THREADS < wt;
             const int qb = vb ? qa + PT_THREADS : qa;
             const unsigned ca = cnt[qa], cb = cnt[qb];
             uint32_t ra = 0, rb = 0;
-            const bool da = fast_px(qa, fast_cand(ca), ca, ra);
-            const bool db = fast_px(qb, vb && fast_cand(cb), cb, rb);
+            bool da, db;
+            if (SHARP) {
+                da = fast_px2(qa, fast_cand(ca), ca, ra);
+                db = fast_px2(qb, vb && fast_cand(cb), cb, rb);
+            } else {
+                da = fast_px(qa, fast_cand(ca), ca, ra);
+                db = fast_px(qb, vb && fast_cand(cb), cb, rb);
+            }
             if (da) put(qa, ra);
             else plist[atomicAdd((unsigned*)&flags[2], 1u)] = (uint16_t)qa;
             if (db) put(qb, rb);
@@ -796,7 +841,7 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
             }
         }
     };
-    if (!SHARP) {
+    {
         __syncthreads();
         // the leftovers below usually fit one wave; the other three write the depth-map output meanwhile
         if (tid >= 64) store_depth(tid - 64, PT_THREADS - 64);
@@ -880,7 +925,6 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
             for (int q = tid; q < wt; q += PT_THREADS)
                 m[q] = ((int)res[3 * q] + (int)res[3 * q + 1] + (int)res[3 * q + 2]) == 0 ? 1.0f : 0.0f;
         }
-        if (SHARP) store_depth(tid, PT_THREADS);  // (soft: written during pass 2)
     }
     if (rec_wg) __builtin_amdgcn_s_waitcnt(0);
     stamp(9);
