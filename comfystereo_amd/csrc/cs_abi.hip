@@ -337,7 +337,8 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
             T.out_h = A.h; T.out_w = 2 * A.w;
             T.eye[0].xoff = 0; T.eye[0].yoff = 0; T.eye[1].xoff = A.w; T.eye[1].yoff = 0;
         }
-        if (fill == CS_FILL_POLYLINES_SOFT && halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 6)))
+        const bool used_polypoint = fill == CS_FILL_POLYLINES_SOFT && halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 6));
+        if (used_polypoint)
             e = launch_polypoint(T, halo, rowflag, stream);
         else
             e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, T, halo, rowflag, stream);
@@ -358,7 +359,13 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         e = launch_collect_rows(rowflag, (int)rows, count, list, stream);
         if (e != hipSuccess) return fail_hip(e, "flagged-row collection");
         A.row_list = list; A.row_count = count;
-    }
+        if (A.tilemap) {   // lazy depth blur: the row kernel reads complete rows of the blurred maps
+            if (!used_polypoint) return fail(CS_EHIP, "internal: lazy depth tiles without the point-owner kernel");
+            e = launch_lazy_rows(list, count, A.lazy_gray, const_cast<float*>(A.eye[0].depth), const_cast<float*>(A.eye[1].depth),
+                                 A.tilemap, A.stats, A.h, A.w, stream);
+            if (e != hipSuccess) return fail_hip(e, "lazy depth rows");
+        }
+    } else if (A.tilemap) return fail(CS_EHIP, "internal: lazy depth tiles without the tiled polylines path");
     if ((fill == CS_FILL_NONE || fill == CS_FILL_INVERSE || fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING) &&
         !dev_switch(CS_DEBUG_NO_TILE)) {
         // the halo-tile kernel where it applies; 'naive' hands the rows it cannot decide to the row kernel
@@ -443,7 +450,7 @@ int cs_output_shape(const cs_params* p, int* out_h, int* out_w, int* mask_h, int
 
 
 struct WsLayout {
-    size_t stats, rowflag, gray_src, gray, L, R, wl, wr, extra, total;
+    size_t stats, rowflag, gray_src, gray, L, R, wl, wr, tilemap, extra, total;
 };
 static WsLayout ws_layout(const cs_params* p) {
     WsLayout W;
@@ -452,12 +459,14 @@ static WsLayout ws_layout(const cs_params* p) {
     W.rowflag = o; o += rowflag_bytes(n * (size_t)p->h);
     bool resize = p->depth_h != p->h || p->depth_w != p->w;
     W.gray_src = o; if (resize) o += al256(n * (size_t)p->depth_h * p->depth_w * 4);
-    W.gray = o; o += al256(n * hw * 4);
     bool blur = p->depth_map_blur && p->depth_blur_strength > 0;  // strength <= 0: the reference returns the depth as is (:1194)
+    // (the gray buffer sits BETWEEN the blurred maps: the lazy-tile readers address either of a pair with a 32-bit offset)
     W.L = o; if (blur) o += al256(n * hw * 4);
+    W.gray = o; o += al256(n * hw * 4);
     W.R = o; if (blur) o += al256(n * hw * 4);
     W.wl = o; if (blur) o += al256(n * hw * 4);
     W.wr = o; if (blur) o += al256(n * hw * 4);
+    W.tilemap = o; if (blur) o += al256(blur_tilemap_bytes(p->n, p->h, p->w));
     W.extra = o;
     if (p->fill == CS_FILL_HYBRID_EDGE || p->fill == CS_FILL_HYBRID_EDGE_PLUS) o += al256(hybrid_workspace_bytes(p->n, p->h, p->w));
     if (p->fill == CS_FILL_GPU_WARP) o += al256(gpuwarp_workspace_bytes(p->n, p->h, p->w, p->batch_size, p->flags & 4));
@@ -508,12 +517,22 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
                        gpu_warp ? (p->batch_size > 0 ? (p->batch_size < n ? p->batch_size : n) : n) : 0, blur ? 1 : 0);
     const float* dL = gray;
     const float* dR = gray;
-    int scale_from_stats = 1;
+    int scale_from_stats = 1, lazy = 0;
+    const int halo = poly_halo(p->divergence * (1 + p->stereo_balance), p->divergence * (1 - p->stereo_balance), p->separation,
+                               p->stereo_offset_exponent, p->convergence_point, w);
     if (blur) {
         float* L = (float*)(ws + W.L);
         float* R = (float*)(ws + W.R);
+        // lazy tiles: when the point-owner polylines kernel is the consumer, the blur leaves the edge-free tiles (a scaled copy
+        // of the gray depth) unwritten and hands over the map of the tiles it did write
+        const int pt_variant = dev_switch(CS_DEBUG_PT_VARIANT);
+        const bool want_lazy = p->fill == CS_FILL_POLYLINES_SOFT && !(p->flags & 24) && halo <= polypoint_max_halo() &&
+                               (pt_variant == 0 || (pt_variant >= 3 && pt_variant <= 6)) && !dev_switch(CS_DEBUG_NO_TILE) &&
+                               !dev_switch(CS_DEBUG_BLUR_FULL_COPY) && p->mode != CS_MODE_LEFT_ONLY && p->mode != CS_MODE_ONLY_RIGHT &&
+                               al256((size_t)n * hw * 4) < (1ull << 32) - (1u << 20);
         rc = launch_blur(gray, n, h, w, p->depth_blur_strength, p->depth_blur_edge_threshold, p->depth_blur_strength, p->depth_blur_falloff,
-                         p->depth_blur_vert_smooth, L, R, (float*)(ws + W.wl), (float*)(ws + W.wr), stats, 1, stream);
+                         p->depth_blur_vert_smooth, L, R, (float*)(ws + W.wl), (float*)(ws + W.wr), stats, 1, stream,
+                         want_lazy ? (uint32_t*)(ws + W.tilemap) : nullptr, &lazy);
         if (rc) return fail(rc, "depth blur: unsupported parameters (strength must round to >= 1)");
         dL = L; dR = R;
         scale_from_stats = 0;  // the blur kernel already wrote scaled depth
@@ -552,6 +571,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     A.out_h = out_h; A.out_w = out_w;
     A.single = -1;
     A.dbg = dev_switch(CS_DEBUG_DBG);
+    if (lazy) { A.tilemap = (const uint32_t*)(ws + W.tilemap); A.lazy_gray = gray; A.tm_words = blur_tilemap_words(w); }
     switch (p->mode) {
     case CS_MODE_LEFT_RIGHT: A.eye[1].xoff = w; break;
     case CS_MODE_RIGHT_LEFT: A.eye[0].xoff = w; break;
@@ -563,11 +583,9 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     case CS_MODE_ONLY_RIGHT: A.single = 1; break;
     }
     if (p->fill == CS_FILL_HYBRID_EDGE || p->fill == CS_FILL_HYBRID_EDGE_PLUS) {
-        rc = launch_hybrid(A, ws + W.extra, stream, p->fill == CS_FILL_HYBRID_EDGE_PLUS,
-                           poly_halo(left_div, right_div, p->separation, p->stereo_offset_exponent, p->convergence_point, w));
+        rc = launch_hybrid(A, ws + W.extra, stream, p->fill == CS_FILL_HYBRID_EDGE_PLUS, halo);
         if (rc) return fail(rc, "hybrid_edge launch failed");
     } else {
-        int halo = poly_halo(left_div, right_div, p->separation, p->stereo_offset_exponent, p->convergence_point, w);
         rc = run_rows(p->fill, A, halo, (uint8_t*)(ws + W.rowflag), stream, A.anaglyph ? (uint8_t*)(ws + W.extra) : nullptr);
         if (rc) return rc;
     }

@@ -237,7 +237,9 @@ __global__ void __launch_bounds__(256) k_blur_edges(BlurArgs A, unsigned long lo
 // neighbours come from the adjacent lanes (shuffles; the first / last lane of a wave loads them).  A lane's four edge bits
 // form a nibble, eight lanes' nibbles a 32-bit half word (OR over xor-shuffles), two halves a word of the bit row.
 #define BLUR_ER4 8  // image rows per thread
-__global__ void __launch_bounds__(256) k_blur_edges4(BlurArgs A, unsigned long long* mask_l, unsigned long long* mask_r, int MW) {
+// `blk` (lazy mode, or null): per 64-column x 8-row block {min, max of the scaled depth, any edge bit, -} for k_blur_classify
+__global__ void __launch_bounds__(256) k_blur_edges4(BlurArgs A, unsigned long long* mask_l, unsigned long long* mask_r, int MW,
+                                                     float4* blk) {
     const int lane = threadIdx.x & 63;
     const int x = (blockIdx.x * 256 + threadIdx.x) * 4, yb = blockIdx.y * BLUR_ER4, frame = blockIdx.z;
     const int w = A.w, h = A.h;
@@ -264,6 +266,7 @@ __global__ void __launch_bounds__(256) k_blur_edges4(BlurArgs A, unsigned long l
         if (x + 4 >= w) nr[i] = 0.0f;  // (the neighbour lane holds zeros anyway; explicit for the frame's last column)
     }
     const int word = x >> 6;
+    unsigned long long anybits = 0ull;
 #pragma unroll
     for (int j = 0; j < BLUR_ER4; j++) {
         const int y = yb + j;
@@ -294,7 +297,23 @@ __global__ void __launch_bounds__(256) k_blur_edges4(BlurArgs A, unsigned long l
         if ((lane & 15) == 0 && word < MW && y < h) {
             mask_l[((size_t)frame * h + y) * MW + word] = (unsigned long long)hl | ((unsigned long long)hl_hi << 32);
             mask_r[((size_t)frame * h + y) * MW + word] = (unsigned long long)hr | ((unsigned long long)hr_hi << 32);
+            anybits |= (unsigned long long)(hl | hr) | ((unsigned long long)(hl_hi | hr_hi) << 32);
         }
+    }
+    if (blk) {
+        float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < BLUR_ER4; j++) {
+            if (yb + j < h && x < w) {   // (w % 4 == 0: a lane's four columns are inside together)
+                const float4 q = v[j + 1];
+                mn = fminf(fminf(mn, fminf(q.x, q.y)), fminf(q.z, q.w));
+                mx = fmaxf(fmaxf(mx, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+        if ((lane & 15) == 0 && word < MW && yb < h)
+            blk[((size_t)frame * gridDim.y + blockIdx.y) * MW + word] = make_float4(mn, mx, anybits ? 1.0f : 0.0f, 0.0f);
     }
 }
 
@@ -395,6 +414,53 @@ __global__ void __launch_bounds__(256) k_blur_copy(BlurArgs A, const unsigned lo
             *reinterpret_cast<float4*>(A.out_r + off) = o;
             mn = fminf(fminf(mn, fminf(o.x, o.y)), fminf(o.z, o.w));
             mx = fmaxf(fmaxf(mx, fmaxf(o.x, o.y)), fmaxf(o.z, o.w));
+        }
+    }
+    if (A.stats_rw) {
+        uint32_t* st = A.stats_rw + frame * ST_WORDS;
+        block_minmax_update(mn, mx, &st[ST_L_MIN], &st[ST_L_MAX], red);
+        block_minmax_update(mn, mx, &st[ST_R_MIN], &st[ST_R_MAX], red);
+    }
+}
+
+// Lazy mode (the consumer reads edge-free tiles from the gray depth itself, RowArgs::tilemap): nothing is copied, so the
+// classification works from k_blur_edges4's block summaries alone -- one thread per tile: edge bits within reach (exact
+// test on the bit rows, only inside blocks that have bits) -> worklist + tile map; otherwise the tile's min / max joins the
+// frame's output statistics.  No pass over the depth.
+__global__ void __launch_bounds__(256) k_blur_classify(BlurArgs A, const unsigned long long* mask_l, const unsigned long long* mask_r,
+                                                       int MW, const float4* blk, int HB, uint32_t* work_count, uint32_t* worklist,
+                                                       uint32_t* tilemap, int tm_words) {
+    __shared__ float red[2 * 16];
+    const int w = A.w, h = A.h, v = A.vert, R = A.radius, frame = blockIdx.y;
+    const int gx = (w + BLUR_TW - 1) / BLUR_TW, gy = (h + BLUR_TR - 1) / BLUR_TR;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const bool live = t < gx * gy;
+    const int ty = live ? t / gx : 0, tx = live ? t - ty * gx : 0;
+    const int x0 = tx * BLUR_TW, y0 = ty * BLUR_TR;
+    const int ya = max(y0 - v, 0), yz = min(y0 + BLUR_TR - 1 + v, h - 1);          // rows within reach
+    const int xa = max(x0 - R, 0), xz = min(x0 + BLUR_TW - 1 + R, w - 1);          // columns within reach
+    bool edge = live && A.fall_mode == 5;
+    const float4* fb = blk + (size_t)frame * HB * MW;
+    if (live && !edge) {
+        for (int b = ya / BLUR_ER4; b <= yz / BLUR_ER4 && !edge; b++)
+            for (int wi = xa >> 6; wi <= (xz >> 6) && !edge; wi++) {
+                if (fb[(size_t)b * MW + wi].z == 0.0f) continue;
+                const int lo = max(xa, wi * 64) - wi * 64, hi = min(xz, wi * 64 + 63) - wi * 64;
+                const unsigned long long colmask = (~0ull >> (63 - hi)) & (~0ull << lo);
+                for (int y = max(ya, b * BLUR_ER4); y <= min(yz, b * BLUR_ER4 + BLUR_ER4 - 1); y++) {
+                    const size_t ro = ((size_t)frame * h + y) * MW + wi;
+                    if ((mask_l[ro] | mask_r[ro]) & colmask) { edge = true; break; }
+                }
+            }
+    }
+    float mn = INFINITY, mx = -INFINITY;
+    if (live && edge) {
+        worklist[atomicAdd(work_count, 1u)] = ((uint32_t)frame << 20) | ((uint32_t)ty << 10) | (uint32_t)tx;
+        atomicOr(&tilemap[((size_t)frame * gy + ty) * tm_words + (tx >> 5)], 1u << (tx & 31));
+    } else if (live) {
+        for (int b = y0 / BLUR_ER4; b <= min(y0 + BLUR_TR - 1, h - 1) / BLUR_ER4; b++) {
+            const float4 q = fb[(size_t)b * MW + tx];
+            mn = fminf(mn, q.x); mx = fmaxf(mx, q.y);
         }
     }
     if (A.stats_rw) {
@@ -637,6 +703,39 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
     }
 }
 
+int blur_tilemap_words(int w) { return ((w + BLUR_TW - 1) / BLUR_TW + 31) / 32 + 1; }
+size_t blur_tilemap_bytes(int n, int h, int w) {
+    return (size_t)n * ((h + BLUR_TR - 1) / BLUR_TR) * blur_tilemap_words(w) * 4;
+}
+
+// flagged rows of the tiled warp kernels are redone by row kernels that read complete depth rows: write the lazy tiles' part
+__global__ void __launch_bounds__(256) k_lazy_rows(const uint32_t* list, const uint32_t* count, const float* gray, float* out_l,
+                                                   float* out_r, const uint32_t* tilemap, const uint32_t* stats, int h, int w,
+                                                   int tm_words) {
+    const uint32_t nrows = *count;
+    const int gy = (h + BLUR_TR - 1) / BLUR_TR;
+    for (uint32_t i = blockIdx.x; i < nrows; i += gridDim.x) {
+        const uint32_t fr = list[i];
+        const int frame = (int)(fr / (uint32_t)h), row = (int)(fr - (uint32_t)frame * (uint32_t)h);
+        const float scale = stats[frame * ST_WORDS + ST_SCALE255] ? 255.0f : 1.0f;
+        const uint32_t* tm = tilemap + ((size_t)frame * gy + row / BLUR_TR) * tm_words;
+        const size_t base = (size_t)fr * w;
+        for (int x = threadIdx.x; x < w; x += 256) {
+            const int t = x / BLUR_TW;
+            if (!((tm[t >> 5] >> (t & 31)) & 1u)) {
+                const float v = gray[base + x] * scale;
+                out_l[base + x] = v; out_r[base + x] = v;
+            }
+        }
+    }
+}
+hipError_t launch_lazy_rows(const uint32_t* list, const uint32_t* count, const float* gray, float* out_l, float* out_r,
+                            const uint32_t* tilemap, const uint32_t* stats, int h, int w, hipStream_t stream) {
+    hipLaunchKernelGGL(k_lazy_rows, dim3(1024), dim3(256), 0, stream, list, count, gray, out_l, out_r, tilemap, stats, h, w,
+                       blur_tilemap_words(w));
+    return hipGetLastError();
+}
+
 static size_t blur_fused_lds(int v, int R, int bs) {
     int WR = BLUR_TR + 2 * v, EW = BLUR_TW + 2 * R, NW = (EW + 63) >> 6;
     (void)EW;
@@ -646,7 +745,8 @@ static size_t blur_fused_lds(int v, int R, int bs) {
 
 int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double mask_width,
                 double falloff, int vert, float* out_l, float* out_r, float* wl, float* wr, uint32_t* stats, int node_path,
-                hipStream_t stream) {
+                hipStream_t stream, uint32_t* tilemap, int* lazy_used) {
+    if (lazy_used) *lazy_used = 0;
     BlurArgs A;
     A.depth = depth; A.n = n; A.h = h; A.w = w;
     A.stats = node_path ? stats : nullptr;
@@ -669,19 +769,33 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
         const int MW = (w + 63) / 64;
         unsigned long long* mask_l = reinterpret_cast<unsigned long long*>(wl);
         unsigned long long* mask_r = reinterpret_cast<unsigned long long*>(wr);
+        // edge-free tiles are copied by k_blur_copy; the others reach k_blur_fused through a worklist behind the bit rows
+        const int gy = (h + BLUR_TR - 1) / BLUR_TR, gx = (w + BLUR_TW - 1) / BLUR_TW, HB = (h + BLUR_ER4 - 1) / BLUR_ER4;
+        const size_t mask_bytes = ((size_t)n * h * MW * 8 + 255) & ~(size_t)255, list_bytes = 256 + (size_t)n * gy * gx * 4;
+        const size_t blk_bytes = (size_t)n * HB * MW * 16;
+        const bool listed = (w & 3) == 0 && gx < 1024 && gy < 1024 && n < 4096 && mask_bytes + list_bytes <= (size_t)n * h * w * 4;
+        // lazy mode: block summaries behind the second bit-row buffer
+        const bool lazy = tilemap && node_path && listed && !dev_switch(CS_DEBUG_BLUR_EDGES_SCALAR) && BLUR_TR % BLUR_ER4 == 0 &&
+                          mask_bytes + blk_bytes <= (size_t)n * h * w * 4;
+        float4* blk = lazy ? reinterpret_cast<float4*>(reinterpret_cast<char*>(wr) + mask_bytes) : nullptr;
         if ((w & 3) == 0 && !dev_switch(CS_DEBUG_BLUR_EDGES_SCALAR))
-            hipLaunchKernelGGL(k_blur_edges4, dim3((w + 1023) / 1024, (h + BLUR_ER4 - 1) / BLUR_ER4, n), dim3(256), 0, stream, A, mask_l, mask_r, MW);
+            hipLaunchKernelGGL(k_blur_edges4, dim3((w + 1023) / 1024, HB, n), dim3(256), 0, stream, A, mask_l, mask_r, MW, blk);
         else
             hipLaunchKernelGGL(k_blur_edges, dim3((w + 255) / 256, (h + BLUR_ER - 1) / BLUR_ER, n), dim3(256), 0, stream, A, mask_l, mask_r, MW);
-        // edge-free tiles are copied by k_blur_copy; the others reach k_blur_fused through a worklist behind the bit rows
-        const int gy = (h + BLUR_TR - 1) / BLUR_TR, gx = (w + BLUR_TW - 1) / BLUR_TW;
-        const size_t mask_bytes = ((size_t)n * h * MW * 8 + 255) & ~(size_t)255, list_bytes = 256 + (size_t)n * gy * gx * 4;
-        if ((w & 3) == 0 && gx < 1024 && gy < 1024 && n < 4096 && mask_bytes + list_bytes <= (size_t)n * h * w * 4) {
+        if (listed) {
             uint32_t* work_count = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(wl) + mask_bytes);
             uint32_t* worklist = work_count + 64;
             if (hipMemsetAsync(work_count, 0, 4, stream) != hipSuccess) return CS_EHIP;
-            hipLaunchKernelGGL(k_blur_copy, dim3((gx + BLUR_CW - 1) / BLUR_CW, gy, n), dim3(256), 0, stream, A,
-                               (const unsigned long long*)mask_l, (const unsigned long long*)mask_r, MW, work_count, worklist);
+            if (lazy) {
+                if (hipMemsetAsync(tilemap, 0, blur_tilemap_bytes(n, h, w), stream) != hipSuccess) return CS_EHIP;
+                if (lazy_used) *lazy_used = 1;
+                hipLaunchKernelGGL(k_blur_classify, dim3((gx * gy + 255) / 256, n), dim3(256), 0, stream, A,
+                                   (const unsigned long long*)mask_l, (const unsigned long long*)mask_r, MW, (const float4*)blk, HB,
+                                   work_count, worklist, tilemap, blur_tilemap_words(w));
+            } else {
+                hipLaunchKernelGGL(k_blur_copy, dim3((gx + BLUR_CW - 1) / BLUR_CW, gy, n), dim3(256), 0, stream, A,
+                                   (const unsigned long long*)mask_l, (const unsigned long long*)mask_r, MW, work_count, worklist);
+            }
             const size_t total = (size_t)n * gy * gx;
             const int pg = (int)(total < 2048 ? total : 2048);
             hipLaunchKernelGGL(k_blur_fused, dim3(pg), dim3(256), ldsF, stream, A, (const unsigned long long*)mask_l,

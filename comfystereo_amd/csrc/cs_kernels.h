@@ -49,6 +49,12 @@ struct RowArgs {
     // hybrid_edge scratch (HBM): splat result of every eye, written by k_hybrid_splat
     uint8_t* hyb_base;  // [n][neyes][h][w][3]
     uint8_t* hyb_mask;  // [n][neyes][h][w]
+    // lazy depth blur (cs_blur.hip): tiles of 64 x 32 pixels without an edge in reach are NOT written to the blurred depth
+    // maps eye[].depth; bit (tile column) of tilemap[(frame * tile_rows + tile_row) * tm_words ..] is set for the tiles that
+    // are, every other pixel is lazy_gray * (x255 scale of the frame).  Null: the blurred maps are complete.
+    const uint32_t* tilemap;
+    const float* lazy_gray;
+    int tm_words;
     const uint32_t* row_list;     // or null: process only these rows (frame * h + row), *row_count of them (tiled-path fallback)
     const uint32_t* row_count;
     int dbg;            // development only (cs_debug_set(CS_DEBUG_DBG, n)): see dev_switch() below
@@ -89,7 +95,14 @@ hipError_t launch_depth_codes(const float* depth, int n, int h, int w, const uin
 // whose stats say so, and the per-frame min/max of both outputs are accumulated into stats.
 int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double mask_width,
                 double falloff, int vert, float* out_l, float* out_r, float* wl, float* wr, uint32_t* stats, int node_path,
-                hipStream_t stream);
+                hipStream_t stream, uint32_t* tilemap = nullptr, int* lazy_used = nullptr);
+// lazy mode (tilemap != nullptr, zeroed by launch_blur): edge-free tiles are left unwritten and the tile map says which tiles
+// were written (RowArgs::tilemap); *lazy_used = 0 when the parameters took a path that writes everything.
+int blur_tilemap_words(int w);                 // 32-bit words per tile row, including the pad word the readers rely on
+size_t blur_tilemap_bytes(int n, int h, int w);
+// the rows of `list` (frame * h + row, *count of them) complete in out_l / out_r: gray * scale for the unwritten tiles
+hipError_t launch_lazy_rows(const uint32_t* list, const uint32_t* count, const float* gray, float* out_l, float* out_r,
+                            const uint32_t* tilemap, const uint32_t* stats, int h, int w, hipStream_t stream);
 
 // cs_rowwarp.hip (hybrid_edge: k_hybrid_splat + the fill pass of k_rowwarp)
 size_t hybrid_workspace_bytes(int n, int h, int w);

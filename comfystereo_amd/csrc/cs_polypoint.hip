@@ -70,6 +70,10 @@ struct PolyPointArgs {
     int out_h, out_w;
     uint8_t* rowflag;
     int dbg;
+    // lazy depth blur (RowArgs::tilemap): the blurred maps only hold the tiles the map names, the rest is gray * scale
+    const uint32_t* tilemap;
+    const float* gray;
+    int tm_words;
 };
 
 struct F3 { float x, y, z; };
@@ -196,12 +200,50 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     float dpre[SLOTS];
     F3 cpre[SLOTS];
     B3 cpre8[SLOTS];
+    // lazy depth blur: bit (t & 31) of `zbits` covers tile column t of the staged range (<= 32 tiles of 64 columns); the lane
+    // reads the lower of the two buffers, or `zdelta` bytes further up when its tile's bit is set, and multiplies what it
+    // read by 1 (blurred map: already scaled) or by the frame's x255 scale (gray) -- all selected with bit operations
+    const bool lazy = A.tilemap != nullptr;
+    const char* dbase = drow;
+    uint32_t zbits = 0, zdelta = 0, zmul_set = 0x3f800000u, zmul_clr = 0x3f800000u;
+    uint32_t zmul[SLOTS];
+    if (lazy) {
+        const char* const grow = reinterpret_cast<const char*>(A.gray + rowpix + s0);
+        const uint32_t* tm = A.tilemap + ((uint32_t)frame * (uint32_t)((h + 31) >> 5) + (uint32_t)(row >> 5)) * (uint32_t)A.tm_words;
+        const int t0 = s0 >> 6;
+        const uint32_t w0 = tm[t0 >> 5], w1 = tm[(t0 >> 5) + 1];   // (the map rows end with a pad word)
+        const uint32_t sc = st[ST_SCALE255] ? 0x437f0000u /* 255.0f */ : 0x3f800000u;
+        // the image loads do not depend on the map: they go out while the scalar loads above are in flight
 #pragma unroll
-    for (int k = 0; k < SLOTS; k++) {
-        const uint32_t jc = (uint32_t)min(tid + k * NT, ns - 1);
-        dpre[k] = *reinterpret_cast<const float*>(drow + 4u * jc);
-        if (OUT == PO_ASD) cpre8[k] = *reinterpret_cast<const B3*>(irow8 + 3u * jc);
-        else cpre[k] = *reinterpret_cast<const F3*>(irow + 12u * jc);
+        for (int k = 0; k < SLOTS; k++) {
+            const uint32_t jc = (uint32_t)min(tid + k * NT, ns - 1);
+            if (OUT == PO_ASD) cpre8[k] = *reinterpret_cast<const B3*>(irow8 + 3u * jc);
+            else cpre[k] = *reinterpret_cast<const F3*>(irow + 12u * jc);
+        }
+        const uint32_t low = (1u << (t0 & 31)) - 1u;                // tiles of the second word wrap into the low bits
+        const uint32_t bits = (w0 & ~low) | (w1 & low);             // set: the tile was written to the blurred map
+        const bool gray_low = grow < drow;
+        dbase = gray_low ? grow : drow;
+        zdelta = (uint32_t)(gray_low ? drow - grow : grow - drow);
+        zbits = gray_low ? bits : ~bits;
+        zmul_set = gray_low ? 0x3f800000u : sc;
+        zmul_clr = gray_low ? sc : 0x3f800000u;
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) {
+            const uint32_t jc = (uint32_t)min(tid + k * NT, ns - 1);
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)zbits, ((uint32_t)s0 + jc) >> 6, 1u);   // 0 / ~0
+            zmul[k] = (m & zmul_set) | (~m & zmul_clr);
+            dpre[k] = *reinterpret_cast<const float*>(dbase + (4u * jc + (m & zdelta)));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) {
+            const uint32_t jc = (uint32_t)min(tid + k * NT, ns - 1);
+            zmul[k] = 0x3f800000u;
+            dpre[k] = *reinterpret_cast<const float*>(drow + 4u * jc);
+            if (OUT == PO_ASD) cpre8[k] = *reinterpret_cast<const B3*>(irow8 + 3u * jc);
+            else cpre[k] = *reinterpret_cast<const F3*>(irow + 12u * jc);
+        }
     }
     const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
     const float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
@@ -218,6 +260,10 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         flags[tid] = (int)(0x7fffffffu * ((is_min >> tid) & 1u)) | -(int)((is_max >> tid) & 1u);
     }
     __syncthreads();  // barrier 0: tables, flags
+    if (lazy) {
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) dpre[k] *= __builtin_bit_cast(float, zmul[k]);
+    }
 
     const float o0f = (float)o0, o1f = (float)(o0 + wt);   // tile = [o0f, o1f)
     bool hazard = false;
@@ -933,6 +979,7 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     A.out_h = R.out_h; A.out_w = R.out_w;
     A.rowflag = rowflag;
     A.dbg = R.dbg;
+    A.tilemap = R.tilemap; A.gray = R.lazy_gray; A.tm_words = R.tm_words;
     const int out = R.out_u8 ? PO_ASD : (R.stereo_is_u8 ? (R.no_mask ? PO_U8NM : PO_U8) : PO_F32);
     if ((out == PO_ASD) != (R.image_u8 != nullptr)) return hipErrorInvalidValue;  // uint8 image in <=> uint8 image out
     if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31) || A.h > 8 * 65535 || 2 * A.n > 65535)

@@ -1,0 +1,97 @@
+"""Lazy depth-blur tiles (cs_blur.hip k_blur_classify + the tile map read by the point-owner polylines kernel).
+
+With the depth blur on and polylines_soft as the technique, tiles of the blurred depth maps without an edge in reach are
+not written: the warp kernel reads gray * scale for them (reference stereoimage_generation.py:1171-1251 blends
+w*blur + (1-w)*depth with w == 0 there).  cs_debug_set(CS_DEBUG_BLUR_FULL_COPY, 1) writes every tile instead: both forms
+must give identical bits, and equal the oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import node_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from comfystereo_amd import engine as e
+    assert torch.cuda.is_available()
+    return e
+
+
+def cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run(engine, img, depth, mode, div=6.0, sep=0.0, **kw):
+    out = engine.generate(cuda(img), cuda(depth), div, sep, mode, 0.1, 0.5, 2.0, "polylines_soft", 20.0, 20.0, True,
+                          depth_blur_falloff=2.0, depth_blur_vert_smooth=6, **kw)
+    return [o.cpu().numpy() for o in out]
+
+
+@pytest.mark.parametrize("mode", ["left-right", "top-bottom", "red-cyan-anaglyph", "right-left"])
+@pytest.mark.parametrize("kind", ["stepped", "blobs"])
+def test_lazy_equals_full_copy_and_oracle(engine, dev_switch, mode, kind):
+    n, h, w = 2, 200, 1284      # 21 tile columns (the last one partial), 7 tile rows (the last one partial)
+    img = synth.image_f32(n, h, w, seed=3)
+    depth = synth.depth_batch(kind, n, h, w, channels=3)
+    lazy = run(engine, img, depth, mode)
+    dev_switch("blur_full_copy", 1)
+    full = run(engine, img, depth, mode)
+    for a, b in zip(lazy, full):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    want = node_oracle.generate(img, depth, 6.0, 0.0, mode, 0.1, 0.5, 2.0, "Fill - Polylines Soft", 20.0, 20.0, True,
+                                depth_blur_falloff=2.0, depth_blur_vert_smooth=6)
+    for k in range(4):
+        assert np.array_equal(lazy[k], want[k]), (mode, kind, k)
+
+
+def test_lazy_with_unit_range_depth_scaled_by_255(engine, dev_switch):
+    """depth in 0..1: the frame is multiplied by 255 (reference :1504); lazy tiles apply that factor in the warp kernel."""
+    n, h, w = 2, 96, 2048 + 64
+    img = synth.image_f32(n, h, w, seed=9)
+    depth = synth.depth_batch("stepped", n, h, w, channels=3)
+    depth[1] *= 255.0   # one frame of each kind in the batch
+    lazy = run(engine, img, depth, "left-right")
+    dev_switch("blur_full_copy", 1)
+    full = run(engine, img, depth, "left-right")
+    for a, b in zip(lazy, full):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    want = node_oracle.generate(img, depth, 6.0, 0.0, "left-right", 0.1, 0.5, 2.0, "Fill - Polylines Soft", 20.0, 20.0, True,
+                                depth_blur_falloff=2.0, depth_blur_vert_smooth=6)
+    for k in range(4):
+        assert np.array_equal(lazy[k], want[k]), k
+
+
+def test_lazy_rows_the_tile_kernel_flags_are_completed(engine, dev_switch):
+    """Depth clipped to 0 / 1 around convergence 0.5 ties everywhere: every row goes to the general row kernel, which reads
+    complete depth rows -- k_lazy_rows fills in the unwritten tiles first."""
+    n, h, w = 1, 70, 1600
+    img = synth.image_f32(n, h, w, seed=4)
+    d = (synth.blobs(h, w, seed=2) > 0.5).astype(np.float32)
+    depth = np.repeat(d[None, :, :, None], 3, axis=3)
+    lazy = run(engine, img, depth, "left-right", div=3.0)
+    dev_switch("blur_full_copy", 1)
+    full = run(engine, img, depth, "left-right", div=3.0)
+    for a, b in zip(lazy, full):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    want = node_oracle.generate(img, depth, 3.0, 0.0, "left-right", 0.1, 0.5, 2.0, "Fill - Polylines Soft", 20.0, 20.0, True,
+                                depth_blur_falloff=2.0, depth_blur_vert_smooth=6)
+    for k in range(4):
+        assert np.array_equal(lazy[k], want[k]), k
+
+
+def test_lazy_falloff_zero_marks_every_tile(engine, dev_switch):
+    """falloff 0: every weight is 1, no tile is a copy -- the map is full and nothing is read from the gray depth."""
+    n, h, w = 1, 64, 640
+    img = synth.image_f32(n, h, w, seed=6)
+    depth = synth.depth_batch("blobs", n, h, w, channels=3)
+    a = engine.generate(cuda(img), cuda(depth), 5.0, 0.0, "left-right", 0.0, 0.5, 2.0, "polylines_soft", 12.0, 12.0, True,
+                        depth_blur_falloff=0.0, depth_blur_vert_smooth=3)
+    want = node_oracle.generate(img, depth, 5.0, 0.0, "left-right", 0.0, 0.5, 2.0, "Fill - Polylines Soft", 12.0, 12.0, True,
+                                depth_blur_falloff=0.0, depth_blur_vert_smooth=3)
+    for k in range(4):
+        assert np.array_equal(a[k].cpu().numpy(), want[k]), k
