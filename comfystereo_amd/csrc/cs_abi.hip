@@ -337,8 +337,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
             T.out_h = A.h; T.out_w = 2 * A.w;
             T.eye[0].xoff = 0; T.eye[0].yoff = 0; T.eye[1].xoff = A.w; T.eye[1].yoff = 0;
         }
-        const bool used_polypoint = fill == CS_FILL_POLYLINES_SOFT && halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 6));
-        if (used_polypoint)
+        if (fill == CS_FILL_POLYLINES_SOFT && halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 6)))
             e = launch_polypoint(T, halo, rowflag, stream);
         else
             e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, T, halo, rowflag, stream);
@@ -359,13 +358,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         e = launch_collect_rows(rowflag, (int)rows, count, list, stream);
         if (e != hipSuccess) return fail_hip(e, "flagged-row collection");
         A.row_list = list; A.row_count = count;
-        if (A.tilemap) {   // lazy depth blur: the row kernel reads complete rows of the blurred maps
-            if (!used_polypoint) return fail(CS_EHIP, "internal: lazy depth tiles without the point-owner kernel");
-            e = launch_lazy_rows(list, count, A.lazy_gray, const_cast<float*>(A.eye[0].depth), const_cast<float*>(A.eye[1].depth),
-                                 A.tilemap, A.stats, A.h, A.w, stream);
-            if (e != hipSuccess) return fail_hip(e, "lazy depth rows");
-        }
-    } else if (A.tilemap) return fail(CS_EHIP, "internal: lazy depth tiles without the tiled polylines path");
+    }
     if ((fill == CS_FILL_NONE || fill == CS_FILL_INVERSE || fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING) &&
         !dev_switch(CS_DEBUG_NO_TILE)) {
         // the halo-tile kernel where it applies; 'naive' hands the rows it cannot decide to the row kernel
@@ -384,6 +377,13 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
             if (e != hipSuccess) return fail_hip(e, "flagged-row collection");
             A.row_list = list; A.row_count = count;
         } else if (e != hipErrorNotSupported) return fail_hip(e, "forward tile kernel launch");
+    }
+    if (A.tilemap) {
+        // lazy depth-blur tiles: the row kernels read complete rows of the blurred maps -- fill in the unwritten tiles of the
+        // rows they are about to visit (the rows a tile kernel flagged; every row when no tile kernel took the call)
+        hipError_t e = launch_lazy_rows(A.row_list, A.row_count, A.n * A.h, A.lazy_gray, const_cast<float*>(A.eye[0].depth),
+                                        const_cast<float*>(A.eye[1].depth), A.tilemap, A.stats, A.h, A.w, stream);
+        if (e != hipSuccess) return fail_hip(e, "lazy depth rows");
     }
     hipError_t e = launch_rowwarp(fill, A, threads_for(fill, A.w), stream);
     if (e != hipSuccess) return fail_hip(e, "row kernel launch");
@@ -523,12 +523,13 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     if (blur) {
         float* L = (float*)(ws + W.L);
         float* R = (float*)(ws + W.R);
-        // lazy tiles: when the point-owner polylines kernel is the consumer, the blur leaves the edge-free tiles (a scaled copy
-        // of the gray depth) unwritten and hands over the map of the tiles it did write
-        const int pt_variant = dev_switch(CS_DEBUG_PT_VARIANT);
-        const bool want_lazy = p->fill == CS_FILL_POLYLINES_SOFT && !(p->flags & 24) && halo <= polypoint_max_halo() &&
-                               (pt_variant == 0 || (pt_variant >= 3 && pt_variant <= 6)) && !dev_switch(CS_DEBUG_NO_TILE) &&
-                               !dev_switch(CS_DEBUG_BLUR_FULL_COPY) && p->mode != CS_MODE_LEFT_ONLY && p->mode != CS_MODE_ONLY_RIGHT &&
+        // lazy tiles: the tile kernels (cs_polypoint / cs_polytile / cs_fwdtile) read the edge-free tiles of the blurred depth
+        // -- a scaled copy of the gray depth -- from the gray depth itself, so the blur leaves them unwritten and hands over
+        // the map of the tiles it did write; run_rows completes the rows that still go to a row kernel
+        const bool tile_fill = p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP || p->fill == CS_FILL_NONE ||
+                               p->fill == CS_FILL_INVERSE || p->fill == CS_FILL_NAIVE || p->fill == CS_FILL_NAIVE_INTERPOLATING;
+        const bool want_lazy = tile_fill && !(p->flags & 24) && !dev_switch(CS_DEBUG_NO_TILE) && !dev_switch(CS_DEBUG_BLUR_FULL_COPY) &&
+                               p->mode != CS_MODE_LEFT_ONLY && p->mode != CS_MODE_ONLY_RIGHT &&
                                al256((size_t)n * hw * 4) < (1ull << 32) - (1u << 20);
         rc = launch_blur(gray, n, h, w, p->depth_blur_strength, p->depth_blur_edge_threshold, p->depth_blur_strength, p->depth_blur_falloff,
                          p->depth_blur_vert_smooth, L, R, (float*)(ws + W.wl), (float*)(ws + W.wr), stats, 1, stream,

@@ -709,13 +709,13 @@ size_t blur_tilemap_bytes(int n, int h, int w) {
 }
 
 // flagged rows of the tiled warp kernels are redone by row kernels that read complete depth rows: write the lazy tiles' part
-__global__ void __launch_bounds__(256) k_lazy_rows(const uint32_t* list, const uint32_t* count, const float* gray, float* out_l,
-                                                   float* out_r, const uint32_t* tilemap, const uint32_t* stats, int h, int w,
-                                                   int tm_words) {
-    const uint32_t nrows = *count;
+__global__ void __launch_bounds__(256) k_lazy_rows(const uint32_t* list, const uint32_t* count, int total, const float* gray,
+                                                   float* out_l, float* out_r, const uint32_t* tilemap, const uint32_t* stats,
+                                                   int h, int w, int tm_words) {
+    const uint32_t nrows = list ? *count : (uint32_t)total;
     const int gy = (h + BLUR_TR - 1) / BLUR_TR;
     for (uint32_t i = blockIdx.x; i < nrows; i += gridDim.x) {
-        const uint32_t fr = list[i];
+        const uint32_t fr = list ? list[i] : i;
         const int frame = (int)(fr / (uint32_t)h), row = (int)(fr - (uint32_t)frame * (uint32_t)h);
         const float scale = stats[frame * ST_WORDS + ST_SCALE255] ? 255.0f : 1.0f;
         const uint32_t* tm = tilemap + ((size_t)frame * gy + row / BLUR_TR) * tm_words;
@@ -729,9 +729,9 @@ __global__ void __launch_bounds__(256) k_lazy_rows(const uint32_t* list, const u
         }
     }
 }
-hipError_t launch_lazy_rows(const uint32_t* list, const uint32_t* count, const float* gray, float* out_l, float* out_r,
+hipError_t launch_lazy_rows(const uint32_t* list, const uint32_t* count, int total, const float* gray, float* out_l, float* out_r,
                             const uint32_t* tilemap, const uint32_t* stats, int h, int w, hipStream_t stream) {
-    hipLaunchKernelGGL(k_lazy_rows, dim3(1024), dim3(256), 0, stream, list, count, gray, out_l, out_r, tilemap, stats, h, w,
+    hipLaunchKernelGGL(k_lazy_rows, dim3(list ? 1024 : 4096), dim3(256), 0, stream, list, count, total, gray, out_l, out_r, tilemap, stats, h, w,
                        blur_tilemap_words(w));
     return hipGetLastError();
 }

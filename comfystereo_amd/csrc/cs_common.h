@@ -125,4 +125,38 @@ __device__ __forceinline__ void block_minmax_update(float mn, float mx, uint32_t
     __syncthreads();
 }
 
+// ---- lazy depth-blur tiles (cs_blur.hip k_blur_classify, RowArgs::tilemap) ------------------------------------------
+// The blurred depth map of an eye only holds the 64 x 32 tiles the map names; everywhere else the value is
+// gray * (the frame's x255 scale).  A tile kernel that stages the columns [s0, s0 + 2048) of one row sets a selector up
+// once per workgroup (scalar work) and then selects per lane with three bit operations: the lane reads the LOWER of the
+// two buffers, `delta` bytes further up when the bit of its tile is set, and multiplies by 1 (blurred: already scaled) or
+// by the scale (gray).  The two buffers must lie within 4 GB of each other (checked on the host).
+struct LazySel {
+    const char* base;                    // row start (column s0) in the lower buffer
+    uint32_t bits, delta, mul_set, mul_clr;
+};
+__device__ __forceinline__ LazySel lazy_select(const uint32_t* tilemap, int tm_words, int frame, int h, int row, int s0,
+                                               const char* blurred_row, const char* gray_row, uint32_t scale255) {
+    const uint32_t* tm = tilemap + ((uint32_t)frame * (uint32_t)((h + 31) >> 5) + (uint32_t)(row >> 5)) * (uint32_t)tm_words;
+    const int t0 = s0 >> 6;
+    const uint32_t w0 = tm[t0 >> 5], w1 = tm[(t0 >> 5) + 1];   // (the map rows end with a pad word)
+    const uint32_t low = (1u << (t0 & 31)) - 1u;                // tiles of the second word wrap into the low bits
+    const uint32_t bits = (w0 & ~low) | (w1 & low);             // bit (t & 31) set: tile t was written to the blurred map
+    const uint32_t sc = scale255 ? 0x437f0000u /* 255.0f */ : 0x3f800000u;
+    const bool gray_low = gray_row < blurred_row;
+    LazySel Z;
+    Z.base = gray_low ? gray_row : blurred_row;
+    Z.delta = (uint32_t)(gray_low ? blurred_row - gray_row : gray_row - blurred_row);
+    Z.bits = gray_low ? bits : ~bits;
+    Z.mul_set = gray_low ? 0x3f800000u : sc;
+    Z.mul_clr = gray_low ? sc : 0x3f800000u;
+    return Z;
+}
+// depth of column `col` = s0 + j (not yet multiplied by `mul`)
+__device__ __forceinline__ float lazy_load(const LazySel& Z, uint32_t col, uint32_t j, float& mul) {
+    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)Z.bits, col >> 6, 1u);   // 0 / ~0
+    mul = __builtin_bit_cast(float, (m & Z.mul_set) | (~m & Z.mul_clr));
+    return *reinterpret_cast<const float*>(Z.base + (4u * j + (m & Z.delta)));
+}
+
 }  // namespace cs

@@ -46,6 +46,7 @@ struct FwdTileArgs {
     float* mask; float* depth_l; float* depth_r;
     int out_h, out_w;
     int dbg;
+    const uint32_t* tilemap; const float* gray; int tm_words;   // lazy depth-blur tiles (cs_common.h) or null
 };
 
 struct FwF3 { float x, y, z; };
@@ -86,12 +87,33 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
     const char* const drow1 = reinterpret_cast<const char*>(A.eye[1].depth + rowpix + s0);
     FwF3 cpre[SLOTS];
     float dpre[2][SLOTS];
+    if (A.tilemap) {   // lazy depth-blur tiles: edge-free tiles come from the gray depth
+        const char* const grow = reinterpret_cast<const char*>(A.gray + rowpix + s0);
+        const uint32_t s255 = st[ST_SCALE255];
+        const LazySel Z0 = lazy_select(A.tilemap, A.tm_words, frame, h, row, s0, drow0, grow, s255);
+        const LazySel Z1 = lazy_select(A.tilemap, A.tm_words, frame, h, row, s0, drow1, grow, s255);
+        float mul[2][SLOTS];
 #pragma unroll
-    for (int k = 0; k < SLOTS; k++) {
-        const uint32_t jc = (uint32_t)min(tid + k * NT, ns - 1);
-        cpre[k] = *reinterpret_cast<const FwF3*>(irow + 12u * jc);
-        dpre[0][k] = *reinterpret_cast<const float*>(drow0 + 4u * jc);
-        dpre[1][k] = *reinterpret_cast<const float*>(drow1 + 4u * jc);
+        for (int k = 0; k < SLOTS; k++) {
+            const uint32_t jc = (uint32_t)min(tid + k * NT, ns - 1);
+            cpre[k] = *reinterpret_cast<const FwF3*>(irow + 12u * jc);
+        }
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) {
+            const uint32_t jc = (uint32_t)min(tid + k * NT, ns - 1);
+            dpre[0][k] = lazy_load(Z0, (uint32_t)s0 + jc, jc, mul[0][k]);
+            dpre[1][k] = lazy_load(Z1, (uint32_t)s0 + jc, jc, mul[1][k]);
+        }
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) { dpre[0][k] *= mul[0][k]; dpre[1][k] *= mul[1][k]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) {
+            const uint32_t jc = (uint32_t)min(tid + k * NT, ns - 1);
+            cpre[k] = *reinterpret_cast<const FwF3*>(irow + 12u * jc);
+            dpre[0][k] = *reinterpret_cast<const float*>(drow0 + 4u * jc);
+            dpre[1][k] = *reinterpret_cast<const float*>(drow1 + 4u * jc);
+        }
     }
     const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
     // colours: np.clip(x * 255, 0, 255).astype(uint8) (reference :1508), once for both eyes
@@ -377,6 +399,7 @@ hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, uint8_t* rowflag, 
     A.stereo = R.stereo; A.stereo_is_u8 = R.stereo_is_u8; A.mask = R.mask; A.depth_l = R.depth_l; A.depth_r = R.depth_r;
     A.out_h = R.out_h; A.out_w = R.out_w;
     A.dbg = R.dbg;
+    A.tilemap = R.tilemap; A.gray = R.lazy_gray; A.tm_words = R.tm_words;
     const int ntiles = (R.w + A.T - 1) / A.T;
     const size_t npt = (size_t)NT * SLOTS;
     const size_t lds = npt * 4 + npt * 8 + (npt / 64) * 8 + (fill == CS_FILL_NAIVE_INTERPOLATING ? npt * (4 + 4 + 2 + 1) : 0) + 64;

@@ -100,8 +100,9 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
 // were written (RowArgs::tilemap); *lazy_used = 0 when the parameters took a path that writes everything.
 int blur_tilemap_words(int w);                 // 32-bit words per tile row, including the pad word the readers rely on
 size_t blur_tilemap_bytes(int n, int h, int w);
-// the rows of `list` (frame * h + row, *count of them) complete in out_l / out_r: gray * scale for the unwritten tiles
-hipError_t launch_lazy_rows(const uint32_t* list, const uint32_t* count, const float* gray, float* out_l, float* out_r,
+// the rows of `list` (frame * h + row, *count of them; null: all `total` rows) complete in out_l / out_r: gray * scale for
+// the unwritten tiles
+hipError_t launch_lazy_rows(const uint32_t* list, const uint32_t* count, int total, const float* gray, float* out_l, float* out_r,
                             const uint32_t* tilemap, const uint32_t* stats, int h, int w, hipStream_t stream);
 
 // cs_rowwarp.hip (hybrid_edge: k_hybrid_splat + the fill pass of k_rowwarp)

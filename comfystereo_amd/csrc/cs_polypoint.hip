@@ -200,46 +200,29 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     float dpre[SLOTS];
     F3 cpre[SLOTS];
     B3 cpre8[SLOTS];
-    // lazy depth blur: bit (t & 31) of `zbits` covers tile column t of the staged range (<= 32 tiles of 64 columns); the lane
-    // reads the lower of the two buffers, or `zdelta` bytes further up when its tile's bit is set, and multiplies what it
-    // read by 1 (blurred map: already scaled) or by the frame's x255 scale (gray) -- all selected with bit operations
+    // lazy depth-blur tiles (cs_common.h): edge-free tiles come from the gray depth, times the frame's x255 scale
     const bool lazy = A.tilemap != nullptr;
-    const char* dbase = drow;
-    uint32_t zbits = 0, zdelta = 0, zmul_set = 0x3f800000u, zmul_clr = 0x3f800000u;
-    uint32_t zmul[SLOTS];
+    float zmul[SLOTS];
     if (lazy) {
-        const char* const grow = reinterpret_cast<const char*>(A.gray + rowpix + s0);
-        const uint32_t* tm = A.tilemap + ((uint32_t)frame * (uint32_t)((h + 31) >> 5) + (uint32_t)(row >> 5)) * (uint32_t)A.tm_words;
-        const int t0 = s0 >> 6;
-        const uint32_t w0 = tm[t0 >> 5], w1 = tm[(t0 >> 5) + 1];   // (the map rows end with a pad word)
-        const uint32_t sc = st[ST_SCALE255] ? 0x437f0000u /* 255.0f */ : 0x3f800000u;
-        // the image loads do not depend on the map: they go out while the scalar loads above are in flight
+        const LazySel Z = lazy_select(A.tilemap, A.tm_words, frame, h, row, s0, drow,
+                                      reinterpret_cast<const char*>(A.gray + rowpix + s0), st[ST_SCALE255]);
+        // the image loads do not depend on the map: they go out while the selector's scalar loads are in flight
 #pragma unroll
         for (int k = 0; k < SLOTS; k++) {
             const uint32_t jc = (uint32_t)min(tid + k * NT, ns - 1);
             if (OUT == PO_ASD) cpre8[k] = *reinterpret_cast<const B3*>(irow8 + 3u * jc);
             else cpre[k] = *reinterpret_cast<const F3*>(irow + 12u * jc);
         }
-        const uint32_t low = (1u << (t0 & 31)) - 1u;                // tiles of the second word wrap into the low bits
-        const uint32_t bits = (w0 & ~low) | (w1 & low);             // set: the tile was written to the blurred map
-        const bool gray_low = grow < drow;
-        dbase = gray_low ? grow : drow;
-        zdelta = (uint32_t)(gray_low ? drow - grow : grow - drow);
-        zbits = gray_low ? bits : ~bits;
-        zmul_set = gray_low ? 0x3f800000u : sc;
-        zmul_clr = gray_low ? sc : 0x3f800000u;
 #pragma unroll
         for (int k = 0; k < SLOTS; k++) {
             const uint32_t jc = (uint32_t)min(tid + k * NT, ns - 1);
-            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)zbits, ((uint32_t)s0 + jc) >> 6, 1u);   // 0 / ~0
-            zmul[k] = (m & zmul_set) | (~m & zmul_clr);
-            dpre[k] = *reinterpret_cast<const float*>(dbase + (4u * jc + (m & zdelta)));
+            dpre[k] = lazy_load(Z, (uint32_t)s0 + jc, jc, zmul[k]);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < SLOTS; k++) {
             const uint32_t jc = (uint32_t)min(tid + k * NT, ns - 1);
-            zmul[k] = 0x3f800000u;
+            zmul[k] = 1.0f;
             dpre[k] = *reinterpret_cast<const float*>(drow + 4u * jc);
             if (OUT == PO_ASD) cpre8[k] = *reinterpret_cast<const B3*>(irow8 + 3u * jc);
             else cpre[k] = *reinterpret_cast<const F3*>(irow + 12u * jc);
@@ -262,7 +245,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     __syncthreads();  // barrier 0: tables, flags
     if (lazy) {
 #pragma unroll
-        for (int k = 0; k < SLOTS; k++) dpre[k] *= __builtin_bit_cast(float, zmul[k]);
+        for (int k = 0; k < SLOTS; k++) dpre[k] *= zmul[k];
     }
 
     const float o0f = (float)o0, o1f = (float)(o0 + wt);   // tile = [o0f, o1f)

@@ -98,6 +98,7 @@ struct PolyTileArgs {
     int stereo_is_u8;
     int out_h, out_w;
     uint8_t* rowflag;  // [n][h] set to 1 when the row must be redone by the general kernel
+    const uint32_t* tilemap; const float* gray; int tm_words;   // lazy depth-blur tiles (cs_common.h) or null
     int dbg;           // env CS_DBG: 14 = count the pixels per evaluation path into the spare stats words, 17 = no exponent
                        // shortcuts (tests compare the two); more in development builds, see CS_PT_TIMESTAMPS
 };
@@ -187,10 +188,21 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
     constexpr int PT_PF = 3;
     const float* drow = E.depth + rowpix;
     float dpre[PT_PF];
+    // lazy depth-blur tiles: edge-free tiles come from the gray depth (times the frame's x255 scale)
+    const bool lazy = A.tilemap != nullptr;
+    LazySel Z;
+    if (lazy) Z = lazy_select(A.tilemap, A.tm_words, frame, h, row, s0, reinterpret_cast<const char*>(drow + s0),
+                              reinterpret_cast<const char*>(A.gray + rowpix + s0), st[ST_SCALE255]);
+    auto depth_at = [&](int j) {   // column s0 + j of this eye's depth row
+        if (!lazy) return drow[s0 + j];
+        float mul;
+        const float v = lazy_load(Z, (uint32_t)(s0 + j), (uint32_t)j, mul);
+        return v * mul;
+    };
 #pragma unroll
     for (int k = 0; k < PT_PF; k++) {
         const int j = tid + k * PT_THREADS;
-        dpre[k] = j < ns ? drow[s0 + j] : 0.0f;
+        dpre[k] = j < ns ? depth_at(j) : 0.0f;
     }
     const int nq = (hot_image && (w & 3) == 0) ? ns / 4 : 0;  // (rowpix + s0) % 4 == 0 -> 16-byte aligned groups of 4 pixels
     const float4* s4 = reinterpret_cast<const float4*>(hot_image + (rowpix + s0) * 3);
@@ -244,7 +256,7 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
     stamp(1);
     PT_DEV_CUTOFF(8);
     if (!eye_on) {
-        for (int q = tid; q < wt; q += PT_THREADS) dep8[q] = csm::f32_to_u8_wrap((drow[o0 + q] * scale) * 255.0f);
+        for (int q = tid; q < wt; q += PT_THREADS) dep8[q] = csm::f32_to_u8_wrap((depth_at(o0 + q - s0) * scale) * 255.0f);
     }
     if (eye_on) {
         const bool flat = dmax == dmin;
@@ -329,7 +341,7 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
         }
         for (int j = tid + PT_PF * PT_THREADS; j < ns; j += PT_THREADS) {  // (halos beyond 128 columns only)
             float sgn, ax;
-            pre(j, drow[s0 + j], sgn, ax);
+            pre(j, depth_at(j), sgn, ax);
             bool r = false;
             float pwv = pow_mode == 1 ? ax : (pow_mode == 2 ? square(ax, r) : 0.0f);
             if (pow_mode == 0 || __any(r)) {
@@ -958,6 +970,7 @@ hipError_t launch_polytile(int sharp, const RowArgs& R, int S, uint8_t* rowflag,
     A.out_h = R.out_h; A.out_w = R.out_w;
     A.rowflag = rowflag;
     A.dbg = R.dbg;
+    A.tilemap = R.tilemap; A.gray = R.lazy_gray; A.tm_words = R.tm_words;
     const int tiles = (A.w + PT_T - 1) / PT_T;
     dim3 grid(tiles * 8, (A.h + 7) / 8, A.single >= 0 ? A.n : 2 * A.n), block(PT_THREADS);
     const int variant = dev_switch(CS_DEBUG_PT_VARIANT);

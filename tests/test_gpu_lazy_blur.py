@@ -26,10 +26,52 @@ def cuda(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def run(engine, img, depth, mode, div=6.0, sep=0.0, **kw):
-    out = engine.generate(cuda(img), cuda(depth), div, sep, mode, 0.1, 0.5, 2.0, "polylines_soft", 20.0, 20.0, True,
+def run(engine, img, depth, mode, div=6.0, sep=0.0, fill="polylines_soft", **kw):
+    out = engine.generate(cuda(img), cuda(depth), div, sep, mode, 0.1, 0.5, 2.0, fill, 20.0, 20.0, True,
                           depth_blur_falloff=2.0, depth_blur_vert_smooth=6, **kw)
     return [o.cpu().numpy() for o in out]
+
+
+UI = {"none": "No fill", "inverse": "No fill - Reverse projection", "naive": "Fill - Naive",
+      "naive_interpolating": "Fill - Naive interpolating", "polylines_sharp": "Fill - Polylines Sharp",
+      "polylines_soft": "Fill - Polylines Soft"}
+
+
+@pytest.mark.parametrize("fill", ["none", "inverse", "naive", "naive_interpolating", "polylines_sharp"])
+@pytest.mark.parametrize("mode", ["left-right", "red-cyan-anaglyph"])
+def test_lazy_other_tile_kernels(engine, dev_switch, fill, mode):
+    """cs_fwdtile.hip (none / inverse / naive / naive_interpolating, both eyes per workgroup) and cs_polytile.hip (sharp) read
+    the tile map as well; the rows `naive` hands to the row kernel are completed first."""
+    n, h, w = 2, 100, 1284
+    img = synth.image_f32(n, h, w, seed=5)
+    depth = synth.depth_batch("blobs", n, h, w, channels=3)
+    lazy = run(engine, img, depth, mode, fill=fill)
+    dev_switch("blur_full_copy", 1)
+    full = run(engine, img, depth, mode, fill=fill)
+    for a, b in zip(lazy, full):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    want = node_oracle.generate(img, depth, 6.0, 0.0, mode, 0.1, 0.5, 2.0, UI[fill], 20.0, 20.0, True,
+                                depth_blur_falloff=2.0, depth_blur_vert_smooth=6)
+    for k in range(4):
+        assert np.array_equal(lazy[k], want[k]), (fill, mode, k)
+
+
+@pytest.mark.parametrize("fill,div", [("none", 90.0), ("polylines_soft", 130.0), ("polylines_soft", 180.0)])
+def test_lazy_when_the_call_falls_back_to_wider_kernels(engine, dev_switch, fill, div):
+    """Divergences whose halo exceeds the tile kernels' (none: row kernel for every row -> every row completed first;
+    polylines_soft: the first-generation tile kernel, then the row kernel): same bits as the full copy and the oracle."""
+    n, h, w = 1, 40, 1600
+    img = synth.image_f32(n, h, w, seed=8)
+    depth = synth.depth_batch("blobs", n, h, w, channels=3)
+    lazy = run(engine, img, depth, "left-right", div=div, fill=fill)
+    dev_switch("blur_full_copy", 1)
+    full = run(engine, img, depth, "left-right", div=div, fill=fill)
+    for a, b in zip(lazy, full):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    want = node_oracle.generate(img, depth, div, 0.0, "left-right", 0.1, 0.5, 2.0, UI[fill], 20.0, 20.0, True,
+                                depth_blur_falloff=2.0, depth_blur_vert_smooth=6)
+    for k in range(4):
+        assert np.array_equal(lazy[k], want[k]), (fill, div, k)
 
 
 @pytest.mark.parametrize("mode", ["left-right", "top-bottom", "red-cyan-anaglyph", "right-left"])
