@@ -987,6 +987,9 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
     for (int q = tid; q < wt; q += HYT_NT) {
         const int jcol = o0 + q;
         // bins of j_c = jcol-1, jcol, jcol+1  ->  local bins q, q+1, q+2
+        // (gathering the range into registers through a 6-element sorting network and evaluating the exps predicated, for
+        // instruction-level parallelism, was measured SLOWER: 3.6 -> 3.9 ms per 16 frames -- the wave then runs as many
+        // exps as its longest lane for every lane)
         int p0 = q > 0 ? binoff[q - 1] : 0, e0 = binoff[q];
         int p1 = e0, e1 = binoff[q + 1];
         int p2 = e1, e2 = binoff[q + 2];
@@ -1080,62 +1083,92 @@ __device__ void technique_hybrid_fill(const Lds& L, const RowArgs& A, int frame,
 struct Px3f { float x, y, z; };
 struct Px3b { uint8_t x, y, z; };
 
-__device__ __forceinline__ void hybrid_fill_px(const RowArgs& A, const unsigned long long* etab, int frame, int eyei, int row, int j,
-                                               uint8_t out[3]) {
+// edge_aware_gap_fill (reference :1745-1774) only does arithmetic for untouched pixels with touched neighbours -- a few
+// percent of the pixels, but spread over most waves (1-10 lanes each), and every (pixel, neighbour) pair costs a float64
+// exp.  So the pairs of the workgroup's 256 pixels (both eyes) are COMPACTED: owners reserve slots with one LDS atomic and
+// write descriptors, the weights are computed densely, one pair per lane, and the owners then accumulate their pairs in the
+// reference's raster order (the float32 sums are order-dependent).
+#define HYF_MAXP (256 * 8)
+__global__ void __launch_bounds__(256) k_hybrid_fill(RowArgs A) {
+    __shared__ unsigned long long etab[256];
+    __shared__ double wgs[HYF_MAXP];       // weight w_s * w_r of pair p
+    __shared__ uint16_t desc[HYF_MAXP];    // owner lane (8 bits) | neighbour k = 3 (di + 1) + (dj + 1) (4 bits)
+    __shared__ unsigned npairs[2];
+    const int tid = threadIdx.x;
+    etab[tid] = d_hyb_exp_tab[tid];
+    if (tid < 2) npairs[tid] = 0;
+    __syncthreads();
+    const int j = blockIdx.x * 256 + tid, row = blockIdx.y, frame = blockIdx.z;
     const int w = A.w, h = A.h;
-    const uint8_t* base = A.hyb_base + (((size_t)frame * A.neyes + eyei) * h) * (size_t)w * 3;
-    const uint8_t* mask = A.hyb_mask + (((size_t)frame * A.neyes + eyei) * h) * (size_t)w;
-    const uint8_t* b = base + ((size_t)row * w + j) * 3;
-    float r0 = (float)b[0], r1 = (float)b[1], r2 = (float)b[2];
-    if (mask[(size_t)row * w + j] == 0 && A.dbg != 41) {
-        float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
-        double wt = 0.0;
-        double g0 = 0.0;
-        bool have_g0 = false;
-        for (int di = -1; di <= 1; di++)
-            for (int dj = -1; dj <= 1; dj++) {
-                int ni = row + di, nj = j + dj;
-                if (ni < 0 || ni >= h || nj < 0 || nj >= w) continue;
-                if (mask[(size_t)ni * w + nj] == 0) continue;
-                if (!have_g0) { g0 = hyb_guidance(A, frame, row, j); have_g0 = true; }
-                int dsq = di * di + dj * dj;
-                // math.exp(-dsq / 2) for dsq = 1, 2 (the centre is never a touched neighbour): the two values of glibc's exp,
-                // i.e. of csm::exp_exact (tests/test_cs_math_host.py compares) -- no need to evaluate them per neighbour
-                const double w_s = dsq == 1 ? CS_EXP_M05 : CS_EXP_M10;
-                double diff = g0 - hyb_guidance(A, frame, ni, nj);
-                double w_r = csm::exp_exact(-(diff * diff) / 200.0, etab);
-                double wg = w_s * w_r;
-                float wg32 = (float)wg;
+    const bool live = j < w;
+    const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
+    const size_t pix = ((size_t)frame * h + row) * w + j;
+    uint8_t px[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    for (int e = 0; e < A.neyes; e++) {   // (uniform trip count and branches around the barriers)
+        if (A.single >= 0 && A.single != e) continue;
+        if (!A.eye[e].enabled) {
+            if (live) { px[e][0] = src_u8(A, frame, row, j, 0); px[e][1] = src_u8(A, frame, row, j, 1); px[e][2] = src_u8(A, frame, row, j, 2); }
+            continue;
+        }
+        const uint8_t* base = A.hyb_base + (((size_t)frame * A.neyes + e) * h) * (size_t)w * 3;
+        const uint8_t* mask = A.hyb_mask + (((size_t)frame * A.neyes + e) * h) * (size_t)w;
+        unsigned t = 0, off = 0;
+        if (live) {
+            const uint8_t* b = base + ((size_t)row * w + j) * 3;
+            px[e][0] = b[0]; px[e][1] = b[1]; px[e][2] = b[2];   // (integer codes: the reference's clamp and cast change nothing)
+            if (mask[(size_t)row * w + j] == 0 && A.dbg != 41) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const int ni = row + k / 3 - 1, nj = j + k % 3 - 1;
+                    if (k != 4 && ni >= 0 && ni < h && nj >= 0 && nj < w && mask[(size_t)ni * w + nj] != 0) t |= 1u << k;
+                }
+                if (t) {
+                    off = atomicAdd(&npairs[e], (unsigned)__popc(t));
+                    unsigned r = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; k++)
+                        if (t & (1u << k)) desc[off + r++] = (uint16_t)(tid | (k << 8));
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned np = npairs[e];
+        for (unsigned p = tid; p < np; p += 256) {
+            const unsigned d = desc[p];
+            const int jo = blockIdx.x * 256 + (int)(d & 0xffu), k = (int)(d >> 8);
+            const int ni = row + k / 3 - 1, nj = jo + k % 3 - 1;
+            // math.exp(-dsq / 2) for dsq = 1, 2 (the centre is never a touched neighbour): the two values of glibc's exp, i.e.
+            // of csm::exp_exact (tests/test_cs_math_host.py compares) -- no need to evaluate them per neighbour
+            const double w_s = (k & 1) ? CS_EXP_M05 : CS_EXP_M10;
+            const double diff = hyb_guidance(A, frame, row, jo) - hyb_guidance(A, frame, ni, nj);
+            wgs[p] = w_s * csm::exp_exact(-(diff * diff) / 200.0, etab);
+        }
+        __syncthreads();
+        if (t) {
+            float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
+            double wt = 0.0;
+            unsigned r = 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                if (!(t & (1u << k))) continue;
+                const int ni = row + k / 3 - 1, nj = j + k % 3 - 1;
+                const double wg = wgs[off + r++];
+                const float wg32 = (float)wg;
                 const uint8_t* nb = base + ((size_t)ni * w + nj) * 3;
                 n0 = n0 + (float)nb[0] * wg32;
                 n1 = n1 + (float)nb[1] * wg32;
                 n2 = n2 + (float)nb[2] * wg32;
                 wt += wg;
             }
-        if (wt > 0.0) {
-            float wt32 = (float)wt;
-            r0 = n0 / wt32; r1 = n1 / wt32; r2 = n2 / wt32;
+            if (wt > 0.0) {
+                const float wt32 = (float)wt;
+                float r0 = n0 / wt32, r1 = n1 / wt32, r2 = n2 / wt32;
+                r0 = fminf(fmaxf(r0, 0.0f), 255.0f); r1 = fminf(fmaxf(r1, 0.0f), 255.0f); r2 = fminf(fmaxf(r2, 0.0f), 255.0f);
+                px[e][0] = (uint8_t)(int)r0; px[e][1] = (uint8_t)(int)r1; px[e][2] = (uint8_t)(int)r2;
+            }
         }
     }
-    r0 = fminf(fmaxf(r0, 0.0f), 255.0f); r1 = fminf(fmaxf(r1, 0.0f), 255.0f); r2 = fminf(fmaxf(r2, 0.0f), 255.0f);
-    out[0] = (uint8_t)(int)r0; out[1] = (uint8_t)(int)r1; out[2] = (uint8_t)(int)r2;
-}
-
-__global__ void __launch_bounds__(256) k_hybrid_fill(RowArgs A) {
-    __shared__ unsigned long long etab[256];
-    etab[threadIdx.x] = d_hyb_exp_tab[threadIdx.x];
-    __syncthreads();
-    const int j = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y, frame = blockIdx.z;
-    const int w = A.w, h = A.h;
-    if (j >= w) return;
-    const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
-    const size_t pix = ((size_t)frame * h + row) * w + j;
-    uint8_t px[2][3] = {{0, 0, 0}, {0, 0, 0}};
-    for (int e = 0; e < A.neyes; e++) {
-        if (A.single >= 0 && A.single != e) continue;
-        if (A.eye[e].enabled) hybrid_fill_px(A, etab, frame, e, row, j, px[e]);
-        else { px[e][0] = src_u8(A, frame, row, j, 0); px[e][1] = src_u8(A, frame, row, j, 1); px[e][2] = src_u8(A, frame, row, j, 2); }
-    }
+    if (!live) return;
     auto store = [&](int e, uint8_t r, uint8_t g, uint8_t b) {   // (RowOut's destination arithmetic)
         const EyeArgs& E = A.eye[e];
         const size_t o = ((size_t)frame * A.out_h + row + E.yoff) * A.out_w + E.xoff + j;
