@@ -607,6 +607,77 @@ __device__ int poly_sequential_wave(const Poly& P, const Lds& L, int csg_cap_ref
     return 0;
 }
 
+// Replay of a STRETCH of the row by one wave (round 2, end).  The order of the reference's active list is a function of its
+// history -- except where the list holds exactly one segment: then the state is `[that segment]` whatever happened before.
+// The parallel evaluation marks those pixels ("reset": one active segment at the pixel's last sub-interval) next to the
+// order-dependent ones, and only the stretches from the pixel after a reset to the last order-dependent pixel before the
+// next reset are replayed -- tens to hundreds of columns instead of the row, independent of each other, one wave each.
+// The list of a stretch is short: one 64-entry chunk (more -> -1, and the row takes the whole-row replay).
+// State at the top of pixel c0: the list is [seg0] (seg0 < 0: empty, c0 == 0), segments perm[0 .. sgp0) have been added.
+template <class Emit>
+__device__ int poly_replay_stretch(const Poly& P, const Lds& L, int csg_cap_ref, const Emit& emit, int c0, int c1, int seg0,
+                                   int sgp0, uint16_t* csg, uint16_t* holepos) {
+    const int lane = threadIdx.x & 63;
+    const int sg_end = P.npt - 1;
+    const int cap = min(min(csg_cap_ref, P.cap), 64);
+    int csg_end = 0, sg_pointer = sgp0;
+    if (seg0 >= 0) { if (lane == 0) csg[0] = (uint16_t)seg0; csg_end = 1; }
+    int pt_i = (int)P.binoff[c0] - 1;   // binoff[c] = number of points left of pixel c; the sweep's own loop settles it
+    for (int col = c0; col <= c1; col++) {
+        float color[3] = {0.5f, 0.5f, 0.5f};
+        while (poly_x(P, P.perm[pt_i]) < (float)col) pt_i++;
+        pt_i--;
+        while (poly_x(P, P.perm[pt_i]) < (float)(col + 1)) {
+            const SubInt s = poly_subinterval(col, poly_x(P, P.perm[pt_i]), poly_x(P, P.perm[pt_i + 1]));
+            while (sg_pointer < sg_end && poly_x(P, P.perm[sg_pointer]) < s.center) {
+                if (csg_end >= cap) return -1;
+                if (lane == 0) csg[csg_end] = P.perm[sg_pointer];
+                csg_end++; sg_pointer++;
+            }
+            wave_lds_sync();
+            // ---- removal: the closed form of the swap-remove scan (poly_sequential_wave), one chunk, masks in registers
+            const int n = csg_end;
+            const int mine_o = lane < n ? (int)csg[lane] : 0;
+            const unsigned long long m = __ballot(lane < n && poly_x(P, mine_o + 1) < s.center);
+            if (m) {
+                const int ns = n - __popcll(m);
+                const unsigned long long pref = ns >= 64 ? ~0ull : ((1ull << ns) - 1ull);
+                const unsigned long long valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+                const unsigned long long holes = m & pref, surv = ~m & valid & ~pref;
+                if ((holes >> lane) & 1ull) holepos[__popcll(holes & ((1ull << lane) - 1ull))] = (uint16_t)lane;
+                wave_lds_sync();
+                if ((surv >> lane) & 1ull) csg[holepos[__popcll(lane == 63 ? 0ull : (surv >> (lane + 1)))]] = (uint16_t)mine_o;
+                csg_end = ns;
+                wave_lds_sync();
+            }
+            // ---- selection: first maximum of the closeness over the list (strict compare)
+            int best = 0;
+            if (csg_end != 1) {
+                float cl = -INFINITY;
+                if (lane < csg_end) {
+                    const int o = csg[lane];
+                    const float x0 = poly_x(P, o), x1 = poly_x(P, o + 1);
+                    const float ip_k = (s.center - x0) / (x1 - x0);
+                    const float c = (1.0f - ip_k) * poly_z(P, o) + ip_k * poly_z(P, o + 1);
+                    if (0.0f < ip_k && ip_k < 1.0f) cl = c;
+                }
+                float bc = (float)(-1e-7);
+                unsigned long long mm = __ballot(bc < cl);
+                while (mm) {
+                    const int b = __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cl), b));
+                    if (bc < v) { bc = v; best = b; }
+                }
+            }
+            poly_accumulate(P, L.img, csg[best], s.center, s.sig64, s.sig_d, s.sig_f, color);
+            pt_i++;
+        }
+        if (lane == 0) emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
+    }
+    return 0;
+}
+
 // rasterise the forward segments into per-pixel lists; PASS 0 counts, PASS 1 fills
 template <int PASS>
 __device__ __forceinline__ void poly_seg_pixels(const Poly& P, int o, int& p0, int& p1) {
@@ -714,50 +785,131 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         }
         __syncthreads();
         if (dbg == 4) return;
-        // P3c: one lane per output pixel (reference :1951-1991)
-        for (int col = tid; col < w; col += nt) {
-            float color[3] = {0.5f, 0.5f, 0.5f};
-            const int pos0 = P.binoff[col], pos1 = P.binoff[col + 1];  // bin col+1 = [col, col+1)
-            const int ls = col > 0 ? P.segoff[col - 1] : 0, le = P.segoff[col];
-            float prev = (float)col;
-            bool hazard = false;
-            float a = poly_x(P, P.perm[pos0 - 1]);
-            for (int k = pos0 - 1; k < pos1; k++) {
-                float b = poly_x(P, P.perm[k + 1]);
-                SubInt s = poly_subinterval(col, a, b);
-                a = b;
-                if (s.center < prev || s.center > (float)(col + 1)) hazard = true;
-                prev = s.center;
-                if (s.sig64 ? s.sig_d == 0.0 : s.sig_f == 0.0f) continue;  // adds exactly nothing
-                int nact = 0, nqual = 0, best = -1, single = -1;
-                float bc = (float)(-1e-7);
-                bool tie = false;
-                for (int e = ls; e < le; e++) {
-                    int o = P.entries[e];
-                    float x0 = poly_x(P, o), x1 = poly_x(P, o + 1);
-                    if (!(x0 < s.center) || x1 < s.center) continue;
-                    nact++;
-                    single = o;
-                    float ip_k = (s.center - x0) / (x1 - x0);
-                    if (0.0f < ip_k && ip_k < 1.0f) {
-                        float cl = (1.0f - ip_k) * poly_z(P, o) + ip_k * poly_z(P, o + 1);
-                        nqual++;
-                        if (bc < cl) { bc = cl; best = o; tie = false; }
-                        else if (cl == bc) tie = true;
+        // P3c: one lane per output pixel (reference :1951-1991).  Next to the pixel's colour: is it ORDER-DEPENDENT (hazard), and
+        // does the active list hold exactly one segment after its last sub-interval (reset, see poly_replay_stretch) -- as bit
+        // rows over the (idle) long-segment array
+        unsigned long long* hzw = (unsigned long long*)P.longs;
+        unsigned long long* rsw = hzw + ((w + 63) >> 6);
+        for (int colb = 0; colb < w; colb += nt) {
+            const int col = colb + tid;
+            bool hazard = false, reset = false;
+            if (col < w) {
+                float color[3] = {0.5f, 0.5f, 0.5f};
+                const int pos0 = P.binoff[col], pos1 = P.binoff[col + 1];  // bin col+1 = [col, col+1)
+                const int ls = col > 0 ? P.segoff[col - 1] : 0, le = P.segoff[col];
+                float prev = (float)col;
+                float a = poly_x(P, P.perm[pos0 - 1]);
+                for (int k = pos0 - 1; k < pos1; k++) {
+                    float b = poly_x(P, P.perm[k + 1]);
+                    SubInt s = poly_subinterval(col, a, b);
+                    a = b;
+                    if (s.center < prev || s.center > (float)(col + 1)) hazard = true;
+                    prev = s.center;
+                    if (s.sig64 ? s.sig_d == 0.0 : s.sig_f == 0.0f) continue;  // adds exactly nothing
+                    int nact = 0, nqual = 0, best = -1, single = -1;
+                    float bc = (float)(-1e-7);
+                    bool tie = false;
+                    for (int e = ls; e < le; e++) {
+                        int o = P.entries[e];
+                        float x0 = poly_x(P, o), x1 = poly_x(P, o + 1);
+                        if (!(x0 < s.center) || x1 < s.center) continue;
+                        nact++;
+                        single = o;
+                        float ip_k = (s.center - x0) / (x1 - x0);
+                        if (0.0f < ip_k && ip_k < 1.0f) {
+                            float cl = (1.0f - ip_k) * poly_z(P, o) + ip_k * poly_z(P, o + 1);
+                            nqual++;
+                            if (bc < cl) { bc = cl; best = o; tie = false; }
+                            else if (cl == bc) tie = true;
+                        }
                     }
+                    int seg;
+                    if (nact == 1) seg = single;
+                    else if (nqual == 0 || tie) { hazard = true; seg = single; }
+                    else seg = best;
+                    if (seg >= 0) poly_accumulate(P, L.img, seg, s.center, s.sig64, s.sig_d, s.sig_f, color);
+                    reset = k == pos1 - 1 && nact == 1;
                 }
-                int seg;
-                if (nact == 1) seg = single;
-                else if (nqual == 0 || tie) { hazard = true; seg = single; }
-                else seg = best;
-                if (seg >= 0) poly_accumulate(P, L.img, seg, s.center, s.sig64, s.sig_d, s.sig_f, color);
+                reset = reset && !hazard;
+                if (hazard) *flag_hazard = 1;
+                else if (dbg == 5) { if (color[0] == 12345.0f) emit(col, 1, 2, 3); }
+                else emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
             }
-            if (hazard) *flag_hazard = 1;
-            else if (dbg == 5) { if (color[0] == 12345.0f) emit(col, 1, 2, 3); }
-            else emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
+            const unsigned long long hm = __ballot(hazard), rm = __ballot(reset);
+            if (lane == 0 && colb + 64 * wave < w && w <= 8192) { hzw[(colb >> 6) + wave] = hm; rsw[(colb >> 6) + wave] = rm; }
         }
     }
     __syncthreads();
+    // ---- order-dependent pixels: replay the stretches between reset points, one wave per stretch (poly_replay_stretch)
+    constexpr int NSTR = 256;           // stretches per row
+    int* nstretch = L.misc + 3;
+    int* stretch_bad = L.misc + 4;
+    const int tail0 = (*ntotal + 7) & ~7;   // the idle tail of the per-pixel segment lists: stretch list + 256 bytes of scratch per wave
+    if (!overflow && *flag_hazard && w <= 8192 && dbg != 26 && dbg != 27 && tail0 + 2 * NSTR + 128 * nwaves + 8 <= P.cap) {
+        uint32_t* slist = (uint32_t*)(P.entries + tail0);   // start | end << 16 (pixel columns)
+        uint16_t* wscr = P.entries + tail0 + 2 * NSTR;
+        if (tid == 0) {
+            const unsigned long long* hzw = (const unsigned long long*)P.longs;
+            const unsigned long long* rsw = hzw + ((w + 63) >> 6);
+            int count = 0, last_reset = -1, start = 0, end = 0;
+            bool open = false;
+            for (int wi = 0; wi < (w + 63) >> 6; wi++) {
+                const unsigned long long hz = hzw[wi], rs = rsw[wi];
+                if (hz == 0ull) {   // (the common word: no order-dependent pixel)
+                    if (rs) {
+                        if (open) { if (count < NSTR) slist[count] = (uint32_t)start | ((uint32_t)end << 16); count++; open = false; }
+                        last_reset = wi * 64 + 63 - __clzll((long long)rs);
+                    }
+                    continue;
+                }
+                unsigned long long ev = hz | rs;
+                while (ev) {
+                    const int b = __ffsll((long long)ev) - 1;
+                    ev &= ev - 1;
+                    const int col = wi * 64 + b;
+                    if ((hz >> b) & 1ull) {
+                        if (!open) { open = true; start = last_reset + 1; }
+                        end = col;
+                    } else {
+                        if (open) { if (count < NSTR) slist[count] = (uint32_t)start | ((uint32_t)end << 16); count++; open = false; }
+                        last_reset = col;
+                    }
+                }
+            }
+            if (open) { if (count < NSTR) slist[count] = (uint32_t)start | ((uint32_t)end << 16); count++; }
+            *nstretch = count <= NSTR ? count : -1;
+            *stretch_bad = 0;
+        }
+        __syncthreads();
+        const int nstr = *nstretch;
+        if (nstr > 0) {
+            bool bad = false;
+            for (int si = wave; si < nstr && !bad; si += nwaves) {
+                const int c0 = (int)(slist[si] & 0xffffu), c1 = (int)(slist[si] >> 16);
+                int seg0 = -1, sgp0 = 0;
+                if (c0 > 0) {   // the state after pixel c0 - 1: its single active segment, the points left of its last centre
+                    const int r = c0 - 1;
+                    const int pos1 = P.binoff[r + 1];
+                    const SubInt s = poly_subinterval(r, poly_x(P, P.perm[pos1 - 1]), poly_x(P, P.perm[pos1]));
+                    const int ls = r > 0 ? P.segoff[r - 1] : 0, le = P.segoff[r];
+                    for (int e = ls; e < le; e++) {
+                        const int o = P.entries[e];
+                        if (poly_x(P, o) < s.center && !(poly_x(P, o + 1) < s.center)) seg0 = o;
+                    }
+                    sgp0 = pos1;
+                    while (sgp0 > 0 && !(poly_x(P, P.perm[sgp0 - 1]) < s.center)) sgp0--;
+                    if (seg0 < 0) bad = true;   // (cannot happen: the pixel was marked because exactly one segment is active there)
+                }
+                if (!bad && poly_replay_stretch(P, L, E.csg_cap, emit, c0, c1, seg0, sgp0, wscr + 128 * wave, wscr + 128 * wave + 64)) bad = true;
+            }
+            if (bad && lane == 0) *stretch_bad = 1;
+        }
+        __syncthreads();
+        if (nstr > 0 && !*stretch_bad) {
+            if (stats_rw && tid == 0) atomicAdd(&stats_rw[ST_FALLBACK_ROWS], 1u);
+            return;
+        }
+    }
     if (overflow || *flag_hazard) {
         // order-dependent row: replay the reference sweep literally -- by the first wave (its 64 lanes share the list work
         // of every step), or by one lane when the wave form runs out of scratch

@@ -246,6 +246,26 @@ def test_order_dependent_rows_take_the_wave_replay(engine):
                 assert np.array_equal(g, w_), (fill, mode, name)
 
 
+@pytest.mark.parametrize("fill,ui", [("polylines_soft", "Fill - Polylines Soft"), ("polylines_sharp", "Fill - Polylines Sharp")])
+def test_saturated_depth_ties_are_replayed_in_stretches(engine, fill, ui):
+    """Depth clipped to exactly 0 / 1 (what saturating depth estimators deliver) at convergence 0.5: every overlap of a near
+    and a far layer is an exact closeness tie.  The rows are order-dependent only inside those overlaps; the row kernel replays
+    the stretches between two pixels where the reference's active list holds a single segment (poly_replay_stretch), not the
+    rows.  Bit-exact against the oracle, several frames so that rows with zero, one and many stretches occur."""
+    n, h, w = 3, 96, 1540
+    img = synth.image_f32(n, h, w, seed=21)
+    depth = synth.depth_batch("clipped", n, h, w, channels=3)
+    for mode, div in (("left-right", 6.0), ("red-cyan-anaglyph", 9.0), ("top-bottom", 2.5)):
+        want = node_oracle.generate(img, depth, div, 0.0, mode, 0.2, 0.5, 2.0, ui, 20.0, 20.0, False, batch_size=12)
+        p = engine.make_params(n, h, w, h, w, 3, fill, mode, div, 0.0, 0.2, 0.5, 2.0, False, 20.0, 20.0, 1.0, 0, 12)
+        plan = engine.Plan(p, torch.device("cuda"))
+        got = [t.cpu().numpy() for t in plan.run(cuda(img), cuda(depth))]
+        st = plan.stats()
+        assert int(st[:, 10].sum()) > 0 and int(st[:, 9].sum()) == 0   # rows with replayed pixels; no kernel error flags
+        for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+            assert np.array_equal(g, w_), (fill, mode, name)
+
+
 def test_anaglyph_through_the_tile_kernels_mixes_flagged_and_composed_rows(engine):
     """Anaglyph polylines: a frame whose upper half ties everywhere (rows redone by the row kernel, final form) and whose
     lower half is smooth (eyes composed from the tile kernels' scratch)."""

@@ -44,7 +44,15 @@ def blobs(h, w, seed=0, n=4):
     return d.astype(np.float32)
 
 
-DEPTHS = {"radial": radial, "stepped": stepped, "noisy_ramp": noisy_ramp, "random8": random8, "blobs": blobs}
+def clipped(h, w, seed=0):
+    """Saturated depth: blobs clipped to exactly 0 / 1 over large areas with smooth ramps between -- at convergence 0.5 the two
+    plateaus have bit-equal |disparity|, so every overlap of a near and a far layer is an exact closeness tie (the realistic
+    source of order-dependent rows: depth estimators saturate)."""
+    d = (blobs(h, w, seed=seed) - np.float32(0.5)) * np.float32(4.0) + np.float32(0.5)
+    return np.clip(d, 0.0, 1.0).astype(np.float32)
+
+
+DEPTHS = {"clipped": clipped, "radial": radial, "stepped": stepped, "noisy_ramp": noisy_ramp, "random8": random8, "blobs": blobs}
 
 
 def image_u8(h, w, seed=0, hazards=True):
