@@ -614,51 +614,85 @@ __device__ int poly_sequential_wave(const Poly& P, const Lds& L, int csg_cap_ref
 // next reset are replayed -- tens to hundreds of columns instead of the row, independent of each other, one wave each.
 // The list of a stretch is short: one 64-entry chunk (more -> -1, and the row takes the whole-row replay).
 // State at the top of pixel c0: the list is [seg0] (seg0 < 0: empty, c0 == 0), segments perm[0 .. sgp0) have been added.
+// The list lives in REGISTERS: lane i holds entry i (segment id, both end points' x and |disparity|), so the dead test and
+// the closeness of a step need no memory at all, and the 64 sorted points around the sweep position sit in a register
+// window read with v_readlane.  LDS is touched when a segment enters the list (its far end point), when a removal leaves
+// holes in front of survivors (their lane numbers are handed over, then cross-lane moves) and for the winner's colours.
 template <class Emit>
 __device__ int poly_replay_stretch(const Poly& P, const Lds& L, int csg_cap_ref, const Emit& emit, int c0, int c1, int seg0,
-                                   int sgp0, uint16_t* csg, uint16_t* holepos) {
+                                   int sgp0, uint16_t* srcpos) {
     const int lane = threadIdx.x & 63;
     const int sg_end = P.npt - 1;
     const int cap = min(min(csg_cap_ref, P.cap), 64);
+    auto rl_f = [](float v, int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i)); };
+    // entry `lane` of the list
+    int e_o = 0;
+    float e_x0 = 0.0f, e_x1 = 0.0f, e_z0 = 0.0f, e_z1 = 0.0f;
     int csg_end = 0, sg_pointer = sgp0;
-    if (seg0 >= 0) { if (lane == 0) csg[0] = (uint16_t)seg0; csg_end = 1; }
+    if (seg0 >= 0) {
+        e_o = seg0; e_x0 = poly_x(P, seg0); e_x1 = poly_x(P, seg0 + 1); e_z0 = poly_z(P, seg0); e_z1 = poly_z(P, seg0 + 1);
+        csg_end = 1;
+    }
+    // window of the sorted points: lane k holds point perm[wbase + k]
+    int wbase = 0, wo = 0;
+    float wx = 0.0f;
+    auto window = [&](int lo) {   // (two points of slack below: the sweep steps back by one at every pixel)
+        wbase = max(lo - 2, 0);
+        wo = P.perm[min(wbase + lane, P.npt - 1)];
+        wx = poly_x(P, wo);
+    };
+    bool lost = false;   // the sweep position and the add pointer drifted more than a window apart (long runs of equal x)
+    auto need = [&](int lo, int hi) {
+        if (lo < wbase || hi >= wbase + 64) { window(lo); lost = lost || hi >= wbase + 64; }
+    };
     int pt_i = (int)P.binoff[c0] - 1;   // binoff[c] = number of points left of pixel c; the sweep's own loop settles it
+    window(min(pt_i, sg_pointer));
     for (int col = c0; col <= c1; col++) {
         float color[3] = {0.5f, 0.5f, 0.5f};
-        while (poly_x(P, P.perm[pt_i]) < (float)col) pt_i++;
+        need(pt_i, pt_i + 1);
+        while (rl_f(wx, pt_i - wbase) < (float)col) { pt_i++; need(pt_i, pt_i + 1); }
         pt_i--;
-        while (poly_x(P, P.perm[pt_i]) < (float)(col + 1)) {
-            const SubInt s = poly_subinterval(col, poly_x(P, P.perm[pt_i]), poly_x(P, P.perm[pt_i + 1]));
-            while (sg_pointer < sg_end && poly_x(P, P.perm[sg_pointer]) < s.center) {
+        need(pt_i, pt_i + 1);
+        while (rl_f(wx, pt_i - wbase) < (float)(col + 1)) {
+            const SubInt s = poly_subinterval(col, rl_f(wx, pt_i - wbase), rl_f(wx, pt_i + 1 - wbase));
+            need(min(pt_i, sg_pointer), max(pt_i + 1, sg_pointer));
+            if (lost) return -1;
+            while (sg_pointer < sg_end && rl_f(wx, sg_pointer - wbase) < s.center) {
                 if (csg_end >= cap) return -1;
-                if (lane == 0) csg[csg_end] = P.perm[sg_pointer];
+                const int o = __builtin_amdgcn_readlane(wo, sg_pointer - wbase);
+                const float nx0 = rl_f(wx, sg_pointer - wbase), nx1 = poly_x(P, o + 1), nz0 = poly_z(P, o), nz1 = poly_z(P, o + 1);
+                if (lane == csg_end) { e_o = o; e_x0 = nx0; e_x1 = nx1; e_z0 = nz0; e_z1 = nz1; }
                 csg_end++; sg_pointer++;
+                need(min(pt_i, sg_pointer), max(pt_i + 1, sg_pointer));
+                if (lost) return -1;
             }
-            wave_lds_sync();
-            // ---- removal: the closed form of the swap-remove scan (poly_sequential_wave), one chunk, masks in registers
+            // ---- removal: the closed form of the swap-remove scan (poly_sequential_wave) on ballots
             const int n = csg_end;
-            const int mine_o = lane < n ? (int)csg[lane] : 0;
-            const unsigned long long m = __ballot(lane < n && poly_x(P, mine_o + 1) < s.center);
+            const unsigned long long m = __ballot(lane < n && e_x1 < s.center);
             if (m) {
                 const int ns = n - __popcll(m);
                 const unsigned long long pref = ns >= 64 ? ~0ull : ((1ull << ns) - 1ull);
                 const unsigned long long valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
                 const unsigned long long holes = m & pref, surv = ~m & valid & ~pref;
-                if ((holes >> lane) & 1ull) holepos[__popcll(holes & ((1ull << lane) - 1ull))] = (uint16_t)lane;
-                wave_lds_sync();
-                if ((surv >> lane) & 1ull) csg[holepos[__popcll(lane == 63 ? 0ull : (surv >> (lane + 1)))]] = (uint16_t)mine_o;
+                if (holes) {   // survivors behind the new end move into the holes: k-th hole <- k-th survivor from the end
+                    if ((surv >> lane) & 1ull) srcpos[__popcll(lane == 63 ? 0ull : (surv >> (lane + 1)))] = (uint16_t)lane;
+                    wave_lds_sync();
+                    const bool hole = (holes >> lane) & 1ull;
+                    const int src = hole ? (int)srcpos[__popcll(holes & ((1ull << lane) - 1ull))] : lane;
+                    const int mo = __shfl(e_o, src);
+                    const float mx0 = __shfl(e_x0, src), mx1 = __shfl(e_x1, src), mz0 = __shfl(e_z0, src), mz1 = __shfl(e_z1, src);
+                    if (hole) { e_o = mo; e_x0 = mx0; e_x1 = mx1; e_z0 = mz0; e_z1 = mz1; }
+                    wave_lds_sync();
+                }
                 csg_end = ns;
-                wave_lds_sync();
             }
             // ---- selection: first maximum of the closeness over the list (strict compare)
             int best = 0;
             if (csg_end != 1) {
                 float cl = -INFINITY;
                 if (lane < csg_end) {
-                    const int o = csg[lane];
-                    const float x0 = poly_x(P, o), x1 = poly_x(P, o + 1);
-                    const float ip_k = (s.center - x0) / (x1 - x0);
-                    const float c = (1.0f - ip_k) * poly_z(P, o) + ip_k * poly_z(P, o + 1);
+                    const float ip_k = (s.center - e_x0) / (e_x1 - e_x0);
+                    const float c = (1.0f - ip_k) * e_z0 + ip_k * e_z1;
                     if (0.0f < ip_k && ip_k < 1.0f) cl = c;
                 }
                 float bc = (float)(-1e-7);
@@ -666,12 +700,35 @@ __device__ int poly_replay_stretch(const Poly& P, const Lds& L, int csg_cap_ref,
                 while (mm) {
                     const int b = __ffsll((long long)mm) - 1;
                     mm &= mm - 1;
-                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cl), b));
+                    const float v = rl_f(cl, b);
                     if (bc < v) { bc = v; best = b; }
                 }
             }
-            poly_accumulate(P, L.img, csg[best], s.center, s.sig64, s.sig_d, s.sig_f, color);
+            // colour contribution of the winner (poly_accumulate with its end points from the registers)
+            {
+                const int seg = __builtin_amdgcn_readlane(e_o, best);
+                const int col_l = poly_col(P, seg), col_r = poly_col(P, seg + 1);
+                if (col_l == col_r) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        if (s.sig64) color[c] = (float)((double)color[c] + (double)L.img[3 * col_l + c] * s.sig_d);
+                        else color[c] = color[c] + (float)L.img[3 * col_l + c] * s.sig_f;
+                    }
+                } else {
+                    const float x0 = rl_f(e_x0, best), x1 = rl_f(e_x1, best);
+                    const float ip_k = (s.center - x0) / (x1 - x0);
+                    const float om = 1.0f - ip_k;
+                    const float sg = s.sig64 ? (float)s.sig_d : s.sig_f;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const float a = (float)L.img[3 * col_l + c] * om;
+                        const float b = (float)L.img[3 * col_r + c] * ip_k;
+                        color[c] = color[c] + (a + b) * sg;
+                    }
+                }
+            }
             pt_i++;
+            need(pt_i, pt_i + 1);
         }
         if (lane == 0) emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
     }
@@ -900,11 +957,15 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                     while (sgp0 > 0 && !(poly_x(P, P.perm[sgp0 - 1]) < s.center)) sgp0--;
                     if (seg0 < 0) bad = true;   // (cannot happen: the pixel was marked because exactly one segment is active there)
                 }
-                if (!bad && poly_replay_stretch(P, L, E.csg_cap, emit, c0, c1, seg0, sgp0, wscr + 128 * wave, wscr + 128 * wave + 64)) bad = true;
+                if (!bad && poly_replay_stretch(P, L, E.csg_cap, emit, c0, c1, seg0, sgp0, wscr + 128 * wave)) bad = true;
             }
             if (bad && lane == 0) *stretch_bad = 1;
         }
         __syncthreads();
+        if (dbg == 14 && stats_rw && tid == 0) {   // diagnostics: rows done in stretches / stretches / rows the stretch form gave up
+            atomicAdd(&stats_rw[(nstr > 0 && !*stretch_bad) ? 12 : 14], 1u);
+            atomicAdd(&stats_rw[13], (unsigned)max(nstr, 0));
+        }
         if (nstr > 0 && !*stretch_bad) {
             if (stats_rw && tid == 0) atomicAdd(&stats_rw[ST_FALLBACK_ROWS], 1u);
             return;
