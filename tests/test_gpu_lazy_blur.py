@@ -137,3 +137,21 @@ def test_lazy_falloff_zero_marks_every_tile(engine, dev_switch):
                                 depth_blur_falloff=0.0, depth_blur_vert_smooth=3)
     for k in range(4):
         assert np.array_equal(a[k].cpu().numpy(), want[k]), k
+
+
+@pytest.mark.parametrize("fill,mode", [("polylines_soft", "left-right"), ("none", "red-cyan-anaglyph"), ("polylines_sharp", "top-bottom")])
+def test_lazy_with_the_compact_uint8_stereoscope(engine, fill, mode):
+    """cs_params.flags bit 1 (the form multi-GPU shards are gathered in) with the blur on: the uint8 codes expand to the
+    float32 output of the same call."""
+    n, h, w = 2, 72, 1284
+    img = cuda(synth.image_f32(n, h, w, seed=7))
+    depth = cuda(synth.depth_batch("blobs", n, h, w, channels=3))
+    ref = engine.generate(img, depth, 6.0, 0.0, mode, 0.0, 0.5, 2.0, fill, 20.0, 20.0, True, depth_blur_falloff=2.0,
+                          depth_blur_vert_smooth=6)
+    p = engine.make_params(n, h, w, h, w, 3, fill, mode, 6.0, 0.0, 0.0, 0.5, 2.0, True, 20.0, 20.0, 2.0, 6, 4)
+    plan = engine.Plan(p, img.device, stereo_u8=True)
+    out = plan.run(img, depth)
+    assert out[0].dtype == torch.uint8
+    assert torch.equal(engine.expand_u8(out[0]), ref[0])
+    for k in (1, 2, 3):
+        assert torch.equal(out[k], ref[k])
