@@ -1202,7 +1202,9 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
         // bins of j_c = jcol-1, jcol, jcol+1  ->  local bins q, q+1, q+2
         // (gathering the range into registers through a 6-element sorting network and evaluating the exps predicated, for
         // instruction-level parallelism, was measured SLOWER: 3.6 -> 3.9 ms per 16 frames -- the wave then runs as many
-        // exps as its longest lane for every lane)
+        // exps as its longest lane for every lane; the three weights of every SOURCE computed in the staging loop and read
+        // here from an 18 KB float64 LDS array: 3.6 -> 4.4 ms -- fewer workgroups per CU and the 8-byte LDS traffic cost
+        // more than the divergence)
         int p0 = q > 0 ? binoff[q - 1] : 0, e0 = binoff[q];
         int p1 = e0, e1 = binoff[q + 1];
         int p2 = e1, e2 = binoff[q + 2];
