@@ -1415,40 +1415,42 @@ __global__ void __launch_bounds__(256) k_hybrid_fill(RowArgs A) {
 // the row kernel
 // ---------------------------------------------------------------------------------------------
 // Destination of one eye row: converts uint8 pixels to the output layout as they are produced.
+// (holds VALUES, not a pointer to the kernel's argument struct: an address-taken by-value kernel argument is copied to
+// scratch memory -- 340 bytes per lane -- and a kernel with scratch pays for it at every wave launch, also when the
+// flagged-row list is empty: 28 -> 210 us per launch)
 struct RowOut {
-    const RowArgs* A;
-    const Lds* L;
-    int frame, row, eye, w;
+    uint8_t* out_u8; float* stereo; float* mask;
+    const uint8_t* ana_c; uint8_t* ana; const float* lut;   // (LDS) anaglyph stash, byte -> float table
+    int h, out_h, out_w, xoff, yoff, anaglyph, stereo_is_u8;
+    int frame, row, w;
     bool stash;  // first eye of an anaglyph: only remember the channels the composite takes from it
     __device__ __forceinline__ void operator()(int c, uint8_t r, uint8_t g, uint8_t b) const {
-        const RowArgs& a = *A;
-        if (a.out_u8) {
-            uint8_t* d = a.out_u8 + (((size_t)frame * a.h + row) * w + c) * 3;
+        if (out_u8) {
+            uint8_t* d = out_u8 + (((size_t)frame * h + row) * w + c) * 3;
             d[0] = r; d[1] = g; d[2] = b;
             return;
         }
         if (stash) {
-            if (a.anaglyph == 1) L->ana[c] = r;
-            else { L->ana[2 * c] = g; L->ana[2 * c + 1] = b; }
+            if (anaglyph == 1) ana[c] = r;
+            else { ana[2 * c] = g; ana[2 * c + 1] = b; }
             return;
         }
-        if (a.anaglyph == 1) r = L->ana[c];
-        else if (a.anaglyph == 2) { g = L->ana[2 * c]; b = L->ana[2 * c + 1]; }
-        const EyeArgs& E = a.eye[eye];
-        const size_t o = ((size_t)frame * a.out_h + row + E.yoff) * a.out_w + E.xoff + c;
-        if (a.stereo_is_u8) {
-            uint8_t* d8 = reinterpret_cast<uint8_t*>(a.stereo) + o * 3;
+        if (anaglyph == 1) r = ana[c];
+        else if (anaglyph == 2) { g = ana[2 * c]; b = ana[2 * c + 1]; }
+        const size_t o = ((size_t)frame * out_h + row + yoff) * out_w + xoff + c;
+        if (stereo_is_u8) {
+            uint8_t* d8 = reinterpret_cast<uint8_t*>(stereo) + o * 3;
             d8[0] = r; d8[1] = g; d8[2] = b;
         } else {
-            float* d = a.stereo + o * 3;
-            d[0] = L->lut[r]; d[1] = L->lut[g]; d[2] = L->lut[b];
+            float* d = stereo + o * 3;
+            d[0] = lut[r]; d[1] = lut[g]; d[2] = lut[b];
         }
-        a.mask[o] = ((int)r + (int)g + (int)b) == 0 ? 1.0f : 0.0f;  // GenerateStereo.py:355-361
+        mask[o] = ((int)r + (int)g + (int)b) == 0 ? 1.0f : 0.0f;  // GenerateStereo.py:355-361
     }
 };
 
 template <int FILL>
-__device__ void rowwarp_row(const RowArgs& A, const int row, const int frame, char* smem) {
+__device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, const int frame, char* smem) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int w = A.w, h = A.h;
     Lds L = carve(smem, FILL, w, A.anaglyph);
@@ -1497,10 +1499,20 @@ __device__ void rowwarp_row(const RowArgs& A, const int row, const int frame, ch
 
     const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
     for (int e = 0; e < A.neyes; e++) {
-        const EyeArgs& E = A.eye[e];
+        // (field-by-field selects: a dynamically indexed -- or aggregate-selected -- kernel-argument array makes the compiler copy
+        // the whole argument struct to scratch memory)
+        EyeArgs E;
+        E.depth = e ? A.eye[1].depth : A.eye[0].depth;
+        E.div32 = e ? A.eye[1].div32 : A.eye[0].div32; E.sep32 = e ? A.eye[1].sep32 : A.eye[0].sep32;
+        E.div64 = e ? A.eye[1].div64 : A.eye[0].div64; E.sep64 = e ? A.eye[1].sep64 : A.eye[0].sep64;
+        E.enabled = e ? A.eye[1].enabled : A.eye[0].enabled; E.asc = e ? A.eye[1].asc : A.eye[0].asc;
+        E.naive_lim = e ? A.eye[1].naive_lim : A.eye[0].naive_lim; E.csg_cap = e ? A.eye[1].csg_cap : A.eye[0].csg_cap;
+        E.st_min = e ? A.eye[1].st_min : A.eye[0].st_min; E.st_max = e ? A.eye[1].st_max : A.eye[0].st_max;
+        E.xoff = e ? A.eye[1].xoff : A.eye[0].xoff; E.yoff = e ? A.eye[1].yoff : A.eye[0].yoff;
         if (A.single >= 0 && A.single != e) continue;
         const bool last = (e == A.neyes - 1) || A.single >= 0;
-        RowOut out{&A, &L, frame, row, e, w, A.anaglyph != 0 && !last};
+        RowOut out{A.out_u8, A.stereo, A.mask, L.ana, L.ana, L.lut, A.h, A.out_h, A.out_w, E.xoff, E.yoff, A.anaglyph, A.stereo_is_u8,
+                   frame, row, w, A.anaglyph != 0 && !last};
         if (E.enabled) {
             // normalised depth: (d - min) / (max - min) - convergence (reference :1587-1600)
             float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
@@ -1597,7 +1609,7 @@ __device__ void rowwarp_row(const RowArgs& A, const int row, const int frame, ch
     // depth-map outputs: (depth*255).astype(uint8) wraps mod 256 (quirk Q7), then /255, 3 channels
     if (A.depth_l) {
         for (int e = 0; e < 2; e++) {
-            const float* drow = A.eye[e].depth + rowpix;
+            const float* drow = (e == 0 ? A.eye[0].depth : A.eye[1].depth) + rowpix;
             float* dst = (e == 0 ? A.depth_l : A.depth_r) + rowpix * 3;
             for (int c = tid; c < w; c += nt) {
                 float v = L.lut[csm::f32_to_u8_wrap((drow[c] * scale) * 255.0f)];
@@ -1612,21 +1624,24 @@ __device__ void rowwarp_row(const RowArgs& A, const int row, const int frame, ch
 template <int FILL>
 __global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (!A.row_list) {
-        rowwarp_row<FILL>(A, blockIdx.x, blockIdx.y, smem);
-        return;
-    }
+    // ONE call site of the (force-inlined) row function: as a real call it takes the argument struct by reference, i.e. a
+    // 340-byte scratch copy per lane and scratch set-up at every wave launch (28 -> 210 us for the usual EMPTY flagged-row pass)
+    const bool listed = A.row_list != nullptr;
     // rows are handed out dynamically (row_count[1] = next index): a row that needs the sequential replay takes 100x
     // longer than the others
-    const uint32_t count = A.row_count[0];
+    const uint32_t count = listed ? A.row_count[0] : 1u;
     __shared__ uint32_t s_next;
-    while (true) {
-        if (threadIdx.x == 0) s_next = atomicAdd(const_cast<uint32_t*>(&A.row_count[1]), 1u);
-        __syncthreads();
-        const uint32_t i = s_next;
-        if (i >= count) break;
-        const uint32_t e = A.row_list[i];
-        rowwarp_row<FILL>(A, (int)(e % (uint32_t)A.h), (int)(e / (uint32_t)A.h), smem);
+    for (uint32_t it = 0;; it++) {
+        int row = blockIdx.x, frame = blockIdx.y;
+        if (listed) {
+            if (threadIdx.x == 0) s_next = atomicAdd(const_cast<uint32_t*>(&A.row_count[1]), 1u);
+            __syncthreads();
+            const uint32_t i = s_next;
+            if (i >= count) break;
+            const uint32_t e = A.row_list[i];
+            row = (int)(e % (uint32_t)A.h); frame = (int)(e / (uint32_t)A.h);
+        } else if (it) break;
+        rowwarp_row<FILL>(A, row, frame, smem);
         __syncthreads();  // the row's LDS (and s_next) is reused by the next one
     }
 }
@@ -1647,7 +1662,15 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
     size_t lds = lds_common_bytes(fill, A.w, A.anaglyph) + lds_tech_bytes(fill, A.w);
     const long long rows = (long long)A.h * A.n;
     dim3 grid(A.h, A.n), block(threads);
-    if (A.row_list) grid = dim3((unsigned)(rows < 2048 ? rows : 2048), 1);
+    if (A.row_list) {
+        // flagged rows (usually none): persistent workgroups, as many as are resident at once -- every wave of this kernel sets
+        // up scratch (the replay code spills), so an empty launch costs per WORKGROUP: 2048 of them took 0.21 ms
+        long long per_cu = 2048 / threads;
+        if (lds > 0 && (long long)(CS_LDS_BYTES / lds) < per_cu) per_cu = (long long)(CS_LDS_BYTES / lds);
+        if (per_cu < 1) per_cu = 1;
+        const long long resident = 256 * per_cu;
+        grid = dim3((unsigned)(rows < resident ? rows : resident), 1);
+    }
 #define CS_LAUNCH(F)                                                                                              \
     case F: {                                                                                                     \
         hipError_t e = hipFuncSetAttribute((const void*)k_rowwarp<F>, hipFuncAttributeMaxDynamicSharedMemorySize, \
