@@ -237,6 +237,15 @@ __global__ void __launch_bounds__(256) k_blur_edges(BlurArgs A, unsigned long lo
 // neighbours come from the adjacent lanes (shuffles; the first / last lane of a wave loads them).  A lane's four edge bits
 // form a nibble, eight lanes' nibbles a 32-bit half word (OR over xor-shuffles), two halves a word of the bit row.
 #define BLUR_ER4 8  // image rows per thread
+// cross-lane moves as DPP modifiers (2-4 cycles each) instead of ds_bpermute round trips through the LDS crossbar (the
+// kernel was bound by those: 80 per thread).  Lanes without a source keep their own value.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) { return __builtin_bit_cast(float, dpp_u32<CTRL>(__builtin_bit_cast(unsigned, v))); }
+enum { DPP_XOR1 = 0xB1 /* quad_perm [1,0,3,2] */, DPP_XOR2 = 0x4E /* quad_perm [2,3,0,1] */, DPP_HALF_MIRROR = 0x141 /* i <-> 7 - i */,
+       DPP_ROW_MIRROR = 0x140 /* i <-> 15 - i */, DPP_ROW_SHL8 = 0x108 /* i <- i + 8 (row of 16) */, DPP_WAVE_SHL1 = 0x130 /* i <- i + 1 */,
+       DPP_WAVE_SHR1 = 0x138 /* i <- i - 1 */ };
 // `blk` (lazy mode, or null): per 64-column x 8-row block {min, max of the scaled depth, any edge bit, -} for k_blur_classify
 __global__ void __launch_bounds__(256) k_blur_edges4(BlurArgs A, unsigned long long* mask_l, unsigned long long* mask_r, int MW,
                                                      float4* blk) {
@@ -260,7 +269,7 @@ __global__ void __launch_bounds__(256) k_blur_edges4(BlurArgs A, unsigned long l
 #pragma unroll
     for (int i = 0; i < BLUR_ER4 + 2; i++) {
         v[i].x *= scale; v[i].y *= scale; v[i].z *= scale; v[i].w *= scale;
-        const float fl = __shfl_up(v[i].w, 1), fr = __shfl_down(v[i].x, 1);
+        const float fl = dpp_f32<DPP_WAVE_SHR1>(v[i].w), fr = dpp_f32<DPP_WAVE_SHL1>(v[i].x);
         nl[i] = lane == 0 ? nl[i] * scale : fl;
         nr[i] = lane == 63 ? nr[i] * scale : fr;
         if (x + 4 >= w) nr[i] = 0.0f;  // (the neighbour lane holds zeros anyway; explicit for the frame's last column)
@@ -291,9 +300,11 @@ __global__ void __launch_bounds__(256) k_blur_edges4(BlurArgs A, unsigned long l
             nib_r |= (in && (g < 0.0f) && (es > 0.5f)) ? 1u << c : 0u;
         }
         unsigned hl = nib_l << (4 * (lane & 7)), hr = nib_r << (4 * (lane & 7));
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) { hl |= __shfl_xor(hl, o); hr |= __shfl_xor(hr, o); }
-        const unsigned hl_hi = __shfl_down(hl, 8), hr_hi = __shfl_down(hr, 8);
+        // OR over the eight lanes of a half row: xor 1, xor 2, then the two quads swapped (i <-> 7 - i)
+        hl |= dpp_u32<DPP_XOR1>(hl); hr |= dpp_u32<DPP_XOR1>(hr);
+        hl |= dpp_u32<DPP_XOR2>(hl); hr |= dpp_u32<DPP_XOR2>(hr);
+        hl |= dpp_u32<DPP_HALF_MIRROR>(hl); hr |= dpp_u32<DPP_HALF_MIRROR>(hr);
+        const unsigned hl_hi = dpp_u32<DPP_ROW_SHL8>(hl), hr_hi = dpp_u32<DPP_ROW_SHL8>(hr);
         if ((lane & 15) == 0 && word < MW && y < h) {
             mask_l[((size_t)frame * h + y) * MW + word] = (unsigned long long)hl | ((unsigned long long)hl_hi << 32);
             mask_r[((size_t)frame * h + y) * MW + word] = (unsigned long long)hr | ((unsigned long long)hr_hi << 32);
@@ -310,8 +321,10 @@ __global__ void __launch_bounds__(256) k_blur_edges4(BlurArgs A, unsigned long l
                 mx = fmaxf(fmaxf(mx, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
             }
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+        mn = fminf(mn, dpp_f32<DPP_XOR1>(mn)); mx = fmaxf(mx, dpp_f32<DPP_XOR1>(mx));
+        mn = fminf(mn, dpp_f32<DPP_XOR2>(mn)); mx = fmaxf(mx, dpp_f32<DPP_XOR2>(mx));
+        mn = fminf(mn, dpp_f32<DPP_HALF_MIRROR>(mn)); mx = fmaxf(mx, dpp_f32<DPP_HALF_MIRROR>(mx));
+        mn = fminf(mn, dpp_f32<DPP_ROW_MIRROR>(mn)); mx = fmaxf(mx, dpp_f32<DPP_ROW_MIRROR>(mx));
         if ((lane & 15) == 0 && word < MW && yb < h)
             blk[((size_t)frame * gridDim.y + blockIdx.y) * MW + word] = make_float4(mn, mx, anybits ? 1.0f : 0.0f, 0.0f);
     }
