@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256) k_blur_edges(BlurArgs A, unsigned long lo
 // row (8x fewer load instructions -- the scalar version is bound by the L1 request rate, not by HBM); the two missing
 // neighbours come from the adjacent lanes (shuffles; the first / last lane of a wave loads them).  A lane's four edge bits
 // form a nibble, eight lanes' nibbles a 32-bit half word (OR over xor-shuffles), two halves a word of the bit row.
-#define BLUR_ER4 8  // image rows per thread
+#define BLUR_ER4 4  // image rows per thread (8: 0.66 ms, 16: 0.85, 2: 0.71 -- the halo rows come from L2; fewer registers, more waves)
 // cross-lane moves as DPP modifiers (2-4 cycles each) instead of ds_bpermute round trips through the LDS crossbar (the
 // kernel was bound by those: 80 per thread).  Lanes without a source keep their own value.
 template <int CTRL>
