@@ -246,7 +246,7 @@ __device__ __forceinline__ float dpp_f32(float v) { return __builtin_bit_cast(fl
 enum { DPP_XOR1 = 0xB1 /* quad_perm [1,0,3,2] */, DPP_XOR2 = 0x4E /* quad_perm [2,3,0,1] */, DPP_HALF_MIRROR = 0x141 /* i <-> 7 - i */,
        DPP_ROW_MIRROR = 0x140 /* i <-> 15 - i */, DPP_ROW_SHL8 = 0x108 /* i <- i + 8 (row of 16) */, DPP_WAVE_SHL1 = 0x130 /* i <- i + 1 */,
        DPP_WAVE_SHR1 = 0x138 /* i <- i - 1 */ };
-// `blk` (lazy mode, or null): per 64-column x 8-row block {min, max of the scaled depth, any edge bit, -} for k_blur_classify
+// `blk` (lazy mode, or null): per 64-column x BLUR_ER4-row block {min, max of the scaled depth, any edge bit, -} for k_blur_classify
 __global__ void __launch_bounds__(256) k_blur_edges4(BlurArgs A, unsigned long long* mask_l, unsigned long long* mask_r, int MW,
                                                      float4* blk) {
     const int lane = threadIdx.x & 63;
