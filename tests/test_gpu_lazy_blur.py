@@ -155,3 +155,24 @@ def test_lazy_with_the_compact_uint8_stereoscope(engine, fill, mode):
     assert torch.equal(engine.expand_u8(out[0]), ref[0])
     for k in (1, 2, 3):
         assert torch.equal(out[k], ref[k])
+
+
+@pytest.mark.parametrize("shape", [(2, 100, 1282), (1, 61, 1284), (2, 20, 60)])
+def test_lazy_odd_shapes_and_resized_depth(engine, dev_switch, shape):
+    """Widths that are not multiples of 4 (the blur then writes complete maps), heights that end inside a tile row, frames
+    smaller than one tile, and a depth map at another resolution (the tile map then refers to the RESIZED gray depth)."""
+    n, h, w = shape
+    img = synth.image_f32(n, h, w, seed=2)
+    for dshape in ((h, w), (h // 2 + 3, w // 2 + 5)):
+        depth = synth.depth_batch("blobs", n, dshape[0], dshape[1], channels=3)
+        lazy = run(engine, img, depth, "left-right")
+        dev_switch("blur_full_copy", 1)
+        full = run(engine, img, depth, "left-right")
+        dev_switch("blur_full_copy", 0)
+        for a, b in zip(lazy, full):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (shape, dshape)
+        if dshape == (h, w):
+            want = node_oracle.generate(img, depth, 6.0, 0.0, "left-right", 0.1, 0.5, 2.0, "Fill - Polylines Soft", 20.0, 20.0, True,
+                                        depth_blur_falloff=2.0, depth_blur_vert_smooth=6)
+            for k in range(4):
+                assert np.array_equal(lazy[k], want[k]), (shape, k)
