@@ -282,3 +282,26 @@ def test_anaglyph_through_the_tile_kernels_mixes_flagged_and_composed_rows(engin
         assert 0 < redone < 2 * h
         for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
             assert np.array_equal(g, w_), (mode, name)
+
+
+def test_bench_batch_of_64_frames_through_the_lazy_blur_tiles(engine, dev_switch):
+    """The bench call itself: 64 x 4K with the blur on.  It is the one call whose buffer distances (2.1 GB between the gray
+    depth and a blurred map) come near the 32-bit offsets the tile kernels select with; every frame must equal the same
+    frame processed in a batch of four with complete blurred maps."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 90 * (1 << 30):
+        pytest.skip("needs ~60 GB of device memory")
+    n = 64
+    dev = torch.device("cuda")
+    img = torch.from_numpy(synth.image_f32(1, H4, W4, seed=1)).to(dev).expand(n, -1, -1, -1).contiguous()
+    depth = torch.cat([torch.from_numpy(synth.depth_batch("stepped", 8, H4, W4, channels=3)).to(dev) for _ in range(n // 8)])
+    depth[8:] += 0.001 * torch.arange(n - 8, device=dev).view(-1, 1, 1, 1)   # (frames differ: a mixed-up frame index would show)
+    mk = lambda k: engine.make_params(k, H4, W4, H4, W4, 3, "polylines_soft", "left-right", 8.0, 0.0, 0.0, 0.5, 2.0, True, 20.0,
+                                      20.0, 2.0, 6, 12)
+    out = engine.Plan(mk(n), dev).run(img, depth)
+    dev_switch("blur_full_copy", 1)
+    small = engine.Plan(mk(4), dev)
+    for f0 in range(0, n, 4):
+        ref = small.run(img[f0:f0 + 4], depth[f0:f0 + 4])
+        for k in range(4):
+            assert torch.equal(out[k][f0:f0 + 4], ref[k]), (f0, k)
