@@ -535,7 +535,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
                                al256((size_t)n * hw * 4) < (1ull << 32) - (1u << 20);
         rc = launch_blur(gray, n, h, w, p->depth_blur_strength, p->depth_blur_edge_threshold, p->depth_blur_strength, p->depth_blur_falloff,
                          p->depth_blur_vert_smooth, L, R, (float*)(ws + W.wl), (float*)(ws + W.wr), stats, 1, stream,
-                         want_lazy ? (uint32_t*)(ws + W.tilemap) : nullptr, &lazy);
+                         dev_switch(CS_DEBUG_BLUR_FULL_COPY) ? nullptr : (uint32_t*)(ws + W.tilemap), want_lazy ? &lazy : nullptr);
         if (rc) return fail(rc, "depth blur: unsupported parameters (strength must round to >= 1)");
         dL = L; dR = R;
         scale_from_stats = 0;  // the blur kernel already wrote scaled depth

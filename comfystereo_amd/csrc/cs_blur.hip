@@ -749,6 +749,38 @@ hipError_t launch_lazy_rows(const uint32_t* list, const uint32_t* count, int tot
     return hipGetLastError();
 }
 
+// Complete maps for consumers that read whole rows (gpu_warp, hybrid_edge, the row kernels): the tiles the map does not name
+// are a scaled copy of the gray depth.  A pure streaming kernel -- the classification (and the frame statistics of these
+// tiles) is k_blur_classify's: k_blur_copy, which does both, is bound by its classification chain (1.35 ms per 64 4K frames).
+__global__ void __launch_bounds__(256) k_blur_copy_tiles(BlurArgs A, const uint32_t* tilemap, int tm_words) {
+    const int tid = threadIdx.x;
+    const int X0 = blockIdx.x * (BLUR_CW * BLUR_TW), y0 = blockIdx.y * BLUR_TR, frame = blockIdx.z;
+    const int w = A.w, h = A.h;
+    constexpr int C4 = BLUR_CW * BLUR_TW / 4, RPT = BLUR_TR * C4 / 256;
+    const int c4 = tid % C4, rb = tid / C4;
+    const int x = X0 + 4 * c4;
+    const int t = x / BLUR_TW;
+    const uint32_t word = tilemap[((size_t)frame * gridDim.y + blockIdx.y) * tm_words + (t >> 5)];
+    if (x >= w || ((word >> (t & 31)) & 1u)) return;
+    const float scale = (A.stats && A.stats[frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
+    float4 vv[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; i++) {
+        const int y = y0 + rb + (256 / C4) * i;
+        vv[i] = y < h ? *reinterpret_cast<const float4*>(A.depth + ((size_t)frame * h + y) * w + x) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; i++) {
+        const int y = y0 + rb + (256 / C4) * i;
+        if (y < h) {
+            const float4 o = make_float4(vv[i].x * scale, vv[i].y * scale, vv[i].z * scale, vv[i].w * scale);
+            const size_t off = ((size_t)frame * h + y) * w + x;
+            *reinterpret_cast<float4*>(A.out_l + off) = o;
+            *reinterpret_cast<float4*>(A.out_r + off) = o;
+        }
+    }
+}
+
 static size_t blur_fused_lds(int v, int R, int bs) {
     int WR = BLUR_TR + 2 * v, EW = BLUR_TW + 2 * R, NW = (EW + 63) >> 6;
     (void)EW;
@@ -759,6 +791,8 @@ static size_t blur_fused_lds(int v, int R, int bs) {
 int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double mask_width,
                 double falloff, int vert, float* out_l, float* out_r, float* wl, float* wr, uint32_t* stats, int node_path,
                 hipStream_t stream, uint32_t* tilemap, int* lazy_used) {
+    // (lazy_used == nullptr with a tile map: the caller wants COMPLETE maps; the map is then only the classification's output)
+    const bool want_lazy = lazy_used != nullptr;
     if (lazy_used) *lazy_used = 0;
     BlurArgs A;
     A.depth = depth; A.n = n; A.h = h; A.w = w;
@@ -801,10 +835,12 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
             if (hipMemsetAsync(work_count, 0, 4, stream) != hipSuccess) return CS_EHIP;
             if (lazy) {
                 if (hipMemsetAsync(tilemap, 0, blur_tilemap_bytes(n, h, w), stream) != hipSuccess) return CS_EHIP;
-                if (lazy_used) *lazy_used = 1;
                 hipLaunchKernelGGL(k_blur_classify, dim3((gx * gy + 255) / 256, n), dim3(256), 0, stream, A,
                                    (const unsigned long long*)mask_l, (const unsigned long long*)mask_r, MW, (const float4*)blk, HB,
                                    work_count, worklist, tilemap, blur_tilemap_words(w));
+                if (want_lazy) *lazy_used = 1;
+                else hipLaunchKernelGGL(k_blur_copy_tiles, dim3((gx + BLUR_CW - 1) / BLUR_CW, gy, n), dim3(256), 0, stream, A,
+                                        (const uint32_t*)tilemap, blur_tilemap_words(w));
             } else {
                 hipLaunchKernelGGL(k_blur_copy, dim3((gx + BLUR_CW - 1) / BLUR_CW, gy, n), dim3(256), 0, stream, A,
                                    (const unsigned long long*)mask_l, (const unsigned long long*)mask_r, MW, work_count, worklist);

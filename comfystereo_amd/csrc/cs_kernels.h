@@ -96,8 +96,9 @@ hipError_t launch_depth_codes(const float* depth, int n, int h, int w, const uin
 int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double mask_width,
                 double falloff, int vert, float* out_l, float* out_r, float* wl, float* wr, uint32_t* stats, int node_path,
                 hipStream_t stream, uint32_t* tilemap = nullptr, int* lazy_used = nullptr);
-// lazy mode (tilemap != nullptr, zeroed by launch_blur): edge-free tiles are left unwritten and the tile map says which tiles
-// were written (RowArgs::tilemap); *lazy_used = 0 when the parameters took a path that writes everything.
+// tilemap != nullptr (zeroed by launch_blur): the tiles are classified from the edge kernel's block summaries and the map names
+// the tiles with an edge in reach.  lazy_used != nullptr: edge-free tiles are left UNWRITTEN (RowArgs::tilemap; *lazy_used = 0
+// when the parameters took a path that writes everything); lazy_used == nullptr: a streaming copy completes the maps.
 int blur_tilemap_words(int w);                 // 32-bit words per tile row, including the pad word the readers rely on
 size_t blur_tilemap_bytes(int n, int h, int w);
 // the rows of `list` (frame * h + row, *count of them; null: all `total` rows) complete in out_l / out_r: gray * scale for
