@@ -23,6 +23,9 @@ MODE = {
     "only-right": 6, "cyan-red-reverseanaglyph": 7,
 }
 
+# the ABI version the ctypes signatures below were written for (include/comfystereo_amd.h CS_ABI_VERSION)
+ABI_VERSION = 2
+
 EXPORTS = [
     "cs_version", "cs_last_error", "cs_max_width", "cs_max_width_mode", "cs_output_shape", "cs_workspace_bytes", "cs_generate",
     "cs_asd_workspace_bytes", "cs_apply_stereo_divergence", "cs_apply_stereo_divergence2", "cs_blur_workspace_bytes", "cs_directional_blur",
@@ -71,6 +74,9 @@ def lib():
     ip = ctypes.POINTER(ctypes.c_int)
     L.cs_version.restype = c_int
     L.cs_version.argtypes = []
+    if L.cs_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {L.cs_version()}, these bindings were written for {ABI_VERSION}: "
+                          "rebuild it (`make -C comfystereo_amd/csrc`)")
     L.cs_last_error.restype = ctypes.c_char_p
     L.cs_last_error.argtypes = []
     L.cs_max_width_mode.restype = c_int

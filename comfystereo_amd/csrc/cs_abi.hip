@@ -23,6 +23,13 @@ static int fail_hip(hipError_t e, const char* where) {
     return CS_EHIP;
 }
 
+// launch_blur's three failure classes get their own message (CS_EHIP reads the HIP error that caused it)
+static int fail_blur(int rc) {
+    if (rc == CS_EHIP) return fail_hip(hipGetLastError(), "depth blur");
+    if (rc == CS_ELIMIT) return fail(rc, "depth blur: frame or blur kernel too wide for the LDS of the two-pass path");
+    return fail(rc, "depth blur: unsupported parameters (strength must round to >= 1)");
+}
+
 // development switches: explicit state set through cs_debug_set (never the environment)
 static std::atomic<int> g_dev[CS_DEBUG_KEYS];
 int dev_switch(int key) { return (key >= 0 && key < CS_DEBUG_KEYS) ? g_dev[key].load(std::memory_order_relaxed) : 0; }
@@ -536,7 +543,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
         rc = launch_blur(gray, n, h, w, p->depth_blur_strength, p->depth_blur_edge_threshold, p->depth_blur_strength, p->depth_blur_falloff,
                          p->depth_blur_vert_smooth, L, R, (float*)(ws + W.wl), (float*)(ws + W.wr), stats, 1, stream,
                          dev_switch(CS_DEBUG_BLUR_FULL_COPY) ? nullptr : (uint32_t*)(ws + W.tilemap), want_lazy ? &lazy : nullptr);
-        if (rc) return fail(rc, "depth blur: unsupported parameters (strength must round to >= 1)");
+        if (rc) return fail_blur(rc);
         dL = L; dR = R;
         scale_from_stats = 0;  // the blur kernel already wrote scaled depth
     }
@@ -673,7 +680,7 @@ int cs_directional_blur(const float* depth, int n, int h, int w, double blur_str
     hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);
     int rc = launch_blur(depth, n, h, w, blur_strength, edge_threshold, blur_mask_width, falloff_exponent, vert_smooth_px, out_l, out_r, wl,
                          wr, stats, 0, stream);
-    if (rc) return fail(rc, "depth blur: unsupported parameters (strength must round to >= 1)");
+    if (rc) return fail_blur(rc);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CS_OK : fail_hip(e, "cs_directional_blur");
 }
