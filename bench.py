@@ -251,7 +251,10 @@ def main():
     if rank == 0:
         fps = frames * a.steps / dt
         kern_ms = tot_ms.value / max(launches.value, 1)
-        frames_per_launch = job.cg.cf if job is not None else nloc
+        # launches of the dominant kernel per step: cs_generate cuts a batch into frame chunks (the pre-pass of chunk c + 1
+        # runs under the warp of chunk c on a second stream), the sharded job into all-gather chunks
+        launches_per_step = max(1, round(launches.value / max(a.steps, 1)))
+        frames_per_launch = nloc / launches_per_step
         alg_bytes = frames_per_launch * cfg["bytes_px"] * H * W  # per launch of the dominant kernel on this rank
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         traffic, traffic_source = None, None

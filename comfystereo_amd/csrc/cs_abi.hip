@@ -344,7 +344,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
             T.out_h = A.h; T.out_w = 2 * A.w;
             T.eye[0].xoff = 0; T.eye[0].yoff = 0; T.eye[1].xoff = A.w; T.eye[1].yoff = 0;
         }
-        if (fill == CS_FILL_POLYLINES_SOFT && halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 6)))
+        if (fill == CS_FILL_POLYLINES_SOFT && halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 6) || (variant >= 13 && variant <= 16)))
             e = launch_polypoint(T, halo, rowflag, stream);
         else
             e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, T, halo, rowflag, stream);
@@ -457,12 +457,13 @@ int cs_output_shape(const cs_params* p, int* out_h, int* out_w, int* mask_h, int
 
 
 struct WsLayout {
-    size_t stats, rowflag, gray_src, gray, L, R, wl, wr, tilemap, extra, total;
+    size_t rowflag, gray_src, gray, L, R, wl, wr, tilemap, extra, total;
 };
+// Scratch of one chunk of frames (everything but the per-frame statistics words, which stay one array for the whole call
+// at the start of the workspace so that callers find them at a fixed place).
 static WsLayout ws_layout(const cs_params* p) {
     WsLayout W;
     size_t hw = (size_t)p->h * p->w, n = p->n, o = 0;
-    W.stats = o; o += al256(n * ST_WORDS * 4);
     W.rowflag = o; o += rowflag_bytes(n * (size_t)p->h);
     bool resize = p->depth_h != p->h || p->depth_w != p->w;
     W.gray_src = o; if (resize) o += al256(n * (size_t)p->depth_h * p->depth_w * 4);
@@ -484,43 +485,89 @@ static WsLayout ws_layout(const cs_params* p) {
     return W;
 }
 
-size_t cs_workspace_bytes(const cs_params* p) { return p ? ws_layout(p).total : 0; }
+// ---- frame chunks: the pre-pass of chunk c + 1 under the warp of chunk c ---------------------------------------------
+// The warp kernels are bound by instruction issue (k_polypoint: VALU busy 85 %, HBM half idle), the pre-pass (gray depth,
+// edge bit rows, tile classification, fused blur) by HBM.  A call therefore cuts its batch into chunks of frames -- every
+// quantity of the path is per frame (gpu_warp: per reference sub-batch, so its chunks are multiples of batch_size) -- and
+// issues the pre-pass of every chunk on an auxiliary high-priority stream, the warps on the caller's stream, one event per
+// chunk in between: while chunk c is warped, the pre-pass of chunk c + 1 fills the idle memory system.  Fork / join is by
+// events only (legal under stream capture); all work the call enqueues is ordered before whatever the caller enqueues
+// next on its stream.  cs_debug_set(CS_DEBUG_CHUNKS, 1) = one chunk on the caller's stream alone (the round-2 schedule),
+// k > 1 = k chunks whatever the batch.
+struct ChunkPlan { int nch, cf; };
+static ChunkPlan plan_chunks(const cs_params* p) {
+    const int n = p->n, forced = dev_switch(CS_DEBUG_CHUNKS);
+    int unit = 1;
+    if (p->fill == CS_FILL_GPU_WARP) unit = p->batch_size > 0 ? (p->batch_size < n ? p->batch_size : n) : n;
+    if (forced == 1 || n < 2 * unit) return ChunkPlan{1, n};
+    const size_t hw = (size_t)p->h * p->w;
+    // a chunk's pre-pass must outlast the launch gaps it introduces: at least ~32 Mpixel per chunk, at most 4 chunks
+    int minf = forced > 1 ? 1 : (int)(((size_t)32 << 20) / hw);
+    if (minf < 1) minf = 1;
+    const int want = forced > 1 ? forced : 4;
+    int cf = (n + want - 1) / want;
+    if (cf < minf) cf = minf;
+    cf = (cf + unit - 1) / unit * unit;
+    const int nch = (n + cf - 1) / cf;
+    if (nch < 2) return ChunkPlan{1, n};
+    return ChunkPlan{nch, cf};
+}
+static size_t ws_total(const cs_params* p) {
+    const ChunkPlan C = plan_chunks(p);
+    cs_params q = *p;
+    q.n = C.cf;
+    return al256((size_t)p->n * ST_WORDS * 4) + (size_t)C.nch * ws_layout(&q).total;
+}
 
-int cs_generate(const cs_params* p, const float* image, const float* depth, float* stereo, float* depth_l,
-                float* depth_r, float* mask, void* workspace, size_t workspace_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!p || !image || !depth || !stereo || !depth_l || !depth_r || !mask || !workspace) return fail(CS_EINVAL, "null pointer");
-    if (p->n <= 0 || p->h <= 0 || p->w <= 0 || p->depth_h <= 0 || p->depth_w <= 0 || p->depth_c <= 0)
-        return fail(CS_EINVAL, "non-positive size");
-    if (p->fill < 0 || p->fill > CS_FILL_HYBRID_EDGE_PLUS) return fail(CS_EINVAL, "unknown fill technique");
-    int out_h, out_w, mask_h, mask_w;
-    int rc = cs_output_shape(p, &out_h, &out_w, &mask_h, &mask_w);
-    if (rc) return rc;
-    if (p->w > cs_max_width_mode(p->fill, p->mode)) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
-    WsLayout W = ws_layout(p);
-    if (workspace_bytes < W.total) return fail(CS_EWORKSPACE, "workspace too small");
-    char* ws = (char*)workspace;
-    uint32_t* stats = (uint32_t*)(ws + W.stats);
+// the auxiliary stream (highest priority the device offers) and its fork / ready events: one set per device, created on
+// first use, shared by every caller (the events order each call's own work; sharing the stream only serialises the
+// pre-passes of concurrent callers)
+static const int AUX_MAX_DEV = 16, AUX_EVENTS = 8;
+struct AuxStream { hipStream_t s; hipEvent_t fork, ready[AUX_EVENTS]; bool ok; };
+static std::mutex g_aux_mu;
+static AuxStream g_aux[AUX_MAX_DEV];
+static AuxStream* aux_stream() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= AUX_MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lock(g_aux_mu);
+    AuxStream& A = g_aux[dev];
+    if (A.ok) return &A;
+    int least = 0, greatest = 0;   // (the numerically lowest value is the highest priority)
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
+    if (hipStreamCreateWithPriority(&A.s, hipStreamNonBlocking, greatest) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&A.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    for (int i = 0; i < AUX_EVENTS; i++)
+        if (hipEventCreateWithFlags(&A.ready[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    A.ok = true;
+    return &A;
+}
+
+size_t cs_workspace_bytes(const cs_params* p) { return (p && p->n > 0) ? ws_total(p) : 0; }
+
+// One chunk of frames: the pre-pass on `sp`, the warp on `stream` (the same stream, or `ready` recorded on sp and awaited
+// by stream in between).  `stats`: the chunk's slice of the call's statistics words; `ws`: the chunk's scratch (ws_layout).
+static int generate_chunk(const cs_params* p, const float* image, const float* depth, float* stereo, float* depth_l,
+                          float* depth_r, float* mask, uint32_t* stats, char* ws, int out_h, int out_w, hipStream_t sp,
+                          hipStream_t stream, hipEvent_t ready) {
+    int rc;
+    const WsLayout W = ws_layout(p);
     float* gray = (float*)(ws + W.gray);
     const int n = p->n, h = p->h, w = p->w, hw = h * w;
     const bool gpu_warp = p->fill == CS_FILL_GPU_WARP;
-    if (gpu_warp && (p->flags & 2)) return fail(CS_EINVAL, "gpu_warp colours are not k/255: no uint8 stereoscope output");
-    if ((p->flags & 24) && !dialect_d64_ok(p->fill))
-        return fail(CS_EINVAL, "dialect D64 (flags bits 3/4) exists for none / naive / naive_interpolating / inverse only");
     const bool blur = p->depth_map_blur && p->depth_blur_strength > 0;  // strength <= 0 == blur off (reference :1194, :1050)
 
-    hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);
+    hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, sp, stats, n);
     const bool resize = p->depth_h != h || p->depth_w != w;
     if (resize) {
         float* gs = (float*)(ws + W.gray_src);
         int shw = p->depth_h * p->depth_w;
-        hipLaunchKernelGGL(k_gray, dim3(grid_for(shw / 32 + 1, 256), n), dim3(256), 0, stream, depth, gs, shw, p->depth_c, stats, 0);
-        hipLaunchKernelGGL(k_resize_bilinear, dim3(grid_for(hw, 256), n), dim3(256), 0, stream, gs, p->depth_h, p->depth_w, gray, h, w, stats);
+        hipLaunchKernelGGL(k_gray, dim3(grid_for(shw / 32 + 1, 256), n), dim3(256), 0, sp, depth, gs, shw, p->depth_c, stats, 0);
+        hipLaunchKernelGGL(k_resize_bilinear, dim3(grid_for(hw, 256), n), dim3(256), 0, sp, gs, p->depth_h, p->depth_w, gray, h, w, stats);
     } else {
         // (>= 8 float4 groups per thread: the per-workgroup min/max reduction is amortised -- 3x faster at 1080p)
-        hipLaunchKernelGGL(k_gray, dim3(grid_for(hw / 32 + 1, 256), n), dim3(256), 0, stream, depth, gray, hw, p->depth_c, stats, 1);
+        hipLaunchKernelGGL(k_gray, dim3(grid_for(hw / 32 + 1, 256), n), dim3(256), 0, sp, depth, gray, hw, p->depth_c, stats, 1);
     }
-    hipLaunchKernelGGL(k_finalize_stats, dim3((n + 63) / 64), dim3(64), 0, stream, stats, n,
+    hipLaunchKernelGGL(k_finalize_stats, dim3((n + 63) / 64), dim3(64), 0, sp, stats, n,
                        gpu_warp ? (p->batch_size > 0 ? (p->batch_size < n ? p->batch_size : n) : n) : 0, blur ? 1 : 0);
     const float* dL = gray;
     const float* dR = gray;
@@ -541,7 +588,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
                                p->mode != CS_MODE_LEFT_ONLY && p->mode != CS_MODE_ONLY_RIGHT &&
                                al256((size_t)n * hw * 4) < (1ull << 32) - (1u << 20);
         rc = launch_blur(gray, n, h, w, p->depth_blur_strength, p->depth_blur_edge_threshold, p->depth_blur_strength, p->depth_blur_falloff,
-                         p->depth_blur_vert_smooth, L, R, (float*)(ws + W.wl), (float*)(ws + W.wr), stats, 1, stream,
+                         p->depth_blur_vert_smooth, L, R, (float*)(ws + W.wl), (float*)(ws + W.wr), stats, 1, sp,
                          dev_switch(CS_DEBUG_BLUR_FULL_COPY) ? nullptr : (uint32_t*)(ws + W.tilemap), want_lazy ? &lazy : nullptr);
         if (rc) return fail_blur(rc);
         dL = L; dR = R;
@@ -550,6 +597,11 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     const double left_div = p->divergence * (1 + p->stereo_balance);
     const double right_div = p->divergence * (1 - p->stereo_balance);
 
+    if (sp != stream) {   // the warp of this chunk waits for its pre-pass; the next chunk's pre-pass runs under it
+        hipError_t e = hipEventRecord(ready, sp);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, ready, 0);
+        if (e != hipSuccess) return fail_hip(e, "chunk hand-over");
+    }
     ProfScope prof(stream);
     if (gpu_warp) {
         rc = launch_gpuwarp_node(p, image, dL, dR, scale_from_stats, stats, stereo, depth_l, depth_r, mask, out_h, out_w,
@@ -601,6 +653,54 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CS_OK : fail_hip(e, "cs_generate");
+}
+
+int cs_generate(const cs_params* p, const float* image, const float* depth, float* stereo, float* depth_l,
+                float* depth_r, float* mask, void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p || !image || !depth || !stereo || !depth_l || !depth_r || !mask || !workspace) return fail(CS_EINVAL, "null pointer");
+    if (p->n <= 0 || p->h <= 0 || p->w <= 0 || p->depth_h <= 0 || p->depth_w <= 0 || p->depth_c <= 0)
+        return fail(CS_EINVAL, "non-positive size");
+    if (p->fill < 0 || p->fill > CS_FILL_HYBRID_EDGE_PLUS) return fail(CS_EINVAL, "unknown fill technique");
+    int out_h, out_w, mask_h, mask_w;
+    int rc = cs_output_shape(p, &out_h, &out_w, &mask_h, &mask_w);
+    if (rc) return rc;
+    if (p->w > cs_max_width_mode(p->fill, p->mode)) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
+    if (workspace_bytes < ws_total(p)) return fail(CS_EWORKSPACE, "workspace too small");
+    if (p->fill == CS_FILL_GPU_WARP && (p->flags & 2)) return fail(CS_EINVAL, "gpu_warp colours are not k/255: no uint8 stereoscope output");
+    if ((p->flags & 24) && !dialect_d64_ok(p->fill))
+        return fail(CS_EINVAL, "dialect D64 (flags bits 3/4) exists for none / naive / naive_interpolating / inverse only");
+    char* const ws = (char*)workspace;
+    uint32_t* const stats = (uint32_t*)ws;
+    char* const scratch = ws + al256((size_t)p->n * ST_WORDS * 4);
+    const ChunkPlan C = plan_chunks(p);
+    if (C.nch == 1) return generate_chunk(p, image, depth, stereo, depth_l, depth_r, mask, stats, scratch, out_h, out_w, stream, stream, nullptr);
+
+    AuxStream* const X = aux_stream();
+    if (!X) return fail_hip(hipGetLastError(), "auxiliary stream");
+    // fork: the pre-passes start after everything the caller has enqueued so far (inputs, the previous call's use of the
+    // workspace); join: the last chunk's warp waits for the last pre-pass, and the auxiliary stream holds nothing else
+    hipError_t e = hipEventRecord(X->fork, stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(X->s, X->fork, 0);
+    if (e != hipSuccess) return fail_hip(e, "chunk fork");
+    cs_params q = *p;
+    q.n = C.cf;
+    const size_t chunk_ws = ws_layout(&q).total;
+    const size_t in_px = (size_t)p->h * p->w, d_px = (size_t)p->depth_h * p->depth_w * p->depth_c;
+    const size_t st_px = (size_t)out_h * out_w * 3, mk_px = (size_t)mask_h * mask_w;
+    const size_t st_bytes = (p->flags & 2) ? 1 : 4;   // uint8 stereoscope codes (flags bit 1) or float32
+    rc = CS_OK;
+    for (int c = 0; c < C.nch && rc == CS_OK; c++) {
+        const int f0 = c * C.cf;
+        q.n = (f0 + C.cf <= p->n) ? C.cf : p->n - f0;
+        rc = generate_chunk(&q, image + f0 * in_px * 3, depth + f0 * d_px, (float*)((char*)stereo + f0 * st_px * st_bytes),
+                            depth_l + f0 * in_px * 3, depth_r + f0 * in_px * 3, mask + f0 * mk_px, stats + (size_t)f0 * ST_WORDS,
+                            scratch + (size_t)c * chunk_ws, out_h, out_w, X->s, stream, X->ready[c % AUX_EVENTS]);
+    }
+    if (rc != CS_OK) {   // whatever was enqueued on the auxiliary stream still precedes the caller's next work
+        if (hipEventRecord(X->ready[0], X->s) == hipSuccess) (void)hipStreamWaitEvent(stream, X->ready[0], 0);
+    }
+    return rc;
 }
 
 size_t cs_asd_workspace_bytes(int n, int h, int w) {

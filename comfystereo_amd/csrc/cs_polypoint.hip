@@ -43,7 +43,12 @@ namespace cs {
 #define PP_DEV_IS(n) false
 #define PP_HAZARD(code) do { hazard = true; } while (0)
 #endif
+#ifndef PP_DCAP
 #define PP_DCAP 128          // pixels under reversed segments a tile can hold in its lists (more -> row redo)
+#endif
+#ifndef PP_MINW
+#define PP_MINW 7            // workgroups per CU the default geometry is compiled for (register budget)
+#endif
 #define PP_DIRTY 0x80u       // dflag: pixel lies under a reversed segment; low 7 bits = its list slot
 
 __constant__ csm::PowfTables c_pp_powf_tables = CS_POWF_TABLES_INIT;
@@ -907,6 +912,9 @@ static int polypoint_tile(int w, int S, int nslots, int nt) {
     if (nslots + 1 >= 4096) return 0;  // 12-bit point field of the list entries
     int tmax = (nslots - 2 * S - 4) & ~3;
     if (tmax > 4 * nt) tmax = 4 * nt;  // one pass zeroes the per-pixel flags
+#ifdef PP_TMAX
+    if (tmax > PP_TMAX) tmax = PP_TMAX;   // (development: narrower tiles)
+#endif
     if (tmax < 64) return 0;
     const int tiles = (w + tmax - 1) / tmax;
     int t = ((w + tiles - 1) / tiles + 3) & ~3;
@@ -920,7 +928,10 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
     constexpr int KP = 4, KS = 5;
     const int tiles = (A.w + A.T - 1) / A.T;
     dim3 grid(tiles * 8, (A.h + 7) / 8, A.single >= 0 ? A.n : 2 * A.n), block(NT);   // (see the kernel's prologue)
-    const size_t lds = polypoint_lds(NT, SLOTS, A.T, KP, KS);
+    size_t lds = polypoint_lds(NT, SLOTS, A.T, KP, KS);
+    // (development: CS_DEBUG_PT_VARIANT 13..16 pads the LDS request so that only 3..6 workgroups fit a CU -- occupancy what-if)
+    const int occ = dev_switch(CS_DEBUG_PT_VARIANT) - 10;
+    if (occ >= 3 && occ <= 6) { const size_t pad = (size_t)(163840 / (occ + 1) + 1024) & ~(size_t)255; if (pad > lds) lds = pad; }
 #define PP_LAUNCH(O)                                                                                                         \
     {                                                                                                                        \
         hipError_t e = hipFuncSetAttribute((const void*)k_polypoint<NT, SLOTS, O, KP, KS, MINW>,                             \
@@ -971,7 +982,7 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     case 4: return polypoint_launch<256, 4, 5>(A, out, stream);
     case 5: return polypoint_launch<384, 3, 7>(A, out, stream);
     case 6: return polypoint_launch<320, 3, 6>(A, out, stream);
-    default: return polypoint_launch<256, 3, 7>(A, out, stream);
+    default: return polypoint_launch<256, 3, PP_MINW>(A, out, stream);
     }
 }
 

@@ -305,3 +305,61 @@ def test_bench_batch_of_64_frames_through_the_lazy_blur_tiles(engine, dev_switch
         ref = small.run(img[f0:f0 + 4], depth[f0:f0 + 4])
         for k in range(4):
             assert torch.equal(out[k][f0:f0 + 4], ref[k]), (f0, k)
+
+
+# ---- every BASELINE.json configuration at its full frame size against the oracle (round 3) -------------------------------
+NAMES = ("stereoscope", "depth_left", "depth_right", "mask")
+
+
+def test_cfg3_4k_hybrid_edge_blur_on_vs_oracle(engine):
+    """BASELINE cfg 3: one 4K frame, divergence 8, hybrid_edge + edge-aware depth blur (reference
+    stereoimage_generation.py:1622-1661, :1745-1774): stereoscope, both depth maps and the imperfect-fill mask, bit for bit."""
+    img = synth.image_f32(1, H4, W4, seed=21)
+    depth = synth.depth_batch("stepped", 1, H4, W4, channels=3)
+    got = gen(engine, img, depth, "hybrid_edge", "left-right")
+    want = node_oracle.generate(img, depth, 8.0, 0.0, "left-right", 0.0, 0.5, 2.0, "Imperfect fill - Hybrid Edge", 20.0, 20.0, True,
+                                depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+    for g, w_, name in zip(got, want, NAMES):
+        assert g.shape == w_.shape and np.array_equal(g, w_), name
+    assert want[3].sum() > 0   # the mask is not trivially empty: pixels with no touched neighbour stay black
+
+
+def test_cfg5_4k_no_fill_anaglyph_mask_vs_oracle(engine):
+    """BASELINE cfg 5: one 4K frame, `No fill`, red-cyan anaglyph (:1850-1868, :1996-2010) with the no-fill mask
+    (GenerateStereo.py:355-361) compared with array_equal -- "bit-exact masks vs reference"."""
+    img = synth.image_f32(1, H4, W4, seed=22)
+    depth = synth.depth_batch("stepped", 1, H4, W4, channels=3)
+    got = gen(engine, img, depth, "none", "red-cyan-anaglyph")
+    want = node_oracle.generate(img, depth, 8.0, 0.0, "red-cyan-anaglyph", 0.0, 0.5, 2.0, "No fill", 20.0, 20.0, True,
+                                depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+    for g, w_, name in zip(got, want, NAMES):
+        assert g.shape == w_.shape and np.array_equal(g, w_), name
+    assert 0 < want[3].mean() < 0.5   # disocclusions of both eyes' holes that coincide in the composite + genuine black pixels
+
+
+def test_cfg4_1080p_gpu_warp_sub_batch_vs_oracle(engine):
+    """BASELINE cfg 4: one reference sub-batch (batch_size 12) of 1080p frames, gpu_warp, radial depth with a moving centre
+    (stereoimage_generation.py:1005-1128, :277-450): masks and depth maps exact, colours within the bounds of
+    conftest.assert_warp_colours (the oracle mirrors torch's arithmetic: 2e-6)."""
+    n, h, w = 12, 1080, 1920
+    img = synth.image_f32(1, h, w, seed=23).repeat(n, axis=0)
+    img[1::2] = img[1::2, ::-1]   # (two different images, cheaply)
+    depth = synth.depth_batch("radial", n, h, w, channels=3)
+    got = gen(engine, img, depth, "gpu_warp", "left-right", div=4.5)
+    want = node_oracle.generate(img, depth, 4.5, 0.0, "left-right", 0.0, 0.5, 2.0, "GPU Warp (Fast)", 20.0, 20.0, True,
+                                depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+    for k in (1, 2, 3):
+        assert got[k].shape == want[k].shape and np.array_equal(got[k], want[k]), NAMES[k]
+    assert np.abs(got[0] - want[0]).max() <= 2e-6
+
+
+def test_cfg2_1080p_polylines_soft_frame_vs_oracle(engine):
+    """BASELINE cfg 2: 1080p, divergence 3.5, polylines_soft, left-right (:1912-1992)."""
+    n, h, w = 2, 1080, 1920
+    img = synth.image_f32(n, h, w, seed=24)
+    depth = synth.depth_batch("stepped", n, h, w, channels=3)
+    got = gen(engine, img, depth, "polylines_soft", "left-right", div=3.5)
+    want = node_oracle.generate(img, depth, 3.5, 0.0, "left-right", 0.0, 0.5, 2.0, "Fill - Polylines Soft", 20.0, 20.0, True,
+                                depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+    for g, w_, name in zip(got, want, NAMES):
+        assert np.array_equal(g, w_), name
