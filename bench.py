@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--verify", action="store_true", help="N > 1: check the reassembled float32 batch against a local float32 run")
+    ap.add_argument("--gather", default="collective", choices=["collective", "p2p"],
+                    help="N > 1: all_gather_into_tensor (RCCL) or the direct peer fan-out (batched send / recv to every peer)")
     a = ap.parse_args()
     cfg = dict(CONFIGS[a.config])
     frames = a.frames or cfg["frames"]
@@ -163,7 +165,7 @@ def main():
     # all-gather of the rank's block.
     job = None
     if world > 1 and not gpu_warp:
-        job = sharding.ShardedStereoJob(params, frames, (out_h, out_w, 3), device)
+        job = sharding.ShardedStereoJob(params, frames, (out_h, out_w, 3), device, method=a.gather)
         plans = job.plans
     else:
         plan = engine.Plan(params(nloc), device)
@@ -186,7 +188,7 @@ def main():
         elif job is not None:
             job.step(image, depth, expand=expand)
         else:
-            gathered_f32[0] = sharding.all_gather_frames(plan.run(image, depth)[0], bounds)
+            gathered_f32[0] = sharding.all_gather_frames(plan.run(image, depth)[0], bounds, method=a.gather)
 
     def fence():
         torch.cuda.synchronize()
@@ -207,6 +209,15 @@ def main():
             dt = float(t.item())
         return dt
 
+    ranks = None
+    if world > 1:   # what the collective library really spans: an all-reduce of ones, every rank's device
+        ones = torch.ones(1, dtype=torch.int32, device=device)
+        dist.all_reduce(ones)
+        devs = [None] * world
+        dist.all_gather_object(devs, {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(local_rank),
+                                      "pci": getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None)})
+        ranks = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "all_reduce_of_ones": int(ones.item()),
+                 "devices": devs}
     L = _native.lib()
     for _ in range(a.warmup):
         step()
@@ -268,26 +279,36 @@ def main():
                     traffic_source = f"profiles/pmc_traffic.json[{key}] (PMC passes of {tj[key].get('profile', 'the committed profile')}, not measured in this run)"
             except Exception:  # noqa: BLE001
                 traffic = None
+        # The dominant kernel's OWN algorithmic bytes: it reads the image (12 B/px) and one 4-byte depth value per eye (the
+        # blurred maps of the two eyes; one shared gray map with the blur off) and writes every output; the 12 B/px RGB depth
+        # input of the node is read by the gray / blur pre-pass, not by this kernel.  `frac` is quoted on these bytes;
+        # `frac_node_bytes` divides the whole node boundary's bytes by the same kernel time and
+        # `pipeline_frac` by the whole step.
+        own_px = cfg["bytes_px"] - 12 + (8 if blur else 4)
+        own_bytes = frames_per_launch * own_px * H * W
+        achieved_own = own_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        pipeline = frames * a.steps * cfg["bytes_px"] * H * W / dt / 1e9 / world
+        roofline = {"bound": "hbm", "achieved": achieved_own, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved_own / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                    "kernel": cfg["kernel"], "kernel_ms": kern_ms, "launches": launches.value,
+                    "launches_per_step": launches_per_step,
+                    "algorithmic_bytes_per_launch": own_bytes,
+                    "algorithmic_bytes_note": f"{own_px} B per source pixel = what this kernel reads and writes once (image 12, one depth value "
+                                              f"per eye, every output); the node boundary of SURVEY.md 8d is {cfg['bytes_px']} B/px (it adds the "
+                                              "12 B/px RGB depth input that the gray / blur pre-pass reads)",
+                    "achieved_node_bytes": achieved, "frac_node_bytes": achieved / HBM_PEAK_GBS,
+                    "pipeline_achieved": pipeline, "pipeline_frac": pipeline / HBM_PEAK_GBS}
         line = {
             "metric": cfg["name"], "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg['what']}, depth blur {'on' if blur else 'off'} (widget defaults)",
                        "frames_total": frames, "frames_per_gpu": nloc, "sharding": "by frame, contiguous blocks",
+                       "gather": a.gather if world > 1 else None,
                        "collective": "none" if world == 1 else (
                            f"all_gather(stereoscope as uint8 codes) over RCCL in {job.n_chunks} chunk(s) overlapped with compute"
                            " + expand to float32 on every rank" if job is not None else "all_gather(stereoscope float32) over RCCL")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": cfg["kernel"], "kernel_ms": kern_ms, "launches": launches.value,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "algorithmic_bytes_note": f"{cfg['bytes_px']} B per source pixel = every input read once and every output written "
-                                                   "once at the float32 node boundary (SURVEY.md 8d); the dominant kernel itself does not "
-                                                   "read the 12 B/px RGB depth input (the gray / blur pre-pass does): kernel-own bytes = "
-                                                   f"{cfg['bytes_px'] - 12 + (8 if blur else 4)} B/px",
-                         # the same with the kernel's OWN algorithmic bytes (its depth input is the gray / blurred depth, not RGB)
-                         "frac_kernel_own": achieved / HBM_PEAK_GBS * (cfg["bytes_px"] - 12 + (8 if blur else 4)) / cfg["bytes_px"],
-                         "pipeline_achieved": frames * a.steps * cfg["bytes_px"] * H * W / dt / 1e9 / world},
+            "roofline": roofline,
             "diagnostics": {"rows_redone_by_general_kernel": tile_redo_rows, "rows_replayed_sequentially": fallback_rows,
                             "kernel_error_flags": err_flags},
         }
@@ -295,6 +316,8 @@ def main():
             line["value_blur_off"] = value_blur_off
         if split is not None:
             line["split"] = split
+        if ranks is not None:
+            line["ranks"] = ranks
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, a.cpu_frames, blur)
         elif not a.no_cpu_baseline:

@@ -496,7 +496,7 @@ static WsLayout ws_layout(const cs_params* p) {
 // k > 1 = k chunks whatever the batch.
 struct ChunkPlan { int nch, cf; };
 static ChunkPlan plan_chunks(const cs_params* p) {
-    const int n = p->n, forced = dev_switch(CS_DEBUG_CHUNKS);
+    const int n = p->n, forced = dev_switch(CS_DEBUG_CHUNKS) % 100;   // (+100: auxiliary stream of the LOWEST priority)
     int unit = 1;
     if (p->fill == CS_FILL_GPU_WARP) unit = p->batch_size > 0 ? (p->batch_size < n ? p->batch_size : n) : n;
     if (forced == 1 || n < 2 * unit) return ChunkPlan{1, n};
@@ -525,16 +525,17 @@ static size_t ws_total(const cs_params* p) {
 static const int AUX_MAX_DEV = 16, AUX_EVENTS = 8;
 struct AuxStream { hipStream_t s; hipEvent_t fork, ready[AUX_EVENTS]; bool ok; };
 static std::mutex g_aux_mu;
-static AuxStream g_aux[AUX_MAX_DEV];
-static AuxStream* aux_stream() {
+static AuxStream g_aux[AUX_MAX_DEV][2];
+// low = 0: the highest priority the device offers, 1: the lowest (the pre-pass only fills what the warp leaves free)
+static AuxStream* aux_stream(int low) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= AUX_MAX_DEV) return nullptr;
     std::lock_guard<std::mutex> lock(g_aux_mu);
-    AuxStream& A = g_aux[dev];
+    AuxStream& A = g_aux[dev][low ? 1 : 0];
     if (A.ok) return &A;
     int least = 0, greatest = 0;   // (the numerically lowest value is the highest priority)
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
-    if (hipStreamCreateWithPriority(&A.s, hipStreamNonBlocking, greatest) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithPriority(&A.s, hipStreamNonBlocking, low ? least : greatest) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&A.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
     for (int i = 0; i < AUX_EVENTS; i++)
         if (hipEventCreateWithFlags(&A.ready[i], hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -676,7 +677,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     const ChunkPlan C = plan_chunks(p);
     if (C.nch == 1) return generate_chunk(p, image, depth, stereo, depth_l, depth_r, mask, stats, scratch, out_h, out_w, stream, stream, nullptr);
 
-    AuxStream* const X = aux_stream();
+    AuxStream* const X = aux_stream(dev_switch(CS_DEBUG_CHUNKS) >= 100);
     if (!X) return fail_hip(hipGetLastError(), "auxiliary stream");
     // fork: the pre-passes start after everything the caller has enqueued so far (inputs, the previous call's use of the
     // workspace); join: the last chunk's warp waits for the last pre-pass, and the auxiliary stream holds nothing else

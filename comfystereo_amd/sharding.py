@@ -27,13 +27,39 @@ def _host_staged(t, group=None):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def all_gather_frames(local, bounds, group=None):
-    """All-gather tensors whose dim 0 is this rank's frame block -> the full [N, ...] tensor on every rank."""
+def all_gather_frames(local, bounds, group=None, method="collective"):
+    """All-gather tensors whose dim 0 is this rank's frame block -> the full [N, ...] tensor on every rank.
+
+    method "collective": one `all_gather_into_tensor` (RCCL picks ring / direct by message size).
+    method "p2p": direct peer fan-out (SURVEY.md 8e's fallback) -- every rank sends its block to each peer and receives each
+    peer's block straight into its slice of the result, all 2 (world - 1) transfers in one batch: on the fully connected
+    xGMI node every pair has its own link, so a rank's block leaves over its 7 links at once instead of travelling a ring;
+    blocks of different sizes need no padding."""
     if _host_staged(local, group):
-        return all_gather_frames(local.cpu(), bounds, group).to(local.device)
+        return all_gather_frames(local.cpu(), bounds, group, method).to(local.device)
     world = dist.get_world_size(group)
     sizes = [bounds[r + 1] - bounds[r] for r in range(world)]
     n = bounds[-1]
+    if method == "p2p":
+        rank = dist.get_rank(group)
+        local = local.contiguous()
+        out = torch.empty((n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        out[bounds[rank]:bounds[rank + 1]].copy_(local)
+        ops = []
+        for r in range(world):
+            peer = dist.get_global_rank(group, r) if group is not None else r
+            if r == rank:
+                continue
+            if sizes[rank]:
+                ops.append(dist.P2POp(dist.isend, local, peer, group))
+            if sizes[r]:
+                ops.append(dist.P2POp(dist.irecv, out[bounds[r]:bounds[r + 1]], peer, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return out
+    if method != "collective":
+        raise ValueError(f"unknown all-gather method {method!r}")
     if len(set(sizes)) == 1:
         out = torch.empty((n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
@@ -47,7 +73,7 @@ def all_gather_frames(local, bounds, group=None):
 
 
 def generate_sharded(run_local, image, depth_map, fill, batch_size, group=None, gather=("stereoscope", "mask"),
-                     expand=None):
+                     expand=None, method="collective"):
     """Run `run_local(image_block, depth_block) -> (stereo, depth_l, depth_r, mask)` on this rank's frame block
     and reassemble the requested outputs on every rank.  `image` / `depth_map` are the FULL batch (each rank
     slices its own block; nothing is sent before compute).
@@ -68,7 +94,7 @@ def generate_sharded(run_local, image, depth_map, fill, batch_size, group=None, 
         local = tuple(t[:0] for t in probe)
     out = {}
     for name, t in zip(names, local):
-        out[name] = all_gather_frames(t, bounds, group) if name in gather else t
+        out[name] = all_gather_frames(t, bounds, group, method) if name in gather else t
     if expand is not None and "stereoscope" in gather:
         out["stereoscope"] = expand(out["stereoscope"])
     return out, bounds
@@ -90,7 +116,11 @@ class ChunkedGather:
     def usable(n_frames, world, n_chunks):
         return n_frames % world == 0 and (n_frames // world) % n_chunks == 0 and n_frames >= world * n_chunks
 
-    def __init__(self, n_frames, n_chunks, frame_shape, dtype, device, group=None):
+    def __init__(self, n_frames, n_chunks, frame_shape, dtype, device, group=None, method="collective"):
+        """method: "collective" (all_gather_into_tensor) or "p2p" (direct peer fan-out, see all_gather_frames)."""
+        if method not in ("collective", "p2p"):
+            raise ValueError(f"unknown all-gather method {method!r}")
+        self.method = method
         self.group = group
         self.world = dist.get_world_size(group)
         assert self.usable(n_frames, self.world, n_chunks)
@@ -111,17 +141,33 @@ class ChunkedGather:
         """Local frame range of chunk c inside this rank's block."""
         return c * self.cf, (c + 1) * self.cf
 
+    def _gather_async(self, dst, src):
+        """Start the gather of `src` (this rank's chunk) into `dst` ([world * cf, ...]); returns the requests to wait for."""
+        if self.method == "collective":
+            return [dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)]
+        rank = dist.get_rank(self.group)
+        dst[rank * self.cf:(rank + 1) * self.cf].copy_(src)
+        ops = []
+        for r in range(self.world):
+            if r == rank:
+                continue
+            peer = dist.get_global_rank(self.group, r) if self.group is not None else r
+            ops.append(dist.P2POp(dist.isend, src, peer, self.group))
+            ops.append(dist.P2POp(dist.irecv, dst[r * self.cf:(r + 1) * self.cf], peer, self.group))
+        return dist.batch_isend_irecv(ops) if ops else []
+
     def launch(self, c, local_chunk):
         assert local_chunk.shape[0] == self.cf and local_chunk.is_contiguous()
         if self.host:
             self.h_local[c].copy_(local_chunk, non_blocking=True)
             torch.cuda.current_stream().synchronize()  # the host copy must be complete before gloo reads it
-            self.works[c] = dist.all_gather_into_tensor(self.h_all[c], self.h_local[c], group=self.group, async_op=True)
+            self.works[c] = self._gather_async(self.h_all[c], self.h_local[c])
             return
-        self.works[c] = dist.all_gather_into_tensor(self.staging[c], local_chunk, group=self.group, async_op=True)
+        self.works[c] = self._gather_async(self.staging[c], local_chunk)
 
     def finish(self, c, sink):
-        self.works[c].wait()
+        for req in self.works[c]:
+            req.wait()
         self.works[c] = None
         if self.host:
             self.staging[c].copy_(self.h_all[c], non_blocking=True)
@@ -139,14 +185,14 @@ class ShardedStereoJob:
     make_params(n_frames) -> engine params for a chunk of that many frames.  step(image_block, depth_block) returns the
     reassembled float32 stereoscope [N, out_h, out_w, 3] (the same tensor every step)."""
 
-    def __init__(self, make_params, n_frames, out_shape, device, group=None, chunk_options=(4, 2, 1)):
+    def __init__(self, make_params, n_frames, out_shape, device, group=None, chunk_options=(4, 2, 1), method="collective"):
         from . import engine
         self.engine = engine
         world = dist.get_world_size(group)
         self.n_chunks = next((k for k in chunk_options if ChunkedGather.usable(n_frames, world, k)), 0)
         if self.n_chunks == 0:
             raise ValueError(f"{n_frames} frames do not split evenly over {world} ranks")
-        self.cg = ChunkedGather(n_frames, self.n_chunks, tuple(out_shape), torch.uint8, device, group)
+        self.cg = ChunkedGather(n_frames, self.n_chunks, tuple(out_shape), torch.uint8, device, group, method)
         self.plans = [engine.Plan(make_params(self.cg.cf), device, stereo_u8=True) for _ in range(self.n_chunks)]
         self.gathered = torch.empty((n_frames,) + tuple(out_shape), dtype=torch.float32, device=device)
         self.bounds = self.cg.bounds

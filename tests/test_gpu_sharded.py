@@ -114,8 +114,9 @@ def test_two_ranks_with_the_hip_kernels_equal_the_oracle_on_the_whole_batch(fill
     assert all(ok for _, ok, _ in res), res
 
 
-@pytest.mark.parametrize("config,frames", [("metric", 8), ("cfg5", 4), ("cfg4", 48)])
-def test_bench_two_ranks_verify(config, frames):
+@pytest.mark.parametrize("config,frames,gather", [("metric", 8, "collective"), ("cfg5", 4, "collective"), ("cfg4", 48, "collective"),
+                                                  ("metric", 8, "p2p"), ("cfg4", 48, "p2p")])
+def test_bench_two_ranks_verify(config, frames, gather):
     """`bench.py --gpus 2 --verify` (the N > 1 step the driver times) as two torchrun ranks sharing the GPU: every rank's
     block of the reassembled batch and one foreign sub-batch equal a local float32 run; the line carries the three-way
     split of BASELINE.md section 4."""
@@ -123,7 +124,7 @@ def test_bench_two_ranks_verify(config, frames):
     env = dict(os.environ, CS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--config", config, "--frames", str(frames), "--verify", "--no-cpu-baseline"]
+           "--config", config, "--frames", str(frames), "--verify", "--no-cpu-baseline", "--gather", gather]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("[verify] rank") == 2 and "MISMATCH" not in r.stdout
@@ -131,3 +132,5 @@ def test_bench_two_ranks_verify(config, frames):
     assert line["n_gpus"] == 2 and line["config"]["frames_total"] == frames
     assert set(line["split"]) >= {"kernels_only_fps", "kernels_plus_allgather_fps", "end_to_end_fps"}
     assert line["diagnostics"]["kernel_error_flags"] == 0
+    assert line["ranks"]["world_size"] == 2 and line["ranks"]["all_reduce_of_ones"] == 2 and len(line["ranks"]["devices"]) == 2
+    assert line["config"]["gather"] == gather

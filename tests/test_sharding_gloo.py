@@ -32,7 +32,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, fill, n, q):
+def _worker(rank, world, port, fill, n, q, method="collective"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -62,7 +62,8 @@ def _worker(rank, world, port, fill, n, q):
         def expand(k):
             return k.to(torch.float32) / 255.0
 
-    out, bounds = sharding.generate_sharded(run_local, torch.from_numpy(img), torch.from_numpy(dep), fill, 2, expand=expand)
+    out, bounds = sharding.generate_sharded(run_local, torch.from_numpy(img), torch.from_numpy(dep), fill, 2, expand=expand,
+                                            method=method)
     full = node_oracle.generate(img, dep, *args, batch_size=2)
     ok = np.array_equal(out["stereoscope"].numpy(), full[0]) and np.array_equal(out["mask"].numpy(), full[3])
     ok = ok and out["depth_left"].shape[0] == bounds[rank + 1] - bounds[rank]
@@ -71,12 +72,14 @@ def _worker(rank, world, port, fill, n, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fill,n", [("polylines_soft", 5), ("gpu_warp", 6), ("none", 1)])
-def test_two_rank_gather_equals_unsharded(fill, n):
+@pytest.mark.parametrize("fill,n,method", [("polylines_soft", 5, "collective"), ("gpu_warp", 6, "collective"), ("none", 1, "collective"),
+                                           ("polylines_soft", 5, "p2p"), ("none", 1, "p2p")])
+def test_two_rank_gather_equals_unsharded(fill, n, method):
+    """both forms of the all-gather: the collective and the direct peer fan-out (unequal blocks, an empty block)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, fill, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, fill, n, q, method)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -86,13 +89,13 @@ def test_two_rank_gather_equals_unsharded(fill, n):
     assert all(ok for _, ok, _ in res), res
 
 
-def _chunk_worker(rank, world, port, n, chunks, q):
+def _chunk_worker(rank, world, port, n, chunks, q, method="collective"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     shape = (3, 5)
     full = torch.arange(n * 15, dtype=torch.int32).reshape(n, *shape).to(torch.uint8)  # frame f is recognisable
-    g = sharding.ChunkedGather(n, chunks, shape, torch.uint8, "cpu")
+    g = sharding.ChunkedGather(n, chunks, shape, torch.uint8, "cpu", method=method)
     b0 = g.bounds[rank]
     out = torch.zeros((n,) + shape, dtype=torch.float32)
     for step in range(2):  # the staging buffers are reused step after step
@@ -112,14 +115,14 @@ def _chunk_worker(rank, world, port, n, chunks, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,chunks", [(8, 2), (12, 3), (4, 1)])
-def test_chunked_gather_reassembles_in_frame_order(n, chunks):
+@pytest.mark.parametrize("n,chunks,method", [(8, 2, "collective"), (12, 3, "collective"), (4, 1, "collective"), (12, 3, "p2p")])
+def test_chunked_gather_reassembles_in_frame_order(n, chunks, method):
     """sharding.ChunkedGather (bench.py's N > 1 step): chunk c of every rank lands at bounds[r] + c * cf."""
     assert sharding.ChunkedGather.usable(64, 8, 4) and not sharding.ChunkedGather.usable(10, 4, 2)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_chunk_worker, args=(r, 2, port, n, chunks, q)) for r in range(2)]
+    procs = [ctx.Process(target=_chunk_worker, args=(r, 2, port, n, chunks, q, method)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)
