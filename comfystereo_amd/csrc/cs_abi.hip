@@ -486,27 +486,25 @@ static WsLayout ws_layout(const cs_params* p) {
 }
 
 // ---- frame chunks: the pre-pass of chunk c + 1 under the warp of chunk c ---------------------------------------------
-// The warp kernels are bound by instruction issue (k_polypoint: VALU busy 85 %, HBM half idle), the pre-pass (gray depth,
-// edge bit rows, tile classification, fused blur) by HBM.  A call therefore cuts its batch into chunks of frames -- every
-// quantity of the path is per frame (gpu_warp: per reference sub-batch, so its chunks are multiples of batch_size) -- and
-// issues the pre-pass of every chunk on an auxiliary high-priority stream, the warps on the caller's stream, one event per
-// chunk in between: while chunk c is warped, the pre-pass of chunk c + 1 fills the idle memory system.  Fork / join is by
-// events only (legal under stream capture); all work the call enqueues is ordered before whatever the caller enqueues
-// next on its stream.  cs_debug_set(CS_DEBUG_CHUNKS, 1) = one chunk on the caller's stream alone (the round-2 schedule),
-// k > 1 = k chunks whatever the batch.
+// A call can cut its batch into chunks of frames -- every quantity of the path is per frame (gpu_warp: per reference
+// sub-batch, so its chunks are multiples of batch_size) -- and issue the pre-pass of every chunk (gray depth, edge bit rows,
+// tile classification, fused blur: HBM-bound) on an auxiliary stream, the warps on the caller's stream, one event per chunk
+// in between, so that the pre-pass of chunk c + 1 runs under the warp of chunk c.  Fork / join is by events only (legal
+// under stream capture); all work the call enqueues is ordered before whatever the caller enqueues next on its stream.
+// MEASURED (round 3, profiles/r03_overlap.txt): the schedule is correct and overlaps, and it is a zero-sum game -- the warp
+// kernels are bound by the latency of their resident workgroups (k_polypoint: time x workgroups per CU is constant from 3
+// to 6 workgroups per CU), every co-resident pre-pass workgroup takes wave slots and memory queue from them: 64 4K frames
+// polylines_soft 14.3 ms in one chunk, 14.5 / 14.8 / 15.1 / 15.6 ms in 2 / 4 / 8 / 16 chunks with the auxiliary stream at
+// the highest priority, 14.3 / 14.5 / 14.8 in 2 / 4 / 8 at the caller's priority; cfg 3 / 4 / 5 gain 0.1 - 2 %.  The
+// default is therefore ONE chunk on the caller's stream; cs_debug_set(CS_DEBUG_CHUNKS, k) with k > 1 cuts k chunks
+// (+100: auxiliary stream at the default priority instead of the highest).
 struct ChunkPlan { int nch, cf; };
 static ChunkPlan plan_chunks(const cs_params* p) {
-    const int n = p->n, forced = dev_switch(CS_DEBUG_CHUNKS) % 100;   // (+100: auxiliary stream of the LOWEST priority)
+    const int n = p->n, forced = dev_switch(CS_DEBUG_CHUNKS) % 100;   // (+100: auxiliary stream at the default priority)
     int unit = 1;
     if (p->fill == CS_FILL_GPU_WARP) unit = p->batch_size > 0 ? (p->batch_size < n ? p->batch_size : n) : n;
-    if (forced == 1 || n < 2 * unit) return ChunkPlan{1, n};
-    const size_t hw = (size_t)p->h * p->w;
-    // a chunk's pre-pass must outlast the launch gaps it introduces: at least ~32 Mpixel per chunk, at most 4 chunks
-    int minf = forced > 1 ? 1 : (int)(((size_t)32 << 20) / hw);
-    if (minf < 1) minf = 1;
-    const int want = forced > 1 ? forced : 4;
-    int cf = (n + want - 1) / want;
-    if (cf < minf) cf = minf;
+    if (forced <= 1 || n < 2 * unit) return ChunkPlan{1, n};
+    int cf = (n + forced - 1) / forced;
     cf = (cf + unit - 1) / unit * unit;
     const int nch = (n + cf - 1) / cf;
     if (nch < 2) return ChunkPlan{1, n};

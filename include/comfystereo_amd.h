@@ -223,7 +223,7 @@ enum cs_debug_key {
     CS_DEBUG_BLUR_TWO_PASS = 3,     /* depth blur: two-pass row kernels */
     CS_DEBUG_BLUR_EDGES_SCALAR = 4, /* depth blur: one-column-per-lane edge kernel */
     CS_DEBUG_BLUR_FULL_COPY = 5,    /* depth blur: write the edge-free tiles as well (no lazy tile map for the warp kernel) */
-    CS_DEBUG_CHUNKS = 6,            /* cs_generate: 1 = one chunk on the caller's stream (no auxiliary stream), k > 1 = k frame chunks */
+    CS_DEBUG_CHUNKS = 6,            /* cs_generate: k > 1 = k frame chunks, pre-passes on an auxiliary stream (+100: at default priority); default one chunk */
     CS_DEBUG_KEYS = 8
 };
 CS_API int cs_debug_set(int key, int value);

@@ -1,5 +1,6 @@
-"""Frame chunks of cs_generate (cs_abi.hip plan_chunks / generate_chunk): a batch is cut into chunks of frames, the pre-pass
-of chunk c + 1 (gray depth, min / max, depth blur) runs on an auxiliary high-priority stream under the warp of chunk c.
+"""Frame chunks of cs_generate (cs_abi.hip plan_chunks / generate_chunk; a development option -- measured zero-sum, the
+default is one chunk): a batch is cut into chunks of frames, the pre-pass of chunk c + 1 (gray depth, min / max, depth blur)
+runs on an auxiliary stream under the warp of chunk c.
 
 Every quantity of the path is per frame (reference GenerateStereo.py:181-269 loops over frames; gpu_warp decides its two
 0..255 scalings per sub-batch of `batch_size` frames, :119-128 and stereoimage_generation.py:1045, :313-316), so the chunked
@@ -93,11 +94,12 @@ def test_chunked_uint8_stereoscope_and_stats(engine, dev_switch):
     assert st.shape == (n, 16) and int(st[:, 9].sum()) == 0
 
 
-def test_auto_chunks_on_a_batch(engine, dev_switch):
-    """The automatic plan (4K-sized work per chunk) on a 1080p batch equals the one-chunk schedule."""
+def test_chunks_on_a_1080p_batch(engine, dev_switch):
+    """Four chunks of a 1080p batch (auxiliary stream at the default priority) equal the one-chunk schedule."""
     n, h, w = 32, 1080, 1920
     img = synth.image_f32(1, h, w, seed=14).repeat(n, axis=0)
     depth = synth.depth_batch("stepped", n, h, w, channels=3)
+    dev_switch("chunks", 104)
     auto = run(engine, img, depth, "polylines_soft", "left-right", True)
     dev_switch("chunks", 1)
     one = run(engine, img, depth, "polylines_soft", "left-right", True)
