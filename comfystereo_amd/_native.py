@@ -29,7 +29,7 @@ ABI_VERSION = 2
 EXPORTS = [
     "cs_version", "cs_last_error", "cs_max_width", "cs_max_width_mode", "cs_output_shape", "cs_workspace_bytes", "cs_generate",
     "cs_asd_workspace_bytes", "cs_apply_stereo_divergence", "cs_apply_stereo_divergence2", "cs_blur_workspace_bytes", "cs_directional_blur",
-    "cs_warp_workspace_bytes", "cs_forward_warp", "cs_warp_mesh_workspace_bytes", "cs_forward_warp_mesh", "cs_expand_u8", "cs_stereo_shift_workspace_bytes", "cs_stereo_shift", "cs_profile", "cs_profile_read", "cs_debug_set",
+    "cs_warp_workspace_bytes", "cs_forward_warp", "cs_warp_mesh_workspace_bytes", "cs_forward_warp_mesh", "cs_expand_u8", "cs_pack_u8", "cs_host_expand_u8", "cs_host_copy", "cs_stereo_shift_workspace_bytes", "cs_stereo_shift", "cs_profile", "cs_profile_read", "cs_debug_set",
     "cs_test_powf", "cs_test_exp",
 ]
 
@@ -110,6 +110,12 @@ def lib():
     L.cs_forward_warp_mesh.argtypes = [vp, vp, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_double, vp, vp, vp, c_size, vp]
     L.cs_forward_warp.restype = c_int
     L.cs_forward_warp.argtypes = [vp, vp, c_int, c_int, c_int, c_double, c_double, c_double, c_double, vp, vp, vp, c_size, vp]
+    L.cs_pack_u8.restype = c_int
+    L.cs_pack_u8.argtypes = [vp, vp, c_size, c_int, c_int, vp]
+    L.cs_host_expand_u8.restype = c_int
+    L.cs_host_expand_u8.argtypes = [vp, vp, c_size, c_int, c_int, c_int]
+    L.cs_host_copy.restype = c_int
+    L.cs_host_copy.argtypes = [vp, vp, c_size, c_int]
     L.cs_stereo_shift_workspace_bytes.restype = c_size
     L.cs_stereo_shift_workspace_bytes.argtypes = []
     L.cs_stereo_shift.restype = c_int

@@ -179,6 +179,28 @@ __global__ void __launch_bounds__(256) k_expand_u8(const uint8_t* __restrict__ i
 }
 
 
+// float32 node outputs -> their uint8 codes (the compact form the host pipeline moves over PCIe): mode 0: value k / 255 -> k
+// (exact: fl(k / 255) * 255 lies within half an ulp-scale of k); mode 1: non-zero flag (mask).  `stride` floats between
+// consecutive values (3: one code per pixel of a three-equal-channel depth map).
+__global__ void __launch_bounds__(256) k_pack_u8(const float* __restrict__ in, uint8_t* __restrict__ out, size_t count, int stride,
+                                                 int mode) {
+    const size_t nq = count / 4, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nq; i += step) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float v = in[(4 * i + j) * (size_t)stride];
+            const uint32_t k = mode ? (v != 0.0f ? 1u : 0u) : (uint32_t)__builtin_rintf(v * 255.0f);
+            pk |= (k & 0xffu) << (8 * j);
+        }
+        reinterpret_cast<uint32_t*>(out)[i] = pk;
+    }
+    for (size_t i = 4 * nq + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += step) {
+        const float v = in[i * (size_t)stride];
+        out[i] = (uint8_t)(mode ? (v != 0.0f ? 1u : 0u) : (uint32_t)__builtin_rintf(v * 255.0f));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // stereo_shift_torch (reference stereo_utils.py:15-88): the `none` forward map on a float payload (latents [b][c][h][w]).
 // One workgroup per (row, batch item): winner source column per destination by LDS atomics (the reference's sweep makes the
@@ -829,6 +851,16 @@ int cs_expand_u8(const uint8_t* codes, float* out, size_t count, void* stream) {
     return e == hipSuccess ? CS_OK : fail_hip(e, "cs_expand_u8");
 }
 
+
+int cs_pack_u8(const float* values, uint8_t* codes, size_t count, int stride, int mode, void* stream) {
+    if (!values || !codes) return fail(CS_EINVAL, "null pointer");
+    if (stride < 1 || mode < 0 || mode > 1) return fail(CS_EINVAL, "cs_pack_u8: stride >= 1, mode 0 (k / 255 values) or 1 (mask flags)");
+    if ((uintptr_t)codes & 3) return fail(CS_EINVAL, "cs_pack_u8 needs a 4-byte aligned code buffer");
+    if (count == 0) return CS_OK;
+    hipLaunchKernelGGL(k_pack_u8, dim3(grid_for(count / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, values, codes, count, stride, mode);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CS_OK : fail_hip(e, "cs_pack_u8");
+}
 
 size_t cs_stereo_shift_workspace_bytes(void) { return al256(ST_WORDS * 4); }
 

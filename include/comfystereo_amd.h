@@ -190,6 +190,21 @@ CS_API int cs_forward_warp_mesh(const float *image, const float *depth, int n, i
 CS_API int cs_expand_u8(const uint8_t *codes, float *out, size_t count, void *stream);
 
 /*
+ * The compact node boundary of the host pipeline (replaces the float32 device -> host copies around
+ * convertResult / np2tensor / generate_mask, reference GenerateStereo.py:41-44, 159-177, 355-378).
+ * cs_pack_u8 (device): codes[i] = the uint8 code of values[i * stride] -- mode 0: value k / 255 -> k; mode 1: non-zero -> 1
+ * (mask).  stride 3 takes one code per pixel of a depth map with three equal channels.
+ * cs_host_expand_u8 (HOST memory, blocking, `threads` worker threads, 0 = one per online core up to 64):
+ * out[i * replicate + r] = codes[i] / 255.0f (mode 0, true division) or codes[i] != 0 (mode 1), r < replicate <= 4.
+ * Bit-identical to the float32 outputs of cs_generate for the CPU techniques.
+ */
+CS_API int cs_pack_u8(const float *values, uint8_t *codes, size_t count, int stride, int mode, void *stream);
+CS_API int cs_host_expand_u8(const uint8_t *codes, float *out, size_t count, int replicate, int mode, int threads);
+/* cs_host_copy (HOST memory, blocking): memcpy in `threads` contiguous slices (0 = one per online core up to 64) -- the
+ * staging copy of a pageable input tensor into a pinned buffer (reference GenerateStereo.py:126-131, .to(device)). */
+CS_API int cs_host_copy(void *dst, const void *src, size_t bytes, int threads);
+
+/*
  * stereo_shift_torch (reference stereo_utils.py:15-88; callers stereodiffusion_nodes.py:650, :664): the depth-driven
  * forward shift of the `none` technique on a float payload -- diffusion latents.  input [b][c][h][w] float32, depth
  * [b][h][w] float32 (normalised with its global min / max like the reference, :36-45) -> out [2b][c][h][w]: the left

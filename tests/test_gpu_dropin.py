@@ -109,12 +109,24 @@ def test_host_pipeline_equals_the_whole_batch(monkeypatch, fill, n, batch):
     per_frame_out = 4 * (h * 2 * w * 3 + 2 * h * w * 3 + h * 2 * w)
     monkeypatch.setattr(host_pipeline, "CHUNK_OUT_BYTES", 2 * per_frame_out + 1)  # two frames per chunk
     seen = []
-    for pinned in (True, False):  # results written straight into pinned tensors / staged into pageable ones
+    for pinned in (True, False):  # float32 boundary: results written straight into pinned tensors / staged into pageable ones
         seen.clear()
-        got = host_pipeline.generate_host(img, dep, *args, progress=seen.append, pinned_outputs=pinned)
+        got = host_pipeline.generate_host(img, dep, *args, progress=seen.append, pinned_outputs=pinned, compact=False)
         assert sum(seen) == n
         for g, r in zip(got, ref):
             assert not g.is_cuda and g.is_pinned() == pinned and torch.equal(g, r)
+    if fill != "gpu_warp":
+        # compact boundary (round 3; the default for the CPU techniques): uint8 codes over PCIe, float32 written by host threads
+        monkeypatch.setattr(host_pipeline, "CHUNK_IN_BYTES", 2 * 4 * (h * w * 3 + h * w * 3) + 1)  # two frames per chunk
+        for threads in (0, 1, 3):
+            seen.clear()
+            got = host_pipeline.generate_host(img, dep, *args, progress=seen.append, expand_threads=threads)
+            assert sum(seen) == n
+            for g, r in zip(got, ref):
+                assert not g.is_cuda and not g.is_pinned() and g.dtype == torch.float32 and torch.equal(g, r)
+    else:
+        with pytest.raises(ValueError):
+            host_pipeline.generate_host(img, dep, *args, compact=True)
     # caller-provided result tensors: pinned ones are written directly, pageable ones through the staging
     shapes = host_pipeline.result_shapes(img.shape, "left-right", fill)
     for pin in (True, False):

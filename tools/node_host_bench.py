@@ -58,3 +58,12 @@ for _ in range(a.iters):
 torch.cuda.synchronize()
 dt_out = (time.perf_counter() - t0) / a.iters
 print(f"results into caller-provided pinned tensors (out=): {a.n/dt_out:.1f} frames/s, {gb/dt_out:.1f} GB/s")
+if fill != "gpu_warp":   # the float32 boundary of round 2 for comparison (compact=False)
+    host_pipeline.generate_host(img, dep, *hargs, compact=False)
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        o = host_pipeline.generate_host(img, dep, *hargs, compact=False)
+        del o
+    torch.cuda.synchronize()
+    dt_f = (time.perf_counter() - t0) / a.iters
+    print(f"float32 boundary (compact=False, pinned results): {a.n/dt_f:.1f} frames/s")
