@@ -1412,6 +1412,161 @@ __global__ void __launch_bounds__(256) k_hybrid_fill(RowArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// hybrid_edge, second pass in STREAMING form (round 3; eyes in separate slots -- side by side, top / bottom, one eye, the
+// uint8 form of apply_stereo_divergence -- and w % 4 == 0).  edge_aware_gap_fill (reference :1745-1774) changes only the
+// untouched pixels that have a touched neighbour: a few percent.  So
+//   k_hybrid_out4 : four pixels per lane with 16-byte accesses: the splat result of EVERY pixel -> stereoscope slot, mask,
+//                   both depth-map outputs (the elementwise 95+ % of the pass at the streaming rate); untouched pixels are
+//                   appended to the list of their (frame, eye, row) -- 16-bit columns, one wave-aggregated atomic per wave
+//                   on the row's own counter (no hot address);
+//   k_hybrid_gaps : one wave per (frame, eye, row), one lane per listed pixel: the 3 x 3 window of touched neighbours in the
+//                   reference's raster order (float32 sums are order-dependent), libm-exact float64 exp, and the pixel's
+//                   stereoscope value and mask are overwritten where the window is not empty.
+// k_hybrid_fill above remains for the anaglyph modes (the composite's mask needs both eyes of a pixel) and odd widths.
+// ---------------------------------------------------------------------------------------------
+struct U3 { uint32_t x, y, z; };
+__global__ void __launch_bounds__(256) k_hybrid_out4(RowArgs A, uint32_t* __restrict__ gap_count, uint16_t* __restrict__ gap_list) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int j = (blockIdx.x * 256 + tid) * 4, row = blockIdx.y, frame = blockIdx.z;
+    const int w = A.w, h = A.h;
+    const bool live = j < w;   // (w % 4 == 0: a live lane owns four whole pixels)
+    const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
+    const size_t pix = ((size_t)frame * h + row) * w + j;
+    for (int e = 0; e < A.neyes; e++) {   // (wave-uniform control flow: the ballots below need whole waves)
+        if (A.single >= 0 && A.single != e) continue;
+        uint32_t c[3] = {0, 0, 0};   // 12 colour bytes of the four pixels
+        unsigned gap = 0;
+        if (live) {
+            if (!A.eye[e].enabled) {   // divergence < 0.001: the source image (quirk Q10)
+                uint8_t b[12];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) b[3 * q + ch] = src_u8(A, frame, row, j + q, ch);
+#pragma unroll
+                for (int q = 0; q < 3; q++) c[q] = (uint32_t)b[4 * q] | ((uint32_t)b[4 * q + 1] << 8) | ((uint32_t)b[4 * q + 2] << 16) | ((uint32_t)b[4 * q + 3] << 24);
+            } else {
+                const size_t epix = (((size_t)frame * A.neyes + e) * h + row) * (size_t)w + j;
+                const U3 v = *reinterpret_cast<const U3*>(A.hyb_base + epix * 3);
+                c[0] = v.x; c[1] = v.y; c[2] = v.z;
+                const uint32_t m = *reinterpret_cast<const uint32_t*>(A.hyb_mask + epix);
+#pragma unroll
+                for (int q = 0; q < 4; q++) gap |= (((m >> (8 * q)) & 0xffu) == 0u ? 1u : 0u) << q;
+            }
+        }
+        // ---- untouched pixels -> the row's list
+        {
+            unsigned long long mb[4];
+            unsigned total = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                mb[q] = __ballot((gap >> q) & 1u);
+                total += (unsigned)__popcll(mb[q]);
+            }
+            if (total) {   // wave-uniform
+                const size_t rid = ((size_t)frame * A.neyes + e) * h + row;
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&gap_count[rid], total);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                uint16_t* lst = gap_list + rid * (size_t)w;
+                unsigned before = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mb[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb[q], 0u));
+                    if ((gap >> q) & 1u) lst[base + before + below] = (uint16_t)(j + q);
+                    before += (unsigned)__popcll(mb[q]);
+                }
+            }
+        }
+        if (!live) continue;
+        // ---- the four pixels in their output form
+        const uint32_t r0 = c[0] & 0xff, g0 = (c[0] >> 8) & 0xff, b0 = (c[0] >> 16) & 0xff, r1 = c[0] >> 24;
+        const uint32_t g1 = c[1] & 0xff, b1 = (c[1] >> 8) & 0xff, r2 = (c[1] >> 16) & 0xff, g2 = c[1] >> 24;
+        const uint32_t b2 = c[2] & 0xff, r3 = (c[2] >> 8) & 0xff, g3 = (c[2] >> 16) & 0xff, b3 = c[2] >> 24;
+        if (A.out_u8) {
+            *reinterpret_cast<U3*>(A.out_u8 + pix * 3) = U3{c[0], c[1], c[2]};
+        } else {
+            const EyeArgs& E = A.eye[e];
+            const size_t o = ((size_t)frame * A.out_h + row + E.yoff) * A.out_w + E.xoff + j;
+            if (A.stereo_is_u8) *reinterpret_cast<U3*>(reinterpret_cast<uint8_t*>(A.stereo) + o * 3) = U3{c[0], c[1], c[2]};
+            else {
+                float4* d = reinterpret_cast<float4*>(A.stereo + o * 3);
+                using csm::code_over_255;
+                d[0] = make_float4(code_over_255((float)r0), code_over_255((float)g0), code_over_255((float)b0), code_over_255((float)r1));
+                d[1] = make_float4(code_over_255((float)g1), code_over_255((float)b1), code_over_255((float)r2), code_over_255((float)g2));
+                d[2] = make_float4(code_over_255((float)b2), code_over_255((float)r3), code_over_255((float)g3), code_over_255((float)b3));
+            }
+            *reinterpret_cast<float4*>(A.mask + o) = make_float4((r0 + g0 + b0) == 0 ? 1.0f : 0.0f, (r1 + g1 + b1) == 0 ? 1.0f : 0.0f,
+                                                                 (r2 + g2 + b2) == 0 ? 1.0f : 0.0f, (r3 + g3 + b3) == 0 ? 1.0f : 0.0f);
+        }
+    }
+    // depth-map outputs: (depth*255).astype(uint8) wraps mod 256 (quirk Q7), then /255, 3 channels
+    if (live && A.depth_l) {
+        const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
+        for (int e = 0; e < 2; e++) {
+            const float4 dv = *reinterpret_cast<const float4*>(A.eye[e].depth + pix);
+            const float v0 = csm::code_over_255((float)csm::f32_to_u8_wrap((dv.x * scale) * 255.0f));
+            const float v1 = csm::code_over_255((float)csm::f32_to_u8_wrap((dv.y * scale) * 255.0f));
+            const float v2 = csm::code_over_255((float)csm::f32_to_u8_wrap((dv.z * scale) * 255.0f));
+            const float v3 = csm::code_over_255((float)csm::f32_to_u8_wrap((dv.w * scale) * 255.0f));
+            float4* d = reinterpret_cast<float4*>((e == 0 ? A.depth_l : A.depth_r) + pix * 3);
+            d[0] = make_float4(v0, v0, v0, v1);
+            d[1] = make_float4(v1, v1, v2, v2);
+            d[2] = make_float4(v2, v3, v3, v3);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_hybrid_gaps(RowArgs A, const uint32_t* __restrict__ gap_count, const uint16_t* __restrict__ gap_list) {
+    const int row = blockIdx.x, e = blockIdx.y, frame = blockIdx.z;
+    const int w = A.w, h = A.h;
+    const size_t rid = ((size_t)frame * A.neyes + e) * h + row;
+    const unsigned count = gap_count[rid];
+    if (count == 0) return;
+    const uint16_t* lst = gap_list + rid * (size_t)w;
+    const uint8_t* base = A.hyb_base + (((size_t)frame * A.neyes + e) * h) * (size_t)w * 3;
+    const uint8_t* mask = A.hyb_mask + (((size_t)frame * A.neyes + e) * h) * (size_t)w;
+    for (unsigned i = threadIdx.x; i < count; i += 64) {
+        const int j = lst[i];
+        float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
+        double wt = 0.0, gc = 0.0;
+        bool have = false;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {   // the reference's raster order over the window (:1757-1770)
+            if (k == 4) continue;
+            const int ni = row + k / 3 - 1, nj = j + k % 3 - 1;
+            if (ni < 0 || ni >= h || nj < 0 || nj >= w) continue;
+            if (mask[(size_t)ni * w + nj] == 0) continue;
+            if (!have) { gc = hyb_guidance(A, frame, row, j); have = true; }
+            // math.exp(-dsq / 2) for dsq = 1, 2: the two values of glibc's exp (see k_hybrid_fill)
+            const double w_s = (k & 1) ? CS_EXP_M05 : CS_EXP_M10;
+            const double diff = gc - hyb_guidance(A, frame, ni, nj);
+            const double wg = w_s * csm::exp_exact(-(diff * diff) / 200.0, d_hyb_exp_tab);
+            const float wg32 = (float)wg;
+            const uint8_t* nb = base + ((size_t)ni * w + nj) * 3;
+            n0 = n0 + (float)nb[0] * wg32;
+            n1 = n1 + (float)nb[1] * wg32;
+            n2 = n2 + (float)nb[2] * wg32;
+            wt += wg;
+        }
+        if (!(wt > 0.0)) continue;   // no touched neighbour: the pixel stays as k_hybrid_out4 wrote it ("imperfect" mask)
+        const float wt32 = (float)wt;
+        float r0 = n0 / wt32, r1 = n1 / wt32, r2 = n2 / wt32;
+        r0 = fminf(fmaxf(r0, 0.0f), 255.0f); r1 = fminf(fmaxf(r1, 0.0f), 255.0f); r2 = fminf(fmaxf(r2, 0.0f), 255.0f);
+        const uint8_t cr = (uint8_t)(int)r0, cg = (uint8_t)(int)r1, cb = (uint8_t)(int)r2;
+        if (A.out_u8) {
+            *reinterpret_cast<Px3b*>(A.out_u8 + (((size_t)frame * h + row) * w + j) * 3) = Px3b{cr, cg, cb};
+        } else {
+            const EyeArgs& E = A.eye[e];
+            const size_t o = ((size_t)frame * A.out_h + row + E.yoff) * A.out_w + E.xoff + j;
+            if (A.stereo_is_u8) *reinterpret_cast<Px3b*>(reinterpret_cast<uint8_t*>(A.stereo) + o * 3) = Px3b{cr, cg, cb};
+            else *reinterpret_cast<Px3f*>(A.stereo + o * 3) = Px3f{csm::code_over_255((float)cr), csm::code_over_255((float)cg), csm::code_over_255((float)cb)};
+            A.mask[o] = ((int)cr + (int)cg + (int)cb) == 0 ? 1.0f : 0.0f;  // GenerateStereo.py:355-361
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // the row kernel
 // ---------------------------------------------------------------------------------------------
 // Destination of one eye row: converts uint8 pixels to the output layout as they are produced.
@@ -1697,7 +1852,13 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
 
 size_t rowwarp_lds_bytes(int fill, int w, int anaglyph) { return lds_common_bytes(fill, w, anaglyph) + lds_tech_bytes(fill, w); }
 
-size_t hybrid_workspace_bytes(int n, int h, int w) { return (size_t)n * 2 * h * w * 4 + 256; }
+// splat result (3 + 1 bytes per pixel and eye), then the gap lists of the streaming fill: a counter per (frame, eye, row) and
+// 16-bit columns, w per row
+static size_t hybrid_splat_bytes(int n, int h, int w) { return ((size_t)n * 2 * h * w * 4 + 255) & ~(size_t)255; }
+static size_t hybrid_count_bytes(int n, int h) { return ((size_t)n * 2 * h * 4 + 255) & ~(size_t)255; }
+size_t hybrid_workspace_bytes(int n, int h, int w) {
+    return hybrid_splat_bytes(n, h, w) + hybrid_count_bytes(n, h) + (size_t)n * 2 * h * w * 2 + 256;
+}
 int hybrid_max_width() {
     int lo = 0, hi = 1 << 15;
     while (lo < hi) {
@@ -1723,7 +1884,16 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int pl
     } else
         hipLaunchKernelGGL(k_hybrid_splat, dim3(A.h, A.n, A.neyes), dim3(threads), lds, stream, A);
     if (plus) e = launch_rowwarp(CS_FILL_HYBRID_EDGE_PLUS, A, threads, stream);
-    else {
+    else if (!A.anaglyph && A.w % 4 == 0 && A.w <= 65535 && A.h <= 65535 && A.n <= 65535 && !dev_switch(CS_DEBUG_NO_TILE)) {
+        // streaming form: every pixel's splat result by 16-byte accesses, then the listed untouched pixels
+        uint32_t* cnt = (uint32_t*)((char*)workspace + hybrid_splat_bytes(A.n, A.h, A.w));
+        uint16_t* lst = (uint16_t*)((char*)cnt + hybrid_count_bytes(A.n, A.h));
+        e = hipMemsetAsync(cnt, 0, (size_t)A.n * A.neyes * A.h * 4, stream);
+        if (e != hipSuccess) return CS_EHIP;
+        hipLaunchKernelGGL(k_hybrid_out4, dim3((A.w / 4 + 255) / 256, A.h, A.n), dim3(256), 0, stream, A, cnt, lst);
+        hipLaunchKernelGGL(k_hybrid_gaps, dim3(A.h, A.neyes, A.n), dim3(64), 0, stream, A, (const uint32_t*)cnt, (const uint16_t*)lst);
+        e = hipGetLastError();
+    } else {
         hipLaunchKernelGGL(k_hybrid_fill, dim3((A.w + 255) / 256, A.h, A.n), dim3(256), 0, stream, A);
         e = hipGetLastError();
     }
