@@ -1425,94 +1425,106 @@ __global__ void __launch_bounds__(256) k_hybrid_fill(RowArgs A) {
 // k_hybrid_fill above remains for the anaglyph modes (the composite's mask needs both eyes of a pixel) and odd widths.
 // ---------------------------------------------------------------------------------------------
 struct U3 { uint32_t x, y, z; };
+// (every store instruction of a wave writes ONE contiguous kilobyte: the byte -> float expansion of the stereoscope is
+// elementwise in units of 4 bytes -> 16 bytes whatever the pixel boundaries; a first version that gave each lane four whole
+// pixels and three 16-byte stores 48 bytes apart ran at 3.4 TB/s instead of the streaming rate)
 __global__ void __launch_bounds__(256) k_hybrid_out4(RowArgs A, uint32_t* __restrict__ gap_count, uint16_t* __restrict__ gap_list) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int j = (blockIdx.x * 256 + tid) * 4, row = blockIdx.y, frame = blockIdx.z;
+    const int j0 = blockIdx.x * 1024, row = blockIdx.y, frame = blockIdx.z;   // this workgroup: pixels [j0, j0 + 1024) of the row
     const int w = A.w, h = A.h;
-    const bool live = j < w;   // (w % 4 == 0: a live lane owns four whole pixels)
+    const int npx = min(1024, w - j0);            // multiple of 4
+    const int nq = npx * 3 / 4;                   // 4-byte groups of the npx * 3 colour bytes / floats
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
-    const size_t pix = ((size_t)frame * h + row) * w + j;
+    const size_t pix0 = ((size_t)frame * h + row) * w + j0;
+    using csm::code_over_255;
     for (int e = 0; e < A.neyes; e++) {   // (wave-uniform control flow: the ballots below need whole waves)
         if (A.single >= 0 && A.single != e) continue;
-        uint32_t c[3] = {0, 0, 0};   // 12 colour bytes of the four pixels
+        const EyeArgs& E = A.eye[e];
+        const bool on = E.enabled;
+        const size_t epix0 = (((size_t)frame * A.neyes + e) * h + row) * (size_t)w + j0;
+        const size_t o0 = A.out_u8 ? pix0 : ((size_t)frame * A.out_h + row + E.yoff) * A.out_w + E.xoff + j0;
+        // ---- colours: byte group m (4 codes) -> 4 floats k / 255 (or the 4 codes)
+        for (int m = tid; m < nq; m += 256) {
+            uint32_t c;
+            if (on) c = reinterpret_cast<const uint32_t*>(A.hyb_base + epix0 * 3)[m];
+            else if (A.image_u8) c = reinterpret_cast<const uint32_t*>(A.image_u8 + pix0 * 3)[m];
+            else {   // divergence < 0.001: the source image (quirk Q10), np.clip(x * 255, 0, 255).astype(uint8)
+                const float4 v = reinterpret_cast<const float4*>(A.image_f32 + pix0 * 3)[m];
+                c = (uint32_t)(int)fminf(fmaxf(v.x * 255.0f, 0.0f), 255.0f) | ((uint32_t)(int)fminf(fmaxf(v.y * 255.0f, 0.0f), 255.0f) << 8) |
+                    ((uint32_t)(int)fminf(fmaxf(v.z * 255.0f, 0.0f), 255.0f) << 16) | ((uint32_t)(int)fminf(fmaxf(v.w * 255.0f, 0.0f), 255.0f) << 24);
+            }
+            if (A.out_u8) reinterpret_cast<uint32_t*>(A.out_u8 + o0 * 3)[m] = c;
+            else if (A.stereo_is_u8) reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.stereo) + o0 * 3)[m] = c;
+            else reinterpret_cast<float4*>(A.stereo + o0 * 3)[m] =
+                     make_float4(code_over_255((float)(c & 0xffu)), code_over_255((float)((c >> 8) & 0xffu)),
+                                 code_over_255((float)((c >> 16) & 0xffu)), code_over_255((float)(c >> 24)));
+        }
+        // ---- mask of four whole pixels per lane (GenerateStereo.py:355-361) and the untouched pixels -> the row's list
+        const int j = 4 * tid;
+        const bool live = j < npx;
         unsigned gap = 0;
         if (live) {
-            if (!A.eye[e].enabled) {   // divergence < 0.001: the source image (quirk Q10)
+            uint32_t c0, c1, c2;
+            if (on) { const U3 v = *reinterpret_cast<const U3*>(A.hyb_base + (epix0 + j) * 3); c0 = v.x; c1 = v.y; c2 = v.z; }
+            else {
                 uint8_t b[12];
 #pragma unroll
                 for (int q = 0; q < 4; q++)
 #pragma unroll
-                    for (int ch = 0; ch < 3; ch++) b[3 * q + ch] = src_u8(A, frame, row, j + q, ch);
+                    for (int ch = 0; ch < 3; ch++) b[3 * q + ch] = src_u8(A, frame, row, j0 + j + q, ch);
+                c0 = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+                c1 = (uint32_t)b[4] | ((uint32_t)b[5] << 8) | ((uint32_t)b[6] << 16) | ((uint32_t)b[7] << 24);
+                c2 = (uint32_t)b[8] | ((uint32_t)b[9] << 8) | ((uint32_t)b[10] << 16) | ((uint32_t)b[11] << 24);
+            }
+            if (on) {
+                const uint32_t mk = *reinterpret_cast<const uint32_t*>(A.hyb_mask + epix0 + j);
 #pragma unroll
-                for (int q = 0; q < 3; q++) c[q] = (uint32_t)b[4 * q] | ((uint32_t)b[4 * q + 1] << 8) | ((uint32_t)b[4 * q + 2] << 16) | ((uint32_t)b[4 * q + 3] << 24);
-            } else {
-                const size_t epix = (((size_t)frame * A.neyes + e) * h + row) * (size_t)w + j;
-                const U3 v = *reinterpret_cast<const U3*>(A.hyb_base + epix * 3);
-                c[0] = v.x; c[1] = v.y; c[2] = v.z;
-                const uint32_t m = *reinterpret_cast<const uint32_t*>(A.hyb_mask + epix);
-#pragma unroll
-                for (int q = 0; q < 4; q++) gap |= (((m >> (8 * q)) & 0xffu) == 0u ? 1u : 0u) << q;
+                for (int q = 0; q < 4; q++) gap |= (((mk >> (8 * q)) & 0xffu) == 0u ? 1u : 0u) << q;
+            }
+            if (!A.out_u8) {
+                const uint32_t s0 = (c0 & 0xff) + ((c0 >> 8) & 0xff) + ((c0 >> 16) & 0xff);
+                const uint32_t s1 = (c0 >> 24) + (c1 & 0xff) + ((c1 >> 8) & 0xff);
+                const uint32_t s2 = ((c1 >> 16) & 0xff) + (c1 >> 24) + (c2 & 0xff);
+                const uint32_t s3 = ((c2 >> 8) & 0xff) + ((c2 >> 16) & 0xff) + (c2 >> 24);
+                *reinterpret_cast<float4*>(A.mask + o0 + j) = make_float4(s0 == 0 ? 1.0f : 0.0f, s1 == 0 ? 1.0f : 0.0f, s2 == 0 ? 1.0f : 0.0f, s3 == 0 ? 1.0f : 0.0f);
             }
         }
-        // ---- untouched pixels -> the row's list
-        {
-            unsigned long long mb[4];
-            unsigned total = 0;
+        unsigned long long mb[4];
+        unsigned total = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            mb[q] = __ballot((gap >> q) & 1u);
+            total += (unsigned)__popcll(mb[q]);
+        }
+        if (total) {   // wave-uniform: one atomic per wave on the row's own counter
+            const size_t rid = ((size_t)frame * A.neyes + e) * h + row;
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&gap_count[rid], total);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            uint16_t* lst = gap_list + rid * (size_t)w;
+            unsigned before = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                mb[q] = __ballot((gap >> q) & 1u);
-                total += (unsigned)__popcll(mb[q]);
+                const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mb[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb[q], 0u));
+                if ((gap >> q) & 1u) lst[base + before + below] = (uint16_t)(j0 + j + q);
+                before += (unsigned)__popcll(mb[q]);
             }
-            if (total) {   // wave-uniform
-                const size_t rid = ((size_t)frame * A.neyes + e) * h + row;
-                unsigned base = 0;
-                if (lane == 0) base = atomicAdd(&gap_count[rid], total);
-                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                uint16_t* lst = gap_list + rid * (size_t)w;
-                unsigned before = 0;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mb[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb[q], 0u));
-                    if ((gap >> q) & 1u) lst[base + before + below] = (uint16_t)(j + q);
-                    before += (unsigned)__popcll(mb[q]);
-                }
-            }
-        }
-        if (!live) continue;
-        // ---- the four pixels in their output form
-        const uint32_t r0 = c[0] & 0xff, g0 = (c[0] >> 8) & 0xff, b0 = (c[0] >> 16) & 0xff, r1 = c[0] >> 24;
-        const uint32_t g1 = c[1] & 0xff, b1 = (c[1] >> 8) & 0xff, r2 = (c[1] >> 16) & 0xff, g2 = c[1] >> 24;
-        const uint32_t b2 = c[2] & 0xff, r3 = (c[2] >> 8) & 0xff, g3 = (c[2] >> 16) & 0xff, b3 = c[2] >> 24;
-        if (A.out_u8) {
-            *reinterpret_cast<U3*>(A.out_u8 + pix * 3) = U3{c[0], c[1], c[2]};
-        } else {
-            const EyeArgs& E = A.eye[e];
-            const size_t o = ((size_t)frame * A.out_h + row + E.yoff) * A.out_w + E.xoff + j;
-            if (A.stereo_is_u8) *reinterpret_cast<U3*>(reinterpret_cast<uint8_t*>(A.stereo) + o * 3) = U3{c[0], c[1], c[2]};
-            else {
-                float4* d = reinterpret_cast<float4*>(A.stereo + o * 3);
-                using csm::code_over_255;
-                d[0] = make_float4(code_over_255((float)r0), code_over_255((float)g0), code_over_255((float)b0), code_over_255((float)r1));
-                d[1] = make_float4(code_over_255((float)g1), code_over_255((float)b1), code_over_255((float)r2), code_over_255((float)g2));
-                d[2] = make_float4(code_over_255((float)b2), code_over_255((float)r3), code_over_255((float)g3), code_over_255((float)b3));
-            }
-            *reinterpret_cast<float4*>(A.mask + o) = make_float4((r0 + g0 + b0) == 0 ? 1.0f : 0.0f, (r1 + g1 + b1) == 0 ? 1.0f : 0.0f,
-                                                                 (r2 + g2 + b2) == 0 ? 1.0f : 0.0f, (r3 + g3 + b3) == 0 ? 1.0f : 0.0f);
         }
     }
-    // depth-map outputs: (depth*255).astype(uint8) wraps mod 256 (quirk Q7), then /255, 3 channels
-    if (live && A.depth_l) {
+    // ---- depth-map outputs: (depth*255).astype(uint8) wraps mod 256 (quirk Q7), then /255 on 3 channels.  Float group m of
+    // the [pixel][3] output covers pixels p = 4m / 3 and (m % 3 != 0 ? ... : p + 1): its four floats are
+    //   m % 3 == 0: p p p p+1     m % 3 == 1: p p p+1 p+1     m % 3 == 2: p p+1 p+1 p+1
+    if (A.depth_l) {
         const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
         for (int e = 0; e < 2; e++) {
-            const float4 dv = *reinterpret_cast<const float4*>(A.eye[e].depth + pix);
-            const float v0 = csm::code_over_255((float)csm::f32_to_u8_wrap((dv.x * scale) * 255.0f));
-            const float v1 = csm::code_over_255((float)csm::f32_to_u8_wrap((dv.y * scale) * 255.0f));
-            const float v2 = csm::code_over_255((float)csm::f32_to_u8_wrap((dv.z * scale) * 255.0f));
-            const float v3 = csm::code_over_255((float)csm::f32_to_u8_wrap((dv.w * scale) * 255.0f));
-            float4* d = reinterpret_cast<float4*>((e == 0 ? A.depth_l : A.depth_r) + pix * 3);
-            d[0] = make_float4(v0, v0, v0, v1);
-            d[1] = make_float4(v1, v1, v2, v2);
-            d[2] = make_float4(v2, v3, v3, v3);
+            const float* dsrc = A.eye[e].depth + pix0;
+            float4* ddst = reinterpret_cast<float4*>((e == 0 ? A.depth_l : A.depth_r) + pix0 * 3);
+            for (int m = tid; m < nq; m += 256) {
+                const int p = (4 * m) / 3, r = m - 3 * (m / 3);
+                const float va = code_over_255((float)csm::f32_to_u8_wrap((dsrc[p] * scale) * 255.0f));
+                const float vb = code_over_255((float)csm::f32_to_u8_wrap((dsrc[p + 1] * scale) * 255.0f));   // (p + 1 < npx: 4m + 3 < 3 npx)
+                ddst[m] = make_float4(va, r == 2 ? vb : va, r == 0 ? va : vb, vb);
+            }
         }
     }
 }
@@ -1890,7 +1902,7 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int pl
         uint16_t* lst = (uint16_t*)((char*)cnt + hybrid_count_bytes(A.n, A.h));
         e = hipMemsetAsync(cnt, 0, (size_t)A.n * A.neyes * A.h * 4, stream);
         if (e != hipSuccess) return CS_EHIP;
-        hipLaunchKernelGGL(k_hybrid_out4, dim3((A.w / 4 + 255) / 256, A.h, A.n), dim3(256), 0, stream, A, cnt, lst);
+        hipLaunchKernelGGL(k_hybrid_out4, dim3((A.w + 1023) / 1024, A.h, A.n), dim3(256), 0, stream, A, cnt, lst);
         hipLaunchKernelGGL(k_hybrid_gaps, dim3(A.h, A.neyes, A.n), dim3(64), 0, stream, A, (const uint32_t*)cnt, (const uint16_t*)lst);
         e = hipGetLastError();
     } else {
