@@ -1210,14 +1210,7 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
         int p2 = e1, e2 = binoff[q + 2];
         float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, ws = 0.0f;
         bool touched = false;
-        while (p0 < e0 || p1 < e1 || p2 < e2) {
-            const int x0 = p0 < e0 ? sorted[p0] : 0x7fffffff;
-            const int x1 = p1 < e1 ? sorted[p1] : 0x7fffffff;
-            const int x2 = p2 < e2 ? sorted[p2] : 0x7fffffff;
-            int j;
-            if (x0 < x1 && x0 < x2) { j = x0; p0++; }
-            else if (x1 < x2) { j = x1; p1++; }
-            else { j = x2; p2++; }
+        auto contribute = [&](int j) {
             const float diff = destx[j] - (float)jcol;
             const float arg = -(diff * diff) / 2.0f;
             const double wg = csm::exp_exact((double)arg, etab);
@@ -1227,6 +1220,25 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
             acc2 = (float)((double)acc2 + (double)((c >> 16) & 0xffu) * wg);
             ws = ws + (float)wg;
             touched = true;
+        };
+        // The three bins are adjacent in `sorted`.  Where the polyline runs forward the sources of bin q all precede those of
+        // bin q + 1 and those precede bin q + 2: the merged source order IS the concatenation sorted[p0 .. e2) -- checked at
+        // the two junctions; a wave whose lanes all pass (everywhere but at occlusion folds) skips the 3-way merge.
+        const bool ordered = !(p0 < e0 && e0 < e2 && sorted[e0 - 1] > sorted[e0]) && !(p0 < e1 && e1 < e2 && sorted[e1 - 1] > sorted[e1]);
+        if (__all(ordered || q >= wt)) {
+            for (int p = p0; __any(p < e2); p++)
+                if (p < e2) contribute(sorted[p]);
+        } else {
+            while (p0 < e0 || p1 < e1 || p2 < e2) {
+                const int x0 = p0 < e0 ? sorted[p0] : 0x7fffffff;
+                const int x1 = p1 < e1 ? sorted[p1] : 0x7fffffff;
+                const int x2 = p2 < e2 ? sorted[p2] : 0x7fffffff;
+                int j;
+                if (x0 < x1 && x0 < x2) { j = x0; p0++; }
+                else if (x1 < x2) { j = x1; p1++; }
+                else { j = x2; p2++; }
+                contribute(j);
+            }
         }
         uint8_t v[3] = {0, 0, 0};
         if (ws > 0.0f) {
