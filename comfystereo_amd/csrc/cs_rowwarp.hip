@@ -1152,6 +1152,8 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
     const size_t rowpix = ((size_t)frame * h + row) * w;
     const float* drow = E.depth + rowpix;
     const int pow_mode = A.dbg == 17 ? 0 : (A.e32 == 2.0f ? 2 : (A.e32 == 1.0f ? 1 : 0));
+    const bool range_ok = range > 0x1p-40f && range < 0x1p40f;
+    const float yr = range_ok ? rcp_refined(range) : 0.0f;
     __syncthreads();
     for (int j = tid; j < ns; j += HYT_NT) {
         const int x = s0 + j;
@@ -1161,7 +1163,12 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
         const uint32_t b = (uint32_t)(int)fminf(fmaxf(px[2] * 255.0f, 0.0f), 255.0f);
         img[j] = r | g << 8 | b << 16;
         const float d = drow[x] * scale;
-        const float nd = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
+        // (d - dmin) / range through the refined reciprocal of the frame's range (cs_common.h div_with: the IEEE quotient for
+        // numerators that are 0 or >= 2^-60 and a range within 2^+-40; anything else takes the full division, wave-uniformly)
+        const float a = d - dmin;
+        float qn = div_with(a, range, yr);
+        if (__any(!(a == 0.0f || a >= 0x1p-60f)) || !range_ok) qn = a / range;
+        const float nd = flat ? 0.0f - A.conv32 : qn - A.conv32;
         const float ax = fabsf(nd);
         float p;
         bool risky = pow_mode == 0;
@@ -1242,7 +1249,9 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
         }
         uint8_t v[3] = {0, 0, 0};
         if (ws > 0.0f) {
-            float v0 = acc0 / ws, v1 = acc1 / ws, v2 = acc2 / ws;
+            // (weights are exp(-d^2 / 2) with |d| < 2: ws >= 0.13, the sums are 0 or >= 0.13 -- div_with's proven range)
+            const float yw = rcp_refined(ws);
+            float v0 = div_with(acc0, ws, yw), v1 = div_with(acc1, ws, yw), v2 = div_with(acc2, ws, yw);
             v0 = v0 < 0.0f ? 0.0f : (v0 > 255.0f ? 255.0f : v0);
             v1 = v1 < 0.0f ? 0.0f : (v1 > 255.0f ? 255.0f : v1);
             v2 = v2 < 0.0f ? 0.0f : (v2 > 255.0f ? 255.0f : v2);
