@@ -697,12 +697,19 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     const ChunkPlan C = plan_chunks(p);
     if (C.nch == 1) return generate_chunk(p, image, depth, stereo, depth_l, depth_r, mask, stats, scratch, out_h, out_w, stream, stream, nullptr);
 
-    AuxStream* const X = aux_stream(dev_switch(CS_DEBUG_CHUNKS) >= 100);
-    if (!X) return fail_hip(hipGetLastError(), "auxiliary stream");
+    // mode (CS_DEBUG_CHUNKS / 100): 0 = pre-passes on the highest-priority auxiliary stream, warps on the caller's stream;
+    // 1 = pre-passes on an auxiliary stream of the default priority; 2 = pre-passes at the default priority AND the warps on
+    // the highest-priority auxiliary stream (the warp keeps its workgroup slots, the pre-pass only fills what is left)
+    const int mode = dev_switch(CS_DEBUG_CHUNKS) / 100;
+    AuxStream* const X = aux_stream(mode >= 1);
+    AuxStream* const Wp = mode == 2 ? aux_stream(0) : nullptr;
+    if (!X || (mode == 2 && !Wp)) return fail_hip(hipGetLastError(), "auxiliary stream");
+    hipStream_t warp_stream = Wp ? Wp->s : stream;
     // fork: the pre-passes start after everything the caller has enqueued so far (inputs, the previous call's use of the
     // workspace); join: the last chunk's warp waits for the last pre-pass, and the auxiliary stream holds nothing else
     hipError_t e = hipEventRecord(X->fork, stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(X->s, X->fork, 0);
+    if (e == hipSuccess && Wp) e = hipStreamWaitEvent(Wp->s, X->fork, 0);
     if (e != hipSuccess) return fail_hip(e, "chunk fork");
     cs_params q = *p;
     q.n = C.cf;
@@ -716,9 +723,13 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
         q.n = (f0 + C.cf <= p->n) ? C.cf : p->n - f0;
         rc = generate_chunk(&q, image + f0 * in_px * 3, depth + f0 * d_px, (float*)((char*)stereo + f0 * st_px * st_bytes),
                             depth_l + f0 * in_px * 3, depth_r + f0 * in_px * 3, mask + f0 * mk_px, stats + (size_t)f0 * ST_WORDS,
-                            scratch + (size_t)c * chunk_ws, out_h, out_w, X->s, stream, X->ready[c % AUX_EVENTS]);
+                            scratch + (size_t)c * chunk_ws, out_h, out_w, X->s, warp_stream, X->ready[c % AUX_EVENTS]);
     }
-    if (rc != CS_OK) {   // whatever was enqueued on the auxiliary stream still precedes the caller's next work
+    // join: whatever was enqueued on the auxiliary streams precedes the caller's next work (also after a failure)
+    if (Wp) {
+        if (hipEventRecord(Wp->fork, Wp->s) == hipSuccess) (void)hipStreamWaitEvent(stream, Wp->fork, 0);
+    }
+    if (rc != CS_OK || Wp) {
         if (hipEventRecord(X->ready[0], X->s) == hipSuccess) (void)hipStreamWaitEvent(stream, X->ready[0], 0);
     }
     return rc;
