@@ -741,9 +741,22 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
                 }
             }
         }
-        int so[PT_KS];
+        // x-extent of every listed segment, read once: the sub-interval loop below first finds the ACTIVE segments of a centre
+        // from these (x0 < centre <= x1; a missing or reversed segment never is), then evaluates only those -- in list order,
+        // which is all the reference's scan depends on: an inactive segment changes neither the count, nor the pick, nor the
+        // best closeness.  Under one reversed segment two layers overlap, so two evaluations replace five.
+        float se0[PT_KS], se1[PT_KS];
 #pragma unroll
-        for (int k = 0; k < PT_KS; k++) so[k] = (k < wns && k < nsg) ? (int)sgs[s * PT_KS + k] : -1;
+        for (int e = 0; e < PT_KS; e++) {
+            se0[e] = INFINITY; se1[e] = -INFINITY;
+            if (e < wns) {
+                const bool have = e < nsg;
+                const int oe = have ? (int)sgs[s * PT_KS + e] : 0;
+                const float x0 = P[oe].w, x1 = P[oe + 1].w;
+                se0[e] = have ? x0 : INFINITY;
+                se1[e] = have ? x1 : -INFINITY;
+            }
+        }
         float color0 = 0.5f, color1 = 0.5f, color2 = 0.5f;
         float prev = colf, a = -INFINITY;
         for (int k = 0; k <= wnp; k++) {   // wave-uniform trip count; lanes with k > np idle
@@ -761,40 +774,55 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             if (live && (center < prev || center > colp1)) PP_HAZARD(64);
             prev = live ? center : prev;
             const bool work = live && (sig64 ? C.sig_dd != 0.0 : sig_f != 0.0f);
-            int nact = 0, pick = -1, nqual = 0, best = -1;
+            unsigned am = 0;
+#pragma unroll
+            for (int e = 0; e < PT_KS; e++)
+                if (e < wns) am |= ((se0[e] < center) && !(se1[e] < center)) ? (1u << e) : 0u;
+            const int nact = __popc(am);
+            int nqual = 0, o_pick = -1, o_best = -1;
+            float ip_pick = 0.0f, ip_best = 0.0f;
             float bc = (float)(-1e-7);
             bool tie = false;
+            // one step of the reference's scan (:1972-1980) for a segment that is active (`on`), polyline point oe -> oe + 1.
+            // 0 < centre - x0 <= x1 - x0 <= 3 w: div_core's proven range.
+            auto scan_step = [&](bool on, int oe) {
+                const float x0 = P[oe].w, x1 = P[oe + 1].w;
+                const float ip_e = div_core(center - x0, x1 - x0);
+                o_pick = on ? oe : o_pick;
+                ip_pick = on ? ip_e : ip_pick;
+                const bool qual = on && 0.0f < ip_e && ip_e < 1.0f;
+                const float cl = (1.0f - ip_e) * pz[oe] + ip_e * pz[oe + 1];
+                nqual += qual ? 1 : 0;
+                const bool better = qual && bc < cl;
+                tie = better ? false : (tie || (qual && cl == bc));
+                o_best = better ? oe : o_best;
+                ip_best = better ? ip_e : ip_best;
+                bc = better ? cl : bc;
+            };
+            if (!__any(work && nact > 2)) {
 #pragma unroll
-            for (int e = 0; e < PT_KS; e++) {
-                if (e < wns) {
-                    const bool have = so[e] >= 0;
-                    const int oe = have ? so[e] : 0;
-                    const float e0 = P[oe].w, e1 = P[oe + 1].w;
-                    const bool actv = have && (e0 < center) && !(e1 < center);
-                    nact += actv ? 1 : 0;
-                    pick = actv ? e : pick;
-                    const float ip_e = (center - e0) / (e1 - e0);
-                    const bool qual = actv && 0.0f < ip_e && ip_e < 1.0f;
-                    const float cl = (1.0f - ip_e) * pz[oe] + ip_e * pz[oe + 1];
-                    nqual += qual ? 1 : 0;
-                    const bool better = qual && bc < cl;
-                    tie = better ? false : (tie || (qual && cl == bc));
-                    best = better ? e : best;
-                    bc = better ? cl : bc;
+                for (int t = 0; t < 2; t++) {
+                    const bool on = am != 0u;
+                    const int e = on ? __ffs((int)am) - 1 : 0;
+                    am &= am - 1u;
+                    scan_step(on, on ? (int)sgs[s * PT_KS + e] : 1);
                 }
+            } else {
+#pragma unroll
+                for (int e = 0; e < PT_KS; e++)
+                    if (e < wns) {
+                        const bool on = (am >> e) & 1u;
+                        scan_step(on, on ? (int)sgs[s * PT_KS + e] : 1);
+                    }
             }
             const bool multi = work && nact != 1;
             if (multi && (nqual == 0 || tie)) PP_HAZARD(128);
-            pick = (multi && best >= 0) ? best : pick;
-            const bool contrib = work && pick >= 0;
-            int o = 1;
-#pragma unroll
-            for (int e = 0; e < PT_KS; e++)
-                if (e < wns) o = (e == pick && so[e] >= 0) ? so[e] : o;
-            const float4 pl = P[contrib ? o : 1], pr = P[contrib ? o + 1 : 2];
-            const float x0 = contrib ? pl.w : 0.0f, x1 = contrib ? pr.w : 1.0f;
+            const bool use_best = multi && o_best >= 0;
+            const bool contrib = work && (use_best || o_pick >= 0);
+            const int o = contrib ? (use_best ? o_best : o_pick) : 1;
+            const float ip_k = use_best ? ip_best : ip_pick;   // (the chosen segment's parameter: the same division as :1986)
+            const float4 pl = P[o], pr = P[o + 1];
             const int jl = min(max(o - 1, 0), ns - 1), jr = min(max(o, 0), ns - 1);
-            const float ip_k = (center - x0) / (x1 - x0);
             const float om = 1.0f - ip_k;
             const float sgm = sig64 ? (float)C.sig_dd : sig_f;
             float n0 = color0 + (pl.x * om + pr.x * ip_k) * sgm;
