@@ -166,6 +166,10 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     uint16_t* pts = dpix + PP_DCAP;                                               // [DCAP][PT_KP]
     uint16_t* sgs = pts + PP_DCAP * PT_KP;                                        // [DCAP][PT_KS]
     int* flags = (int*)(sgs + PP_DCAP * PT_KS);                                   // [PF_WORDS]
+    // k / 255 (convertResult / np2tensor, reference GenerateStereo.py:41-44) by table: the kernel is bound by the NUMBER of
+    // vector instructions (one quad-cycle each whatever the type, profiles/r03_polypoint.txt), and a table read costs one
+    // (the shift) where the arithmetic of cs_math.h code_over_255 costs three; the LDS pipe has room
+    float* lut = (float*)(flags + PF_WORDS);                                      // [256]
 
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
     const uint32_t rowpix = ((uint32_t)frame * (uint32_t)h + (uint32_t)row) * (uint32_t)w;   // pixel index < 2^31 (checked on the host)
@@ -215,6 +219,9 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         reinterpret_cast<uint32_t*>(tabs_lds)[tid] = reinterpret_cast<const uint32_t*>(&c_pp_powf_tables)[tid];
     if (tid < (T + 3) / 4) reinterpret_cast<uint32_t*>(dflag)[tid] = 0;   // T <= 4 NT (checked on the host)
     if (tid < PP_DCAP / 2) reinterpret_cast<uint32_t*>(dcnt)[tid] = 0;
+    if (OUT == PO_F32) {
+        for (int i = tid; i < 256; i += NT) lut[i] = code_over_255((float)i);
+    }
     if (tid < PF_WORDS) {   // minima start at INT_MAX, maxima at -1, counters at 0
         constexpr unsigned is_min = (1u << PF_DLO) | (1u << PF_JLO), is_max = (1u << PF_DHI) | (1u << PF_JHI);
         flags[tid] = (int)(0x7fffffffu * ((is_min >> tid) & 1u)) | -(int)((is_max >> tid) & 1u);
@@ -266,6 +273,14 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         if (OUT != PO_ASD && OUT != PO_U8NM) *reinterpret_cast<float*>(mk_row + 4u * uq) = __builtin_fmaxf(__builtin_fmaxf(r, g), b) == 0.0f ? 1.0f : 0.0f;
     };
     auto emit = [&](int q, int r, int g, int b) { emit_f(q, (float)r, (float)g, (float)b); };   // the same from integer codes
+    // the same from the colour sums 0.5 <= k < 255.5 before truncation (the two hot call sites): the conversion truncates
+    auto emit_k = [&](int q, float k0, float k1, float k2) {
+        const uint32_t uq = (uint32_t)q;
+        const uint32_t r = (uint32_t)k0, g = (uint32_t)k1, b = (uint32_t)k2;
+        if (OUT == PO_F32) *reinterpret_cast<F3*>(st_row + 12u * uq) = F3{lut[r], lut[g], lut[b]};
+        else *reinterpret_cast<B3*>(st_row + 3u * uq) = B3{(uint8_t)r, (uint8_t)g, (uint8_t)b};
+        if (OUT != PO_ASD && OUT != PO_U8NM) *reinterpret_cast<float*>(mk_row + 4u * uq) = (r | g | b) == 0u ? 1.0f : 0.0f;
+    };
 
     // =====================================================================================================
     // phase B: stage the lane's points: colour codes as floats, the libm-exact disparity -> x, reversed segments
@@ -298,7 +313,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         for (int k = 0; k < SLOTS; k++) {
             const int q = tid + k * NT + qoff;   // tile pixel of this source column
             if ((unsigned)q < (unsigned)wt) {
-                const float v = code_over_255((float)(code[k] & 0xff));
+                const float v = OUT == PO_F32 ? lut[code[k] & 0xff] : code_over_255((float)(code[k] & 0xff));
                 *reinterpret_cast<F3*>(dd_row + 12u * (uint32_t)q) = F3{v, v, v};
             }
         }
@@ -483,7 +498,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             k1 = k1 + (pc.y * om1 + pp.y * ip1) * sig1;
             k2 = k2 + (pc.z * om1 + pp.z * ip1) * sig1;
             // (0.5 <= k < 255.5: the lerp operands are codes 0..255, the piece lengths sum to less than 1)
-            if (fast) emit_f(q, truncf(k0), truncf(k1), truncf(k2));
+            if (fast) emit_k(q, k0, k1, k2);
         }
         // the first point of a pixel that is not done yet: several points / special typing -> pass 2 (chain path)
         if (g_first > 0.0f && !fast && !dirty && act) list_push(PK_CHAIN, o, q);
@@ -693,7 +708,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             const float k1 = 0.5f + (a.y * om + b.y * ip) * sig_whole;
             const float k2 = 0.5f + (a.z * om + b.z * ip) * sig_whole;
             // the segment is forward, starts left of the pixel and ends right of it (checked when it was listed)
-            if (lean) emit_f(q, truncf(k0), truncf(k1), truncf(k2));
+            if (lean) emit_k(q, k0, k1, k2);
         }
         const bool rest = act && !lean;
         if (__any(rest)) {
@@ -903,7 +918,7 @@ hipError_t launch_anaglyph_compose(const uint8_t* sbs, const uint8_t* rowflag, i
 static size_t polypoint_lds(int nt, int slots, int T, int KP, int KS) {
     const size_t npt = (size_t)slots * nt + 4;
     return 16 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((T + 3) & ~3) + 2 * PP_DCAP * (2 + (size_t)KP + KS) +
-           4 * PF_WORDS + 64;
+           4 * PF_WORDS + 1024 + 64;
 }
 
 // Tile width for a row of `w` pixels with halo S: the staged range (T + 2S + 2 points) plus the right sentinel must fit the
