@@ -79,6 +79,9 @@ struct PolyPointArgs {
     const uint32_t* tilemap;
     const float* gray;
     int tm_words;
+    // the per-eye constants packed in 64-bit words, so that the eye of a workgroup is picked by three 64-bit scalar selects
+    // instead of eight 32-bit ones: {div32, sep32}, {xoff, yoff}, {st_min, st_max | enabled << 16}
+    unsigned long long epk[2][3];
 };
 
 struct F3 { float x, y, z; };
@@ -112,7 +115,8 @@ enum { PK_CHAIN = 0u, PK_BRIDGE = 1u };
 template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW>
 __global__ void __launch_bounds__(NT, MINW)
 k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
-            int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, PolyPointArgs A) {
+            int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode,
+            PolyPointArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = hot_T;
@@ -132,13 +136,13 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     const int frame = hot_single >= 0 ? zi : (zi >> 1);
     EyeArgs E;
     E.depth = eyei ? hot_depth1 : hot_depth0;
-    E.div32 = eyei ? A.eye[1].div32 : A.eye[0].div32;
-    E.sep32 = eyei ? A.eye[1].sep32 : A.eye[0].sep32;
-    E.enabled = eyei ? A.eye[1].enabled : A.eye[0].enabled;
-    E.st_min = eyei ? A.eye[1].st_min : A.eye[0].st_min;
-    E.st_max = eyei ? A.eye[1].st_max : A.eye[0].st_max;
-    E.xoff = eyei ? A.eye[1].xoff : A.eye[0].xoff;
-    E.yoff = eyei ? A.eye[1].yoff : A.eye[0].yoff;
+    {
+        const unsigned long long ea = eyei ? A.epk[1][0] : A.epk[0][0], eb = eyei ? A.epk[1][1] : A.epk[0][1],
+                                 ec = eyei ? A.epk[1][2] : A.epk[0][2];
+        E.div32 = __builtin_bit_cast(float, (uint32_t)ea); E.sep32 = __builtin_bit_cast(float, (uint32_t)(ea >> 32));
+        E.xoff = (int)(uint32_t)eb; E.yoff = (int)(uint32_t)(eb >> 32);
+        E.st_min = (int)(uint32_t)ec; E.st_max = (int)((uint32_t)(ec >> 32) & 0xffffu); E.enabled = (int)((ec >> 48) & 1u);
+    }
     const bool eye_on = E.enabled;
     const int w = hot_w, h = hot_h;
     const int o0 = tile * T, wt = min(T, w - o0);
@@ -158,10 +162,11 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // in constant memory (512 bytes, L1-resident: no copy, nothing to wait for before barrier 0: +2 %); any other exponent
     // sends every point through the clone, and the tables are copied into LDS (overlaying plist until barrier 1: +6 % there)
     csm::PowfTables* const tabs_lds = (csm::PowfTables*)plist;
-    const bool all_powf = A.dbg == 17 || !(A.e32 == 2.0f || A.e32 == 1.0f);
+    const bool all_powf = hot_pow_mode == 0;   // (host: dbg == 17 or an exponent other than 1 and 2)
     static_assert(sizeof(csm::PowfTables) == 512, "tables overlay");
-    uint8_t* dflag = (uint8_t*)(plist + max(T, 128));                             // [T] PP_DIRTY | slot
-    uint16_t* dcnt = (uint16_t*)(dflag + ((T + 3) & ~3));                         // [DCAP] points (low 8) | segments (high 8)
+    // (the two offsets that depend on T come precomputed in preloaded kernel arguments: plist + max(T, 128) and + (T + 3 & ~3))
+    uint8_t* dflag = (uint8_t*)(smem + hot_off_dflag);                            // [T] PP_DIRTY | slot
+    uint16_t* dcnt = (uint16_t*)(smem + hot_off_dcnt);                            // [DCAP] points (low 8) | segments (high 8)
     uint16_t* dpix = dcnt + PP_DCAP;                                              // [DCAP] pixel of the slot
     uint16_t* pts = dpix + PP_DCAP;                                               // [DCAP][PT_KP]
     uint16_t* sgs = pts + PP_DCAP * PT_KP;                                        // [DCAP][PT_KS]
@@ -335,7 +340,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         // numerators that are 0 or >= 2^-60 and a range within 2^+-40 (depth maps are 0..255); otherwise: plain division.
         const bool range_ok = range > 0x1p-40f && range < 0x1p40f;
         const float yr = range_ok ? rcp_refined(range) : 0.0f;
-        const int pow_mode = all_powf ? 0 : (A.e32 == 2.0f ? 2 : 1);
+        const int pow_mode = hot_pow_mode;
         float sg[SLOTS], axs[SLOTS], pw[SLOTS], av[SLOTS];
         uint32_t amin = 0xffffffffu;
 #pragma unroll
@@ -415,24 +420,21 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     __syncthreads();  // barrier 1: points staged, in-wave reversed segments marked
     if (PP_DEV_IS(31)) return;
 
-    // ---- the segment pairs the staging loop could not see (lane 63 of every chunk, the left sentinel's pair): every wave
-    // computes the same answer; wave 0 marks, and only then a barrier is needed (rare)
+    // ---- the segment pairs the staging loop could not see: lane 63 of every 64-point chunk (its right neighbour was staged
+    // by another wave) and the left sentinel's pair.  Every wave checks the chunks IT staged -- lanes 0 .. SLOTS-1, one pair
+    // each; wave 0 also the sentinel's -- and marks what it finds; the barrier is unconditional (a first version let every
+    // wave check all pairs so that the barrier could be skipped when none is reversed: 75 instructions per wave for a dozen
+    // comparisons, and the kernel is bound by the number of instructions it issues).
     {
-        const int nb = (ns - 1) >> 6;  // pairs (j, j+1) with j = 64 b + 63
-        bool any = false;
-        for (int b0 = 0; b0 < nb + 1; b0 += 64) {
-            const int b = b0 + lane;
-            int o = -1;
-            if (b < nb) o = 1 + 64 * b + 63;
-            else if (b == nb && left_edge) o = 0;
-            const float xa = o >= 0 ? P[o].w : 0.0f, xb = o >= 0 ? P[o + 1].w : 1.0f;
-            const unsigned long long mrev = __ballot(o >= 0 && !(xa < xb));
-            if (mrev) {
-                any = true;
-                if (wave == 0) mark_reversed(mrev, xa, xb);
-            }
-        }
-        if (any) __syncthreads();
+        int o = -1;
+        if (lane < SLOTS) {
+            const int j = lane * NT + wave * 64 + 63;
+            if (j <= ns - 2) o = 1 + j;   // the pair (j, j + 1) of real points
+        } else if (lane == SLOTS && wave == 0 && left_edge) o = 0;
+        const float xa = o >= 0 ? P[o].w : 0.0f, xb = o >= 0 ? P[o + 1].w : 1.0f;
+        const unsigned long long mrev = __ballot(o >= 0 && !(xa < xb));
+        if (mrev) mark_reversed(mrev, xa, xb);
+        __syncthreads();
     }
     const int ndirty = min(flags[PF_NDIRTY], PP_DCAP);
     const bool fold_tile = flags[PF_NDIRTY] > 0;
@@ -945,6 +947,16 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
     dim3 grid(tiles * 8, (A.h + 7) / 8, A.single >= 0 ? A.n : 2 * A.n), block(NT);   // (see the kernel's prologue)
     size_t lds = polypoint_lds(NT, SLOTS, A.T, KP, KS);
     // (development: CS_DEBUG_PT_VARIANT 13..16 pads the LDS request so that only 3..6 workgroups fit a CU -- occupancy what-if)
+    const int npt = SLOTS * NT + 4;
+    const int off_dflag = 16 * npt + 4 * npt + 4 * (A.T > 128 ? A.T : 128), off_dcnt = off_dflag + ((A.T + 3) & ~3);
+    const int pow_mode = (A.dbg == 17 || !(A.e32 == 2.0f || A.e32 == 1.0f)) ? 0 : (A.e32 == 2.0f ? 2 : 1);
+    for (int e = 0; e < 2; e++) {
+        const EyeArgs& E = A.eye[e];
+        A.epk[e][0] = (unsigned long long)__builtin_bit_cast(uint32_t, E.div32) | ((unsigned long long)__builtin_bit_cast(uint32_t, E.sep32) << 32);
+        A.epk[e][1] = (unsigned long long)(uint32_t)E.xoff | ((unsigned long long)(uint32_t)E.yoff << 32);
+        A.epk[e][2] = (unsigned long long)(uint32_t)E.st_min | ((unsigned long long)((uint32_t)E.st_max & 0xffffu) << 32) |
+                      ((unsigned long long)(E.enabled ? 1u : 0u) << 48);
+    }
     const int occ = dev_switch(CS_DEBUG_PT_VARIANT) - 10;
     if (occ >= 3 && occ <= 6) { const size_t pad = (size_t)(163840 / (occ + 1) + 1024) & ~(size_t)255; if (pad > lds) lds = pad; }
 #define PP_LAUNCH(O)                                                                                                         \
@@ -953,7 +965,7 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
         if (e != hipSuccess) return e;                                                                                       \
         hipLaunchKernelGGL((k_polypoint<NT, SLOTS, O, KP, KS, MINW>), grid, block, lds, stream, A.image_f32, A.eye[0].depth, \
-                           A.eye[1].depth, A.w, A.h, A.S, A.T, A.single, A);                                                 \
+                           A.eye[1].depth, A.w, A.h, A.S, A.T, A.single, off_dflag, off_dcnt, pow_mode, A);                  \
     }
     if (out == PO_F32) PP_LAUNCH(PO_F32)
     else if (out == PO_U8) PP_LAUNCH(PO_U8)
