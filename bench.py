@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--config", default="metric", choices=sorted(CONFIGS))
     ap.add_argument("--frames", type=int, default=0, help="total frames in the batch (sharded over the GPUs); 0 = the config's")
     ap.add_argument("--no-blur", action="store_true")
+    ap.add_argument("--depth", default="", choices=["", "clipped", "random8", "blobs"],
+                    help="replace the config's synthetic depth: clipped = saturated to exact 0 / 1 over large areas (exact closeness "
+                         "ties: order-dependent rows, the stretch replay kernel), random8 = 8-bit noise (every row replayed whole)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--verify", action="store_true", help="N > 1: check the reassembled float32 batch against a local float32 run")
@@ -157,6 +160,13 @@ def main():
     b0, b1 = bounds[rank], bounds[rank + 1]
     nloc = b1 - b0
     image, depth = make_inputs(torch, cfg, nloc, b0, device)
+    if a.depth:   # (host-generated by tools/synth.py, eight distinct frames repeated)
+        import numpy as np
+        import synth
+        base = np.stack([synth.DEPTHS[a.depth](H, W, seed=b0 + i) for i in range(min(8, nloc))])
+        reps = (nloc + base.shape[0] - 1) // base.shape[0]
+        depth = torch.from_numpy(np.tile(base, (reps, 1, 1))[:nloc]).to(device)[..., None].expand(nloc, H, W, 3).contiguous()
+        cfg["what"] = cfg["what"].replace("stepped depth", f"{a.depth} depth").replace("radial depth with a moving centre", f"{a.depth} depth")
     out_h, out_w = engine.output_shape(params(1))[:2]
 
     # N > 1, CPU techniques: shards travel over xGMI as uint8 codes (the stereoscope is k/255 exactly: 4x fewer bytes), the

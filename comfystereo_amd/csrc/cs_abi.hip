@@ -344,8 +344,17 @@ static size_t rowflag_bytes(size_t rows) { return al256(rows) + 256 + al256(rows
 // anaglyph scratch of the tiled polylines path: both eyes as uint8 codes side by side
 static size_t poly_anaglyph_bytes(int n, int h, int w) { return al256((size_t)n * h * 2 * w * 3); }
 
-static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_t stream, uint8_t* ana_sbs = nullptr) {
+static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_t stream, uint8_t* ana_sbs = nullptr,
+                    void* replay_scratch = nullptr) {
     const bool poly = fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP;
+    // polylines, eyes in separate output slots: the stretches of order-dependent rows are replayed by a kernel of their own
+    // (cs_rowwarp.hip k_poly_replay) instead of inside the row kernel
+    const bool replay = poly && replay_scratch && rowflag && !A.anaglyph && !dev_switch(CS_DEBUG_NO_REPLAY_KERNEL) &&
+                        poly_replay_bytes(A.n, A.h, A.w, fill == CS_FILL_POLYLINES_SHARP) > 0;
+    if (replay) {
+        hipError_t e = poly_replay_attach(A, fill == CS_FILL_POLYLINES_SHARP, replay_scratch, stream);
+        if (e != hipSuccess) return fail_hip(e, "replay scratch");
+    }
     if (poly && (!A.anaglyph || (ana_sbs && A.image_f32 && !A.out_u8)) && halo <= polytile_max_halo() && rowflag &&
         !dev_switch(CS_DEBUG_NO_TILE)) {
         // workspace: [n*h flag bytes][count, padded to 256][n*h list entries]
@@ -416,6 +425,21 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
     }
     hipError_t e = launch_rowwarp(fill, A, threads_for(fill, A.w), stream);
     if (e != hipSuccess) return fail_hip(e, "row kernel launch");
+    if (replay) {
+        e = launch_poly_replay(fill == CS_FILL_POLYLINES_SHARP, A, stream);
+        if (e != hipSuccess) return fail_hip(e, "stretch replay launch");
+        // rows with a stretch the replay kernel gave up on (usually none): once more through the row kernel, export off
+        const size_t rows = (size_t)A.n * A.h;
+        uint32_t* count2 = (uint32_t*)(rowflag + al256(rows)) + 8;   // (a second {count, cursor} pair in the padded counter block)
+        uint32_t* list = (uint32_t*)(rowflag + al256(rows)) + 64;
+        e = hipMemsetAsync(count2, 0, 8, stream);
+        if (e == hipSuccess) e = launch_collect_rows(poly_replay_retry_flags(A), (int)rows, count2, list, stream);
+        if (e != hipSuccess) return fail_hip(e, "replay retry collection");
+        RowArgs R = A;
+        R.rp_dump = nullptr; R.row_list = list; R.row_count = count2;
+        e = launch_rowwarp(fill, R, threads_for(fill, A.w), stream);
+        if (e != hipSuccess) return fail_hip(e, "row kernel launch (replay retry)");
+    }
     return CS_OK;
 }
 
@@ -503,6 +527,8 @@ static WsLayout ws_layout(const cs_params* p) {
     if ((p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP) &&
         (p->mode == CS_MODE_RED_CYAN_ANAGLYPH || p->mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH))
         o += poly_anaglyph_bytes(p->n, p->h, p->w);
+    else if (p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP)   // scratch of the stretch replay kernel
+        o += al256(poly_replay_bytes(p->n, p->h, p->w, p->fill == CS_FILL_POLYLINES_SHARP));
     W.total = o;
     return W;
 }
@@ -669,7 +695,8 @@ static int generate_chunk(const cs_params* p, const float* image, const float* d
         rc = launch_hybrid(A, ws + W.extra, stream, p->fill == CS_FILL_HYBRID_EDGE_PLUS, halo);
         if (rc) return fail(rc, "hybrid_edge launch failed");
     } else {
-        rc = run_rows(p->fill, A, halo, (uint8_t*)(ws + W.rowflag), stream, A.anaglyph ? (uint8_t*)(ws + W.extra) : nullptr);
+        rc = run_rows(p->fill, A, halo, (uint8_t*)(ws + W.rowflag), stream, A.anaglyph ? (uint8_t*)(ws + W.extra) : nullptr,
+                      A.anaglyph ? nullptr : (void*)(ws + W.extra));
         if (rc) return rc;
     }
     hipError_t e = hipGetLastError();
@@ -736,7 +763,8 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
 }
 
 size_t cs_asd_workspace_bytes(int n, int h, int w) {
-    return al256((size_t)n * ST_WORDS * 4) + rowflag_bytes((size_t)n * h) + al256(hybrid_workspace_bytes(n, h, w));
+    return al256((size_t)n * ST_WORDS * 4) + rowflag_bytes((size_t)n * h) + al256(hybrid_workspace_bytes(n, h, w)) +
+           al256(poly_replay_bytes(n, h, w, 1));
 }
 
 int cs_apply_stereo_divergence(const uint8_t* image_u8, const float* depth, int n, int h, int w, double divergence,
@@ -783,7 +811,9 @@ int cs_apply_stereo_divergence2(const uint8_t* image_u8, const float* depth, int
         if (rc) return fail(rc, "hybrid_edge launch failed");
     } else {
         int halo = poly_halo(divergence, divergence, separation, exponent, convergence, w);
-        int rc = run_rows(fill, A, halo, (uint8_t*)workspace + al256((size_t)n * ST_WORDS * 4), stream);
+        int rc = run_rows(fill, A, halo, (uint8_t*)workspace + al256((size_t)n * ST_WORDS * 4), stream, nullptr,
+                          (char*)workspace + al256((size_t)n * ST_WORDS * 4) + rowflag_bytes((size_t)n * h) +
+                              al256(hybrid_workspace_bytes(n, h, w)));
         if (rc) return rc;
     }
     hipError_t e = hipGetLastError();

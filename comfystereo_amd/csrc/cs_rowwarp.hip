@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 namespace cs {
+static inline size_t al256r(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // ---------------------------------------------------------------------------------------------
 // LDS carving
@@ -620,7 +621,7 @@ __device__ int poly_sequential_wave(const Poly& P, const Lds& L, int csg_cap_ref
 // holes in front of survivors (their lane numbers are handed over, then cross-lane moves) and for the winner's colours.
 template <class Emit>
 __device__ int poly_replay_stretch(const Poly& P, const Lds& L, int csg_cap_ref, const Emit& emit, int c0, int c1, int seg0,
-                                   int sgp0, uint16_t* srcpos) {
+                                   int sgp0, uint16_t* srcpos, int pts_left_of_c0) {
     const int lane = threadIdx.x & 63;
     const int sg_end = P.npt - 1;
     const int cap = min(min(csg_cap_ref, P.cap), 64);
@@ -645,7 +646,7 @@ __device__ int poly_replay_stretch(const Poly& P, const Lds& L, int csg_cap_ref,
     auto need = [&](int lo, int hi) {
         if (lo < wbase || hi >= wbase + 64) { window(lo); lost = lost || hi >= wbase + 64; }
     };
-    int pt_i = (int)P.binoff[c0] - 1;   // binoff[c] = number of points left of pixel c; the sweep's own loop settles it
+    int pt_i = pts_left_of_c0 - 1;   // (binoff[c0]: the number of points left of pixel c0; the sweep's own loop settles it)
     window(min(pt_i, sg_pointer));
     for (int col = c0; col <= c1; col++) {
         float color[3] = {0.5f, 0.5f, 0.5f};
@@ -747,9 +748,19 @@ __device__ __forceinline__ void poly_seg_pixels(const Poly& P, int o, int& p0, i
     p1 = f1 > (float)(P.w - 1) ? P.w - 1 : (int)f1;
 }
 
+// windows of the stretch replay kernel (k_poly_replay): sorted points / source columns one stretch may touch
+#define RP_PW 1024
+#define RP_CW 1024
+#define RP_DESC 8   // words per stretch descriptor
+struct RpCtx {      // where a row exports its stretches to (dump == null: replay inside the row kernel)
+    uint8_t* dump; uint32_t* list; uint32_t* ctr; uint32_t slots, cap, slot_bytes; uint32_t rowid; int eye;
+};
+__host__ __device__ inline size_t rp_perm_bytes(int w, int sharp) { return align16(2 * (size_t)poly_npt(w, sharp)); }
+__host__ __device__ inline size_t rp_slot_bytes(int w, int sharp) { return rp_perm_bytes(w, sharp) + align16(4 * (size_t)w); }
+
 template <int SHARP, class Emit>
 __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float e32, uint32_t* stats_rw,
-                                    const Emit& emit, int dbg) {
+                                    const Emit& emit, int dbg, const RpCtx* X = nullptr) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
     Poly P;
     P.w = w; P.sharp = SHARP; P.npt = poly_npt(w, SHARP); P.cap = poly_cap(w, SHARP);
@@ -939,6 +950,77 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         }
         __syncthreads();
         const int nstr = *nstretch;
+        // ---- export: the stretches of this row go to the replay kernel (k_poly_replay: one wave per stretch, thousands in
+        // flight) instead of being replayed here by 1-3 of this workgroup's 16 waves while the row's LDS stays allocated
+        constexpr int RP_NSTR = 64;   // stretches per row the export handles (usually 1-3)
+        if (nstr > 0 && nstr <= RP_NSTR && X && X->dump && dbg != 28 &&
+            tail0 + 2 * NSTR + 128 * nwaves + 2 * RP_DESC * RP_NSTR + 8 <= P.cap) {
+            int* rp_ok = L.misc + 5;
+            int* rp_slot = L.misc + 6;
+            int* rp_base = L.misc + 7;
+            uint32_t* sinfo = (uint32_t*)(wscr + 128 * nwaves);   // [RP_NSTR][RP_DESC]: the descriptor of a stretch, words 1..7
+            if (tid == 0) *rp_ok = 1;
+            __syncthreads();
+            for (int si = wave; si < nstr; si += nwaves) {
+                const int c0 = (int)(slist[si] & 0xffffu), c1 = (int)(slist[si] >> 16);
+                int seg0 = -1, sgp0 = 0;
+                if (c0 > 0) {   // the state after pixel c0 - 1: its single active segment, the points left of its last centre
+                    const int r = c0 - 1;
+                    const int pos1 = P.binoff[r + 1];
+                    const SubInt sb = poly_subinterval(r, poly_x(P, P.perm[pos1 - 1]), poly_x(P, P.perm[pos1]));
+                    const int ls = r > 0 ? P.segoff[r - 1] : 0, le = P.segoff[r];
+                    for (int e = ls; e < le; e++) {
+                        const int o = P.entries[e];
+                        if (poly_x(P, o) < sb.center && !(poly_x(P, o + 1) < sb.center)) seg0 = o;
+                    }
+                    sgp0 = pos1;
+                    while (sgp0 > 0 && !(poly_x(P, P.perm[sgp0 - 1]) < sb.center)) sgp0--;
+                }
+                // sorted points the replay can look at: from three below its two cursors to a 64-entry window past the last
+                // point left of pixel c1 + 1; source columns: those points', their right neighbours', the start segment's
+                const int pw0 = max(min((int)P.binoff[c0] - 1, sgp0) - 3, 0), pw1 = min((int)P.binoff[c1 + 1] + 66, npt - 1);
+                int cmin = 0x7fffffff, cmax = -1;
+                for (int i = pw0 + lane; i <= pw1; i += 64) {
+                    const int o = P.perm[i];
+                    cmin = min(cmin, poly_col(P, o)); cmax = max(cmax, poly_col(P, min(o + 1, npt - 1)));
+                }
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { cmin = min(cmin, __shfl_xor(cmin, d)); cmax = max(cmax, __shfl_xor(cmax, d)); }
+                if (seg0 >= 0) { cmin = min(cmin, poly_col(P, seg0)); cmax = max(cmax, poly_col(P, seg0 + 1)); }
+                if (lane == 0) {
+                    const bool good = (c0 == 0 || seg0 >= 0) && pw1 - pw0 + 1 <= RP_PW && cmax - cmin + 1 <= RP_CW;
+                    if (!good) *rp_ok = 0;
+                    uint32_t* q = sinfo + RP_DESC * si;
+                    q[1] = slist[si]; q[2] = (uint32_t)seg0; q[3] = (uint32_t)sgp0; q[4] = (uint32_t)pw0 | ((uint32_t)pw1 << 16);
+                    q[5] = (uint32_t)cmin | ((uint32_t)cmax << 16); q[6] = X->rowid | ((uint32_t)X->eye << 31); q[7] = (uint32_t)P.binoff[c0];
+                }
+            }
+            __syncthreads();
+            if (*rp_ok && tid == 0) {
+                const uint32_t slot = atomicAdd(&X->ctr[0], 1u);
+                const uint32_t base = atomicAdd(&X->ctr[1], (uint32_t)nstr);
+                *rp_slot = (int)slot; *rp_base = (int)base;
+                if (slot >= X->slots || base + (uint32_t)nstr > X->cap) {
+                    *rp_ok = 0;   // no room: replay here; the reserved descriptors (those inside the list) say "skip"
+                    for (uint32_t i = base; i < base + (uint32_t)nstr && i < X->cap; i++) X->list[(size_t)i * RP_DESC] = 0xffffffffu;
+                }
+            }
+            __syncthreads();
+            if (*rp_ok) {
+                const uint32_t slot = (uint32_t)*rp_slot, base = (uint32_t)*rp_base;
+                uint8_t* d = X->dump + (size_t)slot * X->slot_bytes;
+                uint16_t* dperm = (uint16_t*)d;
+                float* dcd = (float*)(d + rp_perm_bytes(w, SHARP));
+                for (int i = tid; i < npt; i += nt) dperm[i] = P.perm[i];
+                for (int c = tid; c < w; c += nt) dcd[c] = P.cd[c];
+                for (int i = tid; i < nstr * RP_DESC; i += nt) {
+                    const int si = i / RP_DESC, k = i - si * RP_DESC;
+                    X->list[(size_t)(base + (uint32_t)si) * RP_DESC + k] = k == 0 ? slot : sinfo[i];
+                }
+                if (stats_rw && tid == 0) atomicAdd(&stats_rw[ST_FALLBACK_ROWS], 1u);
+                return;
+            }
+        }
         if (nstr > 0) {
             bool bad = false;
             for (int si = wave; si < nstr && !bad; si += nwaves) {
@@ -957,7 +1039,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                     while (sgp0 > 0 && !(poly_x(P, P.perm[sgp0 - 1]) < s.center)) sgp0--;
                     if (seg0 < 0) bad = true;   // (cannot happen: the pixel was marked because exactly one segment is active there)
                 }
-                if (!bad && poly_replay_stretch(P, L, E.csg_cap, emit, c0, c1, seg0, sgp0, wscr + 128 * wave)) bad = true;
+                if (!bad && poly_replay_stretch(P, L, E.csg_cap, emit, c0, c1, seg0, sgp0, wscr + 128 * wave, (int)P.binoff[c0])) bad = true;
             }
             if (bad && lane == 0) *stretch_bad = 1;
         }
@@ -1730,8 +1812,12 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
                                       (int*)(L.tech + align16(8 * (size_t)w) + align16(4 * (size_t)w)),
                                       [=](int c) { return key[c] > init; });
             } else if (FILL == CS_FILL_INVERSE) technique_inverse(L, w, E, A.e32, A.d64, A.e64);
-            else if (FILL == CS_FILL_POLYLINES_SOFT) technique_polylines<0>(L, w, E, A.e32, st_rw, out, A.dbg);
-            else if (FILL == CS_FILL_POLYLINES_SHARP) technique_polylines<1>(L, w, E, A.e32, st_rw, out, A.dbg);
+            else if (FILL == CS_FILL_POLYLINES_SOFT || FILL == CS_FILL_POLYLINES_SHARP) {
+                // (eyes in separate output slots: the stretches of order-dependent rows may go to the replay kernel)
+                const RpCtx X{A.anaglyph ? nullptr : A.rp_dump, A.rp_list, A.rp_ctr, A.rp_slots, A.rp_cap, A.rp_slot_bytes,
+                              (uint32_t)frame * (uint32_t)A.h + (uint32_t)row, e};
+                technique_polylines<FILL == CS_FILL_POLYLINES_SHARP ? 1 : 0>(L, w, E, A.e32, st_rw, out, A.dbg, &X);
+            }
             else if (FILL == CS_FILL_HYBRID_EDGE_PLUS) {
                 // hybrid_edge into `res`, then the polylines_soft row into `alt`; pixels that stayed black take the latter
                 technique_hybrid_fill(L, A, frame, row, e);
@@ -1832,6 +1918,110 @@ __global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
         rowwarp_row<FILL>(A, row, frame, smem);
         __syncthreads();  // the row's LDS (and s_next) is reused by the next one
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stretch replay as a kernel of its own (round 3).  The row kernel holds a whole row in LDS (80 KB at 4K: two rows per CU)
+// and an order-dependent row keeps 1-3 of its 16 waves busy for a millisecond: ~2 000 replaying waves on the chip, every
+// row's workgroup alive until its longest stretch ends.  A stretch only looks at the sorted points around its pixels and
+// at the source columns those points come from -- a few hundred of each -- so the row kernel dumps the row's sorted order
+// and coord_d (RowArgs::rp_dump), appends a descriptor per stretch, and this kernel gives every stretch a WAVE with 7 KB of
+// LDS windows: 22 waves per CU, 5 600 stretches in flight, pulled from the list through one atomic cursor.
+// A stretch the wave form gives up on (list longer than 64, window drift) flags its row in `retry`; run_rows sends those
+// rows through the row kernel once more with the export switched off (their whole-row replay).
+// ---------------------------------------------------------------------------------------------
+struct ReplayOut {   // RowOut's destination arithmetic without the anaglyph stash (eyes in separate slots only)
+    uint8_t* out_u8; float* stereo; float* mask;
+    int h, out_h, out_w, xoff, yoff, stereo_is_u8, frame, row, w;
+    __device__ __forceinline__ void operator()(int c, uint8_t r, uint8_t g, uint8_t b) const {
+        if (out_u8) {
+            uint8_t* d = out_u8 + (((size_t)frame * h + row) * w + c) * 3;
+            d[0] = r; d[1] = g; d[2] = b;
+            return;
+        }
+        const size_t o = ((size_t)frame * out_h + row + yoff) * out_w + xoff + c;
+        if (stereo_is_u8) {
+            uint8_t* d8 = reinterpret_cast<uint8_t*>(stereo) + o * 3;
+            d8[0] = r; d8[1] = g; d8[2] = b;
+        } else {
+            float* d = stereo + o * 3;
+            d[0] = csm::code_over_255((float)r); d[1] = csm::code_over_255((float)g); d[2] = csm::code_over_255((float)b);
+        }
+        mask[o] = ((int)r + (int)g + (int)b) == 0 ? 1.0f : 0.0f;  // GenerateStereo.py:355-361
+    }
+};
+
+template <int SHARP>
+__global__ void __launch_bounds__(64) k_poly_replay(RowArgs A, uint8_t* __restrict__ retry) {
+    __shared__ uint16_t permw[RP_PW];
+    __shared__ float cdw[RP_CW];
+    __shared__ uint8_t imgw[3 * RP_CW];
+    __shared__ uint16_t srcpos[128];
+    const int lane = threadIdx.x;
+    const uint32_t count = min(A.rp_ctr[1], A.rp_cap);
+    const int w = A.w, h = A.h;
+    for (;;) {
+        uint32_t idx = 0;
+        if (lane == 0) idx = atomicAdd(&A.rp_ctr[2], 1u);
+        idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+        if (idx >= count) break;
+        const uint32_t* q = A.rp_list + (size_t)idx * RP_DESC;
+        const uint32_t slot = q[0];
+        if (slot == 0xffffffffu) continue;
+        const int c0 = (int)(q[1] & 0xffffu), c1 = (int)(q[1] >> 16), seg0 = (int)q[2], sgp0 = (int)q[3];
+        const int pw0 = (int)(q[4] & 0xffffu), pw1 = (int)(q[4] >> 16), cmin = (int)(q[5] & 0xffffu), cmax = (int)(q[5] >> 16);
+        const uint32_t rowid = q[6] & 0x7fffffffu;
+        const int eye = (int)(q[6] >> 31), pt0 = (int)q[7];
+        const int frame = (int)(rowid / (uint32_t)h), row = (int)(rowid - (uint32_t)frame * (uint32_t)h);
+        const uint8_t* d = A.rp_dump + (size_t)slot * A.rp_slot_bytes;
+        const uint16_t* dperm = (const uint16_t*)d;
+        const float* dcd = (const float*)(d + rp_perm_bytes(w, SHARP));
+        for (int i = lane; i <= pw1 - pw0; i += 64) permw[i] = dperm[pw0 + i];
+        for (int c = lane; c <= cmax - cmin; c += 64) {
+            cdw[c] = dcd[cmin + c];
+            imgw[3 * c] = src_u8(A, frame, row, cmin + c, 0);
+            imgw[3 * c + 1] = src_u8(A, frame, row, cmin + c, 1);
+            imgw[3 * c + 2] = src_u8(A, frame, row, cmin + c, 2);
+        }
+        wave_lds_sync();
+        // the windows, addressed like the whole arrays (every index the replay touches lies inside: cs_rowwarp.hip export)
+        Poly P;
+        P.w = w; P.sharp = SHARP; P.npt = poly_npt(w, SHARP); P.cap = poly_cap(w, SHARP);
+        P.sep32 = eye ? A.eye[1].sep32 : A.eye[0].sep32;
+        P.perm = permw - pw0; P.binoff = nullptr; P.segoff = nullptr; P.entries = nullptr; P.longs = nullptr;
+        P.cd = cdw - cmin;
+        Lds L;
+        L.lut = nullptr; L.tabs = nullptr; L.misc = nullptr; L.res = nullptr; L.ana = nullptr; L.nd = nullptr; L.tech = nullptr;
+        L.img = imgw - 3 * cmin;
+        const ReplayOut out{A.out_u8, A.stereo, A.mask, h, A.out_h, A.out_w, eye ? A.eye[1].xoff : A.eye[0].xoff,
+                            eye ? A.eye[1].yoff : A.eye[0].yoff, A.stereo_is_u8, frame, row, w};
+        const int rc = poly_replay_stretch(P, L, eye ? A.eye[1].csg_cap : A.eye[0].csg_cap, out, c0, c1, seg0, sgp0, srcpos, pt0);
+        if (rc && lane == 0) retry[rowid] = 1;
+        wave_lds_sync();
+    }
+}
+
+size_t poly_replay_bytes(int n, int h, int w, int sharp) {
+    if (w > 8192) return 0;
+    const size_t rows = (size_t)n * h;   // slots for half of the eye rows, four stretches per slot on average
+    return 256 + al256r(rows) + al256r(rows * 4 * RP_DESC * 4) + rows * rp_slot_bytes(w, sharp) + 256;
+}
+// scratch: [counters 256 B][retry flags, one byte per row][descriptor list][dump slots]
+hipError_t poly_replay_attach(RowArgs& A, int sharp, void* scratch, hipStream_t stream) {
+    const size_t rows = (size_t)A.n * A.h;
+    char* b = (char*)scratch;
+    A.rp_ctr = (uint32_t*)b;
+    A.rp_list = (uint32_t*)(b + 256 + al256r(rows));
+    A.rp_dump = (uint8_t*)(b + 256 + al256r(rows) + al256r(rows * 4 * RP_DESC * 4));
+    A.rp_slots = (uint32_t)rows; A.rp_cap = (uint32_t)(rows * 4); A.rp_slot_bytes = (uint32_t)rp_slot_bytes(A.w, sharp);
+    return hipMemsetAsync(b, 0, 256 + al256r(rows), stream);   // counters and retry flags
+}
+uint8_t* poly_replay_retry_flags(const RowArgs& A) { return (uint8_t*)A.rp_ctr + 256; }
+hipError_t launch_poly_replay(int sharp, const RowArgs& A, hipStream_t stream) {
+    const dim3 grid(256 * 22), block(64);
+    if (sharp) hipLaunchKernelGGL(k_poly_replay<1>, grid, block, 0, stream, A, poly_replay_retry_flags(A));
+    else hipLaunchKernelGGL(k_poly_replay<0>, grid, block, 0, stream, A, poly_replay_retry_flags(A));
+    return hipGetLastError();
 }
 
 // rows flagged by the tiled path -> compact list

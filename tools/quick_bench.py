@@ -15,7 +15,7 @@ from comfystereo_amd import engine, _native
 # development switches from the environment (tools only: the library itself never reads the environment)
 for _env, _key in (("CS_DBG", "dbg"), ("CS_NO_TILE", "no_tile"), ("CS_PT_VARIANT", "pt_variant"),
                    ("CS_BLUR_TWO_PASS", "blur_two_pass"), ("CS_BLUR_EDGES_SCALAR", "blur_edges_scalar"),
-                   ("CS_BLUR_FULL_COPY", "blur_full_copy"), ("CS_CHUNKS", "chunks")):
+                   ("CS_BLUR_FULL_COPY", "blur_full_copy"), ("CS_CHUNKS", "chunks"), ("CS_NO_REPLAY_KERNEL", "no_replay_kernel")):
     if os.environ.get(_env):
         _native.debug_set(_key, int(os.environ[_env]))
 
