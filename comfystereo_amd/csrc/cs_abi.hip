@@ -437,7 +437,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         if (e != hipSuccess) return fail_hip(e, "replay retry collection");
         RowArgs R = A;
         R.rp_dump = nullptr; R.row_list = list; R.row_count = count2;
-        e = launch_rowwarp(fill, R, threads_for(fill, A.w), stream);
+        e = launch_rowwarp(fill, R, threads_for(fill, A.w), stream, 32);
         if (e != hipSuccess) return fail_hip(e, "row kernel launch (replay retry)");
     }
     return CS_OK;

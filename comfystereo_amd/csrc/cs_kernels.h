@@ -77,7 +77,7 @@ int dev_switch(int key);
 
 // cs_rowwarp.hip
 hipError_t launch_collect_rows(const uint8_t* flag, int total, uint32_t* count, uint32_t* list, hipStream_t stream);
-hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream);
+hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream, int max_groups = 0);
 size_t rowwarp_lds_bytes(int fill, int w, int anaglyph = 1);   // anaglyph modes stash two channels of the first eye (2 B per pixel)
 // scratch of the stretch replay kernel for a call of n frames (0: the frame is too wide for its windows); poly_replay_attach
 // carves it into A.rp_* and zeroes the counters; launch_poly_replay runs the descriptors the row pass appended

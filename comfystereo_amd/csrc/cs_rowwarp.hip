@@ -647,7 +647,8 @@ __device__ int poly_replay_stretch(const Poly& P, const Lds& L, int csg_cap_ref,
         if (lo < wbase || hi >= wbase + 64) { window(lo); lost = lost || hi >= wbase + 64; }
     };
     int pt_i = pts_left_of_c0 - 1;   // (binoff[c0]: the number of points left of pixel c0; the sweep's own loop settles it)
-    window(min(pt_i, sg_pointer));
+    bool first_step = true;
+    window(seg0 < 0 ? pt_i : min(pt_i, sg_pointer));
     for (int col = c0; col <= c1; col++) {
         float color[3] = {0.5f, 0.5f, 0.5f};
         need(pt_i, pt_i + 1);
@@ -656,8 +657,60 @@ __device__ int poly_replay_stretch(const Poly& P, const Lds& L, int csg_cap_ref,
         need(pt_i, pt_i + 1);
         while (rl_f(wx, pt_i - wbase) < (float)(col + 1)) {
             const SubInt s = poly_subinterval(col, rl_f(wx, pt_i - wbase), rl_f(wx, pt_i + 1 - wbase));
+            if (first_step && seg0 < 0) {
+                // ---- the very first step of a row (stretch from column 0, empty list, nothing added yet): the reference
+                // appends EVERY segment that starts left of the centre -- all the points an eye shifts out of the frame, more
+                // than the 64-entry list and window hold at 4K -- and removes the ended ones in the same step.  Both at once,
+                // in closed form: of the K segments added (sorted positions 0 .. K-1) the ns survivors end up as
+                // [alive positions < ns in place; the k-th dead position < ns takes the k-th survivor from the end].
+                int K = 0, ns_total = 0;
+                unsigned long long alive0 = 0ull;
+                int alive_before = 0;   // alive entries in the chunks before this lane's chunk ... per chunk below
+                // pass 1: K and the number of survivors
+                for (int base = 0; base < sg_end; base += 64) {
+                    const int k = base + lane;
+                    const int o = P.perm[min(k, sg_end - 1)];
+                    const bool in = k < sg_end && poly_x(P, o) < s.center;
+                    const unsigned long long mi = __ballot(in);
+                    const unsigned long long ma = __ballot(in && !(poly_x(P, o + 1) < s.center));
+                    if (base == 0) alive0 = ma;
+                    K += __popcll(mi); ns_total += __popcll(ma);
+                    if (mi != ~0ull) break;   // (sorted: the first point right of the centre ends the run)
+                }
+                if (ns_total > cap) return -1;
+                // pass 2: every survivor finds its slot
+                int my_o = -1;
+                for (int base = 0; base < K; base += 64) {
+                    const int k = base + lane;
+                    const int o = P.perm[min(k, sg_end - 1)];
+                    const bool al = k < K && !(poly_x(P, o + 1) < s.center);
+                    const unsigned long long ma = __ballot(al);
+                    if (al) {
+                        if (k < ns_total) my_o = o;   // (k < ns_total <= 64: chunk 0, lane k: stays in place)
+                        else {                         // a survivor behind the new end: the r-th from the end fills the r-th hole
+                            const int after_in_chunk = __popcll(lane == 63 ? 0ull : (ma >> (lane + 1)));
+                            const int r = ns_total - alive_before - __popcll(ma) + after_in_chunk;   // survivors behind this one
+                            srcpos[r] = (uint16_t)o;
+                        }
+                    }
+                    alive_before += __popcll(ma);
+                }
+                wave_lds_sync();
+                {
+                    const unsigned long long pref = ns_total >= 64 ? ~0ull : ((1ull << ns_total) - 1ull);
+                    const unsigned long long holes = ~alive0 & pref;
+                    if ((holes >> lane) & 1ull) my_o = (int)srcpos[__popcll(holes & ((1ull << lane) - 1ull))];
+                }
+                wave_lds_sync();
+                if (lane < ns_total) {
+                    e_o = my_o; e_x0 = poly_x(P, my_o); e_x1 = poly_x(P, my_o + 1); e_z0 = poly_z(P, my_o); e_z1 = poly_z(P, my_o + 1);
+                }
+                csg_end = ns_total; sg_pointer = K;
+                window(min(pt_i, sg_pointer));
+            }
+            first_step = false;
             need(min(pt_i, sg_pointer), max(pt_i + 1, sg_pointer));
-            if (lost) return -1;
+            if (lost) return -2;
             while (sg_pointer < sg_end && rl_f(wx, sg_pointer - wbase) < s.center) {
                 if (csg_end >= cap) return -1;
                 const int o = __builtin_amdgcn_readlane(wo, sg_pointer - wbase);
@@ -665,7 +718,7 @@ __device__ int poly_replay_stretch(const Poly& P, const Lds& L, int csg_cap_ref,
                 if (lane == csg_end) { e_o = o; e_x0 = nx0; e_x1 = nx1; e_z0 = nz0; e_z1 = nz1; }
                 csg_end++; sg_pointer++;
                 need(min(pt_i, sg_pointer), max(pt_i + 1, sg_pointer));
-                if (lost) return -1;
+                if (lost) return -2;
             }
             // ---- removal: the closed form of the swap-remove scan (poly_sequential_wave) on ballots
             const int n = csg_end;
@@ -1997,6 +2050,8 @@ __global__ void __launch_bounds__(64) k_poly_replay(RowArgs A, uint8_t* __restri
                             eye ? A.eye[1].yoff : A.eye[0].yoff, A.stereo_is_u8, frame, row, w};
         const int rc = poly_replay_stretch(P, L, eye ? A.eye[1].csg_cap : A.eye[0].csg_cap, out, c0, c1, seg0, sgp0, srcpos, pt0);
         if (rc && lane == 0) retry[rowid] = 1;
+        if (A.dbg == 14 && A.stats_rw && lane == 0)   // diagnostics: stretches replayed / given up (list > 64) / given up (window drift)
+            atomicAdd(&A.stats_rw[(size_t)frame * ST_WORDS + (rc == 0 ? 12 : (rc == -1 ? 13 : 15))], 1u);
         wave_lds_sync();
     }
 }
@@ -2036,7 +2091,7 @@ hipError_t launch_collect_rows(const uint8_t* flag, int total, uint32_t* count, 
 }
 
 // host-side launcher (called from cs_abi.hip)
-hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream) {
+hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream, int max_groups) {
     size_t lds = lds_common_bytes(fill, A.w, A.anaglyph) + lds_tech_bytes(fill, A.w);
     const long long rows = (long long)A.h * A.n;
     dim3 grid(A.h, A.n), block(threads);
@@ -2047,7 +2102,9 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
         if (lds > 0 && (long long)(CS_LDS_BYTES / lds) < per_cu) per_cu = (long long)(CS_LDS_BYTES / lds);
         if (per_cu < 1) per_cu = 1;
         const long long resident = 256 * per_cu;
-        grid = dim3((unsigned)(rows < resident ? rows : resident), 1);
+        long long groups = rows < resident ? rows : resident;
+        if (max_groups > 0 && groups > max_groups) groups = max_groups;   // (a pass that is almost always empty: fewer idle launches)
+        grid = dim3((unsigned)groups, 1);
     }
 #define CS_LAUNCH(F)                                                                                              \
     case F: {                                                                                                     \

@@ -363,3 +363,25 @@ def test_cfg2_1080p_polylines_soft_frame_vs_oracle(engine):
                                 depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
     for g, w_, name in zip(got, want, NAMES):
         assert np.array_equal(g, w_), name
+
+
+def test_4k_saturated_depth_stretch_replay_kernel_vs_oracle(engine, dev_switch):
+    """Round 3: the stretches of order-dependent rows are replayed by a kernel of their own (k_poly_replay: one wave per stretch
+    over the row's dumped sorted points) -- same bits as the replay inside the row kernel (cs_debug_set no_replay_kernel) and as
+    the oracle (reference :1961-1980).  At 4K and divergence 8 an eye shifts up to 77 points out of the frame: a stretch that
+    starts at column 0 begins with the reference's bulk add + remove of all of them (more than the 64-entry list), the closed
+    form in poly_replay_stretch."""
+    h, w = 240, 3840   # (a band of a 4K frame: the oracle replays every row)
+    img = synth.image_f32(2, h, w, seed=31)
+    depth = np.stack([synth.clipped(2160, w, seed=s)[900:900 + h] for s in (0, 3)])[..., None].repeat(3, -1)
+    args = (8.0, 0.0, "left-right", 0.0, 0.5, 2.0)
+    want = node_oracle.generate(img, depth, *args, "Fill - Polylines Soft", 20.0, 20.0, False, batch_size=12)
+    p = engine.make_params(2, h, w, h, w, 3, "polylines_soft", "left-right", 8.0, 0.0, 0.0, 0.5, 2.0, False, 20.0, 20.0, 1.0, 0, 12)
+    plan = engine.Plan(p, torch.device("cuda"))
+    got = [t.cpu().numpy() for t in plan.run(cuda(img), cuda(depth))]
+    assert int(plan.stats()[:, 10].sum()) > 0 and int(plan.stats()[:, 9].sum()) == 0
+    dev_switch("no_replay_kernel", 1)
+    inrow = [t.cpu().numpy() for t in engine.Plan(p, torch.device("cuda")).run(cuda(img), cuda(depth))]
+    for g, r, w_, name in zip(got, inrow, want, NAMES):
+        assert np.array_equal(g, r), ("replay kernel vs row kernel", name)
+        assert np.array_equal(g, w_), ("vs oracle", name)
