@@ -17,8 +17,9 @@ def mean(path, kernel, counter):
     raise SystemExit(f"{counter} of {kernel} not found in {path}")
 
 
-fetch_kib = mean(f"{run}/pmc_fetch.txt", kernel, "FETCH_SIZE")
-write_kib = mean(f"{run}/pmc_write.txt", kernel, "WRITE_SIZE")
+# several kernels of one bracket: "k_a+k_b+k_c" (their dispatches are summed)
+fetch_kib = sum(mean(f"{run}/pmc_fetch.txt", k, "FETCH_SIZE") for k in kernel.split("+"))
+write_kib = sum(mean(f"{run}/pmc_write.txt", k, "WRITE_SIZE") for k in kernel.split("+"))
 out = "profiles/pmc_traffic.json"
 try:
     d = json.load(open(out))
