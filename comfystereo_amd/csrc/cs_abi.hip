@@ -338,7 +338,11 @@ static bool dialect_d64_ok(int fill) {
     return fill == CS_FILL_NONE || fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING || fill == CS_FILL_INVERSE;
 }
 // flags of the rows the tiled polylines path hands to the row kernel + their compacted list (run_rows)
-static size_t rowflag_bytes(size_t rows) { return al256(rows) + 256 + al256(rows * 4); }
+// flagged-row block: [row flags, one byte per row][count / cursor pairs, 256 B][stretch-replay counters, 256 B][replay retry
+// flags, one byte per row] -- everything one memset clears -- then [row list, 4 B per row]
+static size_t rowflag_bytes(size_t rows) { return 2 * al256(rows) + 512 + al256(rows * 4); }
+static size_t rowflag_clear_bytes(size_t rows) { return 2 * al256(rows) + 512; }
+static uint32_t* rowflag_list(uint8_t* rowflag, size_t rows) { return (uint32_t*)(rowflag + rowflag_clear_bytes(rows)); }
 
 // polylines: tiled fast path + general row kernel over the rows it flagged; everything else: row kernel
 // anaglyph scratch of the tiled polylines path: both eyes as uint8 codes side by side
@@ -351,18 +355,18 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
     // (cs_rowwarp.hip k_poly_replay) instead of inside the row kernel
     const bool replay = poly && replay_scratch && rowflag && !A.anaglyph && !dev_switch(CS_DEBUG_NO_REPLAY_KERNEL) &&
                         poly_replay_bytes(A.n, A.h, A.w, fill == CS_FILL_POLYLINES_SHARP) > 0;
-    if (replay) {
-        hipError_t e = poly_replay_attach(A, fill == CS_FILL_POLYLINES_SHARP, replay_scratch, stream);
-        if (e != hipSuccess) return fail_hip(e, "replay scratch");
-    }
+    bool cleared = false;   // the flagged-row block (row flags, counters, replay counters and retry flags) has been zeroed
+    if (replay)
+        (void)poly_replay_attach(A, fill == CS_FILL_POLYLINES_SHARP, replay_scratch, rowflag + al256((size_t)A.n * A.h) + 256, stream);
     if (poly && (!A.anaglyph || (ana_sbs && A.image_f32 && !A.out_u8)) && halo <= polytile_max_halo() && rowflag &&
         !dev_switch(CS_DEBUG_NO_TILE)) {
         // workspace: [n*h flag bytes][count, padded to 256][n*h list entries]
         const size_t rows = (size_t)A.n * A.h;
         uint32_t* count = (uint32_t*)(rowflag + al256(rows));
-        uint32_t* list = count + 64;
-        hipError_t e = hipMemsetAsync(rowflag, 0, al256(rows) + 256, stream);
+        uint32_t* list = rowflag_list(rowflag, rows);
+        hipError_t e = hipMemsetAsync(rowflag, 0, rowflag_clear_bytes(rows), stream);
         if (e != hipSuccess) return fail_hip(e, "rowflag memset");
+        cleared = true;
         // soft: the point-owner kernel (cs_polypoint.hip) unless the halo is too wide for it or the development switch
         // CS_DEBUG_PT_VARIANT >= 1 asks for the first generation (cs_polytile.hip); sharp: first generation
         const int variant = dev_switch(CS_DEBUG_PT_VARIANT);   // 0 / 3 / 4: point-owner kernel; other values: first generation
@@ -403,14 +407,14 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         const bool flagging = (fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING) && rowflag;
         const size_t rows = (size_t)A.n * A.h;
         if (flagging) {
-            hipError_t e = hipMemsetAsync(rowflag, 0, al256(rows) + 256, stream);
+            hipError_t e = hipMemsetAsync(rowflag, 0, rowflag_clear_bytes(rows), stream);
             if (e != hipSuccess) return fail_hip(e, "rowflag memset");
         }
         hipError_t e = launch_fwdtile(fill, A, halo, flagging ? rowflag : nullptr, stream);
         if (e == hipSuccess) {
             if (!flagging) return CS_OK;
             uint32_t* count = (uint32_t*)(rowflag + al256(rows));
-            uint32_t* list = count + 64;
+            uint32_t* list = rowflag_list(rowflag, rows);
             e = launch_collect_rows(rowflag, (int)rows, count, list, stream);
             if (e != hipSuccess) return fail_hip(e, "flagged-row collection");
             A.row_list = list; A.row_count = count;
@@ -423,6 +427,10 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
                                         const_cast<float*>(A.eye[1].depth), A.tilemap, A.stats, A.h, A.w, stream);
         if (e != hipSuccess) return fail_hip(e, "lazy depth rows");
     }
+    if (replay && !cleared) {   // (no tile kernel took the call: the block has not been cleared yet)
+        hipError_t e0 = hipMemsetAsync(rowflag, 0, rowflag_clear_bytes((size_t)A.n * A.h), stream);
+        if (e0 != hipSuccess) return fail_hip(e0, "rowflag memset");
+    }
     hipError_t e = launch_rowwarp(fill, A, threads_for(fill, A.w), stream);
     if (e != hipSuccess) return fail_hip(e, "row kernel launch");
     if (replay) {
@@ -430,10 +438,9 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         if (e != hipSuccess) return fail_hip(e, "stretch replay launch");
         // rows with a stretch the replay kernel gave up on (usually none): once more through the row kernel, export off
         const size_t rows = (size_t)A.n * A.h;
-        uint32_t* count2 = (uint32_t*)(rowflag + al256(rows)) + 8;   // (a second {count, cursor} pair in the padded counter block)
-        uint32_t* list = (uint32_t*)(rowflag + al256(rows)) + 64;
-        e = hipMemsetAsync(count2, 0, 8, stream);
-        if (e == hipSuccess) e = launch_collect_rows(poly_replay_retry_flags(A), (int)rows, count2, list, stream);
+        uint32_t* count2 = (uint32_t*)(rowflag + al256(rows)) + 8;   // (a second {count, cursor} pair in the cleared counter block)
+        uint32_t* list = rowflag_list(rowflag, rows);
+        e = launch_collect_rows(poly_replay_retry_flags(A), (int)rows, count2, list, stream);
         if (e != hipSuccess) return fail_hip(e, "replay retry collection");
         RowArgs R = A;
         R.rp_dump = nullptr; R.row_list = list; R.row_count = count2;

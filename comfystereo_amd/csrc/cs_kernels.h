@@ -82,7 +82,7 @@ size_t rowwarp_lds_bytes(int fill, int w, int anaglyph = 1);   // anaglyph modes
 // scratch of the stretch replay kernel for a call of n frames (0: the frame is too wide for its windows); poly_replay_attach
 // carves it into A.rp_* and zeroes the counters; launch_poly_replay runs the descriptors the row pass appended
 size_t poly_replay_bytes(int n, int h, int w, int sharp);
-hipError_t poly_replay_attach(RowArgs& A, int sharp, void* scratch, hipStream_t stream);
+hipError_t poly_replay_attach(RowArgs& A, int sharp, void* scratch, void* ctr_retry, hipStream_t stream);
 hipError_t launch_poly_replay(int sharp, const RowArgs& A, hipStream_t stream);
 uint8_t* poly_replay_retry_flags(const RowArgs& A);   // one byte per row: set by a stretch the replay kernel gave up on
 

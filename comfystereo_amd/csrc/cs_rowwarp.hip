@@ -2012,6 +2012,7 @@ __global__ void __launch_bounds__(64) k_poly_replay(RowArgs A, uint8_t* __restri
     __shared__ uint16_t srcpos[128];
     const int lane = threadIdx.x;
     const uint32_t count = min(A.rp_ctr[1], A.rp_cap);
+    if (count == 0) return;   // (the usual case: no order-dependent row in the batch -- no traffic on the cursor word)
     const int w = A.w, h = A.h;
     for (;;) {
         uint32_t idx = 0;
@@ -2059,17 +2060,19 @@ __global__ void __launch_bounds__(64) k_poly_replay(RowArgs A, uint8_t* __restri
 size_t poly_replay_bytes(int n, int h, int w, int sharp) {
     if (w > 8192) return 0;
     const size_t rows = (size_t)n * h;   // slots for half of the eye rows, four stretches per slot on average
-    return 256 + al256r(rows) + al256r(rows * 4 * RP_DESC * 4) + rows * rp_slot_bytes(w, sharp) + 256;
+    return al256r(rows * 4 * RP_DESC * 4) + rows * rp_slot_bytes(w, sharp) + 256;
 }
-// scratch: [counters 256 B][retry flags, one byte per row][descriptor list][dump slots]
-hipError_t poly_replay_attach(RowArgs& A, int sharp, void* scratch, hipStream_t stream) {
+// scratch: [descriptor list][dump slots]; `ctr_retry`: [counters 256 B][retry flags, one byte per row], zeroed by the caller
+// (it lies in the flagged-row block that run_rows clears with one memset)
+hipError_t poly_replay_attach(RowArgs& A, int sharp, void* scratch, void* ctr_retry, hipStream_t stream) {
     const size_t rows = (size_t)A.n * A.h;
     char* b = (char*)scratch;
-    A.rp_ctr = (uint32_t*)b;
-    A.rp_list = (uint32_t*)(b + 256 + al256r(rows));
-    A.rp_dump = (uint8_t*)(b + 256 + al256r(rows) + al256r(rows * 4 * RP_DESC * 4));
+    A.rp_ctr = (uint32_t*)ctr_retry;
+    A.rp_list = (uint32_t*)b;
+    A.rp_dump = (uint8_t*)(b + al256r(rows * 4 * RP_DESC * 4));
     A.rp_slots = (uint32_t)rows; A.rp_cap = (uint32_t)(rows * 4); A.rp_slot_bytes = (uint32_t)rp_slot_bytes(A.w, sharp);
-    return hipMemsetAsync(b, 0, 256 + al256r(rows), stream);   // counters and retry flags
+    (void)stream;
+    return hipSuccess;
 }
 uint8_t* poly_replay_retry_flags(const RowArgs& A) { return (uint8_t*)A.rp_ctr + 256; }
 hipError_t launch_poly_replay(int sharp, const RowArgs& A, hipStream_t stream) {
