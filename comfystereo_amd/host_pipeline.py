@@ -136,15 +136,15 @@ def generate_host(image, depth_map, divergence, separation, modes, stereo_balanc
                 raise ValueError(f"out tensors must be contiguous CPU float32 tensors of shapes {shapes}")
         if all(t.is_pinned() for t in out):
             final = out
-    if final is None and out is None and pinned_outputs and not compact:
+    if final is None and out is None and pinned_outputs:
+        # (compact boundary too: the host threads then write into pinned blocks that PyTorch's host allocator caches -- no page
+        # faults on the way in, and dropping 15 GB of results is not a 0.7 s munmap on the caller's side, profiles/r03_host.txt)
         try:
             final = tuple(torch.empty(sh, dtype=torch.float32, pin_memory=True) for sh in shapes)
         except RuntimeError:  # not enough lockable memory: fall back to pageable results through staging buffers
             final = None
-    direct = final is not None and not compact
-    if compact and final is None:
-        final = out if out is not None else tuple(torch.empty(sh, dtype=torch.float32) for sh in shapes)
-    elif not direct:
+    direct = final is not None and not compact   # (float32 boundary: the device writes straight into pinned results)
+    if final is None:
         final = out if out is not None else tuple(torch.empty(sh, dtype=torch.float32) for sh in shapes)
     ranges = [(b0, min(b0 + chunk, total)) for b0 in range(0, total, chunk)]
     slots = [_Stage(params(chunk), dshape, device, not direct, compact) for _ in range(min(2, len(ranges)))]

@@ -118,12 +118,12 @@ def test_host_pipeline_equals_the_whole_batch(monkeypatch, fill, n, batch):
     if fill != "gpu_warp":
         # compact boundary (round 3; the default for the CPU techniques): uint8 codes over PCIe, float32 written by host threads
         monkeypatch.setattr(host_pipeline, "CHUNK_IN_BYTES", 2 * 4 * (h * w * 3 + h * w * 3) + 1)  # two frames per chunk
-        for threads in (0, 1, 3):
+        for threads, pinned in ((0, True), (1, False), (3, True)):
             seen.clear()
-            got = host_pipeline.generate_host(img, dep, *args, progress=seen.append, expand_threads=threads)
+            got = host_pipeline.generate_host(img, dep, *args, progress=seen.append, expand_threads=threads, pinned_outputs=pinned)
             assert sum(seen) == n
             for g, r in zip(got, ref):
-                assert not g.is_cuda and not g.is_pinned() and g.dtype == torch.float32 and torch.equal(g, r)
+                assert not g.is_cuda and g.is_pinned() == pinned and g.dtype == torch.float32 and torch.equal(g, r)
     else:
         with pytest.raises(ValueError):
             host_pipeline.generate_host(img, dep, *args, compact=True)
