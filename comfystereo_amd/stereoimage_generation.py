@@ -55,8 +55,9 @@ def create_stereoimages(original_image, depthmap, divergence, separation=0.0, mo
     if len(modes) == 0:
         return []
     if not (isinstance(depthmap, torch.Tensor) and isinstance(original_image, torch.Tensor)):
-        raise NotImplementedError("numpy/PIL inputs take the reference's scipy blur path (reflect borders), which "
-                                  "the node never uses; pass torch tensors")
+        return _create_stereoimages_numpy(original_image, depthmap, divergence, separation, modes, stereo_balance,
+                                          stereo_offset_exponent, fill_technique, depth_blur_strength,
+                                          direction_aware_depth_blur, return_modified_depth, convergence_point)
     for m in modes:
         if m not in _MODES:
             raise Exception('Unknown mode')
@@ -87,6 +88,57 @@ def create_stereoimages(original_image, depthmap, divergence, separation=0.0, mo
             return stereo_images, Image.fromarray(left8), Image.fromarray(right8)
         return stereo_images, Image.fromarray(left8)
     return stereo_images
+
+
+def _create_stereoimages_numpy(original_image, depthmap, divergence, separation, modes, stereo_balance,
+                               stereo_offset_exponent, fill_technique, depth_blur_strength, direction_aware_depth_blur,
+                               return_modified_depth, convergence_point):
+    """numpy / PIL inputs (reference :1486-1499, 1519-1574): the uint8 image is used as it is, the depth map as float32 without
+    the x255 step of the tensor path, each eye is apply_stereo_divergence (HIP, cs_apply_stereo_divergence), the modified
+    depth is clip(depth, 0, 255).astype(uint8).  With the depth blur ON the reference takes its scipy blur
+    (`directional_motion_blur`: sobel + convolve1d with 'nearest' borders, :1346-1419) -- not built: the node never passes
+    numpy arrays, so that one combination raises."""
+    for m in modes:
+        if m not in _MODES:
+            raise Exception('Unknown mode')
+    if direction_aware_depth_blur and depth_blur_strength > 0:
+        raise NotImplementedError("numpy / PIL inputs with the depth blur on take the reference's scipy blur path "
+                                  "(directional_motion_blur, 'nearest' borders); pass torch tensors for the blurred path")
+    image = np.asarray(original_image)
+    depth = np.asarray(depthmap).astype(np.float32)
+    if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
+        raise ValueError("numpy / PIL images must be uint8 [H, W, 3] (the reference indexes them as such)")
+    assert depth.shape == image.shape[:2], 'Depthmap and the image must have the same size'   # (reference :1586)
+    dev = _device()
+    img_t = torch.from_numpy(np.array(image, dtype=np.uint8, order='C', copy=True)).to(dev)   # (PIL arrays are read-only)
+    dep_t = torch.from_numpy(np.ascontiguousarray(depth)).to(dev)
+    left_div, right_div = divergence * (1 + stereo_balance), divergence * (1 - stereo_balance)
+
+    def eye(div_signed, sep_signed, enabled):
+        if not enabled or fill_technique not in _CPU_FILLS:   # (< 0.001: the source image, :1536; unknown technique: :1620)
+            return img_t
+        return engine.apply_stereo_divergence(img_t, dep_t, div_signed, sep_signed, stereo_offset_exponent, fill_technique,
+                                              convergence_point)
+
+    left = eye(+1 * left_div, -1 * separation, not (left_div < 0.001))
+    right = eye(-1 * right_div, separation, not (right_div < 0.001))
+
+    def anaglyph(a, b):   # overlap_red_cyan (:1996-2010): R from a, G and B from b
+        return torch.cat([a[..., :1], b[..., 1:]], dim=-1)
+
+    results = []
+    for m in modes:
+        r = {'left-right': lambda: torch.cat([left, right], 1), 'right-left': lambda: torch.cat([right, left], 1),
+             'top-bottom': lambda: torch.cat([left, right], 0), 'bottom-top': lambda: torch.cat([right, left], 0),
+             'red-cyan-anaglyph': lambda: anaglyph(left, right), 'left-only': lambda: left, 'only-right': lambda: right,
+             'cyan-red-reverseanaglyph': lambda: anaglyph(right, left)}[m]()
+        results.append(Image.fromarray(r.contiguous().cpu().numpy()))
+    if not return_modified_depth:
+        return results
+    mod = Image.fromarray(torch.clamp(dep_t, 0, 255).to(torch.uint8).cpu().numpy())
+    if direction_aware_depth_blur:
+        return results, mod, mod.copy()
+    return results, mod
 
 
 def create_stereoimages_gpu(image_tensor, depth_tensor, divergence, separation=0.0, modes=None,

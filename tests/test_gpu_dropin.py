@@ -211,3 +211,32 @@ def test_stereo_shift_torch_matches_reference_vectors_and_oracle():
         d = rng.random((b, h, w)).astype(np.float32)
         got = stereo_shift_torch(torch.from_numpy(x).cuda(), torch.from_numpy(d).cuda(), sf, both, e)
         assert got.is_cuda and np.array_equal(got.cpu().numpy(), so.stereo_shift(x, d, sf, both, e))
+
+
+def test_create_stereoimages_numpy_and_pil_inputs():
+    """create_stereoimages with numpy / PIL inputs, depth blur off (reference stereoimage_generation.py:1486-1499, 1519-1574):
+    fixtures captured from the reference (tools/make_goldens.py --only-numpy-inputs), every technique, all return forms.
+    With the blur on, that input form takes the reference's scipy blur: documented refusal."""
+    from PIL import Image
+    from conftest import Golden
+    from comfystereo_amd import stereoimage_generation as sig
+    g = Golden("create_stereoimages_numpy.npz")
+    for case in g.meta["cases"]:
+        img, depth = g[f"{case['group']}/img"], g[f"{case['group']}/depth"]
+        res, mod = sig.create_stereoimages(Image.fromarray(img) if case["pil"] else img, depth.tolist() if case["pil"] else depth,
+                                           case["divergence"], case["separation"], case["modes"], case["stereo_balance"],
+                                           case["stereo_offset_exponent"], case["fill_technique"], 0.0, 6.0, False, True,
+                                           case["convergence_point"])
+        assert len(res) == len(case["modes"])
+        for k, r in enumerate(res):
+            assert isinstance(r, Image.Image) and np.array_equal(np.asarray(r), g[f"{case['id']}/out{k}"]), (case["id"], k)
+        assert np.array_equal(np.asarray(mod), g[f"{case['id']}/mod"]), case["id"]
+    img, depth = g["c0/img"], g["c0/depth"]
+    only = sig.create_stereoimages(img, depth, 5.0, 0.0, "left-right", 0.0, 2.0, "polylines_soft", 0.0, 6.0, False, False)
+    assert isinstance(only, list) and len(only) == 1
+    three = sig.create_stereoimages(img, depth, 5.0, 0.0, ["left-right"], 0.0, 2.0, "none", 0.0, 6.0, True, True)
+    assert len(three) == 3   # (direction-aware flag with strength 0: the reference returns the depth twice, :1378)
+    with pytest.raises(NotImplementedError):
+        sig.create_stereoimages(img, depth, 5.0, 0.0, ["left-right"], 0.0, 2.0, "none", 5.0, 6.0, True, True)
+    with pytest.raises(Exception):
+        sig.create_stereoimages(img, depth, 5.0, modes=["sideways"])

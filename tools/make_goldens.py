@@ -414,6 +414,35 @@ def gen_dialect_f64(sig):
     print("dialect_f64:", len(cases), "cases;", [c["pixels_differing_from_d32"] for c in cases], "pixels differ from D32 ('none')")
 
 
+def gen_numpy_inputs(sig):
+    """create_stereoimages with numpy / PIL inputs, depth blur off (reference :1486-1499, 1527-1574: no x255 scaling, no clip,
+    uint8 image used as it is, depth output = clip(depth, 0, 255).astype(uint8)); every technique, several modes."""
+    from PIL import Image
+    rng = np.random.default_rng(77)
+    arrays, cases = {}, []
+    for ci, (h, w, kind) in enumerate([(40, 96, "stepped"), (33, 130, "blobs")]):
+        img = synth.image_u8(h, w, seed=40 + ci)
+        depth = (synth.DEPTHS[kind](h, w) * np.float32(255.0)).astype(np.float32)
+        arrays[f"c{ci}/img"] = img
+        arrays[f"c{ci}/depth"] = depth
+        for fi, fill in enumerate(FILLS):
+            modes = [["left-right", "red-cyan-anaglyph"], ["top-bottom"], ["right-left", "only-right"], ["bottom-top", "left-only"]][fi % 4]
+            bal = [0.0, 0.3, -0.4][fi % 3]
+            kw = dict(divergence=[5.0, 8.0][ci], separation=[0.0, 1.0][fi % 2], modes=modes, stereo_balance=bal,
+                      stereo_offset_exponent=[2.0, 1.0, 1.4][fi % 3], fill_technique=fill, convergence_point=[0.5, 0.2][fi % 2])
+            as_pil = fi % 2 == 1   # PIL image in, list input for the depth map
+            res, mod = sig.create_stereoimages(Image.fromarray(img) if as_pil else img, depth.tolist() if as_pil else depth,
+                                               kw["divergence"], kw["separation"], modes, bal, kw["stereo_offset_exponent"], fill,
+                                               0.0, 6.0, False, True, kw["convergence_point"])
+            cid = f"c{ci}/{fill}"
+            for k, r in enumerate(res):
+                arrays[f"{cid}/out{k}"] = np.asarray(r)
+            arrays[f"{cid}/mod"] = np.asarray(mod)
+            cases.append(dict(id=cid, group=f"c{ci}", pil=as_pil, **kw))
+    np.savez_compressed(os.path.join(OUT, "create_stereoimages_numpy.npz"), meta=json.dumps(dict(cases=cases)), **arrays)
+    print("create_stereoimages with numpy / PIL inputs:", len(cases), "cases")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     refload.quiet()
@@ -440,6 +469,9 @@ def main():
     if "--only-digests" in sys.argv:
         gen_digests(gs)
         return
+    if "--only-numpy-inputs" in sys.argv:
+        gen_numpy_inputs(sig)
+        return
     if "--only-dialect" in sys.argv:
         gen_dialect_f64(sig)
         return
@@ -453,6 +485,7 @@ def main():
     gen_warp_1080p(sig)
     gen_digests(gs)
     gen_dialect_f64(sig)
+    gen_numpy_inputs(sig)
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
