@@ -96,3 +96,34 @@ def test_debug_switches_are_explicit_and_release_builds_reject_the_phase_cutoffs
     for f in os.listdir(src):
         if f.endswith((".hip", ".h")):
             assert "getenv" not in open(os.path.join(src, f)).read(), f
+
+
+def test_host_expansion_and_copy_need_no_gpu():
+    """cs_host_expand_u8 / cs_host_copy (the compact node boundary's host half, cs_host.hip): plain host code.
+    out = codes / 255.0f by true division (np2tensor / convertResult, reference GenerateStereo.py:41-44, 365-378), replicated
+    over the channels of a depth map, or the 0 / 1 mask flags (:355-361)."""
+    import ctypes
+    import numpy as np
+    from comfystereo_amd import _native
+    L = _native.lib()
+    rng = np.random.default_rng(5)
+    for count in (0, 1, 7, 4099, 1 << 20):
+        codes = rng.integers(0, 256, count, dtype=np.uint8)
+        for threads in (1, 3, 0):
+            out = np.full(count, -1.0, np.float32)
+            assert L.cs_host_expand_u8(codes.ctypes.data, out.ctypes.data, count, 1, 0, threads) == 0 or count == 0
+            assert np.array_equal(out.view(np.uint32), (codes.astype(np.float32) / np.float32(255.0)).view(np.uint32))
+            out3 = np.full(3 * count, -1.0, np.float32)
+            assert L.cs_host_expand_u8(codes.ctypes.data, out3.ctypes.data, count, 3, 0, threads) == 0 or count == 0
+            assert np.array_equal(out3.reshape(-1, 3), np.repeat((codes.astype(np.float32) / np.float32(255.0))[:, None], 3, 1))
+            m = np.full(count, -1.0, np.float32)
+            assert L.cs_host_expand_u8(codes.ctypes.data, m.ctypes.data, count, 1, 1, threads) == 0 or count == 0
+            assert np.array_equal(m, (codes != 0).astype(np.float32))
+        src = rng.integers(0, 256, count * 3 + 5, dtype=np.uint8)
+        dst = np.zeros_like(src)
+        assert L.cs_host_copy(dst.ctypes.data, src.ctypes.data, src.size, 4) == 0
+        assert np.array_equal(dst, src)
+    one = np.zeros(4, np.float32)
+    assert L.cs_host_expand_u8(None, one.ctypes.data, 4, 1, 0, 1) != 0          # null pointer
+    assert L.cs_host_expand_u8(one.ctypes.data, one.ctypes.data, 4, 5, 0, 1) != 0   # replicate out of range
+    assert L.cs_host_copy(None, one.ctypes.data, 4, 1) != 0
