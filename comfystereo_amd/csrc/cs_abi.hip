@@ -612,11 +612,20 @@ static int generate_chunk(const cs_params* p, const float* image, const float* d
 
     hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, sp, stats, n);
     const bool resize = p->depth_h != h || p->depth_w != w;
+    // RGB depth + blur: the gray conversion also builds the blur's edge bit rows (one pass over the depth input)
+    const bool blur_map = !dev_switch(CS_DEBUG_BLUR_FULL_COPY);
+    const bool pre_edges = blur && !resize && p->depth_c == 3 &&
+                           blur_pre_edges_ok(n, h, w, p->depth_blur_strength, p->depth_blur_edge_threshold, p->depth_blur_strength,
+                                             p->depth_blur_vert_smooth, blur_map);
     if (resize) {
         float* gs = (float*)(ws + W.gray_src);
         int shw = p->depth_h * p->depth_w;
         hipLaunchKernelGGL(k_gray, dim3(grid_for(shw / 32 + 1, 256), n), dim3(256), 0, sp, depth, gs, shw, p->depth_c, stats, 0);
         hipLaunchKernelGGL(k_resize_bilinear, dim3(grid_for(hw, 256), n), dim3(256), 0, sp, gs, p->depth_h, p->depth_w, gray, h, w, stats);
+    } else if (pre_edges) {
+        hipError_t e = launch_gray_edges(depth, gray, n, h, w, stats, p->depth_blur_strength, p->depth_blur_edge_threshold,
+                                         p->depth_blur_strength, p->depth_blur_vert_smooth, (float*)(ws + W.wl), (float*)(ws + W.wr), sp);
+        if (e != hipSuccess) return fail_hip(e, "gray + edge pass");
     } else {
         // (>= 8 float4 groups per thread: the per-workgroup min/max reduction is amortised -- 3x faster at 1080p)
         hipLaunchKernelGGL(k_gray, dim3(grid_for(hw / 32 + 1, 256), n), dim3(256), 0, sp, depth, gray, hw, p->depth_c, stats, 1);
@@ -643,7 +652,7 @@ static int generate_chunk(const cs_params* p, const float* image, const float* d
                                al256((size_t)n * hw * 4) < (1ull << 32) - (1u << 20);
         rc = launch_blur(gray, n, h, w, p->depth_blur_strength, p->depth_blur_edge_threshold, p->depth_blur_strength, p->depth_blur_falloff,
                          p->depth_blur_vert_smooth, L, R, (float*)(ws + W.wl), (float*)(ws + W.wr), stats, 1, sp,
-                         dev_switch(CS_DEBUG_BLUR_FULL_COPY) ? nullptr : (uint32_t*)(ws + W.tilemap), want_lazy ? &lazy : nullptr);
+                         blur_map ? (uint32_t*)(ws + W.tilemap) : nullptr, want_lazy ? &lazy : nullptr, pre_edges ? 1 : 0);
         if (rc) return fail_blur(rc);
         dL = L; dR = R;
         scale_from_stats = 0;  // the blur kernel already wrote scaled depth

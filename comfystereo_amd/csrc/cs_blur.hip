@@ -35,6 +35,9 @@ struct BlurArgs {
     float* wl; float* wr;  // [n][h][w]
     float* out_l; float* out_r;
     int dbg;  // development only (env CS_DBG)
+    // edge bit rows made by k_gray_edges: two planes (x1 / x255 hypothesis) `mask_plane` 64-bit words apart, the frame's
+    // ST_SCALE255 word picks; block summaries unscaled with one "any bit" flag per plane.  0: one plane (k_blur_edges4)
+    size_t mask_plane;
 };
 
 __constant__ csm::PowfTables c_blur_powf_tables = CS_POWF_TABLES_INIT;
@@ -330,6 +333,180 @@ __global__ void __launch_bounds__(256) k_blur_edges4(BlurArgs A, unsigned long l
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_gray_edges: the gray conversion of an RGB depth map (cs_abi.hip k_gray: GenerateStereo.py:134-139) and the edge bit rows
+// of k_blur_edges4 in ONE pass over the depth input -- the gray depth is not read back for the Sobel (4 B/px less HBM
+// traffic, one launch less: 0.58 ms per 64 4K frames).  The x255 decision of the frame (reference :1475, :1045) needs the
+// frame's maximum, which only exists when this kernel has finished, so the bit rows are built for BOTH hypotheses (plane 0:
+// scale 1, plane 1: scale 255; the Sobel of the scaled values is not the scaled Sobel in float32) and the consumers pick the
+// plane by the frame's ST_SCALE255 word.  One wave per 256 columns x GE_RB rows, marching down in blocks of BLUR_ER4 rows
+// with a two-row overlap; four columns per lane (three 16-byte loads per row), neighbours through DPP; the block summaries
+// hold the UNSCALED min / max (x -> fl(x * s) is monotone: the scaled extremes are the extremes scaled) and one
+// "any edge bit" flag per hypothesis.
+// `thr`: the largest float t with fl(t / den) <= 0.5, so that  clamp(|g| / den, 0, 1) > 0.5  <=>  |g| > thr  (the division
+// is monotone in |g|; NaN fails both); computed on the host by blur_edge_threshold().
+// ---------------------------------------------------------------------------------------------
+#define GE_RB 32
+static_assert(GE_RB % BLUR_ER4 == 0, "strips are whole summary blocks");
+__global__ void __launch_bounds__(64) k_gray_edges(const float* __restrict__ rgb, float* __restrict__ gray, int h, int w,
+                                                   uint32_t* stats, float thr, unsigned long long* mask_l,
+                                                   unsigned long long* mask_r, size_t plane, int MW, float4* blk, int HB) {
+    const int lane = threadIdx.x;
+    const int x = (blockIdx.x * 64 + lane) * 4, yb0 = blockIdx.y * GE_RB, frame = blockIdx.z;
+    const float* src = rgb + (size_t)frame * h * w * 3;
+    float* dst = gray + (size_t)frame * h * w;
+    const bool incol = x < w;   // (w % 4 == 0: a lane's four columns are inside together)
+    // the one neighbour column a wave has to load itself: x - 1 for its first lane, x + 4 for its last
+    const int xn = lane == 0 ? x - 1 : x + 4;
+    const bool nb_lane = (lane == 0 && x > 0 && incol) || (lane == 63 && x + 4 < w);
+    struct Row { float4 v; float nb, lo, hi; };   // lo / hi: extremes of everything the row contributes to this lane's Sobel taps
+    const bool pad0 = x == 0 || x + 4 >= w;   // a zero-padded neighbour column
+    auto gray_of = [](float r, float g, float b) { return (0.2989f * r + 0.5870f * g) + 0.1140f * b; };
+    auto load_row = [&](int yy, float4& a, float4& b, float4& c, float& n0, float& n1, float& n2) {
+        // (loads from a clamped, always valid address; the VALUES are selected: a conditional load of a float4 becomes a
+        // load through a selected pointer with the zero vector in scratch memory)
+        const bool rowok = yy >= 0 && yy < h;
+        const float* r = src + ((size_t)(rowok ? yy : 0) * w) * 3;
+        const float4* q = reinterpret_cast<const float4*>(r + (size_t)(incol ? x : 0) * 3);
+        const float4 ta = q[0], tb = q[1], tc = q[2];
+        const bool ok = rowok && incol;
+        a = make_float4(ok ? ta.x : 0.f, ok ? ta.y : 0.f, ok ? ta.z : 0.f, ok ? ta.w : 0.f);
+        b = make_float4(ok ? tb.x : 0.f, ok ? tb.y : 0.f, ok ? tb.z : 0.f, ok ? tb.w : 0.f);
+        c = make_float4(ok ? tc.x : 0.f, ok ? tc.y : 0.f, ok ? tc.z : 0.f, ok ? tc.w : 0.f);
+        n0 = n1 = n2 = 0.0f;
+        if (rowok && nb_lane) { const float* pn = r + (size_t)xn * 3; n0 = pn[0]; n1 = pn[1]; n2 = pn[2]; }
+    };
+    auto to_row = [&](const float4& a, const float4& b, const float4& c, float n0, float n1, float n2) {
+        Row R;
+        R.v.x = gray_of(a.x, a.y, a.z); R.v.y = gray_of(a.w, b.x, b.y); R.v.z = gray_of(b.z, b.w, c.x); R.v.w = gray_of(c.y, c.z, c.w);
+        R.nb = gray_of(n0, n1, n2);   // (zeros in, zero out)
+        const float e = nb_lane ? R.nb : (pad0 ? 0.0f : R.v.x);
+        R.lo = fminf(fminf(fminf(R.v.x, R.v.y), fminf(R.v.z, R.v.w)), e);
+        R.hi = fmaxf(fmaxf(fmaxf(R.v.x, R.v.y), fmaxf(R.v.z, R.v.w)), e);
+        return R;
+    };
+    Row G[BLUR_ER4 + 2];   // rows y0 - 1 .. y0 + ER4 of the current block (gray, unscaled; zero outside the frame)
+    {
+        float4 a[2], b[2], c[2]; float n0[2], n1[2], n2[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) load_row(yb0 - 1 + i, a[i], b[i], c[i], n0[i], n1[i], n2[i]);
+#pragma unroll
+        for (int i = 0; i < 2; i++) G[BLUR_ER4 + i] = to_row(a[i], b[i], c[i], n0[i], n1[i], n2[i]);
+    }
+    float mn_f = INFINITY, mx_f = -INFINITY;
+    const int word = x >> 6;
+    // the RGB rows of the NEXT block are requested before the current block is worked on (the wave's own loads stay in flight
+    // under its Sobel and its stores: with 2-3 waves per SIMD the other waves alone do not cover the memory latency)
+    float4 pa[BLUR_ER4], pb[BLUR_ER4], pc[BLUR_ER4]; float p0[BLUR_ER4], p1[BLUR_ER4], p2[BLUR_ER4];
+#pragma unroll
+    for (int i = 0; i < BLUR_ER4; i++) load_row(yb0 + 1 + i, pa[i], pb[i], pc[i], p0[i], p1[i], p2[i]);
+    for (int y0 = yb0; y0 < yb0 + GE_RB && y0 < h; y0 += BLUR_ER4) {
+        G[0] = G[BLUR_ER4]; G[1] = G[BLUR_ER4 + 1];
+#pragma unroll
+        for (int i = 0; i < BLUR_ER4; i++) G[2 + i] = to_row(pa[i], pb[i], pc[i], p0[i], p1[i], p2[i]);
+        if (y0 + BLUR_ER4 < yb0 + GE_RB && y0 + BLUR_ER4 < h) {
+#pragma unroll
+            for (int i = 0; i < BLUR_ER4; i++) load_row(y0 + BLUR_ER4 + 1 + i, pa[i], pb[i], pc[i], p0[i], p1[i], p2[i]);
+        }
+        // the block's own rows are G[1 .. ER4]: store the gray depth, min / max
+        float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < BLUR_ER4; j++) {
+            const int y = y0 + j;
+            if (y < h && incol) {
+                const float4 q = G[1 + j].v;
+                *reinterpret_cast<float4*>(dst + (size_t)y * w + x) = q;
+                mn = fminf(fminf(mn, fminf(q.x, q.y)), fminf(q.z, q.w));
+                mx = fmaxf(fmaxf(mx, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
+            }
+        }
+        mn_f = fminf(mn_f, mn); mx_f = fmaxf(mx_f, mx);
+        unsigned any[2] = {0u, 0u};
+        // |g| <= 4 s (max - min) + rounding (< 32 ulp of s max|v|) over the six rows of the window, neighbours and zero padding
+        // included: where that stays below the threshold no pixel of the block is an edge, and the Sobel is skipped (flat
+        // regions -- most of a depth map; with depth in 0..1 the whole x1 plane).  Wave-uniform.
+        float wlo = G[0].lo, whi = G[0].hi;
+#pragma unroll
+        for (int i = 1; i < BLUR_ER4 + 2; i++) { wlo = fminf(wlo, G[i].lo); whi = fmaxf(whi, G[i].hi); }
+        wlo = wave_min(wlo); whi = wave_max(whi);
+        const float span = 4.0f * (whi - wlo) * 1.0001f + 1e-5f * fmaxf(fabsf(wlo), fabsf(whi));
+#pragma unroll
+        for (int hyp = 0; hyp < 2; hyp++) {
+            const float scale = hyp ? 255.0f : 1.0f;
+            if (span * scale < thr) {   // (NaN / infinite spans compute)
+                if ((lane & 15) == 0 && word < MW) {
+#pragma unroll
+                    for (int j = 0; j < BLUR_ER4; j++) {
+                        if (y0 + j < h) {
+                            const size_t o = (size_t)hyp * plane + ((size_t)frame * h + y0 + j) * MW + word;
+                            mask_l[o] = 0ull; mask_r[o] = 0ull;
+                        }
+                    }
+                }
+                continue;
+            }
+            // the six rows scaled, with both neighbours (k_blur_edges4's v / nl / nr)
+            float4 v[BLUR_ER4 + 2]; float nl[BLUR_ER4 + 2], nr[BLUR_ER4 + 2];
+#pragma unroll
+            for (int i = 0; i < BLUR_ER4 + 2; i++) {
+                v[i] = make_float4(G[i].v.x * scale, G[i].v.y * scale, G[i].v.z * scale, G[i].v.w * scale);
+                const float nbs = G[i].nb * scale;
+                const float fl = dpp_f32<DPP_WAVE_SHR1>(v[i].w), fr = dpp_f32<DPP_WAVE_SHL1>(v[i].x);
+                nl[i] = lane == 0 ? nbs : fl;
+                nr[i] = lane == 63 ? nbs : fr;
+                if (x + 4 >= w) nr[i] = 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < BLUR_ER4; j++) {
+                const int y = y0 + j;
+                unsigned nib_l = 0, nib_r = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float L[3], R[3];
+#pragma unroll
+                    for (int t = 0; t < 3; t++) {
+                        const float4 q = v[j + t];
+                        L[t] = c == 0 ? nl[j + t] : (c == 1 ? q.x : (c == 2 ? q.y : q.z));
+                        R[t] = c == 0 ? q.y : (c == 1 ? q.z : (c == 2 ? q.w : nr[j + t]));
+                    }
+                    float g = 0.0f;
+                    g = fmaf(-1.0f, L[0], g); g = fmaf(1.0f, R[0], g);
+                    g = fmaf(-2.0f, L[1], g); g = fmaf(2.0f, R[1], g);
+                    g = fmaf(-1.0f, L[2], g); g = fmaf(1.0f, R[2], g);
+                    // (g > 0 and |g| > thr) == g > thr for thr >= 0; likewise on the negative side
+                    nib_l |= (incol && g > thr) ? 1u << c : 0u;
+                    nib_r |= (incol && g < -thr) ? 1u << c : 0u;
+                }
+                unsigned hl = nib_l << (4 * (lane & 7)), hr = nib_r << (4 * (lane & 7));
+                hl |= dpp_u32<DPP_XOR1>(hl); hr |= dpp_u32<DPP_XOR1>(hr);
+                hl |= dpp_u32<DPP_XOR2>(hl); hr |= dpp_u32<DPP_XOR2>(hr);
+                hl |= dpp_u32<DPP_HALF_MIRROR>(hl); hr |= dpp_u32<DPP_HALF_MIRROR>(hr);
+                const unsigned hl_hi = dpp_u32<DPP_ROW_SHL8>(hl), hr_hi = dpp_u32<DPP_ROW_SHL8>(hr);
+                if ((lane & 15) == 0 && word < MW && y < h) {
+                    const size_t o = (size_t)hyp * plane + ((size_t)frame * h + y) * MW + word;
+                    mask_l[o] = (unsigned long long)hl | ((unsigned long long)hl_hi << 32);
+                    mask_r[o] = (unsigned long long)hr | ((unsigned long long)hr_hi << 32);
+                    any[hyp] |= hl | hr | hl_hi | hr_hi;
+                }
+            }
+        }
+        mn = fminf(mn, dpp_f32<DPP_XOR1>(mn)); mx = fmaxf(mx, dpp_f32<DPP_XOR1>(mx));
+        mn = fminf(mn, dpp_f32<DPP_XOR2>(mn)); mx = fmaxf(mx, dpp_f32<DPP_XOR2>(mx));
+        mn = fminf(mn, dpp_f32<DPP_HALF_MIRROR>(mn)); mx = fmaxf(mx, dpp_f32<DPP_HALF_MIRROR>(mx));
+        mn = fminf(mn, dpp_f32<DPP_ROW_MIRROR>(mn)); mx = fmaxf(mx, dpp_f32<DPP_ROW_MIRROR>(mx));
+        if ((lane & 15) == 0 && word < MW)
+            blk[((size_t)frame * HB + y0 / BLUR_ER4) * MW + word] = make_float4(mn, mx, any[0] ? 1.0f : 0.0f, any[1] ? 1.0f : 0.0f);
+    }
+    mn_f = wave_min(mn_f); mx_f = wave_max(mx_f);
+    if (lane == 0) {
+        uint32_t* st_min = &stats[frame * ST_WORDS + ST_GRAY_MIN];
+        uint32_t* st_max = &stats[frame * ST_WORDS + ST_GRAY_MAX];
+        const uint32_t kmn = csm::f2ord(mn_f), kmx = csm::f2ord(mx_f);
+        if (kmn < __hip_atomic_load(st_min, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(st_min, kmn);
+        if (kmx > __hip_atomic_load(st_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st_max, kmx);
+    }
+}
+
 // 64 bits of a frame-wide bit row starting at (possibly negative / out of range) bit position `fb`
 __device__ __forceinline__ unsigned long long mask_window(const unsigned long long* row, int MW, int fb) {
     if (fb <= -64) return 0ull;
@@ -454,10 +631,14 @@ __global__ void __launch_bounds__(256) k_blur_classify(BlurArgs A, const unsigne
     const int xa = max(x0 - R, 0), xz = min(x0 + BLUR_TW - 1 + R, w - 1);          // columns within reach
     bool edge = live && A.fall_mode == 5;
     const float4* fb = blk + (size_t)frame * HB * MW;
+    const bool second = A.mask_plane && A.stats && A.stats[frame * ST_WORDS + ST_SCALE255];
+    const float bscale = second ? 255.0f : 1.0f;   // (two planes: the summaries are unscaled)
+    mask_l += second ? A.mask_plane : 0; mask_r += second ? A.mask_plane : 0;
     if (live && !edge) {
         for (int b = ya / BLUR_ER4; b <= yz / BLUR_ER4 && !edge; b++)
             for (int wi = xa >> 6; wi <= (xz >> 6) && !edge; wi++) {
-                if (fb[(size_t)b * MW + wi].z == 0.0f) continue;
+                const float4 sm = fb[(size_t)b * MW + wi];
+                if ((second ? sm.w : sm.z) == 0.0f) continue;
                 const int lo = max(xa, wi * 64) - wi * 64, hi = min(xz, wi * 64 + 63) - wi * 64;
                 const unsigned long long colmask = (~0ull >> (63 - hi)) & (~0ull << lo);
                 for (int y = max(ya, b * BLUR_ER4); y <= min(yz, b * BLUR_ER4 + BLUR_ER4 - 1); y++) {
@@ -473,7 +654,7 @@ __global__ void __launch_bounds__(256) k_blur_classify(BlurArgs A, const unsigne
     } else if (live) {
         for (int b = y0 / BLUR_ER4; b <= min(y0 + BLUR_TR - 1, h - 1) / BLUR_ER4; b++) {
             const float4 q = fb[(size_t)b * MW + tx];
-            mn = fminf(mn, q.x); mx = fmaxf(mx, q.y);
+            mn = fminf(mn, q.x * bscale); mx = fmaxf(mx, q.y * bscale);
         }
     }
     if (A.stats_rw) {
@@ -525,6 +706,7 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
         if (tid == 0) *any_edge = 0;
         const float scale = (A.stats && A.stats[frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
         const float* d = A.depth + (size_t)frame * h * w;
+        const size_t po = (A.mask_plane && scale != 1.0f) ? A.mask_plane : 0;
         __syncthreads();
         // 2. the tile's window of the frame-wide edge bit rows (k_blur_edges): rows y0-v .., bits x0-R ..
         const unsigned long long lastmask = (EW & 63) ? (~0ull >> (64 - (EW & 63))) : ~0ull;
@@ -534,8 +716,8 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
             unsigned long long bl = 0ull, br = 0ull;
             if (yy >= 0 && yy < h) {
                 const size_t ro = ((size_t)frame * h + yy) * MW;
-                bl = mask_window(mask_l + ro, MW, x0 - R + 64 * k);
-                br = mask_window(mask_r + ro, MW, x0 - R + 64 * k);
+                bl = mask_window(mask_l + po + ro, MW, x0 - R + 64 * k);
+                br = mask_window(mask_r + po + ro, MW, x0 - R + 64 * k);
                 if (k == NW - 1) { bl &= lastmask; br &= lastmask; }
             }
             mL[item] = bl; mR[item] = br;
@@ -788,9 +970,62 @@ static size_t blur_fused_lds(int v, int R, int bs) {
            sizeof(csm::PowfTables) + 64 + 4 * (size_t)(R + 2);
 }
 
+// The geometry launch_blur and launch_gray_edges share: which path the parameters take and where the bit rows, the worklist
+// and the block summaries lie inside the two weight scratch buffers (each n * h * w floats).
+struct BlurPlan {
+    bool fused, listed, lazy;
+    int MW, HB, gx, gy;
+    size_t plane_bytes, mask_bytes, list_bytes, blk_bytes;
+};
+static BlurPlan blur_plan(int n, int h, int w, double strength, double mask_width, int vert, bool tilemap, bool node_path, int planes) {
+    BlurPlan P;
+    const int bs = (int)nearbyint(strength), radius = (int)mask_width, v = vert > 0 ? vert : 0;
+    P.fused = bs >= 1 && blur_fused_lds(v, radius, bs) <= 64 * 1024 && radius >= 1 && !dev_switch(CS_DEBUG_BLUR_TWO_PASS);
+    P.MW = (w + 63) / 64;
+    P.gy = (h + BLUR_TR - 1) / BLUR_TR; P.gx = (w + BLUR_TW - 1) / BLUR_TW; P.HB = (h + BLUR_ER4 - 1) / BLUR_ER4;
+    P.plane_bytes = ((size_t)n * h * P.MW * 8 + 255) & ~(size_t)255;
+    P.mask_bytes = P.plane_bytes * planes;
+    P.list_bytes = 256 + (size_t)n * P.gy * P.gx * 4;
+    P.blk_bytes = (size_t)n * P.HB * P.MW * 16;
+    P.listed = P.fused && (w & 3) == 0 && P.gx < 1024 && P.gy < 1024 && n < 4096 && P.mask_bytes + P.list_bytes <= (size_t)n * h * w * 4;
+    // lazy mode: block summaries behind the second bit-row buffer
+    P.lazy = tilemap && node_path && P.listed && !dev_switch(CS_DEBUG_BLUR_EDGES_SCALAR) && BLUR_TR % BLUR_ER4 == 0 &&
+             P.mask_bytes + P.blk_bytes <= (size_t)n * h * w * 4;
+    return P;
+}
+
+// the largest float t >= 0 with fl(t / den) <= 0.5 (k_gray_edges); < 0: no such value (den not positive and finite)
+static float blur_edge_threshold(float den) {
+    if (!(den > 0.0f) || !std::isfinite(den)) return -1.0f;
+    volatile float d = den;
+    float t = 0.5f * den;
+    if (!std::isfinite(t)) return -1.0f;
+    auto quot = [&](float a) { volatile float q = a / d; return (float)q; };
+    for (int i = 0; i < 8 && quot(t) > 0.5f; i++) t = nextafterf(t, 0.0f);
+    for (int i = 0; i < 8 && quot(nextafterf(t, INFINITY)) <= 0.5f; i++) t = nextafterf(t, INFINITY);
+    if (quot(t) > 0.5f || quot(nextafterf(t, INFINITY)) <= 0.5f || !(t > 0.0f)) return -1.0f;
+    return t;
+}
+
+bool blur_pre_edges_ok(int n, int h, int w, double strength, double edge_threshold, double mask_width, int vert, bool tilemap) {
+    if (dev_switch(CS_DEBUG_BLUR_NO_PRE_EDGES)) return false;
+    const BlurPlan P = blur_plan(n, h, w, strength, mask_width, vert, tilemap, true, 2);
+    return P.lazy && (w & 3) == 0 && blur_edge_threshold((float)(10.0 * edge_threshold)) >= 0.0f;
+}
+
+hipError_t launch_gray_edges(const float* rgb, float* gray, int n, int h, int w, uint32_t* stats, double strength,
+                             double edge_threshold, double mask_width, int vert, float* wl, float* wr, hipStream_t stream) {
+    const BlurPlan P = blur_plan(n, h, w, strength, mask_width, vert, true, true, 2);
+    hipLaunchKernelGGL(k_gray_edges, dim3((w + 255) / 256, (h + GE_RB - 1) / GE_RB, n), dim3(64), 0, stream, rgb, gray, h, w, stats,
+                       blur_edge_threshold((float)(10.0 * edge_threshold)), reinterpret_cast<unsigned long long*>(wl),
+                       reinterpret_cast<unsigned long long*>(wr), P.plane_bytes / 8, P.MW,
+                       reinterpret_cast<float4*>(reinterpret_cast<char*>(wr) + P.mask_bytes), P.HB);
+    return hipGetLastError();
+}
+
 int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double mask_width,
                 double falloff, int vert, float* out_l, float* out_r, float* wl, float* wr, uint32_t* stats, int node_path,
-                hipStream_t stream, uint32_t* tilemap, int* lazy_used) {
+                hipStream_t stream, uint32_t* tilemap, int* lazy_used, int pre_edges) {
     // (lazy_used == nullptr with a tile map: the caller wants COMPLETE maps; the map is then only the classification's output)
     const bool want_lazy = lazy_used != nullptr;
     if (lazy_used) *lazy_used = 0;
@@ -807,25 +1042,24 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
     A.fall_mode = falloff == 1.0 ? 0 : falloff == 0.5 ? 1 : falloff == 2.0 ? 2 : falloff == 3.0 ? 3 : falloff == 0.0 ? 5 : 4;
     A.wl = wl; A.wr = wr; A.out_l = out_l; A.out_r = out_r;
     A.dbg = dev_switch(CS_DEBUG_DBG);
-    const int nofuse = dev_switch(CS_DEBUG_BLUR_TWO_PASS);
+    A.mask_plane = 0;
+    const BlurPlan P = blur_plan(n, h, w, strength, mask_width, A.vert, tilemap != nullptr, node_path != 0, pre_edges ? 2 : 1);
+    if (pre_edges && !P.lazy) return CS_EINVAL;   // (the caller asked blur_pre_edges_ok)
     size_t ldsF = blur_fused_lds(A.vert, A.radius, A.bs);
-    if (ldsF <= 64 * 1024 && A.radius >= 1 && !nofuse) {
+    if (P.fused) {
         hipError_t e = hipFuncSetAttribute((const void*)k_blur_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
         if (e != hipSuccess) return CS_EHIP;
         // the weight scratch buffers double as the frame-wide edge bit rows (2 x ceil(w/64) words per image row)
-        const int MW = (w + 63) / 64;
+        const int MW = P.MW;
         unsigned long long* mask_l = reinterpret_cast<unsigned long long*>(wl);
         unsigned long long* mask_r = reinterpret_cast<unsigned long long*>(wr);
         // edge-free tiles are copied by k_blur_copy; the others reach k_blur_fused through a worklist behind the bit rows
-        const int gy = (h + BLUR_TR - 1) / BLUR_TR, gx = (w + BLUR_TW - 1) / BLUR_TW, HB = (h + BLUR_ER4 - 1) / BLUR_ER4;
-        const size_t mask_bytes = ((size_t)n * h * MW * 8 + 255) & ~(size_t)255, list_bytes = 256 + (size_t)n * gy * gx * 4;
-        const size_t blk_bytes = (size_t)n * HB * MW * 16;
-        const bool listed = (w & 3) == 0 && gx < 1024 && gy < 1024 && n < 4096 && mask_bytes + list_bytes <= (size_t)n * h * w * 4;
-        // lazy mode: block summaries behind the second bit-row buffer
-        const bool lazy = tilemap && node_path && listed && !dev_switch(CS_DEBUG_BLUR_EDGES_SCALAR) && BLUR_TR % BLUR_ER4 == 0 &&
-                          mask_bytes + blk_bytes <= (size_t)n * h * w * 4;
+        const int gy = P.gy, gx = P.gx, HB = P.HB;
+        const size_t mask_bytes = P.mask_bytes;
+        const bool listed = P.listed, lazy = P.lazy;
         float4* blk = lazy ? reinterpret_cast<float4*>(reinterpret_cast<char*>(wr) + mask_bytes) : nullptr;
-        if ((w & 3) == 0 && !dev_switch(CS_DEBUG_BLUR_EDGES_SCALAR))
+        if (pre_edges) A.mask_plane = P.plane_bytes / 8;   // (k_gray_edges wrote the bit rows and the summaries)
+        else if ((w & 3) == 0 && !dev_switch(CS_DEBUG_BLUR_EDGES_SCALAR))
             hipLaunchKernelGGL(k_blur_edges4, dim3((w + 1023) / 1024, HB, n), dim3(256), 0, stream, A, mask_l, mask_r, MW, blk);
         else
             hipLaunchKernelGGL(k_blur_edges, dim3((w + 255) / 256, (h + BLUR_ER - 1) / BLUR_ER, n), dim3(256), 0, stream, A, mask_l, mask_r, MW);

@@ -109,7 +109,13 @@ hipError_t launch_depth_codes(const float* depth, int n, int h, int w, const uin
 // whose stats say so, and the per-frame min/max of both outputs are accumulated into stats.
 int launch_blur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double mask_width,
                 double falloff, int vert, float* out_l, float* out_r, float* wl, float* wr, uint32_t* stats, int node_path,
-                hipStream_t stream, uint32_t* tilemap = nullptr, int* lazy_used = nullptr);
+                hipStream_t stream, uint32_t* tilemap = nullptr, int* lazy_used = nullptr, int pre_edges = 0);
+// One pass over an RGB depth map instead of k_gray + k_blur_edges4: gray depth, its per-frame min / max and the edge bit rows
+// for both x255 hypotheses (cs_blur.hip k_gray_edges).  blur_pre_edges_ok: the parameters take launch_blur's lazy-tile path
+// (the only consumer of the two-plane bit rows); launch_blur is then called with pre_edges = 1 and the same wl / wr.
+bool blur_pre_edges_ok(int n, int h, int w, double strength, double edge_threshold, double mask_width, int vert, bool tilemap);
+hipError_t launch_gray_edges(const float* rgb, float* gray, int n, int h, int w, uint32_t* stats, double strength,
+                             double edge_threshold, double mask_width, int vert, float* wl, float* wr, hipStream_t stream);
 // tilemap != nullptr (zeroed by launch_blur): the tiles are classified from the edge kernel's block summaries and the map names
 // the tiles with an edge in reach.  lazy_used != nullptr: edge-free tiles are left UNWRITTEN (RowArgs::tilemap; *lazy_used = 0
 // when the parameters took a path that writes everything); lazy_used == nullptr: a streaming copy completes the maps.

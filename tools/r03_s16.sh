@@ -1,30 +1,8 @@
 #!/bin/bash
+# both-eyes workgroups of k_polypoint: A/B against HEAD first (cheap), parity second
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python - <<'PY'
-import sys, time
-sys.path.insert(0,'.'); sys.path.insert(0,'tools')
-import torch, synth
-from comfystereo_amd import host_pipeline
-from comfystereo_amd.GenerateStereo import StereoImageNode
-n,h,w=32,2160,3840
-img = torch.from_numpy(synth.image_f32(1, h, w, seed=1)).expand(n, -1, -1, -1).contiguous()
-dep = torch.from_numpy(synth.depth_batch("stepped", n, h, w, channels=3))
-hargs = (8.0, 0.0, "left-right", 0.0, 0.5, 2.0, "polylines_soft", 20.0, 20.0, True, 2.0, 6, 12)
-nargs = (8.0, 0.0, "left-right", 0.0, 0.5, 2.0, "Fill - Polylines Soft", 20.0, 20.0, True, 2.0, 6, 12)
-node = StereoImageNode()
-def t(f, keep):
-    held = None
-    r = []
-    for _ in range(4):
-        t0=time.perf_counter(); out = f(); torch.cuda.synchronize(); r.append(round(n/(time.perf_counter()-t0),1))
-        if keep: held = out
-        else: del out
-    return r
-host_pipeline.generate_host(img, dep, *hargs)
-print("generate_host, results released each time:", t(lambda: host_pipeline.generate_host(img, dep, *hargs), False))
-print("generate_host, previous results kept alive:", t(lambda: host_pipeline.generate_host(img, dep, *hargs), True))
-print("node.generate, released:", t(lambda: node.generate(img, dep, *nargs), False))
-print("node.generate, kept:", t(lambda: node.generate(img, dep, *nargs), True))
-print("generate_host with a progress callback, released:", t(lambda: host_pipeline.generate_host(img, dep, *hargs, progress=lambda k: None), False))
-import subprocess; print(subprocess.run("free -g | head -2", shell=True, capture_output=True, text=True).stdout)
-PY
+mkdir -p gpurun_out/s16
+LIBS="comfystereo_amd/libcs_base.so comfystereo_amd/libcomfystereo_hip.so" tools/abn.sh --n 32 --blur 0 --iters 10
+LIBS="comfystereo_amd/libcs_base.so comfystereo_amd/libcomfystereo_hip.so" tools/abn.sh --n 32 --blur 1 --iters 10 --kind blobs
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py tests/test_gpu_lazy_blur.py -x -q -m gpu > gpurun_out/s16/tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/s16/tests.log
+timeout 400 python tools/extended_fuzz.py 240 11000 > gpurun_out/s16/fuzz.log 2>&1; echo "fuzz rc=$?"; tail -2 gpurun_out/s16/fuzz.log

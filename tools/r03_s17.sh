@@ -1,7 +1,8 @@
 #!/bin/bash
+# one-pass gray + edge bit rows (k_gray_edges): parity, then A/B against HEAD, then kernel trace
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for k in clipped random8; do
-  timeout 600 python tools/quick_bench.py --n 8 --blur 0 --iters 2 --kind $k 2>&1 | tail -3
-done
-rm -rf /tmp/pt; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pt -o p -- python3 tools/quick_bench.py --n 8 --blur 0 --iters 2 --kind clipped > /dev/null 2>&1
-db=$(find /tmp/pt -name '*.db' | head -1); python3 tools/prof_summary.py $db gpurun_out/clipped_trace.txt > /dev/null; head -8 gpurun_out/clipped_trace.txt | cut -c1-150
+mkdir -p gpurun_out/s17
+timeout 900 python -m pytest tests/test_gpu_gray_edges.py tests/test_gpu_lazy_blur.py -x -q -m gpu > gpurun_out/s17/tests.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/s17/tests.log
+LIBS="comfystereo_amd/libcs_base.so comfystereo_amd/libcomfystereo_hip.so" tools/abn.sh --n 64 --blur 1 --iters 10
+rm -rf /tmp/pt; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pt -o p -- python3 tools/quick_bench.py --n 64 --blur 1 --iters 5 > /tmp/run.log 2>&1
+db=$(find /tmp/pt -name '*.db' | head -1); [ -n "$db" ] && python3 tools/prof_summary.py $db gpurun_out/s17/trace.txt > /dev/null; head -14 gpurun_out/s17/trace.txt
