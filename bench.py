@@ -44,7 +44,7 @@ CONFIGS = {
                  name="SBS frames/sec, 1080p warp+polylines_soft (BASELINE cfg 2)", kernel="k_polypoint",
                  what="BASELINE.json configs[1]: 1080p, divergence 3.5, polylines_soft, left-right SBS, stepped depth, batch of 32 frames"),
     "cfg3": dict(h=2160, w=3840, frames=16, fill="hybrid_edge", mode="left-right", div=8.0, depth="stepped", bytes_px=80,
-                 name="SBS frames/sec, 4K hybrid_edge + depth blur (BASELINE cfg 3)", kernel="k_hybrid_splat_tile + k_hybrid_out4 + k_hybrid_gaps (the HIP-event bracket covers the three launches)",
+                 name="SBS frames/sec, 4K hybrid_edge + depth blur (BASELINE cfg 3)", kernel="k_hybrid_splat_tile<fused outputs> + k_hybrid_gaps (the HIP-event bracket covers both launches)",
                  what="BASELINE.json configs[2]: 4K, divergence 8.0, hybrid_edge fill + edge-aware depth blur, batch of 16 frames"),
     "cfg4": dict(h=1080, w=1920, frames=256, fill="gpu_warp", mode="left-right", div=4.5, depth="radial", bytes_px=76,
                  name="SBS frames/sec, 256x1080p gpu_warp (BASELINE cfg 4)", kernel="k_gpuwarp",

@@ -1249,6 +1249,9 @@ __global__ void __launch_bounds__(1024) k_hybrid_splat(RowArgs A) {
     }
 }
 
+struct Px3f { float x, y, z; };
+struct Px3b { uint8_t x, y, z; };
+
 // The same splat for an output TILE of one eye row (node path, float32 image): only the sources within S + 2 columns of
 // the tile can touch it, so a 256-thread workgroup stages them three per lane and runs the counting sort, the in-bin
 // ranking and the 3-way merge on ~770 sources out of 14 KB of LDS (8 workgroups per CU) instead of on a whole row out of
@@ -1256,7 +1259,13 @@ __global__ void __launch_bounds__(1024) k_hybrid_splat(RowArgs A) {
 #define HYT_NT 256
 #define HYT_SLOTS 3
 #define HYT_NPT (HYT_NT * HYT_SLOTS)
-__global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, int T) {
+// FUSED (two-eye layouts of the node path): the tile's pixels go straight to the node outputs -- stereoscope value, no-fill
+// mask, this eye's depth-map codes -- and the untouched pixels to the gap list of their row, i.e. everything k_hybrid_out4
+// does in a pass of its own (2.1 ms per 16 4K frames at 4 TB/s) happens under the float64 arithmetic of this kernel, which
+// leaves the memory pipes idle.  The 3 + 1 byte splat result is still written: k_hybrid_gaps reads the neighbours from it.
+template <bool FUSED>
+__global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, int T, uint32_t* __restrict__ gap_count,
+                                                              uint16_t* __restrict__ gap_list) {
     __shared__ unsigned long long etab[256];
     __shared__ uint32_t img[HYT_NPT];          // colour codes r | g << 8 | b << 16 of source s0 + j
     __shared__ float destx[HYT_NPT];
@@ -1265,6 +1274,8 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
     __shared__ uint16_t scratch[HYT_NPT];
     __shared__ uint16_t sorted[HYT_NPT];
     __shared__ int scan_ws[32];
+    __shared__ uint8_t dcode[FUSED ? HYT_NPT : 4];   // depth-map code of source s0 + j (the tile's own columns are among them)
+    __shared__ float lut255[FUSED ? 256 : 1];        // k / 255
     const int tid = threadIdx.x;
     const int xi = blockIdx.x;
     const int row = blockIdx.y * 8 + (xi & 7);
@@ -1273,8 +1284,34 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
     const int frame = blockIdx.z / A.neyes, eyei = blockIdx.z - frame * A.neyes;
     const int w = A.w, h = A.h;
     const EyeArgs& E = A.eye[eyei];
-    if (!E.enabled) return;  // eye = source image; the fill pass never reads this slot
     const int o0 = tile * T, wt = min(T, w - o0);
+    const size_t out0 = FUSED ? ((size_t)frame * A.out_h + row + E.yoff) * A.out_w + E.xoff : 0;   // output pixel of column 0
+    // this eye's depth-map output: (depth * 255).astype(uint8) wraps mod 256 (quirk Q7), code / 255 on three channels
+    if (FUSED) lut255[tid] = csm::code_over_255((float)tid);   // (HYT_NT == 256; read after the kernel's barriers)
+    auto depth_code_out = [&](int jcol, uint8_t code) {
+        float* dd = eyei == 0 ? A.depth_l : A.depth_r;
+        const size_t pix = ((size_t)frame * h + row) * w + jcol;
+        const float v = lut255[code];
+        *reinterpret_cast<Px3f*>(dd + pix * 3) = Px3f{v, v, v};
+    };
+    auto colour_out = [&](int jcol, uint32_t r, uint32_t g, uint32_t b) {
+        const size_t o = out0 + jcol;
+        if (A.stereo_is_u8) *reinterpret_cast<Px3b*>(reinterpret_cast<uint8_t*>(A.stereo) + o * 3) = Px3b{(uint8_t)r, (uint8_t)g, (uint8_t)b};
+        else *reinterpret_cast<Px3f*>(A.stereo + o * 3) = Px3f{lut255[r], lut255[g], lut255[b]};
+        A.mask[o] = (r + g + b) == 0u ? 1.0f : 0.0f;   // GenerateStereo.py:355-361
+    };
+    if (!E.enabled) {
+        if (FUSED) __syncthreads();   // the table  // eye = source image (quirk Q10); the fill pass never reads this slot
+        if (FUSED) {
+            const float scale0 = (A.scale_from_stats && A.stats[(size_t)frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
+            for (int q = tid; q < wt; q += HYT_NT) {
+                const int jcol = o0 + q;
+                colour_out(jcol, src_u8(A, frame, row, jcol, 0), src_u8(A, frame, row, jcol, 1), src_u8(A, frame, row, jcol, 2));
+                depth_code_out(jcol, csm::f32_to_u8_wrap((E.depth[((size_t)frame * h + row) * w + jcol] * scale0) * 255.0f));
+            }
+        }
+        return;
+    }
     const int s0 = max(0, o0 - S - 2), s1 = min(w, o0 + wt + S + 2), ns = s1 - s0;
     const int nbin = wt + 2;   // j_c = o0 - 1 .. o0 + wt
     etab[tid] = d_hyb_exp_tab[tid];
@@ -1298,6 +1335,7 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
         const uint32_t b = (uint32_t)(int)fminf(fmaxf(px[2] * 255.0f, 0.0f), 255.0f);
         img[j] = r | g << 8 | b << 16;
         const float d = drow[x] * scale;
+        if (FUSED) dcode[j] = csm::f32_to_u8_wrap(d * 255.0f);   // (no global load in the output loop: its latency is exposed there)
         // (d - dmin) / range through the refined reciprocal of the frame's range (cs_common.h div_with: the IEEE quotient for
         // numerators that are 0 or >= 2^-60 and a range within 2^+-40; anything else takes the full division, wave-uniformly)
         const float a = d - dmin;
@@ -1392,8 +1430,28 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
             v2 = v2 < 0.0f ? 0.0f : (v2 > 255.0f ? 255.0f : v2);
             v[0] = (uint8_t)(int)v0; v[1] = (uint8_t)(int)v1; v[2] = (uint8_t)(int)v2;
         }
-        base[3 * jcol + 0] = v[0]; base[3 * jcol + 1] = v[1]; base[3 * jcol + 2] = v[2];
-        maskrow[jcol] = touched ? 1 : 0;
+        if (!FUSED) {
+            base[3 * jcol + 0] = v[0]; base[3 * jcol + 1] = v[1]; base[3 * jcol + 2] = v[2];
+            maskrow[jcol] = touched ? 1 : 0;
+        } else {
+            // (the splat result for k_hybrid_gaps<true>: one dword r | g << 8 | b << 16 | touched << 24 per pixel in the same scratch)
+            reinterpret_cast<uint32_t*>(A.hyb_base)[(((size_t)frame * A.neyes + eyei) * h + row) * w + jcol] =
+                (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | (touched ? 1u << 24 : 0u);
+            colour_out(jcol, v[0], v[1], v[2]);
+            depth_code_out(jcol, dcode[jcol - s0]);
+            // untouched pixels -> the row's list: one atomic per wave on the row's own counter (the active lanes of this
+            // iteration; readfirstlane reads the first ACTIVE lane, which is the one that holds the reservation)
+            const unsigned long long gb = __ballot(!touched);
+            if (gb) {
+                const size_t rid = ((size_t)frame * A.neyes + eyei) * h + row;
+                const unsigned long long act = __ballot(true);
+                unsigned slot = 0;
+                if ((tid & 63) == __ffsll((long long)act) - 1) slot = atomicAdd(&gap_count[rid], (unsigned)__popcll(gb));
+                slot = (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
+                const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(gb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)gb, 0u));
+                if (!touched) gap_list[rid * (size_t)w + slot + below] = (uint16_t)jcol;
+            }
+        }
     }
 }
 
@@ -1451,8 +1509,6 @@ __device__ void technique_hybrid_fill(const Lds& L, const RowArgs& A, int frame,
 // hybrid_edge, second pass as a plain elementwise kernel (the row kernel's LDS staging, scans and barriers buy nothing
 // here: edge_aware_gap_fill only reads the splat result around the pixel).  One lane per source column of one row: both
 // eyes of the pixel, the layout / anaglyph composition of RowOut, the no-fill mask and both depth-map outputs.
-struct Px3f { float x, y, z; };
-struct Px3b { uint8_t x, y, z; };
 
 // edge_aware_gap_fill (reference :1745-1774) only does arithmetic for untouched pixels with touched neighbours -- a few
 // percent of the pixels, but spread over most waves (1-10 lanes each), and every (pixel, neighbour) pair costs a float64
@@ -1685,6 +1741,8 @@ __global__ void __launch_bounds__(256) k_hybrid_out4(RowArgs A, uint32_t* __rest
     }
 }
 
+// PACKED: the splat result as k_hybrid_splat_tile<true> writes it (one dword per pixel: r | g << 8 | b << 16 | touched << 24)
+template <bool PACKED>
 __global__ void __launch_bounds__(64) k_hybrid_gaps(RowArgs A, const uint32_t* __restrict__ gap_count, const uint16_t* __restrict__ gap_list) {
     const int row = blockIdx.x, e = blockIdx.y, frame = blockIdx.z;
     const int w = A.w, h = A.h;
@@ -1704,17 +1762,24 @@ __global__ void __launch_bounds__(64) k_hybrid_gaps(RowArgs A, const uint32_t* _
             if (k == 4) continue;
             const int ni = row + k / 3 - 1, nj = j + k % 3 - 1;
             if (ni < 0 || ni >= h || nj < 0 || nj >= w) continue;
-            if (mask[(size_t)ni * w + nj] == 0) continue;
+            uint32_t pk = 0;
+            if (PACKED) {
+                pk = reinterpret_cast<const uint32_t*>(A.hyb_base)[(((size_t)frame * A.neyes + e) * h + ni) * (size_t)w + nj];
+                if ((pk >> 24) == 0u) continue;
+            } else if (mask[(size_t)ni * w + nj] == 0) continue;
             if (!have) { gc = hyb_guidance(A, frame, row, j); have = true; }
             // math.exp(-dsq / 2) for dsq = 1, 2: the two values of glibc's exp (see k_hybrid_fill)
             const double w_s = (k & 1) ? CS_EXP_M05 : CS_EXP_M10;
             const double diff = gc - hyb_guidance(A, frame, ni, nj);
             const double wg = w_s * csm::exp_exact(-(diff * diff) / 200.0, d_hyb_exp_tab);
             const float wg32 = (float)wg;
-            const uint8_t* nb = base + ((size_t)ni * w + nj) * 3;
-            n0 = n0 + (float)nb[0] * wg32;
-            n1 = n1 + (float)nb[1] * wg32;
-            n2 = n2 + (float)nb[2] * wg32;
+            if (!PACKED) {
+                const uint8_t* nb = base + ((size_t)ni * w + nj) * 3;
+                pk = (uint32_t)nb[0] | ((uint32_t)nb[1] << 8) | ((uint32_t)nb[2] << 16);
+            }
+            n0 = n0 + (float)(pk & 0xffu) * wg32;
+            n1 = n1 + (float)((pk >> 8) & 0xffu) * wg32;
+            n2 = n2 + (float)((pk >> 16) & 0xffu) * wg32;
             wt += wg;
         }
         if (!(wt > 0.0)) continue;   // no touched neighbour: the pixel stays as k_hybrid_out4 wrote it ("imperfect" mask)
@@ -2163,7 +2228,21 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int pl
     if (halo >= 0 && A.image_f32 && tmax >= 128 && !dev_switch(CS_DEBUG_NO_TILE) && (size_t)A.n * A.neyes <= 65535) {
         const int tiles = (A.w + tmax - 1) / tmax;
         const int T = ((A.w + tiles - 1) / tiles + 3) & ~3;
-        hipLaunchKernelGGL(k_hybrid_splat_tile, dim3(((A.w + T - 1) / T) * 8, (A.h + 7) / 8, A.n * A.neyes), dim3(HYT_NT), 0, stream, A, halo, T);
+        // two-eye layouts: the splat writes the node outputs itself, only the gap pixels are left (CS_DEBUG_HYBRID_UNFUSED: the
+        // separate streaming pass k_hybrid_out4)
+        const bool fused = !plus && !A.anaglyph && !A.out_u8 && A.single < 0 && A.neyes == 2 && A.depth_l && A.depth_r && A.mask &&
+                           A.w <= 65535 && !dev_switch(CS_DEBUG_HYBRID_UNFUSED);
+        const dim3 grid(((A.w + T - 1) / T) * 8, (A.h + 7) / 8, A.n * A.neyes);
+        if (fused) {
+            uint32_t* cnt = (uint32_t*)((char*)workspace + hybrid_splat_bytes(A.n, A.h, A.w));
+            uint16_t* lst = (uint16_t*)((char*)cnt + hybrid_count_bytes(A.n, A.h));
+            e = hipMemsetAsync(cnt, 0, (size_t)A.n * A.neyes * A.h * 4, stream);
+            if (e != hipSuccess) return CS_EHIP;
+            hipLaunchKernelGGL(k_hybrid_splat_tile<true>, grid, dim3(HYT_NT), 0, stream, A, halo, T, cnt, lst);
+            hipLaunchKernelGGL(k_hybrid_gaps<true>, dim3(A.h, A.neyes, A.n), dim3(64), 0, stream, A, (const uint32_t*)cnt, (const uint16_t*)lst);
+            return hipGetLastError() == hipSuccess ? CS_OK : CS_EHIP;
+        }
+        hipLaunchKernelGGL(k_hybrid_splat_tile<false>, grid, dim3(HYT_NT), 0, stream, A, halo, T, (uint32_t*)nullptr, (uint16_t*)nullptr);
     } else
         hipLaunchKernelGGL(k_hybrid_splat, dim3(A.h, A.n, A.neyes), dim3(threads), lds, stream, A);
     if (plus) e = launch_rowwarp(CS_FILL_HYBRID_EDGE_PLUS, A, threads, stream);
@@ -2174,7 +2253,7 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int pl
         e = hipMemsetAsync(cnt, 0, (size_t)A.n * A.neyes * A.h * 4, stream);
         if (e != hipSuccess) return CS_EHIP;
         hipLaunchKernelGGL(k_hybrid_out4, dim3((A.w + 1023) / 1024, A.h, A.n), dim3(256), 0, stream, A, cnt, lst);
-        hipLaunchKernelGGL(k_hybrid_gaps, dim3(A.h, A.neyes, A.n), dim3(64), 0, stream, A, (const uint32_t*)cnt, (const uint16_t*)lst);
+        hipLaunchKernelGGL(k_hybrid_gaps<false>, dim3(A.h, A.neyes, A.n), dim3(64), 0, stream, A, (const uint32_t*)cnt, (const uint16_t*)lst);
         e = hipGetLastError();
     } else {
         hipLaunchKernelGGL(k_hybrid_fill, dim3((A.w + 255) / 256, A.h, A.n), dim3(256), 0, stream, A);

@@ -241,7 +241,8 @@ enum cs_debug_key {
     CS_DEBUG_CHUNKS = 6,            /* cs_generate: k > 1 = k frame chunks, pre-passes on an auxiliary stream (+100: at default priority); default one chunk */
     CS_DEBUG_NO_REPLAY_KERNEL = 7,  /* polylines: order-dependent stretches replayed inside the row kernel (round-2 schedule) */
     CS_DEBUG_BLUR_NO_PRE_EDGES = 8, /* depth blur: k_gray + k_blur_edges4 instead of the one-pass k_gray_edges */
-    CS_DEBUG_KEYS = 9
+    CS_DEBUG_HYBRID_UNFUSED = 9,    /* hybrid_edge: splat result -> node outputs in a streaming pass of its own (k_hybrid_out4) */
+    CS_DEBUG_KEYS = 10
 };
 CS_API int cs_debug_set(int key, int value);
 

@@ -14,7 +14,7 @@ from oracle import node_oracle
 
 pytestmark = pytest.mark.gpu
 
-UI = {"none": "No fill", "polylines_soft": "Fill - Polylines Soft", "hybrid_edge": "Fill - Hybrid Edge",
+UI = {"none": "No fill", "polylines_soft": "Fill - Polylines Soft", "hybrid_edge": "Imperfect fill - Hybrid Edge",
       "gpu_warp": "GPU Warp (Fast)"}
 
 
