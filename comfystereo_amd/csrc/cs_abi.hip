@@ -333,10 +333,13 @@ static int poly_halo(double div_percent_a, double div_percent_b, double sep_perc
 }
 
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
-// techniques with a D64 (numba typing) instantiation: the forward-map family and the z-buffered inverse map
+// techniques with a D64 (numba typing) instantiation: the forward-map family, the z-buffered inverse map and -- through the
+// general row kernel only, the sweep of full D64 as a literal one-lane replay -- the polylines techniques
 static bool dialect_d64_ok(int fill) {
-    return fill == CS_FILL_NONE || fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING || fill == CS_FILL_INVERSE;
+    return fill == CS_FILL_NONE || fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING || fill == CS_FILL_INVERSE ||
+           fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP;
 }
+static const char* const DIALECT_MSG = "dialect D64 (flags bits 3/4) exists for none / naive / naive_interpolating / inverse / polylines_soft / polylines_sharp";
 // flags of the rows the tiled polylines path hands to the row kernel + their compacted list (run_rows)
 // flagged-row block: [row flags, one byte per row][count / cursor pairs, 256 B][stretch-replay counters, 256 B][replay retry
 // flags, one byte per row] -- everything one memset clears -- then [row list, 4 B per row]
@@ -353,13 +356,13 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
     const bool poly = fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP;
     // polylines, eyes in separate output slots: the stretches of order-dependent rows are replayed by a kernel of their own
     // (cs_rowwarp.hip k_poly_replay) instead of inside the row kernel
-    const bool replay = poly && replay_scratch && rowflag && !A.anaglyph && !dev_switch(CS_DEBUG_NO_REPLAY_KERNEL) &&
+    const bool replay = poly && !A.d64 && replay_scratch && rowflag && !A.anaglyph && !dev_switch(CS_DEBUG_NO_REPLAY_KERNEL) &&
                         poly_replay_bytes(A.n, A.h, A.w, fill == CS_FILL_POLYLINES_SHARP) > 0;
     bool cleared = false;   // the flagged-row block (row flags, counters, replay counters and retry flags) has been zeroed
     if (replay)
         (void)poly_replay_attach(A, fill == CS_FILL_POLYLINES_SHARP, replay_scratch, rowflag + al256((size_t)A.n * A.h) + 256, stream);
-    if (poly && (!A.anaglyph || (ana_sbs && A.image_f32 && !A.out_u8)) && halo <= polytile_max_halo() && rowflag &&
-        !dev_switch(CS_DEBUG_NO_TILE)) {
+    if (poly && !A.d64 && (!A.anaglyph || (ana_sbs && A.image_f32 && !A.out_u8)) && halo <= polytile_max_halo() && rowflag &&
+        !dev_switch(CS_DEBUG_NO_TILE)) {   // (the tile kernels are dialect D32)
         // workspace: [n*h flag bytes][count, padded to 256][n*h list entries]
         const size_t rows = (size_t)A.n * A.h;
         uint32_t* count = (uint32_t*)(rowflag + al256(rows));
@@ -483,6 +486,11 @@ static int max_width_for(int fill, int anaglyph) {
         else hi = mid - 1;
     }
     return lo;
+}
+// polylines under the float64 disparity chain keep 8 more bytes per column in LDS (cs_rowwarp.hip Poly::xd)
+static bool dialect_width_ok(int fill, int w, int anaglyph, int d64) {
+    if (!(d64 & 1) || (fill != CS_FILL_POLYLINES_SOFT && fill != CS_FILL_POLYLINES_SHARP)) return true;
+    return rowwarp_lds_bytes(fill, w, anaglyph) + 8 * (size_t)w + 16 <= CS_LDS_BYTES;
 }
 int cs_max_width(int fill) { return max_width_for(fill, 1); }
 int cs_max_width_mode(int fill, int mode) {
@@ -729,11 +737,13 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     int out_h, out_w, mask_h, mask_w;
     int rc = cs_output_shape(p, &out_h, &out_w, &mask_h, &mask_w);
     if (rc) return rc;
-    if (p->w > cs_max_width_mode(p->fill, p->mode)) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
+    if (p->w > cs_max_width_mode(p->fill, p->mode) ||
+        !dialect_width_ok(p->fill, p->w, p->mode == CS_MODE_RED_CYAN_ANAGLYPH || p->mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH, (p->flags >> 3) & 3))
+        return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
     if (workspace_bytes < ws_total(p)) return fail(CS_EWORKSPACE, "workspace too small");
     if (p->fill == CS_FILL_GPU_WARP && (p->flags & 2)) return fail(CS_EINVAL, "gpu_warp colours are not k/255: no uint8 stereoscope output");
     if ((p->flags & 24) && !dialect_d64_ok(p->fill))
-        return fail(CS_EINVAL, "dialect D64 (flags bits 3/4) exists for none / naive / naive_interpolating / inverse only");
+        return fail(CS_EINVAL, DIALECT_MSG);
     char* const ws = (char*)workspace;
     uint32_t* const stats = (uint32_t*)ws;
     char* const scratch = ws + al256((size_t)p->n * ST_WORDS * 4);
@@ -795,12 +805,12 @@ int cs_apply_stereo_divergence2(const uint8_t* image_u8, const float* depth, int
                                 uint8_t* out_u8, void* workspace, size_t workspace_bytes, void* stream_) {
     if (dialect < 0 || dialect > 3) return fail(CS_EINVAL, "dialect: 0 (D32), 1 (float64 disparities), 2 (int64 sums), 3 (D64)");
     if (dialect && !dialect_d64_ok(fill))
-        return fail(CS_EINVAL, "dialect D64 exists for none / naive / naive_interpolating / inverse only");
+        return fail(CS_EINVAL, DIALECT_MSG);
     hipStream_t stream = (hipStream_t)stream_;
     if (!image_u8 || !depth || !out_u8 || !workspace) return fail(CS_EINVAL, "null pointer");
     if (n <= 0 || h <= 0 || w <= 0) return fail(CS_EINVAL, "non-positive size");
     if (fill < 0 || fill > CS_FILL_HYBRID_EDGE_PLUS || fill == CS_FILL_GPU_WARP) return fail(CS_EINVAL, "unknown fill technique");
-    if (w > max_width_for(fill, 0)) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
+    if (w > max_width_for(fill, 0) || !dialect_width_ok(fill, w, 0, dialect)) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
     if (workspace_bytes < cs_asd_workspace_bytes(n, h, w)) return fail(CS_EWORKSPACE, "workspace too small");
     uint32_t* stats = (uint32_t*)workspace;
     hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);

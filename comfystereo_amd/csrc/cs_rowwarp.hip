@@ -368,6 +368,9 @@ struct Poly {
     uint16_t* entries;  // [cap] segment ids (also: in-bin scratch during sorting, csg during the fallback)
     uint16_t* longs;    // [1024] long segments
     const float* cd;    // [w] coord_d
+    // dialect bit 0 (float64 disparity chain, cs_params.flags bit 3): col + 0.5 + coord_d + separation_px as the float64 value
+    // the reference holds before it is stored into the float32 `pt` array; cd then holds (float)coord_d.  null: D32
+    const double* xd;   // [w]
 };
 
 // x of polyline point o in reference order (:1921-1935): sentinels at -w and 2w, else
@@ -377,6 +380,10 @@ __device__ __forceinline__ float poly_x(const Poly& P, int o) {
     if (o >= P.npt - 1) return (float)(2.0 * P.w);
     const float half32 = (float)0.45;
     int c = P.sharp ? (o - 1) >> 1 : o - 1;
+    if (P.xd) {   // one rounding, from float64 (the half width is the Python float 0.45 there)
+        const double b = P.xd[c];
+        return P.sharp ? (float)(((o - 1) & 1) ? b + 0.45 : b - 0.45) : (float)b;
+    }
     float x = ((float)c + 0.5f + P.cd[c]) + P.sep32;
     if (P.sharp) x = ((o - 1) & 1) ? x + half32 : x - half32;
     return x;
@@ -483,6 +490,67 @@ __device__ int poly_sequential(const Poly& P, const Lds& L, int csg_cap_ref, con
             // csg_end == 0 cannot happen (the polyline is connected from -w to 2w); slot 0 then
             // still holds a valid (stale) id because the list is never empty after its first fill.
             poly_accumulate(P, L.img, csg[best], s.center, s.sig64, s.sig_d, s.sig_f, color);
+            pt_i++;
+        }
+        emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
+    }
+    return 0;
+}
+
+// The sweep with numba's typing (dialect bit 1; derived, oracle/stereo_oracle.c oracle_polylines holds the
+// same statements): the ends of a sub-interval, its significance and its centre are float64 -- max(col, x) + EPSILON with
+// the epsilon always alive --, float32 array elements meet them in float64 compares, ip_k is a float64 numerator over the
+// float32 difference x1 - x0, closeness and the colour products are float64, and every sub-interval rounds once into the
+// float32 `color`.  One lane replays a row literally; the dialect is a compatibility path, not a fast one.
+template <class Emit>
+__device__ int poly_sequential64(const Poly& P, const Lds& L, int csg_cap_ref, const Emit& emit) {
+    const int w = P.w, sg_end = P.npt - 1;
+    uint16_t* csg = P.entries;
+    const int cap = min(csg_cap_ref, P.cap);
+    int csg_end = 0, sg_pointer = 0, pt_i = 0;
+    for (int col = 0; col < w; col++) {
+        float color[3] = {0.5f, 0.5f, 0.5f};
+        while (poly_x(P, P.perm[pt_i]) < (float)col) pt_i++;
+        pt_i--;
+        while (poly_x(P, P.perm[pt_i]) < (float)(col + 1)) {
+            const double from_d = fmax((double)col, (double)poly_x(P, P.perm[pt_i])) + 1e-7;
+            const double to_d = fmin((double)(col + 1), (double)poly_x(P, P.perm[pt_i + 1])) - 1e-7;
+            const double sig = to_d - from_d;
+            const double center = from_d + 0.5 * sig;
+            while (sg_pointer < sg_end && (double)poly_x(P, P.perm[sg_pointer]) < center) {
+                if (csg_end >= cap) return -1;
+                csg[csg_end++] = P.perm[sg_pointer++];
+            }
+            int ci = 0;
+            while (ci < csg_end) {
+                if ((double)poly_x(P, csg[ci] + 1) < center) { csg[ci] = csg[csg_end - 1]; csg_end--; }
+                else ci++;
+            }
+            int best = 0;
+            if (csg_end != 1) {
+                double bc = -1e-7;
+                for (ci = 0; ci < csg_end; ci++) {
+                    const int o = csg[ci];
+                    const float x0 = poly_x(P, o), x1 = poly_x(P, o + 1);
+                    const double ip_k = (center - (double)x0) / (double)(x1 - x0);
+                    const double cl = (1.0 - ip_k) * (double)poly_z(P, o) + ip_k * (double)poly_z(P, o + 1);
+                    if (bc < cl && 0.0 < ip_k && ip_k < 1.0) { bc = cl; best = ci; }
+                }
+            }
+            const int seg = csg[best];
+            const int col_l = poly_col(P, seg), col_r = poly_col(P, seg + 1);
+            if (col_l == col_r) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) color[c] = (float)((double)color[c] + (double)L.img[3 * col_l + c] * sig);
+            } else {
+                const float x0 = poly_x(P, seg), x1 = poly_x(P, seg + 1);
+                const double ip_k = (center - (double)x0) / (double)(x1 - x0);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const double v = ((double)L.img[3 * col_l + c] * (1.0 - ip_k) + (double)L.img[3 * col_r + c] * ip_k) * sig;
+                    color[c] = (float)((double)color[c] + v);
+                }
+            }
             pt_i++;
         }
         emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
@@ -813,7 +881,7 @@ __host__ __device__ inline size_t rp_slot_bytes(int w, int sharp) { return rp_pe
 
 template <int SHARP, class Emit>
 __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float e32, uint32_t* stats_rw,
-                                    const Emit& emit, int dbg, const RpCtx* X = nullptr) {
+                                    const Emit& emit, int dbg, const RpCtx* X = nullptr, int d64 = 0, double e64 = 0.0) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
     Poly P;
     P.w = w; P.sharp = SHARP; P.npt = poly_npt(w, SHARP); P.cap = poly_cap(w, SHARP);
@@ -823,15 +891,25 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
     P.binoff = (uint16_t*)t; t += align16(2 * ((size_t)w + 4));
     P.segoff = (uint16_t*)t; t += align16(2 * ((size_t)w + 2));
     P.entries = (uint16_t*)t; t += align16(2 * (size_t)P.cap);
-    P.longs = (uint16_t*)t;
+    P.longs = (uint16_t*)t; t += align16(2 * 1024);
     P.cd = L.nd;
+    double* xd = (d64 & 1) ? (double*)t : nullptr;   // (launch_rowwarp adds the 8 w bytes for the dialect)
+    P.xd = xd;
     const int npt = P.npt, nbin = w + 2, LONGCAP = 1024;
     int* flag_hazard = L.misc + 0;
     int* nlong = L.misc + 1;
     int* ntotal = L.misc + 2;
     int* scan_ws = L.misc + 8;
     // P1: coord_d (in place over nd), point x's, histogram of bins (count of bin b at binoff[b+1])
-    for (int c = tid; c < w; c += nt) L.nd[c] = disparity(L.nd[c], e32, E.div32, L.tabs);
+    if (xd) {
+        for (int c = tid; c < w; c += nt) {
+            const double cd = disparity64(L.nd[c], e64, E.div64);
+            xd[c] = (((double)c + 0.5) + cd) + E.sep64;
+            L.nd[c] = (float)cd;   // (only |coord_d| as float32 is read from here on: the z of the point)
+        }
+    } else {
+        for (int c = tid; c < w; c += nt) L.nd[c] = disparity(L.nd[c], e32, E.div32, L.tabs);
+    }
     for (int i = tid; i < (w + 4) / 2; i += nt) ((unsigned*)P.binoff)[i] = 0;
     for (int i = tid; i < (w + 2) / 2; i += nt) ((unsigned*)P.segoff)[i] = 0;
     if (tid == 0) { *flag_hazard = 0; *nlong = 0; *ntotal = 0; }
@@ -906,6 +984,63 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         }
         __syncthreads();
         if (dbg == 4) return;
+        if (d64 & 2) {
+            // P3c with numba's typing of the sweep (poly_sequential64 has the statements): one lane per output pixel; a pixel
+            // whose choice depends on the order of the active list (several active segments, none or two equally close)
+            // sends the row to the literal one-lane replay below
+            for (int col = tid; col < w; col += nt) {
+                float color[3] = {0.5f, 0.5f, 0.5f};
+                const int pos0 = P.binoff[col], pos1 = P.binoff[col + 1];
+                const int ls = col > 0 ? P.segoff[col - 1] : 0, le = P.segoff[col];
+                bool hazard = false;
+                double prev = (double)col;
+                float a = poly_x(P, P.perm[pos0 - 1]);
+                for (int k = pos0 - 1; k < pos1; k++) {
+                    const float b = poly_x(P, P.perm[k + 1]);
+                    const double from_d = fmax((double)col, (double)a) + 1e-7, to_d = fmin((double)(col + 1), (double)b) - 1e-7;
+                    const double sig = to_d - from_d, center = from_d + 0.5 * sig;
+                    a = b;
+                    if (center < prev || center > (double)(col + 1)) hazard = true;
+                    prev = center;
+                    int nact = 0, nqual = 0, best = -1, single = -1;
+                    double bc = -1e-7;
+                    bool tie = false;
+                    for (int e = ls; e < le; e++) {
+                        const int o = P.entries[e];
+                        const float x0 = poly_x(P, o), x1 = poly_x(P, o + 1);
+                        if (!((double)x0 < center) || (double)x1 < center) continue;
+                        nact++;
+                        single = o;
+                        const double ip_k = (center - (double)x0) / (double)(x1 - x0);
+                        if (0.0 < ip_k && ip_k < 1.0) {
+                            const double cl = (1.0 - ip_k) * (double)poly_z(P, o) + ip_k * (double)poly_z(P, o + 1);
+                            nqual++;
+                            if (bc < cl) { bc = cl; best = o; tie = false; }
+                            else if (cl == bc) tie = true;
+                        }
+                    }
+                    int seg;
+                    if (nact == 1) seg = single;
+                    else { if (nqual == 0 || tie) hazard = true; seg = nqual ? best : single; }
+                    if (seg < 0) { hazard = true; continue; }
+                    const int col_l = poly_col(P, seg), col_r = poly_col(P, seg + 1);
+                    if (col_l == col_r) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++) color[c] = (float)((double)color[c] + (double)L.img[3 * col_l + c] * sig);
+                    } else {
+                        const float x0 = poly_x(P, seg), x1 = poly_x(P, seg + 1);
+                        const double ip_k = (center - (double)x0) / (double)(x1 - x0);
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const double v = ((double)L.img[3 * col_l + c] * (1.0 - ip_k) + (double)L.img[3 * col_r + c] * ip_k) * sig;
+                            color[c] = (float)((double)color[c] + v);
+                        }
+                    }
+                }
+                if (hazard) *flag_hazard = 1;
+                else emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
+            }
+        } else {
         // P3c: one lane per output pixel (reference :1951-1991).  Next to the pixel's colour: is it ORDER-DEPENDENT (hazard), and
         // does the active list hold exactly one segment after its last sub-interval (reset, see poly_replay_stretch) -- as bit
         // rows over the (idle) long-segment array
@@ -959,8 +1094,20 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
             const unsigned long long hm = __ballot(hazard), rm = __ballot(reset);
             if (lane == 0 && colb + 64 * wave < w && w <= 8192) { hzw[(colb >> 6) + wave] = hm; rsw[(colb >> 6) + wave] = rm; }
         }
+        }
     }
     __syncthreads();
+    if (d64 & 2) {
+        if ((overflow || *flag_hazard) && tid == 0) {   // order-dependent row: the literal replay (it rewrites every pixel)
+            const int rc = poly_sequential64(P, L, E.csg_cap, emit);
+            if (stats_rw) {
+                atomicAdd(&stats_rw[ST_FALLBACK_ROWS], 1u);
+                if (rc) atomicOr(&stats_rw[ST_ERROR], 1u);
+            }
+        }
+        __syncthreads();
+        return;
+    }
     // ---- order-dependent pixels: replay the stretches between reset points, one wave per stretch (poly_replay_stretch)
     constexpr int NSTR = 256;           // stretches per row
     int* nstretch = L.misc + 3;
@@ -1934,7 +2081,7 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
                 // (eyes in separate output slots: the stretches of order-dependent rows may go to the replay kernel)
                 const RpCtx X{A.anaglyph ? nullptr : A.rp_dump, A.rp_list, A.rp_ctr, A.rp_slots, A.rp_cap, A.rp_slot_bytes,
                               (uint32_t)frame * (uint32_t)A.h + (uint32_t)row, e};
-                technique_polylines<FILL == CS_FILL_POLYLINES_SHARP ? 1 : 0>(L, w, E, A.e32, st_rw, out, A.dbg, &X);
+                technique_polylines<FILL == CS_FILL_POLYLINES_SHARP ? 1 : 0>(L, w, E, A.e32, st_rw, out, A.dbg, &X, A.d64, A.e64);
             }
             else if (FILL == CS_FILL_HYBRID_EDGE_PLUS) {
                 // hybrid_edge into `res`, then the polylines_soft row into `alt`; pixels that stayed black take the latter
@@ -2108,7 +2255,7 @@ __global__ void __launch_bounds__(64) k_poly_replay(RowArgs A, uint8_t* __restri
         P.w = w; P.sharp = SHARP; P.npt = poly_npt(w, SHARP); P.cap = poly_cap(w, SHARP);
         P.sep32 = eye ? A.eye[1].sep32 : A.eye[0].sep32;
         P.perm = permw - pw0; P.binoff = nullptr; P.segoff = nullptr; P.entries = nullptr; P.longs = nullptr;
-        P.cd = cdw - cmin;
+        P.cd = cdw - cmin; P.xd = nullptr;   // (dialect D32 only: run_rows does not attach the replay kernel otherwise)
         Lds L;
         L.lut = nullptr; L.tabs = nullptr; L.misc = nullptr; L.res = nullptr; L.ana = nullptr; L.nd = nullptr; L.tech = nullptr;
         L.img = imgw - 3 * cmin;
@@ -2161,6 +2308,8 @@ hipError_t launch_collect_rows(const uint8_t* flag, int total, uint32_t* count, 
 // host-side launcher (called from cs_abi.hip)
 hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream, int max_groups) {
     size_t lds = lds_common_bytes(fill, A.w, A.anaglyph) + lds_tech_bytes(fill, A.w);
+    if ((A.d64 & 1) && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP)) lds += align16(8 * (size_t)A.w);   // Poly::xd
+    if (lds > CS_LDS_BYTES) return hipErrorInvalidValue;
     const long long rows = (long long)A.h * A.n;
     dim3 grid(A.h, A.n), block(threads);
     if (A.row_list) {

@@ -96,8 +96,13 @@ typedef struct cs_params {
                                    (float32 disparities, uint8 pixel sums that wrap) -- the pinned
                                    contract.  bit 3: float64 disparity chain, bit 4: int64 pixel
                                    sums; both = D64, the typing numba gives the reference's kernels
-                                   (derived).  none / naive /
-                                   naive_interpolating / inverse only, else CS_EINVAL              */
+                                   (derived).  polylines_soft / sharp: bit 3 =
+                                   point coordinates from the float64 chain, rounded once into the
+                                   float32 point array (pinned: tests/golden/dialect_f64.npz), bit 4 =
+                                   numba's float64 typing of the sweep (derived; a literal one-lane
+                                   replay per row in the general row kernel -- a compatibility path).
+                                   none / naive / naive_interpolating / inverse / polylines_* only,
+                                   else CS_EINVAL                                                  */
     double divergence, separation, stereo_balance, convergence_point, stereo_offset_exponent;
     double depth_blur_strength, depth_blur_edge_threshold, depth_blur_falloff;
 } cs_params;

@@ -64,6 +64,11 @@ static inline uint8_t f32_to_u8_wrap(float v) {
  * functions return when they are handed normalized_depth.astype(float64). */
 static int g_dialect = 0;
 EXPORT void oracle_set_dialect(int d) { g_dialect = d & 3; }
+/* polylines: bit 0 as everywhere (the point coordinates come out of the float64 chain and are rounded once when they are
+ * stored into the float32 `pt` array; pinned by dialect_f64.npz like the forward maps); bit 1 = numba's typing of the sweep
+ * (derived): sub-interval ends, significance and centre in float64 (the epsilon always survives),
+ * comparisons of float32 array elements with them in float64, ip_k = float64 numerator / float32 difference, closeness and
+ * the colour products in float64, one rounding into the float32 `color` per sub-interval. */
 static inline double disparity_f64(float d, double e, double div_px) {
     double sign = d >= 0.0f ? 1.0 : -1.0;
     return (sign * pow((double)fabsf(d), e)) * div_px;
@@ -210,6 +215,17 @@ EXPORT int oracle_polylines(const uint8_t *img, const float *nd, int h, int w, d
         pt[pt_end++] = (pt_t){(float)(-1.0 * w), 0.0f, 0.0f}; /* :1921 */
         for (int col = 0; col < w; col++) {
             float d = nd[(size_t)row * w + col];
+            if (g_dialect & 1) {   /* float64 chain, rounded once into the float32 array (Appendix A) */
+                double cd = disparity_f64(d, exponent, div_px);
+                double cx = (((double)col + 0.5) + cd) + sep_px;
+                if (!sharp) {
+                    pt[pt_end++] = (pt_t){(float)cx, (float)fabs(cd), (float)col};
+                } else {
+                    pt[pt_end++] = (pt_t){(float)(cx - 0.45), (float)fabs(cd), (float)col};
+                    pt[pt_end++] = (pt_t){(float)(cx + 0.45), (float)fabs(cd), (float)col};
+                }
+                continue;
+            }
             float coord_d = disparity_f32(d, e32, div32);                 /* :1926 */
             float coord_x = ((float)(col + 0.5) + coord_d) + sep32;      /* :1927 */
             if (!sharp) {
@@ -239,6 +255,47 @@ EXPORT int oracle_polylines(const uint8_t *img, const float *nd, int h, int w, d
             while (pt[pt_i].x < (float)col) pt_i++;
             pt_i--;
             while (pt[pt_i].x < (float)(col + 1)) {
+                if (g_dialect & 2) {   /* numba's typing of the sweep (derived) */
+                    double from_d = fmax((double)col, (double)pt[pt_i].x) + EPS;
+                    double to_d = fmin((double)(col + 1), (double)pt[pt_i + 1].x) - EPS;
+                    double sig = to_d - from_d;
+                    double center = from_d + 0.5 * sig;
+                    while (sg_pointer < sg_end && (double)sg[sg_pointer].x0 < center) {
+                        if (csg_end >= csg_cap) { rc = -1; break; }
+                        csg[csg_end++] = sg[sg_pointer++];
+                    }
+                    if (rc) break;
+                    int ci = 0;
+                    while (ci < csg_end) {
+                        if ((double)csg[ci].x1 < center) { csg[ci] = csg[csg_end - 1]; csg_end--; }
+                        else ci++;
+                    }
+                    int best = 0;
+                    if (csg_end != 1) {
+                        double best_closeness = -EPS;
+                        for (ci = 0; ci < csg_end; ci++) {
+                            double ip_k = (center - (double)csg[ci].x0) / (double)(csg[ci].x1 - csg[ci].x0);
+                            double closeness = (1.0 - ip_k) * (double)csg[ci].z0 + ip_k * (double)csg[ci].z1;
+                            if (best_closeness < closeness && 0.0 < ip_k && ip_k < 1.0) {
+                                best_closeness = closeness;
+                                best = ci;
+                            }
+                        }
+                    }
+                    int col_l = (int)((double)csg[best].c0 + EPS);
+                    int col_r = (int)((double)csg[best].c1 + EPS);
+                    if (col_l == col_r) {
+                        for (int c = 0; c < 3; c++) color[c] = (float)((double)color[c] + (double)irow[col_l * 3 + c] * sig);
+                    } else {
+                        double ip_k = (center - (double)csg[best].x0) / (double)(csg[best].x1 - csg[best].x0);
+                        for (int c = 0; c < 3; c++) {
+                            double v = ((double)irow[col_l * 3 + c] * (1.0 - ip_k) + (double)irow[col_r * 3 + c] * ip_k) * sig;
+                            color[c] = (float)((double)color[c] + v);
+                        }
+                    }
+                    pt_i++;
+                    continue;
+                }
                 /* coord_from = max(col, pt.x) + EPSILON ; coord_to = min(col+1, next.x) - EPSILON */
                 int from64, to64;
                 double from_d = 0, to_d = 0;

@@ -36,6 +36,33 @@ def test_f64_disparity_chain_matches_the_reference_inner_functions(gold):
             np.testing.assert_array_equal(_run(z, c, fill, "f64-disparity"), z[f"{c['id']}/{fill}"], err_msg=f"{c['id']}/{fill}")
 
 
+def test_f64_disparity_chain_polylines(gold):
+    """polylines_soft / sharp: the point coordinates leave the float64 chain and are rounded once when they are stored into
+    the reference's float32 `pt` array (:1924-1934); the sweep keeps the no-numba typing.  Pinned bit for bit."""
+    z, cases = gold
+    differs = 0
+    for c in cases:
+        for fill in ("polylines_soft", "polylines_sharp"):
+            got = _run(z, c, fill, "f64-disparity")
+            np.testing.assert_array_equal(got, z[f"{c['id']}/{fill}"], err_msg=f"{c['id']}/{fill}")
+            differs += int((got != _run(z, c, fill, "D32")).any(-1).sum())
+    assert differs > 0   # (the two chains do not give the same frames)
+
+
+def test_numba_sweep_typing_is_close_to_the_float32_sweep(gold):
+    """Full D64 for polylines (float64 sub-intervals, interpolation and products: derived from numba's typing rules, not
+    pinnable here): colours differ from the float64-chain / float32-sweep frames by one code on a minority of the pixels, and
+    by more on a handful (a sub-interval whose epsilon float32 absorbs picks another segment at an occlusion boundary) -- a
+    sanity bound on the derived arithmetic, not a parity claim."""
+    z, cases = gold
+    for c in cases:
+        for fill in ("polylines_soft", "polylines_sharp"):
+            a, b = _run(z, c, fill, "f64-disparity").astype(np.int32), _run(z, c, fill, "D64").astype(np.int32)
+            d = np.abs(a - b).max(-1)
+            assert (d > 1).mean() < 2e-3, (c["id"], fill)
+            assert (d > 0).mean() < 0.2, (c["id"], fill)
+
+
 def test_where_the_dialects_diverge(gold):
     """Report (and bound) the divergence: ordinary depth maps give identical frames -- a float32 disparity only truncates
     differently when it lies within an ulp of an integer -- the searched near-integer case differs in a fifth of its pixels."""

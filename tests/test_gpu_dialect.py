@@ -12,7 +12,9 @@ from oracle import node_oracle, oracle
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "dialect_f64.npz")
-FILLS = ("none", "naive", "naive_interpolating", "inverse")
+# polylines: through the general row kernel (the tile kernels are dialect D32); the float64 chain is pinned by the fixture, the
+# numba typing of the sweep (full D64) is derived -- checked against the oracle's statement of the same rules
+FILLS = ("none", "naive", "naive_interpolating", "inverse", "polylines_soft", "polylines_sharp")
 
 
 def _gpu(img, depth, c, fill, dialect):
@@ -50,7 +52,7 @@ def test_other_techniques_refuse_the_dialect():
     from comfystereo_amd import engine
     img = torch.zeros((1, 16, 32, 3), dtype=torch.uint8, device="cuda")
     dep = torch.rand((1, 16, 32), device="cuda")
-    for fill in ("polylines_soft", "polylines_sharp", "hybrid_edge"):
+    for fill in ("hybrid_edge", "hybrid_edge_plus", "none_post"):
         with pytest.raises(RuntimeError, match="D64"):
             engine.apply_stereo_divergence(img, dep, 3.0, 0.0, 1.0, fill, 0.5, dialect="D64")
 
@@ -65,7 +67,8 @@ def test_node_path_with_the_dialect_switch():
     oracle.set_dialect("D64")
     try:
         for ui, mode in (("Fill - Naive interpolating", "left-right"), ("No fill - Reverse projection", "red-cyan-anaglyph"),
-                         ("Fill - Naive", "top-bottom")):
+                         ("Fill - Naive", "top-bottom"), ("Fill - Polylines Soft", "left-right"),
+                         ("Fill - Polylines Sharp", "red-cyan-anaglyph"), ("Fill - Polylines Soft", "bottom-top")):
             fill = node_oracle.FILL_KEYS[ui]
             p = engine.make_params(n, h, w, h, w, 3, fill, mode, 7.0, 0.5, 0.0, 0.5, 1.3, False, 6.0, 6.0, 1.0, 0, 4)
             assert (p.flags >> 3) & 3 == 3
@@ -74,8 +77,39 @@ def test_node_path_with_the_dialect_switch():
             for g, wv in zip(got, want):
                 np.testing.assert_array_equal(g, wv)
         with pytest.raises(RuntimeError, match="D64"):
-            p = engine.make_params(n, h, w, h, w, 3, "polylines_soft", "left-right", 7.0, 0.5, 0.0, 0.5, 1.3, False, 6.0, 6.0, 1.0, 0, 4)
+            p = engine.make_params(n, h, w, h, w, 3, "hybrid_edge", "left-right", 7.0, 0.5, 0.0, 0.5, 1.3, False, 6.0, 6.0, 1.0, 0, 4)
             engine.Plan(p, torch.device("cuda")).run(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda())
     finally:
         engine.DIALECT = "D32"
         oracle.set_dialect("D32")
+
+
+@pytest.mark.parametrize("dialect", ["f64-disparity", "int64-sum", "D64"])
+@pytest.mark.parametrize("fill", ["polylines_soft", "polylines_sharp"])
+def test_polylines_dialects_on_a_wide_noisy_row(fill, dialect):
+    """1600 columns (the float64 coordinates take 8 more bytes of LDS per column), depth with occlusion folds and ties: every
+    dialect bit alone and both, HIP vs the oracle under the same setting."""
+    rs = np.random.RandomState(23)
+    h, w = 6, 1600
+    img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    depth = synth.depth_batch("blobs", 1, h, w, channels=1)[0, ..., 0].astype(np.float32)
+    depth[2] = np.round(depth[2] * 4) / 4          # plateaus: equal |disparity| on both sides of a fold
+    depth[3] = rs.randint(0, 256, w).astype(np.float32) / 255.0
+    c = dict(divergence=5.0, separation=0.5, exponent=1.3, convergence=0.5)
+    oracle.set_dialect(dialect)
+    try:
+        want = oracle.apply_stereo_divergence(img, depth, 5.0, 0.5, 1.3, fill, 0.5)
+    finally:
+        oracle.set_dialect("D32")
+    np.testing.assert_array_equal(_gpu(img, depth, c, fill, dialect), want)
+
+
+def test_polylines_dialect_width_limit():
+    """The float64 coordinates need 8 w more bytes of LDS: frames the D32 row kernel still takes are refused with CS_ELIMIT."""
+    from comfystereo_amd import _native, engine
+    wmax = _native.lib().cs_max_width(engine.FILL["polylines_sharp"])
+    img = torch.zeros((1, 2, wmax, 3), dtype=torch.uint8, device="cuda")
+    dep = torch.rand((1, 2, wmax), device="cuda")
+    engine.apply_stereo_divergence(img, dep, 1.0, 0.0, 1.0, "polylines_sharp", 0.5)          # D32: accepted
+    with pytest.raises(RuntimeError, match="too wide"):
+        engine.apply_stereo_divergence(img, dep, 1.0, 0.0, 1.0, "polylines_sharp", 0.5, dialect="D64")

@@ -75,8 +75,11 @@ def test_fuzz_dialect_d64(engine, seed):
     try:
         for _ in range(12):
             img, depth, div, sep, e, conv = make_case(rng)
-            for fill in ("none", "naive", "naive_interpolating", "inverse"):
-                want = oracle.apply_stereo_divergence(img, depth, div, sep, e, fill, conv)
+            for fill in ("none", "naive", "naive_interpolating", "inverse", "polylines_soft", "polylines_sharp"):
+                try:
+                    want = oracle.apply_stereo_divergence(img, depth, div, sep, e, fill, conv)
+                except IndexError:  # (polylines: the reference's csg scratch would overflow for this input)
+                    continue
                 got = engine.apply_stereo_divergence(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda(), div, sep, e,
                                                      fill, conv, dialect="D64").cpu().numpy()
                 bad = np.argwhere(got != want)

@@ -406,6 +406,10 @@ def gen_dialect_f64(sig):
         for fill in ("none", "naive", "naive_interpolating"):
             arrays[f"{cid}/{fill}"] = sig.apply_stereo_divergence_naive(img, nd64, div_px, sep_px, e, fill)
         arrays[f"{cid}/inverse"] = sig.apply_stereo_divergence_inverse(img, nd64, div_px, sep_px, e)
+        # polylines: the point coordinates leave the float64 chain and are rounded once into the float32 `pt` array (:1924-1934);
+        # the sweep after that keeps the no-numba typing (np.float32 array elements)
+        for fill in ("polylines_soft", "polylines_sharp"):
+            arrays[f"{cid}/{fill}"] = sig.apply_stereo_divergence_polylines(img, nd64, div_px, sep_px, e, fill)
         # how often the two dialects disagree on this case (reported by the tests)
         d32 = sig.apply_stereo_divergence_naive(img, nd32, div_px, sep_px, e, "none")
         cases.append(dict(id=str(cid), kind=kind, divergence=div, separation=sep, exponent=e, convergence=conv,

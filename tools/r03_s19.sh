@@ -1,13 +1,20 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for rep in 1 2 3; do
-for sw in 0 1; do
-  printf "stepped64 no_replay_kernel=$sw: "; CS_NO_REPLAY_KERNEL=$sw timeout 600 python tools/quick_bench.py --n 64 --blur 1 --iters 10 2>&1 | tail -1 | sed 's/.*: //'
-done; done
-mkdir -p gpurun_out/r03_ties
-for k in clipped random8; do
-  timeout 900 python bench.py --depth $k --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r03_ties/bench_$k.json 2>/dev/null; python3 -c "
-import json; j=json.load(open('gpurun_out/r03_ties/bench_$k.json')); print('$k', round(j['value'],1), 'fps', round(j['ms_per_step'],1), 'ms', j['diagnostics'])"
-done
-rm -rf /tmp/pt; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pt -o p -- python3 bench.py --depth clipped --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-db=$(find /tmp/pt -name '*.db' | head -1); python3 tools/prof_summary.py $db gpurun_out/r03_ties/clipped_kernel_trace.txt > /dev/null; head -9 gpurun_out/r03_ties/clipped_kernel_trace.txt | cut -c1-150
+mkdir -p gpurun_out/s19
+timeout 900 python -m pytest tests/test_gpu_dialect.py tests/test_gpu_fuzz.py -x -q -m gpu > gpurun_out/s19/tests.log 2>&1; echo "tests rc=$?"; tail -15 gpurun_out/s19/tests.log
+timeout 300 python - <<'PY' 2>&1 | tail -5
+import time, torch, numpy as np, sys
+sys.path.insert(0, "tools")
+import synth
+from comfystereo_amd import engine
+n, h, w = 2, 2160, 3840
+img = torch.from_numpy(synth.image_f32(1, h, w, seed=1)).expand(n, -1, -1, -1).contiguous().cuda()
+dep = torch.from_numpy(synth.depth_batch("stepped", n, h, w, channels=3)).cuda()
+for d in ("D32", "f64-disparity", "D64"):
+    engine.DIALECT = d
+    p = engine.make_params(n, h, w, h, w, 3, "polylines_soft", "left-right", 8.0, 0.0, 0.0, 0.5, 2.0, False, 20.0, 20.0, 2.0, 6, 4)
+    plan = engine.Plan(p, torch.device("cuda"))
+    plan.run(img, dep); torch.cuda.synchronize()
+    t0 = time.perf_counter(); plan.run(img, dep); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"polylines_soft 4K SBS blur off, dialect {d}: {n / dt:.1f} frames/s")
+PY
