@@ -337,9 +337,9 @@ static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // general row kernel only, the sweep of full D64 as a literal one-lane replay -- the polylines techniques
 static bool dialect_d64_ok(int fill) {
     return fill == CS_FILL_NONE || fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING || fill == CS_FILL_INVERSE ||
-           fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP;
+           fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP || fill == CS_FILL_HYBRID_EDGE;
 }
-static const char* const DIALECT_MSG = "dialect D64 (flags bits 3/4) exists for none / naive / naive_interpolating / inverse / polylines_soft / polylines_sharp";
+static const char* const DIALECT_MSG = "dialect D64 (flags bits 3/4) exists for none / naive / naive_interpolating / inverse / polylines_soft / polylines_sharp / hybrid_edge";
 // flags of the rows the tiled polylines path hands to the row kernel + their compacted list (run_rows)
 // flagged-row block: [row flags, one byte per row][count / cursor pairs, 256 B][stretch-replay counters, 256 B][replay retry
 // flags, one byte per row] -- everything one memset clears -- then [row list, 4 B per row]
@@ -489,8 +489,8 @@ static int max_width_for(int fill, int anaglyph) {
 }
 // polylines under the float64 disparity chain keep 8 more bytes per column in LDS (cs_rowwarp.hip Poly::xd)
 static bool dialect_width_ok(int fill, int w, int anaglyph, int d64) {
-    if (!(d64 & 1) || (fill != CS_FILL_POLYLINES_SOFT && fill != CS_FILL_POLYLINES_SHARP)) return true;
-    return rowwarp_lds_bytes(fill, w, anaglyph) + 8 * (size_t)w + 16 <= CS_LDS_BYTES;
+    if (!(d64 & 1) || (fill != CS_FILL_POLYLINES_SOFT && fill != CS_FILL_POLYLINES_SHARP && fill != CS_FILL_HYBRID_EDGE)) return true;
+    return rowwarp_lds_bytes(fill, w, fill == CS_FILL_HYBRID_EDGE ? 0 : anaglyph) + 8 * (size_t)w + 16 <= CS_LDS_BYTES;
 }
 int cs_max_width(int fill) { return max_width_for(fill, 1); }
 int cs_max_width_mode(int fill, int mode) {

@@ -1310,7 +1310,9 @@ __global__ void __launch_bounds__(1024) k_hybrid_splat(RowArgs A) {
     uint16_t* binoff = (uint16_t*)t; t += align16(2 * ((size_t)w + 4));   // bin b = j_c + 1, b in [0, w+1]
     uint16_t* scratch = (uint16_t*)t; t += align16(2 * ((size_t)w + 4));
     uint16_t* sorted = (uint16_t*)t; t += align16(2 * ((size_t)w + 4));
-    unsigned long long* etab = (unsigned long long*)t;
+    unsigned long long* etab = (unsigned long long*)t; t += 2048;
+    // dialect bit 0 (float64 disparity chain): dest_x as the float64 the reference holds (launch_hybrid adds the 8 w bytes)
+    double* destx64 = (A.d64 & 1) ? (double*)t : nullptr;
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
     uint8_t* base = A.hyb_base + ((((size_t)frame * A.neyes + eyei) * h + row) * w) * 3;
     uint8_t* maskrow = A.hyb_mask + (((size_t)frame * A.neyes + eyei) * h + row) * w;
@@ -1334,10 +1336,18 @@ __global__ void __launch_bounds__(1024) k_hybrid_splat(RowArgs A) {
     for (int x = tid; x < w; x += nt) {
         float d = drow[x] * scale;
         float nd = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
-        float off = disparity(nd, A.e32, E.div32, L.tabs);
-        float dx = ((float)x + 0.5f + off) + E.sep32;
-        destx[x] = dx;
-        float fl = floorf(dx);
+        float fl;
+        if (destx64) {
+            const double dx = (((double)x + 0.5) + disparity64(nd, A.e64, E.div64)) + E.sep64;
+            destx64[x] = dx;
+            const double fd = floor(dx);
+            fl = fd < -2.0 ? -2.0f : (fd > (double)w + 1.0 ? (float)w + 1.0f : (float)fd);   // (exact inside the range that matters)
+        } else {
+            float off = disparity(nd, A.e32, E.div32, L.tabs);
+            float dx = ((float)x + 0.5f + off) + E.sep32;
+            destx[x] = dx;
+            fl = floorf(dx);
+        }
         int b = fl < -1.0f ? -1 : (fl > (float)w ? -1 : (int)fl + 1);  // j_c in [-1, w] can still touch a column
         L.nd[x] = __int_as_float(b);
         if (b >= 0) atomic_add_u16(binoff, b + 1, 1);
@@ -1374,13 +1384,19 @@ __global__ void __launch_bounds__(1024) k_hybrid_splat(RowArgs A) {
             if (x0 < x1 && x0 < x2) { x = x0; p0++; }
             else if (x1 < x2) { x = x1; p1++; }
             else { x = x2; p2++; }
-            float diff = destx[x] - (float)j;
-            float arg = -(diff * diff) / 2.0f;
-            double wg = csm::exp_exact((double)arg, etab);
+            double wg;
+            if (destx64) {
+                const double diff = destx64[x] - (double)j;
+                wg = csm::exp_exact(-(diff * diff) / 2.0, etab);
+            } else {
+                float diff = destx[x] - (float)j;
+                float arg = -(diff * diff) / 2.0f;
+                wg = csm::exp_exact((double)arg, etab);
+            }
             acc0 = (float)((double)acc0 + (double)L.img[3 * x + 0] * wg);
             acc1 = (float)((double)acc1 + (double)L.img[3 * x + 1] * wg);
             acc2 = (float)((double)acc2 + (double)L.img[3 * x + 2] * wg);
-            ws = ws + (float)wg;
+            ws = (A.d64 & 2) ? (float)((double)ws + wg) : ws + (float)wg;   // (numba: float32 += float64 adds in float64)
             touched = true;
         }
         uint8_t o0 = 0, o1 = 0, o2 = 0;
@@ -2369,12 +2385,14 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int pl
     A.hyb_base = (uint8_t*)workspace;
     A.hyb_mask = A.hyb_base + (size_t)A.n * A.neyes * A.h * A.w * 3;
     size_t lds = rowwarp_lds_bytes(CS_FILL_HYBRID_EDGE, A.w, 0);
+    if (A.d64 & 1) lds += align16(8 * (size_t)A.w);   // k_hybrid_splat: dest_x in float64
+    if (lds > CS_LDS_BYTES) return CS_ELIMIT;
     int threads = A.w <= 256 ? 256 : (A.w <= 1024 ? 512 : 1024);
     hipError_t e = hipFuncSetAttribute((const void*)k_hybrid_splat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return CS_EHIP;
     // the tile form of the splat for the node path (float32 image) when a tile fits next to its halo
     const int tmax = (HYT_NPT - 2 * (halo + 2) - 8) & ~3;
-    if (halo >= 0 && A.image_f32 && tmax >= 128 && !dev_switch(CS_DEBUG_NO_TILE) && (size_t)A.n * A.neyes <= 65535) {
+    if (halo >= 0 && A.image_f32 && tmax >= 128 && !A.d64 && !dev_switch(CS_DEBUG_NO_TILE) && (size_t)A.n * A.neyes <= 65535) {   // (tile form: dialect D32)
         const int tiles = (A.w + tmax - 1) / tmax;
         const int T = ((A.w + tiles - 1) / tiles + 3) & ~3;
         // two-eye layouts: the splat writes the node outputs itself, only the gap pixels are left (CS_DEBUG_HYBRID_UNFUSED: the

@@ -127,7 +127,7 @@ def apply_stereo_divergence(image_u8, depth, divergence, separation, stereo_offs
     """reference stereoimage_generation.py:1576-1620 for [N,H,W,3] uint8 + [N,H,W] float32 device tensors.
     dialect: "D32" = the reference without numba (the pinned contract); "D64" = numba's typing (float64 disparities,
     int64 pixel sums; for polylines_soft / polylines_sharp float64 point coordinates and the float64 sweep -- a literal
-    one-lane replay per row, ~100x slower than D32); none / naive / naive_interpolating / inverse / polylines only."""
+    one-lane replay per row, ~100x slower than D32); none / naive / naive_interpolating / inverse / polylines_* / hybrid_edge only."""
     L = _native.lib()
     image_u8 = _dev(image_u8).contiguous()
     depth = _dev(depth).contiguous().float()

@@ -101,8 +101,10 @@ typedef struct cs_params {
                                    float32 point array (pinned: tests/golden/dialect_f64.npz), bit 4 =
                                    numba's float64 typing of the sweep (derived; a literal one-lane
                                    replay per row in the general row kernel -- a compatibility path).
-                                   none / naive / naive_interpolating / inverse / polylines_* only,
-                                   else CS_EINVAL                                                  */
+                                   hybrid_edge: bit 3 = dest_x, its distance to the column and the exp
+                                   argument in float64 (pinned), bit 4 = float64 weight sums (derived).
+                                   none / naive / naive_interpolating / inverse / polylines_* /
+                                   hybrid_edge only, else CS_EINVAL                                */
     double divergence, separation, stereo_balance, convergence_point, stereo_offset_exponent;
     double depth_blur_strength, depth_blur_edge_threshold, depth_blur_falloff;
 } cs_params;

@@ -421,19 +421,37 @@ EXPORT void oracle_hybrid_edge(const uint8_t *img, const float *nd, int h, int w
     for (int row = 0; row < h; row++) {
         for (int x = 0; x < w; x++) {
             float d = nd[(size_t)row * w + x];
-            float off = disparity_f32(d, e32, div32);           /* :1637 */
-            float dest_x = ((float)(x + 0.5) + off) + sep32;   /* :1638 */
-            long jc = (long)floorf(dest_x);
+            /* dialect bit 0: offset, dest_x, diff and the exp argument in float64 (what the reference's own function
+             * computes for normalized_depth.astype(float64): pinned by dialect_f64.npz); bit 1 (numba, derived): the weight
+             * sum adds in float64 before the float32 store (Appendix A) */
+            double dest_d = 0.0;
+            float dest_x = 0.0f;
+            long jc;
+            if (g_dialect & 1) {
+                dest_d = (((double)x + 0.5) + disparity_f64(d, exponent, div_px)) + sep_px;
+                jc = (long)floor(dest_d);
+            } else {
+                float off = disparity_f32(d, e32, div32);           /* :1637 */
+                dest_x = ((float)(x + 0.5) + off) + sep32;         /* :1638 */
+                jc = (long)floorf(dest_x);
+            }
             for (int dd = -1; dd <= 1; dd++) {
                 long j = jc + dd;
                 if (j < 0 || j >= w) continue;
-                float diff = dest_x - (float)j;
-                float arg = -(diff * diff) / 2.0f;             /* float32 until math.exp */
-                double wght = om_exp((double)arg);             /* :1644 */
+                double wght;
+                if (g_dialect & 1) {
+                    double diff = dest_d - (double)j;
+                    wght = om_exp(-(diff * diff) / 2.0);
+                } else {
+                    float diff = dest_x - (float)j;
+                    float arg = -(diff * diff) / 2.0f;             /* float32 until math.exp */
+                    wght = om_exp((double)arg);                    /* :1644 */
+                }
                 size_t o = (size_t)row * w + j;
                 for (int c = 0; c < 3; c++)                    /* :1646 uint8*float -> f64; f32+f64 -> f64 -> store f32 */
                     accum[o * 3 + c] = (float)((double)accum[o * 3 + c] + (double)img[((size_t)row * w + x) * 3 + c] * wght);
-                wsum[o] = wsum[o] + (float)wght;               /* :1647 */
+                if (g_dialect & 2) wsum[o] = (float)((double)wsum[o] + wght);
+                else wsum[o] = wsum[o] + (float)wght;          /* :1647 */
                 mask[o] = 1;
             }
         }

@@ -49,6 +49,20 @@ def test_f64_disparity_chain_polylines(gold):
     assert differs > 0   # (the two chains do not give the same frames)
 
 
+def test_f64_disparity_chain_hybrid_edge(gold):
+    """hybrid_edge: dest_x, its distance to the column and the exp argument in float64 (:1636-1644); pinned bit for bit.  The
+    numba typing on top of it (float64 weight sums, derived) may move a colour by a code here and there."""
+    z, cases = gold
+    differs = 0
+    for c in cases:
+        got = _run(z, c, "hybrid_edge", "f64-disparity")
+        np.testing.assert_array_equal(got, z[f"{c['id']}/hybrid_edge"], err_msg=c["id"])
+        differs += int((got != _run(z, c, "hybrid_edge", "D32")).any(-1).sum())
+        d = np.abs(got.astype(np.int32) - _run(z, c, "hybrid_edge", "D64").astype(np.int32)).max(-1)
+        assert (d > 1).mean() < 2e-3, c["id"]
+    assert differs > 0
+
+
 def test_numba_sweep_typing_is_close_to_the_float32_sweep(gold):
     """Full D64 for polylines (float64 sub-intervals, interpolation and products: derived from numba's typing rules, not
     pinnable here): colours differ from the float64-chain / float32-sweep frames by one code on a minority of the pixels, and

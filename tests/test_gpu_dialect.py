@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "dialect_f64.npz")
 # polylines: through the general row kernel (the tile kernels are dialect D32); the float64 chain is pinned by the fixture, the
 # numba typing of the sweep (full D64) is derived -- checked against the oracle's statement of the same rules
-FILLS = ("none", "naive", "naive_interpolating", "inverse", "polylines_soft", "polylines_sharp")
+FILLS = ("none", "naive", "naive_interpolating", "inverse", "polylines_soft", "polylines_sharp", "hybrid_edge")
 
 
 def _gpu(img, depth, c, fill, dialect):
@@ -52,7 +52,7 @@ def test_other_techniques_refuse_the_dialect():
     from comfystereo_amd import engine
     img = torch.zeros((1, 16, 32, 3), dtype=torch.uint8, device="cuda")
     dep = torch.rand((1, 16, 32), device="cuda")
-    for fill in ("hybrid_edge", "hybrid_edge_plus", "none_post"):
+    for fill in ("hybrid_edge_plus", "none_post", "inverse_post"):
         with pytest.raises(RuntimeError, match="D64"):
             engine.apply_stereo_divergence(img, dep, 3.0, 0.0, 1.0, fill, 0.5, dialect="D64")
 
@@ -68,7 +68,8 @@ def test_node_path_with_the_dialect_switch():
     try:
         for ui, mode in (("Fill - Naive interpolating", "left-right"), ("No fill - Reverse projection", "red-cyan-anaglyph"),
                          ("Fill - Naive", "top-bottom"), ("Fill - Polylines Soft", "left-right"),
-                         ("Fill - Polylines Sharp", "red-cyan-anaglyph"), ("Fill - Polylines Soft", "bottom-top")):
+                         ("Fill - Polylines Sharp", "red-cyan-anaglyph"), ("Fill - Polylines Soft", "bottom-top"),
+                         ("Imperfect fill - Hybrid Edge", "left-right"), ("Imperfect fill - Hybrid Edge", "red-cyan-anaglyph")):
             fill = node_oracle.FILL_KEYS[ui]
             p = engine.make_params(n, h, w, h, w, 3, fill, mode, 7.0, 0.5, 0.0, 0.5, 1.3, False, 6.0, 6.0, 1.0, 0, 4)
             assert (p.flags >> 3) & 3 == 3
@@ -77,7 +78,7 @@ def test_node_path_with_the_dialect_switch():
             for g, wv in zip(got, want):
                 np.testing.assert_array_equal(g, wv)
         with pytest.raises(RuntimeError, match="D64"):
-            p = engine.make_params(n, h, w, h, w, 3, "hybrid_edge", "left-right", 7.0, 0.5, 0.0, 0.5, 1.3, False, 6.0, 6.0, 1.0, 0, 4)
+            p = engine.make_params(n, h, w, h, w, 3, "hybrid_edge_plus", "left-right", 7.0, 0.5, 0.0, 0.5, 1.3, False, 6.0, 6.0, 1.0, 0, 4)
             engine.Plan(p, torch.device("cuda")).run(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda())
     finally:
         engine.DIALECT = "D32"

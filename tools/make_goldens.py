@@ -410,6 +410,8 @@ def gen_dialect_f64(sig):
         # the sweep after that keeps the no-numba typing (np.float32 array elements)
         for fill in ("polylines_soft", "polylines_sharp"):
             arrays[f"{cid}/{fill}"] = sig.apply_stereo_divergence_polylines(img, nd64, div_px, sep_px, e, fill)
+        # hybrid_edge: dest_x, its distance to the column and the exp argument in float64 (:1636-1644)
+        arrays[f"{cid}/hybrid_edge"] = sig.apply_stereo_divergence_hybrid_edge(img, nd64, div_px, sep_px, e)
         # how often the two dialects disagree on this case (reported by the tests)
         d32 = sig.apply_stereo_divergence_naive(img, nd32, div_px, sep_px, e, "none")
         cases.append(dict(id=str(cid), kind=kind, divergence=div, separation=sep, exponent=e, convergence=conv,
