@@ -879,9 +879,12 @@ struct RpCtx {      // where a row exports its stretches to (dump == null: repla
 __host__ __device__ inline size_t rp_perm_bytes(int w, int sharp) { return align16(2 * (size_t)poly_npt(w, sharp)); }
 __host__ __device__ inline size_t rp_slot_bytes(int w, int sharp) { return rp_perm_bytes(w, sharp) + align16(4 * (size_t)w); }
 
-template <int SHARP, class Emit>
+// DIALECT: the instantiation that can run the dialect bits d64 (separate kernels, k_rowwarp<FILL, true>: the D32 kernel keeps
+// its registers and its code as they were)
+template <int SHARP, bool DIALECT, class Emit>
 __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float e32, uint32_t* stats_rw,
-                                    const Emit& emit, int dbg, const RpCtx* X = nullptr, int d64 = 0, double e64 = 0.0) {
+                                    const Emit& emit, int dbg, const RpCtx* X = nullptr, int d64_ = 0, double e64 = 0.0) {
+    const int d64 = DIALECT ? d64_ : 0;
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
     Poly P;
     P.w = w; P.sharp = SHARP; P.npt = poly_npt(w, SHARP); P.cap = poly_cap(w, SHARP);
@@ -893,7 +896,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
     P.entries = (uint16_t*)t; t += align16(2 * (size_t)P.cap);
     P.longs = (uint16_t*)t; t += align16(2 * 1024);
     P.cd = L.nd;
-    double* xd = (d64 & 1) ? (double*)t : nullptr;   // (launch_rowwarp adds the 8 w bytes for the dialect)
+    double* xd = (DIALECT && (d64 & 1)) ? (double*)t : nullptr;   // (launch_rowwarp adds the 8 w bytes for the dialect)
     P.xd = xd;
     const int npt = P.npt, nbin = w + 2, LONGCAP = 1024;
     int* flag_hazard = L.misc + 0;
@@ -901,7 +904,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
     int* ntotal = L.misc + 2;
     int* scan_ws = L.misc + 8;
     // P1: coord_d (in place over nd), point x's, histogram of bins (count of bin b at binoff[b+1])
-    if (xd) {
+    if (DIALECT && xd) {
         for (int c = tid; c < w; c += nt) {
             const double cd = disparity64(L.nd[c], e64, E.div64);
             xd[c] = (((double)c + 0.5) + cd) + E.sep64;
@@ -984,7 +987,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         }
         __syncthreads();
         if (dbg == 4) return;
-        if (d64 & 2) {
+        if (DIALECT && (d64 & 2)) {
             // P3c with numba's typing of the sweep (poly_sequential64 has the statements): one lane per output pixel; a pixel
             // whose choice depends on the order of the active list (several active segments, none or two equally close)
             // sends the row to the literal one-lane replay below
@@ -1097,7 +1100,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         }
     }
     __syncthreads();
-    if (d64 & 2) {
+    if (DIALECT && (d64 & 2)) {
         if ((overflow || *flag_hazard) && tid == 0) {   // order-dependent row: the literal replay (it rewrites every pixel)
             const int rc = poly_sequential64(P, L, E.csg_cap, emit);
             if (stats_rw) {
@@ -2000,7 +2003,7 @@ struct RowOut {
     }
 };
 
-template <int FILL>
+template <int FILL, bool DIALECT>
 __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, const int frame, char* smem) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int w = A.w, h = A.h;
@@ -2097,7 +2100,7 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
                 // (eyes in separate output slots: the stretches of order-dependent rows may go to the replay kernel)
                 const RpCtx X{A.anaglyph ? nullptr : A.rp_dump, A.rp_list, A.rp_ctr, A.rp_slots, A.rp_cap, A.rp_slot_bytes,
                               (uint32_t)frame * (uint32_t)A.h + (uint32_t)row, e};
-                technique_polylines<FILL == CS_FILL_POLYLINES_SHARP ? 1 : 0>(L, w, E, A.e32, st_rw, out, A.dbg, &X, A.d64, A.e64);
+                technique_polylines<FILL == CS_FILL_POLYLINES_SHARP ? 1 : 0, DIALECT>(L, w, E, A.e32, st_rw, out, A.dbg, &X, A.d64, A.e64);
             }
             else if (FILL == CS_FILL_HYBRID_EDGE_PLUS) {
                 // hybrid_edge into `res`, then the polylines_soft row into `alt`; pixels that stayed black take the latter
@@ -2110,7 +2113,7 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
                 }
                 __syncthreads();
                 auto into_alt = [=](int c, uint8_t r, uint8_t g, uint8_t b) { alt[3 * c] = r; alt[3 * c + 1] = g; alt[3 * c + 2] = b; };
-                technique_polylines<0>(L, w, E, A.e32, st_rw, into_alt, A.dbg);
+                technique_polylines<0, false>(L, w, E, A.e32, st_rw, into_alt, A.dbg);
                 __syncthreads();
                 for (int c = tid; c < w; c += nt)
                     if (L.res[3 * c] == 0 && L.res[3 * c + 1] == 0 && L.res[3 * c + 2] == 0) {
@@ -2176,7 +2179,7 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
 
 // One workgroup per row (both eyes); or, behind the tiled polylines path, a fixed number of workgroups working off the
 // list of rows that path flagged (`row_list`: frame * h + row) -- usually empty, so nothing the size of the batch is launched.
-template <int FILL>
+template <int FILL, bool DIALECT = false>
 __global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ONE call site of the (force-inlined) row function: as a real call it takes the argument struct by reference, i.e. a
@@ -2196,7 +2199,7 @@ __global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
             const uint32_t e = A.row_list[i];
             row = (int)(e % (uint32_t)A.h); frame = (int)(e / (uint32_t)A.h);
         } else if (it) break;
-        rowwarp_row<FILL>(A, row, frame, smem);
+        rowwarp_row<FILL, DIALECT>(A, row, frame, smem);
         __syncthreads();  // the row's LDS (and s_next) is reused by the next one
     }
 }
@@ -2346,6 +2349,15 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
         if (e != hipSuccess) return e;                                                                            \
         hipLaunchKernelGGL(k_rowwarp<F>, grid, block, lds, stream, A);                                            \
         break;                                                                                                    \
+    }
+    if ((A.d64 & 3) && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP)) {   // the dialect instantiations
+        hipError_t e = fill == CS_FILL_POLYLINES_SOFT
+            ? hipFuncSetAttribute((const void*)k_rowwarp<CS_FILL_POLYLINES_SOFT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+            : hipFuncSetAttribute((const void*)k_rowwarp<CS_FILL_POLYLINES_SHARP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (fill == CS_FILL_POLYLINES_SOFT) hipLaunchKernelGGL((k_rowwarp<CS_FILL_POLYLINES_SOFT, true>), grid, block, lds, stream, A);
+        else hipLaunchKernelGGL((k_rowwarp<CS_FILL_POLYLINES_SHARP, true>), grid, block, lds, stream, A);
+        return hipGetLastError();
     }
     switch (fill) {
         CS_LAUNCH(CS_FILL_NONE)

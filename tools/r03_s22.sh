@@ -1,9 +1,11 @@
 #!/bin/bash
+# k_blur_fused phase cut-offs (dev build): where do the 19 us per tile go?
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/s22
-timeout 2400 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_fuzz.py tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/s22/tests.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/s22/tests.log
-timeout 400 python tools/extended_fuzz.py 200 17000 > gpurun_out/s22/fuzz.log 2>&1; echo "fuzz rc=$?"; tail -2 gpurun_out/s22/fuzz.log
-CS_DBG=14 python tools/quick_bench.py --n 8 --blur 0 --iters 1 --kind clipped 2>&1 | tail -4 | head -1
-for n in 8 32 64; do
-  printf "clipped blur=0 n=$n: "; timeout 600 python tools/quick_bench.py --n $n --blur 0 --iters 2 --kind clipped 2>&1 | tail -1 | sed 's/.*: //'
-done
+for dbg in 0 21 22 23 24; do
+  rm -rf /tmp/pt
+  CS_DBG=$dbg CS_LIB_PATH=$PWD/comfystereo_amd/libcomfystereo_hip_dev.so timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/pt -o p -- python3 tools/quick_bench.py --n 32 --blur 1 --iters 3 --fill none > /tmp/run.log 2>&1
+  db=$(find /tmp/pt -name '*.db' | head -1)
+  [ -n "$db" ] && python3 tools/prof_summary.py $db /tmp/t.txt > /dev/null
+  echo "dbg=$dbg $(grep k_blur_fused /tmp/t.txt | awk '{print $(NF-1)}') us"
+done | tee gpurun_out/s22/phases.txt

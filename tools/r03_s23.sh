@@ -1,10 +1,15 @@
 #!/bin/bash
+# round-3 closing profiles (tag r03d): default bench (kernel trace + PMC passes), BASELINE configs 2-5 (kernel trace + bench line),
+# PMC passes of cfg3 (its kernels changed), host bench, tie bench lines
+bash tools/r03_profiles.sh r03d
+for c in cfg3; do bash tools/gpu_profile.sh r03d_${c}_pmc --config $c > /dev/null 2>&1; done
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out/s23
-timeout 2400 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_fuzz.py tests/test_gpu_parity.py tests/test_gpu_lazy_blur.py tests/test_gpu_chunks.py tests/test_gpu_dropin.py -x -q -m gpu > gpurun_out/s23/tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/s23/tests.log
-timeout 300 python tools/extended_fuzz.py 120 19000 > gpurun_out/s23/fuzz.log 2>&1; echo "fuzz rc=$?"; tail -1 gpurun_out/s23/fuzz.log
-for rep in 1 2 3; do
-for sw in 0 1; do
-  printf "stepped64 no_replay_kernel=$sw: "; CS_NO_REPLAY_KERNEL=$sw timeout 600 python tools/quick_bench.py --n 64 --blur 1 --iters 10 2>&1 | tail -1 | sed 's/.*: //'
-done; done
-printf "clipped blur=0 n=64: "; timeout 600 python tools/quick_bench.py --n 64 --blur 0 --iters 2 --kind clipped 2>&1 | tail -1 | sed 's/.*: //'
+mkdir -p gpurun_out/r03d_ties
+for d in clipped random8; do
+  timeout 600 python bench.py --depth $d --no-blur --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r03d_ties/bench_${d}_blur_off.json 2>/dev/null
+  timeout 600 python bench.py --depth $d --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r03d_ties/bench_${d}_blur_on.json 2>/dev/null
+done
+for f in gpurun_out/r03d_ties/*.json; do python3 -c "
+import json,sys
+j=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f'.split('/')[-1], round(j['value'],1), 'fps')"; done
+grep -h "FETCH_SIZE\|WRITE_SIZE" gpurun_out/r03d_cfg3_pmc/pmc_fetch.txt gpurun_out/r03d_cfg3_pmc/pmc_write.txt | cut -c1-60,95-150 | head -8

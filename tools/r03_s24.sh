@@ -1,19 +1,16 @@
 #!/bin/bash
+# (1) the D32 tie path after the dialect moved into kernels of its own: random8 / clipped against the build before D64
+# (2) hybrid splat with parked pixels: parity + cfg3 A/B
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python - <<'PY'
-import sys, time
-sys.path.insert(0,'.'); sys.path.insert(0,'tools')
-import torch, synth
-from comfystereo_amd.GenerateStereo import StereoImageNode
-n,h,w=32,2160,3840
-img = torch.from_numpy(synth.image_f32(1, h, w, seed=1)).expand(n, -1, -1, -1).contiguous()
-dep = torch.from_numpy(synth.depth_batch("stepped", n, h, w, channels=3))
-node = StereoImageNode()
-args = (8.0, 0.0, "left-right", 0.0, 0.5, 2.0, "Fill - Polylines Soft", 20.0, 20.0, True, 2.0, 6, 12)
-r=[]
-out=None
-for i in range(8):
-    t0=time.perf_counter(); out = node.generate(img, dep, *args); torch.cuda.synchronize(); r.append(round(n/(time.perf_counter()-t0),1))
-print("node.generate, results kept (first call = cold):", r)
-PY
-timeout 600 python tools/node_host_bench.py --n 32 --iters 2 2>&1 | tail -3
+mkdir -p gpurun_out/s24
+timeout 900 python -m pytest tests/test_gpu_dialect.py tests/test_gpu_hybrid_fused.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py -x -q -m gpu > gpurun_out/s24/tests.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/s24/tests.log
+for L in comfystereo_amd/libcs_base.so comfystereo_amd/libcomfystereo_hip.so; do
+  for kind in random8 clipped; do
+    printf "%-28s %-8s " "$(basename $L)" $kind; CS_LIB_PATH=$PWD/$L timeout 300 python tools/quick_bench.py --n 4 --blur 0 --iters 2 --kind $kind 2>&1 | tail -1 | sed 's/.*: //'
+  done
+done
+for i in 1 2 3; do
+  for L in comfystereo_amd/libcs_base.so comfystereo_amd/libcomfystereo_hip.so; do
+    printf "%-28s " "$(basename $L)"; CS_LIB_PATH=$PWD/$L timeout 300 python bench.py --config cfg3 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(round(d['value'],1), 'fps', round(d['ms_per_step'],3), 'ms', 'kernel', round(d['roofline']['kernel_ms'],3))"
+  done
+done
