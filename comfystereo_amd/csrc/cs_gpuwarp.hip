@@ -692,13 +692,17 @@ static int gw_launch(GwArgs& A, hipStream_t stream) {
         return CS_OK;
     }
     size_t lds = gw_lds_bytes(A.w);
+    if (A.pow_mode != 4) lds -= sizeof(csm::PowfTables) + 64;   // (the tables are the LAST item of the layout and only the general exponent reads them)
     // workgroup size: about 4 columns per thread (measured at 1080p: 512 threads 2.30 ms per 32 frames, 1024: 2.71, 256: 2.94)
     int threads = A.w <= 1024 ? 256 : (A.w <= 2048 ? 512 : 1024);
     const int forced = dev_switch(CS_DEBUG_PT_VARIANT);   // (development: workgroup size)
     if (forced == 21) threads = 512;
     if (forced == 22 && A.w <= 4 * 256) threads = 256;
     if (forced == 23) threads = 1024;
-    const bool wide = threads > 512, pow2 = A.pow_mode == 2;
+    // 1080p: a row takes 40.5 KB without the tables -- FOUR 512-thread workgroups per CU instead of three if the kernel also
+    // fits 64 registers (the 8-waves-per-SIMD instantiation; development switch 24: the 6-wave one)
+    const bool four = threads == 512 && 4 * ((lds + 511) & ~(size_t)511) <= CS_LDS_BYTES && forced != 24;
+    const bool wide = threads > 512 || four, pow2 = A.pow_mode == 2;
     const void* fn = wide ? (pow2 ? (const void*)k_gpuwarp<8, 2> : (const void*)k_gpuwarp<8, -1>)
                           : (pow2 ? (const void*)k_gpuwarp<6, 2> : (const void*)k_gpuwarp<6, -1>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
