@@ -155,8 +155,15 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     const bool left_edge = s0 == 0, right_edge = s1 == w;
 
     // ---- LDS carve ----
-    float4* P = (float4*)smem;                                                    // [NPT] {R, G, B, x} of point o
+    // a point = its colour codes in one dword (r | g << 8 | b << 16) and x: 8 bytes instead of a float4 -- four point slots
+    // per lane (1024 points, tiles of 768 pixels: halo 1.21 x instead of 1.29 x, the prologue amortised over 39 % more
+    // pixels) still fit seven workgroups per CU; a reader pays one v_cvt_f32_ubyteN per channel
+    struct PQ { uint32_t rgb; float x; };
+    PQ* P = (PQ*)smem;                                                            // [NPT] point o
     float* pz = (float*)(P + NPT);                                                // [NPT] |coord_d|
+    auto ch0 = [](uint32_t c) { return (float)(c & 0xffu); };
+    auto ch1 = [](uint32_t c) { return (float)((c >> 8) & 0xffu); };
+    auto ch2 = [](uint32_t c) { return (float)((c >> 16) & 0xffu); };
     uint32_t* plist = (uint32_t*)(pz + NPT);                                      // [max(T, 128)] pixels evaluated in pass 2
     // The powf tables: exponents 1 and 2 only run the clone for the 0.4 % risky squares and read the tables where they are,
     // in constant memory (512 bytes, L1-resident: no copy, nothing to wait for before barrier 0: +2 %); any other exponent
@@ -293,15 +300,13 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // colour: np.clip(x * 255, 0, 255).astype(uint8) (reference :1508) as the float value of the code -> P[o].rgb right away
     // (slots beyond the row end hold the last column's colour: slot ns is the right sentinel, :1935)
     const int qoff = s0 - o0;
+    uint32_t rgbk[SLOTS];   // (kept in registers until x is known: one 8-byte LDS store per point)
 #pragma unroll
     for (int k = 0; k < SLOTS; k++) {
-        F3 c;
-        if (OUT == PO_ASD) c = F3{(float)cpre8[k].x, (float)cpre8[k].y, (float)cpre8[k].z};
-        else c = F3{truncf(__builtin_amdgcn_fmed3f(cpre[k].x * 255.0f, 0.0f, 255.0f)),
-                    truncf(__builtin_amdgcn_fmed3f(cpre[k].y * 255.0f, 0.0f, 255.0f)),
-                    truncf(__builtin_amdgcn_fmed3f(cpre[k].z * 255.0f, 0.0f, 255.0f))};
-        *reinterpret_cast<F3*>(P + 1 + tid + k * NT) = c;
-        if (k == 0 && tid == 0) *reinterpret_cast<F3*>(P) = c;   // left sentinel (:1921): the first column's colour
+        if (OUT == PO_ASD) rgbk[k] = (uint32_t)cpre8[k].x | ((uint32_t)cpre8[k].y << 8) | ((uint32_t)cpre8[k].z << 16);
+        else rgbk[k] = (uint32_t)__builtin_amdgcn_fmed3f(cpre[k].x * 255.0f, 0.0f, 255.0f) |
+                       ((uint32_t)__builtin_amdgcn_fmed3f(cpre[k].y * 255.0f, 0.0f, 255.0f) << 8) |
+                       ((uint32_t)__builtin_amdgcn_fmed3f(cpre[k].z * 255.0f, 0.0f, 255.0f) << 16);
     }
     // this eye's depth-map output: (depth * 255).astype(uint8) wraps mod 256 (quirk Q7), value code / 255 on three channels
     if (OUT != PO_ASD && !PP_DEV_IS(37)) {
@@ -324,12 +329,10 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         }
     }
     if (!eye_on) {   // divergence < 0.001 for this eye: the source image (quirk Q10); rare, kept out of the hot path
-        __syncthreads();
 #pragma unroll
         for (int k = 0; k < SLOTS; k++) {
             const int q = tid + k * NT + qoff;
-            const float4 c = P[1 + tid + k * NT];
-            if ((unsigned)q < (unsigned)wt) emit_f(q, c.x, c.y, c.z);
+            if ((unsigned)q < (unsigned)wt) emit_f(q, ch0(rgbk[k]), ch1(rgbk[k]), ch2(rgbk[k]));
         }
         return;
     }
@@ -391,7 +394,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         const float tidf = (float)tid;
         const float jf0 = (float)s0 + tidf + 0.5f;  // exact: integers + 0.5 below 2^23
         int wjlo = 0x7fffffff, wjhi = -1;
-        float* const Pxw = reinterpret_cast<float*>(P + 1 + tid) + 3;
+        PQ* const Pw = P + 1 + tid;
         float* const pzw = pz + 1 + tid;
 #pragma unroll
         for (int k = 0; k < SLOTS; k++) {
@@ -400,7 +403,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             float x = ((jf0 + (float)(k * NT)) + cdj) + E.sep32;                   // coord_x   (:1927)
             // slots beyond the staged range: x = 2w + (j - ns), strictly increasing, slot ns = the right sentinel (:1935)
             x = j < ns ? x : tidf + (float)(2 * w - ns + k * NT);
-            Pxw[4 * k * NT] = x;
+            Pw[k * NT] = PQ{rgbk[k], x};
             pzw[k * NT] = fabsf(cdj);
             // reversed segment (j -> j+1)?  The right neighbour sits in the next lane (lane 63: +inf; the pairs across wave
             // chunks and the left sentinel's pair are checked after the barrier).
@@ -415,7 +418,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             wjhi = max(wjhi, m2 ? base + 63 - __clzll((long long)m2) : -1);
         }
         if (lane == 0) { atomicMin(&flags[PF_JLO], wjlo); atomicMax(&flags[PF_JHI], wjhi); }
-        if (tid == 0) P[0].w = (float)(-1.0 * w);   // left sentinel (:1921) at the frame border
+        if (tid == 0) P[0] = PQ{rgbk[0], (float)(-1.0 * w)};   // left sentinel (:1921): the first column's colour (frame border only)
     }
     __syncthreads();  // barrier 1: points staged, in-wave reversed segments marked
     if (PP_DEV_IS(31)) return;
@@ -431,7 +434,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             const int j = lane * NT + wave * 64 + 63;
             if (j <= ns - 2) o = 1 + j;   // the pair (j, j + 1) of real points
         } else if (lane == SLOTS && wave == 0 && left_edge) o = 0;
-        const float xa = o >= 0 ? P[o].w : 0.0f, xb = o >= 0 ? P[o + 1].w : 1.0f;
+        const float xa = o >= 0 ? P[o].x : 0.0f, xb = o >= 0 ? P[o + 1].x : 1.0f;
         const unsigned long long mrev = __ballot(o >= 0 && !(xa < xb));
         if (mrev) mark_reversed(mrev, xa, xb);
         __syncthreads();
@@ -465,8 +468,8 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         const bool act = jb + tid <= jhi;
         const int j = min(jb + tid, jhi);
         const int o = 1 + j;
-        const float4 pm = P[o - 1], pc = P[o], pp = P[o + 1];
-        const float x = pc.w, xm = pm.w, xp = pp.w;
+        const PQ pm = P[o - 1], pc = P[o], pp = P[o + 1];
+        const float x = pc.x, xm = pm.x, xp = pp.x;
         const float f0 = floorf(x), f1 = floorf(xp), f0p1 = f0 + 1.0f;
         // ---- the fast path: one point in the pixel, two pieces [col, x] and [x, col+1] on the segments (o-1 -> o),
         // (o -> o+1).  Piece 0: from = col + eps (-> col in float32 for col >= 2), to = x - eps; piece 1: from = x + eps,
@@ -493,12 +496,13 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             const float ip0 = div_core(c0 - xm, den0), ip1 = div_core(c1 - x, den1);
             const float om0 = 1.0f - ip0, om1 = 1.0f - ip1;
             // (both pieces have positive length here; the lerp operands are finite)
-            float k0 = 0.5f + (pm.x * om0 + pc.x * ip0) * sig0;
-            float k1 = 0.5f + (pm.y * om0 + pc.y * ip0) * sig0;
-            float k2 = 0.5f + (pm.z * om0 + pc.z * ip0) * sig0;
-            k0 = k0 + (pc.x * om1 + pp.x * ip1) * sig1;
-            k1 = k1 + (pc.y * om1 + pp.y * ip1) * sig1;
-            k2 = k2 + (pc.z * om1 + pp.z * ip1) * sig1;
+            const float cr = ch0(pc.rgb), cg = ch1(pc.rgb), cb = ch2(pc.rgb);
+            float k0 = 0.5f + (ch0(pm.rgb) * om0 + cr * ip0) * sig0;
+            float k1 = 0.5f + (ch1(pm.rgb) * om0 + cg * ip0) * sig0;
+            float k2 = 0.5f + (ch2(pm.rgb) * om0 + cb * ip0) * sig0;
+            k0 = k0 + (cr * om1 + ch0(pp.rgb) * ip1) * sig1;
+            k1 = k1 + (cg * om1 + ch1(pp.rgb) * ip1) * sig1;
+            k2 = k2 + (cb * om1 + ch2(pp.rgb) * ip1) * sig1;
             // (0.5 <= k < 255.5: the lerp operands are codes 0..255, the piece lengths sum to less than 1)
             if (fast) emit_k(q, k0, k1, k2);
         }
@@ -577,7 +581,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // ---- the left sentinel's segment (0 -> 1), frame border only: the pixels 0 .. floor(x1) - 1 under it take the chain path
     // (their piece is "flat"); in fold tiles it is a listed segment like the others
     if (left_edge && tid == 0) {
-        const float x1 = P[1].w, fs = floorf(x1);
+        const float x1 = P[1].x, fs = floorf(x1);
         if ((float)(-1.0 * w) < x1) {
             const int e1 = min((int)fs - 1 - o0, wt - 1);
             if (fs - 1.0f >= o0f)
@@ -615,7 +619,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         int npr = 0;
         if (act && !bridge) {
             npr = 1;
-            while (npr <= PT_KP && floorf(P[min(o1in + npr, npts - 1)].w) == colf) npr++;
+            while (npr <= PT_KP && floorf(P[min(o1in + npr, npts - 1)].x) == colf) npr++;
         }
         const int o1 = bridge ? o1in + 1 : o1in;   // np == 0: the segment's END point
         const int np = act ? min(npr, PT_KP) : 0;
@@ -632,8 +636,8 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         for (int k = 0; k < PT_KP + 2; k++) {
             if (k <= wnp + 1) {
                 const int o = chain && k <= np + 1 ? o1 - 1 + k : 0;
-                const float4 v = P[o];
-                cx[k] = v.w; c0[k] = v.x; c1[k] = v.y; c2[k] = v.z;
+                const PQ v = P[o];
+                cx[k] = v.x; c0[k] = ch0(v.rgb); c1[k] = ch1(v.rgb); c2[k] = ch2(v.rgb);
                 cj[k] = min(max(o - 1, 0), ns - 1);
             } else { cx[k] = 0.0f; c0[k] = c1[k] = c2[k] = 0.0f; cj[k] = 0; }
         }
@@ -702,13 +706,13 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         // bridge pixels of real segments away from the first two columns: one whole-pixel piece, closed-form constants
         const bool lean = act && bridge && o >= 1 && o + 1 <= npts - 2 && o0 + q >= 2;
         if (__any(lean)) {
-            const float4 a = P[lean ? o : 1], b = P[lean ? o + 1 : 2];
+            const PQ a = P[lean ? o : 1], b = P[lean ? o + 1 : 2];
             const float colf = (float)(o0 + q);
             const float center = colf + 0.5f;
-            const float ip = div_core(center - a.w, b.w - a.w), om = 1.0f - ip;
-            const float k0 = 0.5f + (a.x * om + b.x * ip) * sig_whole;
-            const float k1 = 0.5f + (a.y * om + b.y * ip) * sig_whole;
-            const float k2 = 0.5f + (a.z * om + b.z * ip) * sig_whole;
+            const float ip = div_core(center - a.x, b.x - a.x), om = 1.0f - ip;
+            const float k0 = 0.5f + (ch0(a.rgb) * om + ch0(b.rgb) * ip) * sig_whole;
+            const float k1 = 0.5f + (ch1(a.rgb) * om + ch1(b.rgb) * ip) * sig_whole;
+            const float k2 = 0.5f + (ch2(a.rgb) * om + ch2(b.rgb) * ip) * sig_whole;
             // the segment is forward, starts left of the pixel and ends right of it (checked when it was listed)
             if (lean) emit_k(q, k0, k1, k2);
         }
@@ -748,7 +752,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         for (int k = 0; k < PT_KP; k++) {
             if (k < wnp) {
                 int o = k < np ? (int)pts[s * PT_KP + k] : 0x7fffffff;
-                float x = k < np ? P[o].w : INFINITY;
+                float x = k < np ? P[o].x : INFINITY;
 #pragma unroll
                 for (int m2 = 0; m2 <= k; m2++) {
                     const bool lt = x < xs[m2] || (x == xs[m2] && o < os[m2]);
@@ -769,7 +773,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             if (e < wns) {
                 const bool have = e < nsg;
                 const int oe = have ? (int)sgs[s * PT_KS + e] : 0;
-                const float x0 = P[oe].w, x1 = P[oe + 1].w;
+                const float x0 = P[oe].x, x1 = P[oe + 1].x;
                 se0[e] = have ? x0 : INFINITY;
                 se1[e] = have ? x1 : -INFINITY;
             }
@@ -803,7 +807,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             // one step of the reference's scan (:1972-1980) for a segment that is active (`on`), polyline point oe -> oe + 1.
             // 0 < centre - x0 <= x1 - x0 <= 3 w: div_core's proven range.
             auto scan_step = [&](bool on, int oe) {
-                const float x0 = P[oe].w, x1 = P[oe + 1].w;
+                const float x0 = P[oe].x, x1 = P[oe + 1].x;
                 const float ip_e = div_core(center - x0, x1 - x0);
                 o_pick = on ? oe : o_pick;
                 ip_pick = on ? ip_e : ip_pick;
@@ -838,7 +842,8 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             const bool contrib = work && (use_best || o_pick >= 0);
             const int o = contrib ? (use_best ? o_best : o_pick) : 1;
             const float ip_k = use_best ? ip_best : ip_pick;   // (the chosen segment's parameter: the same division as :1986)
-            const float4 pl = P[o], pr = P[o + 1];
+            const PQ pq_l = P[o], pq_r = P[o + 1];
+            const F3 pl{ch0(pq_l.rgb), ch1(pq_l.rgb), ch2(pq_l.rgb)}, pr{ch0(pq_r.rgb), ch1(pq_r.rgb), ch2(pq_r.rgb)};
             const int jl = min(max(o - 1, 0), ns - 1), jr = min(max(o, 0), ns - 1);
             const float om = 1.0f - ip_k;
             const float sgm = sig64 ? (float)C.sig_dd : sig_f;
@@ -919,7 +924,7 @@ hipError_t launch_anaglyph_compose(const uint8_t* sbs, const uint8_t* rowflag, i
 
 static size_t polypoint_lds(int nt, int slots, int T, int KP, int KS) {
     const size_t npt = (size_t)slots * nt + 4;
-    return 16 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((T + 3) & ~3) + 2 * PP_DCAP * (2 + (size_t)KP + KS) +
+    return 8 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((T + 3) & ~3) + 2 * PP_DCAP * (2 + (size_t)KP + KS) +
            4 * PF_WORDS + 1024 + 64;
 }
 
@@ -948,7 +953,7 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
     size_t lds = polypoint_lds(NT, SLOTS, A.T, KP, KS);
     // (development: CS_DEBUG_PT_VARIANT 13..16 pads the LDS request so that only 3..6 workgroups fit a CU -- occupancy what-if)
     const int npt = SLOTS * NT + 4;
-    const int off_dflag = 16 * npt + 4 * npt + 4 * (A.T > 128 ? A.T : 128), off_dcnt = off_dflag + ((A.T + 3) & ~3);
+    const int off_dflag = 8 * npt + 4 * npt + 4 * (A.T > 128 ? A.T : 128), off_dcnt = off_dflag + ((A.T + 3) & ~3);
     const int pow_mode = (A.dbg == 17 || !(A.e32 == 2.0f || A.e32 == 1.0f)) ? 0 : (A.e32 == 2.0f ? 2 : 1);
     for (int e = 0; e < 2; e++) {
         const EyeArgs& E = A.eye[e];
@@ -978,13 +983,14 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
 // Launch for the eyes of `R` (SBS / TB / single-eye / uint8 outputs; no anaglyph).  `rowflag` must be zeroed by the caller;
 // afterwards the general kernel is run over the flagged rows.
 hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream_t stream) {
-    // workgroup geometry: threads x point slots per lane.  256 x 3 (7 workgroups per CU at the bench halo) is the default;
-    // development switch CS_DEBUG_PT_VARIANT: 3 = 256 x 3, 4 = 256 x 4, 5 = 384 x 3, 6 = 320 x 3
+    // workgroup geometry: threads x point slots per lane.  256 x 4 (7 workgroups per CU at the bench halo, 19.5 KB of LDS each) is
+    // the default; development switch CS_DEBUG_PT_VARIANT: 3 = 256 x 3 (the default until the end of round 3), 4 = 256 x 4,
+    // 5 = 384 x 3, 6 = 320 x 3
     const int forced = dev_switch(CS_DEBUG_PT_VARIANT);
-    int geo = (forced >= 3 && forced <= 6) ? forced : 3;
+    int geo = (forced >= 3 && forced <= 6) ? forced : 4;
     auto nt_of = [](int g) { return g == 5 ? 384 : (g == 6 ? 320 : 256); };
     auto sl_of = [](int g) { return g == 4 ? 4 : 3; };
-    if (polypoint_tile(R.w, S, nt_of(geo) * sl_of(geo), nt_of(geo)) == 0 && geo == 3) geo = 5;
+    if (polypoint_tile(R.w, S, nt_of(geo) * sl_of(geo), nt_of(geo)) == 0 && (geo == 3 || geo == 4)) geo = 5;
     const int nt = nt_of(geo), slots = sl_of(geo);
     PolyPointArgs A;
     A.n = R.n; A.h = R.h; A.w = R.w; A.S = S;
@@ -1006,10 +1012,11 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31) || A.h > 8 * 65535 || 2 * A.n > 65535)
         return hipErrorInvalidValue;   // 32-bit pixel indices, grid limits
     switch (geo) {
-    case 4: return polypoint_launch<256, 4, 5>(A, out, stream);
+    case 3: return polypoint_launch<256, 3, PP_MINW>(A, out, stream);
+    case 4: return polypoint_launch<256, 4, PP_MINW>(A, out, stream);
     case 5: return polypoint_launch<384, 3, 7>(A, out, stream);
     case 6: return polypoint_launch<320, 3, 6>(A, out, stream);
-    default: return polypoint_launch<256, 3, PP_MINW>(A, out, stream);
+    default: return polypoint_launch<256, 4, PP_MINW>(A, out, stream);
     }
 }
 

@@ -1,34 +1,10 @@
 #!/bin/bash
+# k_polypoint with 8-byte point records and four slots per lane (tiles of 768): A/B against HEAD, parity, fuzz
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python - <<'PY'
-import sys, time, ctypes
-sys.path.insert(0,'.')
-import numpy as np, torch
-from comfystereo_amd import _native
-L=_native.lib()
-N=1_600_000_000   # 6.4 GB of float32 per tensor
-codes=np.random.default_rng(0).integers(0,256,N,dtype=np.uint8)
-def fill(t):
-    t0=time.perf_counter(); L.cs_host_expand_u8(codes.ctypes.data, t.data_ptr(), N, 1, 0, 32); return round(N*4/(time.perf_counter()-t0)/1e9,1)
-def thp():
-    d={}
-    for ln in open('/proc/meminfo'):
-        if ln.startswith(('AnonHugePages','MemFree')): d[ln.split(':')[0]]=ln.split()[1]
-    return d
-print(thp())
-kept=[]
-r=[]
-for i in range(6):
-    t=torch.empty(N,dtype=torch.float32); r.append(fill(t)); kept.append(t)
-print("fresh tensors, all kept:", r, thp())
-kept.clear()
-r=[]
-for i in range(6):
-    t=torch.empty(N,dtype=torch.float32); r.append(fill(t)); del t
-print("fresh tensors, released each time:", r, thp())
-r=[]
-for i in range(6):
-    t=torch.empty(N,dtype=torch.float32); r.append(fill(t)); kept.append(t)
-print("kept again:", r, thp())
-print(open('/sys/kernel/mm/transparent_hugepage/enabled').read().strip(), '|', open('/sys/kernel/mm/transparent_hugepage/defrag').read().strip())
-PY
+mkdir -p gpurun_out/s26
+LIBS="comfystereo_amd/libcs_base.so comfystereo_amd/libcomfystereo_hip.so" tools/abn.sh --n 32 --blur 0 --iters 10
+for i in 1 2; do printf "new, 256x3 (PT_VARIANT=3)   "; CS_PT_VARIANT=3 timeout 200 python tools/quick_bench.py --n 32 --blur 0 --iters 10 2>&1 | tail -1 | sed 's/.*: //'; done
+LIBS="comfystereo_amd/libcs_base.so comfystereo_amd/libcomfystereo_hip.so" tools/abn.sh --n 32 --blur 1 --iters 10 --kind blobs
+LIBS="comfystereo_amd/libcs_base.so comfystereo_amd/libcomfystereo_hip.so" tools/abn.sh --n 32 --blur 1 --iters 10 --h 1080 --w 1920 --div 3.5
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py tests/test_gpu_lazy_blur.py tests/test_gpu_chunks.py -x -q -m gpu > gpurun_out/s26/tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/s26/tests.log
+timeout 400 python tools/extended_fuzz.py 240 11000 > gpurun_out/s26/fuzz.log 2>&1; echo "fuzz rc=$?"; tail -2 gpurun_out/s26/fuzz.log
