@@ -382,7 +382,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
             T.out_h = A.h; T.out_w = 2 * A.w;
             T.eye[0].xoff = 0; T.eye[0].yoff = 0; T.eye[1].xoff = A.w; T.eye[1].yoff = 0;
         }
-        if (fill == CS_FILL_POLYLINES_SOFT && halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 6) || (variant >= 13 && variant <= 16)))
+        if (fill == CS_FILL_POLYLINES_SOFT && halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16)))
             e = launch_polypoint(T, halo, rowflag, stream);
         else
             e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, T, halo, rowflag, stream);

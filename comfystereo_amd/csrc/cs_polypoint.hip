@@ -115,7 +115,7 @@ enum { PK_CHAIN = 0u, PK_BRIDGE = 1u };
 template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW>
 __global__ void __launch_bounds__(NT, MINW)
 k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
-            int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode,
+            int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode, int hot_npt,
             PolyPointArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -151,7 +151,9 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // sentinels only matter when the staged range touches the frame border.  Every lane stages SLOTS points j = tid + 256 k;
     // slots beyond the row end re-read the last column and get x = 2w + (j - ns): slot ns IS the right sentinel.
     const int npts = ns + 2;
-    constexpr int NPT = SLOTS * NT + 4;
+    // point records allocated: what the tile can stage (T + 2 S + sentinels, host: polypoint_npt), not every slot -- the
+    // slots past it are only ever the filler beyond the right sentinel and are not stored
+    const int NPT = hot_npt;
     const bool left_edge = s0 == 0, right_edge = s1 == w;
 
     // ---- LDS carve ----
@@ -403,8 +405,10 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             float x = ((jf0 + (float)(k * NT)) + cdj) + E.sep32;                   // coord_x   (:1927)
             // slots beyond the staged range: x = 2w + (j - ns), strictly increasing, slot ns = the right sentinel (:1935)
             x = j < ns ? x : tidf + (float)(2 * w - ns + k * NT);
-            Pw[k * NT] = PQ{rgbk[k], x};
-            pzw[k * NT] = fabsf(cdj);
+            if (SLOTS * NT + 4 == NPT || 1 + j < NPT) {   // (compile-time true for geometries whose every slot is allocated)
+                Pw[k * NT] = PQ{rgbk[k], x};
+                pzw[k * NT] = fabsf(cdj);
+            }
             // reversed segment (j -> j+1)?  The right neighbour sits in the next lane (lane 63: +inf; the pairs across wave
             // chunks and the left sentinel's pair are checked after the barrier).
             const float xn = wave_next(x);
@@ -922,8 +926,14 @@ hipError_t launch_anaglyph_compose(const uint8_t* sbs, const uint8_t* rowflag, i
     return hipGetLastError();
 }
 
-static size_t polypoint_lds(int nt, int slots, int T, int KP, int KS) {
-    const size_t npt = (size_t)slots * nt + 4;
+// point records a workgroup allocates: the staged range of a tile (T + 2 S + 2 source columns), both sentinels and the one
+// filler slot a boundary-pair check may read behind them -- never more than the slots there are
+static int polypoint_npt(int nt, int slots, int T, int S) {
+    const int all = slots * nt + 4, need = ((T + 2 * S + 2 + 2 + 1 + 3) & ~3) + 4;
+    return need < all ? need : all;
+}
+static size_t polypoint_lds(int nt, int slots, int T, int S, int KP, int KS) {
+    const size_t npt = (size_t)polypoint_npt(nt, slots, T, S);
     return 8 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((T + 3) & ~3) + 2 * PP_DCAP * (2 + (size_t)KP + KS) +
            4 * PF_WORDS + 1024 + 64;
 }
@@ -950,9 +960,9 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
     constexpr int KP = 4, KS = 5;
     const int tiles = (A.w + A.T - 1) / A.T;
     dim3 grid(tiles * 8, (A.h + 7) / 8, A.single >= 0 ? A.n : 2 * A.n), block(NT);   // (see the kernel's prologue)
-    size_t lds = polypoint_lds(NT, SLOTS, A.T, KP, KS);
+    size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS);
     // (development: CS_DEBUG_PT_VARIANT 13..16 pads the LDS request so that only 3..6 workgroups fit a CU -- occupancy what-if)
-    const int npt = SLOTS * NT + 4;
+    const int npt = polypoint_npt(NT, SLOTS, A.T, A.S);
     const int off_dflag = 8 * npt + 4 * npt + 4 * (A.T > 128 ? A.T : 128), off_dcnt = off_dflag + ((A.T + 3) & ~3);
     const int pow_mode = (A.dbg == 17 || !(A.e32 == 2.0f || A.e32 == 1.0f)) ? 0 : (A.e32 == 2.0f ? 2 : 1);
     for (int e = 0; e < 2; e++) {
@@ -970,7 +980,7 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
         if (e != hipSuccess) return e;                                                                                       \
         hipLaunchKernelGGL((k_polypoint<NT, SLOTS, O, KP, KS, MINW>), grid, block, lds, stream, A.image_f32, A.eye[0].depth, \
-                           A.eye[1].depth, A.w, A.h, A.S, A.T, A.single, off_dflag, off_dcnt, pow_mode, A);                  \
+                           A.eye[1].depth, A.w, A.h, A.S, A.T, A.single, off_dflag, off_dcnt, pow_mode, npt, A);                  \
     }
     if (out == PO_F32) PP_LAUNCH(PO_F32)
     else if (out == PO_U8) PP_LAUNCH(PO_U8)
@@ -987,9 +997,9 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     // the default; development switch CS_DEBUG_PT_VARIANT: 3 = 256 x 3 (the default until the end of round 3), 4 = 256 x 4,
     // 5 = 384 x 3, 6 = 320 x 3
     const int forced = dev_switch(CS_DEBUG_PT_VARIANT);
-    int geo = (forced >= 3 && forced <= 6) ? forced : 4;
+    int geo = (forced >= 3 && forced <= 7) ? forced : 4;
     auto nt_of = [](int g) { return g == 5 ? 384 : (g == 6 ? 320 : 256); };
-    auto sl_of = [](int g) { return g == 4 ? 4 : 3; };
+    auto sl_of = [](int g) { return g == 4 ? 4 : (g == 7 ? 5 : 3); };
     if (polypoint_tile(R.w, S, nt_of(geo) * sl_of(geo), nt_of(geo)) == 0 && (geo == 3 || geo == 4)) geo = 5;
     const int nt = nt_of(geo), slots = sl_of(geo);
     PolyPointArgs A;
@@ -1016,6 +1026,7 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     case 4: return polypoint_launch<256, 4, PP_MINW>(A, out, stream);
     case 5: return polypoint_launch<384, 3, 7>(A, out, stream);
     case 6: return polypoint_launch<320, 3, 6>(A, out, stream);
+    case 7: return polypoint_launch<256, 5, PP_MINW>(A, out, stream);
     default: return polypoint_launch<256, 4, PP_MINW>(A, out, stream);
     }
 }
