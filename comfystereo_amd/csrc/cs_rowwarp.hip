@@ -1423,7 +1423,9 @@ struct Px3b { uint8_t x, y, z; };
 // ranking and the 3-way merge on ~770 sources out of 14 KB of LDS (8 workgroups per CU) instead of on a whole row out of
 // 50 KB (2 per CU).  Exponents 2 / 1 take the exact shortcuts of cs_math.h.  Results identical to k_hybrid_splat's.
 #define HYT_NT 256
-#define HYT_SLOTS 3
+#ifndef HYT_SLOTS
+#define HYT_SLOTS 4
+#endif
 #define HYT_NPT (HYT_NT * HYT_SLOTS)
 // FUSED (two-eye layouts of the node path): the tile's pixels go straight to the node outputs -- stereoscope value, no-fill
 // mask, this eye's depth-map codes -- and the untouched pixels to the gap list of their row, i.e. everything k_hybrid_out4

@@ -1,5 +1,9 @@
 #!/bin/bash
+# hybrid splat tile: 4 source slots per lane (default now) against 5; parity
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout 600 python -m pytest tests/test_gpu_dropin.py -x -q -m gpu 2>&1 | tail -2
-for m in "node keep" "node release" "host_pageable keep" "host_pageable release"; do python tools/host_probe_r03.py $m 2>&1 | grep "keep \[\|release \["; done
-timeout 600 python tools/node_host_bench.py --n 32 --iters 3 2>&1 | tail -3
+for i in 1 2; do
+  for L in comfystereo_amd/libcomfystereo_hip.so comfystereo_amd/libcs_hyt5.so; do
+    printf "%-28s " "$(basename $L)"; CS_LIB_PATH=$PWD/$L timeout 300 python bench.py --config cfg3 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(round(d['value'],1), 'fps', round(d['ms_per_step'],3), 'ms', 'kernel', round(d['roofline']['kernel_ms'],3))"
+  done
+done
+timeout 900 python -m pytest tests -x -q -m gpu -k "hybrid or cfg3 or fused or fuzz or parity" > gpurun_out/s28_tests.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/s28_tests.log
