@@ -364,7 +364,10 @@ int fwdtile_max_halo() { return (256 * 3 - 64) / 2; }
 // `none` / `naive` / `inverse` through the tile kernel (`naive`: rows it flags in `rowflag` must be redone by the row kernel).  Returns hipErrorNotSupported when the call is not one of its cases (the caller then
 // launches the row kernel).
 hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, uint8_t* rowflag, hipStream_t stream) {
-    constexpr int NT = 256, SLOTS = 3;
+    // source slots per lane: 3 for the pure streaming fills (none / inverse: HBM-bound, wider tiles only cost occupancy: -2..4 %),
+    // 4 for naive / naive_interpolating, whose tiles carry a search window on top of the halo (+13 % / +10 %)
+    constexpr int NT = 256;
+    const int SLOTS = (fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING) ? 4 : 3;
     if (fill != CS_FILL_NONE && fill != CS_FILL_INVERSE && fill != CS_FILL_NAIVE && fill != CS_FILL_NAIVE_INTERPOLATING) return hipErrorNotSupported;
     if (!R.image_f32 || R.out_u8 || R.d64 || R.neyes != 2 || !R.depth_l || !R.depth_r || R.row_list) return hipErrorNotSupported;
     const int S = S0 + (fill == CS_FILL_INVERSE ? 2 : 0);   // (the splat also touches the column right of floor(dest))
@@ -404,10 +407,10 @@ hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, uint8_t* rowflag, 
     const size_t npt = (size_t)NT * SLOTS;
     const size_t lds = npt * 4 + npt * 8 + (npt / 64) * 8 + (fill == CS_FILL_NAIVE_INTERPOLATING ? npt * (4 + 4 + 2 + 1) : 0) + 64;
     const dim3 grid(ntiles * 8, (R.h + 7) / 8, R.n), block(NT);
-    if (fill == CS_FILL_INVERSE) hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_INVERSE>), grid, block, lds, stream, A);
-    else if (fill == CS_FILL_NAIVE) hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_NAIVE>), grid, block, lds, stream, A);
-    else if (fill == CS_FILL_NAIVE_INTERPOLATING) hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_NAIVE_INTERPOLATING>), grid, block, lds, stream, A);
-    else hipLaunchKernelGGL((k_fwdtile<NT, SLOTS, CS_FILL_NONE>), grid, block, lds, stream, A);
+    if (fill == CS_FILL_INVERSE) hipLaunchKernelGGL((k_fwdtile<NT, 3, CS_FILL_INVERSE>), grid, block, lds, stream, A);
+    else if (fill == CS_FILL_NAIVE) hipLaunchKernelGGL((k_fwdtile<NT, 4, CS_FILL_NAIVE>), grid, block, lds, stream, A);
+    else if (fill == CS_FILL_NAIVE_INTERPOLATING) hipLaunchKernelGGL((k_fwdtile<NT, 4, CS_FILL_NAIVE_INTERPOLATING>), grid, block, lds, stream, A);
+    else hipLaunchKernelGGL((k_fwdtile<NT, 3, CS_FILL_NONE>), grid, block, lds, stream, A);
     return hipGetLastError();
 }
 
