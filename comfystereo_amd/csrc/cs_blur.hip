@@ -346,8 +346,16 @@ __global__ void __launch_bounds__(256) k_blur_edges4(BlurArgs A, unsigned long l
 // `thr`: the largest float t with fl(t / den) <= 0.5, so that  clamp(|g| / den, 0, 1) > 0.5  <=>  |g| > thr  (the division
 // is monotone in |g|; NaN fails both); computed on the host by blur_edge_threshold().
 // ---------------------------------------------------------------------------------------------
+#ifndef GE_RB
 #define GE_RB 32
+#endif
+#ifndef GE_WAVES
+#define GE_WAVES 0   // (development: > 0 = amdgpu_waves_per_eu)
+#endif
 static_assert(GE_RB % BLUR_ER4 == 0, "strips are whole summary blocks");
+#if GE_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(GE_WAVES)))
+#endif
 __global__ void __launch_bounds__(64) k_gray_edges(const float* __restrict__ rgb, float* __restrict__ gray, int h, int w,
                                                    uint32_t* stats, float thr, unsigned long long* mask_l,
                                                    unsigned long long* mask_r, size_t plane, int MW, float4* blk, int HB) {
