@@ -53,7 +53,6 @@ struct GwArgs {
 };
 
 struct Px3 { float x, y, z; };
-#define GW_WALK 48
 #ifdef CS_DEV
 #define GW_DEV_IS(n) (A.dbg == (n))
 #else
@@ -96,6 +95,17 @@ __device__ __forceinline__ float gw_div_with(float a, float b, float y1) {   // 
     const float q1 = __builtin_fmaf(r0, y1, q0);
     const float r1 = __builtin_fmaf(-b, q1, a);
     return __builtin_fmaf(r1, y1, q1);
+}
+// inclusive prefix maximum over the 64 lanes of a wave: four row_shr steps inside the rows of 16, then lane 15 / 31 of the
+// lower rows broadcast into the upper ones (DPP; lanes without a source keep their own value)
+__device__ __forceinline__ int wave_incl_max(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3
+    return v;
 }
 __device__ __forceinline__ bool gw_core_ok(float a) { const float m = fabsf(a); return a == 0.0f || (m >= 0x1p-60f && m < 0x1p60f); }
 
@@ -278,23 +288,29 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
         __syncthreads();   // (every read of ndn is done: its storage takes the scan)
         int rightmost = -1;
         for (int i = 0; i < (nt >> 6); i++) rightmost = max(rightmost, ws[16 + i]);
-        // "left nearest filled" of the gap pixels: gaps are a few percent of a row and a few pixels wide, so every gap pixel
-        // walks left over the (final) source map, at most GW_WALK columns; only when some gap is wider than that does the
-        // workgroup run the prefix-max scan over the whole row (adversarial depth: long runs of disconnected pairs)
-        bool unresolved = false;
-        for (int x = tid; x < w; x += nt) {
-            if (sm[x] < 0.0f) {
-                flags[x] |= 1u;
-                int l = x - 1, steps = 0;
-                while (l >= 0 && sm[l] < 0.0f && steps < GW_WALK) { l--; steps++; }
-                if (l >= 0 && sm[l] < 0.0f) unresolved = true;
-                winner[x] = l;   // (-1: no filled column to the left)
-            }
+        // "left nearest filled" of the gap pixels = prefix maximum of (filled ? x : -1).  A wave's lanes hold 64 consecutive
+        // columns per pass, so the prefix inside a chunk is a DPP scan (6 steps), the chunks' totals go through the (now idle)
+        // M array and every chunk takes the maximum of the totals before it -- no dependent LDS walk over the gap (round 2-3:
+        // every gap pixel walked left, up to 48 dependent reads, the wave waiting for its longest gap: 21 % of the kernel at
+        // divergence 8 %), and no whole-row scan for wide gaps
+        int* const ctot = M;         // [chunks] last filled column of chunk c, or -1
+        const int wpb = nt >> 6;     // chunks per pass
+        for (int xb = 0, k = 0; xb < w; xb += nt, k++) {   // (workgroup-uniform trip count: the DPP scan needs whole waves)
+            const int x = xb + tid;
+            const bool gap = x < w && sm[x] < 0.0f;
+            const int f = (x < w && !gap) ? x : -1;
+            const int incl = wave_incl_max(f);
+            if (lane == 63) ctot[k * wpb + wave] = incl;
+            if (gap) { flags[x] |= 1u; winner[x] = incl; }   // (completed below by this same thread)
         }
-        if (__syncthreads_or(unresolved)) {
-            for (int x = tid; x < w; x += nt) winner[x] = !(sm[x] < 0.0f) ? x : -1;
-            __syncthreads();
-            block_scan_inclusive(winner, w, -1, OpMax(), ws);
+        __syncthreads();
+        for (int xb = 0, k = 0; xb < w; xb += nt, k++) {
+            const int c = k * wpb + wave;   // this wave's chunk: the totals of chunks 0 .. c-1 (c <= 121)
+            int t = lane < c ? ctot[lane] : -1;
+            if (c > 64) t = max(t, lane + 64 < c ? ctot[lane + 64] : -1);
+            t = __builtin_amdgcn_readlane(wave_incl_max(t), 63);
+            const int x = xb + tid;
+            if (x < w && sm[x] < 0.0f) winner[x] = max(winner[x], t);   // (-1: no filled column to the left)
         }
         if (GW_DEV_IS(54)) { __syncthreads(); continue; }
         // final source position of column x (gap fill :393-438), then the bilinear taps of the grid_sample round trip (:440-448)
