@@ -260,11 +260,37 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
         for (int x = tid; x < w; x += nt) {
             float z = -1.0f, src = -1.0f;
             if (x > 0 && x < w - 1) {
-                // interior column: the deciding pair of round k has fs == x - k, so its column value is x itself
+                // interior column: the deciding pair of round k has fs == x - k, so its column value is x itself.  The LDS
+                // reads of the four rounds go out together (clamped index, validity applied afterwards): the rounds are
+                // only sequential in the z-test -- the kernel is bound by such dependent chains, not by the instruction count
+                int ii[4];
+                float dlk[4], drk[4];
+                unsigned fgk[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) ii[k] = M[x - k + 7];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const int i = M[x - k + 7];
-                    if (i >= 0) propose(i, (float)x, z, src);
+                    const int j = max(ii[k], 0);
+                    dlk[k] = D[j]; drk[k] = D[j + 1]; fgk[k] = flags[j];
+                }
+                const float cfl = (float)x;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float sw = drk[k] - dlk[k];
+                    const float safe = fabsf(sw) < (float)1e-4 ? 1.0f : sw;
+                    const float num = cfl - dlk[k];
+                    const bool maybe = ii[k] >= 0 && (fgk[k] & 2u) &&
+                                       !((num < 0.0f && safe > 0.0f) || (num > 0.0f && safe < 0.0f) || fabsf(num) >= 1.001f * fabsf(safe));
+                    if (maybe) {
+                        const int i = ii[k];
+                        const float frac = gw_core_ok(num) ? gw_div_core(num, safe) : num / safe;
+                        const bool valid = frac >= 0.0f && frac < 1.0f;
+                        const float iz = ndn[i] * (1.0f - frac) + ndn[i + 1] * frac;
+                        if (valid && iz > z + (float)1e-6) {
+                            z = iz;
+                            src = (float)i + frac;
+                        }
+                    }
                 }
             } else {
                 // the clamped columns: the deciding pair's own fs + k decides whether it is in range at all
