@@ -299,3 +299,25 @@ def test_compact_u8_stereoscope_expands_to_the_float_output(engine, fill, mode):
     assert torch.equal(engine.expand_u8(out[0]), ref[0])
     for k in (1, 2, 3):
         assert torch.equal(out[k], ref[k])
+
+
+@pytest.mark.parametrize("w,div_px", [(3000, 240.0), (1920, -200.0), (700, 150.0), (130, 90.0)])
+def test_forward_warp_wide_gaps_vs_oracle(engine, w, div_px):
+    """Disocclusion gaps wider than a wave's 64-column chunk, gaps that start at column 0 (no filled column to the left) and
+    rows that are mostly gap: the left-nearest filled column comes from a DPP prefix maximum per chunk plus the chunk totals
+    (cs_gpuwarp.hip wave_incl_max); 1024-, 512- and 256-thread workgroups (3, 4 and 3 passes over the row)."""
+    rs = np.random.RandomState(31)
+    b, h = 2, 5
+    img = rs.rand(b, 3, h, w).astype(np.float32)
+    depth = np.zeros((b, h, w), np.float32)
+    depth[:, 0] = (np.arange(w) > w // 3).astype(np.float32)                 # one step: one gap of |div_px| / 4 .. / 2 columns
+    depth[:, 1] = ((np.arange(w) // 97) % 2).astype(np.float32)              # alternating plateaus: a gap at every other edge
+    depth[:, 2] = np.clip(np.arange(w) / (0.3 * w), 0, 1)                    # ramp then flat: stretching, no gap
+    depth[:, 3] = (rs.rand(w) > 0.5).astype(np.float32)                      # noise: mostly gaps
+    depth[:, 4] = 1.0 - (np.arange(w) > 40).astype(np.float32)               # a step next to the left border
+    depth[1] = depth[1, :, ::-1]
+    for e, conv in ((2.0, 0.5), (1.0, 0.0), (0.5, 1.0)):
+        want, wmask = oracle.forward_warp_gpu(img, depth, div_px, 1.5, e, conv)
+        got, gmask = engine.forward_warp(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda(), div_px, 1.5, e, conv)
+        assert np.array_equal(gmask.cpu().numpy(), wmask), (w, div_px, e)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-6)
