@@ -674,9 +674,12 @@ __global__ void __launch_bounds__(256) k_blur_classify(BlurArgs A, const unsigne
 
 // k_blur_fused: persistent workgroups over the tiles of `worklist` (work_count entries, packed frame | tile row | tile
 // column); worklist == nullptr: plain grid over all tiles (blockIdx = tile).
+// `tstat` (worklist form): the tile's output extremes {min L, max L, min R, max R} per wave, 4 x float4 per worklist entry --
+// k_blur_tile_stats folds them into the frame statistics afterwards (two workgroup reductions with four barriers and the
+// atomic pre-checks per tile were 10 % of this kernel)
 __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigned long long* mask_l,
                                                     const unsigned long long* mask_r, int MW, const uint32_t* work_count,
-                                                    const uint32_t* worklist) {
+                                                    const uint32_t* worklist, float4* tstat) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         // weight as a function of the nearest-edge distance d = 0 .. R (d >= R: clamp(1 - d/R) == 0), once per workgroup
@@ -697,7 +700,7 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
         }
         __syncthreads();
     }
-    auto tile = [&](const int x0, const int y0, const int frame) {
+    auto tile = [&](const int x0, const int y0, const int frame, float4* tile_stat) {
         const int w = A.w, h = A.h, v = A.vert, bs = A.bs, pad = A.bs / 2, R = A.radius;
         const int WR = BLUR_TR + 2 * v;          // weight rows: frame rows y0 - v ..
         const int EW = BLUR_TW + 2 * R;          // edge columns: frame cols x0 - R ..
@@ -745,7 +748,10 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
                     mn = fminf(mn, dvv); mx = fmaxf(mx, dvv);
                 }
             }
-            if (A.stats_rw) {
+            if (A.stats_rw && tile_stat) {
+                mn = wave_min(mn); mx = wave_max(mx);
+                if (lane == 0) tile_stat[wave] = make_float4(mn, mx, mn, mx);
+            } else if (A.stats_rw) {
                 __shared__ float red2[2 * 16];
                 uint32_t* st = A.stats_rw + frame * ST_WORDS;
                 block_minmax_update(mn, mx, &st[ST_L_MIN], &st[ST_L_MAX], red2);
@@ -887,7 +893,10 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
                 }
             }
         }
-        if (A.stats_rw) {
+        if (A.stats_rw && tile_stat) {
+            lmin = wave_min(lmin); lmax = wave_max(lmax); rmin = wave_min(rmin); rmax = wave_max(rmax);
+            if (lane == 0) tile_stat[wave] = make_float4(lmin, lmax, rmin, rmax);
+        } else if (A.stats_rw) {
             __shared__ float red[2 * 16];
             uint32_t* st = A.stats_rw + frame * ST_WORDS;
             block_minmax_update(lmin, lmax, &st[ST_L_MIN], &st[ST_L_MAX], red);
@@ -895,15 +904,35 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
         }
     };
     if (!worklist) {
-        tile(blockIdx.x * BLUR_TW, blockIdx.y * BLUR_TR, blockIdx.z);
+        tile(blockIdx.x * BLUR_TW, blockIdx.y * BLUR_TR, blockIdx.z, nullptr);
         return;
     }
     const uint32_t count = *work_count;
     for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
         const uint32_t e = worklist[i];
-        tile((int)(e & 1023u) * BLUR_TW, (int)((e >> 10) & 1023u) * BLUR_TR, (int)(e >> 20));
+        tile((int)(e & 1023u) * BLUR_TW, (int)((e >> 10) & 1023u) * BLUR_TR, (int)(e >> 20), tstat ? tstat + 4 * (size_t)i : nullptr);
         __syncthreads();  // the tile's LDS is reused by the next one
     }
+}
+
+// The listed tiles' output extremes -> the frame statistics: workgroup (b, frame) folds the entries of its frame among every
+// gridDim.x-th slice of the worklist, then one pair of pre-checked atomics per workgroup.
+__global__ void __launch_bounds__(256) k_blur_tile_stats(const uint32_t* work_count, const uint32_t* worklist, const float4* tstat,
+                                                         uint32_t* stats) {
+    __shared__ float red[2 * 16];
+    const uint32_t count = *work_count, frame = blockIdx.y;
+    float lmin = INFINITY, lmax = -INFINITY, rmin = INFINITY, rmax = -INFINITY;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
+        if ((worklist[i] >> 20) != frame) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float4 q = tstat[4 * (size_t)i + k];
+            lmin = fminf(lmin, q.x); lmax = fmaxf(lmax, q.y); rmin = fminf(rmin, q.z); rmax = fmaxf(rmax, q.w);
+        }
+    }
+    uint32_t* st = stats + frame * ST_WORDS;
+    block_minmax_update(lmin, lmax, &st[ST_L_MIN], &st[ST_L_MAX], red);
+    block_minmax_update(rmin, rmax, &st[ST_R_MIN], &st[ST_R_MAX], red);
 }
 
 int blur_tilemap_words(int w) { return ((w + BLUR_TW - 1) / BLUR_TW + 31) / 32 + 1; }
@@ -993,7 +1022,7 @@ static BlurPlan blur_plan(int n, int h, int w, double strength, double mask_widt
     P.gy = (h + BLUR_TR - 1) / BLUR_TR; P.gx = (w + BLUR_TW - 1) / BLUR_TW; P.HB = (h + BLUR_ER4 - 1) / BLUR_ER4;
     P.plane_bytes = ((size_t)n * h * P.MW * 8 + 255) & ~(size_t)255;
     P.mask_bytes = P.plane_bytes * planes;
-    P.list_bytes = 256 + (size_t)n * P.gy * P.gx * 4;
+    P.list_bytes = 256 + (size_t)n * P.gy * P.gx * (4 + 64);   // counter, worklist, then 4 x float4 of output extremes per entry
     P.blk_bytes = (size_t)n * P.HB * P.MW * 16;
     P.listed = P.fused && (w & 3) == 0 && P.gx < 1024 && P.gy < 1024 && n < 4096 && P.mask_bytes + P.list_bytes <= (size_t)n * h * w * 4;
     // lazy mode: block summaries behind the second bit-row buffer
@@ -1089,11 +1118,15 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
             }
             const size_t total = (size_t)n * gy * gx;
             const int pg = (int)(total < 2048 ? total : 2048);
+            float4* tstat = A.stats_rw ? reinterpret_cast<float4*>(reinterpret_cast<char*>(worklist) + ((total * 4 + 15) & ~(size_t)15)) : nullptr;
             hipLaunchKernelGGL(k_blur_fused, dim3(pg), dim3(256), ldsF, stream, A, (const unsigned long long*)mask_l,
-                               (const unsigned long long*)mask_r, MW, (const uint32_t*)work_count, (const uint32_t*)worklist);
+                               (const unsigned long long*)mask_r, MW, (const uint32_t*)work_count, (const uint32_t*)worklist, tstat);
+            if (tstat)
+                hipLaunchKernelGGL(k_blur_tile_stats, dim3(4, n), dim3(256), 0, stream, (const uint32_t*)work_count,
+                                   (const uint32_t*)worklist, (const float4*)tstat, A.stats_rw);
         } else {
             hipLaunchKernelGGL(k_blur_fused, dim3(gx, gy, n), dim3(256), ldsF, stream, A, (const unsigned long long*)mask_l,
-                               (const unsigned long long*)mask_r, MW, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                               (const unsigned long long*)mask_r, MW, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (float4*)nullptr);
         }
         return CS_OK;
     }
