@@ -179,6 +179,7 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
         const float* drow = E.depth + ((size_t)frame * h + y) * w;
         // ---- pass 1: normalised depth, pixel offset, x + offset (:300-328); four columns per thread with their loads first
         const float yr = crange_ok ? gw_rcp_refined(crange) : 0.0f;   // several numerators over one denominator
+        float* const depth_out = !A.depth_l ? nullptr : (e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + y) * w) * 3;
         for (int xb = tid; xb < w; xb += 4 * nt) {
             float dv[4];
 #pragma unroll
@@ -191,6 +192,10 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
                 if (div255) {
                     asm volatile("" ::: "memory");   // (a real branch: the division is not worth speculating)
                     v = v / 255.0f;
+                }
+                if (depth_out) {   // this eye's depth-map output (see the end of the kernel)
+                    const float vo = A.noclamp ? v : fminf(fmaxf(v, 0.0f), 1.0f);
+                    *reinterpret_cast<Px3*>(depth_out + 3 * x) = Px3{vo, vo, vo};
                 }
                 const float num = v - dmin;
                 float nrm = (crange_ok && gw_core_ok(num)) ? gw_div_with(num, crange, yr) : num / crange;
@@ -417,9 +422,12 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
     if (A.mask_f32)
         for (int x = tid; x < w; x += nt) A.mask_f32[((size_t)frame * h + y) * w + x] = (flags[x] & 1u) ? 1.0f : 0.0f;
     if (A.depth_l) {
-        // left_depth / 255 if its (sub-batch) max > 1 (:1125-1126), clamp(0,1), 3 channels (GenerateStereo.py:165-168)
+        // left_depth / 255 if its (sub-batch) max > 1 (:1125-1126), clamp(0,1), 3 channels (GenerateStereo.py:165-168).
+        // Eyes that ran the warp wrote theirs in pass 1, where the depth is in registers anyway (and the stores overlap
+        // with the rest of the row's work); here: the eyes the loop above skipped (eye = source image, or a single-eye call)
         for (int e = 0; e < 2; e++) {
             const GwEye& E = A.eye[e];
+            if (e < A.neyes && E.enabled) continue;
             const bool div255 = st[E.st_div] != 0;
             const float* drow = E.depth + ((size_t)frame * h + y) * w;
             float* dst = (e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + y) * w) * 3;
