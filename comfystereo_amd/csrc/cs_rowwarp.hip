@@ -1495,14 +1495,25 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
     const bool range_ok = range > 0x1p-40f && range < 0x1p40f;
     const float yr = range_ok ? rcp_refined(range) : 0.0f;
     __syncthreads();
-    for (int j = tid; j < ns; j += HYT_NT) {
+    // all global loads of the lane's sources first (clamped index: no branches), one memory round trip for the four slots
+    Px3f pxv[HYT_SLOTS];
+    float dpv[HYT_SLOTS];
+#pragma unroll
+    for (int k = 0; k < HYT_SLOTS; k++) {
+        const int jc = min(tid + k * HYT_NT, ns - 1);
+        pxv[k] = *reinterpret_cast<const Px3f*>(A.image_f32 + (rowpix + s0 + jc) * 3);
+        dpv[k] = drow[s0 + jc];
+    }
+#pragma unroll
+    for (int k = 0; k < HYT_SLOTS; k++) {
+        const int j = tid + k * HYT_NT;
+        if (j >= ns) break;
         const int x = s0 + j;
-        const float* px = A.image_f32 + (rowpix + x) * 3;
-        const uint32_t r = (uint32_t)(int)fminf(fmaxf(px[0] * 255.0f, 0.0f), 255.0f);
-        const uint32_t g = (uint32_t)(int)fminf(fmaxf(px[1] * 255.0f, 0.0f), 255.0f);
-        const uint32_t b = (uint32_t)(int)fminf(fmaxf(px[2] * 255.0f, 0.0f), 255.0f);
+        const uint32_t r = (uint32_t)(int)fminf(fmaxf(pxv[k].x * 255.0f, 0.0f), 255.0f);
+        const uint32_t g = (uint32_t)(int)fminf(fmaxf(pxv[k].y * 255.0f, 0.0f), 255.0f);
+        const uint32_t b = (uint32_t)(int)fminf(fmaxf(pxv[k].z * 255.0f, 0.0f), 255.0f);
         img[j] = r | g << 8 | b << 16;
-        const float d = drow[x] * scale;
+        const float d = dpv[k] * scale;
         if (FUSED) dcode[j] = csm::f32_to_u8_wrap(d * 255.0f);   // (no global load in the output loop: its latency is exposed there)
         // (d - dmin) / range through the refined reciprocal of the frame's range (cs_common.h div_with: the IEEE quotient for
         // numerators that are 0 or >= 2^-60 and a range within 2^+-40; anything else takes the full division, wave-uniformly)
