@@ -1936,6 +1936,42 @@ __global__ void __launch_bounds__(64) k_hybrid_gaps(RowArgs A, const uint32_t* _
         float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
         double wt = 0.0, gc = 0.0;
         bool have = false;
+        if (PACKED && A.image_f32) {
+            // node path: the eight neighbour records first, then the source pixels of the whole window (clamped coordinates,
+            // nine 12-byte loads in flight), then the sums in the reference's raster order out of registers -- the loop
+            // below waits for two dependent global loads per touched neighbour, one after the other
+            uint32_t pkv[9];
+            const uint32_t* rec = reinterpret_cast<const uint32_t*>(A.hyb_base) + (((size_t)frame * A.neyes + e) * h) * (size_t)w;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int ni = row + k / 3 - 1, nj = j + k % 3 - 1;
+                const bool in = k != 4 && ni >= 0 && ni < h && nj >= 0 && nj < w;
+                const uint32_t v = rec[(size_t)min(max(ni, 0), h - 1) * w + min(max(nj, 0), w - 1)];
+                pkv[k] = in ? v : 0u;
+            }
+            Px3f gv[9];
+            const float* im = A.image_f32 + ((size_t)frame * h) * (size_t)w * 3;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int ni = min(max(row + k / 3 - 1, 0), h - 1), nj = min(max(j + k % 3 - 1, 0), w - 1);
+                gv[k] = *reinterpret_cast<const Px3f*>(im + ((size_t)ni * w + nj) * 3);
+            }
+            auto code = [](float v) { return (double)(uint8_t)(int)fminf(fmaxf(v * 255.0f, 0.0f), 255.0f); };
+            auto guid = [&](const Px3f& p) { return (0.299 * code(p.x) + 0.587 * code(p.y)) + 0.114 * code(p.z); };
+            gc = guid(gv[4]);
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                if (k == 4 || (pkv[k] >> 24) == 0u) continue;
+                const double w_s = (k & 1) ? CS_EXP_M05 : CS_EXP_M10;
+                const double diff = gc - guid(gv[k]);
+                const double wg = w_s * csm::exp_exact(-(diff * diff) / 200.0, d_hyb_exp_tab);
+                const float wg32 = (float)wg;
+                n0 = n0 + (float)(pkv[k] & 0xffu) * wg32;
+                n1 = n1 + (float)((pkv[k] >> 8) & 0xffu) * wg32;
+                n2 = n2 + (float)((pkv[k] >> 16) & 0xffu) * wg32;
+                wt += wg;
+            }
+        } else
 #pragma unroll
         for (int k = 0; k < 9; k++) {   // the reference's raster order over the window (:1757-1770)
             if (k == 4) continue;
