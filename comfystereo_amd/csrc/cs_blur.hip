@@ -734,9 +734,11 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
             mL[item] = bl; mR[item] = br;
             if (bl | br) *any_edge = 1;
         }
-        __syncthreads();
+        // (worklist form: k_blur_classify listed the tile BECAUSE an edge is within reach -- no test, no barrier here, and the
+        // loads of the depth tile below overlap with the loads of the bit rows above)
+        if (!worklist) __syncthreads();
         if (A.dbg == 21) return;
-        if (*any_edge == 0 && A.fall_mode != 5) {
+        if (!worklist && *any_edge == 0 && A.fall_mode != 5) {
             // no edge within reach of the tile: every weight is exactly 0, so 0*blur + (1-0)*depth == depth
             float mn = INFINITY, mx = -INFINITY;
             for (int i = tid; i < BLUR_TR * BLUR_TW; i += 256) {
