@@ -734,11 +734,9 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
             mL[item] = bl; mR[item] = br;
             if (bl | br) *any_edge = 1;
         }
-        // (worklist form: k_blur_classify listed the tile BECAUSE an edge is within reach -- no test, no barrier here, and the
-        // loads of the depth tile below overlap with the loads of the bit rows above)
-        if (!worklist) __syncthreads();
+        __syncthreads();   // (the bit-row windows are read by every thread in step 3)
         if (A.dbg == 21) return;
-        if (!worklist && *any_edge == 0 && A.fall_mode != 5) {
+        if (*any_edge == 0 && A.fall_mode != 5) {
             // no edge within reach of the tile: every weight is exactly 0, so 0*blur + (1-0)*depth == depth
             float mn = INFINITY, mx = -INFINITY;
             for (int i = tid; i < BLUR_TR * BLUR_TW; i += 256) {
