@@ -655,7 +655,10 @@ static int generate_chunk(const cs_params* p, const float* image, const float* d
         // does hybrid_edge: +0.32 ms per 16 frames in the f64-bound tile splat against 0.26 ms of copy.)
         const bool tile_fill = p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP || p->fill == CS_FILL_NONE ||
                                p->fill == CS_FILL_INVERSE || p->fill == CS_FILL_NAIVE || p->fill == CS_FILL_NAIVE_INTERPOLATING;
-        const bool want_lazy = tile_fill && !(p->flags & 24) && !dev_switch(CS_DEBUG_NO_TILE) && !dev_switch(CS_DEBUG_BLUR_FULL_COPY) &&
+        // gpu_warp (scatter-round warp, rows of at most 2048 columns) reads the map too since the end of round 3: the kernel is
+        // bound by its dependent chains, not by its instruction count -- the selector costs less than the copy of the tiles
+        const bool warp_lazy = gpu_warp && !(p->flags & 4) && w <= gpuwarp_lazy_max_width() && !dev_switch(CS_DEBUG_GPUWARP_FULL_MAPS);
+        const bool want_lazy = (tile_fill || warp_lazy) && !(p->flags & 24) && !dev_switch(CS_DEBUG_NO_TILE) && !dev_switch(CS_DEBUG_BLUR_FULL_COPY) &&
                                p->mode != CS_MODE_LEFT_ONLY && p->mode != CS_MODE_ONLY_RIGHT &&
                                al256((size_t)n * hw * 4) < (1ull << 32) - (1u << 20);
         rc = launch_blur(gray, n, h, w, p->depth_blur_strength, p->depth_blur_edge_threshold, p->depth_blur_strength, p->depth_blur_falloff,
@@ -676,7 +679,8 @@ static int generate_chunk(const cs_params* p, const float* image, const float* d
     ProfScope prof(stream);
     if (gpu_warp) {
         rc = launch_gpuwarp_node(p, image, dL, dR, scale_from_stats, stats, stereo, depth_l, depth_r, mask, out_h, out_w,
-                                 ws + W.extra, stream);
+                                 ws + W.extra, stream, lazy ? (const uint32_t*)(ws + W.tilemap) : nullptr, lazy ? gray : nullptr,
+                                 lazy ? blur_tilemap_words(w) : 0);
         if (rc) return fail(rc, "gpu_warp launch failed");
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? CS_OK : fail_hip(e, "cs_generate");

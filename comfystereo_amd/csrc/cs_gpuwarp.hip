@@ -50,6 +50,9 @@ struct GwArgs {
     float grad_thr;    // mesh: gradient_threshold of the triangle culling (reference :455, 1.5)
     uint8_t* keep;     // mesh: [neyes][groups][h-1][w-1] keep bits (bit 0 triangle A, bit 1 triangle B)
     int group;         // mesh: frames per group (the tensor forward_warp_mesh is handed)
+    // lazy depth-blur tiles (cs_common.h lazy_select; rows of at most 2048 columns, scatter-round warp only): the blurred maps
+    // only hold the tiles the map names, everything else is gray * (the frame's x255 scale)
+    const uint32_t* tilemap; const float* gray; int tm_words;
 };
 
 struct Px3 { float x, y, z; };
@@ -154,6 +157,17 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
     const float ysx = sxw_ok ? gw_rcp_refined(sxw) : 0.0f;
     const bool interleaved = A.img_sc == 1 && A.img_sx == 3 && A.out_sc == 1 && A.out_sx == 3;
 
+    // lazy depth-blur tiles: both eyes' selectors up front (their scalar loads overlap with the set-up above instead of
+    // standing in front of each eye's depth loads)
+    const bool lazy = A.tilemap != nullptr;
+    LazySel Z0, Z1;
+    Z0.base = Z1.base = nullptr; Z0.bits = Z1.bits = 0; Z0.delta = Z1.delta = 0; Z0.mul_set = Z1.mul_set = Z0.mul_clr = Z1.mul_clr = 0;
+    if (lazy) {
+        const char* grow = reinterpret_cast<const char*>(A.gray + ((size_t)frame * h + y) * w);
+        Z0 = lazy_select(A.tilemap, A.tm_words, frame, h, y, 0, reinterpret_cast<const char*>(A.eye[0].depth + ((size_t)frame * h + y) * w), grow, st[ST_SCALE255]);
+        if (A.neyes > 1)
+            Z1 = lazy_select(A.tilemap, A.tm_words, frame, h, y, 0, reinterpret_cast<const char*>(A.eye[1].depth + ((size_t)frame * h + y) * w), grow, st[ST_SCALE255]);
+    }
     for (int e = 0; e < A.neyes; e++) {
         const GwEye& E = A.eye[e];
         if (!E.enabled) {
@@ -177,18 +191,25 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
         const float* const img_row1 = A.image + frame * A.img_sf + iy1 * A.img_sy;
         float* const out_row = A.out + frame * A.out_sf + (y + E.yoff) * A.out_sy + E.xoff * A.out_sx;
         const float* drow = E.depth + ((size_t)frame * h + y) * w;
+        LazySel Z;   // (field by field: an aggregate select of two structs may go through scratch memory)
+        Z.base = e ? Z1.base : Z0.base; Z.bits = e ? Z1.bits : Z0.bits; Z.delta = e ? Z1.delta : Z0.delta;
+        Z.mul_set = e ? Z1.mul_set : Z0.mul_set; Z.mul_clr = e ? Z1.mul_clr : Z0.mul_clr;
         // ---- pass 1: normalised depth, pixel offset, x + offset (:300-328); four columns per thread with their loads first
         const float yr = crange_ok ? gw_rcp_refined(crange) : 0.0f;   // several numerators over one denominator
         float* const depth_out = !A.depth_l ? nullptr : (e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + y) * w) * 3;
         for (int xb = tid; xb < w; xb += 4 * nt) {
-            float dv[4];
+            float dv[4], dm[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) dv[u] = xb + u * nt < w ? drow[xb + u * nt] : 0.0f;
+            for (int u = 0; u < 4; u++) {
+                const int x = min(xb + u * nt, w - 1);
+                dm[u] = scale;
+                dv[u] = lazy ? lazy_load(Z, (uint32_t)x, (uint32_t)x, dm[u]) : drow[x];
+            }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int x = xb + u * nt;
                 if (x >= w) continue;
-                float v = dv[u] * scale;
+                float v = dv[u] * dm[u];
                 if (div255) {
                     asm volatile("" ::: "memory");   // (a real branch: the division is not worth speculating)
                     v = v / 255.0f;
@@ -431,15 +452,22 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
             const bool div255 = st[E.st_div] != 0;
             const float* drow = E.depth + ((size_t)frame * h + y) * w;
             float* dst = (e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + y) * w) * 3;
+            LazySel Z;
+            if (A.tilemap) Z = lazy_select(A.tilemap, A.tm_words, frame, h, y, 0, reinterpret_cast<const char*>(drow),
+                                           reinterpret_cast<const char*>(A.gray + ((size_t)frame * h + y) * w), st[ST_SCALE255]);
             for (int xb = tid; xb < w; xb += 4 * nt) {   // (loads first; /255 behind a real branch)
-                float dv[4];
+                float dv[4], dm[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) dv[u] = xb + u * nt < w ? drow[xb + u * nt] : 0.0f;
+                for (int u = 0; u < 4; u++) {
+                    const int x = min(xb + u * nt, w - 1);
+                    dm[u] = scale;
+                    dv[u] = A.tilemap ? lazy_load(Z, (uint32_t)x, (uint32_t)x, dm[u]) : drow[x];
+                }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int x = xb + u * nt;
                     if (x >= w) continue;
-                    float v = dv[u] * scale;
+                    float v = dv[u] * dm[u];
                     if (div255) {
                         asm volatile("" ::: "memory");
                         v = v / 255.0f;
@@ -794,7 +822,7 @@ int launch_gpuwarp_plain(const float* image, const float* depth, int n, int h, i
 
 int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL, const float* dR, int scale_from_stats,
                         uint32_t* stats, float* stereo, float* depth_l, float* depth_r, float* mask, int out_h,
-                        int out_w, void* extra, hipStream_t stream) {
+                        int out_w, void* extra, hipStream_t stream, const uint32_t* tilemap, const float* gray, int tm_words) {
     const int n = p->n, h = p->h, w = p->w;
     int group = p->batch_size > 0 ? (p->batch_size < n ? p->batch_size : n) : n;
     hipLaunchKernelGGL(k_gpuwarp_flags, dim3((n + 63) / 64), dim3(64), 0, stream, stats, n, group);
@@ -834,7 +862,10 @@ int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL,
     A.noclamp = p->flags & 1;
     A.dbg = dev_switch(CS_DEBUG_DBG);
     A.mesh = (p->flags & 4) ? 1 : 0; A.grad_thr = 1.5f; A.keep = (uint8_t*)extra + 256; A.group = group;
+    if (tilemap && (A.mesh || w > gpuwarp_lazy_max_width())) return CS_EINVAL;   // (the caller asked gpuwarp_lazy_max_width)
+    A.tilemap = tilemap; A.gray = gray; A.tm_words = tm_words;
     return gw_launch(A, stream);
 }
+int gpuwarp_lazy_max_width() { return 2048; }   // one lazy selector = 32 tiles of 64 columns
 
 }  // namespace cs

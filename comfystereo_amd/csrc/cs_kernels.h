@@ -141,6 +141,9 @@ int launch_gpuwarp_plain(const float* image, const float* depth, int n, int h, i
                          void* workspace, hipStream_t stream, int mesh = 0, double grad_thr = 1.5);
 int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL, const float* dR, int scale_from_stats,
                         uint32_t* stats, float* stereo, float* depth_l, float* depth_r, float* mask, int out_h,
-                        int out_w, void* workspace, hipStream_t stream);
+                        int out_w, void* workspace, hipStream_t stream, const uint32_t* tilemap = nullptr,
+                        const float* gray = nullptr, int tm_words = 0);
+// lazy depth-blur tiles in k_gpuwarp (tilemap != nullptr): rows of at most this many columns, not the mesh-quality warp
+int gpuwarp_lazy_max_width();
 
 }  // namespace cs

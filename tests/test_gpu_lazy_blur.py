@@ -176,3 +176,26 @@ def test_lazy_odd_shapes_and_resized_depth(engine, dev_switch, shape):
                                         depth_blur_falloff=2.0, depth_blur_vert_smooth=6)
             for k in range(4):
                 assert np.array_equal(lazy[k], want[k]), (shape, k)
+
+
+@pytest.mark.parametrize("mode,balance", [("left-right", 0.0), ("top-bottom", 0.3), ("red-cyan-anaglyph", 0.0), ("left-right", 1.0)])
+def test_gpu_warp_reads_the_tile_map(engine, dev_switch, mode, balance):
+    """gpu_warp (rows of at most 2048 columns) reads the lazy tiles as well (cs_gpuwarp.hip pass 1; stereo_balance 1: one eye is
+    the source image and its depth map is written by the tail loop): identical bits with complete maps
+    (cs_debug_set(CS_DEBUG_GPUWARP_FULL_MAPS, 1)), mask equal to the oracle's, colours within the gpu_warp tolerance."""
+    n, h, w = 3, 70, 1284
+    img = synth.image_f32(n, h, w, seed=21)
+    depth = synth.depth_batch("blobs", n, h, w, channels=3).astype(np.float32)
+    depth[1] *= 255.0   # the x255 decision is taken over the sub-batch (reference :1045): these three frames stay unscaled
+    args = (5.0, 0.5, mode, balance, 0.5, 2.0)
+    lazy = [o.cpu().numpy() for o in engine.generate(cuda(img), cuda(depth), *args, "gpu_warp", 20.0, 20.0, True,
+                                                     depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=3)]
+    dev_switch("gpuwarp_full_maps", 1)
+    full = [o.cpu().numpy() for o in engine.generate(cuda(img), cuda(depth), *args, "gpu_warp", 20.0, 20.0, True,
+                                                     depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=3)]
+    for k, (a, b) in enumerate(zip(lazy, full)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (mode, balance, k)
+    want = node_oracle.generate(img, depth, *args, "GPU Warp (Fast)", 20.0, 20.0, True, depth_blur_falloff=2.0,
+                                depth_blur_vert_smooth=6, batch_size=3)
+    assert np.array_equal(lazy[3], want[3]) and np.array_equal(lazy[1], want[1]) and np.array_equal(lazy[2], want[2])
+    assert np.abs(lazy[0] - want[0]).max() <= 1e-4
