@@ -35,7 +35,8 @@ EXPORTS = [
 
 # enum cs_debug_key (development switches; tests and profiling tools only)
 DEBUG = {"dbg": 0, "no_tile": 1, "pt_variant": 2, "blur_two_pass": 3, "blur_edges_scalar": 4, "blur_full_copy": 5, "chunks": 6, "no_replay_kernel": 7,
-         "blur_no_pre_edges": 8, "hybrid_unfused": 9, "gpuwarp_full_maps": 10}
+         "blur_no_pre_edges": 8, "hybrid_unfused": 9, "gpuwarp_full_maps": 10,
+         "hybrid_full_maps": 11}
 
 
 class Params(ctypes.Structure):

@@ -658,7 +658,13 @@ static int generate_chunk(const cs_params* p, const float* image, const float* d
         // gpu_warp (scatter-round warp, rows of at most 2048 columns) reads the map too since the end of round 3: the kernel is
         // bound by its dependent chains, not by its instruction count -- the selector costs less than the copy of the tiles
         const bool warp_lazy = gpu_warp && !(p->flags & 4) && w <= gpuwarp_lazy_max_width() && !dev_switch(CS_DEBUG_GPUWARP_FULL_MAPS);
-        const bool want_lazy = (tile_fill || warp_lazy) && !(p->flags & 24) && !dev_switch(CS_DEBUG_NO_TILE) && !dev_switch(CS_DEBUG_BLUR_FULL_COPY) &&
+        // hybrid_edge through the fused splat tile kernel (two-eye layouts): the same; the disabled-eye path and the unfused
+        // forms read complete maps, so the map is only used when both eyes run
+        const bool two_eyes = !(p->divergence * (1 + p->stereo_balance) < 0.001) && !(p->divergence * (1 - p->stereo_balance) < 0.001);
+        const bool ana = p->mode == CS_MODE_RED_CYAN_ANAGLYPH || p->mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH;
+        const bool hyb_lazy = p->fill == CS_FILL_HYBRID_EDGE && two_eyes && !dev_switch(CS_DEBUG_HYBRID_FULL_MAPS) &&
+                              hybrid_fused_ok(n, w, halo, ana, -1, (p->flags >> 3) & 3, 0);
+        const bool want_lazy = (tile_fill || warp_lazy || hyb_lazy) && !(p->flags & 24) && !dev_switch(CS_DEBUG_NO_TILE) && !dev_switch(CS_DEBUG_BLUR_FULL_COPY) &&
                                p->mode != CS_MODE_LEFT_ONLY && p->mode != CS_MODE_ONLY_RIGHT &&
                                al256((size_t)n * hw * 4) < (1ull << 32) - (1u << 20);
         rc = launch_blur(gray, n, h, w, p->depth_blur_strength, p->depth_blur_edge_threshold, p->depth_blur_strength, p->depth_blur_falloff,

@@ -128,6 +128,7 @@ hipError_t launch_lazy_rows(const uint32_t* list, const uint32_t* count, int tot
 
 // cs_rowwarp.hip (hybrid_edge: k_hybrid_splat + the fill pass of k_rowwarp)
 size_t hybrid_workspace_bytes(int n, int h, int w);
+bool hybrid_fused_ok(int n, int w, int halo, int anaglyph, int single, int d64, int plus);
 int hybrid_max_width();
 int launch_hybrid(const RowArgs& A, void* workspace, hipStream_t stream, int plus = 0, int halo = -1);  // plus: hybrid_edge_plus; halo >= 0: bound of |offset| (tile splat)
 

@@ -1502,7 +1502,22 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
     for (int k = 0; k < HYT_SLOTS; k++) {
         const int jc = min(tid + k * HYT_NT, ns - 1);
         pxv[k] = *reinterpret_cast<const Px3f*>(A.image_f32 + (rowpix + s0 + jc) * 3);
-        dpv[k] = drow[s0 + jc];
+    }
+    float dmul[HYT_SLOTS];
+    if (FUSED && A.tilemap) {   // lazy depth-blur tiles (cs_common.h): edge-free tiles come from the gray depth, times the x255 scale
+        const LazySel Z = lazy_select(A.tilemap, A.tm_words, frame, h, row, s0, reinterpret_cast<const char*>(drow + s0),
+                                      reinterpret_cast<const char*>(A.lazy_gray + rowpix + s0), st[ST_SCALE255]);
+#pragma unroll
+        for (int k = 0; k < HYT_SLOTS; k++) {
+            const int jc = min(tid + k * HYT_NT, ns - 1);
+            dpv[k] = lazy_load(Z, (uint32_t)(s0 + jc), (uint32_t)jc, dmul[k]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < HYT_SLOTS; k++) {
+            dmul[k] = scale;
+            dpv[k] = drow[s0 + min(tid + k * HYT_NT, ns - 1)];
+        }
     }
 #pragma unroll
     for (int k = 0; k < HYT_SLOTS; k++) {
@@ -1513,7 +1528,7 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
         const uint32_t g = (uint32_t)(int)fminf(fmaxf(pxv[k].y * 255.0f, 0.0f), 255.0f);
         const uint32_t b = (uint32_t)(int)fminf(fmaxf(pxv[k].z * 255.0f, 0.0f), 255.0f);
         img[j] = r | g << 8 | b << 16;
-        const float d = dpv[k] * scale;
+        const float d = dpv[k] * dmul[k];
         if (FUSED) dcode[j] = csm::f32_to_u8_wrap(d * 255.0f);   // (no global load in the output loop: its latency is exposed there)
         // (d - dmin) / range through the refined reciprocal of the frame's range (cs_common.h div_with: the IEEE quotient for
         // numerators that are 0 or >= 2^-60 and a range within 2^+-40; anything else takes the full division, wave-uniformly)
@@ -2441,6 +2456,13 @@ int hybrid_max_width() {
     }
     return lo;
 }
+// does launch_hybrid take the fused tile form (k_hybrid_splat_tile<true>) for a node-path call with these properties?  (the
+// caller decides with it whether the depth blur may leave its edge-free tiles unwritten)
+bool hybrid_fused_ok(int n, int w, int halo, int anaglyph, int single, int d64, int plus) {
+    const int tmax = (HYT_NPT - 2 * (halo + 2) - 8) & ~3;
+    return halo >= 0 && tmax >= 128 && !d64 && !dev_switch(CS_DEBUG_NO_TILE) && (size_t)n * 2 <= 65535 && !plus && !anaglyph && single < 0 &&
+           w <= 65535 && !dev_switch(CS_DEBUG_HYBRID_UNFUSED);
+}
 int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int plus, int halo) {
     RowArgs A = A0;
     A.hyb_base = (uint8_t*)workspace;
@@ -2458,8 +2480,9 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int pl
         const int T = ((A.w + tiles - 1) / tiles + 3) & ~3;
         // two-eye layouts: the splat writes the node outputs itself, only the gap pixels are left (CS_DEBUG_HYBRID_UNFUSED: the
         // separate streaming pass k_hybrid_out4)
-        const bool fused = !plus && !A.anaglyph && !A.out_u8 && A.single < 0 && A.neyes == 2 && A.depth_l && A.depth_r && A.mask &&
-                           A.w <= 65535 && !dev_switch(CS_DEBUG_HYBRID_UNFUSED);
+        const bool fused = !A.out_u8 && A.neyes == 2 && A.depth_l && A.depth_r && A.mask &&
+                           hybrid_fused_ok(A.n, A.w, halo, A.anaglyph, A.single, A.d64, plus);
+        if (A.tilemap && !fused) return CS_EINVAL;   // (lazy blur tiles are only readable by the fused form)
         const dim3 grid(((A.w + T - 1) / T) * 8, (A.h + 7) / 8, A.n * A.neyes);
         if (fused) {
             uint32_t* cnt = (uint32_t*)((char*)workspace + hybrid_splat_bytes(A.n, A.h, A.w));

@@ -250,7 +250,8 @@ enum cs_debug_key {
     CS_DEBUG_BLUR_NO_PRE_EDGES = 8, /* depth blur: k_gray + k_blur_edges4 instead of the one-pass k_gray_edges */
     CS_DEBUG_HYBRID_UNFUSED = 9,    /* hybrid_edge: splat result -> node outputs in a streaming pass of its own (k_hybrid_out4) */
     CS_DEBUG_GPUWARP_FULL_MAPS = 10, /* gpu_warp with the depth blur: complete blurred maps (k_blur_copy_tiles) instead of the tile map */
-    CS_DEBUG_KEYS = 11
+    CS_DEBUG_HYBRID_FULL_MAPS = 11, /* hybrid_edge with the depth blur: complete blurred maps instead of the tile map */
+    CS_DEBUG_KEYS = 12
 };
 CS_API int cs_debug_set(int key, int value);
 

@@ -199,3 +199,21 @@ def test_gpu_warp_reads_the_tile_map(engine, dev_switch, mode, balance):
                                 depth_blur_vert_smooth=6, batch_size=3)
     assert np.array_equal(lazy[3], want[3]) and np.array_equal(lazy[1], want[1]) and np.array_equal(lazy[2], want[2])
     assert np.abs(lazy[0] - want[0]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("mode", ["left-right", "bottom-top"])
+def test_hybrid_edge_reads_the_tile_map(engine, dev_switch, mode):
+    """hybrid_edge through the fused splat tile kernel reads the lazy tiles as well: identical bits with complete maps
+    (cs_debug_set(CS_DEBUG_HYBRID_FULL_MAPS, 1)) and the oracle's."""
+    n, h, w = 2, 70, 1284
+    img = synth.image_f32(n, h, w, seed=22)
+    depth = synth.depth_batch("blobs", n, h, w, channels=3)
+    lazy = run(engine, img, depth, mode, fill="hybrid_edge")
+    dev_switch("hybrid_full_maps", 1)
+    full = run(engine, img, depth, mode, fill="hybrid_edge")
+    for a, b in zip(lazy, full):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    want = node_oracle.generate(img, depth, 6.0, 0.0, mode, 0.1, 0.5, 2.0, "Imperfect fill - Hybrid Edge", 20.0, 20.0, True,
+                                depth_blur_falloff=2.0, depth_blur_vert_smooth=6)
+    for k in range(4):
+        assert np.array_equal(lazy[k], want[k]), (mode, k)
