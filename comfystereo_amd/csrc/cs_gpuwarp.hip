@@ -162,12 +162,24 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
     const bool lazy = A.tilemap != nullptr;
     LazySel Z0, Z1;
     Z0.base = Z1.base = nullptr; Z0.bits = Z1.bits = 0; Z0.delta = Z1.delta = 0; Z0.mul_set = Z1.mul_set = Z0.mul_clr = Z1.mul_clr = 0;
+    uint32_t Z0hi = 0, Z1hi = 0;   // columns 2048 .. 4095: a second word of tile bits (the other fields of a selector do not depend on s0
+                                   // when the lane's offset is taken from column 0)
     if (lazy) {
         const char* grow = reinterpret_cast<const char*>(A.gray + ((size_t)frame * h + y) * w);
-        Z0 = lazy_select(A.tilemap, A.tm_words, frame, h, y, 0, reinterpret_cast<const char*>(A.eye[0].depth + ((size_t)frame * h + y) * w), grow, st[ST_SCALE255]);
-        if (A.neyes > 1)
-            Z1 = lazy_select(A.tilemap, A.tm_words, frame, h, y, 0, reinterpret_cast<const char*>(A.eye[1].depth + ((size_t)frame * h + y) * w), grow, st[ST_SCALE255]);
+        const char* d0 = reinterpret_cast<const char*>(A.eye[0].depth + ((size_t)frame * h + y) * w);
+        const char* d1 = reinterpret_cast<const char*>(A.eye[A.neyes > 1 ? 1 : 0].depth + ((size_t)frame * h + y) * w);
+        Z0 = lazy_select(A.tilemap, A.tm_words, frame, h, y, 0, d0, grow, st[ST_SCALE255]);
+        if (A.neyes > 1) Z1 = lazy_select(A.tilemap, A.tm_words, frame, h, y, 0, d1, grow, st[ST_SCALE255]);
+        if (w > 2048) {
+            Z0hi = lazy_select(A.tilemap, A.tm_words, frame, h, y, 2048, d0 + 4 * 2048, grow + 4 * 2048, st[ST_SCALE255]).bits;
+            if (A.neyes > 1) Z1hi = lazy_select(A.tilemap, A.tm_words, frame, h, y, 2048, d1 + 4 * 2048, grow + 4 * 2048, st[ST_SCALE255]).bits;
+        }
     }
+    // depth of column x through a selector whose tile bits are `lo` for columns < 2048 and `hi` above
+    auto lazy_load2 = [](LazySel Zs, uint32_t hi, uint32_t x, float& mul) {
+        Zs.bits = x >= 2048u ? hi : Zs.bits;
+        return lazy_load(Zs, x, x, mul);
+    };
     for (int e = 0; e < A.neyes; e++) {
         const GwEye& E = A.eye[e];
         if (!E.enabled) {
@@ -194,6 +206,7 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
         LazySel Z;   // (field by field: an aggregate select of two structs may go through scratch memory)
         Z.base = e ? Z1.base : Z0.base; Z.bits = e ? Z1.bits : Z0.bits; Z.delta = e ? Z1.delta : Z0.delta;
         Z.mul_set = e ? Z1.mul_set : Z0.mul_set; Z.mul_clr = e ? Z1.mul_clr : Z0.mul_clr;
+        const uint32_t Zhi = e ? Z1hi : Z0hi;
         // ---- pass 1: normalised depth, pixel offset, x + offset (:300-328); four columns per thread with their loads first
         const float yr = crange_ok ? gw_rcp_refined(crange) : 0.0f;   // several numerators over one denominator
         float* const depth_out = !A.depth_l ? nullptr : (e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + y) * w) * 3;
@@ -203,7 +216,7 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
             for (int u = 0; u < 4; u++) {
                 const int x = min(xb + u * nt, w - 1);
                 dm[u] = scale;
-                dv[u] = lazy ? lazy_load(Z, (uint32_t)x, (uint32_t)x, dm[u]) : drow[x];
+                dv[u] = lazy ? lazy_load2(Z, Zhi, (uint32_t)x, dm[u]) : drow[x];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -453,15 +466,16 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
             const float* drow = E.depth + ((size_t)frame * h + y) * w;
             float* dst = (e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + y) * w) * 3;
             LazySel Z;
-            if (A.tilemap) Z = lazy_select(A.tilemap, A.tm_words, frame, h, y, 0, reinterpret_cast<const char*>(drow),
-                                           reinterpret_cast<const char*>(A.gray + ((size_t)frame * h + y) * w), st[ST_SCALE255]);
+            Z.base = e ? Z1.base : Z0.base; Z.bits = e ? Z1.bits : Z0.bits; Z.delta = e ? Z1.delta : Z0.delta;
+            Z.mul_set = e ? Z1.mul_set : Z0.mul_set; Z.mul_clr = e ? Z1.mul_clr : Z0.mul_clr;
+            const uint32_t Zhi = e ? Z1hi : Z0hi;
             for (int xb = tid; xb < w; xb += 4 * nt) {   // (loads first; /255 behind a real branch)
                 float dv[4], dm[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int x = min(xb + u * nt, w - 1);
                     dm[u] = scale;
-                    dv[u] = A.tilemap ? lazy_load(Z, (uint32_t)x, (uint32_t)x, dm[u]) : drow[x];
+                    dv[u] = A.tilemap ? lazy_load2(Z, Zhi, (uint32_t)x, dm[u]) : drow[x];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -866,6 +880,6 @@ int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL,
     A.tilemap = tilemap; A.gray = gray; A.tm_words = tm_words;
     return gw_launch(A, stream);
 }
-int gpuwarp_lazy_max_width() { return 2048; }   // one lazy selector = 32 tiles of 64 columns
+int gpuwarp_lazy_max_width() { return 4096; }   // two words of tile bits = 64 tiles of 64 columns
 
 }  // namespace cs

@@ -183,7 +183,7 @@ def test_gpu_warp_reads_the_tile_map(engine, dev_switch, mode, balance):
     """gpu_warp (rows of at most 2048 columns) reads the lazy tiles as well (cs_gpuwarp.hip pass 1; stereo_balance 1: one eye is
     the source image and its depth map is written by the tail loop): identical bits with complete maps
     (cs_debug_set(CS_DEBUG_GPUWARP_FULL_MAPS, 1)), mask equal to the oracle's, colours within the gpu_warp tolerance."""
-    n, h, w = 3, 70, 1284
+    n, h, w = 3, 70, (1284 if balance == 0.0 else 3080)   # (3080 columns: the second word of tile bits, 1024-thread workgroups)
     img = synth.image_f32(n, h, w, seed=21)
     depth = synth.depth_batch("blobs", n, h, w, channels=3).astype(np.float32)
     depth[1] *= 255.0   # the x255 decision is taken over the sub-batch (reference :1045): these three frames stay unscaled
