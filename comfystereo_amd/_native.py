@@ -30,7 +30,7 @@ EXPORTS = [
     "cs_version", "cs_last_error", "cs_max_width", "cs_max_width_mode", "cs_output_shape", "cs_workspace_bytes", "cs_generate",
     "cs_asd_workspace_bytes", "cs_apply_stereo_divergence", "cs_apply_stereo_divergence2", "cs_blur_workspace_bytes", "cs_directional_blur",
     "cs_warp_workspace_bytes", "cs_forward_warp", "cs_warp_mesh_workspace_bytes", "cs_forward_warp_mesh", "cs_expand_u8", "cs_pack_u8", "cs_host_expand_u8", "cs_host_copy", "cs_stereo_shift_workspace_bytes", "cs_stereo_shift", "cs_profile", "cs_profile_read", "cs_debug_set",
-    "cs_test_powf", "cs_test_exp",
+    "cs_test_powf", "cs_test_exp", "cs_test_edge_threshold",
 ]
 
 # enum cs_debug_key (development switches; tests and profiling tools only)
@@ -134,6 +134,8 @@ def lib():
     L.cs_test_powf.argtypes = [vp, ctypes.c_float, vp, c_size, vp]
     L.cs_test_exp.restype = c_int
     L.cs_test_exp.argtypes = [vp, vp, c_size, vp]
+    L.cs_test_edge_threshold.restype = ctypes.c_float
+    L.cs_test_edge_threshold.argtypes = [ctypes.c_float]
     _lib = L
     return L
 

@@ -1015,6 +1015,8 @@ int cs_test_powf(const float* x, float y, float* out, size_t count, void* stream
     return e == hipSuccess ? CS_OK : fail_hip(e, "cs_test_powf");
 }
 
+float cs_test_edge_threshold(float den) { return blur_edge_threshold_host(den); }
+
 int cs_test_exp(const double* x, double* out, size_t count, void* stream) {
     if (!x || !out) return fail(CS_EINVAL, "null pointer");
     hipLaunchKernelGGL(k_test_exp, dim3(grid_for(count, 256)), dim3(256), 0, (hipStream_t)stream, x, out, count);

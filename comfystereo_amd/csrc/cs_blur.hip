@@ -1044,6 +1044,8 @@ static float blur_edge_threshold(float den) {
     return t;
 }
 
+float blur_edge_threshold_host(float den) { return blur_edge_threshold(den); }   // (cs_test_edge_threshold)
+
 bool blur_pre_edges_ok(int n, int h, int w, double strength, double edge_threshold, double mask_width, int vert, bool tilemap) {
     if (dev_switch(CS_DEBUG_BLUR_NO_PRE_EDGES)) return false;
     const BlurPlan P = blur_plan(n, h, w, strength, mask_width, vert, tilemap, true, 2);

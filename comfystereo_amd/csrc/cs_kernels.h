@@ -113,6 +113,7 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
 // One pass over an RGB depth map instead of k_gray + k_blur_edges4: gray depth, its per-frame min / max and the edge bit rows
 // for both x255 hypotheses (cs_blur.hip k_gray_edges).  blur_pre_edges_ok: the parameters take launch_blur's lazy-tile path
 // (the only consumer of the two-plane bit rows); launch_blur is then called with pre_edges = 1 and the same wl / wr.
+float blur_edge_threshold_host(float den);   // the largest t with fl(t / den) <= 0.5, or < 0 (host arithmetic; no GPU)
 bool blur_pre_edges_ok(int n, int h, int w, double strength, double edge_threshold, double mask_width, int vert, bool tilemap);
 hipError_t launch_gray_edges(const float* rgb, float* gray, int n, int h, int w, uint32_t* stats, double strength,
                              double edge_threshold, double mask_width, int vert, float* wl, float* wr, hipStream_t stream);

@@ -259,6 +259,10 @@ CS_API int cs_debug_set(int key, int value);
  * out[i] = powf(x[i], y) / out[i] = exp(x[i]) evaluated by the same device code the kernels use. */
 CS_API int cs_test_powf(const float *x, float y, float *out, size_t count, void *stream);
 CS_API int cs_test_exp(const double *x, double *out, size_t count, void *stream);
+/* Host only (no GPU): the comparison value k_gray_edges uses for the depth blur's edge test -- the largest float t with
+ * fl(t / den) <= 0.5, so that clamp(|g| / den, 0, 1) > 0.5 (reference stereoimage_generation.py:1213-1222) <=> |g| > t;
+ * negative when den is not positive and finite (the kernels then keep the division). */
+CS_API float cs_test_edge_threshold(float den);
 
 #ifdef __cplusplus
 }

@@ -127,3 +127,26 @@ def test_host_expansion_and_copy_need_no_gpu():
     assert L.cs_host_expand_u8(None, one.ctypes.data, 4, 1, 0, 1) != 0          # null pointer
     assert L.cs_host_expand_u8(one.ctypes.data, one.ctypes.data, 4, 5, 0, 1) != 0   # replicate out of range
     assert L.cs_host_copy(None, one.ctypes.data, 4, 1) != 0
+
+
+def test_edge_threshold_equals_the_division():
+    """k_gray_edges replaces `clamp(|g| / den, 0, 1) > 0.5` (reference stereoimage_generation.py:1213-1222) by `|g| > t` with
+    t = cs_test_edge_threshold(den): for every float in a window of +-64 ulps around t (and a spread of others) the two
+    predicates agree in float32 arithmetic; den <= 0, inf and nan report "keep the division" (negative).  No GPU."""
+    import numpy as np
+    from comfystereo_amd import _native
+    L = _native.lib()
+    rs = np.random.RandomState(5)
+    dens = np.concatenate([np.float32([200.0, 30.0, 5.0, 0.1, 1e-3, 1.0, 255.0, 1e6, 3.3e-5]),
+                           np.exp(rs.uniform(-20, 20, 300)).astype(np.float32)])
+    for den in dens:
+        t = np.float32(L.cs_test_edge_threshold(float(den)))
+        assert t > 0
+        around = (t.view(np.int32) + np.arange(-64, 65, dtype=np.int32)).view(np.float32)
+        g = np.concatenate([around, np.float32([0.0, np.inf, np.nan]), (rs.uniform(0, 4, 64).astype(np.float32) * t)])
+        with np.errstate(invalid="ignore", over="ignore"):
+            want = np.clip(g / den, np.float32(0), np.float32(1)) > np.float32(0.5)   # (np.clip passes NaN through; NaN > 0.5 is False)
+            got = g > t
+        assert np.array_equal(got, want), float(den)
+    for bad in (0.0, -1.0, float("inf"), float("nan")):
+        assert L.cs_test_edge_threshold(bad) < 0
