@@ -650,12 +650,12 @@ static int generate_chunk(const cs_params* p, const float* image, const float* d
         float* R = (float*)(ws + W.R);
         // lazy tiles: the tile kernels (cs_polypoint / cs_polytile / cs_fwdtile) read the edge-free tiles of the blurred depth
         // -- a scaled copy of the gray depth -- from the gray depth itself, so the blur leaves them unwritten and hands over
-        // the map of the tiles it did write; run_rows completes the rows that still go to a row kernel.  (k_gpuwarp with the
-        // same selector: 16.2 -> 17.9 ms per 256 frames at 1080p, more than the copy costs -- it keeps the complete maps; so
-        // does hybrid_edge: +0.32 ms per 16 frames in the f64-bound tile splat against 0.26 ms of copy.)
+        // the map of the tiles it did write; run_rows completes the rows that still go to a row kernel.  (Round 2 measured the
+        // selector in k_gpuwarp and in the hybrid splat as dearer than the copy; with both kernels restructured at the end of
+        // round 3 -- loads first, four workgroups per CU -- it is cheaper: see warp_lazy / hyb_lazy below.)
         const bool tile_fill = p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP || p->fill == CS_FILL_NONE ||
                                p->fill == CS_FILL_INVERSE || p->fill == CS_FILL_NAIVE || p->fill == CS_FILL_NAIVE_INTERPOLATING;
-        // gpu_warp (scatter-round warp, rows of at most 2048 columns) reads the map too since the end of round 3: the kernel is
+        // gpu_warp (scatter-round warp, rows of at most 4096 columns) reads the map too since the end of round 3: the kernel is
         // bound by its dependent chains, not by its instruction count -- the selector costs less than the copy of the tiles
         const bool warp_lazy = gpu_warp && !(p->flags & 4) && w <= gpuwarp_lazy_max_width() && !dev_switch(CS_DEBUG_GPUWARP_FULL_MAPS);
         // hybrid_edge through the fused splat tile kernel (two-eye layouts): the same; the disabled-eye path and the unfused
