@@ -294,7 +294,12 @@ def main():
         # input of the node is read by the gray / blur pre-pass, not by this kernel.  `frac` is quoted on these bytes;
         # `frac_node_bytes` divides the whole node boundary's bytes by the same kernel time and
         # `pipeline_frac` by the whole step.
-        own_px = cfg["bytes_px"] - 12 + (8 if blur else 4)
+        # With the blur on, the tile kernels read the blurred maps only for the 64 x 32 tiles the blur touched (cs_profile_tiles:
+        # their share of this run's batch); everywhere else both eyes read ONE shared gray value: 4 instead of 8 B/px.
+        tile_frac = ctypes.c_double(-1.0)
+        _native.check(L.cs_profile_tiles(ctypes.byref(tile_frac)))
+        depth_px = 4.0 if not blur else (8.0 if tile_frac.value < 0 else 4.0 + 4.0 * tile_frac.value)
+        own_px = cfg["bytes_px"] - 12 + depth_px
         own_bytes = frames_per_launch * own_px * H * W
         achieved_own = own_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         pipeline = frames * a.steps * cfg["bytes_px"] * H * W / dt / 1e9 / world
@@ -303,9 +308,12 @@ def main():
                     "kernel": cfg["kernel"], "kernel_ms": kern_ms, "launches": launches.value,
                     "launches_per_step": launches_per_step,
                     "algorithmic_bytes_per_launch": own_bytes,
-                    "algorithmic_bytes_note": f"{own_px} B per source pixel = what this kernel reads and writes once (image 12, one depth value "
-                                              f"per eye, every output); the node boundary of SURVEY.md 8d is {cfg['bytes_px']} B/px (it adds the "
-                                              "12 B/px RGB depth input that the gray / blur pre-pass reads)",
+                    "algorithmic_bytes_note": f"{own_px:.2f} B per source pixel = what this kernel reads and writes once: image 12, depth "
+                                              f"{depth_px:.2f} (one blurred value per eye in the {max(tile_frac.value, 0.0) * 100:.1f} % of the 64 x 32 tiles the "
+                                              "blur touched, one shared gray value elsewhere; measured on this run's tile map), every output; "
+                                              f"the node boundary of SURVEY.md 8d is {cfg['bytes_px']} B/px (it adds the 12 B/px RGB depth input that the "
+                                              "gray / blur pre-pass reads)",
+                    "blurred_tile_fraction": tile_frac.value if tile_frac.value >= 0 else None,
                     "achieved_node_bytes": achieved, "frac_node_bytes": achieved / HBM_PEAK_GBS,
                     "pipeline_achieved": pipeline, "pipeline_frac": pipeline / HBM_PEAK_GBS}
         line = {

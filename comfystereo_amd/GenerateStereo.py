@@ -10,9 +10,12 @@ import torch
 
 from . import engine, host_pipeline
 
+_IN_COMFYUI = True
 try:  # ComfyUI's progress bar when running inside ComfyUI (reference GenerateStereo.py:27,110)
     from comfy.utils import ProgressBar
 except Exception:  # noqa: BLE001 - standalone use
+    _IN_COMFYUI = False
+
     class ProgressBar:
         def __init__(self, total):
             self.total, self.current = total, 0
@@ -41,6 +44,16 @@ FILL_TECHNIQUE_MAPPING = dict(FILL_TECHNIQUES, **{
 # frames handed to one cs_generate call: bounded by a byte budget, not by the widget's batch_size
 # (288 GB of HBM3E: a chunk of 64 4K frames needs ~55 GB including outputs)
 CHUNK_BYTES = 96 << 30
+
+
+# Warm-up at import (inside ComfyUI only; tools call host_pipeline.prewarm themselves): the first `generate` of a process would
+# otherwise page-lock its result and staging memory inside the call (24 GB/s: 0.8 s for a 32-frame 4K batch, four times the call
+# itself -- 24-48 instead of 150+ frames/s).  A daemon thread allocates the buffers of a call of this shape and releases them into
+# PyTorch's caching allocators while ComfyUI is still loading its models: ~19 GB of pinned host memory and ~12 GB of HBM stay
+# cached for (frames, height, width) = (32, 2160, 3840).  None switches it off; a smaller shape warms less.
+PREWARM = (32, 2160, 3840)
+if _IN_COMFYUI and PREWARM:
+    host_pipeline.prewarm_async(*PREWARM)
 
 
 class StereoImageNode:

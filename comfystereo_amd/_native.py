@@ -24,12 +24,12 @@ MODE = {
 }
 
 # the ABI version the ctypes signatures below were written for (include/comfystereo_amd.h CS_ABI_VERSION)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = [
     "cs_version", "cs_last_error", "cs_max_width", "cs_max_width_mode", "cs_output_shape", "cs_workspace_bytes", "cs_generate",
-    "cs_asd_workspace_bytes", "cs_apply_stereo_divergence", "cs_apply_stereo_divergence2", "cs_blur_workspace_bytes", "cs_directional_blur",
-    "cs_warp_workspace_bytes", "cs_forward_warp", "cs_warp_mesh_workspace_bytes", "cs_forward_warp_mesh", "cs_expand_u8", "cs_pack_u8", "cs_host_expand_u8", "cs_host_copy", "cs_stereo_shift_workspace_bytes", "cs_stereo_shift", "cs_profile", "cs_profile_read", "cs_debug_set",
+    "cs_asd_workspace_bytes", "cs_asd_workspace_bytes_for", "cs_apply_stereo_divergence", "cs_apply_stereo_divergence2", "cs_blur_workspace_bytes", "cs_directional_blur",
+    "cs_warp_workspace_bytes", "cs_forward_warp", "cs_warp_mesh_workspace_bytes", "cs_forward_warp_mesh", "cs_expand_u8", "cs_pack_u8", "cs_host_expand_u8", "cs_host_copy", "cs_take_f32", "cs_host_replicate_f32", "cs_stereo_shift_workspace_bytes", "cs_stereo_shift", "cs_profile", "cs_profile_read", "cs_profile_tiles", "cs_debug_set",
     "cs_test_powf", "cs_test_exp", "cs_test_edge_threshold",
 ]
 
@@ -93,6 +93,8 @@ def lib():
     L.cs_generate.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, c_size, vp]
     L.cs_asd_workspace_bytes.restype = c_size
     L.cs_asd_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    L.cs_asd_workspace_bytes_for.restype = c_size
+    L.cs_asd_workspace_bytes_for.argtypes = [c_int, c_int, c_int, c_int]
     L.cs_apply_stereo_divergence2.restype = c_int
     L.cs_apply_stereo_divergence2.argtypes = [vp, vp, c_int, c_int, c_int, c_double, c_double, c_double, c_int, c_double, c_int,
                                               vp, vp, c_size, vp]
@@ -118,6 +120,10 @@ def lib():
     L.cs_host_expand_u8.argtypes = [vp, vp, c_size, c_int, c_int, c_int]
     L.cs_host_copy.restype = c_int
     L.cs_host_copy.argtypes = [vp, vp, c_size, c_int]
+    L.cs_take_f32.restype = c_int
+    L.cs_take_f32.argtypes = [vp, vp, c_size, c_int, vp]
+    L.cs_host_replicate_f32.restype = c_int
+    L.cs_host_replicate_f32.argtypes = [vp, vp, c_size, c_int, c_int]
     L.cs_stereo_shift_workspace_bytes.restype = c_size
     L.cs_stereo_shift_workspace_bytes.argtypes = []
     L.cs_stereo_shift.restype = c_int
@@ -128,6 +134,8 @@ def lib():
     L.cs_profile.argtypes = [c_int]
     L.cs_profile_read.restype = c_int
     L.cs_profile_read.argtypes = [ctypes.POINTER(c_double), ip]
+    L.cs_profile_tiles.restype = c_int
+    L.cs_profile_tiles.argtypes = [ctypes.POINTER(c_double)]
     L.cs_debug_set.restype = c_int
     L.cs_debug_set.argtypes = [c_int, c_int]
     L.cs_test_powf.restype = c_int

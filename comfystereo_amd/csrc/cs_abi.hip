@@ -7,6 +7,7 @@
 #include <string.h>
 #include <atomic>
 #include <mutex>
+#include <vector>
 
 #include "cs_common.h"
 #include "cs_kernels.h"
@@ -201,6 +202,12 @@ __global__ void __launch_bounds__(256) k_pack_u8(const float* __restrict__ in, u
     }
 }
 
+// every stride-th float (one channel of a depth-map output with equal channels)
+__global__ void __launch_bounds__(256) k_take_f32(const float* __restrict__ in, float* __restrict__ out, size_t count, int stride) {
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += step) out[i] = in[i * (size_t)stride];
+}
+
 // ---------------------------------------------------------------------------------------------
 // stereo_shift_torch (reference stereo_utils.py:15-88): the `none` forward map on a float payload (latents [b][c][h][w]).
 // One workgroup per (row, batch item): winner source column per destination by LDS atomics (the reference's sweep makes the
@@ -279,6 +286,10 @@ static std::mutex g_prof_mu;
 static std::atomic<bool> g_prof_on{false};
 static hipEvent_t g_prof_ev[2 * PROF_MAX];
 static int g_prof_made = 0, g_prof_used = 0;
+// the lazy-tile map of the last profiled cs_generate call (null: the call's warp kernel read complete blurred maps)
+static const uint32_t* g_prof_map = nullptr;
+static int g_prof_map_n = 0, g_prof_map_h = 0, g_prof_map_w = 0;
+static hipStream_t g_prof_map_stream = nullptr;
 struct ProfScope {
     hipStream_t s; int slot;
     explicit ProfScope(hipStream_t stream) : s(stream), slot(-1) {
@@ -715,6 +726,11 @@ static int generate_chunk(const cs_params* p, const float* image, const float* d
     A.single = -1;
     A.dbg = dev_switch(CS_DEBUG_DBG);
     if (lazy) { A.tilemap = (const uint32_t*)(ws + W.tilemap); A.lazy_gray = gray; A.tm_words = blur_tilemap_words(w); }
+    if (g_prof_on.load(std::memory_order_relaxed)) {   // (measurement: cs_profile_tiles reads this call's tile map afterwards)
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        g_prof_map = lazy ? (const uint32_t*)(ws + W.tilemap) : nullptr;
+        g_prof_map_n = n; g_prof_map_h = h; g_prof_map_w = w; g_prof_map_stream = stream;
+    }
     switch (p->mode) {
     case CS_MODE_LEFT_RIGHT: A.eye[1].xoff = w; break;
     case CS_MODE_RIGHT_LEFT: A.eye[0].xoff = w; break;
@@ -764,6 +780,12 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     // 1 = pre-passes on an auxiliary stream of the default priority; 2 = pre-passes at the default priority AND the warps on
     // the highest-priority auxiliary stream (the warp keeps its workgroup slots, the pre-pass only fills what is left)
     const int mode = dev_switch(CS_DEBUG_CHUNKS) / 100;
+    // The auxiliary streams and their fork / ready events are one set per device: two host threads interleaving their
+    // hipEventRecord / hipStreamWaitEvent pairs on them would wait for each other's records.  The chunked schedule (a development
+    // switch) therefore enqueues under one lock, from the fork to the join -- host-side enqueueing only, the GPU work itself
+    // still overlaps; the shared events also make this path unfit for stream capture (the default single-chunk path is).
+    static std::mutex chunk_mu;
+    std::lock_guard<std::mutex> chunk_lock(chunk_mu);
     AuxStream* const X = aux_stream(mode >= 1);
     AuxStream* const Wp = mode == 2 ? aux_stream(0) : nullptr;
     if (!X || (mode == 2 && !Wp)) return fail_hip(hipGetLastError(), "auxiliary stream");
@@ -798,9 +820,18 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     return rc;
 }
 
-size_t cs_asd_workspace_bytes(int n, int h, int w) {
-    return al256((size_t)n * ST_WORDS * 4) + rowflag_bytes((size_t)n * h) + al256(hybrid_workspace_bytes(n, h, w)) +
-           al256(poly_replay_bytes(n, h, w, 1));
+// [statistics][flagged-row block][technique scratch: the splat result of hybrid_edge / the replay pool of polylines]
+static size_t asd_tech_bytes(int n, int h, int w, int fill) {
+    if (fill == CS_FILL_HYBRID_EDGE || fill == CS_FILL_HYBRID_EDGE_PLUS) return al256(hybrid_workspace_bytes(n, h, w));
+    if (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP) return al256(poly_replay_bytes(n, h, w, fill == CS_FILL_POLYLINES_SHARP));
+    return 0;
+}
+size_t cs_asd_workspace_bytes_for(int n, int h, int w, int fill) {
+    return al256((size_t)n * ST_WORDS * 4) + rowflag_bytes((size_t)n * h) + asd_tech_bytes(n, h, w, fill);
+}
+size_t cs_asd_workspace_bytes(int n, int h, int w) {   // enough for any technique
+    const size_t a = cs_asd_workspace_bytes_for(n, h, w, CS_FILL_HYBRID_EDGE), b = cs_asd_workspace_bytes_for(n, h, w, CS_FILL_POLYLINES_SHARP);
+    return a > b ? a : b;
 }
 
 int cs_apply_stereo_divergence(const uint8_t* image_u8, const float* depth, int n, int h, int w, double divergence,
@@ -821,7 +852,7 @@ int cs_apply_stereo_divergence2(const uint8_t* image_u8, const float* depth, int
     if (n <= 0 || h <= 0 || w <= 0) return fail(CS_EINVAL, "non-positive size");
     if (fill < 0 || fill > CS_FILL_HYBRID_EDGE_PLUS || fill == CS_FILL_GPU_WARP) return fail(CS_EINVAL, "unknown fill technique");
     if (w > max_width_for(fill, 0) || !dialect_width_ok(fill, w, 0, dialect)) return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
-    if (workspace_bytes < cs_asd_workspace_bytes(n, h, w)) return fail(CS_EWORKSPACE, "workspace too small");
+    if (workspace_bytes < cs_asd_workspace_bytes_for(n, h, w, fill)) return fail(CS_EWORKSPACE, "workspace too small");
     uint32_t* stats = (uint32_t*)workspace;
     hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);
     hipLaunchKernelGGL(k_minmax, dim3(grid_for((size_t)h * w, 256), n), dim3(256), 0, stream, depth, h * w, stats, ST_L_MIN, ST_L_MAX);
@@ -847,9 +878,9 @@ int cs_apply_stereo_divergence2(const uint8_t* image_u8, const float* depth, int
         if (rc) return fail(rc, "hybrid_edge launch failed");
     } else {
         int halo = poly_halo(divergence, divergence, separation, exponent, convergence, w);
+        const bool poly = fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP;   // (the others have no replay scratch)
         int rc = run_rows(fill, A, halo, (uint8_t*)workspace + al256((size_t)n * ST_WORDS * 4), stream, nullptr,
-                          (char*)workspace + al256((size_t)n * ST_WORDS * 4) + rowflag_bytes((size_t)n * h) +
-                              al256(hybrid_workspace_bytes(n, h, w)));
+                          poly ? (char*)workspace + al256((size_t)n * ST_WORDS * 4) + rowflag_bytes((size_t)n * h) : nullptr);
         if (rc) return rc;
     }
     hipError_t e = hipGetLastError();
@@ -939,6 +970,15 @@ int cs_pack_u8(const float* values, uint8_t* codes, size_t count, int stride, in
     return e == hipSuccess ? CS_OK : fail_hip(e, "cs_pack_u8");
 }
 
+int cs_take_f32(const float* values, float* out, size_t count, int stride, void* stream) {
+    if (!values || !out) return fail(CS_EINVAL, "null pointer");
+    if (stride < 1) return fail(CS_EINVAL, "cs_take_f32: stride >= 1");
+    if (count == 0) return CS_OK;
+    hipLaunchKernelGGL(k_take_f32, dim3(grid_for(count, 256)), dim3(256), 0, (hipStream_t)stream, values, out, count, stride);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CS_OK : fail_hip(e, "cs_take_f32");
+}
+
 size_t cs_stereo_shift_workspace_bytes(void) { return al256(ST_WORDS * 4); }
 
 int cs_stereo_shift(const float* input, const float* depth, int b, int c, int h, int w, double scale_factor, int shift_both,
@@ -1005,6 +1045,28 @@ int cs_profile_read(double* total_ms, int* launches) {
     if (total_ms) *total_ms = tot;
     if (launches) *launches = g_prof_used;
     g_prof_used = 0;
+    return CS_OK;
+}
+
+// Which share of the 64 x 32 tiles of the last profiled cs_generate call had been written to the blurred depth maps (the others
+// are read from the shared gray depth by both eyes: 4 instead of 8 bytes per pixel of depth input for the warp kernel).
+// Blocking (waits for the call's stream, copies the map).  *fraction = -1: that call did not use lazy tiles.
+int cs_profile_tiles(double* fraction) {
+    if (!fraction) return fail(CS_EINVAL, "null pointer");
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    *fraction = -1.0;
+    if (!g_prof_map) return CS_OK;
+    const int n = g_prof_map_n, h = g_prof_map_h, w = g_prof_map_w;
+    const int words = blur_tilemap_words(w), trows = (int)(blur_tilemap_bytes(n, h, w) / ((size_t)n * words * 4));
+    const int tcols = (w + 63) / 64;   // (64-column tiles: cs_blur.hip BLUR_TW)
+    std::vector<uint32_t> host(blur_tilemap_bytes(n, h, w) / 4);
+    hipError_t e = hipStreamSynchronize(g_prof_map_stream);
+    if (e == hipSuccess) e = hipMemcpy(host.data(), g_prof_map, host.size() * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail_hip(e, "cs_profile_tiles");
+    size_t set = 0;
+    for (size_t r = 0; r < (size_t)n * trows; r++)
+        for (int t = 0; t < tcols; t++) set += (host[r * words + (t >> 5)] >> (t & 31)) & 1u;
+    *fraction = (double)set / ((double)n * trows * tcols);
     return CS_OK;
 }
 

@@ -1022,7 +1022,11 @@ static BlurPlan blur_plan(int n, int h, int w, double strength, double mask_widt
     P.gy = (h + BLUR_TR - 1) / BLUR_TR; P.gx = (w + BLUR_TW - 1) / BLUR_TW; P.HB = (h + BLUR_ER4 - 1) / BLUR_ER4;
     P.plane_bytes = ((size_t)n * h * P.MW * 8 + 255) & ~(size_t)255;
     P.mask_bytes = P.plane_bytes * planes;
-    P.list_bytes = 256 + (size_t)n * P.gy * P.gx * (4 + 64);   // counter, worklist, then 4 x float4 of output extremes per entry
+    {   // counter, worklist (4 B per tile, the extremes behind it start on a 16-byte boundary: launch_blur), 4 x float4 of output
+        // extremes per entry
+        const size_t total = (size_t)n * P.gy * P.gx;
+        P.list_bytes = 256 + ((total * 4 + 15) & ~(size_t)15) + total * 64;
+    }
     P.blk_bytes = (size_t)n * P.HB * P.MW * 16;
     P.listed = P.fused && (w & 3) == 0 && P.gx < 1024 && P.gy < 1024 && n < 4096 && P.mask_bytes + P.list_bytes <= (size_t)n * h * w * 4;
     // lazy mode: block summaries behind the second bit-row buffer

@@ -125,6 +125,28 @@ __device__ __forceinline__ void block_minmax_update(float mn, float mx, uint32_t
     __syncthreads();
 }
 
+// ---- grid of the tile kernels that give a workgroup to one (tile, row, EYE): k_polypoint, k_polytile, k_hybrid_splat_tile ----
+// blockIdx.x = tile * 8 + (row & 7): workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md; speed only),
+// so all tiles of a row share one L2.  blockIdx.y (two-eye launches): the two eyes of a GROUP of 8 << CS_EYE_GROUP rows follow
+// each other in dispatch order -- rows 0..127 of the left eye, rows 0..127 of the right eye, rows 128..255 of the left eye ... --
+// so the second eye finds the image rows (and the gray depth of edge-free blur tiles) in its XCD's L2 instead of fetching them
+// again: FETCH_SIZE of k_polypoint halves (16.6 -> 8.3 GB per 64 4K frames, less than the algorithmic 10.6: the gray depth is
+// shared as well) and the kernel is 3.5 % faster (profiles/r04_eye_group.txt).  Groups of 8 rows (the eyes adjacent) are 3 %
+// SLOWER than eye-major order, as round 2 had found: the two eyes of a tile then run at the same time and their output streams
+// collide; with 32 rows or more between them they do not.
+#ifndef CS_EYE_GROUP
+#define CS_EYE_GROUP 4
+#endif
+__host__ __device__ __forceinline__ int eye_group_grid_y(int h) {
+    const int G = 1 << CS_EYE_GROUP, ny = (h + 7) / 8;
+    return 2 * ((ny + G - 1) / G) * G;
+}
+// blockIdx.y of a two-eye launch -> the 8-row block and the eye (rows beyond h: the caller returns)
+__device__ __forceinline__ void eye_group_decode(int yi, int& yrow, int& eye) {
+    yrow = ((yi >> (CS_EYE_GROUP + 1)) << CS_EYE_GROUP) | (yi & ((1 << CS_EYE_GROUP) - 1));
+    eye = (yi >> CS_EYE_GROUP) & 1;
+}
+
 // ---- lazy depth-blur tiles (cs_blur.hip k_blur_classify, RowArgs::tilemap) ------------------------------------------
 // The blurred depth map of an eye only holds the 64 x 32 tiles the map names; everywhere else the value is
 // gray * (the frame's x255 scale).  A tile kernel that stages the columns [s0, s0 + 2048) of one row sets a selector up

@@ -62,7 +62,7 @@ struct RowArgs {
     uint8_t* rp_dump;
     uint32_t* rp_list;
     uint32_t* rp_ctr;
-    uint32_t rp_slots, rp_cap, rp_slot_bytes;
+    uint32_t rp_pool16, rp_cap;   // dump pool in 16-byte units, descriptors in the list
     const uint32_t* row_list;     // or null: process only these rows (frame * h + row), *row_count of them (tiled-path fallback)
     const uint32_t* row_count;
     int dbg;            // development only (cs_debug_set(CS_DEBUG_DBG, n)): see dev_switch() below

@@ -120,20 +120,20 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = hot_T;
-    // grid = (tiles x 8 rows, rows / 8, frames x eyes), decoded with shifts (a scalar division costs ~30 SALU instructions, and
-    // the scalar unit is as busy as the vector units in this kernel).  Workgroup b runs on XCD b % 8 (observed dispatch order,
-    // MI355X_MICROARCH.md; a speed assumption only): with blockIdx.x = tile * 8 + (row & 7) all tiles of a row land on one
-    // XCD, back to back, and the halo columns two neighbouring tiles share come from that XCD's L2 the second time instead
-    // of from HBM (FETCH_SIZE -21 %).  Putting the two eyes of a tile next to each other as well takes the image row out of
-    // HBM for the second eye (FETCH_SIZE -60 %) and is 4 % SLOWER (measured, r02c): the kernel is bound by instruction
-    // issue, not by HBM, and the eyes then compete for the same L1 lines.
+    // grid = (tiles x 8 rows, rows / 8 [x eyes], frames), decoded with shifts (a scalar division costs ~30 SALU instructions).
+    // Workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md; a speed assumption only): with blockIdx.x =
+    // tile * 8 + (row & 7) all tiles of a row land on one XCD, back to back, and the halo columns two neighbouring tiles share
+    // come from that XCD's L2 the second time instead of from HBM (FETCH_SIZE -21 %).  The two eyes: cs_common.h eye_group_decode
+    // (round 4: row groups of the two eyes alternate, the second eye's image rows come from L2; the eyes of a tile directly
+    // next to each other had been measured 4 % slower in round 2 and 3 % slower again in round 4).
     const int xi = blockIdx.x;
-    const int row = blockIdx.y * 8 + (xi & 7);
+    // (two-eye launches: blockIdx.y interleaves the eyes by row groups, cs_common.h eye_group_decode; single-eye: z = frame)
+    int yrow = blockIdx.y, eyei = hot_single;
+    if (hot_single < 0) eye_group_decode((int)blockIdx.y, yrow, eyei);
+    const int row = yrow * 8 + (xi & 7);
     if (row >= hot_h) return;
     const int tile = xi >> 3;
-    const int zi = blockIdx.z;
-    const int eyei = hot_single >= 0 ? hot_single : (zi & 1);
-    const int frame = hot_single >= 0 ? zi : (zi >> 1);
+    const int frame = blockIdx.z;
     EyeArgs E;
     E.depth = eyei ? hot_depth1 : hot_depth0;
     {
@@ -426,6 +426,54 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     }
     __syncthreads();  // barrier 1: points staged, in-wave reversed segments marked
     if (PP_DEV_IS(31)) return;
+    // (model experiment, tools/r04_model.sh: -DPP_PAD_S=n / -DPP_PAD_V=n add n independent scalar / vector adds per wave here,
+    // so that the cost of one more instruction of either kind is measured on the production kernel; never defined in a release)
+#if defined(PP_PAD_S) || defined(PP_PAD_V)
+    {
+        int pa = tid, pb = row, pc = tile, pd = frame;
+#ifdef PP_PAD_S
+        int sa = __builtin_amdgcn_readfirstlane(pa), sb = __builtin_amdgcn_readfirstlane(pb), sc = __builtin_amdgcn_readfirstlane(pc),
+            sd = __builtin_amdgcn_readfirstlane(pd);
+#pragma unroll
+        for (int i = 0; i < PP_PAD_S / 4; i++)
+            asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1" : "+s"(sa), "+s"(sb), "+s"(sc), "+s"(sd));
+        if (sa + sb + sc + sd == 0x7ffffff3) hazard = true;
+#endif
+#ifdef PP_PAD_V
+#pragma unroll
+        for (int i = 0; i < PP_PAD_V / 4; i++)
+            asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1" : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(pd));
+        if (pa + pb + pc + pd == 0x7ffffff3) hazard = true;
+#endif
+    }
+#endif
+#ifdef PP_PAD_P   // packed float32 adds (two results per instruction)
+    {
+        double pa = (double)tid, pb = (double)row;
+#pragma unroll
+        for (int i = 0; i < PP_PAD_P / 2; i++)
+            asm volatile("v_pk_add_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, %1" : "+v"(pa), "+v"(pb));
+        if (pa + pb == 12345.678) hazard = true;
+    }
+#endif
+#ifdef PP_PAD_D   // ONE dependent chain of vector adds (every instruction waits for the previous one's result)
+    {
+        int pa = tid;
+#pragma unroll
+        for (int i = 0; i < PP_PAD_D / 4; i++)
+            asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %0, %0, 1" : "+v"(pa));
+        if (pa == 0x7ffffff3) hazard = true;
+    }
+#endif
+#ifdef PP_PAD_C   // the same with an instruction of the "4-cycle class" of tools/ubench (a conversion)
+    {
+        int pa = tid, pb = row, pc = tile, pd = frame;
+#pragma unroll
+        for (int i = 0; i < PP_PAD_C / 4; i++)
+            asm volatile("v_cvt_f32_ubyte0 %0, %0\n v_cvt_f32_ubyte0 %1, %1\n v_cvt_f32_ubyte0 %2, %2\n v_cvt_f32_ubyte0 %3, %3" : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(pd));
+        if (pa + pb + pc + pd == 0x7ffffff3) hazard = true;
+    }
+#endif
 
     // ---- the segment pairs the staging loop could not see: lane 63 of every 64-point chunk (its right neighbour was staged
     // by another wave) and the left sentinel's pair.  Every wave checks the chunks IT staged -- lanes 0 .. SLOTS-1, one pair
@@ -448,7 +496,15 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     const int dlo = flags[PF_DLO], dhi = flags[PF_DHI];
     if (flags[PF_NDIRTY] > PP_DCAP) PP_HAZARD(1);
     // points that can lie in the tile, plus the one before them (its segment may bridge into the tile); sentinels excluded
+#ifdef PP_PEEL
+    // the point before the first one of the tile only matters through its segment (it may bridge into the tile): that segment is
+    // worked off once, by wave 0, below -- as a lane of the dense pass it made 769 points of the 768 a tile of a flat region
+    // holds, i.e. a fourth pass for one lane with the other three waves waiting at barrier 2
+    const int jfirst = flags[PF_JLO];
+    const int jlo = max(jfirst, 0), jhi = min(flags[PF_JHI], ns - 1);
+#else
     const int jlo = max(flags[PF_JLO] - 1, 0), jhi = min(flags[PF_JHI], ns - 1);
+#endif
     if (tid == 0) { pz[0] = 0.0f; pz[npts - 1] = 0.0f; }   // sentinels (:1921, :1935); read after barrier 2
     if (PP_DEV_IS(32)) return;
 
@@ -462,6 +518,31 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     const float tlo = o0f - 0.5f, thi = o1f - 0.5f;
     const bool edge_tile = left_edge || right_edge;
 
+#ifdef PP_PEEL
+    if (wave == 0 && jfirst >= 1 && jfirst <= jhi + 1 && (jfirst < ns || right_edge) && !PP_DEV_IS(33)) {   // segment (jfirst - 1 -> jfirst): x[jfirst - 1] < o0 <= x[jfirst]
+        const int o = jfirst;                                                // (point id of source jfirst - 1)
+        const float xa = P[o].x, xb = P[o + 1].x;
+        const float fb = floorf(xb);
+        if (xa < xb) {
+            // pixels strictly between the end pixels, inside the tile: 0 .. floor(xb) - 1 (floor(xa) < o0)
+            const int pb = fb > o1f - 1.0f ? wt - 1 : (int)fb - 1 - o0;
+            for (int p = lane; p <= pb; p += 64)
+                if (!(fold_tile && (dflag[p] & PP_DIRTY))) list_push(PK_BRIDGE, o, p);
+            if (fold_tile) {
+                const int p0 = max(0, dlo), p1 = min(fb > o1f - 1.0f ? wt - 1 : (int)fb - o0, dhi);
+                for (int p = p0 + lane; p <= p1; p += 64) {
+                    const unsigned fl = dflag[p];
+                    if (fl & PP_DIRTY) {
+                        const int s = fl & 0x7f;
+                        const unsigned idx = (atomic_add_u16(dcnt, s, 0x100u) >> 8) & 0xffu;
+                        if (idx < PT_KS) sgs[s * PT_KS + idx] = (uint16_t)o;
+                        else PP_HAZARD(16);
+                    }
+                }
+            }
+        }
+    }
+#endif
     // =====================================================================================================
     // phase C: every point that can lie in the tile looks at its pixel (lanes densely packed over [jlo, jhi])
     // =====================================================================================================
@@ -959,7 +1040,7 @@ template <int NT, int SLOTS, int MINW>
 static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream) {
     constexpr int KP = 4, KS = 5;
     const int tiles = (A.w + A.T - 1) / A.T;
-    dim3 grid(tiles * 8, (A.h + 7) / 8, A.single >= 0 ? A.n : 2 * A.n), block(NT);   // (see the kernel's prologue)
+    dim3 grid(tiles * 8, A.single >= 0 ? (A.h + 7) / 8 : eye_group_grid_y(A.h), A.n), block(NT);   // (see the kernel's prologue)
     size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS);
     // (development: CS_DEBUG_PT_VARIANT 13..16 pads the LDS request so that only 3..6 workgroups fit a CU -- occupancy what-if)
     const int npt = polypoint_npt(NT, SLOTS, A.T, A.S);
@@ -1019,7 +1100,7 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     A.tilemap = R.tilemap; A.gray = R.lazy_gray; A.tm_words = R.tm_words;
     const int out = R.out_u8 ? PO_ASD : (R.stereo_is_u8 ? (R.no_mask ? PO_U8NM : PO_U8) : PO_F32);
     if ((out == PO_ASD) != (R.image_u8 != nullptr)) return hipErrorInvalidValue;  // uint8 image in <=> uint8 image out
-    if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31) || A.h > 8 * 65535 || 2 * A.n > 65535)
+    if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31) || A.h > 4 * 65535 - 512 || A.n > 65535)
         return hipErrorInvalidValue;   // 32-bit pixel indices, grid limits
     switch (geo) {
     case 3: return polypoint_launch<256, 3, PP_MINW>(A, out, stream);

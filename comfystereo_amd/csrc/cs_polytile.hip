@@ -136,11 +136,13 @@ k_polytile(const float* __restrict__ hot_image, const float* __restrict__ hot_de
     // and all tiles of a row run on one XCD (workgroup b -> XCD b % 8), so the halo columns neighbouring tiles share come
     // from that L2 (cs_polypoint.hip has the measurements)
     const int bx = blockIdx.x;
-    const int row = blockIdx.y * 8 + (bx & 7);
+    // (two-eye launches: blockIdx.y interleaves the eyes by row groups, cs_common.h eye_group_decode; z = frame)
+    int yrow = blockIdx.y, eyei = hot_single;
+    if (hot_single < 0) eye_group_decode((int)blockIdx.y, yrow, eyei);
+    const int row = yrow * 8 + (bx & 7);
     if (row >= hot_h) return;
     const int tile = bx >> 3;
-    const int eyei = hot_single >= 0 ? hot_single : (int)(blockIdx.z & 1);
-    const int frame = hot_single >= 0 ? (int)blockIdx.z : (int)(blockIdx.z >> 1);
+    const int frame = blockIdx.z;
     // (the eye's arguments are selected field by field: a dynamically indexed kernel-argument array costs a second,
     // dependent scalar-memory round trip before the first global load can be issued)
     EyeArgs E;
@@ -972,7 +974,7 @@ hipError_t launch_polytile(int sharp, const RowArgs& R, int S, uint8_t* rowflag,
     A.dbg = R.dbg;
     A.tilemap = R.tilemap; A.gray = R.lazy_gray; A.tm_words = R.tm_words;
     const int tiles = (A.w + PT_T - 1) / PT_T;
-    dim3 grid(tiles * 8, (A.h + 7) / 8, A.single >= 0 ? A.n : 2 * A.n), block(PT_THREADS);
+    dim3 grid(tiles * 8, A.single >= 0 ? (A.h + 7) / 8 : eye_group_grid_y(A.h), A.n), block(PT_THREADS);
     const int variant = dev_switch(CS_DEBUG_PT_VARIANT);
 #define PT_LAUNCH(SH, KP, KS, MW)                                                                                   \
     {                                                                                                               \

@@ -874,10 +874,12 @@ __device__ __forceinline__ void poly_seg_pixels(const Poly& P, int o, int& p0, i
 #define RP_CW 1024
 #define RP_DESC 8   // words per stretch descriptor
 struct RpCtx {      // where a row exports its stretches to (dump == null: replay inside the row kernel)
-    uint8_t* dump; uint32_t* list; uint32_t* ctr; uint32_t slots, cap, slot_bytes; uint32_t rowid; int eye;
+    uint8_t* dump; uint32_t* list; uint32_t* ctr; uint32_t pool16, cap; uint32_t rowid; int eye;   // pool16: dump bytes / 16
 };
-__host__ __device__ inline size_t rp_perm_bytes(int w, int sharp) { return align16(2 * (size_t)poly_npt(w, sharp)); }
-__host__ __device__ inline size_t rp_slot_bytes(int w, int sharp) { return rp_perm_bytes(w, sharp) + align16(4 * (size_t)w); }
+// what a stretch leaves in the dump pool: ITS windows of the row's sorted order (perm[pw0 .. pw1]) and of coord_d
+// (cd[cmin .. cmax]) -- a few hundred entries each, not the whole row (round 3 dumped 6-8 B per pixel of the row per slot: 3.2 GB
+// of workspace for 64 4K frames; the windows average ~2 KB per stretch)
+__host__ __device__ inline uint32_t rp_win16(int npw, int ncw) { return (uint32_t)((align16(2 * (size_t)npw) + align16(4 * (size_t)ncw)) >> 4); }
 
 // DIALECT: the instantiation that can run the dialect bits d64 (separate kernels, k_rowwarp<FILL, true>: the D32 kernel keeps
 // its registers and its code as they were)
@@ -1200,25 +1202,47 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
             }
             __syncthreads();
             if (*rp_ok && tid == 0) {
-                const uint32_t slot = atomicAdd(&X->ctr[0], 1u);
-                const uint32_t base = atomicAdd(&X->ctr[1], (uint32_t)nstr);
-                *rp_slot = (int)slot; *rp_base = (int)base;
-                if (slot >= X->slots || base + (uint32_t)nstr > X->cap) {
-                    *rp_ok = 0;   // no room: replay here; the reserved descriptors (those inside the list) say "skip"
-                    for (uint32_t i = base; i < base + (uint32_t)nstr && i < X->cap; i++) X->list[(size_t)i * RP_DESC] = 0xffffffffu;
+                // room in the pool for every window of the row (16-byte units; q[0] of a descriptor = where its windows start)
+                uint32_t total16 = 0;
+                for (int si = 0; si < nstr; si++) {
+                    uint32_t* q = sinfo + RP_DESC * si;
+                    q[0] = total16;
+                    total16 += rp_win16((int)(q[4] >> 16) - (int)(q[4] & 0xffffu) + 1, (int)(q[5] >> 16) - (int)(q[5] & 0xffffu) + 1);
                 }
+                // (compare-and-swap, not a blind add: a pool that is full stays exactly full, the counter cannot wrap)
+                uint32_t at16 = __hip_atomic_load(&X->ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool room = false;
+                for (;;) {
+                    if (at16 > X->pool16 || total16 > X->pool16 - at16) break;
+                    const uint32_t seen = atomicCAS(&X->ctr[0], at16, at16 + total16);
+                    if (seen == at16) { room = true; break; }
+                    at16 = seen;
+                }
+                if (room) {
+                    const uint32_t base = atomicAdd(&X->ctr[1], (uint32_t)nstr);
+                    *rp_slot = (int)at16; *rp_base = (int)base;
+                    if (base + (uint32_t)nstr > X->cap) {
+                        room = false;   // descriptor list full; the reserved descriptors (those inside the list) say "skip"
+                        for (uint32_t i = base; i < base + (uint32_t)nstr && i < X->cap; i++) X->list[(size_t)i * RP_DESC] = 0xffffffffu;
+                    }
+                }
+                if (!room) *rp_ok = 0;   // replay here
             }
             __syncthreads();
             if (*rp_ok) {
-                const uint32_t slot = (uint32_t)*rp_slot, base = (uint32_t)*rp_base;
-                uint8_t* d = X->dump + (size_t)slot * X->slot_bytes;
-                uint16_t* dperm = (uint16_t*)d;
-                float* dcd = (float*)(d + rp_perm_bytes(w, SHARP));
-                for (int i = tid; i < npt; i += nt) dperm[i] = P.perm[i];
-                for (int c = tid; c < w; c += nt) dcd[c] = P.cd[c];
+                const uint32_t at16 = (uint32_t)*rp_slot, base = (uint32_t)*rp_base;
+                for (int si = wave; si < nstr; si += nwaves) {
+                    const uint32_t* q = sinfo + RP_DESC * si;
+                    const int pw0 = (int)(q[4] & 0xffffu), pw1 = (int)(q[4] >> 16), cmin = (int)(q[5] & 0xffffu), cmax = (int)(q[5] >> 16);
+                    uint8_t* d = X->dump + ((size_t)(at16 + q[0]) << 4);
+                    uint16_t* dperm = (uint16_t*)d;
+                    float* dcd = (float*)(d + align16(2 * (size_t)(pw1 - pw0 + 1)));
+                    for (int i = lane; i <= pw1 - pw0; i += 64) dperm[i] = P.perm[pw0 + i];
+                    for (int c = lane; c <= cmax - cmin; c += 64) dcd[c] = P.cd[cmin + c];
+                }
                 for (int i = tid; i < nstr * RP_DESC; i += nt) {
                     const int si = i / RP_DESC, k = i - si * RP_DESC;
-                    X->list[(size_t)(base + (uint32_t)si) * RP_DESC + k] = k == 0 ? slot : sinfo[i];
+                    X->list[(size_t)(base + (uint32_t)si) * RP_DESC + k] = k == 0 ? at16 + sinfo[i] : sinfo[i];
                 }
                 if (stats_rw && tid == 0) atomicAdd(&stats_rw[ST_FALLBACK_ROWS], 1u);
                 return;
@@ -1446,10 +1470,13 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
     __shared__ float lut255[FUSED ? 256 : 1];        // k / 255
     const int tid = threadIdx.x;
     const int xi = blockIdx.x;
-    const int row = blockIdx.y * 8 + (xi & 7);
+    // (two-eye launches: blockIdx.y interleaves the eyes by row groups, cs_common.h eye_group_decode; z = frame)
+    int yrow = blockIdx.y, eyei = 0;
+    if (A.neyes == 2) eye_group_decode((int)blockIdx.y, yrow, eyei);
+    const int row = yrow * 8 + (xi & 7);
     if (row >= A.h) return;
     const int tile = xi >> 3;
-    const int frame = blockIdx.z / A.neyes, eyei = blockIdx.z - frame * A.neyes;
+    const int frame = blockIdx.z;
     const int w = A.w, h = A.h;
     const EyeArgs& E = A.eye[eyei];
     const int o0 = tile * T, wt = min(T, w - o0);
@@ -2162,7 +2189,7 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
             } else if (FILL == CS_FILL_INVERSE) technique_inverse(L, w, E, A.e32, A.d64, A.e64);
             else if (FILL == CS_FILL_POLYLINES_SOFT || FILL == CS_FILL_POLYLINES_SHARP) {
                 // (eyes in separate output slots: the stretches of order-dependent rows may go to the replay kernel)
-                const RpCtx X{A.anaglyph ? nullptr : A.rp_dump, A.rp_list, A.rp_ctr, A.rp_slots, A.rp_cap, A.rp_slot_bytes,
+                const RpCtx X{A.anaglyph ? nullptr : A.rp_dump, A.rp_list, A.rp_ctr, A.rp_pool16, A.rp_cap,
                               (uint32_t)frame * (uint32_t)A.h + (uint32_t)row, e};
                 technique_polylines<FILL == CS_FILL_POLYLINES_SHARP ? 1 : 0, DIALECT>(L, w, E, A.e32, st_rw, out, A.dbg, &X, A.d64, A.e64);
             }
@@ -2322,12 +2349,12 @@ __global__ void __launch_bounds__(64) k_poly_replay(RowArgs A, uint8_t* __restri
         const uint32_t rowid = q[6] & 0x7fffffffu;
         const int eye = (int)(q[6] >> 31), pt0 = (int)q[7];
         const int frame = (int)(rowid / (uint32_t)h), row = (int)(rowid - (uint32_t)frame * (uint32_t)h);
-        const uint8_t* d = A.rp_dump + (size_t)slot * A.rp_slot_bytes;
+        const uint8_t* d = A.rp_dump + ((size_t)slot << 4);   // this stretch's windows (export in technique_polylines)
         const uint16_t* dperm = (const uint16_t*)d;
-        const float* dcd = (const float*)(d + rp_perm_bytes(w, SHARP));
-        for (int i = lane; i <= pw1 - pw0; i += 64) permw[i] = dperm[pw0 + i];
+        const float* dcd = (const float*)(d + align16(2 * (size_t)(pw1 - pw0 + 1)));
+        for (int i = lane; i <= pw1 - pw0; i += 64) permw[i] = dperm[i];
         for (int c = lane; c <= cmax - cmin; c += 64) {
-            cdw[c] = dcd[cmin + c];
+            cdw[c] = dcd[c];
             imgw[3 * c] = src_u8(A, frame, row, cmin + c, 0);
             imgw[3 * c + 1] = src_u8(A, frame, row, cmin + c, 1);
             imgw[3 * c + 2] = src_u8(A, frame, row, cmin + c, 2);
@@ -2352,12 +2379,19 @@ __global__ void __launch_bounds__(64) k_poly_replay(RowArgs A, uint8_t* __restri
     }
 }
 
-size_t poly_replay_bytes(int n, int h, int w, int sharp) {
-    if (w > 8192) return 0;
-    const size_t rows = (size_t)n * h;   // slots for half of the eye rows, four stretches per slot on average
-    return al256r(rows * 4 * RP_DESC * 4) + rows * rp_slot_bytes(w, sharp) + 256;
+// the dump pool: 4 KB per image row (the windows of a stretch average ~2 KB, an order-dependent eye row holds 1.3 stretches), never
+// more than one maximal window set per stretch slot; a row that finds the pool (or the descriptor list) full replays inline
+static size_t rp_pool_bytes(size_t rows) {
+    const size_t worst = rows * 4 * ((size_t)rp_win16(RP_PW, RP_CW) << 4), budget = rows * 4096 + (64u << 10);
+    return (worst < budget ? worst : budget) & ~(size_t)15;
 }
-// scratch: [descriptor list][dump slots]; `ctr_retry`: [counters 256 B][retry flags, one byte per row], zeroed by the caller
+size_t poly_replay_bytes(int n, int h, int w, int sharp) {
+    (void)sharp;
+    if (w > 8192) return 0;
+    const size_t rows = (size_t)n * h;   // descriptors: four stretches per image row
+    return al256r(rows * 4 * RP_DESC * 4) + rp_pool_bytes(rows) + 256;
+}
+// scratch: [descriptor list][dump pool]; `ctr_retry`: [counters 256 B][retry flags, one byte per row], zeroed by the caller
 // (it lies in the flagged-row block that run_rows clears with one memset)
 hipError_t poly_replay_attach(RowArgs& A, int sharp, void* scratch, void* ctr_retry, hipStream_t stream) {
     const size_t rows = (size_t)A.n * A.h;
@@ -2365,8 +2399,9 @@ hipError_t poly_replay_attach(RowArgs& A, int sharp, void* scratch, void* ctr_re
     A.rp_ctr = (uint32_t*)ctr_retry;
     A.rp_list = (uint32_t*)b;
     A.rp_dump = (uint8_t*)(b + al256r(rows * 4 * RP_DESC * 4));
-    A.rp_slots = (uint32_t)rows; A.rp_cap = (uint32_t)(rows * 4); A.rp_slot_bytes = (uint32_t)rp_slot_bytes(A.w, sharp);
-    (void)stream;
+    const size_t pool16 = rp_pool_bytes(rows) >> 4;
+    A.rp_pool16 = (uint32_t)(pool16 < 0xffffffffu ? pool16 : 0xffffffffu); A.rp_cap = (uint32_t)(rows * 4);
+    (void)stream; (void)sharp;
     return hipSuccess;
 }
 uint8_t* poly_replay_retry_flags(const RowArgs& A) { return (uint8_t*)A.rp_ctr + 256; }
@@ -2483,7 +2518,7 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int pl
         const bool fused = !A.out_u8 && A.neyes == 2 && A.depth_l && A.depth_r && A.mask &&
                            hybrid_fused_ok(A.n, A.w, halo, A.anaglyph, A.single, A.d64, plus);
         if (A.tilemap && !fused) return CS_EINVAL;   // (lazy blur tiles are only readable by the fused form)
-        const dim3 grid(((A.w + T - 1) / T) * 8, (A.h + 7) / 8, A.n * A.neyes);
+        const dim3 grid(((A.w + T - 1) / T) * 8, A.neyes == 2 ? eye_group_grid_y(A.h) : (A.h + 7) / 8, A.n);
         if (fused) {
             uint32_t* cnt = (uint32_t*)((char*)workspace + hybrid_splat_bytes(A.n, A.h, A.w));
             uint16_t* lst = (uint16_t*)((char*)cnt + hybrid_count_bytes(A.n, A.h));

@@ -137,7 +137,7 @@ def apply_stereo_divergence(image_u8, depth, divergence, separation, stereo_offs
         image_u8, depth = image_u8[None], depth[None]
     n, h, w, _ = image_u8.shape
     out = torch.empty_like(image_u8)
-    nb = L.cs_asd_workspace_bytes(n, h, w)
+    nb = L.cs_asd_workspace_bytes_for(n, h, w, FILL[fill])
     ws = torch.empty((max(nb, 256),), dtype=torch.uint8, device=image_u8.device)
     _native.check(L.cs_apply_stereo_divergence2(_ptr(image_u8), _ptr(depth), n, h, w, float(divergence), float(separation),
                                                 float(stereo_offset_exponent), FILL[fill], float(convergence_point),

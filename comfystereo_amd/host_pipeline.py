@@ -30,6 +30,7 @@ two 0..255 decisions are per reference sub-batch, so chunks are multiples of `ba
 """
 import ctypes
 import os
+import threading
 from concurrent.futures import ThreadPoolExecutor
 
 import torch
@@ -51,26 +52,41 @@ def _chunk_frames(total, per_frame_out, fill, batch_size):
     return chunk
 
 
+# how an output leaves the device: "u8" = one uint8 code per value (cs_pack_u8, or the kernels' own uint8 stereoscope), expanded
+# by host threads (cs_host_expand_u8); "f1" = one float32 channel of three equal ones (cs_take_f32), replicated by host
+# threads (cs_host_replicate_f32); "f32" = the float32 tensor itself, copied straight into the pinned result
+ROUTES = {
+    "compact": ("u8", "u8", "u8", "u8"),      # the CPU techniques: every value is one of 256 codes
+    "warp": ("f32", "f1", "f1", "u8"),        # gpu_warp: genuine float colours; depth maps have three equal channels, the mask is a flag
+    "float": ("f32", "f32", "f32", "f32"),    # round 2's boundary (comparison only)
+}
+
+
 class _Stage:
     """Buffers of one pipeline slot: pinned + device inputs, a Plan (device outputs + workspace), pinned outputs."""
 
-    def __init__(self, p, depth_shape, device, staged_outputs, compact=False):
+    def __init__(self, p, depth_shape, device, routes, staged_f32):
         n, h, w = p.n, p.h, p.w
-        self.plan = engine.Plan(p, device, stereo_u8=compact)
-        self.compact = compact
+        self.plan = engine.Plan(p, device, stereo_u8=routes[0] == "u8")
         self.future = None
-        if compact:   # uint8 codes: device buffers for the packed depth maps / mask, pinned staging for all four outputs
-            u8 = dict(dtype=torch.uint8, device=device)
-            self.dev_codes = [self.plan.stereo, torch.empty((n, h, w), **u8), torch.empty((n, h, w), **u8),
-                              torch.empty(tuple(self.plan.mask.shape), **u8)]
-            self.pin_codes = [torch.empty(t.shape, dtype=torch.uint8, pin_memory=True) for t in self.dev_codes]
-            staged_outputs = False
+        outs = (self.plan.stereo, self.plan.depth_l, self.plan.depth_r, self.plan.mask)
+        self.dev_small = [None] * 4   # the compact device form of an output (u8 codes / one float channel)
+        self.pin_small = [None] * 4   # ... and its pinned landing buffer
+        self.pin_out = [None] * 4     # pinned staging of a float32 output when the result tensor itself is not pinned
+        for k, r in enumerate(routes):
+            if r == "u8":
+                shape = tuple(outs[k].shape) if k in (0, 3) else (n, h, w)
+                self.dev_small[k] = outs[0] if k == 0 else torch.empty(shape, dtype=torch.uint8, device=device)
+                self.pin_small[k] = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+            elif r == "f1":
+                self.dev_small[k] = torch.empty((n, h, w), dtype=torch.float32, device=device)
+                self.pin_small[k] = torch.empty((n, h, w), dtype=torch.float32, pin_memory=True)
+            elif staged_f32:
+                self.pin_out[k] = torch.empty(outs[k].shape, dtype=outs[k].dtype, pin_memory=True)
         self.pin_img = torch.empty((n, h, w, 3), dtype=torch.float32, pin_memory=True)
         self.pin_dep = torch.empty((n,) + tuple(depth_shape), dtype=torch.float32, pin_memory=True)
         self.dev_img = torch.empty((n, h, w, 3), dtype=torch.float32, device=device)
         self.dev_dep = torch.empty((n,) + tuple(depth_shape), dtype=torch.float32, device=device)
-        self.pin_out = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-                        for t in (self.plan.stereo, self.plan.depth_l, self.plan.depth_r, self.plan.mask)] if staged_outputs else None
         self.used = False
         self.e_in = torch.cuda.Event()    # inputs of the slot's current chunk are on the device
         self.e_done = torch.cuda.Event()  # its kernels have finished
@@ -86,6 +102,36 @@ def result_shapes(image_shape, modes, fill="polylines_soft"):
     return (n, oh, ow, 3), (n, h, w, 3), (n, h, w, 3), (n, mh, mw)
 
 
+class _Results:
+    """The four result tensors, allocated by a helper thread while the first chunk is being staged and computed: page-locking
+    15 GB of results (32 4K frames) takes 0.6 s at the 24 GB/s a pinned allocation runs at, three times the whole pipeline --
+    nothing needs the tensors before the first chunk's codes are back on the host.  PyTorch's pinned-memory cache serves the
+    request at once when a previous call's results have been released (or `prewarm` ran)."""
+
+    def __init__(self, shapes, pinned):
+        self.shapes, self.pinned, self.tensors, self.error = shapes, pinned, None, None
+        self.thread = threading.Thread(target=self._run, name="comfystereo-results", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        try:
+            if self.pinned:
+                try:
+                    self.tensors = tuple(torch.empty(sh, dtype=torch.float32, pin_memory=True) for sh in self.shapes)
+                    return
+                except RuntimeError:   # not enough lockable memory: pageable results
+                    self.pinned = False
+            self.tensors = tuple(torch.empty(sh, dtype=torch.float32) for sh in self.shapes)
+        except BaseException as e:   # (re-raised by get() on the caller's thread)
+            self.error = e
+
+    def get(self):
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+        return self.tensors
+
+
 def generate_host(image, depth_map, divergence, separation, modes, stereo_balance, convergence_point,
                   stereo_offset_exponent, fill, depth_blur_edge_threshold, depth_blur_strength, depth_map_blur,
                   depth_blur_falloff=1.0, depth_blur_vert_smooth=0, batch_size=4, device=None, progress=None,
@@ -93,9 +139,7 @@ def generate_host(image, depth_map, divergence, separation, modes, stereo_balanc
     """CPU tensors in (image [N,H,W,3], depth_map [N,H',W',C], float32) -> four CPU float32 tensors, like
     StereoImageNode.generate returns them.  `progress(k)` is called with the number of frames finished.
     out: (stereoscope, depth_left, depth_right, mask) CPU float32 tensors of the result shapes (`result_shapes`) to write
-    into: a caller that keeps PINNED result tensors across calls (`tensor.pin_memory()` once) takes the
-    pinned allocation -- 24 GB/s of page faulting and locking, the bound of the default path -- off the critical path;
-    pageable tensors work too (through the pinned staging buffers)."""
+    into; pageable tensors work too.  compact=False: the float32 boundary of round 2 (comparison)."""
     if not torch.cuda.is_available():
         raise RuntimeError("comfystereo_amd needs an MI355X (PyTorch-ROCm `cuda` device); there is no CPU fallback")
     device = device or torch.device("cuda", torch.cuda.current_device())
@@ -118,7 +162,9 @@ def generate_host(image, depth_map, divergence, separation, modes, stereo_balanc
         compact = fill != 'gpu_warp'
     if compact and fill == 'gpu_warp':
         raise ValueError("gpu_warp colours are not k/255: no compact boundary")
-    if compact:
+    kind = "compact" if compact else ("warp" if fill == 'gpu_warp' else "float")
+    routes = ROUTES[kind]
+    if kind == "compact":
         per_frame_in = 4 * (h * w * 3 + dshape[0] * dshape[1] * dshape[2])
         chunk = max(1, min(total, CHUNK_IN_BYTES // max(per_frame_in, 1)))
         if total >= 4:   # at least four chunks so that staging, transfers, kernels and the host expansion overlap
@@ -126,6 +172,7 @@ def generate_host(image, depth_map, divergence, separation, modes, stereo_balanc
     else:
         chunk = _chunk_frames(total, per_frame_out, fill, batch_size)
     shapes = ((total, oh, ow, 3), (total, h, w, 3), (total, h, w, 3), (total, mh, mw))
+    results = None   # helper thread that allocates the result tensors
     final = None
     if out is not None:
         out = tuple(out)
@@ -134,113 +181,195 @@ def generate_host(image, depth_map, divergence, separation, modes, stereo_balanc
         for t, sh in zip(out, shapes):
             if t.device.type != "cpu" or t.dtype != torch.float32 or tuple(t.shape) != sh or not t.is_contiguous():
                 raise ValueError(f"out tensors must be contiguous CPU float32 tensors of shapes {shapes}")
-        if all(t.is_pinned() for t in out):
-            final = out
-    if final is None and out is None and pinned_outputs:
-        # (compact boundary too: the host threads then write into pinned blocks that PyTorch's host allocator caches -- no page
-        # faults on the way in, and dropping 15 GB of results is not a 0.7 s munmap on the caller's side, profiles/r03_host.txt)
-        try:
-            final = tuple(torch.empty(sh, dtype=torch.float32, pin_memory=True) for sh in shapes)
-        except RuntimeError:  # not enough lockable memory: fall back to pageable results through staging buffers
-            final = None
-    direct = final is not None and not compact   # (float32 boundary: the device writes straight into pinned results)
-    if final is None:
-        final = out if out is not None else tuple(torch.empty(sh, dtype=torch.float32) for sh in shapes)
+        final = out
+    else:
+        # (pinned for the compact boundary too: the host threads then write into blocks that PyTorch's host allocator caches -- no
+        # page faults on the way in, and dropping 15 GB of results is not a 0.7 s munmap on the caller's side, profiles/r03_host.txt)
+        results = _Results(shapes, pinned_outputs)
+    has_f32 = "f32" in routes
+    # float32 routes: the device writes straight into a pinned result tensor; otherwise through a pinned staging buffer.  Known
+    # now for caller-provided tensors, for our own allocation when it has finished (staging buffers are allocated to be safe)
+    direct_known = final is not None
+    direct = direct_known and all(final[k].is_pinned() for k, r in enumerate(routes) if r == "f32")
+    staged_f32 = has_f32 and direct_known and not direct
     ranges = [(b0, min(b0 + chunk, total)) for b0 in range(0, total, chunk)]
-    slots = [_Stage(params(chunk), dshape, device, not direct, compact) for _ in range(min(2, len(ranges)))]
-    tail = None  # a shorter last chunk gets its own (smaller) slot
-    if ranges[-1][1] - ranges[-1][0] != chunk:
-        tail = _Stage(params(ranges[-1][1] - ranges[-1][0]), dshape, device, not direct, compact)
     L = _native.lib()
     nthreads = expand_threads if expand_threads > 0 else max(1, min(32, (os.cpu_count() or 1)))
     copy_threads = max(1, min(16, (os.cpu_count() or 1)))
-    pool = ThreadPoolExecutor(max_workers=1) if compact else None   # (one job at a time: each job is multi-threaded itself)
+    host_jobs = any(r != "f32" for r in routes)
+    pool = ThreadPoolExecutor(max_workers=1) if host_jobs else None   # (one job at a time: each job is multi-threaded itself)
+    state = {"final": final}
+
+    def get_final():
+        if state["final"] is None:
+            state["final"] = results.get()
+        return state["final"]
 
     def expand_chunk(slot, b0, b1):
-        """Worker thread: wait for the chunk's codes in pinned memory, write the float32 results (the GIL is released
-        inside the native calls)."""
+        """Worker thread: wait for the chunk's compact outputs in pinned memory, write the float32 results (the GIL is
+        released inside the native calls)."""
+        fin = get_final()
         slot.e_out.synchronize()
-        n = b1 - b0
-        for k, (rep, mode) in enumerate(((1, 0), (3, 0), (3, 0), (1, 1))):
-            dst = final[k][b0:b1]
+        for k, r in enumerate(routes):
+            if r == "f32":
+                continue
+            dst = fin[k][b0:b1]
+            rep = 1 if k in (0, 3) else 3
             count = dst.numel() // rep
-            rc = L.cs_host_expand_u8(ctypes.c_void_p(slot.pin_codes[k].data_ptr()), ctypes.c_void_p(dst.data_ptr()), count, rep,
-                                     mode, nthreads)
+            src = ctypes.c_void_p(slot.pin_small[k].data_ptr())
+            if r == "u8":
+                rc = L.cs_host_expand_u8(src, ctypes.c_void_p(dst.data_ptr()), count, rep, 1 if k == 3 else 0, nthreads)
+            else:
+                rc = L.cs_host_replicate_f32(src, ctypes.c_void_p(dst.data_ptr()), count, rep, nthreads)
             if rc:
-                raise RuntimeError(f"cs_host_expand_u8 failed ({rc})")
-        return n
+                raise RuntimeError(f"host expansion of output {k} failed ({rc})")
+        return b1 - b0
+
     s_h2d, s_d2h = torch.cuda.Stream(device), torch.cuda.Stream(device)
     s_main = torch.cuda.current_stream(device)
+    slots = []
 
     def drain(slot):  # the slot's chunk is complete on the host
-        if compact:
-            done = slot.future.result()
-            slot.future = None
-            slot.range = None
-            if progress:
-                progress(done)
-            return
-        slot.e_out.synchronize()
         b0, b1 = slot.range
-        if not direct:
-            for dst, src in zip(final, slot.pin_out):
-                dst[b0:b1].copy_(src[: b1 - b0])
+        if slot.future is not None:
+            slot.future.result()
+            slot.future = None
+        slot.e_out.synchronize()
+        if has_f32 and not state["direct"]:
+            fin = get_final()
+            for k, r in enumerate(routes):
+                if r == "f32":
+                    fin[k][b0:b1].copy_(slot.pin_out[k][: b1 - b0])
         slot.range = None
         if progress:
             progress(b1 - b0)
 
-    for i, (b0, b1) in enumerate(ranges):
-        slot = tail if (tail is not None and i == len(ranges) - 1) else slots[i % len(slots)]
-        if slot.range is not None:  # the slot still holds the chunk of two iterations ago
-            if compact:             # its codes must have been expanded out of the pinned staging
+    state["direct"] = direct
+    try:
+        slots = [_Stage(params(chunk), dshape, device, routes, staged_f32) for _ in range(min(2, len(ranges)))]
+        tail = None  # a shorter last chunk gets its own (smaller) slot
+        if ranges[-1][1] - ranges[-1][0] != chunk:
+            tail = _Stage(params(ranges[-1][1] - ranges[-1][0]), dshape, device, routes, staged_f32)
+            slots.append(tail)
+        for i, (b0, b1) in enumerate(ranges):
+            slot = tail if (tail is not None and i == len(ranges) - 1) else slots[i % min(2, len(ranges))]
+            if slot.range is not None:  # the slot still holds the chunk of two iterations ago
                 drain(slot)
-            elif direct:            # its inputs must have left the pinned staging; the rest is ordered on the device
-                slot.e_in.synchronize()
-            else:
-                drain(slot)
-        n = b1 - b0
-        # staging copy pageable -> pinned by the library's own threads (torch's CPU copy_ is bimodal on the MI355X boxes:
-        # 90-170 GB/s or, every few calls, 5 GB/s; cs_host_copy: 130-160 GB/s every time -- profiles/r03_host.txt)
-        for dst, src in ((slot.pin_img, image[b0:b1]), (slot.pin_dep, depth_map[b0:b1])):
-            rc = L.cs_host_copy(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), src.numel() * 4, copy_threads)
-            if rc:
-                raise RuntimeError(f"cs_host_copy failed ({rc})")
-        with torch.cuda.stream(s_h2d):
+            # staging copy pageable -> pinned by the library's own threads (torch's CPU copy_ is bimodal on the MI355X boxes:
+            # 90-170 GB/s or, every few calls, 5 GB/s; cs_host_copy: 130-160 GB/s every time -- profiles/r03_host.txt)
+            for dst, src in ((slot.pin_img, image[b0:b1]), (slot.pin_dep, depth_map[b0:b1])):
+                rc = L.cs_host_copy(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), src.numel() * 4, copy_threads)
+                if rc:
+                    raise RuntimeError(f"cs_host_copy failed ({rc})")
+            with torch.cuda.stream(s_h2d):
+                if slot.used:
+                    s_h2d.wait_event(slot.e_done)  # the kernels that read the device inputs two chunks ago
+                slot.dev_img.copy_(slot.pin_img, non_blocking=True)
+                slot.dev_dep.copy_(slot.pin_dep, non_blocking=True)
+                slot.e_in.record(s_h2d)
+            s_main.wait_event(slot.e_in)
             if slot.used:
-                s_h2d.wait_event(slot.e_done)  # the kernels that read the device inputs two chunks ago
-            slot.dev_img.copy_(slot.pin_img, non_blocking=True)
-            slot.dev_dep.copy_(slot.pin_dep, non_blocking=True)
-            slot.e_in.record(s_h2d)
-        s_main.wait_event(slot.e_in)
-        if slot.used:
-            s_main.wait_event(slot.e_out)      # the device outputs of two chunks ago have been read out
-        slot.plan.run(slot.dev_img, slot.dev_dep)
-        if compact:   # depth maps (one code per pixel) and mask as bytes; the stereoscope already is (flags bit 1)
+                s_main.wait_event(slot.e_out)      # the device outputs of two chunks ago have been read out
+            slot.plan.run(slot.dev_img, slot.dev_dep)
+            outs = (slot.plan.stereo, slot.plan.depth_l, slot.plan.depth_r, slot.plan.mask)
             st = ctypes.c_void_p(s_main.cuda_stream)
-            for src, dst, stride, mode in ((slot.plan.depth_l, slot.dev_codes[1], 3, 0), (slot.plan.depth_r, slot.dev_codes[2], 3, 0),
-                                           (slot.plan.mask, slot.dev_codes[3], 1, 1)):
-                _native.check(L.cs_pack_u8(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), dst.numel(), stride, mode, st))
-        slot.e_done.record(s_main)
-        with torch.cuda.stream(s_d2h):
-            s_d2h.wait_event(slot.e_done)
-            if compact:
-                for src, dst in zip(slot.dev_codes, slot.pin_codes):
-                    dst.copy_(src, non_blocking=True)
-            else:
-                outs = (slot.plan.stereo, slot.plan.depth_l, slot.plan.depth_r, slot.plan.mask)
-                for k, src in enumerate(outs):
-                    dst = final[k][b0:b1] if direct else slot.pin_out[k]
-                    dst.copy_(src, non_blocking=True)
-            slot.e_out.record(s_d2h)
-        if compact:
-            slot.future = pool.submit(expand_chunk, slot, b0, b1)
-        if direct and slot.range is not None and progress:
-            progress(slot.range[1] - slot.range[0])
-        slot.range = (b0, b1)
-        slot.used = True
-    for slot in slots + ([tail] if tail is not None else []):
-        if slot.range is not None:
-            drain(slot)
-    if pool is not None:
-        pool.shutdown(wait=True)
-    return final
+            for k, r in enumerate(routes):   # the compact device forms (the uint8 stereoscope already is one: flags bit 1)
+                if r == "u8" and k != 0:
+                    _native.check(L.cs_pack_u8(ctypes.c_void_p(outs[k].data_ptr()), ctypes.c_void_p(slot.dev_small[k].data_ptr()),
+                                               slot.dev_small[k].numel(), 3 if k in (1, 2) else 1, 1 if k == 3 else 0, st))
+                elif r == "f1":
+                    _native.check(L.cs_take_f32(ctypes.c_void_p(outs[k].data_ptr()), ctypes.c_void_p(slot.dev_small[k].data_ptr()),
+                                                slot.dev_small[k].numel(), 3, st))
+            slot.e_done.record(s_main)
+            if has_f32 and not direct_known:   # our own result tensors: pinned (direct) or not is known once they exist
+                fin = get_final()
+                state["direct"] = direct = all(fin[k].is_pinned() for k, r in enumerate(routes) if r == "f32")
+                direct_known = True
+            with torch.cuda.stream(s_d2h):
+                s_d2h.wait_event(slot.e_done)
+                for k, r in enumerate(routes):
+                    if r == "f32":
+                        if not direct and slot.pin_out[k] is None:   # (pageable results only: a pinned staging buffer)
+                            slot.pin_out[k] = torch.empty(outs[k].shape, dtype=outs[k].dtype, pin_memory=True)
+                        dst = get_final()[k][b0:b1] if direct else slot.pin_out[k]
+                        dst.copy_(outs[k], non_blocking=True)
+                    else:
+                        slot.pin_small[k].copy_(slot.dev_small[k], non_blocking=True)
+                slot.e_out.record(s_d2h)
+            if host_jobs:
+                slot.future = pool.submit(expand_chunk, slot, b0, b1)
+            slot.range = (b0, b1)
+            slot.used = True
+        for slot in slots:
+            if slot.range is not None:
+                drain(slot)
+        return get_final()
+    finally:
+        # (also after an exception: no queued expansion may outlive the call -- it would write into `final` and hold the pinned
+        # slots -- and no transfer may still be in flight when the slots' buffers go back to the allocators)
+        if pool is not None:
+            pool.shutdown(wait=True, cancel_futures=True)
+        for slot in slots:
+            if slot.future is not None and not slot.future.cancelled():
+                try:
+                    slot.future.result()
+                except BaseException:
+                    pass
+        s_h2d.synchronize(); s_d2h.synchronize()
+        if results is not None:
+            results.thread.join()
+
+
+def prewarm(frames, h, w, depth_shape=None, modes="left-right", fill="polylines_soft", batch_size=12, device=None, calls=2):
+    """Allocate -- and release into PyTorch's caching allocators -- the pinned result tensors, the pinned staging buffers and
+    the device buffers a `generate_host` call of this shape needs, so that the FIRST call of a process finds them cached
+    (a pinned allocation runs at 24 GB/s: 0.8 s for the 19 GB of a 32-frame 4K call, four times the call itself).
+    `calls`: result sets to warm (a caller that still holds the previous results needs a second set).  Blocking; run it on a
+    thread (`prewarm_async`).  The memory stays in PyTorch's caches (torch.cuda.empty_cache() / the host allocator's own
+    release give it back)."""
+    if not torch.cuda.is_available():
+        return False
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    dshape = tuple(depth_shape) if depth_shape else (h, w, 3)
+    p = lambda n: engine.make_params(n, h, w, dshape[0], dshape[1], dshape[2], fill, modes, 4.5, 0.0, 0.0, 0.5, 2.0, True,
+                                     20.0, 20.0, 2.0, 6, batch_size)
+    oh, ow, mh, mw = engine.output_shape(p(1))
+    kind = "warp" if fill == "gpu_warp" else "compact"
+    if kind == "compact":
+        per_frame_in = 4 * (h * w * 3 + dshape[0] * dshape[1] * dshape[2])
+        chunk = max(1, min(frames, CHUNK_IN_BYTES // max(per_frame_in, 1)))
+        if frames >= 4:
+            chunk = min(chunk, (frames + 3) // 4)
+    else:
+        chunk = _chunk_frames(frames, 4 * (oh * ow * 3 + 2 * h * w * 3 + mh * mw), fill, batch_size)
+    shapes = ((frames, oh, ow, 3), (frames, h, w, 3), (frames, h, w, 3), (frames, mh, mw))
+    keep = [[torch.empty(sh, dtype=torch.float32, pin_memory=True) for sh in shapes] for _ in range(max(1, calls))]
+    nslots = min(2, (frames + chunk - 1) // chunk)
+    keep.append([_Stage(p(chunk), dshape, device, ROUTES[kind], False) for _ in range(nslots)])
+    if frames % chunk:
+        keep.append(_Stage(p(frames % chunk), dshape, device, ROUTES[kind], False))
+    torch.cuda.synchronize(device)
+    del keep
+    return True
+
+
+_prewarm_thread = None
+
+
+def prewarm_async(*args, **kw):
+    """`prewarm` on a daemon thread (what GenerateStereo.py starts at import when PREWARM names a shape)."""
+    global _prewarm_thread
+
+    def run():
+        try:
+            prewarm(*args, **kw)
+        except Exception:   # a warm-up must never take the process down (no GPU yet, not enough lockable memory ...)
+            pass
+    _prewarm_thread = threading.Thread(target=run, name="comfystereo-prewarm", daemon=True)
+    _prewarm_thread.start()
+    return _prewarm_thread
+
+
+def prewarm_wait():
+    if _prewarm_thread is not None:
+        _prewarm_thread.join()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 2
+#define CS_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define CS_API __attribute__((visibility("default")))
@@ -142,9 +142,10 @@ CS_API int cs_generate(const cs_params *p, const float *image, const float *dept
  * apply_stereo_divergence (reference stereoimage_generation.py:1576-1620) for one eye of `n`
  * independent frames: per-frame min/max normalisation, convergence shift, percent -> pixels, row
  * kernel `fill` (any CPU technique).  image_u8 [n][h][w][3] uint8, depth [n][h][w] float32,
- * out_u8 [n][h][w][3].  workspace: cs_asd_workspace_bytes(n, h, w).
+ * out_u8 [n][h][w][3].  workspace: cs_asd_workspace_bytes_for(n, h, w, fill) (cs_asd_workspace_bytes: enough for any technique).
  */
 CS_API size_t cs_asd_workspace_bytes(int n, int h, int w);
+CS_API size_t cs_asd_workspace_bytes_for(int n, int h, int w, int fill);
 CS_API int cs_apply_stereo_divergence(const uint8_t *image_u8, const float *depth, int n, int h, int w, double divergence,
                                double separation, double stereo_offset_exponent, int fill, double convergence_point,
                                uint8_t *out_u8, void *workspace, size_t workspace_bytes, void *stream);
@@ -210,6 +211,12 @@ CS_API int cs_host_expand_u8(const uint8_t *codes, float *out, size_t count, int
 /* cs_host_copy (HOST memory, blocking): memcpy in `threads` contiguous slices (0 = one per online core up to 64) -- the
  * staging copy of a pageable input tensor into a pinned buffer (reference GenerateStereo.py:126-131, .to(device)). */
 CS_API int cs_host_copy(void *dst, const void *src, size_t bytes, int threads);
+/* gpu_warp's depth-map outputs are genuine floats on three EQUAL channels (reference GenerateStereo.py:165-169: clamp(0, 1),
+ * unsqueeze(-1).expand): cs_take_f32 (device) keeps one channel -- out[i] = values[i * stride] -- so that 4 instead of 12
+ * bytes per pixel cross PCIe, cs_host_replicate_f32 (HOST memory, blocking) writes out[i * replicate + r] = values[i],
+ * r < replicate <= 4, with `threads` worker threads (0 = one per online core up to 64). */
+CS_API int cs_take_f32(const float *values, float *out, size_t count, int stride, void *stream);
+CS_API int cs_host_replicate_f32(const float *values, float *out, size_t count, int replicate, int threads);
 
 /*
  * stereo_shift_torch (reference stereo_utils.py:15-88; callers stereodiffusion_nodes.py:650, :664): the depth-driven
@@ -231,6 +238,9 @@ CS_API int cs_stereo_shift(const float *input, const float *depth, int b, int c,
  */
 CS_API int cs_profile(int enable);
 CS_API int cs_profile_read(double *total_ms, int *launches);
+/* cs_profile_tiles (blocking): the share of 64 x 32 depth tiles the last profiled cs_generate call blurred (the warp kernel reads
+ * the others from the gray depth, shared by both eyes); -1 when that call's warp kernel read complete blurred maps. */
+CS_API int cs_profile_tiles(double *fraction);
 
 /*
  * Development switches for the parity tests and profiling tools (compare two code paths of the same kernel,

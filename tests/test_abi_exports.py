@@ -22,7 +22,7 @@ def test_library_is_built_and_exports_every_declared_symbol():
     assert len(syms) >= 14 and set(syms) == set(_native.EXPORTS)
     for s in syms:
         assert hasattr(L, s), s
-    assert L.cs_version() == 2
+    assert L.cs_version() == _native.ABI_VERSION == 3
 
 
 def test_enums_match_header():
@@ -119,6 +119,16 @@ def test_host_expansion_and_copy_need_no_gpu():
             m = np.full(count, -1.0, np.float32)
             assert L.cs_host_expand_u8(codes.ctypes.data, m.ctypes.data, count, 1, 1, threads) == 0 or count == 0
             assert np.array_equal(m, (codes != 0).astype(np.float32))
+        for off in (1, 2, 3):   # destinations that are not 16-byte aligned (the streaming stores need an aligned body)
+            buf = np.full(3 * count + 8, -1.0, np.float32)
+            o1 = buf[off:off + count]
+            assert L.cs_host_expand_u8(codes.ctypes.data, o1.ctypes.data, count, 1, 0, 3) == 0 or count == 0
+            assert np.array_equal(o1, codes.astype(np.float32) / np.float32(255.0)) and buf[off + count] == -1.0 and buf[off - 1] == -1.0
+            buf[:] = -1.0
+            o3 = buf[off:off + 3 * count]
+            assert L.cs_host_expand_u8(codes.ctypes.data, o3.ctypes.data, count, 3, 0, 3) == 0 or count == 0
+            assert np.array_equal(o3.reshape(-1, 3), np.repeat((codes.astype(np.float32) / np.float32(255.0))[:, None], 3, 1))
+            assert buf[off + 3 * count] == -1.0 and buf[off - 1] == -1.0
         src = rng.integers(0, 256, count * 3 + 5, dtype=np.uint8)
         dst = np.zeros_like(src)
         assert L.cs_host_copy(dst.ctypes.data, src.ctypes.data, src.size, 4) == 0

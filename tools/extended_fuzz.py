@@ -15,6 +15,9 @@ from oracle import node_oracle, oracle
 from comfystereo_amd import engine
 from test_gpu_fuzz import FILLS, make_case
 
+if os.environ.get("CS_FUZZ_FILLS"):   # restrict the run to some techniques (a kernel under development): "polylines_soft,polylines_sharp"
+    FILLS = [f for f in FILLS if f in os.environ["CS_FUZZ_FILLS"].split(",")]
+
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 150.0
 t0 = time.time()
 n_asd = n_node = 0

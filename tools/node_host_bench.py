@@ -18,13 +18,30 @@ ap.add_argument("--h", type=int, default=2160)
 ap.add_argument("--w", type=int, default=3840)
 ap.add_argument("--iters", type=int, default=2)
 ap.add_argument("--fill", default="Fill - Polylines Soft")
+ap.add_argument("--prewarm", type=int, default=1, help="1: what GenerateStereo.py does at import inside ComfyUI (host_pipeline."
+                "prewarm of this shape, waited for: ComfyUI loads its models meanwhile); 0: cold caches")
 a = ap.parse_args()
+from comfystereo_amd import host_pipeline as _hp
+from comfystereo_amd.GenerateStereo import FILL_TECHNIQUE_MAPPING as _FM
+if a.prewarm:
+    t0 = time.perf_counter()
+    _hp.prewarm(a.n, a.h, a.w, fill=_FM[a.fill])
+    print(f"prewarm (at import, off the first call's path): {time.perf_counter() - t0:.2f} s")
 img = torch.from_numpy(synth.image_f32(1, a.h, a.w, seed=1)).expand(a.n, -1, -1, -1).contiguous()
 dep = torch.from_numpy(synth.depth_batch("stepped", a.n, a.h, a.w, channels=3))
 node = StereoImageNode()
 args = (8.0, 0.0, "left-right", 0.0, 0.5, 2.0, a.fill, 20.0, 20.0, True, 2.0, 6, 12)
+t0 = time.perf_counter()
 out = node.generate(img, dep, *args)
 torch.cuda.synchronize()
+dt_first = time.perf_counter() - t0
+print(f"FIRST call of the process ({'prewarmed' if a.prewarm else 'cold'}): {dt_first*1e3:.1f} ms -> {a.n/dt_first:.1f} frames/s")
+t0 = time.perf_counter()
+out2 = node.generate(img, dep, *args)   # (the first call's results still held by the caller)
+torch.cuda.synchronize()
+dt_second = time.perf_counter() - t0
+print(f"second call, first results still held: {dt_second*1e3:.1f} ms -> {a.n/dt_second:.1f} frames/s")
+del out2
 t0 = time.perf_counter()
 for _ in range(a.iters):
     out = node.generate(img, dep, *args)

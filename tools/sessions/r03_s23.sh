@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 closing profiles (tag r03f; r03d: the state before the 4-slot geometries): default bench (kernel trace + PMC passes), BASELINE configs 2-5 (kernel trace + bench line),
 # PMC passes of cfg3 (its kernels changed), host bench, tie bench lines
-bash tools/r03_profiles.sh r03f
+bash tools/sessions/r03_profiles.sh r03f
 for c in cfg3; do bash tools/gpu_profile.sh r03f_${c}_pmc --config $c > /dev/null 2>&1; done
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/r03f_ties
