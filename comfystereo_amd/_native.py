@@ -28,8 +28,8 @@ ABI_VERSION = 3
 
 EXPORTS = [
     "cs_version", "cs_last_error", "cs_max_width", "cs_max_width_mode", "cs_output_shape", "cs_workspace_bytes", "cs_generate",
-    "cs_asd_workspace_bytes", "cs_asd_workspace_bytes_for", "cs_apply_stereo_divergence", "cs_apply_stereo_divergence2", "cs_blur_workspace_bytes", "cs_directional_blur",
-    "cs_warp_workspace_bytes", "cs_forward_warp", "cs_warp_mesh_workspace_bytes", "cs_forward_warp_mesh", "cs_expand_u8", "cs_pack_u8", "cs_host_expand_u8", "cs_host_copy", "cs_take_f32", "cs_host_replicate_f32", "cs_stereo_shift_workspace_bytes", "cs_stereo_shift", "cs_profile", "cs_profile_read", "cs_profile_tiles", "cs_debug_set",
+    "cs_asd_workspace_bytes", "cs_asd_workspace_bytes_for", "cs_apply_stereo_divergence", "cs_apply_stereo_divergence2", "cs_blur_workspace_bytes", "cs_directional_blur", "cs_blur_scipy_workspace_bytes", "cs_directional_blur_scipy",
+    "cs_warp_workspace_bytes", "cs_forward_warp", "cs_forward_warp2", "cs_warp_mesh_workspace_bytes", "cs_forward_warp_mesh", "cs_expand_u8", "cs_pack_u8", "cs_host_expand_u8", "cs_host_copy", "cs_take_f32", "cs_host_replicate_f32", "cs_stereo_shift_workspace_bytes", "cs_stereo_shift", "cs_profile", "cs_profile_read", "cs_profile_tiles", "cs_debug_set",
     "cs_test_powf", "cs_test_exp", "cs_test_edge_threshold",
 ]
 
@@ -106,6 +106,10 @@ def lib():
     L.cs_directional_blur.restype = c_int
     L.cs_directional_blur.argtypes = [vp, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int, vp, vp, vp,
                                       c_size, vp]
+    L.cs_blur_scipy_workspace_bytes.restype = c_size
+    L.cs_blur_scipy_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    L.cs_directional_blur_scipy.restype = c_int
+    L.cs_directional_blur_scipy.argtypes = [vp, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int, vp, vp, vp, c_size, vp]
     L.cs_warp_workspace_bytes.restype = c_size
     L.cs_warp_workspace_bytes.argtypes = [c_int, c_int, c_int]
     L.cs_warp_mesh_workspace_bytes.restype = c_size
@@ -114,6 +118,8 @@ def lib():
     L.cs_forward_warp_mesh.argtypes = [vp, vp, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_double, vp, vp, vp, c_size, vp]
     L.cs_forward_warp.restype = c_int
     L.cs_forward_warp.argtypes = [vp, vp, c_int, c_int, c_int, c_double, c_double, c_double, c_double, vp, vp, vp, c_size, vp]
+    L.cs_forward_warp2.restype = c_int
+    L.cs_forward_warp2.argtypes = [vp, vp, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_int, vp, vp, vp, c_size, vp]
     L.cs_pack_u8.restype = c_int
     L.cs_pack_u8.argtypes = [vp, vp, c_size, c_int, c_int, vp]
     L.cs_host_expand_u8.restype = c_int

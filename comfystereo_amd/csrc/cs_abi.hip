@@ -393,8 +393,8 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
             T.out_h = A.h; T.out_w = 2 * A.w;
             T.eye[0].xoff = 0; T.eye[0].yoff = 0; T.eye[1].xoff = A.w; T.eye[1].yoff = 0;
         }
-        if (fill == CS_FILL_POLYLINES_SOFT && halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16)))
-            e = launch_polypoint(T, halo, rowflag, stream);
+        if (halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16)))
+            e = launch_polypoint(T, halo, rowflag, stream, fill == CS_FILL_POLYLINES_SHARP);
         else
             e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, T, halo, rowflag, stream);
         if (e != hipSuccess) return fail_hip(e, "tiled polylines launch");
@@ -914,12 +914,29 @@ int cs_directional_blur(const float* depth, int n, int h, int w, double blur_str
     return e == hipSuccess ? CS_OK : fail_hip(e, "cs_directional_blur");
 }
 
+size_t cs_blur_scipy_workspace_bytes(int n, int h, int w) { return scipyblur_workspace_bytes(n, h, w); }
+
+int cs_directional_blur_scipy(const float* depth, int n, int h, int w, double blur_strength, double edge_threshold,
+                              double blur_mask_width, double falloff_exponent, int vert_smooth_px, float* out_l, float* out_r,
+                              void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!depth || !out_l || !out_r || !workspace) return fail(CS_EINVAL, "null pointer");
+    if (n <= 0 || h <= 0 || w <= 0) return fail(CS_EINVAL, "non-positive size");
+    if (workspace_bytes < cs_blur_scipy_workspace_bytes(n, h, w)) return fail(CS_EWORKSPACE, "workspace too small");
+    if (!(blur_strength > 0.0)) return fail(CS_EINVAL, "blur_strength <= 0: the reference returns the depth map itself (:1374); the caller does the same");
+    if (!(blur_strength < 1e6) || !(blur_mask_width < 1e6)) return fail(CS_EINVAL, "blur_strength / blur_mask_width out of range");
+    int rc = launch_scipyblur(depth, n, h, w, blur_strength, edge_threshold, blur_mask_width, falloff_exponent, vert_smooth_px,
+                              out_l, out_r, workspace, (hipStream_t)stream_);
+    if (rc == CS_EINVAL) return fail(rc, "blur_strength rounds to a box of 0 taps: the reference fails there too (scipy: no filter weights given)");
+    return rc ? fail(rc, "cs_directional_blur_scipy launch failed") : CS_OK;
+}
+
 size_t cs_warp_workspace_bytes(int n, int h, int w) { return al256((size_t)n * ST_WORDS * 4) + al256(gpuwarp_workspace_bytes(n, h, w, n, 0)); }
 size_t cs_warp_mesh_workspace_bytes(int n, int h, int w) { return al256((size_t)n * ST_WORDS * 4) + al256(gpuwarp_workspace_bytes(n, h, w, n, 1)); }
 
 static int forward_warp_common(const float* image, const float* depth, int n, int h, int w, double divergence_px,
                                double separation_px, double exponent, double convergence, int mesh, double grad_thr,
-                               float* warped, uint8_t* gap_mask, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                               float* warped, uint8_t* gap_mask, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                               int max_stretch = 8) {
     if (!image || !depth || !warped || !gap_mask || !workspace) return fail(CS_EINVAL, "null pointer");
     if (n <= 0 || h <= 0 || w <= 0) return fail(CS_EINVAL, "non-positive size");
     if (mesh && (h < 2 || w < 2)) return fail(CS_EINVAL, "the mesh warp needs at least 2 x 2 pixels");
@@ -931,7 +948,8 @@ static int forward_warp_common(const float* image, const float* depth, int n, in
     hipLaunchKernelGGL(k_stats_init, dim3((n * ST_WORDS + 255) / 256), dim3(256), 0, stream, stats, n);
     hipLaunchKernelGGL(k_minmax, dim3(grid_for((size_t)h * w, 256), n), dim3(256), 0, stream, depth, h * w, stats, ST_L_MIN, ST_L_MAX);
     int rc = launch_gpuwarp_plain(image, depth, n, h, w, divergence_px, separation_px, exponent, convergence, warped,
-                                  gap_mask, stats, (char*)workspace + al256((size_t)n * ST_WORDS * 4), stream, mesh, grad_thr);
+                                  gap_mask, stats, (char*)workspace + al256((size_t)n * ST_WORDS * 4), stream, mesh, grad_thr, max_stretch);
+    if (rc == CS_ELIMIT) return fail(rc, "gpu_warp: gradient_threshold above 13 with max_stretch above 16 is not supported (more than 16 effective scatter rounds)");
     if (rc) return fail(rc, "gpu_warp launch failed");
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CS_OK : fail_hip(e, "cs_forward_warp");
@@ -942,6 +960,13 @@ int cs_forward_warp(const float* image, const float* depth, int n, int h, int w,
                     void* workspace, size_t workspace_bytes, void* stream_) {
     return forward_warp_common(image, depth, n, h, w, divergence_px, separation_px, exponent, convergence, 0, 1.5, warped,
                                gap_mask, workspace, workspace_bytes, (hipStream_t)stream_);
+}
+
+int cs_forward_warp2(const float* image, const float* depth, int n, int h, int w, double divergence_px,
+                     double separation_px, double exponent, double convergence, double gradient_threshold, int max_stretch,
+                     float* warped, uint8_t* gap_mask, void* workspace, size_t workspace_bytes, void* stream_) {
+    return forward_warp_common(image, depth, n, h, w, divergence_px, separation_px, exponent, convergence, 0, gradient_threshold,
+                               warped, gap_mask, workspace, workspace_bytes, (hipStream_t)stream_, max_stretch);
 }
 
 int cs_forward_warp_mesh(const float* image, const float* depth, int n, int h, int w, double divergence_px,

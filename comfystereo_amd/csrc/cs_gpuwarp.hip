@@ -47,7 +47,8 @@ struct GwArgs {
     int noclamp;
     int dbg;           // development (-DCS_DEV builds): phase cut-offs 51-54 of k_gpuwarp
     int mesh;          // 1: mesh-quality warp (k_meshwarp) instead of forward_warp_gpu's scatter rounds
-    float grad_thr;    // mesh: gradient_threshold of the triangle culling (reference :455, 1.5)
+    float grad_thr;    // gradient_threshold: mesh -- the triangle culling (reference :455, 1.5); scatter rounds -- connectivity (:339-340)
+    int rounds;        // scatter rounds that can change a column: min(max_stretch, floor(gradient_threshold + 2) + 1)  (:365)
     uint8_t* keep;     // mesh: [neyes][groups][h-1][w-1] keep bits (bit 0 triangle A, bit 1 triangle B)
     int group;         // mesh: frames per group (the tensor forward_warp_mesh is handed)
     // lazy depth-blur tiles (cs_common.h lazy_select; rows of at most 2048 columns, scatter-round warp only): the blurred maps
@@ -115,21 +116,37 @@ __device__ __forceinline__ bool gw_core_ok(float a) { const float m = fabsf(a); 
 // MINW: waves per SIMD the register budget is sized for -- 8 (64 VGPRs, 8 spilled) lets two 1024-thread workgroups share a
 // CU at 4K; the 512-thread workgroups of narrower frames run 6 per SIMD without spills (+5 % at 1080p)
 // POW: 2 = exponent 2 compiled in (the widget default: x * x, no mode dispatch per pixel), -1 = A.pow_mode at run time
-template <int MINW, int POW>
+// GEN: forward_warp_gpu's keyword parameters away from their defaults (gradient_threshold 1.5, max_stretch 8; reference :277-279):
+// connectivity threshold and the number of rounds at run time, 16 instead of 8 slots for the rounds' border columns.
+template <int MINW, int POW, bool GEN = false>
 __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
+    constexpr int NR = GEN ? 16 : 8;              // rounds the border arrays W0 / W1 and the offset of M provide for
+    const int RV = GEN ? A.rounds : 4;            // rounds that can pass the z-test (see the column pass)
+    const float conn_thr = GEN ? A.grad_thr : 1.5f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id();
+    // Workgroup b runs on XCD b % 8 (observed dispatch order; a speed assumption only).  With row = blockIdx.x the rows y and
+    // y + 1 -- whose image rows BOTH feed output row y through the 4-corner blend of the grid_sample round trip (:441-448) --
+    // sit on different XCDs, and each fetches both rows from the fabric: 2.8 x the algorithmic reads (profiles/r03g_cfg4_pmc).
+    // GW_XCD_ROWS: XCD k takes the rows [k * rpx, (k + 1) * rpx) in order, so the neighbour row is in that XCD's L2.
+#ifdef GW_XCD_ROWS
+    const int rpx = (A.h + 7) >> 3;
+    const int y = (int)(blockIdx.x & 7u) * rpx + (int)(blockIdx.x >> 3);
+    if (y >= A.h) return;
+    const int frame = blockIdx.y, w = A.w, h = A.h;
+#else
     const int y = blockIdx.x, frame = blockIdx.y, w = A.w, h = A.h;
+#endif
     float* ndn = (float*)smem;     // normalised depth (not convergence-shifted); after the column pass: the left-nearest scan
     float* po = ndn + w;           // pixel offset; from the column pass on: the source map
     float* D = po + w;             // x + offset = dl of pair x = dr of pair x-1
     float* zb = D + w;             // z-buffer
-    int* M = (int*)(zb + w);       // [w + 8] highest pair index per floor(min(dl, dr)) = -7 .. w-2
-    int* W0 = M + w + 8;           // [8] per round: highest pair index clamped to column 0
-    int* W1 = W0 + 8;              // [8] per round: highest pair index clamped to column w-1
+    int* M = (int*)(zb + w);       // [w + NR] highest pair index per floor(min(dl, dr)) = -(NR - 1) .. w-2
+    int* W0 = M + w + NR;          // [NR] per round: highest pair index clamped to column 0
+    int* W1 = W0 + NR;             // [NR] per round: highest pair index clamped to column w-1
     int* winner = (int*)ndn;
     float* sm = po;
-    uint8_t* flags = (uint8_t*)(W1 + 8);   // bit 0: gap in some eye (the mask output); bit 1: pair x is connected (this eye)
+    uint8_t* flags = (uint8_t*)(W1 + NR);   // bit 0: gap in some eye (the mask output); bit 1: pair x is connected (this eye)
     int* ws = (int*)(flags + align16((size_t)w));
     csm::PowfTables* T = (csm::PowfTables*)(ws + 32);
     if (A.pow_mode == 4) {
@@ -244,7 +261,7 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
                 D[x] = (float)x + p;
             }
         }
-        for (int x = tid; x < w + 8 + 16; x += nt) M[x] = -1;   // (M, W0, W1 are contiguous)
+        for (int x = tid; x < w + 3 * NR; x += nt) M[x] = -1;   // (M, W0, W1 are contiguous)
         __syncthreads();
         if (GW_DEV_IS(51)) continue;
         // ---- the 8 scatter rounds (:330-391).  In round k the pair (i, i+1) targets column clamp(fs_i + k, 0, w-1),
@@ -257,12 +274,12 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
             {
                 const float dl = D[i], dr = D[i + 1];
                 const float fs = floorf(fminf(dl, dr));
-                const bool connected = fabsf(po[i + 1] - po[i]) < 1.5f;
+                const bool connected = fabsf(po[i + 1] - po[i]) < conn_thr;
                 flags[i] = (uint8_t)((flags[i] & 1u) | (connected ? 2u : 0u));
-                if (fs >= -7.0f && fs <= (float)(w - 2)) atomicMax(&M[(int)fs + 7], i);
-                if (!(fs > 0.0f) || fs + 7.0f >= sxw) {
+                if (fs >= -(float)(NR - 1) && fs <= (float)(w - 2)) atomicMax(&M[(int)fs + NR - 1], i);
+                if (!(fs > 0.0f) || fs + (float)(NR - 1) >= sxw) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
+                    for (int k = 0; k < NR; k++) {
                         const float cfl = fs + (float)k;
                         if (!(cfl > 0.0f)) atomicMax(&W0[k], i);          // fmaxf(NaN, 0) == 0 as well
                         else if (cfl >= sxw) atomicMax(&W1[k], i);
@@ -298,7 +315,12 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
         int myright = -1;
         for (int x = tid; x < w; x += nt) {
             float z = -1.0f, src = -1.0f;
-            if (x > 0 && x < w - 1) {
+            if (GEN && x > 0 && x < w - 1) {
+                for (int k = 0; k < RV; k++) {   // (general parameters: the rounds one after the other)
+                    const int i = M[x - k + NR - 1];
+                    if (i >= 0) propose(i, (float)x, z, src);
+                }
+            } else if (x > 0 && x < w - 1) {
                 // interior column: the deciding pair of round k has fs == x - k, so its column value is x itself.  The LDS
                 // reads of the four rounds go out together (clamped index, validity applied afterwards): the rounds are
                 // only sequential in the z-test -- the kernel is bound by such dependent chains, not by the instruction count
@@ -306,7 +328,7 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
                 float dlk[4], drk[4];
                 unsigned fgk[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) ii[k] = M[x - k + 7];
+                for (int k = 0; k < 4; k++) ii[k] = M[x - k + NR - 1];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int j = max(ii[k], 0);
@@ -333,8 +355,7 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
                 }
             } else {
                 // the clamped columns: the deciding pair's own fs + k decides whether it is in range at all
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < RV; k++) {
                     const int i = x == 0 ? W0[k] : W1[k];
                     if (i >= 0) propose(i, floorf(fminf(D[i], D[i + 1])) + (float)k, z, src);
                 }
@@ -737,8 +758,8 @@ __global__ void k_gpuwarp_flags(uint32_t* stats, int n, int group) {
     stats[f * ST_WORDS + ST_WARP_DIV255_R] = fr;
 }
 
-static size_t gw_lds_bytes(int w) {
-    return 5 * (size_t)w * 4 + 24 * 4 + align16((size_t)w) + 32 * 4 + sizeof(csm::PowfTables) + 64;
+static size_t gw_lds_bytes(int w, int gen = 0) {
+    return 5 * (size_t)w * 4 + (gen ? 48 : 24) * 4 + align16((size_t)w) + 32 * 4 + sizeof(csm::PowfTables) + 64;
 }
 static size_t mesh_lds_bytes(int w) { return 8 * (size_t)w + 5 * (size_t)w * 4 + align16((size_t)w) + 32 * 4 + sizeof(csm::PowfTables) + 64; }
 static size_t mesh_keep_lds_bytes(int w) { return 3 * (size_t)w * 4 + align16((size_t)w) + sizeof(csm::PowfTables) + 64; }
@@ -764,6 +785,17 @@ int gpuwarp_max_width() {
     }
     return lo;
 }
+// Rounds of the scatter loop (:365) that can change a column.  A valid proposal of pair (i, i+1) in round k needs
+// 0 <= frac < 1, i.e. the column fs + k inside [dl, dr) (or (dr, dl] for a reversed pair) with fs = floor(min(dl, dr)) > min - 1;
+// connected pairs have |dr - dl| < 1 + gradient_threshold, so k < gradient_threshold + 2: rounds beyond that only write back
+// what they gathered.  -1: more than the 16 rounds the general kernel provides for (gradient_threshold > 13).
+static int gw_rounds(double gradient_threshold, int max_stretch) {
+    if (max_stretch <= 0) return 0;
+    if (!(gradient_threshold > 0.0)) return 0;   // nothing is connected (also NaN)
+    const double kv = floor((double)(float)gradient_threshold + 2.0) + 1.0;
+    const int rounds = kv < (double)max_stretch ? (int)kv : max_stretch;
+    return rounds > 16 ? -1 : rounds;
+}
 static int pow_mode_of(double e) { return e == 1.0 ? 0 : e == 0.5 ? 1 : e == 2.0 ? 2 : e == 3.0 ? 3 : e == 0.0 ? 5 : 4; }
 
 static int gw_launch(GwArgs& A, hipStream_t stream) {
@@ -783,7 +815,10 @@ static int gw_launch(GwArgs& A, hipStream_t stream) {
         else hipLaunchKernelGGL(k_meshwarp<6>, dim3(A.h, A.n), dim3(threads), lm, stream, A);
         return CS_OK;
     }
-    size_t lds = gw_lds_bytes(A.w);
+    // forward_warp_gpu's keyword parameters away from their defaults: the general instantiation
+    const bool gen = !(A.rounds == 4 && A.grad_thr == 1.5f);
+    if (gen && (A.rounds < 0 || A.rounds > 16)) return CS_ELIMIT;
+    size_t lds = gw_lds_bytes(A.w, gen);
     if (A.pow_mode != 4) lds -= sizeof(csm::PowfTables) + 64;   // (the tables are the LAST item of the layout and only the general exponent reads them)
     // workgroup size: about 4 columns per thread (measured at 1080p: 512 threads 2.30 ms per 32 frames, 1024: 2.71, 256: 2.94)
     int threads = A.w <= 1024 ? 256 : (A.w <= 2048 ? 512 : 1024);
@@ -794,13 +829,20 @@ static int gw_launch(GwArgs& A, hipStream_t stream) {
     // 1080p: a row takes 40.5 KB without the tables -- FOUR 512-thread workgroups per CU instead of three if the kernel also
     // fits 64 registers (the 8-waves-per-SIMD instantiation; development switch 24: the 6-wave one)
     const bool four = threads == 512 && 4 * ((lds + 511) & ~(size_t)511) <= CS_LDS_BYTES && forced != 24;
-    const bool wide = threads > 512 || four, pow2 = A.pow_mode == 2;
-    const void* fn = wide ? (pow2 ? (const void*)k_gpuwarp<8, 2> : (const void*)k_gpuwarp<8, -1>)
-                          : (pow2 ? (const void*)k_gpuwarp<6, 2> : (const void*)k_gpuwarp<6, -1>);
+    const bool wide = threads > 512 || four, pow2 = A.pow_mode == 2 && !gen;
+    const void* fn = gen ? (wide ? (const void*)k_gpuwarp<8, -1, true> : (const void*)k_gpuwarp<6, -1, true>)
+                         : wide ? (pow2 ? (const void*)k_gpuwarp<8, 2> : (const void*)k_gpuwarp<8, -1>)
+                                : (pow2 ? (const void*)k_gpuwarp<6, 2> : (const void*)k_gpuwarp<6, -1>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return CS_EHIP;
+#ifdef GW_XCD_ROWS
+    const dim3 grid(8 * ((A.h + 7) / 8), A.n), block(threads);
+#else
     const dim3 grid(A.h, A.n), block(threads);
-    if (wide && pow2) hipLaunchKernelGGL((k_gpuwarp<8, 2>), grid, block, lds, stream, A);
+#endif
+    if (gen && wide) hipLaunchKernelGGL((k_gpuwarp<8, -1, true>), grid, block, lds, stream, A);
+    else if (gen) hipLaunchKernelGGL((k_gpuwarp<6, -1, true>), grid, block, lds, stream, A);
+    else if (wide && pow2) hipLaunchKernelGGL((k_gpuwarp<8, 2>), grid, block, lds, stream, A);
     else if (wide) hipLaunchKernelGGL((k_gpuwarp<8, -1>), grid, block, lds, stream, A);
     else if (pow2) hipLaunchKernelGGL((k_gpuwarp<6, 2>), grid, block, lds, stream, A);
     else hipLaunchKernelGGL((k_gpuwarp<6, -1>), grid, block, lds, stream, A);
@@ -809,7 +851,7 @@ static int gw_launch(GwArgs& A, hipStream_t stream) {
 
 int launch_gpuwarp_plain(const float* image, const float* depth, int n, int h, int w, double div_px, double sep_px,
                          double exponent, double convergence, float* warped, uint8_t* gap_mask, uint32_t* stats,
-                         void* extra, hipStream_t stream, int mesh, double grad_thr) {
+                         void* extra, hipStream_t stream, int mesh, double grad_thr, int max_stretch) {
     hipLaunchKernelGGL(k_gpuwarp_flags, dim3((n + 63) / 64), dim3(64), 0, stream, stats, n, n);
     GwArgs A;
     memset(&A, 0, sizeof(A));
@@ -831,6 +873,8 @@ int launch_gpuwarp_plain(const float* image, const float* depth, int n, int h, i
     A.mask_u8 = gap_mask;
     A.dbg = dev_switch(CS_DEBUG_DBG);
     A.mesh = mesh; A.grad_thr = (float)grad_thr; A.keep = (uint8_t*)extra + 256; A.group = n;
+    A.rounds = gw_rounds(grad_thr, max_stretch);
+    if (!mesh && A.rounds < 0) return CS_ELIMIT;
     return gw_launch(A, stream);
 }
 
@@ -875,7 +919,7 @@ int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL,
     A.depth_l = depth_l; A.depth_r = depth_r;
     A.noclamp = p->flags & 1;
     A.dbg = dev_switch(CS_DEBUG_DBG);
-    A.mesh = (p->flags & 4) ? 1 : 0; A.grad_thr = 1.5f; A.keep = (uint8_t*)extra + 256; A.group = group;
+    A.mesh = (p->flags & 4) ? 1 : 0; A.grad_thr = 1.5f; A.rounds = 4; A.keep = (uint8_t*)extra + 256; A.group = group;   // (create_stereoimages_gpu calls the warp with its defaults, :1068-1083)
     if (tilemap && (A.mesh || w > gpuwarp_lazy_max_width())) return CS_EINVAL;   // (the caller asked gpuwarp_lazy_max_width)
     A.tilemap = tilemap; A.gray = gray; A.tm_words = tm_words;
     return gw_launch(A, stream);

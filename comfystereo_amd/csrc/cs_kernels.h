@@ -96,7 +96,7 @@ hipError_t launch_fwdtile(int fill, const RowArgs& A, int S, uint8_t* rowflag, h
 int fwdtile_max_halo();
 
 // cs_polypoint.hip: second generation of the tiled path (polylines_soft): one lane per polyline point
-hipError_t launch_polypoint(const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream);
+hipError_t launch_polypoint(const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream, int sharp = 0);
 int polypoint_max_halo();
 // anaglyph modes behind the tile kernel: the eyes as uint8 codes side by side -> the composite (rows flagged in rowflag excepted)
 hipError_t launch_anaglyph_compose(const uint8_t* sbs, const uint8_t* rowflag, int n, int h, int w, int anaglyph, float* stereo,
@@ -133,6 +133,10 @@ bool hybrid_fused_ok(int n, int w, int halo, int anaglyph, int single, int d64, 
 int hybrid_max_width();
 int launch_hybrid(const RowArgs& A, void* workspace, hipStream_t stream, int plus = 0, int halo = -1);  // plus: hybrid_edge_plus; halo >= 0: bound of |offset| (tile splat)
 
+// cs_scipyblur.hip: directional_motion_blur (the scipy depth blur of the numpy / PIL input path, reference :1346-1419)
+size_t scipyblur_workspace_bytes(int n, int h, int w);
+int launch_scipyblur(const float* depth, int n, int h, int w, double strength, double edge_threshold, double mask_width,
+                     double falloff, int vert, float* out_l, float* out_r, void* workspace, hipStream_t stream);
 // cs_gpuwarp.hip
 size_t gpuwarp_workspace_bytes(int n, int h, int w, int group, int mesh);   // group: frames per reference sub-batch
 int gpuwarp_max_width();
@@ -140,7 +144,7 @@ int meshwarp_max_width();
 // mesh != 0: forward_warp_mesh (mesh-quality rasteriser) instead of forward_warp_gpu
 int launch_gpuwarp_plain(const float* image, const float* depth, int n, int h, int w, double div_px, double sep_px,
                          double exponent, double convergence, float* warped, uint8_t* gap_mask, uint32_t* stats,
-                         void* workspace, hipStream_t stream, int mesh = 0, double grad_thr = 1.5);
+                         void* workspace, hipStream_t stream, int mesh = 0, double grad_thr = 1.5, int max_stretch = 8);
 int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL, const float* dR, int scale_from_stats,
                         uint32_t* stats, float* stereo, float* depth_l, float* depth_r, float* mask, int out_h,
                         int out_w, void* workspace, hipStream_t stream, const uint32_t* tilemap = nullptr,

@@ -112,7 +112,12 @@ enum { PO_F32 = 0, PO_U8 = 1, PO_ASD = 2, PO_U8NM = 3 };
 // list entries: kind << 28 | point id << 12 | pixel (tile-local)
 enum { PK_CHAIN = 0u, PK_BRIDGE = 1u };
 
-template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW>
+// SHARP (round 4): polylines_sharp -- every source pixel is TWO polyline points, x - 0.45 and x + 0.45 (reference :1929-1934), joined
+// by a "flat" segment (both ends refer to one source pixel: colour * length, :1981-1984); the segments between neighbouring
+// sources interpolate as in soft.  The lane still owns a SOURCE pixel: one 8-byte record {colour codes, x} per source, the two
+// points are x -+ 0.45 on read.  Point ids: 0 = left sentinel, 1 + 2 j = left point of source j, 2 + 2 j = its right point,
+// 2 ns + 1 = right sentinel.
+template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW, int SHARP>
 __global__ void __launch_bounds__(NT, MINW)
 k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
             int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode, int hot_npt,
@@ -150,7 +155,8 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // local point ids: 0 = left sentinel (x = -w), 1 + j = source column s0 + j, ns + 1 = right sentinel (x = 2w); the
     // sentinels only matter when the staged range touches the frame border.  Every lane stages SLOTS points j = tid + 256 k;
     // slots beyond the row end re-read the last column and get x = 2w + (j - ns): slot ns IS the right sentinel.
-    const int npts = ns + 2;
+    const int npts = SHARP ? 2 * ns + 2 : ns + 2;
+    const float HW = (float)0.45;   // PIXEL_HALF_WIDTH of polylines_sharp as the float32 the point array holds (:1915, :1933-1934)
     // point records allocated: what the tile can stage (T + 2 S + sentinels, host: polypoint_npt), not every slot -- the
     // slots past it are only ever the filler beyond the right sentinel and are not stored
     const int NPT = hot_npt;
@@ -166,6 +172,20 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     auto ch0 = [](uint32_t c) { return (float)(c & 0xffu); };
     auto ch1 = [](uint32_t c) { return (float)((c >> 8) & 0xffu); };
     auto ch2 = [](uint32_t c) { return (float)((c >> 16) & 0xffu); };
+    // point o of the polyline: x, the staged source column its colour comes from, |coord_d| (the slow paths; the fast path
+    // reads the records of its three sources directly)
+    auto pcol = [&](int o) { return min(max(SHARP ? (o - 1) >> 1 : o - 1, 0), ns - 1); };
+    auto px = [&](int o) -> float {
+        if (!SHARP) return P[o].x;
+        const float xc = P[1 + pcol(o)].x;
+        const float v = ((o - 1) & 1) ? xc + HW : xc - HW;
+        return o <= 0 ? (float)(-1.0 * w) : (o >= npts - 1 ? (float)(2.0 * w) : v);
+    };
+    auto prgb = [&](int o) -> uint32_t { return SHARP ? P[1 + pcol(o)].rgb : P[o].rgb; };
+    auto pzv = [&](int o) -> float {
+        if (!SHARP) return pz[o];
+        return (o <= 0 || o >= npts - 1) ? 0.0f : pz[1 + ((o - 1) >> 1)];
+    };
     uint32_t* plist = (uint32_t*)(pz + NPT);                                      // [max(T, 128)] pixels evaluated in pass 2
     // The powf tables: exponents 1 and 2 only run the clone for the 0.4 % risky squares and read the tables where they are,
     // in constant memory (512 bytes, L1-resident: no copy, nothing to wait for before barrier 0: +2 %); any other exponent
@@ -404,19 +424,22 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             const float cdj = (sg[k] * pw[k]) * E.div32;                                   // coord_d   (:1926)
             float x = ((jf0 + (float)(k * NT)) + cdj) + E.sep32;                   // coord_x   (:1927)
             // slots beyond the staged range: x = 2w + (j - ns), strictly increasing, slot ns = the right sentinel (:1935)
-            x = j < ns ? x : tidf + (float)(2 * w - ns + k * NT);
+            // (sharp: centres 2w + 1 + 2 (j - ns): their points lie beyond the sentinel, increasing; the sentinel itself is px())
+            x = j < ns ? x : (SHARP ? 2.0f * tidf + (float)(2 * w + 1 - 2 * ns + 2 * k * NT) : tidf + (float)(2 * w - ns + k * NT));
             if (SLOTS * NT + 4 == NPT || 1 + j < NPT) {   // (compile-time true for geometries whose every slot is allocated)
                 Pw[k * NT] = PQ{rgbk[k], x};
                 pzw[k * NT] = fabsf(cdj);
             }
             // reversed segment (j -> j+1)?  The right neighbour sits in the next lane (lane 63: +inf; the pairs across wave
             // chunks and the left sentinel's pair are checked after the barrier).
-            const float xn = wave_next(x);
-            const unsigned long long mrev = __ballot(!(x < xn));
-            if (mrev) mark_reversed(mrev, x, xn);
+            // (sharp: the segment between the sources runs from this source's right point to the next one's left point; the
+            // segment inside a source, 0.9 long, is never reversed)
+            const float xfrom = SHARP ? x + HW : x, xn = SHARP ? wave_next(x) - HW : wave_next(x);
+            const unsigned long long mrev = __ballot(!(xfrom < xn));
+            if (mrev) mark_reversed(mrev, xfrom, xn);
             // the range of points that can lie in the tile: first j with x >= o0, last j with x < o0 + wt (wave-uniform
             // candidates from ballots; one pair of atomics per wave below)
-            const unsigned long long m1 = __ballot(x >= o0f), m2 = __ballot(x < o1f);
+            const unsigned long long m1 = __ballot(xfrom >= o0f), m2 = __ballot((SHARP ? x - HW : x) < o1f);
             const int base = k * NT + wave * 64;
             wjlo = min(wjlo, m1 ? base + __ffsll((long long)m1) - 1 : 0x7fffffff);
             wjhi = max(wjhi, m2 ? base + 63 - __clzll((long long)m2) : -1);
@@ -486,7 +509,8 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             const int j = lane * NT + wave * 64 + 63;
             if (j <= ns - 2) o = 1 + j;   // the pair (j, j + 1) of real points
         } else if (lane == SLOTS && wave == 0 && left_edge) o = 0;
-        const float xa = o >= 0 ? P[o].x : 0.0f, xb = o >= 0 ? P[o + 1].x : 1.0f;
+        // (records o and o + 1; sharp: right point of the one, left point of the other -- record 0 holds the sentinel's x itself)
+        const float xa = o >= 0 ? P[o].x + ((SHARP && o > 0) ? HW : 0.0f) : 0.0f, xb = o >= 0 ? P[o + 1].x - (SHARP ? HW : 0.0f) : 1.0f;
         const unsigned long long mrev = __ballot(o >= 0 && !(xa < xb));
         if (mrev) mark_reversed(mrev, xa, xb);
         __syncthreads();
@@ -496,16 +520,8 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     const int dlo = flags[PF_DLO], dhi = flags[PF_DHI];
     if (flags[PF_NDIRTY] > PP_DCAP) PP_HAZARD(1);
     // points that can lie in the tile, plus the one before them (its segment may bridge into the tile); sentinels excluded
-#ifdef PP_PEEL
-    // the point before the first one of the tile only matters through its segment (it may bridge into the tile): that segment is
-    // worked off once, by wave 0, below -- as a lane of the dense pass it made 769 points of the 768 a tile of a flat region
-    // holds, i.e. a fourth pass for one lane with the other three waves waiting at barrier 2
-    const int jfirst = flags[PF_JLO];
-    const int jlo = max(jfirst, 0), jhi = min(flags[PF_JHI], ns - 1);
-#else
     const int jlo = max(flags[PF_JLO] - 1, 0), jhi = min(flags[PF_JHI], ns - 1);
-#endif
-    if (tid == 0) { pz[0] = 0.0f; pz[npts - 1] = 0.0f; }   // sentinels (:1921, :1935); read after barrier 2
+    if (!SHARP && tid == 0) { pz[0] = 0.0f; pz[npts - 1] = 0.0f; }   // sentinels (:1921, :1935); read after barrier 2 (sharp: pzv())
     if (PP_DEV_IS(32)) return;
 
     auto list_push = [&](uint32_t kind, int o, int q) {
@@ -518,42 +534,90 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     const float tlo = o0f - 0.5f, thi = o1f - 0.5f;
     const bool edge_tile = left_edge || right_edge;
 
-#ifdef PP_PEEL
-    if (wave == 0 && jfirst >= 1 && jfirst <= jhi + 1 && (jfirst < ns || right_edge) && !PP_DEV_IS(33)) {   // segment (jfirst - 1 -> jfirst): x[jfirst - 1] < o0 <= x[jfirst]
-        const int o = jfirst;                                                // (point id of source jfirst - 1)
-        const float xa = P[o].x, xb = P[o + 1].x;
-        const float fb = floorf(xb);
-        if (xa < xb) {
-            // pixels strictly between the end pixels, inside the tile: 0 .. floor(xb) - 1 (floor(xa) < o0)
-            const int pb = fb > o1f - 1.0f ? wt - 1 : (int)fb - 1 - o0;
-            for (int p = lane; p <= pb; p += 64)
-                if (!(fold_tile && (dflag[p] & PP_DIRTY))) list_push(PK_BRIDGE, o, p);
-            if (fold_tile) {
-                const int p0 = max(0, dlo), p1 = min(fb > o1f - 1.0f ? wt - 1 : (int)fb - o0, dhi);
-                for (int p = p0 + lane; p <= p1; p += 64) {
-                    const unsigned fl = dflag[p];
-                    if (fl & PP_DIRTY) {
-                        const int s = fl & 0x7f;
-                        const unsigned idx = (atomic_add_u16(dcnt, s, 0x100u) >> 8) & 0xffu;
-                        if (idx < PT_KS) sgs[s * PT_KS + idx] = (uint16_t)o;
-                        else PP_HAZARD(16);
-                    }
-                }
-            }
-        }
-    }
-#endif
     // =====================================================================================================
     // phase C: every point that can lie in the tile looks at its pixel (lanes densely packed over [jlo, jhi])
     // =====================================================================================================
+    // ---- pixels strictly between the end pixels of the forward segment (os -> os + 1), x0 -> x1 with floors fl0 / fl1:
+    // disocclusion bridges, one piece each, appended to the list (a run of up to 3 pixels by its lane, longer ones by the
+    // whole wave).  Called by whole waves.
+    auto bridges = [&](bool has_seg, int os, float fl0, float fl1, float den) {
+        const float nbr = fmin3(den, (fl1 - fl0) - 1.5f, fminf(fl1 - o0f - 0.5f, (o1f - 1.5f) - fl0));
+        const bool has_bridge = nbr > 0.0f && has_seg && !PP_DEV_IS(33);
+        if (__any(has_bridge)) {
+            int pa = 1, pb = 0;
+            if (has_bridge) {
+                pa = fl0 < o0f ? 0 : (int)fl0 + 1 - o0;
+                pb = fl1 > o1f - 1.0f ? wt - 1 : (int)fl1 - 1 - o0;
+            }
+            const bool is_long = pb - pa + 1 > 3;
+            if (pb >= pa && !is_long) {
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const int p = pa + t;
+                    if (p <= pb && !(fold_tile && (dflag[p] & PP_DIRTY))) list_push(PK_BRIDGE, os, p);
+                }
+            }
+            unsigned long long m = __ballot(is_long);
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int lpa = __builtin_amdgcn_readlane(pa, src), lpb = __builtin_amdgcn_readlane(pb, src),
+                          lo = __builtin_amdgcn_readlane(os, src);
+                for (int p = lpa + lane; p <= lpb; p += 64)
+                    if (!(fold_tile && (dflag[p] & PP_DIRTY))) list_push(PK_BRIDGE, lo, p);
+            }
+        }
+    };
+    // ---- fold tiles: the point op (pixel floor fp, `in_tile`) and the forward segment (os -> os + 1) go into the lists of the
+    // pixels under reversed segments they lie in / pass over.  Called by whole waves.
+    auto fold_register = [&](bool pt_in_tile, int qp, int op, bool has_seg, int os, float fl0, float fl1, float den) {
+        if (pt_in_tile && (dflag[qp] & PP_DIRTY)) {
+            const int sl = dflag[qp] & 0x7f;
+            const unsigned idx = atomic_add_u16(dcnt, sl, 1u) & 0xffu;
+            if (idx < PT_KP) pts[sl * PT_KP + idx] = (uint16_t)op;
+            else PP_HAZARD(8);
+        }
+        int p0 = 1, p1 = 0;
+        if (den > 0.0f && has_seg && !(fl1 < o0f || fl0 > o1f - 1.0f)) {
+            p0 = fl0 < o0f ? 0 : (int)fl0 - o0;
+            p1 = fl1 > o1f - 1.0f ? wt - 1 : (int)fl1 - o0;
+            p0 = max(p0, dlo); p1 = min(p1, dhi);   // only the dirty stretch of the tile matters
+        }
+        auto reg_seg = [&](int p, int oo) {
+            const unsigned fl = dflag[p];
+            if (fl & PP_DIRTY) {
+                const int sl = fl & 0x7f;
+                const unsigned idx = (atomic_add_u16(dcnt, sl, 0x100u) >> 8) & 0xffu;
+                if (idx < PT_KS) sgs[sl * PT_KS + idx] = (uint16_t)oo;
+                else PP_HAZARD(16);
+            }
+        };
+        const bool seg_long = p1 - p0 > 3;
+        if (__any(p1 >= p0)) {
+            if (!seg_long) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) if (p0 + t <= p1) reg_seg(p0 + t, os);
+            }
+            unsigned long long m = __ballot(seg_long);
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int lp0 = __builtin_amdgcn_readlane(p0, src), lp1 = __builtin_amdgcn_readlane(p1, src),
+                          lo = __builtin_amdgcn_readlane(os, src);
+                for (int p = lp0 + lane; p <= lp1; p += 64) reg_seg(p, lo);
+            }
+        }
+    };
     for (int jb = jlo; jb <= jhi; jb += NT) {
         // (every lane runs the body -- the cooperative loops below need whole waves -- lanes beyond jhi re-read point jhi
         // and are kept from acting by `act`)
         if (jb + wave * 64 > jhi) continue;   // (a wave without a point left has nothing to do or to cooperate on)
         const bool act = jb + tid <= jhi;
         const int j = min(jb + tid, jhi);
-        const int o = 1 + j;
+        const int o = 1 + j;   // record of source j (soft: also the id of its point)
         const PQ pm = P[o - 1], pc = P[o], pp = P[o + 1];
+        const bool has_seg = act && (j + 1 < ns || right_edge);   // the segment towards source j + 1 (or the right sentinel) exists and is this lane's
+        if (!SHARP) {
         const float x = pc.x, xm = pm.x, xp = pp.x;
         const float f0 = floorf(x), f1 = floorf(xp), f0p1 = f0 + 1.0f;
         // ---- the fast path: one point in the pixel, two pieces [col, x] and [x, col+1] on the segments (o-1 -> o),
@@ -593,80 +657,88 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         }
         // the first point of a pixel that is not done yet: several points / special typing -> pass 2 (chain path)
         if (g_first > 0.0f && !fast && !dirty && act) list_push(PK_CHAIN, o, q);
-        // ---- pixels strictly between the end pixels of the forward segment (o -> o+1): disocclusion bridges, one
-        // piece each, appended to the list (a run of up to 3 pixels by its lane, longer ones by the whole wave)
-        const float nbr = fmin3(den1, (f1 - f0) - 1.5f, fminf(f1 - o0f - 0.5f, (o1f - 1.5f) - f0));
-        const bool has_seg = act && (j + 1 < ns || right_edge);   // the segment (o -> o+1) exists and is this lane's
-        const bool has_bridge = nbr > 0.0f && has_seg && !PP_DEV_IS(33);
-        if (__any(has_bridge)) {
-            int pa = 1, pb = 0;
-            if (has_bridge) {
-                pa = f0 < o0f ? 0 : (int)f0 + 1 - o0;
-                pb = f1 > o1f - 1.0f ? wt - 1 : (int)f1 - 1 - o0;
-            }
-            const bool is_long = pb - pa + 1 > 3;
-            if (pb >= pa && !is_long) {
-#pragma unroll
-                for (int t = 0; t < 3; t++) {
-                    const int p = pa + t;
-                    if (p <= pb && !(fold_tile && (dflag[p] & PP_DIRTY))) list_push(PK_BRIDGE, o, p);
-                }
-            }
-            unsigned long long m = __ballot(is_long);
-            while (m) {
-                const int src = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const int lpa = __builtin_amdgcn_readlane(pa, src), lpb = __builtin_amdgcn_readlane(pb, src),
-                          lo = __builtin_amdgcn_readlane(o, src);
-                for (int p = lpa + lane; p <= lpb; p += 64)
-                    if (!(fold_tile && (dflag[p] & PP_DIRTY))) list_push(PK_BRIDGE, lo, p);
-            }
-        }
-        // ---- fold tiles: points and forward segments over the pixels under reversed segments go into those pixels' lists
+        bridges(has_seg, o, f0, f1, den1);
         if (fold_tile && !PP_DEV_IS(33)) {
             const bool in_tile = fminf(f0 - tlo, thi - f0) > 0.0f && act;
-            if (in_tile && (dflag[q] & PP_DIRTY)) {
-                const int s = dflag[q] & 0x7f;
-                const unsigned idx = atomic_add_u16(dcnt, s, 1u) & 0xffu;
-                if (idx < PT_KP) pts[s * PT_KP + idx] = (uint16_t)o;
-                else PP_HAZARD(8);
-            }
-            int p0 = 1, p1 = 0;
-            if (den1 > 0.0f && has_seg && !(f1 < o0f || f0 > o1f - 1.0f)) {
-                p0 = f0 < o0f ? 0 : (int)f0 - o0;
-                p1 = f1 > o1f - 1.0f ? wt - 1 : (int)f1 - o0;
-                p0 = max(p0, dlo); p1 = min(p1, dhi);   // only the dirty stretch of the tile matters
-            }
-            auto reg_seg = [&](int p, int oo) {
-                const unsigned fl = dflag[p];
-                if (fl & PP_DIRTY) {
-                    const int s = fl & 0x7f;
-                    const unsigned idx = (atomic_add_u16(dcnt, s, 0x100u) >> 8) & 0xffu;
-                    if (idx < PT_KS) sgs[s * PT_KS + idx] = (uint16_t)oo;
-                    else PP_HAZARD(16);
-                }
-            };
-            const bool seg_long = p1 - p0 > 3;
-            if (__any(p1 >= p0)) {
-                if (!seg_long) {
-#pragma unroll
-                    for (int t = 0; t < 4; t++) if (p0 + t <= p1) reg_seg(p0 + t, o);
-                }
-                unsigned long long m = __ballot(seg_long);
-                while (m) {
-                    const int src = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const int lp0 = __builtin_amdgcn_readlane(p0, src), lp1 = __builtin_amdgcn_readlane(p1, src),
-                              lo = __builtin_amdgcn_readlane(o, src);
-                    for (int p = lp0 + lane; p <= lp1; p += 64) reg_seg(p, lo);
-                }
-            }
+            fold_register(in_tile, q, o, has_seg, o, f0, f1, den1);
+        }
+        } else {
+        // ================= polylines_sharp: source j = points q1 = x - 0.45 (id 1 + 2 j) and q2 = x + 0.45 (id 2 + 2 j); its
+        // neighbours' nearest points q0 = x[j-1] + 0.45, q3 = x[j+1] - 0.45 and q4 = x[j+1] + 0.45.  Segments: (q0 -> q1) and
+        // (q2 -> q3) interpolate between two sources, (q1 -> q2) and (q3 -> q4) are flat.  The lane owns the pixel whose FIRST
+        // point is one of its two: `A` -- q1 is (q0 left of floor(q1)); else q2 (q1 left of floor(q2)).  Fast path: the pixel's
+        // points are q1? q2? q3? in a row and the next one lies beyond the pixel -- up to four pieces
+        //   [col, q1] lerp(j-1, j)  (A only) | [.., min(q2, col+1)] flat(j) | [q2, min(q3, col+1)] lerp(j, j+1) | [q3, col+1] flat(j+1)
+        // A flat piece adds colour * length, which IS the lerp formula with (1 - ip, ip) = (1, 0) (c * 1 + c' * 0 == c exactly);
+        // an absent piece gets length 0 (adds +0 exactly).  Same margins as soft: pieces of positive length whose centres lie
+        // right of their segment's start (to the left of its end they lie by monotone rounding).
+        const int oa = 1 + 2 * j, ob = oa + 1;
+        float q0 = pm.x + HW, q3 = pp.x - HW, q4 = pp.x + HW;
+        const float q1 = pc.x - HW, q2 = pc.x + HW;
+        if (edge_tile) {   // the frame's sentinels instead of the filler records: exact -w / 2w, no point beyond
+            if (left_edge && j == 0) q0 = (float)(-1.0 * w);
+            if (right_edge && j == ns - 1) { q3 = (float)(2.0 * w); q4 = INFINITY; }
+        }
+        const float fa = floorf(q1), fb = floorf(q2), f3 = floorf(q3);
+        const float ina = fminf(fa - tlo, thi - fa), inb = fminf(fb - tlo, thi - fb);   // > 0: that pixel belongs to this tile
+        const bool A = fminf(fa - q0, ina) > 0.0f;                                      // q1 is the first point of a pixel of the tile
+        const bool B = fminf(fb - q1, inb) > 0.0f;                                      // q2 is
+        const float colf = A ? fa : fb, colp1 = colf + 1.0f;
+        const bool e2 = q2 < colp1, e3 = q3 < colp1;                                     // q2 / q3 inside the pixel (A: q2 may be; B: q2 is)
+        // piece bounds (from = col or point + eps, to = point - eps or col + 1: float32, col >= 2 checked below)
+        const float to0 = q1 - eps32, sg0 = A ? to0 - colf : 0.0f, c0 = colf + 0.5f * sg0;
+        const float fr1 = A ? q1 + eps32 : colf, to1 = e2 ? q2 - eps32 : colp1, sg1 = to1 - fr1, c1 = fr1 + 0.5f * sg1;
+        const float fr2 = q2 + eps32, to2 = e3 ? q3 - eps32 : colp1, sg2r = to2 - fr2, c2 = fr2 + 0.5f * sg2r, sg2 = e2 ? sg2r : 0.0f;
+        const float fr3 = q3 + eps32, sg3r = colp1 - fr3, c3 = fr3 + 0.5f * sg3r, sg3 = e3 ? sg3r : 0.0f;
+        const float den0 = q1 - q0, den2 = q3 - q2;
+        // margins: owner of a pixel with col >= 2; the interpolating segments forward; the point after the pixel's last one
+        // beyond the pixel; every present piece of positive length with its centre right of its segment's start
+        float g = fmin3(colf - 1.5f, den2, (floorf(q4) - colf) - 0.5f);
+        g = fminf(g, A ? fmin3(den0, sg0, c1 - q1) : 1.0f);
+        g = fminf(g, sg1);
+        g = fminf(g, e2 ? fminf(sg2r, c2 - q2) : 1.0f);
+        g = fminf(g, e3 ? fminf(sg3r, c3 - q3) : 1.0f);
+        if (edge_tile) g = fminf(g, fminf((float)j - 0.5f, (float)(ns - 1 - j) - 0.5f));   // sentinel neighbours: other typing
+        const bool own = A || B;
+        const int q = (int)colf - o0;
+        bool dirty = false;
+        if (fold_tile) dirty = own && (dflag[own ? q : 0] & PP_DIRTY) != 0;
+        const bool fast = g > 0.0f && own && !dirty && act;
+        {
+            // (without piece 0 its quotient must still be finite -- the segment (q0 -> q1) may be reversed or empty then, and
+            // NaN * 0 would poison the sums: 0 / 1)
+            const float ip0 = div_core(A ? c0 - q0 : 0.0f, A ? den0 : 1.0f), ip2 = div_core(c2 - q2, den2);
+            const float om0 = 1.0f - ip0, om2 = 1.0f - ip2;
+            const float mr = ch0(pm.rgb), mg = ch1(pm.rgb), mb = ch2(pm.rgb);
+            const float cr = ch0(pc.rgb), cg = ch1(pc.rgb), cb = ch2(pc.rgb);
+            const float nr = ch0(pp.rgb), ng = ch1(pp.rgb), nb = ch2(pp.rgb);
+            float k0 = 0.5f + (mr * om0 + cr * ip0) * sg0;
+            float k1 = 0.5f + (mg * om0 + cg * ip0) * sg0;
+            float k2 = 0.5f + (mb * om0 + cb * ip0) * sg0;
+            k0 = k0 + cr * sg1; k1 = k1 + cg * sg1; k2 = k2 + cb * sg1;
+            k0 = k0 + (cr * om2 + nr * ip2) * sg2;
+            k1 = k1 + (cg * om2 + ng * ip2) * sg2;
+            k2 = k2 + (cb * om2 + nb * ip2) * sg2;
+            k0 = k0 + nr * sg3; k1 = k1 + ng * sg3; k2 = k2 + nb * sg3;
+            if (fast) emit_k(q, k0, k1, k2);
+        }
+        // pixels this source's points are the first of, not done: pass 2 (chain path from that point)
+        if (own && !fast && !dirty && act) list_push(PK_CHAIN, A ? oa : ob, q);
+        if (A && B && act) {   // both points first in their (different) pixels: the second one's takes the chain path
+            const int qb = (int)fb - o0;
+            if (!(fold_tile && (dflag[qb] & PP_DIRTY))) list_push(PK_CHAIN, ob, qb);
+        }
+        bridges(has_seg, ob, fb, f3, den2);   // (the flat segment, 0.9 long, has no pixel strictly inside)
+        if (fold_tile && !PP_DEV_IS(33)) {
+            fold_register(ina > 0.0f && act, (int)fa - o0, oa, act, oa, fa, fb, 1.0f);
+            fold_register(inb > 0.0f && act, (int)fb - o0, ob, has_seg, ob, fb, f3, den2);
+        }
         }
     }
     // ---- the left sentinel's segment (0 -> 1), frame border only: the pixels 0 .. floor(x1) - 1 under it take the chain path
     // (their piece is "flat"); in fold tiles it is a listed segment like the others
     if (left_edge && tid == 0) {
-        const float x1 = P[1].x, fs = floorf(x1);
+        const float x1 = px(1), fs = floorf(x1);
         if ((float)(-1.0 * w) < x1) {
             const int e1 = min((int)fs - 1 - o0, wt - 1);
             if (fs - 1.0f >= o0f)
@@ -704,7 +776,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         int npr = 0;
         if (act && !bridge) {
             npr = 1;
-            while (npr <= PT_KP && floorf(P[min(o1in + npr, npts - 1)].x) == colf) npr++;
+            while (npr <= PT_KP && floorf(px(min(o1in + npr, npts - 1))) == colf) npr++;
         }
         const int o1 = bridge ? o1in + 1 : o1in;   // np == 0: the segment's END point
         const int np = act ? min(npr, PT_KP) : 0;
@@ -721,9 +793,9 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         for (int k = 0; k < PT_KP + 2; k++) {
             if (k <= wnp + 1) {
                 const int o = chain && k <= np + 1 ? o1 - 1 + k : 0;
-                const PQ v = P[o];
-                cx[k] = v.x; c0[k] = ch0(v.rgb); c1[k] = ch1(v.rgb); c2[k] = ch2(v.rgb);
-                cj[k] = min(max(o - 1, 0), ns - 1);
+                const uint32_t vrgb = prgb(o);
+                cx[k] = px(o); c0[k] = ch0(vrgb); c1[k] = ch1(vrgb); c2[k] = ch2(vrgb);
+                cj[k] = pcol(o);
             } else { cx[k] = 0.0f; c0[k] = c1[k] = c2[k] = 0.0f; cj[k] = 0; }
         }
         // every chain segment is forward, the pixel's points lie inside it, the chain enters from the left of the pixel and
@@ -791,10 +863,12 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         // bridge pixels of real segments away from the first two columns: one whole-pixel piece, closed-form constants
         const bool lean = act && bridge && o >= 1 && o + 1 <= npts - 2 && o0 + q >= 2;
         if (__any(lean)) {
-            const PQ a = P[lean ? o : 1], b = P[lean ? o + 1 : 2];
+            // (sharp: a bridge is always the segment between two sources -- right point of the one, left point of the other)
+            const PQ a = P[lean ? (SHARP ? o >> 1 : o) : 1], b = P[lean ? (SHARP ? (o >> 1) + 1 : o + 1) : 2];
+            const float ax = SHARP ? a.x + HW : a.x, bx = SHARP ? b.x - HW : b.x;
             const float colf = (float)(o0 + q);
             const float center = colf + 0.5f;
-            const float ip = div_core(center - a.x, b.x - a.x), om = 1.0f - ip;
+            const float ip = div_core(center - ax, bx - ax), om = 1.0f - ip;
             const float k0 = 0.5f + (ch0(a.rgb) * om + ch0(b.rgb) * ip) * sig_whole;
             const float k1 = 0.5f + (ch1(a.rgb) * om + ch1(b.rgb) * ip) * sig_whole;
             const float k2 = 0.5f + (ch2(a.rgb) * om + ch2(b.rgb) * ip) * sig_whole;
@@ -837,7 +911,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         for (int k = 0; k < PT_KP; k++) {
             if (k < wnp) {
                 int o = k < np ? (int)pts[s * PT_KP + k] : 0x7fffffff;
-                float x = k < np ? P[o].x : INFINITY;
+                float x = k < np ? px(o) : INFINITY;
 #pragma unroll
                 for (int m2 = 0; m2 <= k; m2++) {
                     const bool lt = x < xs[m2] || (x == xs[m2] && o < os[m2]);
@@ -858,7 +932,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             if (e < wns) {
                 const bool have = e < nsg;
                 const int oe = have ? (int)sgs[s * PT_KS + e] : 0;
-                const float x0 = P[oe].x, x1 = P[oe + 1].x;
+                const float x0 = px(oe), x1 = px(oe + 1);
                 se0[e] = have ? x0 : INFINITY;
                 se1[e] = have ? x1 : -INFINITY;
             }
@@ -892,12 +966,12 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             // one step of the reference's scan (:1972-1980) for a segment that is active (`on`), polyline point oe -> oe + 1.
             // 0 < centre - x0 <= x1 - x0 <= 3 w: div_core's proven range.
             auto scan_step = [&](bool on, int oe) {
-                const float x0 = P[oe].x, x1 = P[oe + 1].x;
+                const float x0 = px(oe), x1 = px(oe + 1);
                 const float ip_e = div_core(center - x0, x1 - x0);
                 o_pick = on ? oe : o_pick;
                 ip_pick = on ? ip_e : ip_pick;
                 const bool qual = on && 0.0f < ip_e && ip_e < 1.0f;
-                const float cl = (1.0f - ip_e) * pz[oe] + ip_e * pz[oe + 1];
+                const float cl = (1.0f - ip_e) * pzv(oe) + ip_e * pzv(oe + 1);
                 nqual += qual ? 1 : 0;
                 const bool better = qual && bc < cl;
                 tie = better ? false : (tie || (qual && cl == bc));
@@ -927,9 +1001,9 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             const bool contrib = work && (use_best || o_pick >= 0);
             const int o = contrib ? (use_best ? o_best : o_pick) : 1;
             const float ip_k = use_best ? ip_best : ip_pick;   // (the chosen segment's parameter: the same division as :1986)
-            const PQ pq_l = P[o], pq_r = P[o + 1];
-            const F3 pl{ch0(pq_l.rgb), ch1(pq_l.rgb), ch2(pq_l.rgb)}, pr{ch0(pq_r.rgb), ch1(pq_r.rgb), ch2(pq_r.rgb)};
-            const int jl = min(max(o - 1, 0), ns - 1), jr = min(max(o, 0), ns - 1);
+            const uint32_t rgb_l = prgb(o), rgb_r = prgb(o + 1);
+            const F3 pl{ch0(rgb_l), ch1(rgb_l), ch2(rgb_l)}, pr{ch0(rgb_r), ch1(rgb_r), ch2(rgb_r)};
+            const int jl = pcol(o), jr = pcol(o + 1);
             const float om = 1.0f - ip_k;
             const float sgm = sig64 ? (float)C.sig_dd : sig_f;
             float n0 = color0 + (pl.x * om + pr.x * ip_k) * sgm;
@@ -1036,9 +1110,11 @@ static int polypoint_tile(int w, int S, int nslots, int nt) {
 
 int polypoint_max_halo() { return (3 * 384 - 4 - 64) / 2; }
 
-template <int NT, int SLOTS, int MINW>
+template <int NT, int SLOTS, int MINW, int SHARP>
 static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream) {
-    constexpr int KP = 4, KS = 5;
+    // points / forward segments a pixel under a reversed segment can hold in its lists (more: the row is redone); sharp has two
+    // points per source (the values the first-generation kernel settled on)
+    constexpr int KP = SHARP ? 5 : 4, KS = SHARP ? 7 : 5;
     const int tiles = (A.w + A.T - 1) / A.T;
     dim3 grid(tiles * 8, A.single >= 0 ? (A.h + 7) / 8 : eye_group_grid_y(A.h), A.n), block(NT);   // (see the kernel's prologue)
     size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS);
@@ -1057,10 +1133,10 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
     if (occ >= 3 && occ <= 6) { const size_t pad = (size_t)(163840 / (occ + 1) + 1024) & ~(size_t)255; if (pad > lds) lds = pad; }
 #define PP_LAUNCH(O)                                                                                                         \
     {                                                                                                                        \
-        hipError_t e = hipFuncSetAttribute((const void*)k_polypoint<NT, SLOTS, O, KP, KS, MINW>,                             \
+        hipError_t e = hipFuncSetAttribute((const void*)k_polypoint<NT, SLOTS, O, KP, KS, MINW, SHARP>,                      \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
         if (e != hipSuccess) return e;                                                                                       \
-        hipLaunchKernelGGL((k_polypoint<NT, SLOTS, O, KP, KS, MINW>), grid, block, lds, stream, A.image_f32, A.eye[0].depth, \
+        hipLaunchKernelGGL((k_polypoint<NT, SLOTS, O, KP, KS, MINW, SHARP>), grid, block, lds, stream, A.image_f32, A.eye[0].depth, \
                            A.eye[1].depth, A.w, A.h, A.S, A.T, A.single, off_dflag, off_dcnt, pow_mode, npt, A);                  \
     }
     if (out == PO_F32) PP_LAUNCH(PO_F32)
@@ -1073,12 +1149,13 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
 
 // Launch for the eyes of `R` (SBS / TB / single-eye / uint8 outputs; no anaglyph).  `rowflag` must be zeroed by the caller;
 // afterwards the general kernel is run over the flagged rows.
-hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream_t stream) {
+hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream_t stream, int sharp) {
     // workgroup geometry: threads x point slots per lane.  256 x 4 (7 workgroups per CU at the bench halo, 19.5 KB of LDS each) is
     // the default; development switch CS_DEBUG_PT_VARIANT: 3 = 256 x 3 (the default until the end of round 3), 4 = 256 x 4,
     // 5 = 384 x 3, 6 = 320 x 3
     const int forced = dev_switch(CS_DEBUG_PT_VARIANT);
     int geo = (forced >= 3 && forced <= 7) ? forced : 4;
+    if (sharp && geo != 5) geo = 4;
     auto nt_of = [](int g) { return g == 5 ? 384 : (g == 6 ? 320 : 256); };
     auto sl_of = [](int g) { return g == 4 ? 4 : (g == 7 ? 5 : 3); };
     if (polypoint_tile(R.w, S, nt_of(geo) * sl_of(geo), nt_of(geo)) == 0 && (geo == 3 || geo == 4)) geo = 5;
@@ -1102,13 +1179,17 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     if ((out == PO_ASD) != (R.image_u8 != nullptr)) return hipErrorInvalidValue;  // uint8 image in <=> uint8 image out
     if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31) || A.h > 4 * 65535 - 512 || A.n > 65535)
         return hipErrorInvalidValue;   // 32-bit pixel indices, grid limits
+    if (sharp) {   // (two geometries: the default and the wide-halo one)
+        if (geo == 5) return polypoint_launch<384, 3, 7, 1>(A, out, stream);
+        return polypoint_launch<256, 4, PP_MINW, 1>(A, out, stream);
+    }
     switch (geo) {
-    case 3: return polypoint_launch<256, 3, PP_MINW>(A, out, stream);
-    case 4: return polypoint_launch<256, 4, PP_MINW>(A, out, stream);
-    case 5: return polypoint_launch<384, 3, 7>(A, out, stream);
-    case 6: return polypoint_launch<320, 3, 6>(A, out, stream);
-    case 7: return polypoint_launch<256, 5, PP_MINW>(A, out, stream);
-    default: return polypoint_launch<256, 4, PP_MINW>(A, out, stream);
+    case 3: return polypoint_launch<256, 3, PP_MINW, 0>(A, out, stream);
+    case 4: return polypoint_launch<256, 4, PP_MINW, 0>(A, out, stream);
+    case 5: return polypoint_launch<384, 3, 7, 0>(A, out, stream);
+    case 6: return polypoint_launch<320, 3, 6, 0>(A, out, stream);
+    case 7: return polypoint_launch<256, 5, PP_MINW, 0>(A, out, stream);
+    default: return polypoint_launch<256, 4, PP_MINW, 0>(A, out, stream);
     }
 }
 

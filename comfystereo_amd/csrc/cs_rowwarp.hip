@@ -1227,18 +1227,19 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                     }
                 }
                 if (!room) *rp_ok = 0;   // replay here
+                if (!room && dbg == 14 && stats_rw) atomicAdd(&stats_rw[14], 1u);   // (diagnostics: rows that found the pool full)
             }
             __syncthreads();
             if (*rp_ok) {
                 const uint32_t at16 = (uint32_t)*rp_slot, base = (uint32_t)*rp_base;
-                for (int si = wave; si < nstr; si += nwaves) {
+                for (int si = 0; si < nstr; si++) {   // (usually 1-3 stretches: the whole workgroup copies each one's windows)
                     const uint32_t* q = sinfo + RP_DESC * si;
                     const int pw0 = (int)(q[4] & 0xffffu), pw1 = (int)(q[4] >> 16), cmin = (int)(q[5] & 0xffffu), cmax = (int)(q[5] >> 16);
                     uint8_t* d = X->dump + ((size_t)(at16 + q[0]) << 4);
                     uint16_t* dperm = (uint16_t*)d;
                     float* dcd = (float*)(d + align16(2 * (size_t)(pw1 - pw0 + 1)));
-                    for (int i = lane; i <= pw1 - pw0; i += 64) dperm[i] = P.perm[pw0 + i];
-                    for (int c = lane; c <= cmax - cmin; c += 64) dcd[c] = P.cd[cmin + c];
+                    for (int i = tid; i <= pw1 - pw0; i += nt) dperm[i] = P.perm[pw0 + i];
+                    for (int c = tid; c <= cmax - cmin; c += nt) dcd[c] = P.cd[cmin + c];
                 }
                 for (int i = tid; i < nstr * RP_DESC; i += nt) {
                     const int si = i / RP_DESC, k = i - si * RP_DESC;
@@ -2382,7 +2383,9 @@ __global__ void __launch_bounds__(64) k_poly_replay(RowArgs A, uint8_t* __restri
 // the dump pool: 4 KB per image row (the windows of a stretch average ~2 KB, an order-dependent eye row holds 1.3 stretches), never
 // more than one maximal window set per stretch slot; a row that finds the pool (or the descriptor list) full replays inline
 static size_t rp_pool_bytes(size_t rows) {
-    const size_t worst = rows * 4 * ((size_t)rp_win16(RP_PW, RP_CW) << 4), budget = rows * 4096 + (64u << 10);
+    // (development: CS_DEBUG_PT_VARIANT 31 quadruples the budget -- does a workload run out of pool?)
+    const size_t per_row = dev_switch(CS_DEBUG_PT_VARIANT) == 31 ? 16384 : 4096;
+    const size_t worst = rows * 4 * ((size_t)rp_win16(RP_PW, RP_CW) << 4), budget = rows * per_row + (64u << 10);
     return (worst < budget ? worst : budget) & ~(size_t)15;
 }
 size_t poly_replay_bytes(int n, int h, int w, int sharp) {

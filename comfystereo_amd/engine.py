@@ -163,7 +163,26 @@ def directional_blur(depth, blur_strength, edge_threshold, falloff_exponent=1.0,
     return out_l.reshape(shp), out_r.reshape(shp)
 
 
-def forward_warp(image, depth, divergence_px, separation_px, stereo_offset_exponent, convergence_point=0.5):
+def directional_blur_scipy(depth, blur_strength, edge_threshold, blur_mask_width=5, falloff_exponent=1.0, vert_smooth_px=0):
+    """reference stereoimage_generation.py:1346-1419 (`directional_motion_blur`, the scipy blur of the numpy / PIL input path)
+    for a [N,H,W] (or [H,W]) float32 device tensor, used as given (no 0..255 rescaling) -> (left, right)."""
+    L = _native.lib()
+    depth = _dev(depth).contiguous().float()
+    if blur_strength <= 0:   # (:1374)
+        return depth, depth
+    shp = depth.shape
+    d3 = depth.reshape((-1,) + tuple(shp[-2:]))
+    n, h, w = d3.shape
+    out_l, out_r = torch.empty_like(d3), torch.empty_like(d3)
+    nb = L.cs_blur_scipy_workspace_bytes(n, h, w)
+    ws = torch.empty((max(nb, 256),), dtype=torch.uint8, device=depth.device)
+    _native.check(L.cs_directional_blur_scipy(_ptr(d3), n, h, w, float(blur_strength), float(edge_threshold), float(blur_mask_width),
+                                              float(falloff_exponent), int(vert_smooth_px), _ptr(out_l), _ptr(out_r), _ptr(ws), nb, _stream()))
+    return out_l.reshape(shp), out_r.reshape(shp)
+
+
+def forward_warp(image, depth, divergence_px, separation_px, stereo_offset_exponent, convergence_point=0.5,
+                 gradient_threshold=1.5, max_stretch=8):
     """reference stereoimage_generation.py:277-450: image [B,3,H,W], depth [B,H,W] -> (warped, gap mask bool)."""
     L = _native.lib()
     image = _dev(image).contiguous().float()
@@ -174,9 +193,9 @@ def forward_warp(image, depth, divergence_px, separation_px, stereo_offset_expon
     mask = torch.empty((b, h, w), dtype=torch.uint8, device=image.device)
     nb = L.cs_warp_workspace_bytes(b, h, w)
     ws = torch.empty((max(nb, 256),), dtype=torch.uint8, device=image.device)
-    _native.check(L.cs_forward_warp(_ptr(image), _ptr(depth), b, h, w, float(divergence_px), float(separation_px),
-                                    float(stereo_offset_exponent), float(convergence_point), _ptr(warped), _ptr(mask),
-                                    _ptr(ws), nb, _stream()))
+    _native.check(L.cs_forward_warp2(_ptr(image), _ptr(depth), b, h, w, float(divergence_px), float(separation_px),
+                                     float(stereo_offset_exponent), float(convergence_point), float(gradient_threshold),
+                                     int(max_stretch), _ptr(warped), _ptr(mask), _ptr(ws), nb, _stream()))
     return warped, mask.bool()
 
 

@@ -185,10 +185,16 @@ class ShardedStereoJob:
     make_params(n_frames) -> engine params for a chunk of that many frames.  step(image_block, depth_block) returns the
     reassembled float32 stereoscope [N, out_h, out_w, 3] (the same tensor every step)."""
 
-    def __init__(self, make_params, n_frames, out_shape, device, group=None, chunk_options=(4, 2, 1), method="collective"):
+    def __init__(self, make_params, n_frames, out_shape, device, group=None, chunk_options=None, method="collective"):
         from . import engine
         self.engine = engine
         world = dist.get_world_size(group)
+        if chunk_options is None:
+            # Two ranks share ONE xGMI link: the half batch takes longer on the wire than its kernels save (DESIGN.md section 6:
+            # 10.4 ms against 7.0 ms at 64 4K frames), so there is nothing for chunks to hide behind -- one exchange of the whole
+            # block, without the per-chunk launches and waits.  From four ranks on the wire time per link falls below the
+            # compute time and the chunked, overlapped form pays.
+            chunk_options = (1,) if world == 2 else (4, 2, 1)
         self.n_chunks = next((k for k in chunk_options if ChunkedGather.usable(n_frames, world, k)), 0)
         if self.n_chunks == 0:
             raise ValueError(f"{n_frames} frames do not split evenly over {world} ranks")

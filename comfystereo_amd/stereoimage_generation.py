@@ -57,7 +57,8 @@ def create_stereoimages(original_image, depthmap, divergence, separation=0.0, mo
     if not (isinstance(depthmap, torch.Tensor) and isinstance(original_image, torch.Tensor)):
         return _create_stereoimages_numpy(original_image, depthmap, divergence, separation, modes, stereo_balance,
                                           stereo_offset_exponent, fill_technique, depth_blur_strength,
-                                          direction_aware_depth_blur, return_modified_depth, convergence_point)
+                                          direction_aware_depth_blur, return_modified_depth, convergence_point,
+                                          depth_blur_edge_threshold, depth_blur_falloff, depth_blur_vert_smooth)
     for m in modes:
         if m not in _MODES:
             raise Exception('Unknown mode')
@@ -92,18 +93,16 @@ def create_stereoimages(original_image, depthmap, divergence, separation=0.0, mo
 
 def _create_stereoimages_numpy(original_image, depthmap, divergence, separation, modes, stereo_balance,
                                stereo_offset_exponent, fill_technique, depth_blur_strength, direction_aware_depth_blur,
-                               return_modified_depth, convergence_point):
+                               return_modified_depth, convergence_point, depth_blur_edge_threshold=6.0, depth_blur_falloff=1.0,
+                               depth_blur_vert_smooth=0):
     """numpy / PIL inputs (reference :1486-1499, 1519-1574): the uint8 image is used as it is, the depth map as float32 without
     the x255 step of the tensor path, each eye is apply_stereo_divergence (HIP, cs_apply_stereo_divergence), the modified
     depth is clip(depth, 0, 255).astype(uint8).  With the depth blur ON the reference takes its scipy blur
-    (`directional_motion_blur`: sobel + convolve1d with 'nearest' borders, :1346-1419) -- not built: the node never passes
-    numpy arrays, so that one combination raises."""
+    (`directional_motion_blur`: scipy.ndimage sobel + convolve1d in float64, :1346-1419, called with blur_mask_width =
+    blur_strength, :1490-1493): cs_directional_blur_scipy (round 4), each eye warped with its own blurred map."""
     for m in modes:
         if m not in _MODES:
             raise Exception('Unknown mode')
-    if direction_aware_depth_blur and depth_blur_strength > 0:
-        raise NotImplementedError("numpy / PIL inputs with the depth blur on take the reference's scipy blur path "
-                                  "(directional_motion_blur, 'nearest' borders); pass torch tensors for the blurred path")
     image = np.asarray(original_image)
     depth = np.asarray(depthmap).astype(np.float32)
     if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
@@ -112,16 +111,23 @@ def _create_stereoimages_numpy(original_image, depthmap, divergence, separation,
     dev = _device()
     img_t = torch.from_numpy(np.array(image, dtype=np.uint8, order='C', copy=True)).to(dev)   # (PIL arrays are read-only)
     dep_t = torch.from_numpy(np.ascontiguousarray(depth)).to(dev)
+    dep_l = dep_r = dep_t
+    if direction_aware_depth_blur:   # (strength <= 0: the depth map itself for both eyes, :1374)
+        try:
+            dep_l, dep_r = engine.directional_blur_scipy(dep_t, depth_blur_strength, depth_blur_edge_threshold, depth_blur_strength,
+                                                         depth_blur_falloff, depth_blur_vert_smooth)
+        except RuntimeError as e:   # a strength that rounds to a box of 0 taps: scipy raises in the reference as well
+            raise RuntimeError("no filter weights given") from e
     left_div, right_div = divergence * (1 + stereo_balance), divergence * (1 - stereo_balance)
 
-    def eye(div_signed, sep_signed, enabled):
+    def eye(dep, div_signed, sep_signed, enabled):
         if not enabled or fill_technique not in _CPU_FILLS:   # (< 0.001: the source image, :1536; unknown technique: :1620)
             return img_t
-        return engine.apply_stereo_divergence(img_t, dep_t, div_signed, sep_signed, stereo_offset_exponent, fill_technique,
+        return engine.apply_stereo_divergence(img_t, dep, div_signed, sep_signed, stereo_offset_exponent, fill_technique,
                                               convergence_point)
 
-    left = eye(+1 * left_div, -1 * separation, not (left_div < 0.001))
-    right = eye(-1 * right_div, separation, not (right_div < 0.001))
+    left = eye(dep_l, +1 * left_div, -1 * separation, not (left_div < 0.001))
+    right = eye(dep_r, -1 * right_div, separation, not (right_div < 0.001))
 
     def anaglyph(a, b):   # overlap_red_cyan (:1996-2010): R from a, G and B from b
         return torch.cat([a[..., :1], b[..., 1:]], dim=-1)
@@ -135,10 +141,11 @@ def _create_stereoimages_numpy(original_image, depthmap, divergence, separation,
         results.append(Image.fromarray(r.contiguous().cpu().numpy()))
     if not return_modified_depth:
         return results
-    mod = Image.fromarray(torch.clamp(dep_t, 0, 255).to(torch.uint8).cpu().numpy())
+    # np.clip(depth, 0, 255).astype(np.uint8) (:1567-1572): truncation of the clamped float
     if direction_aware_depth_blur:
-        return results, mod, mod.copy()
-    return results, mod
+        return (results, Image.fromarray(torch.clamp(dep_l, 0, 255).to(torch.uint8).cpu().numpy()),
+                Image.fromarray(torch.clamp(dep_r, 0, 255).to(torch.uint8).cpu().numpy()))
+    return results, Image.fromarray(torch.clamp(dep_t, 0, 255).to(torch.uint8).cpu().numpy())
 
 
 def create_stereoimages_gpu(image_tensor, depth_tensor, divergence, separation=0.0, modes=None,
@@ -200,12 +207,11 @@ def directional_motion_blur_gpu(depth_tensor, blur_strength, edge_threshold, blu
 
 def forward_warp_gpu(image_tensor, depth_tensor, divergence_px, separation_px, stereo_offset_exponent,
                      convergence_point=0.5, gradient_threshold=1.5, max_stretch=8):
-    """reference :277-450 -> (warped [B,C,H,W], gap_mask bool [B,H,W])."""
-    if gradient_threshold != 1.5 or max_stretch != 8:
-        raise NotImplementedError("the kernel implements the reference's only call-site values (1.5, 8)")
+    """reference :277-450 -> (warped [B,C,H,W], gap_mask bool [B,H,W]).  gradient_threshold (connectivity, :339-340) and
+    max_stretch (scatter rounds, :365) are kernel parameters; the reference's own call sites use the defaults."""
     dev = _device()
     return engine.forward_warp(image_tensor.to(dev, torch.float32), depth_tensor.to(dev, torch.float32), divergence_px,
-                               separation_px, stereo_offset_exponent, convergence_point)
+                               separation_px, stereo_offset_exponent, convergence_point, gradient_threshold, max_stretch)
 
 
 def forward_warp_mesh(image_tensor, depth_tensor, divergence_px, separation_px, stereo_offset_exponent,

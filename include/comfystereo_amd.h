@@ -167,6 +167,17 @@ CS_API int cs_directional_blur(const float *depth, int n, int h, int w, double b
                         size_t workspace_bytes, void *stream);
 
 /*
+ * directional_motion_blur (reference stereoimage_generation.py:1346-1419): the scipy depth blur create_stereoimages applies to
+ * numpy / PIL inputs (:1489-1494) -- scipy.ndimage's float64 accumulation, 'reflect' / 'nearest' borders, no x255 rescaling.
+ * depth [n][h][w] float32 (as given) -> out_l / out_r [n][h][w] float32.  workspace: cs_blur_scipy_workspace_bytes(n, h, w).
+ * CS_EINVAL when blur_strength rounds to 0 taps (the reference raises there as well).
+ */
+CS_API size_t cs_blur_scipy_workspace_bytes(int n, int h, int w);
+CS_API int cs_directional_blur_scipy(const float *depth, int n, int h, int w, double blur_strength, double edge_threshold,
+                              double blur_mask_width, double falloff_exponent, int vert_smooth_px, float *out_l, float *out_r,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * forward_warp_gpu (reference stereoimage_generation.py:277-450) for a sub-batch:
  * image [n][3][h][w] float32, depth [n][h][w] float32 -> warped [n][3][h][w] float32,
  * gap_mask [n][h][w] uint8 (1 = disocclusion).  workspace: cs_warp_workspace_bytes(n, h, w).
@@ -175,6 +186,12 @@ CS_API size_t cs_warp_workspace_bytes(int n, int h, int w);
 CS_API int cs_forward_warp(const float *image, const float *depth, int n, int h, int w, double divergence_px,
                     double separation_px, double stereo_offset_exponent, double convergence_point, float *warped,
                     uint8_t *gap_mask, void *workspace, size_t workspace_bytes, void *stream);
+/* the same with the reference's two keyword parameters (stereoimage_generation.py:277-279): gradient_threshold -- adjacent pixels
+ * are connected when their offsets differ by less than it (:339-340), max_stretch -- scatter rounds (:365).  CS_ELIMIT when more
+ * than 16 rounds could change a column (gradient_threshold > 13 together with max_stretch > 16). */
+CS_API int cs_forward_warp2(const float *image, const float *depth, int n, int h, int w, double divergence_px,
+                     double separation_px, double stereo_offset_exponent, double convergence_point, double gradient_threshold,
+                     int max_stretch, float *warped, uint8_t *gap_mask, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * forward_warp_mesh (reference stereoimage_generation.py:453-689), the mesh-quality warp the reference uses whenever

@@ -76,6 +76,9 @@ def lib():
             L.oracle_forward_warp_gpu.restype = None
             L.oracle_forward_warp_gpu.argtypes = [f32p, f32p, c_int, c_int, c_int, c_double, c_double, c_double,
                                                   c_double, f32p, u8p]
+            L.oracle_forward_warp_gpu2.restype = None
+            L.oracle_forward_warp_gpu2.argtypes = [f32p, f32p, c_int, c_int, c_int, c_double, c_double, c_double,
+                                                   c_double, c_double, c_int, f32p, u8p]
         if hasattr(L, "oracle_set_dialect"):
             L.oracle_set_dialect.restype = None
             L.oracle_set_dialect.argtypes = [c_int]
@@ -141,7 +144,8 @@ def blur(depth_f32, strength, edge_threshold, falloff=1.0, vert_smooth=0, mask_w
     return L.reshape(shp), R.reshape(shp)
 
 
-def forward_warp_gpu(image_f32_bchw, depth_f32_bhw, divergence_px, separation_px, exponent, convergence=0.5):
+def forward_warp_gpu(image_f32_bchw, depth_f32_bhw, divergence_px, separation_px, exponent, convergence=0.5,
+                     gradient_threshold=1.5, max_stretch=8):
     """reference stereoimage_generation.py:277-450 (`forward_warp_gpu`) -> (warped [B,C,H,W] f32, gap mask bool)."""
     img = np.ascontiguousarray(image_f32_bchw, dtype=np.float32)
     dep = np.ascontiguousarray(depth_f32_bhw, dtype=np.float32)
@@ -149,8 +153,8 @@ def forward_warp_gpu(image_f32_bchw, depth_f32_bhw, divergence_px, separation_px
     assert c == 3 and dep.shape == (b, h, w)
     out = np.empty_like(img)
     mask = np.empty((b, h, w), dtype=np.uint8)
-    lib().oracle_forward_warp_gpu(_f32(img), _f32(dep), b, h, w, float(divergence_px), float(separation_px),
-                                  float(exponent), float(convergence), _f32(out), _u8(mask))
+    lib().oracle_forward_warp_gpu2(_f32(img), _f32(dep), b, h, w, float(divergence_px), float(separation_px),
+                                   float(exponent), float(convergence), float(gradient_threshold), int(max_stretch), _f32(out), _u8(mask))
     return out, mask.astype(bool)
 
 

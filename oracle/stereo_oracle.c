@@ -790,8 +790,19 @@ EXPORT void oracle_blur(const float *depth, int B, int H, int W, double strength
  * 2 / 1 / 0.5; colours follow the grid_sample coordinate round trip and are compared with a
  * tolerance (torch's vectorised bilinear kernel is not bit-reproducible).
  * ------------------------------------------------------------------------------------------- */
+/* gradient_threshold / max_stretch: the two keyword parameters of the reference signature (:277-279; `offset_diff <
+ * gradient_threshold` compares float32 tensors with the Python float cast to float32, :339-340; `for k in range(max_stretch)`, :365) */
+EXPORT void oracle_forward_warp_gpu2(const float *image, const float *depth, int B, int H, int W, double div_px,
+                                     double sep_px, double exponent, double convergence, double gradient_threshold,
+                                     int max_stretch, float *out, uint8_t *mask);
 EXPORT void oracle_forward_warp_gpu(const float *image, const float *depth, int B, int H, int W, double div_px,
                                     double sep_px, double exponent, double convergence, float *out, uint8_t *mask) {
+    oracle_forward_warp_gpu2(image, depth, B, H, W, div_px, sep_px, exponent, convergence, 1.5, 8, out, mask);
+}
+EXPORT void oracle_forward_warp_gpu2(const float *image, const float *depth, int B, int H, int W, double div_px,
+                                     double sep_px, double exponent, double convergence, double gradient_threshold,
+                                     int max_stretch, float *out, uint8_t *mask) {
+    const float thr32 = (float)gradient_threshold;
     size_t hw = (size_t)H * W;
     int any_gt1 = 0;
     for (size_t i = 0; i < hw * B; i++)
@@ -834,9 +845,9 @@ EXPORT void oracle_forward_warp_gpu(const float *image, const float *depth, int 
                 src[x] = -1.0f;
                 zb[x] = -1.0f;
             }
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < max_stretch; k++) {
                 for (int i = 0; i < W - 1; i++) {
-                    int connected = fabsf(po[i + 1] - po[i]) < 1.5f;
+                    int connected = fabsf(po[i + 1] - po[i]) < thr32;
                     float dl = dest[i], dr = dest[i + 1];
                     float dmn = dl < dr ? dl : dr;
                     long c = (long)floorf(dmn) + k;

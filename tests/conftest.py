@@ -53,6 +53,12 @@ def golden_warp():
 
 
 @pytest.fixture(scope="session")
+def golden_warp_params():
+    """forward_warp_gpu with gradient_threshold / max_stretch away from their defaults (round 4)."""
+    return Golden("forward_warp_params.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_node():
     return Golden("node_generate.npz")
 

@@ -216,7 +216,7 @@ def test_stereo_shift_torch_matches_reference_vectors_and_oracle():
 def test_create_stereoimages_numpy_and_pil_inputs():
     """create_stereoimages with numpy / PIL inputs, depth blur off (reference stereoimage_generation.py:1486-1499, 1519-1574):
     fixtures captured from the reference (tools/make_goldens.py --only-numpy-inputs), every technique, all return forms.
-    With the blur on, that input form takes the reference's scipy blur: documented refusal."""
+    With the blur on, that input form takes the reference's scipy blur: test_create_stereoimages_numpy_inputs_with_the_blur_on."""
     from PIL import Image
     from conftest import Golden
     from comfystereo_amd import stereoimage_generation as sig
@@ -236,7 +236,56 @@ def test_create_stereoimages_numpy_and_pil_inputs():
     assert isinstance(only, list) and len(only) == 1
     three = sig.create_stereoimages(img, depth, 5.0, 0.0, ["left-right"], 0.0, 2.0, "none", 0.0, 6.0, True, True)
     assert len(three) == 3   # (direction-aware flag with strength 0: the reference returns the depth twice, :1378)
-    with pytest.raises(NotImplementedError):
-        sig.create_stereoimages(img, depth, 5.0, 0.0, ["left-right"], 0.0, 2.0, "none", 5.0, 6.0, True, True)
     with pytest.raises(Exception):
         sig.create_stereoimages(img, depth, 5.0, modes=["sideways"])
+
+
+def test_scipy_depth_blur_kernels_match_the_reference():
+    """cs_directional_blur_scipy (cs_scipyblur.hip) = `directional_motion_blur`, reference stereoimage_generation.py:1346-1419:
+    outputs of the reference (tools/make_goldens.py --only-numpy-blur) bit for bit where NumPy's array power is exact, and the
+    oracle restatement on larger frames (several workgroups per row, the even / odd box loops, every border)."""
+    from conftest import Golden
+    from oracle import scipy_blur_oracle as sb
+    from comfystereo_amd import engine
+    g = Golden("numpy_blur.npz")
+    for case in g.meta["cases"]:
+        cid = case["id"]
+        depth = g[f"{cid}/depth"]
+        left, right = engine.directional_blur_scipy(torch.from_numpy(depth).cuda(), case["strength"], case["edge_threshold"], case["strength"],
+                                                    case["falloff"], case["vert"])
+        for got, want in ((left.cpu().numpy(), g[f"{cid}/left"]), (right.cpu().numpy(), g[f"{cid}/right"])):
+            if case["exact_power"]:
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), cid
+            else:
+                assert np.abs(got - want).max() <= 1e-4 * max(1.0, float(np.abs(want).max())), cid
+    for (h, w, kind, strength, thr, falloff, vert) in [(70, 1300, "blobs", 20.0, 20.0, 2.0, 6), (33, 777, "noisy_ramp", 21.0, 0.5, 0.5, 15),
+                                                       (50, 600, "clipped", 64.0, 8.0, 1.0, 0), (12, 300, "stepped", 3.0, 2.0, 1.3, 2)]:
+        depth = np.round(synth.DEPTHS[kind](h, w, **({} if kind == "stepped" else {"seed": 3})) * 255).astype(np.float32)
+        left, right = engine.directional_blur_scipy(torch.from_numpy(np.stack([depth, depth[::-1].copy()])).cuda(), strength, thr, strength, falloff, vert)
+        for f, d in enumerate((depth, depth[::-1].copy())):
+            wl, wr = sb.directional_motion_blur(d, strength, thr, strength, falloff_exponent=falloff, vert_smooth_px=vert)
+            assert np.array_equal(left[f].cpu().numpy(), wl) and np.array_equal(right[f].cpu().numpy(), wr), (kind, f)
+    same_l, same_r = engine.directional_blur_scipy(torch.from_numpy(depth).cuda(), 0.0, 2.0)
+    assert same_l is same_r   # (strength <= 0: the depth map itself, :1374)
+    with pytest.raises(RuntimeError):   # round(0.4) = 0 taps: scipy raises in the reference
+        engine.directional_blur_scipy(torch.from_numpy(depth).cuda(), 0.4, 2.0, 0.4)
+
+
+def test_create_stereoimages_numpy_inputs_with_the_blur_on():
+    """numpy / PIL inputs with direction_aware_depth_blur=True (reference :1486-1499): fixtures of the reference, all return forms."""
+    from PIL import Image
+    from conftest import Golden
+    from comfystereo_amd import stereoimage_generation as sig
+    g = Golden("numpy_blur.npz")
+    for case in g.meta["create_stereoimages"]:
+        cid = case["id"]
+        img, depth = g[f"{cid}/img"], g[f"{cid}/depth"]
+        res, ml, mr = sig.create_stereoimages(Image.fromarray(img) if case["pil"] else img, depth.tolist() if case["pil"] else depth,
+                                              case["divergence"], case["separation"], case["modes"], case["stereo_balance"],
+                                              case["stereo_offset_exponent"], case["fill_technique"], case["depth_blur_strength"],
+                                              case["depth_blur_edge_threshold"], True, True, case["convergence_point"],
+                                              case["depth_blur_falloff"], case["depth_blur_vert_smooth"])
+        assert len(res) == len(case["modes"])
+        for k, r in enumerate(res):
+            assert isinstance(r, Image.Image) and np.array_equal(np.asarray(r), g[f"{cid}/out{k}"]), (cid, k)
+        assert np.array_equal(np.asarray(ml), g[f"{cid}/mod_left"]) and np.array_equal(np.asarray(mr), g[f"{cid}/mod_right"]), cid

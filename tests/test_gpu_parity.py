@@ -211,6 +211,34 @@ def test_forward_warp_goldens(engine, golden_warp):
             assert (mask != want_mask).mean() <= 1e-3 and np.quantile(err, 0.999) <= 1e-3, cid
 
 
+def test_forward_warp_keyword_parameters(engine, golden_warp_params):
+    """forward_warp_gpu(gradient_threshold=, max_stretch=) (reference :277-279, :339-340, :365): the general instantiation of
+    k_gpuwarp against fixtures of the reference and, on wider rows, against the oracle; the module-level shim passes them on."""
+    g = golden_warp_params
+    for case in g.meta["cases"]:
+        cid = case["id"]
+        img = g[f"{cid}/img_u8"].astype(np.float32) / np.float32(255.0)
+        d8 = g[f"{cid}/depth_u8"].astype(np.float32)
+        depth = d8 / np.float32(255.0) if case["depth_scale"] == 1.0 else d8
+        warped, mask = engine.forward_warp(cuda(img), cuda(depth), case["divergence_px"], case["separation_px"], case["exponent"],
+                                           case["convergence"], case["gradient_threshold"], case["max_stretch"])
+        warped, mask = warped.cpu().numpy(), mask.cpu().numpy()
+        want_mask = np.unpackbits(g[f"{cid}/mask"])[: mask.size].reshape(mask.shape).astype(bool)
+        assert np.array_equal(mask, want_mask), cid
+        assert_warp_colours(warped, g[f"{cid}/warped"], want_mask, cid)
+    from comfystereo_amd import stereoimage_generation as sig
+    b, h, w = 2, 40, 1300
+    img = synth.image_f32(b, h, w, seed=16).transpose(0, 3, 1, 2).copy()
+    for kind, dpx, thr, ms in [("blobs", 44.8, 0.7, 8), ("noisy_ramp", -30.0, 4.0, 5), ("stepped", 60.0, 13.0, 16), ("random8", 25.0, 2.5, 1)]:
+        depth = np.stack([synth.DEPTHS[kind](h, w, **({"cx": w / 2 + 40 * j} if kind == "stepped" else {"seed": j})) for j in range(b)]) * np.float32(255.0)
+        warped, mask = sig.forward_warp_gpu(torch.from_numpy(img), torch.from_numpy(depth), dpx, 0.5, 2.0, 0.5, gradient_threshold=thr, max_stretch=ms)
+        ow, om = oracle.forward_warp_gpu(img, depth, dpx, 0.5, 2.0, 0.5, thr, ms)
+        assert np.array_equal(mask.cpu().numpy(), om), (kind, thr, ms)
+        assert np.abs(warped.cpu().numpy() - ow).max() <= 2e-6, (kind, thr, ms)
+    with pytest.raises(RuntimeError):   # more than 16 effective rounds: refused, not truncated
+        engine.forward_warp(cuda(img), cuda(depth), 10.0, 0.0, 2.0, 0.5, 20.0, 32)
+
+
 @pytest.mark.parametrize("kind", ["blobs", "stepped", "noisy_ramp", "random8"])
 def test_forward_warp_vs_oracle(engine, kind):
     b, h, w = 2, 96, 1280

@@ -98,6 +98,71 @@ def test_forward_warp_gpu(golden_warp):
             assert np.quantile(err, 0.999) <= 1e-3, cid
 
 
+def test_forward_warp_gpu_keyword_parameters(golden_warp_params):
+    """gradient_threshold (connectivity, reference :339-340) and max_stretch (scatter rounds, :365) away from the defaults the
+    reference's own call sites use: 0.6 .. 12.5 and 0 .. 20, incl. a threshold of 0 (nothing connected) and no rounds at all."""
+    g = golden_warp_params
+    for case in g.meta["cases"]:
+        cid = case["id"]
+        img = g[f"{cid}/img_u8"].astype(np.float32) / np.float32(255.0)
+        d8 = g[f"{cid}/depth_u8"].astype(np.float32)
+        depth = d8 / np.float32(255.0) if case["depth_scale"] == 1.0 else d8
+        warped, mask = oracle.forward_warp_gpu(img, depth, case["divergence_px"], case["separation_px"], case["exponent"],
+                                               case["convergence"], case["gradient_threshold"], case["max_stretch"])
+        want_mask = np.unpackbits(g[f"{cid}/mask"])[: mask.size].reshape(mask.shape).astype(bool)
+        assert np.array_equal(mask, want_mask), cid
+        assert_warp_colours(warped, g[f"{cid}/warped"], want_mask, cid)
+
+
+def test_scipy_depth_blur_of_the_numpy_input_path():
+    """`directional_motion_blur` (reference :1346-1419; scipy.ndimage sobel / convolve1d restated in oracle/scipy_blur_oracle.py)
+    against outputs of the reference: bit-exact where NumPy's float32 array power is exact (falloff 2 / 1 / 0.5), one ulp of the
+    weight otherwise (NumPy's SIMD pow is not glibc's)."""
+    from conftest import Golden
+    from oracle import scipy_blur_oracle as sb
+    g = Golden("numpy_blur.npz")
+    for case in g.meta["cases"]:
+        cid = case["id"]
+        depth = g[f"{cid}/depth"]
+        left, right = sb.directional_motion_blur(depth, case["strength"], case["edge_threshold"], case["strength"],
+                                                 falloff_exponent=case["falloff"], vert_smooth_px=case["vert"])
+        for got, want in ((left, g[f"{cid}/left"]), (right, g[f"{cid}/right"])):
+            assert got.dtype == np.float32
+            if case["exact_power"]:
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), cid
+            else:
+                assert np.abs(got - want).max() <= 1e-4 * max(1.0, float(np.abs(want).max())), cid
+
+
+def numpy_path_with_blur(apply_div, blur, img, depth, kw):
+    """create_stereoimages for numpy inputs with the blur on (reference :1486-1562), from the two building blocks."""
+    left_d, right_d = blur(depth, kw["depth_blur_strength"], kw["depth_blur_edge_threshold"], kw["depth_blur_strength"],
+                           falloff_exponent=kw["depth_blur_falloff"], vert_smooth_px=kw["depth_blur_vert_smooth"])
+    ld, rd = kw["divergence"] * (1 + kw["stereo_balance"]), kw["divergence"] * (1 - kw["stereo_balance"])
+    e, f, c = kw["stereo_offset_exponent"], kw["fill_technique"], kw["convergence_point"]
+    left = img if ld < 0.001 else apply_div(img, left_d, +1 * ld, -1 * kw["separation"], e, f, c)
+    right = img if rd < 0.001 else apply_div(img, right_d, -1 * rd, kw["separation"], e, f, c)
+    out = []
+    for m in kw["modes"]:
+        out.append({"left-right": lambda: np.hstack([left, right]), "right-left": lambda: np.hstack([right, left]),
+                    "top-bottom": lambda: np.vstack([left, right]), "bottom-top": lambda: np.vstack([right, left]),
+                    "red-cyan-anaglyph": lambda: np.dstack([left[..., :1], right[..., 1:]]), "left-only": lambda: left,
+                    "only-right": lambda: right}[m]())
+    return out, np.clip(left_d, 0, 255).astype(np.uint8), np.clip(right_d, 0, 255).astype(np.uint8)
+
+
+def test_create_stereoimages_numpy_inputs_with_the_blur_on():
+    from conftest import Golden
+    from oracle import scipy_blur_oracle as sb
+    g = Golden("numpy_blur.npz")
+    for case in g.meta["create_stereoimages"]:
+        cid = case["id"]
+        outs, ml, mr = numpy_path_with_blur(oracle.apply_stereo_divergence, sb.directional_motion_blur, g[f"{cid}/img"], g[f"{cid}/depth"], case)
+        for k, o in enumerate(outs):
+            assert np.array_equal(o, g[f"{cid}/out{k}"]), (cid, k)
+        assert np.array_equal(ml, g[f"{cid}/mod_left"]) and np.array_equal(mr, g[f"{cid}/mod_right"]), cid
+
+
 def test_node_generate(golden_node):
     """StereoImageNode.generate: every UI technique x mode + variants (reference GenerateStereo.py:79-353)."""
     g = golden_node

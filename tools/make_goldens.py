@@ -165,6 +165,33 @@ def gen_forward_warp(sig):
     print("forward_warp_gpu:", len(cases), "cases")
 
 
+def gen_forward_warp_params(sig):
+    """forward_warp_gpu with its two keyword parameters away from their defaults (reference :277-279: gradient_threshold --
+    connectivity, :339-340; max_stretch -- scatter rounds, :365): round 4, leaves forward_warp_gpu.npz untouched."""
+    arrays, cases = {}, []
+    specs = [(48, 160, 2, "blobs", 14.0, 0.0, 2.0, 0.5, 255.0, 0.6, 8), (48, 160, 1, "stepped", -16.8, 1.0, 2.0, 0.5, 255.0, 3.0, 8),
+             (64, 96, 1, "noisy_ramp", 12.0, -1.0, 1.0, 0.3, 255.0, 1.5, 2), (32, 128, 1, "random8", -9.0, 0.0, 0.5, 0.7, 255.0, 6.5, 12),
+             (48, 160, 1, "blobs", 20.0, 0.0, 2.0, 0.5, 1.0, 2.0, 3), (40, 200, 1, "stepped", 30.0, 0.0, 2.0, 0.4, 255.0, 12.5, 20),
+             (32, 96, 1, "blobs", 10.0, 0.0, 2.0, 0.5, 255.0, 1.5, 0), (32, 96, 1, "blobs", 10.0, 0.0, 2.0, 0.5, 255.0, 0.0, 8),
+             (48, 160, 1, "noisy_ramp", -14.0, 0.5, 2.0, 0.5, 255.0, 1.5, 3), (48, 160, 1, "blobs", 14.0, 0.0, 2.0, 0.5, 255.0, 1.0, 8)]
+    for i, (H, W, B, kind, dpx, spx, e, conv, scale, thr, ms) in enumerate(specs):
+        d8 = np.stack([np.round((synth.DEPTHS[kind](H, W, cx=W / 2 + 7 * j) if kind in ("radial", "stepped")
+                                 else synth.DEPTHS[kind](H, W, seed=j)) * 255) for j in range(B)]).astype(np.uint8)
+        depth = d8.astype(np.float32) / np.float32(255.0) if scale == 1.0 else d8.astype(np.float32)
+        img8 = np.random.default_rng(140 + i).integers(0, 256, (B, 3, H, W), dtype=np.uint8)
+        img = img8.astype(np.float32) / np.float32(255.0)
+        wr, mr = sig.forward_warp_gpu(torch.from_numpy(img), torch.from_numpy(depth), dpx, spx, e, conv, gradient_threshold=thr,
+                                      max_stretch=ms)
+        arrays[f"c{i}/img_u8"] = img8
+        arrays[f"c{i}/depth_u8"] = d8
+        arrays[f"c{i}/warped"] = wr.numpy()
+        arrays[f"c{i}/mask"] = np.packbits(mr.numpy())
+        cases.append(dict(id=f"c{i}", divergence_px=dpx, separation_px=spx, exponent=e, convergence=conv, depth_scale=scale,
+                          gradient_threshold=thr, max_stretch=ms, shape=[B, H, W]))
+    np.savez_compressed(os.path.join(OUT, "forward_warp_params.npz"), meta=json.dumps(dict(cases=cases)), **arrays)
+    print("forward_warp_params:", len(cases), "cases")
+
+
 def smooth_image(n, h, w, seed):
     """Low-entropy 8-bit image batch (keeps the committed fixture small); includes black pixels."""
     rng = np.random.default_rng(seed)
@@ -449,6 +476,51 @@ def gen_numpy_inputs(sig):
     print("create_stereoimages with numpy / PIL inputs:", len(cases), "cases")
 
 
+def gen_numpy_blur(sig):
+    """Round 4: the scipy depth blur of the numpy / PIL input path (`directional_motion_blur`, reference :1346-1419, called from
+    create_stereoimages :1489-1494): raw blur outputs, and create_stereoimages with numpy / PIL inputs and the blur ON."""
+    from PIL import Image
+    arrays, cases, cs_cases = {}, [], []
+    specs = [(64, 200, "blobs", 20.0, 20.0, 2.0, 6), (48, 160, "stepped", 5.4, 3.0, 1.0, 3), (40, 120, "noisy_ramp", 7.0, 0.5, 0.5, 0),
+             (33, 97, "blobs", 21.0, 6.0, 2.0, 15), (48, 130, "clipped", 33.0, 12.0, 2.0, 2), (20, 64, "random8", 4.0, 2.0, 1.0, 1),
+             (40, 150, "blobs", 9.6, 4.0, 1.7, 4), (36, 140, "stepped", 12.0, 8.0, 3.0, 0), (9, 40, "blobs", 2.0, 1.0, 2.0, 7),
+             (30, 90, "blobs", 1.4, 1.0, 2.0, 0)]
+    for i, (h, w, kind, strength, thr, falloff, vert) in enumerate(specs):
+        depth = np.round((synth.DEPTHS[kind](h, w, seed=i) if kind not in ("radial", "stepped") else synth.DEPTHS[kind](h, w)) * 255).astype(np.float32)
+        if i == 5:
+            depth = depth / np.float32(255.0)   # a 0..1 map: the numpy path does NOT rescale it (reference :1488)
+            thr = 0.004
+        left, right = sig.directional_motion_blur(depth, strength, thr, strength, falloff_exponent=falloff, vert_smooth_px=vert)
+        arrays[f"b{i}/depth"] = depth
+        arrays[f"b{i}/left"] = np.asarray(left, dtype=np.float32)
+        arrays[f"b{i}/right"] = np.asarray(right, dtype=np.float32)
+        assert left.dtype == np.float32
+        cases.append(dict(id=f"b{i}", strength=strength, edge_threshold=thr, falloff=falloff, vert=vert, exact_power=falloff in (2.0, 1.0, 0.5)))
+    for ci, (h, w, kind, fill, modes, strength, thr, falloff, vert, as_pil) in enumerate([
+            (40, 128, "blobs", "polylines_soft", ["left-right"], 20.0, 20.0, 2.0, 6, False),
+            (36, 120, "stepped", "naive_interpolating", ["top-bottom", "red-cyan-anaglyph"], 6.0, 3.0, 1.0, 2, True),
+            (33, 96, "blobs", "hybrid_edge", ["right-left"], 10.0, 6.0, 0.5, 0, False),
+            (40, 128, "noisy_ramp", "polylines_sharp", ["left-right", "only-right"], 8.0, 2.0, 2.0, 3, True),
+            (32, 100, "blobs", "none", ["bottom-top"], 5.0, 4.0, 2.0, 1, False)]):
+        img = synth.image_u8(h, w, seed=60 + ci)
+        depth = (synth.DEPTHS[kind](h, w) * np.float32(255.0)).astype(np.float32)
+        kw = dict(divergence=[5.0, 8.0][ci % 2], separation=[0.0, 1.0][ci % 2], modes=modes, stereo_balance=[0.0, 0.3, -0.4][ci % 3],
+                  stereo_offset_exponent=[2.0, 1.0][ci % 2], fill_technique=fill, convergence_point=0.5,
+                  depth_blur_strength=strength, depth_blur_edge_threshold=thr, depth_blur_falloff=falloff, depth_blur_vert_smooth=vert)
+        res, ml, mr = sig.create_stereoimages(Image.fromarray(img) if as_pil else img, depth.tolist() if as_pil else depth,
+                                              kw["divergence"], kw["separation"], modes, kw["stereo_balance"], kw["stereo_offset_exponent"],
+                                              fill, strength, thr, True, True, 0.5, falloff, vert)
+        arrays[f"s{ci}/img"] = img
+        arrays[f"s{ci}/depth"] = depth
+        for k, r in enumerate(res):
+            arrays[f"s{ci}/out{k}"] = np.asarray(r)
+        arrays[f"s{ci}/mod_left"] = np.asarray(ml)
+        arrays[f"s{ci}/mod_right"] = np.asarray(mr)
+        cs_cases.append(dict(id=f"s{ci}", pil=as_pil, **kw))
+    np.savez_compressed(os.path.join(OUT, "numpy_blur.npz"), meta=json.dumps(dict(cases=cases, create_stereoimages=cs_cases)), **arrays)
+    print("scipy depth blur (numpy / PIL inputs):", len(cases), "blur cases,", len(cs_cases), "create_stereoimages cases")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     refload.quiet()
@@ -478,6 +550,12 @@ def main():
     if "--only-numpy-inputs" in sys.argv:
         gen_numpy_inputs(sig)
         return
+    if "--only-numpy-blur" in sys.argv:
+        gen_numpy_blur(sig)
+        return
+    if "--only-warp-params" in sys.argv:
+        gen_forward_warp_params(sig)
+        return
     if "--only-dialect" in sys.argv:
         gen_dialect_f64(sig)
         return
@@ -492,6 +570,8 @@ def main():
     gen_digests(gs)
     gen_dialect_f64(sig)
     gen_numpy_inputs(sig)
+    gen_forward_warp_params(sig)
+    gen_numpy_blur(sig)
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
