@@ -178,7 +178,9 @@ def main():
         job = sharding.ShardedStereoJob(params, frames, (out_h, out_w, 3), device, method=a.gather)
         plans = job.plans
     else:
-        plan = engine.Plan(params(nloc), device)
+        # (--depth random8 with the blur off: every row is order-dependent and one stretch long -- room for all of them to export)
+        tie_pool = nloc * H * W * 2 * 6 + (64 << 20) if (a.depth == "random8" and cfg["fill"].startswith("polylines")) else 0
+        plan = engine.Plan(params(nloc), device, tie_pool_bytes=tie_pool)
         plans = [plan]
         if world > 1:
             sizes = {bounds[r + 1] - bounds[r] for r in range(world)}

@@ -363,7 +363,7 @@ static uint32_t* rowflag_list(uint8_t* rowflag, size_t rows) { return (uint32_t*
 static size_t poly_anaglyph_bytes(int n, int h, int w) { return al256((size_t)n * h * 2 * w * 3); }
 
 static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_t stream, uint8_t* ana_sbs = nullptr,
-                    void* replay_scratch = nullptr) {
+                    void* replay_scratch = nullptr, size_t replay_surplus = 0) {
     const bool poly = fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP;
     // polylines, eyes in separate output slots: the stretches of order-dependent rows are replayed by a kernel of their own
     // (cs_rowwarp.hip k_poly_replay) instead of inside the row kernel
@@ -371,7 +371,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
                         poly_replay_bytes(A.n, A.h, A.w, fill == CS_FILL_POLYLINES_SHARP) > 0;
     bool cleared = false;   // the flagged-row block (row flags, counters, replay counters and retry flags) has been zeroed
     if (replay)
-        (void)poly_replay_attach(A, fill == CS_FILL_POLYLINES_SHARP, replay_scratch, rowflag + al256((size_t)A.n * A.h) + 256, stream);
+        (void)poly_replay_attach(A, fill == CS_FILL_POLYLINES_SHARP, replay_scratch, rowflag + al256((size_t)A.n * A.h) + 256, stream, replay_surplus);
     if (poly && !A.d64 && (!A.anaglyph || (ana_sbs && A.image_f32 && !A.out_u8)) && halo <= polytile_max_halo() && rowflag &&
         !dev_switch(CS_DEBUG_NO_TILE)) {   // (the tile kernels are dialect D32)
         // workspace: [n*h flag bytes][count, padded to 256][n*h list entries]
@@ -393,7 +393,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
             T.out_h = A.h; T.out_w = 2 * A.w;
             T.eye[0].xoff = 0; T.eye[0].yoff = 0; T.eye[1].xoff = A.w; T.eye[1].yoff = 0;
         }
-        if (halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16)))
+        if (halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16) || (variant >= 41 && variant <= 43)))   // (41 - 43: tie-path what-ifs)
             e = launch_polypoint(T, halo, rowflag, stream, fill == CS_FILL_POLYLINES_SHARP);
         else
             e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, T, halo, rowflag, stream);
@@ -445,10 +445,12 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         hipError_t e0 = hipMemsetAsync(rowflag, 0, rowflag_clear_bytes((size_t)A.n * A.h), stream);
         if (e0 != hipSuccess) return fail_hip(e0, "rowflag memset");
     }
-    hipError_t e = launch_rowwarp(fill, A, threads_for(fill, A.w), stream);
+    // (polylines with the replay kernel attached: the lean instantiation first -- evaluation, stretch list, export; the rows it
+    // cannot export come back through the retry flags below.  CS_DEBUG_PT_VARIANT 43: the full kernel as in round 3)
+    hipError_t e = launch_rowwarp(fill, A, threads_for(fill, A.w), stream, 0, replay && dev_switch(CS_DEBUG_PT_VARIANT) != 43);
     if (e != hipSuccess) return fail_hip(e, "row kernel launch");
     if (replay) {
-        e = launch_poly_replay(fill == CS_FILL_POLYLINES_SHARP, A, stream);
+        e = launch_poly_replay(fill == CS_FILL_POLYLINES_SHARP, A, halo, stream);
         if (e != hipSuccess) return fail_hip(e, "stretch replay launch");
         // rows with a stretch the replay kernel gave up on (usually none): once more through the row kernel, export off
         const size_t rows = (size_t)A.n * A.h;
@@ -458,7 +460,9 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         if (e != hipSuccess) return fail_hip(e, "replay retry collection");
         RowArgs R = A;
         R.rp_dump = nullptr; R.row_list = list; R.row_count = count2;
-        e = launch_rowwarp(fill, R, threads_for(fill, A.w), stream, 32);
+        // (one workgroup per CU: on saturated depth a few hundred rows per frame come back -- stretches whose list outgrows the
+        // wave form's 64 entries --, 32 workgroups made them the tail of the call; an empty launch of 256 costs 0.03 ms)
+        e = launch_rowwarp(fill, R, threads_for(fill, A.w), stream, dev_switch(CS_DEBUG_PT_VARIANT) == 42 ? 32 : 256);
         if (e != hipSuccess) return fail_hip(e, "row kernel launch (replay retry)");
     }
     return CS_OK;
@@ -621,7 +625,7 @@ size_t cs_workspace_bytes(const cs_params* p) { return (p && p->n > 0) ? ws_tota
 // by stream in between).  `stats`: the chunk's slice of the call's statistics words; `ws`: the chunk's scratch (ws_layout).
 static int generate_chunk(const cs_params* p, const float* image, const float* depth, float* stereo, float* depth_l,
                           float* depth_r, float* mask, uint32_t* stats, char* ws, int out_h, int out_w, hipStream_t sp,
-                          hipStream_t stream, hipEvent_t ready) {
+                          hipStream_t stream, hipEvent_t ready, size_t surplus = 0) {
     int rc;
     const WsLayout W = ws_layout(p);
     float* gray = (float*)(ws + W.gray);
@@ -746,7 +750,7 @@ static int generate_chunk(const cs_params* p, const float* image, const float* d
         if (rc) return fail(rc, "hybrid_edge launch failed");
     } else {
         rc = run_rows(p->fill, A, halo, (uint8_t*)(ws + W.rowflag), stream, A.anaglyph ? (uint8_t*)(ws + W.extra) : nullptr,
-                      A.anaglyph ? nullptr : (void*)(ws + W.extra));
+                      A.anaglyph ? nullptr : (void*)(ws + W.extra), surplus);
         if (rc) return rc;
     }
     hipError_t e = hipGetLastError();
@@ -774,7 +778,10 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     uint32_t* const stats = (uint32_t*)ws;
     char* const scratch = ws + al256((size_t)p->n * ST_WORDS * 4);
     const ChunkPlan C = plan_chunks(p);
-    if (C.nch == 1) return generate_chunk(p, image, depth, stereo, depth_l, depth_r, mask, stats, scratch, out_h, out_w, stream, stream, nullptr);
+    // (one chunk: whatever the caller's workspace holds beyond cs_workspace_bytes extends the stretch-replay pool -- the last item
+    // of the layout -- so that a caller who expects tie-heavy depth maps can give every flagged row room to export)
+    if (C.nch == 1) return generate_chunk(p, image, depth, stereo, depth_l, depth_r, mask, stats, scratch, out_h, out_w, stream, stream, nullptr,
+                                          workspace_bytes - ws_total(p));
 
     // mode (CS_DEBUG_CHUNKS / 100): 0 = pre-passes on the highest-priority auxiliary stream, warps on the caller's stream;
     // 1 = pre-passes on an auxiliary stream of the default priority; 2 = pre-passes at the default priority AND the warps on

@@ -128,7 +128,9 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
     // Workgroup b runs on XCD b % 8 (observed dispatch order; a speed assumption only).  With row = blockIdx.x the rows y and
     // y + 1 -- whose image rows BOTH feed output row y through the 4-corner blend of the grid_sample round trip (:441-448) --
     // sit on different XCDs, and each fetches both rows from the fabric: 2.8 x the algorithmic reads (profiles/r03g_cfg4_pmc).
-    // GW_XCD_ROWS: XCD k takes the rows [k * rpx, (k + 1) * rpx) in order, so the neighbour row is in that XCD's L2.
+    // -DGW_XCD_ROWS (measured in round 4, NOT the default): XCD k takes the rows [k * rpx, (k + 1) * rpx) in order, so the
+    // neighbour row is in that XCD's L2 -- FETCH_SIZE x 2 of the kernel 15.1 -> 9.0 GB per 128 1080p frames (-41 %), and the
+    // kernel is 1.3 % SLOWER at 1080p and at 4K (tools/sessions/r04_s7.sh): it is not the fabric that bounds this kernel.
 #ifdef GW_XCD_ROWS
     const int rpx = (A.h + 7) >> 3;
     const int y = (int)(blockIdx.x & 7u) * rpx + (int)(blockIdx.x >> 3);

@@ -57,7 +57,7 @@ struct RowArgs {
     int tm_words;
     // Stretch replay OUTSIDE the row kernel (round 3, cs_rowwarp.hip k_poly_replay): a polylines row whose order-dependent
     // stretches fit the replay kernel's windows dumps its sorted points (perm, coord_d) into a slot of rp_dump and appends one
-    // descriptor per stretch to rp_list; rp_ctr = {slots used, descriptors appended, replay cursor}.  Null: the row kernel
+    // descriptor per stretch to rp_list; rp_ctr = {-, descriptors appended, replay cursor, -, pool units used (64 bits)}.  Null: the row kernel
     // replays its stretches itself (anaglyph modes, hybrid_edge_plus, no scratch).
     uint8_t* rp_dump;
     uint32_t* rp_list;
@@ -77,13 +77,13 @@ int dev_switch(int key);
 
 // cs_rowwarp.hip
 hipError_t launch_collect_rows(const uint8_t* flag, int total, uint32_t* count, uint32_t* list, hipStream_t stream);
-hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream, int max_groups = 0);
+hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream, int max_groups = 0, int lean = 0);
 size_t rowwarp_lds_bytes(int fill, int w, int anaglyph = 1);   // anaglyph modes stash two channels of the first eye (2 B per pixel)
 // scratch of the stretch replay kernel for a call of n frames (0: the frame is too wide for its windows); poly_replay_attach
 // carves it into A.rp_* and zeroes the counters; launch_poly_replay runs the descriptors the row pass appended
 size_t poly_replay_bytes(int n, int h, int w, int sharp);
-hipError_t poly_replay_attach(RowArgs& A, int sharp, void* scratch, void* ctr_retry, hipStream_t stream);
-hipError_t launch_poly_replay(int sharp, const RowArgs& A, hipStream_t stream);
+hipError_t poly_replay_attach(RowArgs& A, int sharp, void* scratch, void* ctr_retry, hipStream_t stream, size_t surplus = 0);
+hipError_t launch_poly_replay(int sharp, const RowArgs& A, int halo, hipStream_t stream);
 uint8_t* poly_replay_retry_flags(const RowArgs& A);   // one byte per row: set by a stretch the replay kernel gave up on
 
 // cs_polytile.hip: tiled fast path of polylines; flags rows it cannot do for the general kernel

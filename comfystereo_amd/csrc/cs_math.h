@@ -195,6 +195,26 @@ CS_HD double exp_exact(double x, const unsigned long long* tab) {
     return fma(scale, t, scale);
 }
 
+// The same for a caller that KNOWS |x| < 512 and x finite (the Gaussian weights of hybrid_edge: -8 < x <= 0): the range test and
+// its branches are gone.  Identical results: the main path maps x = 0 to exactly 1 (r = 0, table entry 0 = {0, 1.0}) and a tiny
+// |x| < 2^-54 to fl(1 + x), which is what libm's early return computes.
+CS_HD double exp_exact_small(double x, const unsigned long long* tab) {
+    double kd = fma(x, CS_EXP_INVLN2N, CS_EXP_SHIFT);
+    uint64_t ki = d2u(kd);
+    kd -= CS_EXP_SHIFT;
+    double r = fma(kd, CS_EXP_NEGLN2HIN, x);
+    r = fma(kd, CS_EXP_NEGLN2LON, r);
+    uint32_t idx = 2u * (uint32_t)(ki & 127u);
+    double tail = u2d(tab[idx]);
+    double scale = u2d(tab[idx + 1] + (ki << 45));
+    double r2 = r * r;
+    double p23 = fma(r, CS_EXP_C3, CS_EXP_C2);
+    double p45 = fma(r, CS_EXP_C5, CS_EXP_C4);
+    double lo = fma(p23, r2, tail + r);
+    double t = fma(r2 * r2, p45, lo);
+    return fma(scale, t, scale);
+}
+
 // numpy float32 -> uint8 astype on x86-64 (cvttss2si, low byte): out-of-range -> 0x80000000 -> 0.
 CS_HD uint8_t f32_to_u8_wrap(float v) {
     int32_t i = (v > -2147483904.0f && v < 2147483648.0f) ? (int32_t)v : (int32_t)0x80000000;

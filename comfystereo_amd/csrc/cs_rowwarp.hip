@@ -687,10 +687,28 @@ __device__ int poly_sequential_wave(const Poly& P, const Lds& L, int csg_cap_ref
 // the closeness of a step need no memory at all, and the 64 sorted points around the sweep position sit in a register
 // window read with v_readlane.  LDS is touched when a segment enters the list (its far end point), when a removal leaves
 // holes in front of survivors (their lane numbers are handed over, then cross-lane moves) and for the winner's colours.
-template <class Emit>
-__device__ int poly_replay_stretch(const Poly& P, const Lds& L, int csg_cap_ref, const Emit& emit, int c0, int c1, int seg0,
-                                   int sgp0, uint16_t* srcpos, int pts_left_of_c0) {
+// `slide` (round 4): the caller may hold only WINDOWS of the row's arrays (k_poly_replay: a few hundred sorted points and source
+// columns around the sweep position in 4 KB of LDS, refilled from the row's dump as the sweep advances).  Before the function
+// reads sorted positions [lo, hi) it calls slide.points(lo, hi), before it reads the coord_d / colour of source columns
+// [lo, hi] slide.columns(lo, hi) -- both may re-base P.perm / P.cd / L.img; false: the range does not fit the windows (-2).
+// What a pixel can touch: the 64 sorted points of the register window (and their right neighbours' columns), and the
+// segments in the list -- every ACTIVE segment (o -> o + 1) covers the sweep position x, and x - column(o) lies in
+// [coord_d(o), 1 + coord_d(o + 1)]: within `halo` columns of the pixel.  NoSlide: the whole row is resident (the row kernel).
+struct NoSlide {
+    static constexpr bool active = false;
+    __device__ __forceinline__ bool points(int, int) const { return true; }
+    __device__ __forceinline__ bool columns(int, int) const { return true; }
+    __device__ __forceinline__ bool holds(int, int) const { return true; }
+    __device__ __forceinline__ void rebase_points(Poly&) const {}
+    __device__ __forceinline__ void rebase_columns(Poly&, Lds&) const {}
+};
+template <class Emit, class Slide>
+__device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit& emit, int c0, int c1, int seg0,
+                                   int sgp0, uint16_t* srcpos, int pts_left_of_c0, Slide& slide, int halo) {
     const int lane = threadIdx.x & 63;
+    int col_cur = c0;
+    if (!slide.columns(c0 - halo, c0 + halo)) return -2;
+    slide.rebase_columns(P, L);
     const int sg_end = P.npt - 1;
     const int cap = min(min(csg_cap_ref, P.cap), 64);
     auto rl_f = [](float v, int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i)); };
@@ -705,24 +723,40 @@ __device__ int poly_replay_stretch(const Poly& P, const Lds& L, int csg_cap_ref,
     // window of the sorted points: lane k holds point perm[wbase + k]
     int wbase = 0, wo = 0;
     float wx = 0.0f;
+    bool lost = false;   // the sweep position and the add pointer drifted more than a window apart (long runs of equal x)
     auto window = [&](int lo) {   // (two points of slack below: the sweep steps back by one at every pixel)
         wbase = max(lo - 2, 0);
+        if (!slide.points(wbase, wbase + 64)) lost = true;
+        slide.rebase_points(P);
         wo = P.perm[min(wbase + lane, P.npt - 1)];
-        wx = poly_x(P, wo);
+        if (Slide::active) {   // the columns of these points and of their right neighbours, next to the active segments'
+            int cl = min(poly_col(P, wo), col_cur - halo), ch = max(poly_col(P, min(wo + 1, P.npt - 1)), col_cur + halo);
+            if (!__all(slide.holds(cl, ch))) {   // (one ballot in the usual case; the wave-wide range only for a refill)
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { cl = min(cl, __shfl_xor(cl, d)); ch = max(ch, __shfl_xor(ch, d)); }
+                if (!slide.columns(cl, ch)) lost = true;
+                slide.rebase_columns(P, L);
+            }
+        }
+        wx = lost ? 0.0f : poly_x(P, wo);
     };
-    bool lost = false;   // the sweep position and the add pointer drifted more than a window apart (long runs of equal x)
     auto need = [&](int lo, int hi) {
         if (lo < wbase || hi >= wbase + 64) { window(lo); lost = lost || hi >= wbase + 64; }
     };
     int pt_i = pts_left_of_c0 - 1;   // (binoff[c0]: the number of points left of pixel c0; the sweep's own loop settles it)
     bool first_step = true;
     window(seg0 < 0 ? pt_i : min(pt_i, sg_pointer));
+    if (lost) return -2;
     for (int col = c0; col <= c1; col++) {
         float color[3] = {0.5f, 0.5f, 0.5f};
+        col_cur = col;
+        if (!slide.columns(col - halo, col + halo)) return -2;
+        slide.rebase_columns(P, L);
         need(pt_i, pt_i + 1);
-        while (rl_f(wx, pt_i - wbase) < (float)col) { pt_i++; need(pt_i, pt_i + 1); }
+        while (!lost && rl_f(wx, pt_i - wbase) < (float)col) { pt_i++; need(pt_i, pt_i + 1); }
         pt_i--;
         need(pt_i, pt_i + 1);
+        if (lost) return -2;
         while (rl_f(wx, pt_i - wbase) < (float)(col + 1)) {
             const SubInt s = poly_subinterval(col, rl_f(wx, pt_i - wbase), rl_f(wx, pt_i + 1 - wbase));
             if (first_step && seg0 < 0) {
@@ -737,7 +771,16 @@ __device__ int poly_replay_stretch(const Poly& P, const Lds& L, int csg_cap_ref,
                 // pass 1: K and the number of survivors
                 for (int base = 0; base < sg_end; base += 64) {
                     const int k = base + lane;
+                    if (!slide.points(base, min(base + 64, sg_end))) return -2;
+                    slide.rebase_points(P);
                     const int o = P.perm[min(k, sg_end - 1)];
+                    if (Slide::active) {   // (points left of the first centre: the columns an eye shifts out of the frame)
+                        int ch = poly_col(P, min(o + 1, P.npt - 1));
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) ch = max(ch, __shfl_xor(ch, d));
+                        if (!slide.columns(0, max(ch, halo))) return -2;
+                        slide.rebase_columns(P, L);
+                    }
                     const bool in = k < sg_end && poly_x(P, o) < s.center;
                     const unsigned long long mi = __ballot(in);
                     const unsigned long long ma = __ballot(in && !(poly_x(P, o + 1) < s.center));
@@ -750,6 +793,8 @@ __device__ int poly_replay_stretch(const Poly& P, const Lds& L, int csg_cap_ref,
                 int my_o = -1;
                 for (int base = 0; base < K; base += 64) {
                     const int k = base + lane;
+                    if (!slide.points(base, min(base + 64, sg_end))) return -2;
+                    slide.rebase_points(P);
                     const int o = P.perm[min(k, sg_end - 1)];
                     const bool al = k < K && !(poly_x(P, o + 1) < s.center);
                     const unsigned long long ma = __ballot(al);
@@ -775,6 +820,7 @@ __device__ int poly_replay_stretch(const Poly& P, const Lds& L, int csg_cap_ref,
                 }
                 csg_end = ns_total; sg_pointer = K;
                 window(min(pt_i, sg_pointer));
+                if (lost) return -2;
             }
             first_step = false;
             need(min(pt_i, sg_pointer), max(pt_i + 1, sg_pointer));
@@ -851,6 +897,7 @@ __device__ int poly_replay_stretch(const Poly& P, const Lds& L, int csg_cap_ref,
             }
             pt_i++;
             need(pt_i, pt_i + 1);
+            if (lost) return -2;
         }
         if (lane == 0) emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
     }
@@ -870,11 +917,15 @@ __device__ __forceinline__ void poly_seg_pixels(const Poly& P, int o, int& p0, i
 }
 
 // windows of the stretch replay kernel (k_poly_replay): sorted points / source columns one stretch may touch
-#define RP_PW 1024
+#define RP_PWS 512    // sorted positions / source columns a replay wave holds in LDS at a time (sliding windows, k_poly_replay:
+#define RP_CWS 1024   // 8.3 KB per wave -- 19 waves per CU by LDS, 20 by registers)
+#define RP_CWS_WIDE 4096   // ... for halos beyond 230 columns
+#define RP_PW 1024    // a typical stretch's windows in the dump (pool sizing only: the windows have no upper limit any more)
 #define RP_CW 1024
 #define RP_DESC 8   // words per stretch descriptor
 struct RpCtx {      // where a row exports its stretches to (dump == null: replay inside the row kernel)
     uint8_t* dump; uint32_t* list; uint32_t* ctr; uint32_t pool16, cap; uint32_t rowid; int eye;   // pool16: dump bytes / 16
+    uint8_t* retry;   // LEAN: one byte per row, set when the row needs the full kernel (its inline replay)
 };
 // what a stretch leaves in the dump pool: ITS windows of the row's sorted order (perm[pw0 .. pw1]) and of coord_d
 // (cd[cmin .. cmax]) -- a few hundred entries each, not the whole row (round 3 dumped 6-8 B per pixel of the row per slot: 3.2 GB
@@ -883,7 +934,11 @@ __host__ __device__ inline uint32_t rp_win16(int npw, int ncw) { return (uint32_
 
 // DIALECT: the instantiation that can run the dialect bits d64 (separate kernels, k_rowwarp<FILL, true>: the D32 kernel keeps
 // its registers and its code as they were)
-template <int SHARP, bool DIALECT, class Emit>
+// LEAN (round 4): the instantiation the FIRST pass over the flagged rows runs when the stretch replay kernel is attached: the
+// parallel evaluation, the stretch list and the export only -- a row that would need the in-row replay (export impossible,
+// no reset points, list overflow) is flagged for the second pass (the full kernel, export off) instead.  Without the replay
+// code the kernel fits 64 registers: two 1024-thread workgroups per CU instead of one.
+template <int SHARP, bool DIALECT, class Emit, bool LEAN = false>
 __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float e32, uint32_t* stats_rw,
                                     const Emit& emit, int dbg, const RpCtx* X = nullptr, int d64_ = 0, double e64 = 0.0) {
     const int d64 = DIALECT ? d64_ : 0;
@@ -1118,10 +1173,21 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
     int* nstretch = L.misc + 3;
     int* stretch_bad = L.misc + 4;
     const int tail0 = (*ntotal + 7) & ~7;   // the idle tail of the per-pixel segment lists: stretch list + 256 bytes of scratch per wave
-    if (!overflow && *flag_hazard && w <= 8192 && dbg != 26 && dbg != 27 && tail0 + 2 * NSTR + 128 * nwaves + 8 <= P.cap) {
-        uint32_t* slist = (uint32_t*)(P.entries + tail0);   // start | end << 16 (pixel columns)
-        uint16_t* wscr = P.entries + tail0 + 2 * NSTR;
-        if (tid == 0) {
+    // Scratch of this phase: the stretch list, 256 bytes per wave for the in-row replay, the descriptors of the export.  The full
+    // kernel takes it from the idle tail of the per-pixel segment lists -- which a row with many overlapping layers (the rows
+    // that tie) does not have: half of the flagged rows of a saturated depth map could not export for that reason alone.  The
+    // LEAN instantiation never replays in the row, so the source row's colour codes (3 w bytes) are dead here: its scratch.
+    const bool img_scratch = LEAN && 3 * (size_t)w >= 4 * NSTR + 4 * RP_DESC * 64 + 16;
+    // A row whose per-pixel segment lists overflowed (dozens of layers over every pixel: depth noise) was not evaluated at all --
+    // but its sorted order exists, and that is all the replay needs: the row is ONE stretch from column 0 (empty list, nothing
+    // added yet), exported like the others when the pool has the room (6 B per pixel).
+    const bool whole_row = overflow && img_scratch && X && X->dump && dbg != 28;
+    if (((!overflow && *flag_hazard) || whole_row) && w <= 8192 && dbg != 26 && dbg != 27 &&
+        (img_scratch || tail0 + 2 * NSTR + 128 * nwaves + 8 <= P.cap)) {
+        uint32_t* slist = img_scratch ? (uint32_t*)L.img : (uint32_t*)(P.entries + tail0);   // start | end << 16 (pixel columns)
+        uint16_t* wscr = img_scratch ? nullptr : P.entries + tail0 + 2 * NSTR;
+        if (tid == 0 && whole_row) { slist[0] = (uint32_t)(w - 1) << 16; *nstretch = 1; *stretch_bad = 0; }
+        if (tid == 0 && !whole_row) {
             const unsigned long long* hzw = (const unsigned long long*)P.longs;
             const unsigned long long* rsw = hzw + ((w + 63) >> 6);
             int count = 0, last_reset = -1, start = 0, end = 0;
@@ -1159,11 +1225,11 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         // flight) instead of being replayed here by 1-3 of this workgroup's 16 waves while the row's LDS stays allocated
         constexpr int RP_NSTR = 64;   // stretches per row the export handles (usually 1-3)
         if (nstr > 0 && nstr <= RP_NSTR && X && X->dump && dbg != 28 &&
-            tail0 + 2 * NSTR + 128 * nwaves + 2 * RP_DESC * RP_NSTR + 8 <= P.cap) {
+            (img_scratch || tail0 + 2 * NSTR + 128 * nwaves + 2 * RP_DESC * RP_NSTR + 8 <= P.cap)) {
             int* rp_ok = L.misc + 5;
             int* rp_slot = L.misc + 6;
-            int* rp_base = L.misc + 7;
-            uint32_t* sinfo = (uint32_t*)(wscr + 128 * nwaves);   // [RP_NSTR][RP_DESC]: the descriptor of a stretch, words 1..7
+            int* rp_base = L.misc + 7;   // first descriptor in the small list
+            uint32_t* sinfo = img_scratch ? (uint32_t*)(L.img + 4 * NSTR) : (uint32_t*)(wscr + 128 * nwaves);   // [RP_NSTR][RP_DESC]: the descriptor of a stretch
             if (tid == 0) *rp_ok = 1;
             __syncthreads();
             for (int si = wave; si < nstr; si += nwaves) {
@@ -1193,7 +1259,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                 for (int d = 1; d < 64; d <<= 1) { cmin = min(cmin, __shfl_xor(cmin, d)); cmax = max(cmax, __shfl_xor(cmax, d)); }
                 if (seg0 >= 0) { cmin = min(cmin, poly_col(P, seg0)); cmax = max(cmax, poly_col(P, seg0 + 1)); }
                 if (lane == 0) {
-                    const bool good = (c0 == 0 || seg0 >= 0) && pw1 - pw0 + 1 <= RP_PW && cmax - cmin + 1 <= RP_CW;
+                    const bool good = c0 == 0 || seg0 >= 0;   // (always: the pixel before was marked because one segment is active)
                     if (!good) *rp_ok = 0;
                     uint32_t* q = sinfo + RP_DESC * si;
                     q[1] = slist[si]; q[2] = (uint32_t)seg0; q[3] = (uint32_t)sgp0; q[4] = (uint32_t)pw0 | ((uint32_t)pw1 << 16);
@@ -1209,23 +1275,16 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                     q[0] = total16;
                     total16 += rp_win16((int)(q[4] >> 16) - (int)(q[4] & 0xffffu) + 1, (int)(q[5] >> 16) - (int)(q[5] & 0xffffu) + 1);
                 }
-                // (compare-and-swap, not a blind add: a pool that is full stays exactly full, the counter cannot wrap)
-                uint32_t at16 = __hip_atomic_load(&X->ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bool room = false;
-                for (;;) {
-                    if (at16 > X->pool16 || total16 > X->pool16 - at16) break;
-                    const uint32_t seen = atomicCAS(&X->ctr[0], at16, at16 + total16);
-                    if (seen == at16) { room = true; break; }
-                    at16 = seen;
-                }
-                if (room) {
-                    const uint32_t base = atomicAdd(&X->ctr[1], (uint32_t)nstr);
-                    *rp_slot = (int)at16; *rp_base = (int)base;
-                    if (base + (uint32_t)nstr > X->cap) {
-                        room = false;   // descriptor list full; the reserved descriptors (those inside the list) say "skip"
-                        for (uint32_t i = base; i < base + (uint32_t)nstr && i < X->cap; i++) X->list[(size_t)i * RP_DESC] = 0xffffffffu;
-                    }
-                }
+                // Two independent atomic adds, back to back (their round trips to L2 overlap; a compare-and-swap loop starves
+                // here -- a few hundred workgroups reserve at once and most attempts fail: 650 -> 490 frames/s on saturated
+                // depth).  The pool counter is 64 bits wide (words 4-5 of the counter block): a full pool cannot make it wrap.
+                const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(X->ctr + 4), (unsigned long long)total16);
+                const uint32_t base = atomicAdd(&X->ctr[1], (uint32_t)nstr);
+                const uint32_t at16 = (uint32_t)at;
+                *rp_slot = (int)at16; *rp_base = (int)base;
+                const bool room = at + total16 <= (unsigned long long)X->pool16 && base + (uint32_t)nstr <= X->cap;
+                if (!room)   // replay here; the reserved descriptors (those inside the list) say "skip"
+                    for (uint32_t i = base; i < base + (uint32_t)nstr && i < X->cap; i++) X->list[(size_t)i * RP_DESC] = 0xffffffffu;
                 if (!room) *rp_ok = 0;   // replay here
                 if (!room && dbg == 14 && stats_rw) atomicAdd(&stats_rw[14], 1u);   // (diagnostics: rows that found the pool full)
             }
@@ -1249,6 +1308,10 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                 return;
             }
         }
+        if (LEAN) {   // (not exported: the full kernel's business)
+            if (tid == 0) X->retry[X->rowid] = 1;
+            return;
+        }
         if (nstr > 0) {
             bool bad = false;
             for (int si = wave; si < nstr && !bad; si += nwaves) {
@@ -1267,7 +1330,9 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                     while (sgp0 > 0 && !(poly_x(P, P.perm[sgp0 - 1]) < s.center)) sgp0--;
                     if (seg0 < 0) bad = true;   // (cannot happen: the pixel was marked because exactly one segment is active there)
                 }
-                if (!bad && poly_replay_stretch(P, L, E.csg_cap, emit, c0, c1, seg0, sgp0, wscr + 128 * wave, (int)P.binoff[c0])) bad = true;
+                NoSlide whole;   // (the row is resident)
+                Poly Pm = P; Lds Lm = L;
+                if (!bad && poly_replay_stretch(Pm, Lm, E.csg_cap, emit, c0, c1, seg0, sgp0, wscr + 128 * wave, (int)P.binoff[c0], whole, 0)) bad = true;
             }
             if (bad && lane == 0) *stretch_bad = 1;
         }
@@ -1280,6 +1345,10 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
             if (stats_rw && tid == 0) atomicAdd(&stats_rw[ST_FALLBACK_ROWS], 1u);
             return;
         }
+    }
+    if (LEAN) {
+        if ((overflow || *flag_hazard) && tid == 0) X->retry[X->rowid] = 1;
+        return;
     }
     if (overflow || *flag_hazard) {
         // order-dependent row: replay the reference sweep literally -- by the first wave (its 64 lanes share the list work
@@ -1415,11 +1484,11 @@ __global__ void __launch_bounds__(1024) k_hybrid_splat(RowArgs A) {
             double wg;
             if (destx64) {
                 const double diff = destx64[x] - (double)j;
-                wg = csm::exp_exact(-(diff * diff) / 2.0, etab);
+                wg = csm::exp_exact_small(-(diff * diff) / 2.0, etab);
             } else {
                 float diff = destx[x] - (float)j;
                 float arg = -(diff * diff) / 2.0f;
-                wg = csm::exp_exact((double)arg, etab);
+                wg = csm::exp_exact_small((double)arg, etab);
             }
             acc0 = (float)((double)acc0 + (double)L.img[3 * x + 0] * wg);
             acc1 = (float)((double)acc1 + (double)L.img[3 * x + 1] * wg);
@@ -1578,23 +1647,55 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
         int b_ = -1;
         if (fl >= (float)(o0 - 1) && fl <= (float)(o0 + wt)) b_ = (int)fl - (o0 - 1);   // j_c in [o0 - 1, o0 + wt] can touch a tile column
         bin[j] = (short)b_;
-        if (b_ >= 0) atomic_add_u16(binoff, b_ + 1, 1);
     }
     __syncthreads();
-    block_scan_inclusive(binoff, nbin + 1, 0, OpAdd(), scan_ws);
-    for (int j = tid; j < ns; j += HYT_NT) {
-        const int b_ = bin[j];
-        if (b_ >= 0) scratch[atomic_add_u16(binoff, b_, 1)] = (uint16_t)j;
+    // ---- sources grouped by destination column.  Where the staged polyline runs FORWARD -- floor(dest_x) does not decrease
+    // from one source to the next: every tile except those on an occlusion fold -- the order by (column, source) IS the source
+    // order, and all that is needed is where each column's sources start: every source writes its index into the columns
+    // between its predecessor's and its own (round 4; no histogram, prefix sum, scatter and in-bin ranking: five barriers and
+    // four passes over LDS less).  Fold tiles take the counting sort as before.
+    bool fwd = true;
+#pragma unroll
+    for (int k = 0; k < HYT_SLOTS; k++) {
+        const int j = tid + k * HYT_NT;
+        if (j + 1 < ns) fwd = fwd && floorf(destx[j]) <= floorf(destx[j + 1]);
     }
-    __syncthreads();
-    const int total = binoff[nbin - 1];
-    for (int k = tid; k < total; k += HYT_NT) {
-        const int j = scratch[k];
-        const int b_ = bin[j];
-        const int bs = b_ > 0 ? binoff[b_ - 1] : 0, be = binoff[b_];
-        int r = 0;
-        for (int t = bs; t < be; t++) r += scratch[t] < j ? 1 : 0;
-        sorted[bs + r] = (uint16_t)j;
+    const bool mono = __syncthreads_and(fwd) != 0 && A.dbg != 29;   // (dbg 29, development: always the counting sort)
+    if (mono) {
+        // binoff[b] = the first source whose column bin (unclipped: floor(dest_x) - (o0 - 1)) is >= b, for b = 0 .. nbin
+        const float base = (float)(o0 - 1);
+#pragma unroll
+        for (int k = 0; k < HYT_SLOTS; k++) {
+            const int j = tid + k * HYT_NT;
+            if (j >= ns) break;
+            const float ub = floorf(destx[j]) - base;
+            const float pb = j > 0 ? floorf(destx[j - 1]) - base : -1.0f;
+            const int lo = pb < -1.0f ? 0 : (pb >= (float)nbin ? nbin + 1 : (int)pb + 1);
+            const int hi = ub < 0.0f ? -1 : (ub >= (float)nbin ? nbin : (int)ub);
+            for (int b = lo; b <= hi; b++) binoff[b] = (uint16_t)j;
+            if (j == ns - 1) for (int b = max(hi + 1, 0); b <= nbin; b++) binoff[b] = (uint16_t)ns;
+        }
+    } else {
+        for (int j = tid; j < ns; j += HYT_NT) {
+            const int b_ = bin[j];
+            if (b_ >= 0) atomic_add_u16(binoff, b_ + 1, 1);
+        }
+        __syncthreads();
+        block_scan_inclusive(binoff, nbin + 1, 0, OpAdd(), scan_ws);
+        for (int j = tid; j < ns; j += HYT_NT) {
+            const int b_ = bin[j];
+            if (b_ >= 0) scratch[atomic_add_u16(binoff, b_, 1)] = (uint16_t)j;
+        }
+        __syncthreads();
+        const int total = binoff[nbin - 1];
+        for (int k = tid; k < total; k += HYT_NT) {
+            const int j = scratch[k];
+            const int b_ = bin[j];
+            const int bs = b_ > 0 ? binoff[b_ - 1] : 0, be = binoff[b_];
+            int r = 0;
+            for (int t = bs; t < be; t++) r += scratch[t] < j ? 1 : 0;
+            sorted[bs + r] = (uint16_t)j;
+        }
     }
     __syncthreads();
     uint8_t* base = A.hyb_base + ((((size_t)frame * A.neyes + eyei) * h + row) * w) * 3;
@@ -1607,15 +1708,16 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
         // exps as its longest lane for every lane; the three weights of every SOURCE computed in the staging loop and read
         // here from an 18 KB float64 LDS array: 3.6 -> 4.4 ms -- fewer workgroups per CU and the 8-byte LDS traffic cost
         // more than the divergence)
-        int p0 = q > 0 ? binoff[q - 1] : 0, e0 = binoff[q];
-        int p1 = e0, e1 = binoff[q + 1];
-        int p2 = e1, e2 = binoff[q + 2];
+        // (forward tiles: binoff[b] = START of bin b and the sources are their own sorted order; fold tiles: binoff[b] = END of bin b)
+        int p0 = mono ? binoff[q] : (q > 0 ? binoff[q - 1] : 0), e0 = mono ? binoff[q + 1] : binoff[q];
+        int p1 = e0, e1 = mono ? binoff[q + 2] : binoff[q + 1];
+        int p2 = e1, e2 = mono ? binoff[q + 3] : binoff[q + 2];
         float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, ws = 0.0f;
         bool touched = false;
         auto contribute = [&](int j) {
             const float diff = destx[j] - (float)jcol;
             const float arg = -(diff * diff) / 2.0f;
-            const double wg = csm::exp_exact((double)arg, etab);
+            const double wg = csm::exp_exact_small((double)arg, etab);   // (-8 < arg <= 0: no range test, cs_math.h)
             const uint32_t c = img[j];
             acc0 = (float)((double)acc0 + (double)(c & 0xffu) * wg);
             acc1 = (float)((double)acc1 + (double)((c >> 8) & 0xffu) * wg);
@@ -1626,8 +1728,11 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
         // The three bins are adjacent in `sorted`.  Where the polyline runs forward the sources of bin q all precede those of
         // bin q + 1 and those precede bin q + 2: the merged source order IS the concatenation sorted[p0 .. e2) -- checked at
         // the two junctions; a wave whose lanes all pass (everywhere but at occlusion folds) skips the 3-way merge.
-        const bool ordered = !(p0 < e0 && e0 < e2 && sorted[e0 - 1] > sorted[e0]) && !(p0 < e1 && e1 < e2 && sorted[e1 - 1] > sorted[e1]);
-        if (__all(ordered || q >= wt)) {
+        const bool ordered = mono || (!(p0 < e0 && e0 < e2 && sorted[e0 - 1] > sorted[e0]) && !(p0 < e1 && e1 < e2 && sorted[e1 - 1] > sorted[e1]));
+        if (mono) {
+            for (int p = p0; __any(p < e2); p++)
+                if (p < e2) contribute(p);
+        } else if (__all(ordered || q >= wt)) {
             for (int p = p0; __any(p < e2); p++)
                 if (p < e2) contribute(sorted[p]);
         } else {
@@ -1708,7 +1813,7 @@ __device__ void technique_hybrid_fill(const Lds& L, const RowArgs& A, int frame,
                 // i.e. of csm::exp_exact (tests/test_cs_math_host.py compares) -- no need to evaluate them per neighbour
                 const double w_s = dsq == 1 ? CS_EXP_M05 : CS_EXP_M10;
                     double diff = g0 - hyb_guidance(A, frame, ni, nj);
-                    double w_r = csm::exp_exact(-(diff * diff) / 200.0, etab);
+                    double w_r = csm::exp_exact_small(-(diff * diff) / 200.0, etab);
                     double wg = w_s * w_r;
                     float wg32 = (float)wg;
                     const uint8_t* nb = base + ((size_t)ni * w + nj) * 3;
@@ -1790,7 +1895,7 @@ __global__ void __launch_bounds__(256) k_hybrid_fill(RowArgs A) {
             // of csm::exp_exact (tests/test_cs_math_host.py compares) -- no need to evaluate them per neighbour
             const double w_s = (k & 1) ? CS_EXP_M05 : CS_EXP_M10;
             const double diff = hyb_guidance(A, frame, row, jo) - hyb_guidance(A, frame, ni, nj);
-            wgs[p] = w_s * csm::exp_exact(-(diff * diff) / 200.0, etab);
+            wgs[p] = w_s * csm::exp_exact_small(-(diff * diff) / 200.0, etab);
         }
         __syncthreads();
         if (t) {
@@ -2007,7 +2112,7 @@ __global__ void __launch_bounds__(64) k_hybrid_gaps(RowArgs A, const uint32_t* _
                 if (k == 4 || (pkv[k] >> 24) == 0u) continue;
                 const double w_s = (k & 1) ? CS_EXP_M05 : CS_EXP_M10;
                 const double diff = gc - guid(gv[k]);
-                const double wg = w_s * csm::exp_exact(-(diff * diff) / 200.0, d_hyb_exp_tab);
+                const double wg = w_s * csm::exp_exact_small(-(diff * diff) / 200.0, d_hyb_exp_tab);
                 const float wg32 = (float)wg;
                 n0 = n0 + (float)(pkv[k] & 0xffu) * wg32;
                 n1 = n1 + (float)((pkv[k] >> 8) & 0xffu) * wg32;
@@ -2029,7 +2134,7 @@ __global__ void __launch_bounds__(64) k_hybrid_gaps(RowArgs A, const uint32_t* _
             // math.exp(-dsq / 2) for dsq = 1, 2: the two values of glibc's exp (see k_hybrid_fill)
             const double w_s = (k & 1) ? CS_EXP_M05 : CS_EXP_M10;
             const double diff = gc - hyb_guidance(A, frame, ni, nj);
-            const double wg = w_s * csm::exp_exact(-(diff * diff) / 200.0, d_hyb_exp_tab);
+            const double wg = w_s * csm::exp_exact_small(-(diff * diff) / 200.0, d_hyb_exp_tab);
             const float wg32 = (float)wg;
             if (!PACKED) {
                 const uint8_t* nb = base + ((size_t)ni * w + nj) * 3;
@@ -2095,7 +2200,7 @@ struct RowOut {
     }
 };
 
-template <int FILL, bool DIALECT>
+template <int FILL, bool DIALECT, bool LEAN = false>
 __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, const int frame, char* smem) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int w = A.w, h = A.h;
@@ -2114,6 +2219,7 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
     }
     // source row -> uint8 RGB (np.clip(x*255, 0, 255).astype(uint8), reference :1508)
     const size_t rowpix = ((size_t)frame * h + row) * w;
+    auto stage_image = [&]() {
     if (A.image_f32) {
         const float* src = A.image_f32 + rowpix * 3;
         if ((w & 3) == 0) {
@@ -2142,9 +2248,13 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
         for (int i = tid; i < 3 * w; i += nt) L.img[i] = src[i];
     }
     __syncthreads();
+    };
+    stage_image();
 
     const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
     for (int e = 0; e < A.neyes; e++) {
+        // (the lean polylines kernel uses the colour row as the scratch of its export phase: staged again for the second eye)
+        if (LEAN && e > 0) { __syncthreads(); stage_image(); }   // (barrier: the first eye's export may still be reading its scratch)
         // (field-by-field selects: a dynamically indexed -- or aggregate-selected -- kernel-argument array makes the compiler copy
         // the whole argument struct to scratch memory)
         EyeArgs E;
@@ -2191,8 +2301,8 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
             else if (FILL == CS_FILL_POLYLINES_SOFT || FILL == CS_FILL_POLYLINES_SHARP) {
                 // (eyes in separate output slots: the stretches of order-dependent rows may go to the replay kernel)
                 const RpCtx X{A.anaglyph ? nullptr : A.rp_dump, A.rp_list, A.rp_ctr, A.rp_pool16, A.rp_cap,
-                              (uint32_t)frame * (uint32_t)A.h + (uint32_t)row, e};
-                technique_polylines<FILL == CS_FILL_POLYLINES_SHARP ? 1 : 0, DIALECT>(L, w, E, A.e32, st_rw, out, A.dbg, &X, A.d64, A.e64);
+                              (uint32_t)frame * (uint32_t)A.h + (uint32_t)row, e, A.rp_ctr ? (uint8_t*)A.rp_ctr + 256 : nullptr};
+                technique_polylines<FILL == CS_FILL_POLYLINES_SHARP ? 1 : 0, DIALECT, decltype(out), LEAN>(L, w, E, A.e32, st_rw, out, A.dbg, &X, A.d64, A.e64);
             }
             else if (FILL == CS_FILL_HYBRID_EDGE_PLUS) {
                 // hybrid_edge into `res`, then the polylines_soft row into `alt`; pixels that stayed black take the latter
@@ -2271,8 +2381,8 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
 
 // One workgroup per row (both eyes); or, behind the tiled polylines path, a fixed number of workgroups working off the
 // list of rows that path flagged (`row_list`: frame * h + row) -- usually empty, so nothing the size of the batch is launched.
-template <int FILL, bool DIALECT = false>
-__global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
+template <int FILL, bool DIALECT = false, bool LEAN = false>
+__global__ void __launch_bounds__(1024, LEAN ? 8 : 4) k_rowwarp(RowArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ONE call site of the (force-inlined) row function: as a real call it takes the argument struct by reference, i.e. a
     // 340-byte scratch copy per lane and scratch set-up at every wave launch (28 -> 210 us for the usual EMPTY flagged-row pass)
@@ -2291,7 +2401,7 @@ __global__ void __launch_bounds__(1024) k_rowwarp(RowArgs A) {
             const uint32_t e = A.row_list[i];
             row = (int)(e % (uint32_t)A.h); frame = (int)(e / (uint32_t)A.h);
         } else if (it) break;
-        rowwarp_row<FILL, DIALECT>(A, row, frame, smem);
+        rowwarp_row<FILL, DIALECT, LEAN>(A, row, frame, smem);
         __syncthreads();  // the row's LDS (and s_next) is reused by the next one
     }
 }
@@ -2327,11 +2437,62 @@ struct ReplayOut {   // RowOut's destination arithmetic without the anaglyph sta
     }
 };
 
-template <int SHARP>
-__global__ void __launch_bounds__(64) k_poly_replay(RowArgs A, uint8_t* __restrict__ retry) {
-    __shared__ uint16_t permw[RP_PW];
-    __shared__ float cdw[RP_CW];
-    __shared__ uint8_t imgw[3 * RP_CW];
+// The windows a replay wave holds in LDS SLIDE along the stretch (round 4): PWS sorted positions and CWS source columns around the
+// sweep position, refilled from the stretch's dump (global memory: perm[pw0 .. pw1], coord_d[cmin .. cmax]; the colours from the
+// image) whenever poly_replay_stretch asks for a range they do not hold.  4.3 KB per wave instead of 7 (or 44 for a stretch that
+// spans a row): 32 waves per CU whatever the stretch length -- a row without reset points (noise depth) is one stretch, and a
+// wave, like any other.
+template <int PWS, int CWS>
+struct DumpSlide {
+    static constexpr bool active = true;
+    const uint16_t* gperm; int pw0, pw1;     // gperm[i] = perm[pw0 + i]
+    const float* gcd; int cmin, cmax;        // gcd[c] = coord_d[cmin + c]
+    const RowArgs* A; int frame, row;
+    uint16_t* permw; float* cdw; uint8_t* imgw;
+    int pb, cb;                              // first sorted position / source column in LDS (very negative: nothing loaded yet)
+    // (the caller re-bases its own pointers after every call: a Poly* in here would keep the row descriptor in memory)
+    __device__ __forceinline__ void rebase_points(Poly& P) const { P.perm = permw - pb; }
+    __device__ __forceinline__ void rebase_columns(Poly& P, Lds& L) const { P.cd = cdw - cb; L.img = imgw - 3 * cb; }
+    __device__ __forceinline__ bool points(int lo, int hi) {   // positions [lo, hi)
+        if (lo >= pb && hi <= pb + PWS) return true;
+        if (hi - lo > PWS) return false;
+        const int lane = threadIdx.x & 63;
+        wave_lds_sync();
+        pb = max(lo - 8, pw0 - 8);            // (a little slack below: the sweep steps back by one point per pixel)
+        for (int i = lane; i < PWS; i += 64) permw[i] = gperm[min(max(pb + i, pw0), pw1) - pw0];
+        wave_lds_sync();
+        return true;
+    }
+    __device__ __forceinline__ bool holds(int lo, int hi) const {   // (per lane: are the columns [lo, hi] in LDS?)
+        return max(lo, cmin) >= cb && min(hi, cmax) < cb + CWS;
+    }
+    __device__ __forceinline__ bool columns(int lo, int hi) {   // columns [lo, hi], clipped to the stretch's window
+        lo = max(lo, cmin); hi = min(hi, cmax);
+        if (lo >= cb && hi < cb + CWS) return true;
+        if (hi - lo + 1 > CWS) return false;
+        const int lane = threadIdx.x & 63;
+        wave_lds_sync();
+        cb = lo;
+        for (int i = lane; i < CWS; i += 64) {
+            const int c = min(cb + i, cmax);
+            cdw[i] = gcd[c - cmin];
+            imgw[3 * i] = src_u8(*A, frame, row, c, 0);
+            imgw[3 * i + 1] = src_u8(*A, frame, row, c, 1);
+            imgw[3 * i + 2] = src_u8(*A, frame, row, c, 2);
+        }
+        wave_lds_sync();
+        return true;
+    }
+};
+
+template <int SHARP, int PWS, int CWS>
+#ifndef RP_MINW
+#define RP_MINW 5   // waves per SIMD the register budget is sized for (96 VGPRs, 4 spilled; 4: 108 VGPRs -3 %, 6: -2 %, 8: -33 %)
+#endif
+__global__ void __launch_bounds__(64, RP_MINW) k_poly_replay(RowArgs A, uint8_t* __restrict__ retry, int halo) {
+    __shared__ uint16_t permw[PWS];
+    __shared__ float cdw[CWS];
+    __shared__ uint8_t imgw[3 * CWS];
     __shared__ uint16_t srcpos[128];
     const int lane = threadIdx.x;
     const uint32_t count = min(A.rp_ctr[1], A.rp_cap);
@@ -2351,28 +2512,30 @@ __global__ void __launch_bounds__(64) k_poly_replay(RowArgs A, uint8_t* __restri
         const int eye = (int)(q[6] >> 31), pt0 = (int)q[7];
         const int frame = (int)(rowid / (uint32_t)h), row = (int)(rowid - (uint32_t)frame * (uint32_t)h);
         const uint8_t* d = A.rp_dump + ((size_t)slot << 4);   // this stretch's windows (export in technique_polylines)
-        const uint16_t* dperm = (const uint16_t*)d;
-        const float* dcd = (const float*)(d + align16(2 * (size_t)(pw1 - pw0 + 1)));
-        for (int i = lane; i <= pw1 - pw0; i += 64) permw[i] = dperm[i];
-        for (int c = lane; c <= cmax - cmin; c += 64) {
-            cdw[c] = dcd[c];
-            imgw[3 * c] = src_u8(A, frame, row, cmin + c, 0);
-            imgw[3 * c + 1] = src_u8(A, frame, row, cmin + c, 1);
-            imgw[3 * c + 2] = src_u8(A, frame, row, cmin + c, 2);
-        }
-        wave_lds_sync();
-        // the windows, addressed like the whole arrays (every index the replay touches lies inside: cs_rowwarp.hip export)
         Poly P;
         P.w = w; P.sharp = SHARP; P.npt = poly_npt(w, SHARP); P.cap = poly_cap(w, SHARP);
         P.sep32 = eye ? A.eye[1].sep32 : A.eye[0].sep32;
-        P.perm = permw - pw0; P.binoff = nullptr; P.segoff = nullptr; P.entries = nullptr; P.longs = nullptr;
-        P.cd = cdw - cmin; P.xd = nullptr;   // (dialect D32 only: run_rows does not attach the replay kernel otherwise)
+        P.perm = nullptr; P.binoff = nullptr; P.segoff = nullptr; P.entries = nullptr; P.longs = nullptr;
+        P.cd = nullptr; P.xd = nullptr;   // (dialect D32 only: run_rows does not attach the replay kernel otherwise)
         Lds L;
         L.lut = nullptr; L.tabs = nullptr; L.misc = nullptr; L.res = nullptr; L.ana = nullptr; L.nd = nullptr; L.tech = nullptr;
-        L.img = imgw - 3 * cmin;
+        L.img = nullptr;
+        DumpSlide<PWS, CWS> slide{(const uint16_t*)d, pw0, pw1, (const float*)(d + align16(2 * (size_t)(pw1 - pw0 + 1))), cmin, cmax,
+                                  &A, frame, row, permw, cdw, imgw, -0x40000000, -0x40000000};
         const ReplayOut out{A.out_u8, A.stereo, A.mask, h, A.out_h, A.out_w, eye ? A.eye[1].xoff : A.eye[0].xoff,
                             eye ? A.eye[1].yoff : A.eye[0].yoff, A.stereo_is_u8, frame, row, w};
-        const int rc = poly_replay_stretch(P, L, eye ? A.eye[1].csg_cap : A.eye[0].csg_cap, out, c0, c1, seg0, sgp0, srcpos, pt0);
+        int rc;
+        if (pw1 - pw0 + 1 <= PWS - 8 && cmax - cmin + 1 <= CWS) {   // (8: the slack points() keeps below its first position)
+            // the usual stretch: its windows fit at once -- loaded whole, replayed without the sliding checks (-10 % on saturated
+            // depth against sliding everything; wave-uniform branch, the replay code exists twice)
+            (void)slide.points(pw0, pw1 + 1);
+            (void)slide.columns(cmin, cmax);
+            slide.rebase_points(P);
+            slide.rebase_columns(P, L);
+            NoSlide whole;
+            rc = poly_replay_stretch(P, L, eye ? A.eye[1].csg_cap : A.eye[0].csg_cap, out, c0, c1, seg0, sgp0, srcpos, pt0, whole, 0);
+        } else
+            rc = poly_replay_stretch(P, L, eye ? A.eye[1].csg_cap : A.eye[0].csg_cap, out, c0, c1, seg0, sgp0, srcpos, pt0, slide, halo);
         if (rc && lane == 0) retry[rowid] = 1;
         if (A.dbg == 14 && A.stats_rw && lane == 0)   // diagnostics: stretches replayed / given up (list > 64) / given up (window drift)
             atomicAdd(&A.stats_rw[(size_t)frame * ST_WORDS + (rc == 0 ? 12 : (rc == -1 ? 13 : 15))], 1u);
@@ -2383,8 +2546,8 @@ __global__ void __launch_bounds__(64) k_poly_replay(RowArgs A, uint8_t* __restri
 // the dump pool: 4 KB per image row (the windows of a stretch average ~2 KB, an order-dependent eye row holds 1.3 stretches), never
 // more than one maximal window set per stretch slot; a row that finds the pool (or the descriptor list) full replays inline
 static size_t rp_pool_bytes(size_t rows) {
-    // (development: CS_DEBUG_PT_VARIANT 31 quadruples the budget -- does a workload run out of pool?)
-    const size_t per_row = dev_switch(CS_DEBUG_PT_VARIANT) == 31 ? 16384 : 4096;
+    // (development: CS_DEBUG_PT_VARIANT 41 quadruples the budget -- does a workload run out of pool?)
+    const size_t per_row = dev_switch(CS_DEBUG_PT_VARIANT) == 41 ? 16384 : 4096;
     const size_t worst = rows * 4 * ((size_t)rp_win16(RP_PW, RP_CW) << 4), budget = rows * per_row + (64u << 10);
     return (worst < budget ? worst : budget) & ~(size_t)15;
 }
@@ -2396,22 +2559,28 @@ size_t poly_replay_bytes(int n, int h, int w, int sharp) {
 }
 // scratch: [descriptor list][dump pool]; `ctr_retry`: [counters 256 B][retry flags, one byte per row], zeroed by the caller
 // (it lies in the flagged-row block that run_rows clears with one memset)
-hipError_t poly_replay_attach(RowArgs& A, int sharp, void* scratch, void* ctr_retry, hipStream_t stream) {
+hipError_t poly_replay_attach(RowArgs& A, int sharp, void* scratch, void* ctr_retry, hipStream_t stream, size_t surplus) {
     const size_t rows = (size_t)A.n * A.h;
     char* b = (char*)scratch;
     A.rp_ctr = (uint32_t*)ctr_retry;
     A.rp_list = (uint32_t*)b;
     A.rp_dump = (uint8_t*)(b + al256r(rows * 4 * RP_DESC * 4));
-    const size_t pool16 = rp_pool_bytes(rows) >> 4;
+    const size_t pool16 = (rp_pool_bytes(rows) + surplus) >> 4;   // (surplus: workspace the caller gave beyond cs_workspace_bytes)
     A.rp_pool16 = (uint32_t)(pool16 < 0xffffffffu ? pool16 : 0xffffffffu); A.rp_cap = (uint32_t)(rows * 4);
     (void)stream; (void)sharp;
     return hipSuccess;
 }
 uint8_t* poly_replay_retry_flags(const RowArgs& A) { return (uint8_t*)A.rp_ctr + 256; }
-hipError_t launch_poly_replay(int sharp, const RowArgs& A, hipStream_t stream) {
-    const dim3 grid(256 * 22), block(64);
-    if (sharp) hipLaunchKernelGGL(k_poly_replay<1>, grid, block, 0, stream, A, poly_replay_retry_flags(A));
-    else hipLaunchKernelGGL(k_poly_replay<0>, grid, block, 0, stream, A, poly_replay_retry_flags(A));
+hipError_t launch_poly_replay(int sharp, const RowArgs& A, int halo, hipStream_t stream) {
+    // the column window holds the columns of the 64 sorted points around the sweep (their span: 64 + 2 halo) and of the active
+    // segments (2 halo + 1): 1024 columns up to a halo of 230, 4096 beyond (a stretch that outgrows them goes to the retry pass)
+    const bool wide = 4 * (halo + 2) + 80 > RP_CWS;
+    const dim3 grid(256 * (wide ? 5 : 19)), block(64);   // (resident waves per CU: 29 KB / 8.3 KB of LDS each)
+    uint8_t* retry = poly_replay_retry_flags(A);
+    if (sharp && wide) hipLaunchKernelGGL((k_poly_replay<1, RP_PWS, RP_CWS_WIDE>), grid, block, 0, stream, A, retry, halo + 2);
+    else if (sharp) hipLaunchKernelGGL((k_poly_replay<1, RP_PWS, RP_CWS>), grid, block, 0, stream, A, retry, halo + 2);
+    else if (wide) hipLaunchKernelGGL((k_poly_replay<0, RP_PWS, RP_CWS_WIDE>), grid, block, 0, stream, A, retry, halo + 2);
+    else hipLaunchKernelGGL((k_poly_replay<0, RP_PWS, RP_CWS>), grid, block, 0, stream, A, retry, halo + 2);
     return hipGetLastError();
 }
 
@@ -2427,7 +2596,7 @@ hipError_t launch_collect_rows(const uint8_t* flag, int total, uint32_t* count, 
 }
 
 // host-side launcher (called from cs_abi.hip)
-hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream, int max_groups) {
+hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream, int max_groups, int lean) {
     size_t lds = lds_common_bytes(fill, A.w, A.anaglyph) + lds_tech_bytes(fill, A.w);
     if ((A.d64 & 1) && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP)) lds += align16(8 * (size_t)A.w);   // Poly::xd
     if (lds > CS_LDS_BYTES) return hipErrorInvalidValue;
@@ -2451,6 +2620,17 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
         if (e != hipSuccess) return e;                                                                            \
         hipLaunchKernelGGL(k_rowwarp<F>, grid, block, lds, stream, A);                                            \
         break;                                                                                                    \
+    }
+    // (only where two rows then share a CU: at 4K polylines_sharp's row takes 88 KB of LDS -- one per CU whatever the registers)
+    if (lean && !(A.d64 & 3) && A.rp_dump && 2 * lds <= CS_LDS_BYTES && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP)) {
+        // first pass with the replay kernel attached: the instantiation without the in-row replay (64 registers, two rows per CU)
+        hipError_t e = fill == CS_FILL_POLYLINES_SOFT
+            ? hipFuncSetAttribute((const void*)k_rowwarp<CS_FILL_POLYLINES_SOFT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+            : hipFuncSetAttribute((const void*)k_rowwarp<CS_FILL_POLYLINES_SHARP, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (fill == CS_FILL_POLYLINES_SOFT) hipLaunchKernelGGL((k_rowwarp<CS_FILL_POLYLINES_SOFT, false, true>), grid, block, lds, stream, A);
+        else hipLaunchKernelGGL((k_rowwarp<CS_FILL_POLYLINES_SHARP, false, true>), grid, block, lds, stream, A);
+        return hipGetLastError();
     }
     if ((A.d64 & 3) && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP)) {   // the dialect instantiations
         hipError_t e = fill == CS_FILL_POLYLINES_SOFT

@@ -66,9 +66,12 @@ def output_shape(p):
 class Plan:
     """Pre-allocated outputs + workspace for repeated calls of one configuration (what bench.py times)."""
 
-    def __init__(self, p, device, stereo_u8=False):
+    def __init__(self, p, device, stereo_u8=False, tie_pool_bytes=0):
         """stereo_u8: the stereoscope is produced as its uint8 codes k (value k/255, CPU techniques only) --
-        the compact form frame shards are all-gathered in; expand with `expand_u8`."""
+        the compact form frame shards are all-gathered in; expand with `expand_u8`.
+        tie_pool_bytes: workspace beyond cs_workspace_bytes; the polylines techniques add it to the pool their order-dependent
+        rows export their stretches through (4 KB per image row by default: enough for saturated depth maps; a batch whose
+        every row is ONE stretch -- depth noise, blur off -- needs 6 B per pixel and eye to keep all rows off the in-row replay)."""
         L = _native.lib()
         self.p = p
         if stereo_u8:
@@ -79,7 +82,7 @@ class Plan:
         self.depth_l = torch.empty((p.n, p.h, p.w, 3), **f32)
         self.depth_r = torch.empty((p.n, p.h, p.w, 3), **f32)
         self.mask = torch.empty((p.n, mh, mw), **f32)
-        self.ws_bytes = L.cs_workspace_bytes(ctypes.byref(p))
+        self.ws_bytes = L.cs_workspace_bytes(ctypes.byref(p)) + int(tie_pool_bytes)
         self.ws = torch.empty((max(self.ws_bytes, 256),), dtype=torch.uint8, device=device)
 
     def run(self, image, depth):

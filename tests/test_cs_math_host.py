@@ -26,6 +26,14 @@ int main() {
     for (uint32_t u = 0; u <= 0x40a00000u; u += 257) {
         float d = csm::u2f(u); float a = -(d * d) / 2.0f;
         if (csm::d2u(exp((double)a)) != csm::d2u(csm::exp_exact((double)a, cs_exp_tab))) bad++;
+        // the branch-free form the hybrid_edge kernels use for their Gaussian weights (0, denormal and tiny arguments included)
+        if (csm::d2u(exp((double)a)) != csm::d2u(csm::exp_exact_small((double)a, cs_exp_tab))) bad++;
+        n++;
+    }
+    for (int i = 0; i < 400000; i++) {   // (-(diff^2) / 200 of edge_aware_gap_fill: doubles in [-330, 0], and tiny ones)
+        double x = -330.0 * (double)i / 400000.0, t = -ldexp(1.0 + i * 1e-6, -40 - (i % 1000));
+        if (csm::d2u(exp(x)) != csm::d2u(csm::exp_exact_small(x, cs_exp_tab))) bad++;
+        if (csm::d2u(exp(t)) != csm::d2u(csm::exp_exact_small(t, cs_exp_tab))) bad++;
         n++;
     }
     for (int i = 0; i < 2000000; i++) {

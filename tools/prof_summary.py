@@ -31,6 +31,16 @@ def main():
                 other_calls += calls
                 other_tot += tot
         lines.append(f"{'(all non-cs kernels: torch input generation / copies)':90s} {other_calls:6d} {other_tot:14.0f}")
+        if "--calls" in sys.argv:   # every dispatch of the kernels whose name contains the given text, in launch order (us)
+            pat = sys.argv[sys.argv.index("--calls") + 1]
+            try:
+                rows = c.execute("select name, start, end from kernels order by start").fetchall()
+                lines.append(f"# dispatches of *{pat}* in launch order (us)")
+                for name, st, en in rows:
+                    if pat in name:
+                        lines.append(f"{short(name):70s} {(en - st) / 1000.0:12.1f}")
+            except sqlite3.Error as e:
+                lines.append(f"# (--calls: no per-dispatch view in this database: {e})")
     else:
         cur = c.execute("select * from counters_collection limit 1")
         cols = [d[0] for d in cur.description]

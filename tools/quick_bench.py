@@ -31,13 +31,14 @@ ap.add_argument("--kind", default="stepped")
 ap.add_argument("--div", type=float, default=8.0)
 ap.add_argument("--blur", type=int, default=0)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--tie-pool-mb", type=int, default=0, help="extra workspace for the stretch-replay pool (engine.Plan tie_pool_bytes)")
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
 img = torch.from_numpy(synth.image_f32(1, a.h, a.w, seed=1)).to(dev).expand(a.n, -1, -1, -1).contiguous()
 depth = torch.from_numpy(synth.depth_batch(a.kind, a.n, a.h, a.w, channels=3)).to(dev)
 p = engine.make_params(a.n, a.h, a.w, a.h, a.w, 3, a.fill, a.mode, a.div, 0.0, 0.0, 0.5, 2.0, bool(a.blur), 20.0, 20.0, 2.0, 6, 12)
-plan = engine.Plan(p, dev)
+plan = engine.Plan(p, dev, tie_pool_bytes=a.tie_pool_mb << 20)
 plan.run(img, depth); torch.cuda.synchronize()
 st = plan.stats()
 import os

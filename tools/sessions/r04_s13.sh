@@ -1,0 +1,16 @@
+#!/bin/bash
+# round-4 session 13: sliding LDS windows in the stretch replay kernel (one list, 4.3 KB per wave, any stretch length) + the lean row
+# kernel's scratch fix (colour row staged again for the second eye): parity (tie tests, full polylines fuzz), saturated / noise depth,
+# waves per SIMD of the replay kernel (4 default / 5 / 6 / 8)
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/r04_s13
+C=comfystereo_amd
+timeout 1500 python -m pytest tests -x -q -m gpu -k "poly or ties or saturated or replay or order or fuzz or stress or metric or cfg2 or wide or 8k" > gpurun_out/r04_s13/tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r04_s13/tests.log
+CS_FUZZ_FILLS=polylines_soft,polylines_sharp timeout 400 python tools/extended_fuzz.py 250 404000 > gpurun_out/r04_s13/fuzz.log 2>&1; echo "fuzz rc=$?"; tail -2 gpurun_out/r04_s13/fuzz.log
+LIBS="$C/libcomfystereo_hip.so $C/libcs_rp5.so $C/libcs_rp6.so $C/libcs_rp8.so" tools/abn.sh --kind clipped --blur 0 --n 64 --iters 3 2>&1 | tee gpurun_out/r04_s13/ab_clipped.txt
+printf "clipped blur off polylines_sharp n=32: "; timeout 300 python tools/quick_bench.py --kind clipped --blur 0 --n 32 --iters 3 --fill polylines_sharp 2>&1 | tail -1 | sed 's/.*: //'
+printf "blobs blur off n=32: "; timeout 300 python tools/quick_bench.py --kind blobs --blur 0 --n 32 --iters 5 2>&1 | tail -1 | sed 's/.*: //'
+printf "random8 blur on n=8: "; timeout 300 python tools/quick_bench.py --kind random8 --blur 1 --n 8 --iters 2 2>&1 | tail -1 | sed 's/.*: //'
+for L in $C/libcomfystereo_hip.so $C/libcs_rp6.so; do printf "random8 blur off n=2 $(basename $L): "; CS_LIB_PATH=$PWD/$L CS_DBG=14 timeout 600 python tools/quick_bench.py --kind random8 --blur 0 --n 2 --iters 1 2>&1 | tail -4; done
+rm -rf /tmp/pt; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pt -o p -- python3 bench.py --depth clipped --no-blur --no-cpu-baseline --steps 2 --warmup 1 > gpurun_out/r04_s13/clipped.log 2>&1
+db=$(find /tmp/pt -name '*.db' | head -1); [ -n "$db" ] && python3 tools/prof_summary.py $db gpurun_out/r04_s13/clipped_kernel_trace.txt --calls k_rowwarp > /dev/null; head -20 gpurun_out/r04_s13/clipped_kernel_trace.txt | cut -c1-150
