@@ -2489,7 +2489,7 @@ template <int SHARP, int PWS, int CWS>
 #ifndef RP_MINW
 #define RP_MINW 5   // waves per SIMD the register budget is sized for (96 VGPRs, 4 spilled; 4: 108 VGPRs -3 %, 6: -2 %, 8: -33 %)
 #endif
-__global__ void __launch_bounds__(64, RP_MINW) k_poly_replay(RowArgs A, uint8_t* __restrict__ retry, int halo) {
+__global__ void __launch_bounds__(64, CWS > 2048 ? 1 : RP_MINW) k_poly_replay(RowArgs A, uint8_t* __restrict__ retry, int halo) {   // (wide windows: LDS-bound)
     __shared__ uint16_t permw[PWS];
     __shared__ float cdw[CWS];
     __shared__ uint8_t imgw[3 * CWS];
@@ -2543,19 +2543,24 @@ __global__ void __launch_bounds__(64, RP_MINW) k_poly_replay(RowArgs A, uint8_t*
     }
 }
 
-// the dump pool: 4 KB per image row (the windows of a stretch average ~2 KB, an order-dependent eye row holds 1.3 stretches), never
-// more than one maximal window set per stretch slot; a row that finds the pool (or the descriptor list) full replays inline
-static size_t rp_pool_bytes(size_t rows) {
-    // (development: CS_DEBUG_PT_VARIANT 41 quadruples the budget -- does a workload run out of pool?)
+// The dump pool.  A stretch's windows average ~2 KB and an order-dependent eye row holds 1.3 stretches: 4 KB per image row carry
+// a batch whose every row ties in places (saturated depth).  A row WITHOUT reset points (depth noise) is one stretch of the
+// whole row: 6 B per pixel and eye.  Batches small enough get that much outright (up to 1 GiB: eleven 4K frames -- the chunks of
+// the host pipeline are eight), larger ones the 4 KB per row; a row that finds the pool (or the descriptor list) full takes the
+// second pass (in-row replay), and a caller can always give more (workspace beyond cs_workspace_bytes extends the pool).
+static size_t rp_pool_bytes(size_t rows, int w, int sharp) {
+    // (development: CS_DEBUG_PT_VARIANT 41 quadruples the per-row budget -- does a workload run out of pool?)
     const size_t per_row = dev_switch(CS_DEBUG_PT_VARIANT) == 41 ? 16384 : 4096;
-    const size_t worst = rows * 4 * ((size_t)rp_win16(RP_PW, RP_CW) << 4), budget = rows * per_row + (64u << 10);
-    return (worst < budget ? worst : budget) & ~(size_t)15;
+    const size_t every_row = rows * 2 * ((size_t)rp_win16(poly_npt(w, sharp), w) << 4), budget = rows * per_row + (64u << 10);
+    const size_t cap = (size_t)1 << 30;
+    size_t pool = every_row <= cap ? every_row : (budget > cap ? budget : cap);
+    if (pool > every_row) pool = every_row;
+    return (pool + 15) & ~(size_t)15;
 }
 size_t poly_replay_bytes(int n, int h, int w, int sharp) {
-    (void)sharp;
     if (w > 8192) return 0;
     const size_t rows = (size_t)n * h;   // descriptors: four stretches per image row
-    return al256r(rows * 4 * RP_DESC * 4) + rp_pool_bytes(rows) + 256;
+    return al256r(rows * 4 * RP_DESC * 4) + rp_pool_bytes(rows, w, sharp) + 256;
 }
 // scratch: [descriptor list][dump pool]; `ctr_retry`: [counters 256 B][retry flags, one byte per row], zeroed by the caller
 // (it lies in the flagged-row block that run_rows clears with one memset)
@@ -2565,9 +2570,9 @@ hipError_t poly_replay_attach(RowArgs& A, int sharp, void* scratch, void* ctr_re
     A.rp_ctr = (uint32_t*)ctr_retry;
     A.rp_list = (uint32_t*)b;
     A.rp_dump = (uint8_t*)(b + al256r(rows * 4 * RP_DESC * 4));
-    const size_t pool16 = (rp_pool_bytes(rows) + surplus) >> 4;   // (surplus: workspace the caller gave beyond cs_workspace_bytes)
+    const size_t pool16 = (rp_pool_bytes(rows, A.w, sharp) + surplus) >> 4;   // (surplus: workspace the caller gave beyond cs_workspace_bytes)
     A.rp_pool16 = (uint32_t)(pool16 < 0xffffffffu ? pool16 : 0xffffffffu); A.rp_cap = (uint32_t)(rows * 4);
-    (void)stream; (void)sharp;
+    (void)stream;
     return hipSuccess;
 }
 uint8_t* poly_replay_retry_flags(const RowArgs& A) { return (uint8_t*)A.rp_ctr + 256; }

@@ -79,3 +79,16 @@ def test_fails_loudly_without_a_gpu():
         host_pipeline.generate_host(img, dep, 4.5, 0, "left-right", 0, 0.5, 2, "polylines_soft", 20, 20, True)
     with pytest.raises(RuntimeError, match="no CPU fallback"):  # the techniques no UI string reaches included
         sig.apply_stereo_divergence(torch.zeros(4, 4, 3, dtype=torch.uint8), dep[0, :, :, 0], 5.0, 0.0, 2.0, "none_post")
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_import_time_warm_up_is_inert_without_a_gpu_and_outside_comfyui():
+    """GenerateStereo.PREWARM (the pinned-memory warm-up the node module starts at import inside ComfyUI):
+    nothing is started outside ComfyUI, and without a GPU the warm-up itself declines instead of raising."""
+    from comfystereo_amd import host_pipeline
+    assert gs.PREWARM == (32, 2160, 3840) and gs._IN_COMFYUI is False
+    assert host_pipeline._prewarm_thread is None
+    assert host_pipeline.prewarm(2, 64, 64) is False
+    t = host_pipeline.prewarm_async(2, 64, 64)
+    host_pipeline.prewarm_wait()
+    assert not t.is_alive()

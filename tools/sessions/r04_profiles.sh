@@ -37,3 +37,11 @@ for c in cfg2 cfg3 cfg4 cfg5; do python3 -c "
 import json,sys
 j=json.load(open('gpurun_out/${TAG}_$c/bench.json')); print('$c', round(j['value'],1), 'fps frac', round(j['roofline']['frac'],3), 'kernel_ms', round(j['roofline']['kernel_ms'],3), 'pipeline', round(j['roofline']['pipeline_frac'],3))"; done
 tail -6 gpurun_out/${TAG}_host_4k.txt
+# HBM traffic of the dominant kernels from this run's PMC passes -> gpurun_out/${TAG}_pmc_traffic.json (copied to profiles/pmc_traffic.json)
+cp profiles/pmc_traffic.json gpurun_out/${TAG}_pmc_traffic_before.json 2>/dev/null
+python3 tools/make_traffic.py gpurun_out/${TAG}_blur_on 64 polylines_soft_4k_blur1 k_polypoint
+python3 tools/make_traffic.py gpurun_out/${TAG}_cfg2_pmc 32 polylines_soft_1080p_blur1 k_polypoint
+python3 tools/make_traffic.py gpurun_out/${TAG}_cfg3_pmc 16 hybrid_edge_4k_blur1 "k_hybrid_splat_tile+k_hybrid_gaps"
+python3 tools/make_traffic.py gpurun_out/${TAG}_cfg4_pmc 256 gpu_warp_1080p_blur1 "k_gpuwarp<"
+python3 tools/make_traffic.py gpurun_out/${TAG}_cfg5_pmc 64 none_4k_blur1 k_fwdtile
+cp profiles/pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json
