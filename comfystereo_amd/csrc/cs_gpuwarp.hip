@@ -118,8 +118,11 @@ __device__ __forceinline__ bool gw_core_ok(float a) { const float m = fabsf(a); 
 // POW: 2 = exponent 2 compiled in (the widget default: x * x, no mode dispatch per pixel), -1 = A.pow_mode at run time
 // GEN: forward_warp_gpu's keyword parameters away from their defaults (gradient_threshold 1.5, max_stretch 8; reference :277-279):
 // connectivity threshold and the number of rounds at run time, 16 instead of 8 slots for the rounds' border columns.
-template <int MINW, int POW, bool GEN = false>
-__global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
+// NODE: the node's layout compiled in (image and output interleaved, every enabled eye writes the three channels): the strides
+// and channel masks of the general form do not occupy scalar registers (round 4: the kernel spilled ~150 scalars per eye)
+template <int MINW, int POW, bool GEN = false, bool NODE = false>
+__attribute__((amdgpu_waves_per_eu(MINW, MINW)))   // (an upper bound as well: the scalar register budget follows the MAXIMUM -- 80 at the default 10)
+__global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
     constexpr int NR = GEN ? 16 : 8;              // rounds the border arrays W0 / W1 and the offset of M provide for
     const int RV = GEN ? A.rounds : 4;            // rounds that can pass the z-test (see the column pass)
     const float conn_thr = GEN ? A.grad_thr : 1.5f;
@@ -174,36 +177,60 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
     const float sxw = (float)(w - 1);
     const bool sxw_ok = w >= 2 && w <= (1 << 20);   // the division core's denominator range
     const float ysx = sxw_ok ? gw_rcp_refined(sxw) : 0.0f;
-    const bool interleaved = A.img_sc == 1 && A.img_sx == 3 && A.out_sc == 1 && A.out_sx == 3;
+    const bool interleaved = NODE || (A.img_sc == 1 && A.img_sx == 3 && A.out_sc == 1 && A.out_sx == 3);
 
-    // lazy depth-blur tiles: both eyes' selectors up front (their scalar loads overlap with the set-up above instead of
-    // standing in front of each eye's depth loads)
+    // lazy depth-blur tiles (cs_common.h): the row's selector of one eye -- `hi`: columns 2048 .. 4095, a second word of tile bits
+    // (the other fields of a selector do not depend on s0 when the lane's offset is taken from column 0).  Set up per eye at the
+    // top of its iteration (round 3 held both eyes' selectors from the kernel's prologue on, so that their scalar loads would
+    // not stand in front of the depth loads: 14 scalar registers carried across the loop -- spilled; per eye is 0.5 % faster)
     const bool lazy = A.tilemap != nullptr;
-    LazySel Z0, Z1;
-    Z0.base = Z1.base = nullptr; Z0.bits = Z1.bits = 0; Z0.delta = Z1.delta = 0; Z0.mul_set = Z1.mul_set = Z0.mul_clr = Z1.mul_clr = 0;
-    uint32_t Z0hi = 0, Z1hi = 0;   // columns 2048 .. 4095: a second word of tile bits (the other fields of a selector do not depend on s0
-                                   // when the lane's offset is taken from column 0)
-    if (lazy) {
-        const char* grow = reinterpret_cast<const char*>(A.gray + ((size_t)frame * h + y) * w);
-        const char* d0 = reinterpret_cast<const char*>(A.eye[0].depth + ((size_t)frame * h + y) * w);
-        const char* d1 = reinterpret_cast<const char*>(A.eye[A.neyes > 1 ? 1 : 0].depth + ((size_t)frame * h + y) * w);
-        Z0 = lazy_select(A.tilemap, A.tm_words, frame, h, y, 0, d0, grow, st[ST_SCALE255]);
-        if (A.neyes > 1) Z1 = lazy_select(A.tilemap, A.tm_words, frame, h, y, 0, d1, grow, st[ST_SCALE255]);
-        if (w > 2048) {
-            Z0hi = lazy_select(A.tilemap, A.tm_words, frame, h, y, 2048, d0 + 4 * 2048, grow + 4 * 2048, st[ST_SCALE255]).bits;
-            if (A.neyes > 1) Z1hi = lazy_select(A.tilemap, A.tm_words, frame, h, y, 2048, d1 + 4 * 2048, grow + 4 * 2048, st[ST_SCALE255]).bits;
-        }
-    }
+    auto lazy_select_eye = [&](int e, int wv, LazySel& Zs, uint32_t& hi) {
+        Zs.base = nullptr; Zs.bits = 0; Zs.delta = 0; Zs.mul_set = Zs.mul_clr = 0; hi = 0;
+        if (!lazy) return;
+        const char* grow = reinterpret_cast<const char*>(A.gray + ((size_t)frame * h + y) * wv);
+        const char* de = reinterpret_cast<const char*>(A.eye[e].depth + ((size_t)frame * h + y) * wv);
+        Zs = lazy_select(A.tilemap, A.tm_words, frame, h, y, 0, de, grow, st[ST_SCALE255]);
+        if (wv > 2048) hi = lazy_select(A.tilemap, A.tm_words, frame, h, y, 2048, de + 4 * 2048, grow + 4 * 2048, st[ST_SCALE255]).bits;
+    };
     // depth of column x through a selector whose tile bits are `lo` for columns < 2048 and `hi` above
     auto lazy_load2 = [](LazySel Zs, uint32_t hi, uint32_t x, float& mul) {
         Zs.bits = x >= 2048u ? hi : Zs.bits;
         return lazy_load(Zs, x, x, mul);
     };
+    const int w_row = w;
     for (int e = 0; e < A.neyes; e++) {
+        // (round 4) The row's width and the LDS base are re-read through an opaque move at the top of every eye: what the compiler
+        // derives from them (the carve-up, a dozen hoisted LDS addresses, loop bounds) is then recomputed per eye with a few
+        // scalar instructions instead of being carried across the loop -- with 80 scalar registers at 8 waves per SIMD it spilled
+        // ~100 of them into vector lanes before the loop and read them back in every phase (v_writelane / v_readlane: vector issue
+        // slots).  Kernel -4.4 % at 1080p (tools/sessions/r04_s18.sh); doing the same at every phase boundary bought nothing more (s19).
+        int w;
+        float *ndn, *po, *D, *zb, *sm, sxw;
+        int *M, *W0, *W1, *winner, *ws;
+        uint8_t* flags;
+        csm::PowfTables* T;
+        auto reread = [&]() {
+            int w_eye = w_row, lds0 = 0;   // (an opaque OFFSET: the pointer itself must keep its LDS address space)
+            asm volatile("" : "+s"(w_eye), "+s"(lds0));
+            w = w_eye;
+            ndn = (float*)(smem + lds0); po = ndn + w; D = po + w; zb = D + w;
+            M = (int*)(zb + w); W0 = M + w + NR; W1 = W0 + NR;
+            winner = (int*)ndn; sm = po;
+            flags = (uint8_t*)(W1 + NR);
+            ws = (int*)(flags + align16((size_t)w));
+            T = (csm::PowfTables*)(ws + 32);
+            sxw = (float)(w - 1);
+        };
+        reread();
         const GwEye& E = A.eye[e];
         if (!E.enabled) {
             // eye = source image (divergence < 0.001): plain copy into the slot
-            if (A.out)
+            if (NODE) {
+                const Px3* srow = reinterpret_cast<const Px3*>(A.image + frame * A.img_sf + y * A.img_sy);
+                Px3* orow = reinterpret_cast<Px3*>(A.out + frame * A.out_sf + (y + E.yoff) * A.out_sy) + E.xoff;
+                if (A.out && E.chan_mask)
+                    for (int x = tid; x < w; x += nt) orow[x] = srow[x];
+            } else if (A.out)
                 for (int x = tid; x < w; x += nt)
                     for (int c = 0; c < 3; c++)
                         if (E.chan_mask & (1 << c))
@@ -220,12 +247,11 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
         const bool crange_ok = crange < 0x1p40f;   // (>= 1e-6 by construction)
         const float* const img_row0 = A.image + frame * A.img_sf + iy0 * A.img_sy;
         const float* const img_row1 = A.image + frame * A.img_sf + iy1 * A.img_sy;
-        float* const out_row = A.out + frame * A.out_sf + (y + E.yoff) * A.out_sy + E.xoff * A.out_sx;
+        float* const out_row = A.out + frame * A.out_sf + (y + E.yoff) * A.out_sy + E.xoff * (NODE ? 3 : A.out_sx);
         const float* drow = E.depth + ((size_t)frame * h + y) * w;
-        LazySel Z;   // (field by field: an aggregate select of two structs may go through scratch memory)
-        Z.base = e ? Z1.base : Z0.base; Z.bits = e ? Z1.bits : Z0.bits; Z.delta = e ? Z1.delta : Z0.delta;
-        Z.mul_set = e ? Z1.mul_set : Z0.mul_set; Z.mul_clr = e ? Z1.mul_clr : Z0.mul_clr;
-        const uint32_t Zhi = e ? Z1hi : Z0hi;
+        LazySel Z;
+        uint32_t Zhi;
+        lazy_select_eye(e, w, Z, Zhi);
         // ---- pass 1: normalised depth, pixel offset, x + offset (:300-328); four columns per thread with their loads first
         const float yr = crange_ok ? gw_rcp_refined(crange) : 0.0f;   // several numerators over one denominator
         float* const depth_out = !A.depth_l ? nullptr : (e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + y) * w) * 3;
@@ -432,7 +458,7 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
             t.nw = wsth * we; t.ne = wsth * ww; t.sw2 = wn * we; t.se = wn * ww;
             return t;
         };
-        if (interleaved && E.chan_mask == 7) {   // node layout, all channels: 12-byte accesses, 32-bit offsets, two columns
+        if (NODE || (interleaved && E.chan_mask == 7)) {   // node layout, all channels: 12-byte accesses, 32-bit offsets, two columns
             const char* const r0 = reinterpret_cast<const char*>(img_row0);   // per step so that eight loads are in flight
             const char* const r1 = reinterpret_cast<const char*>(img_row1);
             constexpr bool TWO = MINW < 8;   // (the 64-register instantiation spills with two columns in flight: -3 % at 4K)
@@ -457,7 +483,7 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
                     *reinterpret_cast<Px3*>(reinterpret_cast<char*>(out_row) + 12u * (uint32_t)x1) = r;
                 }
             }
-        } else {
+        } else if (!NODE) {
             for (int x = tid; x < w; x += nt) {
                 const Taps t = taps_of(x);
                 const float* p00 = img_row0 + (size_t)t.ix0 * A.img_sx;
@@ -489,9 +515,8 @@ __global__ void __launch_bounds__(1024, MINW) k_gpuwarp(GwArgs A) {
             const float* drow = E.depth + ((size_t)frame * h + y) * w;
             float* dst = (e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + y) * w) * 3;
             LazySel Z;
-            Z.base = e ? Z1.base : Z0.base; Z.bits = e ? Z1.bits : Z0.bits; Z.delta = e ? Z1.delta : Z0.delta;
-            Z.mul_set = e ? Z1.mul_set : Z0.mul_set; Z.mul_clr = e ? Z1.mul_clr : Z0.mul_clr;
-            const uint32_t Zhi = e ? Z1hi : Z0hi;
+            uint32_t Zhi;
+            lazy_select_eye(e, w, Z, Zhi);
             for (int xb = tid; xb < w; xb += 4 * nt) {   // (loads first; /255 behind a real branch)
                 float dv[4], dm[4];
 #pragma unroll
@@ -828,13 +853,19 @@ static int gw_launch(GwArgs& A, hipStream_t stream) {
     if (forced == 21) threads = 512;
     if (forced == 22 && A.w <= 4 * 256) threads = 256;
     if (forced == 23) threads = 1024;
+    if (forced == 26) threads = 256;   // (1080p: four workgroups of four waves per CU, 7.5 columns per lane)
     // 1080p: a row takes 40.5 KB without the tables -- FOUR 512-thread workgroups per CU instead of three if the kernel also
     // fits 64 registers (the 8-waves-per-SIMD instantiation; development switch 24: the 6-wave one)
     const bool four = threads == 512 && 4 * ((lds + 511) & ~(size_t)511) <= CS_LDS_BYTES && forced != 24;
     const bool wide = threads > 512 || four, pow2 = A.pow_mode == 2 && !gen;
+    // the node's layout (interleaved image and output, every eye writes the three channels) has instantiations of its own
+    bool node = !gen && A.out && A.img_sc == 1 && A.img_sx == 3 && A.out_sc == 1 && A.out_sx == 3 && forced != 25;
+    for (int e = 0; e < A.neyes; e++) node = node && A.eye[e].chan_mask == 7;
     const void* fn = gen ? (wide ? (const void*)k_gpuwarp<8, -1, true> : (const void*)k_gpuwarp<6, -1, true>)
-                         : wide ? (pow2 ? (const void*)k_gpuwarp<8, 2> : (const void*)k_gpuwarp<8, -1>)
-                                : (pow2 ? (const void*)k_gpuwarp<6, 2> : (const void*)k_gpuwarp<6, -1>);
+                   : node ? (wide ? (pow2 ? (const void*)k_gpuwarp<8, 2, false, true> : (const void*)k_gpuwarp<8, -1, false, true>)
+                                  : (pow2 ? (const void*)k_gpuwarp<6, 2, false, true> : (const void*)k_gpuwarp<6, -1, false, true>))
+                          : wide ? (pow2 ? (const void*)k_gpuwarp<8, 2> : (const void*)k_gpuwarp<8, -1>)
+                                 : (pow2 ? (const void*)k_gpuwarp<6, 2> : (const void*)k_gpuwarp<6, -1>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return CS_EHIP;
 #ifdef GW_XCD_ROWS
@@ -844,6 +875,10 @@ static int gw_launch(GwArgs& A, hipStream_t stream) {
 #endif
     if (gen && wide) hipLaunchKernelGGL((k_gpuwarp<8, -1, true>), grid, block, lds, stream, A);
     else if (gen) hipLaunchKernelGGL((k_gpuwarp<6, -1, true>), grid, block, lds, stream, A);
+    else if (node && wide && pow2) hipLaunchKernelGGL((k_gpuwarp<8, 2, false, true>), grid, block, lds, stream, A);
+    else if (node && wide) hipLaunchKernelGGL((k_gpuwarp<8, -1, false, true>), grid, block, lds, stream, A);
+    else if (node && pow2) hipLaunchKernelGGL((k_gpuwarp<6, 2, false, true>), grid, block, lds, stream, A);
+    else if (node) hipLaunchKernelGGL((k_gpuwarp<6, -1, false, true>), grid, block, lds, stream, A);
     else if (wide && pow2) hipLaunchKernelGGL((k_gpuwarp<8, 2>), grid, block, lds, stream, A);
     else if (wide) hipLaunchKernelGGL((k_gpuwarp<8, -1>), grid, block, lds, stream, A);
     else if (pow2) hipLaunchKernelGGL((k_gpuwarp<6, 2>), grid, block, lds, stream, A);

@@ -21,11 +21,12 @@ def mean(path, kernel, counter):
 fetch_kib = sum(mean(f"{run}/pmc_fetch.txt", k, "FETCH_SIZE") for k in kernel.split("+"))
 write_kib = sum(mean(f"{run}/pmc_write.txt", k, "WRITE_SIZE") for k in kernel.split("+"))
 out = "profiles/pmc_traffic.json"
+kept = run.replace("gpurun_out/", "profiles/", 1)  # where the session copies the run (gpurun_out/ is scratch)
 try:
     d = json.load(open(out))
 except Exception:  # noqa: BLE001
     d = {}
 d[key] = {"bytes_per_frame": (2 * fetch_kib + write_kib) * 1024 / frames, "fetch_kib_raw_per_dispatch": fetch_kib,
-          "write_kib_per_dispatch": write_kib, "frames_per_dispatch": frames, "read_correction": 2.0, "source": run, "profile": run, "kernel": kernel}
+          "write_kib_per_dispatch": write_kib, "frames_per_dispatch": frames, "read_correction": 2.0, "source": kept, "profile": kept, "kernel": kernel}
 json.dump(d, open(out, "w"), indent=1)
 print(d[key])
