@@ -56,7 +56,21 @@ __host__ __device__ inline size_t lds_common_bytes(int fill, int w, int anaglyph
            (fill_uses_res(fill) ? align16(3 * (size_t)w) : 0) + (anaglyph ? align16(2 * (size_t)w) : 0) +
            align16(4 * (size_t)w);
 }
-__host__ __device__ inline int poly_cap(int w, int sharp) { return (sharp ? 4 : 3) * w + 64; }
+#define CS_ROW_LDS_STATIC 64   // static LDS of k_rowwarp next to its dynamic request (16 bytes today: the request may not take all 160 KB)
+// capacity of the per-pixel segment lists of the polylines row kernel (16-bit entries; also the scratch of its counting sort:
+// >= npt).  A row whose lists need more is not evaluated in parallel at all: it goes to the replay (as one whole-row stretch) or to
+// the literal sequential sweep -- slower, same pixels.  polylines_sharp keeps two points per source: beyond 6 954 columns the full
+// capacity (4 w + 64) no longer fits the 160 KB next to the row's other arrays, and the capacity is what the LDS leaves (round 4:
+// 7 680-wide rows are accepted; the tile kernel k_polypoint<SHARP> has no such limit, this only concerns the rows it flags).
+__host__ __device__ inline int poly_cap(int w, int sharp) {
+    const int full = (sharp ? 4 : 3) * w + 64;
+    if (!sharp) return full;
+    const long long other = (long long)lds_common_bytes(CS_FILL_POLYLINES_SHARP, w, 0) + (long long)align16(2 * (size_t)(2 * w + 2)) +
+                            (long long)align16(2 * ((size_t)w + 4)) + (long long)align16(2 * ((size_t)w + 2)) + 2048;
+    const long long fit = (((long long)CS_LDS_BYTES - CS_ROW_LDS_STATIC - other) / 2) & ~7LL;
+    if ((long long)full <= fit) return full;
+    return fit >= 2LL * w + 2 + 4096 ? (int)fit : full;   // (too wide even so: the full figure makes the width check fail)
+}
 __host__ __device__ inline size_t lds_tech_bytes(int fill, int w) {
     switch (fill) {
     case CS_FILL_NONE: return align16(4 * (size_t)w);                       // winner
@@ -2604,7 +2618,7 @@ hipError_t launch_collect_rows(const uint8_t* flag, int total, uint32_t* count, 
 hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream, int max_groups, int lean) {
     size_t lds = lds_common_bytes(fill, A.w, A.anaglyph) + lds_tech_bytes(fill, A.w);
     if ((A.d64 & 1) && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP)) lds += align16(8 * (size_t)A.w);   // Poly::xd
-    if (lds > CS_LDS_BYTES) return hipErrorInvalidValue;
+    if (lds + CS_ROW_LDS_STATIC > CS_LDS_BYTES) return hipErrorInvalidValue;
     const long long rows = (long long)A.h * A.n;
     dim3 grid(A.h, A.n), block(threads);
     if (A.row_list) {
@@ -2627,7 +2641,10 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
         break;                                                                                                    \
     }
     // (only where two rows then share a CU: at 4K polylines_sharp's row takes 88 KB of LDS -- one per CU whatever the registers)
-    if (lean && !(A.d64 & 3) && A.rp_dump && 2 * lds <= CS_LDS_BYTES && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP)) {
+    // (... and for sharp rows so wide that their list capacity is reduced, poly_cap: the lean kernel exports the rows whose lists
+    // overflow as whole-row stretches, the full kernel would sweep them sequentially)
+    const bool reduced_cap = fill == CS_FILL_POLYLINES_SHARP && poly_cap(A.w, 1) < 4 * A.w + 64;
+    if (lean && !(A.d64 & 3) && A.rp_dump && (2 * lds <= CS_LDS_BYTES || reduced_cap) && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP)) {
         // first pass with the replay kernel attached: the instantiation without the in-row replay (64 registers, two rows per CU)
         hipError_t e = fill == CS_FILL_POLYLINES_SOFT
             ? hipFuncSetAttribute((const void*)k_rowwarp<CS_FILL_POLYLINES_SOFT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
@@ -2662,7 +2679,7 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
     return hipGetLastError();
 }
 
-size_t rowwarp_lds_bytes(int fill, int w, int anaglyph) { return lds_common_bytes(fill, w, anaglyph) + lds_tech_bytes(fill, w); }
+size_t rowwarp_lds_bytes(int fill, int w, int anaglyph) { return lds_common_bytes(fill, w, anaglyph) + lds_tech_bytes(fill, w) + CS_ROW_LDS_STATIC; }
 
 // splat result (3 + 1 bytes per pixel and eye), then the gap lists of the streaming fill: a counter per (frame, eye, row) and
 // 16-bit columns, w per row

@@ -193,8 +193,8 @@ def test_forward_warp_1080p_rows_on_the_gpu():
 
 
 UI = {"none": "No fill", "naive": "Fill - Naive", "naive_interpolating": "Fill - Naive interpolating",
-      "polylines_soft": "Fill - Polylines Soft", "inverse": "No fill - Reverse projection",
-      "hybrid_edge": "Imperfect fill - Hybrid Edge", "gpu_warp": "GPU Warp (Fast)"}
+      "polylines_soft": "Fill - Polylines Soft", "polylines_sharp": "Fill - Polylines Sharp",
+      "inverse": "No fill - Reverse projection", "hybrid_edge": "Imperfect fill - Hybrid Edge", "gpu_warp": "GPU Warp (Fast)"}
 
 
 @pytest.mark.parametrize("fill", sorted(UI))
@@ -218,11 +218,36 @@ def test_8k_wide_rows_side_by_side(engine, fill):
 
 
 def test_too_wide_frames_are_refused_not_truncated(engine):
-    h, w = 4, 7680
-    img = synth.image_f32(1, h, w, seed=8)
-    depth = synth.depth_batch("stepped", 1, h, w, channels=3)
-    with pytest.raises(RuntimeError, match="too wide"):
-        gen(engine, img, depth, "polylines_sharp", "left-right", blur=False, div=3.0)
+    """Beyond cs_max_width_mode the call fails (CS_ELIMIT), it does not truncate: polylines_sharp side by side beyond 7 994 columns,
+    and as an anaglyph (two more bytes of LDS per column) already at 7 680."""
+    from comfystereo_amd import _native
+    L = _native.lib()
+    for w, mode in ((8192, "left-right"), (7680, "red-cyan-anaglyph")):
+        assert L.cs_max_width_mode(engine.FILL["polylines_sharp"], engine.MODE[mode]) < w
+        img = synth.image_f32(1, 4, w, seed=8)
+        depth = synth.depth_batch("stepped", 1, 4, w, channels=3)
+        with pytest.raises(RuntimeError, match="too wide"):
+            gen(engine, img, depth, "polylines_sharp", mode, blur=False, div=3.0)
+
+
+@pytest.mark.parametrize("kind", ["clipped", "random8"])
+def test_8k_sharp_rows_with_ties(engine, kind):
+    """7680-wide polylines_sharp rows that the tile kernel FLAGS (exact closeness ties): the row kernel behind it runs with a
+    reduced capacity for its per-pixel segment lists at this width (cs_rowwarp.hip poly_cap) -- rows whose lists overflow are
+    exported as one whole-row stretch to the replay kernel (sliding windows over 15 362 sorted points) or swept sequentially.
+    Same pixels as the oracle; the statistics show that rows did take those paths."""
+    h, w = 5, 7680
+    img = synth.image_f32(1, h, w, seed=21)
+    depth = synth.depth_batch(kind, 1, h, w, channels=3)
+    want = node_oracle.generate(img, depth, 4.0, 0.0, "left-right", 0.0, 0.5, 2.0, UI["polylines_sharp"], 20.0, 20.0, False, batch_size=12)
+    p = engine.make_params(1, h, w, h, w, 3, "polylines_sharp", "left-right", 4.0, 0.0, 0.0, 0.5, 2.0, False, 20.0, 20.0, 1.0, 0, 12)
+    plan = engine.Plan(p, torch.device("cuda"))
+    got = [t.cpu().numpy() for t in plan.run(cuda(img), cuda(depth))]
+    st = plan.stats()
+    assert int(st[:, 11].sum()) > 0, "no row was flagged: the test does not reach the row kernel"
+    assert int(st[:, 9].sum()) == 0   # kernel error flags
+    for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+        assert np.array_equal(g, w_), (kind, name)
 
 
 def test_order_dependent_rows_take_the_wave_replay(engine):
