@@ -112,6 +112,18 @@ __device__ __forceinline__ int wave_incl_max(int v) {
     return v;
 }
 __device__ __forceinline__ bool gw_core_ok(float a) { const float m = fabsf(a); return a == 0.0f || (m >= 0x1p-60f && m < 0x1p60f); }
+// The division core for every lane, the full division only for lanes outside its proven range -- behind a branch that is almost
+// never taken (an if / else of the two forms costs two more exec-mask levels per quotient; the kernel is sensitive to those)
+__device__ __forceinline__ float gw_div(float a, float b) {
+    float q = gw_div_core(a, b);
+    if (__builtin_expect(!gw_core_ok(a), 0)) { asm volatile("" ::: "memory"); q = a / b; }
+    return q;
+}
+__device__ __forceinline__ float gw_div_y(float a, float b, float y1, bool b_ok) {   // (y1: refined reciprocal of b, valid when b_ok)
+    float q = gw_div_with(a, b, y1);
+    if (__builtin_expect(!(b_ok && gw_core_ok(a)), 0)) { asm volatile("" ::: "memory"); q = a / b; }
+    return q;
+}
 
 // MINW: waves per SIMD the register budget is sized for -- 8 (64 VGPRs, 8 spilled) lets two 1024-thread workgroups share a
 // CU at 4K; the 512-thread workgroups of narrower frames run 6 per SIMD without spills (+5 % at 1080p)
@@ -277,7 +289,7 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
                     *reinterpret_cast<Px3*>(depth_out + 3 * x) = Px3{vo, vo, vo};
                 }
                 const float num = v - dmin;
-                float nrm = (crange_ok && gw_core_ok(num)) ? gw_div_with(num, crange, yr) : num / crange;
+                float nrm = gw_div_y(num, crange, yr, crange_ok);
                 nrm = has_range ? nrm : 0.0f;
                 ndn[x] = nrm;
                 const float s = nrm - A.conv32;
@@ -332,7 +344,7 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
                                !((num < 0.0f && safe > 0.0f) || (num > 0.0f && safe < 0.0f) || fabsf(num) >= 1.001f * fabsf(safe));
             if (!maybe) return;
             // (here 1e-4 <= |safe| < 2.51 and |num| < 2.6: inside the division core's range unless num is tiny)
-            const float frac = gw_core_ok(num) ? gw_div_core(num, safe) : num / safe;
+            const float frac = gw_div(num, safe);
             const bool valid = frac >= 0.0f && frac < 1.0f;
             const float iz = ndn[i] * (1.0f - frac) + ndn[i + 1] * frac;
             if (valid && iz > z + (float)1e-6) {
@@ -368,11 +380,13 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
                     const float sw = drk[k] - dlk[k];
                     const float safe = fabsf(sw) < (float)1e-4 ? 1.0f : sw;
                     const float num = cfl - dlk[k];
-                    const bool maybe = ii[k] >= 0 && (fgk[k] & 2u) &&
-                                       !((num < 0.0f && safe > 0.0f) || (num > 0.0f && safe < 0.0f) || fabsf(num) >= 1.001f * fabsf(safe));
+                    // (round 4: ONE test instead of a cascade of five exec-mask branches per round.  The filter only has to be
+                    // conservative -- the exact test is `valid` below: a product below zero means operands of opposite sign, a
+                    // product that underflows to zero is let through)
+                    const bool maybe = (ii[k] >= 0) & ((fgk[k] & 2u) != 0u) & !(num * safe < 0.0f) & !(fabsf(num) >= 1.001f * fabsf(safe));
                     if (maybe) {
                         const int i = ii[k];
-                        const float frac = gw_core_ok(num) ? gw_div_core(num, safe) : num / safe;
+                        const float frac = gw_div(num, safe);
                         const bool valid = frac >= 0.0f && frac < 1.0f;
                         const float iz = ndn[i] * (1.0f - frac) + ndn[i + 1] * frac;
                         if (valid && iz > z + (float)1e-6) {
@@ -448,7 +462,7 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
             }
             const float pos = fminf(fmaxf(s, 0.0f), sxw);
             const float p2 = pos * 2.0f;
-            float gx = ((sxw_ok && gw_core_ok(p2)) ? gw_div_with(p2, sxw, ysx) : p2 / sxw) - 1.0f;
+            float gx = gw_div_y(p2, sxw, ysx, sxw_ok) - 1.0f;
             float xx = (gx + 1.0f) * (sxw / 2.0f);
             xx = fminf(fmaxf(xx, 0.0f), sxw);
             const float xw = floorf(xx);
@@ -582,7 +596,7 @@ __device__ void mesh_stage_row(const GwArgs& A, const GwEye& E, const uint32_t* 
                 v = v / 255.0f;
             }
             const float num = v - dmin;
-            float nrm = (crange_ok && gw_core_ok(num)) ? gw_div_with(num, crange, yr) : num / crange;
+            float nrm = gw_div_y(num, crange, yr, crange_ok);
             nrm = has_range ? nrm : 0.0f;
             nd[x] = nrm;
             const float s = nrm - A.conv32;
