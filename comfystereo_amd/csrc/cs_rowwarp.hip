@@ -708,6 +708,22 @@ __device__ int poly_sequential_wave(const Poly& P, const Lds& L, int csg_cap_ref
 // What a pixel can touch: the 64 sorted points of the register window (and their right neighbours' columns), and the
 // segments in the list -- every ACTIVE segment (o -> o + 1) covers the sweep position x, and x - column(o) lies in
 // [coord_d(o), 1 + coord_d(o + 1)]: within `halo` columns of the pixel.  NoSlide: the whole row is resident (the row kernel).
+// wave maximum of finite / -inf floats, the same value in every lane: four row_shr steps inside the rows of 16, lanes 15 / 31 of
+// the lower rows broadcast into the upper ones (DPP; lanes without a source keep their own value), lane 63 holds the total
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    int b = __builtin_bit_cast(int, v);
+#define CS_DPP_FMAX(CTRL, ROWMASK)                                                                                          \
+    b = __builtin_bit_cast(int, __builtin_fmaxf(__builtin_bit_cast(float, b),                                                \
+                                                  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, CTRL, ROWMASK, 0xf, false))))
+    CS_DPP_FMAX(0x111, 0xf);
+    CS_DPP_FMAX(0x112, 0xf);
+    CS_DPP_FMAX(0x114, 0xf);
+    CS_DPP_FMAX(0x118, 0xf);
+    CS_DPP_FMAX(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    CS_DPP_FMAX(0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+#undef CS_DPP_FMAX
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 63));
+}
 struct NoSlide {
     static constexpr bool active = false;
     __device__ __forceinline__ bool points(int, int) const { return true; }
@@ -879,11 +895,20 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
                 }
                 float bc = (float)(-1e-7);
                 unsigned long long mm = __ballot(bc < cl);
-                while (mm) {
-                    const int b = __ffsll((long long)mm) - 1;
-                    mm &= mm - 1;
-                    const float v = rl_f(cl, b);
-                    if (bc < v) { bc = v; best = b; }
+                if (__popcll(mm) <= 4) {
+                    while (mm) {   // (a few candidates: a scalar pass over them)
+                        const int b = __ffsll((long long)mm) - 1;
+                        mm &= mm - 1;
+                        const float v = rl_f(cl, b);
+                        if (bc < v) { bc = v; best = b; }
+                    }
+                } else {
+                    // Long lists (depth noise: 25-50 entries): the scan's strict compare keeps the FIRST maximum, i.e. the lowest
+                    // lane that holds the wave maximum -- by DPP, not by 8 scalar instructions per candidate (round 4: with 20 such
+                    // waves per CU the replay kernel was bound by the CU's one scalar unit: 203 of 222 ms per 8 noise frames)
+                    const float clc = cl > -INFINITY ? cl : -INFINITY;   // (NaN -> -inf: the scan skips what does not compare greater)
+                    const float mx = wave_max_dpp(clc);
+                    if (bc < mx) best = __ffsll((long long)__ballot(clc == mx)) - 1;
                 }
             }
             // colour contribution of the winner (poly_accumulate with its end points from the registers)
@@ -2467,7 +2492,11 @@ struct DumpSlide {
     // (the caller re-bases its own pointers after every call: a Poly* in here would keep the row descriptor in memory)
     __device__ __forceinline__ void rebase_points(Poly& P) const { P.perm = permw - pb; }
     __device__ __forceinline__ void rebase_columns(Poly& P, Lds& L) const { P.cd = cdw - cb; L.img = imgw - 3 * cb; }
+    // (lo / hi are wave-uniform by construction, but some callers computed them through cross-lane shuffles, which the compiler
+    // must treat as divergent: `lost` and with it EVERY loop-carried value of the replay then lived in vector registers and
+    // every branch became an exec-mask branch -- on a kernel that is bound by the CU's scalar unit.  readfirstlane says so.)
     __device__ __forceinline__ bool points(int lo, int hi) {   // positions [lo, hi)
+        lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
         if (lo >= pb && hi <= pb + PWS) return true;
         if (hi - lo > PWS) return false;
         const int lane = threadIdx.x & 63;
@@ -2481,7 +2510,7 @@ struct DumpSlide {
         return max(lo, cmin) >= cb && min(hi, cmax) < cb + CWS;
     }
     __device__ __forceinline__ bool columns(int lo, int hi) {   // columns [lo, hi], clipped to the stretch's window
-        lo = max(lo, cmin); hi = min(hi, cmax);
+        lo = __builtin_amdgcn_readfirstlane(max(lo, cmin)); hi = __builtin_amdgcn_readfirstlane(min(hi, cmax));
         if (lo >= cb && hi < cb + CWS) return true;
         if (hi - lo + 1 > CWS) return false;
         const int lane = threadIdx.x & 63;
