@@ -160,3 +160,12 @@ def test_edge_threshold_equals_the_division():
         assert np.array_equal(got, want), float(den)
     for bad in (0.0, -1.0, float("inf"), float("nan")):
         assert L.cs_test_edge_threshold(bad) < 0
+
+
+def test_graft_entry_build_checks_the_current_abi_version():
+    """__graft_entry__.build() (the driver's "does it build" check) must compare cs_version() with _native.ABI_VERSION, not
+    with a literal: round 4 bumped the ABI to 3 and a literal 2 would have failed the build check on a correct tree."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "__graft_entry__.py")).read()
+    assert "_native.ABI_VERSION" in src
+    assert not re.search(r"cs_version\(\)\s*==\s*\d", src)
