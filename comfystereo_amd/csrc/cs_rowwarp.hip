@@ -751,8 +751,12 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
         csg_end = 1;
     }
     // window of the sorted points: lane k holds point perm[wbase + k]
+    // (round 4, end: the kernel is bound by the CU's scalar unit.  What a step reads about the point at sorted position k -- its x,
+    // and when the point becomes the start of a list entry: the x of its right neighbour in SOURCE order and both |disparities| --
+    // is fetched per lane when the window is loaded (vector instructions, 64 points at once) and picked up with v_readlane,
+    // instead of three accessor calls per added segment with their wave-uniform sentinel branches and LDS round trips.)
     int wbase = 0, wo = 0;
-    float wx = 0.0f;
+    float wx = 0.0f, wx1 = 0.0f, wz0 = 0.0f, wz1 = 0.0f;
     bool lost = false;   // the sweep position and the add pointer drifted more than a window apart (long runs of equal x)
     auto window = [&](int lo) {   // (two points of slack below: the sweep steps back by one at every pixel)
         wbase = max(lo - 2, 0);
@@ -769,9 +773,13 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
             }
         }
         wx = lost ? 0.0f : poly_x(P, wo);
+        const int wn = min(wo + 1, P.npt - 1);
+        wx1 = lost ? 0.0f : poly_x(P, wn);
+        wz0 = lost ? 0.0f : poly_z(P, wo);
+        wz1 = lost ? 0.0f : poly_z(P, wn);
     };
-    auto need = [&](int lo, int hi) {
-        if (lo < wbase || hi >= wbase + 64) { window(lo); lost = lost || hi >= wbase + 64; }
+    auto need = [&](int lo, int hi) {   // (lo <= hi; one unsigned compare: lo >= wbase and hi < wbase + 64)
+        if ((unsigned)(lo - wbase) > (unsigned)(63 - (hi - lo)) || hi - lo > 63) { window(lo); lost = lost || hi >= wbase + 64; }
     };
     int pt_i = pts_left_of_c0 - 1;   // (binoff[c0]: the number of points left of pixel c0; the sweep's own loop settles it)
     bool first_step = true;
@@ -857,8 +865,9 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
             if (lost) return -2;
             while (sg_pointer < sg_end && rl_f(wx, sg_pointer - wbase) < s.center) {
                 if (csg_end >= cap) return -1;
-                const int o = __builtin_amdgcn_readlane(wo, sg_pointer - wbase);
-                const float nx0 = rl_f(wx, sg_pointer - wbase), nx1 = poly_x(P, o + 1), nz0 = poly_z(P, o), nz1 = poly_z(P, o + 1);
+                const int wk = sg_pointer - wbase;
+                const int o = __builtin_amdgcn_readlane(wo, wk);
+                const float nx0 = rl_f(wx, wk), nx1 = rl_f(wx1, wk), nz0 = rl_f(wz0, wk), nz1 = rl_f(wz1, wk);
                 if (lane == csg_end) { e_o = o; e_x0 = nx0; e_x1 = nx1; e_z0 = nz0; e_z1 = nz1; }
                 csg_end++; sg_pointer++;
                 need(min(pt_i, sg_pointer), max(pt_i + 1, sg_pointer));
@@ -935,7 +944,7 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
                 }
             }
             pt_i++;
-            need(pt_i, pt_i + 1);
+            need(pt_i, pt_i + 1);   // (the loop condition and the next step's sub-interval read positions pt_i and pt_i + 1)
             if (lost) return -2;
         }
         if (lane == 0) emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));

@@ -9,7 +9,7 @@ timeout 900 python bench.py > gpurun_out/${TAG}_bench_default.json 2>/dev/null
 O=gpurun_out/${TAG}_ties; mkdir -p $O
 for k in clipped random8; do
   timeout 900 python bench.py --depth $k --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_${k}_blur_on.json 2>/dev/null
-  timeout 1800 python bench.py --depth $k --no-blur --steps 2 --warmup 1 --no-cpu-baseline --frames $([ $k = random8 ] && echo 8 || echo 64) > $O/bench_${k}_blur_off.json 2>/dev/null
+  timeout 1800 python bench.py --depth $k --no-blur --steps 2 --warmup 1 --no-cpu-baseline --frames 64 > $O/bench_${k}_blur_off.json 2>/dev/null
   for b in on off; do python3 -c "
 import json; j=json.load(open('$O/bench_${k}_blur_$b.json')); print('$k blur $b', round(j['value'],1), 'fps', round(j['ms_per_step'],1), 'ms', j['config']['frames_total'], 'frames', j['diagnostics'])"; done
 done 2>&1 | tee $O/summary.txt
