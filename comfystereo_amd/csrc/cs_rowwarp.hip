@@ -2350,7 +2350,15 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
                 // (eyes in separate output slots: the stretches of order-dependent rows may go to the replay kernel)
                 const RpCtx X{A.anaglyph ? nullptr : A.rp_dump, A.rp_list, A.rp_ctr, A.rp_pool16, A.rp_cap,
                               (uint32_t)frame * (uint32_t)A.h + (uint32_t)row, e, A.rp_ctr ? (uint8_t*)A.rp_ctr + 256 : nullptr};
-                technique_polylines<FILL == CS_FILL_POLYLINES_SHARP ? 1 : 0, DIALECT, decltype(out), LEAN>(L, w, E, A.e32, st_rw, out, A.dbg, &X, A.d64, A.e64);
+                // (lean instantiation: 64 VGPRs / 80 SGPRs, ~340 scalar and ~77 vector registers spilled.  The row's width and the
+                // LDS base re-read through an opaque move per eye -- what the compiler derives from them is recomputed instead of
+                // carried across the eye loop: 336 -> 278 scalar, 77 -> 48 vector spills; the same trick as in k_gpuwarp)
+                int we = w, l0 = 0;
+#ifndef RW_NO_LAUNDER
+                if (LEAN) asm volatile("" : "+s"(we), "+s"(l0));
+#endif
+                const Lds Le = carve(smem + l0, FILL, we, A.anaglyph);
+                technique_polylines<FILL == CS_FILL_POLYLINES_SHARP ? 1 : 0, DIALECT, decltype(out), LEAN>(Le, we, E, A.e32, st_rw, out, A.dbg, &X, A.d64, A.e64);
             }
             else if (FILL == CS_FILL_HYBRID_EDGE_PLUS) {
                 // hybrid_edge into `res`, then the polylines_soft row into `alt`; pixels that stayed black take the latter
