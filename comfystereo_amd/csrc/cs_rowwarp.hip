@@ -724,6 +724,23 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 #undef CS_DPP_FMAX
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 63));
 }
+// Everything the replay wants to know about point `o` (per lane or uniform) without branches: the sentinels (o <= 0, o >= npt - 1)
+// are selected, their column is the clamped one -- poly_x / poly_z / poly_col with their early returns cost exec-mask regions per
+// accessor and, evaluated per lane for 64 window points, enough registers to spill.  D32 only for x (P.xd: the accessor).
+// (values through references: a struct result went through scratch memory)
+__device__ __forceinline__ void poly_point(const Poly& P, const Lds& L, int o, float& px, float& pz, uint32_t& prgb, int& pcol) {
+    const int last = P.npt - 1;
+    const int c = min(max(P.sharp ? (o - 1) >> 1 : o - 1, 0), P.w - 1);
+    const float cdv = P.cd[c];
+    float x = ((float)c + 0.5f + cdv) + P.sep32;
+    if (P.sharp) x = ((o - 1) & 1) ? x + (float)0.45 : x - (float)0.45;
+    x = o <= 0 ? (float)(-1.0 * P.w) : (o >= last ? (float)(2.0 * P.w) : x);
+    if (P.xd) x = poly_x(P, o);
+    px = x;
+    pz = (o <= 0 || o >= last) ? 0.0f : fabsf(cdv);
+    pcol = c;
+    prgb = (uint32_t)L.img[3 * c] | ((uint32_t)L.img[3 * c + 1] << 8) | ((uint32_t)L.img[3 * c + 2] << 16);
+}
 struct NoSlide {
     static constexpr bool active = false;
     __device__ __forceinline__ bool points(int, int) const { return true; }
@@ -745,9 +762,17 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
     // entry `lane` of the list
     int e_o = 0;
     float e_x0 = 0.0f, e_x1 = 0.0f, e_z0 = 0.0f, e_z1 = 0.0f;
+    // ... and the colour codes of its two end points' source pixels (r | g << 8 | b << 16; bit 24 of the first: both ends are the
+    // same source pixel -- the flat typing of :1981-1984): every entry works out its own contribution in parallel and the winner's is
+    // read with v_readlane, instead of a wave-uniform walk (column tests, six LDS reads) on the scalar unit that bounds this kernel
+    uint32_t e_c0 = 0, e_c1 = 0;
     int csg_end = 0, sg_pointer = sgp0;
     if (seg0 >= 0) {
-        e_o = seg0; e_x0 = poly_x(P, seg0); e_x1 = poly_x(P, seg0 + 1); e_z0 = poly_z(P, seg0); e_z1 = poly_z(P, seg0 + 1);
+        int ca, cb;
+        e_o = seg0;
+        poly_point(P, L, seg0, e_x0, e_z0, e_c0, ca);
+        poly_point(P, L, seg0 + 1, e_x1, e_z1, e_c1, cb);
+        e_c0 |= ca == cb ? 1u << 24 : 0u;
         csg_end = 1;
     }
     // window of the sorted points: lane k holds point perm[wbase + k]
@@ -757,6 +782,7 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
     // instead of three accessor calls per added segment with their wave-uniform sentinel branches and LDS round trips.)
     int wbase = 0, wo = 0;
     float wx = 0.0f, wx1 = 0.0f, wz0 = 0.0f, wz1 = 0.0f;
+    uint32_t wc0 = 0, wc1 = 0;
     bool lost = false;   // the sweep position and the add pointer drifted more than a window apart (long runs of equal x)
     auto window = [&](int lo) {   // (two points of slack below: the sweep steps back by one at every pixel)
         wbase = max(lo - 2, 0);
@@ -772,11 +798,11 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
                 slide.rebase_columns(P, L);
             }
         }
-        wx = lost ? 0.0f : poly_x(P, wo);
-        const int wn = min(wo + 1, P.npt - 1);
-        wx1 = lost ? 0.0f : poly_x(P, wn);
-        wz0 = lost ? 0.0f : poly_z(P, wo);
-        wz1 = lost ? 0.0f : poly_z(P, wn);
+        if (lost) { wx = wx1 = wz0 = wz1 = 0.0f; wc0 = wc1 = 0u; return; }
+        int ca, cb;
+        poly_point(P, L, wo, wx, wz0, wc0, ca);
+        poly_point(P, L, min(wo + 1, P.npt - 1), wx1, wz1, wc1, cb);
+        wc0 |= ca == cb ? 1u << 24 : 0u;
     };
     auto need = [&](int lo, int hi) {   // (lo <= hi; one unsigned compare: lo >= wbase and hi < wbase + 64)
         if ((unsigned)(lo - wbase) > (unsigned)(63 - (hi - lo)) || hi - lo > 63) { window(lo); lost = lost || hi >= wbase + 64; }
@@ -854,7 +880,11 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
                 }
                 wave_lds_sync();
                 if (lane < ns_total) {
-                    e_o = my_o; e_x0 = poly_x(P, my_o); e_x1 = poly_x(P, my_o + 1); e_z0 = poly_z(P, my_o); e_z1 = poly_z(P, my_o + 1);
+                    int ca, cb;
+                    e_o = my_o;
+                    poly_point(P, L, my_o, e_x0, e_z0, e_c0, ca);
+                    poly_point(P, L, my_o + 1, e_x1, e_z1, e_c1, cb);
+                    e_c0 |= ca == cb ? 1u << 24 : 0u;
                 }
                 csg_end = ns_total; sg_pointer = K;
                 window(min(pt_i, sg_pointer));
@@ -868,7 +898,8 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
                 const int wk = sg_pointer - wbase;
                 const int o = __builtin_amdgcn_readlane(wo, wk);
                 const float nx0 = rl_f(wx, wk), nx1 = rl_f(wx1, wk), nz0 = rl_f(wz0, wk), nz1 = rl_f(wz1, wk);
-                if (lane == csg_end) { e_o = o; e_x0 = nx0; e_x1 = nx1; e_z0 = nz0; e_z1 = nz1; }
+                const uint32_t nc0 = (uint32_t)__builtin_amdgcn_readlane((int)wc0, wk), nc1 = (uint32_t)__builtin_amdgcn_readlane((int)wc1, wk);
+                if (lane == csg_end) { e_o = o; e_x0 = nx0; e_x1 = nx1; e_z0 = nz0; e_z1 = nz1; e_c0 = nc0; e_c1 = nc1; }
                 csg_end++; sg_pointer++;
                 need(min(pt_i, sg_pointer), max(pt_i + 1, sg_pointer));
                 if (lost) return -2;
@@ -888,19 +919,21 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
                     const int src = hole ? (int)srcpos[__popcll(holes & ((1ull << lane) - 1ull))] : lane;
                     const int mo = __shfl(e_o, src);
                     const float mx0 = __shfl(e_x0, src), mx1 = __shfl(e_x1, src), mz0 = __shfl(e_z0, src), mz1 = __shfl(e_z1, src);
-                    if (hole) { e_o = mo; e_x0 = mx0; e_x1 = mx1; e_z0 = mz0; e_z1 = mz1; }
+                    const uint32_t mc0 = (uint32_t)__shfl((int)e_c0, src), mc1 = (uint32_t)__shfl((int)e_c1, src);
+                    if (hole) { e_o = mo; e_x0 = mx0; e_x1 = mx1; e_z0 = mz0; e_z1 = mz1; e_c0 = mc0; e_c1 = mc1; }
                     wave_lds_sync();
                 }
                 csg_end = ns;
             }
-            // ---- selection: first maximum of the closeness over the list (strict compare)
+            // ---- selection: first maximum of the closeness over the list (strict compare).  Every entry computes its interpolation
+            // weight once -- for the closeness and for its colour contribution
             int best = 0;
+            const float ip_e = (s.center - e_x0) / (e_x1 - e_x0);
             if (csg_end != 1) {
                 float cl = -INFINITY;
                 if (lane < csg_end) {
-                    const float ip_k = (s.center - e_x0) / (e_x1 - e_x0);
-                    const float c = (1.0f - ip_k) * e_z0 + ip_k * e_z1;
-                    if (0.0f < ip_k && ip_k < 1.0f) cl = c;
+                    const float c = (1.0f - ip_e) * e_z0 + ip_e * e_z1;
+                    if (0.0f < ip_e && ip_e < 1.0f) cl = c;
                 }
                 float bc = (float)(-1e-7);
                 unsigned long long mm = __ballot(bc < cl);
@@ -920,27 +953,28 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
                     if (bc < mx) best = __ffsll((long long)__ballot(clc == mx)) - 1;
                 }
             }
-            // colour contribution of the winner (poly_accumulate with its end points from the registers)
+            // ---- colour contribution of the winner (poly_accumulate's arithmetic, :1981-1989): worked out by every entry for itself
+            // (vector instructions, no LDS), the winner's three values picked up with v_readlane
             {
-                const int seg = __builtin_amdgcn_readlane(e_o, best);
-                const int col_l = poly_col(P, seg), col_r = poly_col(P, seg + 1);
-                if (col_l == col_r) {
+                const bool flat_e = (e_c0 >> 24) != 0u;
+                const float om = 1.0f - ip_e;
+                const float sg = s.sig64 ? (float)s.sig_d : s.sig_f;
+                float t[3];
 #pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        if (s.sig64) color[c] = (float)((double)color[c] + (double)L.img[3 * col_l + c] * s.sig_d);
-                        else color[c] = color[c] + (float)L.img[3 * col_l + c] * s.sig_f;
-                    }
+                for (int c = 0; c < 3; c++) {
+                    const float il = (float)((e_c0 >> (8 * c)) & 0xffu), ir = (float)((e_c1 >> (8 * c)) & 0xffu);
+                    const float a = il * om;
+                    const float b = ir * ip_e;
+                    t[c] = flat_e ? il * s.sig_f : (a + b) * sg;
+                }
+                const bool flat_w = (((uint32_t)__builtin_amdgcn_readlane((int)e_c0, best)) >> 24) != 0u;
+                if (flat_w && s.sig64) {   // (both ends one source pixel, whole-pixel piece: the float64 typing of :1983)
+                    const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane((int)e_c0, best);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) color[c] = (float)((double)color[c] + (double)(uint8_t)((cw >> (8 * c)) & 0xffu) * s.sig_d);
                 } else {
-                    const float x0 = rl_f(e_x0, best), x1 = rl_f(e_x1, best);
-                    const float ip_k = (s.center - x0) / (x1 - x0);
-                    const float om = 1.0f - ip_k;
-                    const float sg = s.sig64 ? (float)s.sig_d : s.sig_f;
 #pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const float a = (float)L.img[3 * col_l + c] * om;
-                        const float b = (float)L.img[3 * col_r + c] * ip_k;
-                        color[c] = color[c] + (a + b) * sg;
-                    }
+                    for (int c = 0; c < 3; c++) color[c] = color[c] + rl_f(t[c], best);
                 }
             }
             pt_i++;
