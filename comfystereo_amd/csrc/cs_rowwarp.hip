@@ -753,8 +753,7 @@ template <class Emit, class Slide>
 __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit& emit, int c0, int c1, int seg0,
                                    int sgp0, uint16_t* srcpos, int pts_left_of_c0, Slide& slide, int halo) {
     const int lane = threadIdx.x & 63;
-    int col_cur = c0;
-    if (!slide.columns(c0 - halo, c0 + halo)) return -2;
+    if (!slide.columns(c0 - halo, c0 + halo)) return -2;   // (the start segment's end points, read below)
     slide.rebase_columns(P, L);
     const int sg_end = P.npt - 1;
     const int cap = min(min(csg_cap_ref, P.cap), 64);
@@ -790,7 +789,7 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
         slide.rebase_points(P);
         wo = P.perm[min(wbase + lane, P.npt - 1)];
         if (Slide::active) {   // the columns of these points and of their right neighbours, next to the active segments'
-            int cl = min(poly_col(P, wo), col_cur - halo), ch = max(poly_col(P, min(wo + 1, P.npt - 1)), col_cur + halo);
+            int cl = poly_col(P, wo), ch = poly_col(P, min(wo + 1, P.npt - 1));
             if (!__all(slide.holds(cl, ch))) {   // (one ballot in the usual case; the wave-wide range only for a refill)
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { cl = min(cl, __shfl_xor(cl, d)); ch = max(ch, __shfl_xor(ch, d)); }
@@ -813,9 +812,8 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
     if (lost) return -2;
     for (int col = c0; col <= c1; col++) {
         float color[3] = {0.5f, 0.5f, 0.5f};
-        col_cur = col;
-        if (!slide.columns(col - halo, col + halo)) return -2;
-        slide.rebase_columns(P, L);
+        // (no column window to keep around the pixel any more: since every list entry carries its end points' data -- x, |disparity|,
+        // colour codes, fetched when its point was in the register window -- the sweep reads source columns only in window())
         need(pt_i, pt_i + 1);
         while (!lost && rl_f(wx, pt_i - wbase) < (float)col) { pt_i++; need(pt_i, pt_i + 1); }
         pt_i--;
