@@ -2470,7 +2470,11 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
 // One workgroup per row (both eyes); or, behind the tiled polylines path, a fixed number of workgroups working off the
 // list of rows that path flagged (`row_list`: frame * h + row) -- usually empty, so nothing the size of the batch is launched.
 template <int FILL, bool DIALECT = false, bool LEAN = false>
-__global__ void __launch_bounds__(1024, LEAN ? 8 : 4) k_rowwarp(RowArgs A) {
+#ifndef RW_LEAN_NT
+#define RW_LEAN_NT 1024   // threads of the lean instantiation's workgroups and the waves per SIMD its register budget is sized for
+#define RW_LEAN_W 8       // (two workgroups share a CU either way: 1024 x 8 = 64 VGPRs; 768 x 6 = 85 VGPRs, five pixels per lane)
+#endif
+__global__ void __launch_bounds__(LEAN ? RW_LEAN_NT : 1024, LEAN ? RW_LEAN_W : 4) k_rowwarp(RowArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ONE call site of the (force-inlined) row function: as a real call it takes the argument struct by reference, i.e. a
     // 340-byte scratch copy per lane and scratch set-up at every wave launch (28 -> 210 us for the usual EMPTY flagged-row pass)
@@ -2728,8 +2732,9 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
             ? hipFuncSetAttribute((const void*)k_rowwarp<CS_FILL_POLYLINES_SOFT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
             : hipFuncSetAttribute((const void*)k_rowwarp<CS_FILL_POLYLINES_SHARP, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        if (fill == CS_FILL_POLYLINES_SOFT) hipLaunchKernelGGL((k_rowwarp<CS_FILL_POLYLINES_SOFT, false, true>), grid, block, lds, stream, A);
-        else hipLaunchKernelGGL((k_rowwarp<CS_FILL_POLYLINES_SHARP, false, true>), grid, block, lds, stream, A);
+        const dim3 lblock(threads < RW_LEAN_NT ? threads : RW_LEAN_NT);
+        if (fill == CS_FILL_POLYLINES_SOFT) hipLaunchKernelGGL((k_rowwarp<CS_FILL_POLYLINES_SOFT, false, true>), grid, lblock, lds, stream, A);
+        else hipLaunchKernelGGL((k_rowwarp<CS_FILL_POLYLINES_SHARP, false, true>), grid, lblock, lds, stream, A);
         return hipGetLastError();
     }
     if ((A.d64 & 3) && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP)) {   // the dialect instantiations
