@@ -803,9 +803,16 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
         poly_point(P, L, min(wo + 1, P.npt - 1), wx1, wz1, wc1, cb);
         wc0 |= ca == cb ? 1u << 24 : 0u;
     };
-    auto need = [&](int lo, int hi) {   // (lo <= hi; one unsigned compare: lo >= wbase and hi < wbase + 64)
-        if ((unsigned)(lo - wbase) > (unsigned)(63 - (hi - lo)) || hi - lo > 63) { window(lo); lost = lost || hi >= wbase + 64; }
-    };
+    // positions [lo, hi] (lo <= hi) must be in the register window: one unsigned compare (lo >= wbase and hi < wbase + 64); the
+    // "cannot be held" exit sits inside the rare refill path, so the steady-state step carries no `lost` test at all
+#define RP_NEED(LO, HI)                                                                                     \
+    do {                                                                                                    \
+        const int lo_ = (LO), hi_ = (HI);                                                                   \
+        if ((unsigned)(lo_ - wbase) > (unsigned)(63 - (hi_ - lo_)) || hi_ - lo_ > 63) {                     \
+            window(lo_);                                                                                    \
+            if (lost || hi_ >= wbase + 64) return -2;                                                       \
+        }                                                                                                   \
+    } while (0)
     int pt_i = pts_left_of_c0 - 1;   // (binoff[c0]: the number of points left of pixel c0; the sweep's own loop settles it)
     bool first_step = true;
     window(seg0 < 0 ? pt_i : min(pt_i, sg_pointer));
@@ -814,11 +821,10 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
         float color[3] = {0.5f, 0.5f, 0.5f};
         // (no column window to keep around the pixel any more: since every list entry carries its end points' data -- x, |disparity|,
         // colour codes, fetched when its point was in the register window -- the sweep reads source columns only in window())
-        need(pt_i, pt_i + 1);
-        while (!lost && rl_f(wx, pt_i - wbase) < (float)col) { pt_i++; need(pt_i, pt_i + 1); }
+        RP_NEED(pt_i, pt_i + 1);
+        while (rl_f(wx, pt_i - wbase) < (float)col) { pt_i++; RP_NEED(pt_i, pt_i + 1); }
         pt_i--;
-        need(pt_i, pt_i + 1);
-        if (lost) return -2;
+        RP_NEED(pt_i, pt_i + 1);
         while (rl_f(wx, pt_i - wbase) < (float)(col + 1)) {
             const SubInt s = poly_subinterval(col, rl_f(wx, pt_i - wbase), rl_f(wx, pt_i + 1 - wbase));
             if (first_step && seg0 < 0) {
@@ -889,8 +895,7 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
                 if (lost) return -2;
             }
             first_step = false;
-            need(min(pt_i, sg_pointer), max(pt_i + 1, sg_pointer));
-            if (lost) return -2;
+            RP_NEED(min(pt_i, sg_pointer), max(pt_i + 1, sg_pointer));
             while (sg_pointer < sg_end && rl_f(wx, sg_pointer - wbase) < s.center) {
                 if (csg_end >= cap) return -1;
                 const int wk = sg_pointer - wbase;
@@ -899,8 +904,7 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
                 const uint32_t nc0 = (uint32_t)__builtin_amdgcn_readlane((int)wc0, wk), nc1 = (uint32_t)__builtin_amdgcn_readlane((int)wc1, wk);
                 if (lane == csg_end) { e_o = o; e_x0 = nx0; e_x1 = nx1; e_z0 = nz0; e_z1 = nz1; e_c0 = nc0; e_c1 = nc1; }
                 csg_end++; sg_pointer++;
-                need(min(pt_i, sg_pointer), max(pt_i + 1, sg_pointer));
-                if (lost) return -2;
+                RP_NEED(min(pt_i, sg_pointer), max(pt_i + 1, sg_pointer));
             }
             // ---- removal: the closed form of the swap-remove scan (poly_sequential_wave) on ballots
             const int n = csg_end;
@@ -976,12 +980,12 @@ __device__ int poly_replay_stretch(Poly& P, Lds& L, int csg_cap_ref, const Emit&
                 }
             }
             pt_i++;
-            need(pt_i, pt_i + 1);   // (the loop condition and the next step's sub-interval read positions pt_i and pt_i + 1)
-            if (lost) return -2;
+            RP_NEED(pt_i, pt_i + 1);   // (the loop condition and the next step's sub-interval read positions pt_i and pt_i + 1)
         }
         if (lane == 0) emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
     }
     return 0;
+#undef RP_NEED
 }
 
 // rasterise the forward segments into per-pixel lists; PASS 0 counts, PASS 1 fills

@@ -50,7 +50,7 @@ while time.time() - t0 < budget:
     rng = np.random.default_rng(seed); seed += 1
     n, h, w = int(rng.integers(1, 4)), int(rng.integers(8, 70)), int(rng.choice([64, 200, 516, 1028, 1540]))
     img = synth.image_f32(n, h, w, seed=seed)
-    depth = synth.depth_batch(str(rng.choice(["blobs", "stepped", "radial", "noisy_ramp", "clipped", "clipped"])), n, h, w, channels=3)
+    depth = synth.depth_batch(str(rng.choice(["blobs", "stepped", "radial", "noisy_ramp", "clipped", "clipped", "random8"])), n, h, w, channels=3)
     fill = str(rng.choice([f for f in FILLS if f in ui] + ["gpu_warp"]))  # (node level: the techniques a UI string reaches)
     args = (float(rng.choice([2.0, 5.0, 8.0, 12.0])), float(rng.choice([0.0, 0.5, -1.0])), str(rng.choice(modes)),
             float(rng.choice([0.0, 0.3, -0.5])), float(rng.choice([0.0, 0.5, 1.0])), float(rng.choice([1.0, 2.0, 1.4])))
