@@ -1056,7 +1056,7 @@ int cs_profile(int enable) {
 int cs_debug_set(int key, int value) {
     if (key < 0 || key >= CS_DEBUG_KEYS) return fail(CS_EINVAL, "cs_debug_set: unknown key");
 #ifndef CS_DEV
-    if (key == CS_DEBUG_DBG && value != 0 && value != 14 && value != 17)
+    if (key == CS_DEBUG_DBG && value != 0 && value != 14 && value != 17 && value != 30 && value != 31)   // (30 / 31: column ranges of the polylines row kernel forced / off: same pixels)
         return fail(CS_EINVAL, "cs_debug_set: this CS_DEBUG_DBG value needs a -DCS_DEV build (phase cut-offs leave outputs unwritten)");
 #endif
     g_dev[key].store(value, std::memory_order_relaxed);

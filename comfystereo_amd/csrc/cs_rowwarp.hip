@@ -1089,28 +1089,65 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
     // P3a/b: per-pixel lists of the forward segments that can be active inside the pixel (CSR).
     // Segments spanning > 3 pixels (disocclusion bridges) are rasterised cooperatively, 64 pixels
     // per wave step, instead of serialising one lane.
-    int local = 0;
-    for (int o = tid; o < npt - 1; o += nt) {
-        int p0, p1;
-        poly_seg_pixels<0>(P, o, p0, p1);
-        if (p0 > p1) continue;
-        if (p1 - p0 <= 2) {
-            for (int p = p0; p <= p1; p++) atomic_add_u16(P.segoff, p + 1, 1);
-            local += p1 - p0 + 1;
-        } else {
-            int idx = atomicAdd(nlong, 1);
-            if (idx < LONGCAP) P.longs[idx] = (uint16_t)o;
-            local += p1 - p0 + 1;
+    // Column RANGES (round 4): the lists of all pixels together may not fit `entries` (polylines_sharp rows beyond 6 950 columns:
+    // 3.0 entries per column needed, 2.9 left by the LDS) -- then the row is evaluated in 2 .. 4 ranges of columns, each with its
+    // own count / scan / fill / evaluate over the same arrays (segments clipped to the range; boundaries on multiples of 64 so that
+    // every hazard / reset word belongs to one range).  The long-segment list of the ranges after the first lives in the (dead
+    // since P1) table block, because the first range's hazard / reset words already sit in P.longs.  One range = the old flow.
+    int nr = 1;
+    bool overflow = false;
+    bool ranged = false;
+    for (int r = 0; r < nr && !overflow; r++) {
+        const int cA = nr == 1 ? 0 : (int)(((long long)w * r / nr) & ~63LL);
+        const int cB = (nr == 1 || r == nr - 1) ? w : (int)(((long long)w * (r + 1) / nr) & ~63LL);
+        uint16_t* const longs_r = r == 0 ? P.longs : (uint16_t*)L.tabs;
+        const int longcap_r = r == 0 ? LONGCAP : (int)(sizeof(csm::PowfTables) / 2);
+        if (r > 0 || ranged) {   // (a fresh count: the whole-row pass below only told us that ranges are needed)
+            for (int i = tid; i < (w + 2) / 2; i += nt) ((unsigned*)P.segoff)[i] = 0;
+            if (tid == 0) { *nlong = 0; *ntotal = 0; }
+            __syncthreads();
         }
-    }
-    atomicAdd(ntotal, local);
-    __syncthreads();
-    const int nl = min(*nlong, LONGCAP);
-    const bool overflow = *nlong > LONGCAP || *ntotal > P.cap;
-    if (!overflow) {
+        int local = 0;
+        for (int o = tid; o < npt - 1; o += nt) {
+            int p0, p1;
+            poly_seg_pixels<0>(P, o, p0, p1);
+            p0 = max(p0, cA); p1 = min(p1, cB - 1);
+            if (p0 > p1) continue;
+            if (p1 - p0 <= 2) {
+                for (int p = p0; p <= p1; p++) atomic_add_u16(P.segoff, p + 1, 1);
+                local += p1 - p0 + 1;
+            } else {
+                int idx = atomicAdd(nlong, 1);
+                if (idx < longcap_r) longs_r[idx] = (uint16_t)o;
+                local += p1 - p0 + 1;
+            }
+        }
+        atomicAdd(ntotal, local);
+        __syncthreads();
+        const int nl = min(*nlong, longcap_r);
+        const bool over_r = *nlong > longcap_r || *ntotal > P.cap;
+        if (over_r && nr == 1 && !ranged && !DIALECT && *nlong <= LONGCAP && *ntotal <= 4 * (P.cap - P.cap / 8) && *ntotal < 60000 &&
+            w >= 256 && dbg != 31) {
+            // too many entries for one pass, few enough for up to four: start over in ranges
+            nr = min(4, (*ntotal + (P.cap - P.cap / 8) - 1) / (P.cap - P.cap / 8));
+            nr = max(nr, 2);
+            ranged = true;
+            r = -1;
+            __syncthreads();
+            continue;
+        }
+        if (!over_r && nr == 1 && !ranged && dbg == 30 && w >= 256 && !DIALECT) {   // (development: two ranges although one would do)
+            nr = 2; ranged = true; r = -1;
+            __syncthreads();
+            continue;
+        }
+        overflow = over_r;
+        if (overflow) break;
+        {
         for (int li = wave; li < nl; li += nwaves) {
             int p0, p1;
-            poly_seg_pixels<0>(P, P.longs[li], p0, p1);
+            poly_seg_pixels<0>(P, longs_r[li], p0, p1);
+            p0 = max(p0, cA); p1 = min(p1, cB - 1);
             for (int p = p0 + lane; p <= p1; p += 64) atomic_add_u16(P.segoff, p + 1, 1);
         }
         __syncthreads();
@@ -1118,12 +1155,14 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         for (int o = tid; o < npt - 1; o += nt) {
             int p0, p1;
             poly_seg_pixels<1>(P, o, p0, p1);
+            p0 = max(p0, cA); p1 = min(p1, cB - 1);
             if (p0 > p1 || p1 - p0 > 2) continue;
             for (int p = p0; p <= p1; p++) P.entries[atomic_add_u16(P.segoff, p, 1)] = (uint16_t)o;
         }
         for (int li = wave; li < nl; li += nwaves) {
-            int p0, p1, o = P.longs[li];
+            int p0, p1, o = longs_r[li];
             poly_seg_pixels<1>(P, o, p0, p1);
+            p0 = max(p0, cA); p1 = min(p1, cB - 1);
             for (int p = p0 + lane; p <= p1; p += 64) P.entries[atomic_add_u16(P.segoff, p, 1)] = (uint16_t)o;
         }
         __syncthreads();
@@ -1190,10 +1229,10 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         // rows over the (idle) long-segment array
         unsigned long long* hzw = (unsigned long long*)P.longs;
         unsigned long long* rsw = hzw + ((w + 63) >> 6);
-        for (int colb = 0; colb < w; colb += nt) {
+        for (int colb = cA; colb < cB; colb += nt) {
             const int col = colb + tid;
             bool hazard = false, reset = false;
-            if (col < w) {
+            if (col < cB) {
                 float color[3] = {0.5f, 0.5f, 0.5f};
                 const int pos0 = P.binoff[col], pos1 = P.binoff[col + 1];  // bin col+1 = [col, col+1)
                 const int ls = col > 0 ? P.segoff[col - 1] : 0, le = P.segoff[col];
@@ -1236,9 +1275,16 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                 else emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
             }
             const unsigned long long hm = __ballot(hazard), rm = __ballot(reset);
-            if (lane == 0 && colb + 64 * wave < w && w <= 8192) { hzw[(colb >> 6) + wave] = hm; rsw[(colb >> 6) + wave] = rm; }
+            if (lane == 0 && colb + 64 * wave < cB && w <= 8192) { hzw[(colb >> 6) + wave] = hm; rsw[(colb >> 6) + wave] = rm; }
         }
         }
+        }
+        __syncthreads();   // (the next range reuses segoff / entries)
+    }
+    if (ranged) {   // the table block served as the later ranges' long-segment list: the row's next eye reads it again (disparity())
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_powf_tables);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(L.tabs);
+        for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += nt) dst[i] = src[i];
     }
     __syncthreads();
     if (DIALECT && (d64 & 2)) {
@@ -1252,6 +1298,16 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         __syncthreads();
         return;
     }
+    // the one segment active at `center` (a reset pixel's last sub-interval) without the pixel's list: a wave-wide scan over the
+    // row's segments (rows evaluated in column ranges keep only the last range's lists)
+    auto active_segment_at = [&](float center) -> int {
+        int found = -1;
+        for (int o = lane; o < npt - 1; o += 64)
+            if (poly_x(P, o) < center && !(poly_x(P, o + 1) < center)) found = o;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) found = max(found, __shfl_xor(found, d));
+        return found;
+    };
     // ---- order-dependent pixels: replay the stretches between reset points, one wave per stretch (poly_replay_stretch)
     constexpr int NSTR = 256;           // stretches per row
     int* nstretch = L.misc + 3;
@@ -1323,10 +1379,13 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                     const int r = c0 - 1;
                     const int pos1 = P.binoff[r + 1];
                     const SubInt sb = poly_subinterval(r, poly_x(P, P.perm[pos1 - 1]), poly_x(P, P.perm[pos1]));
-                    const int ls = r > 0 ? P.segoff[r - 1] : 0, le = P.segoff[r];
-                    for (int e = ls; e < le; e++) {
-                        const int o = P.entries[e];
-                        if (poly_x(P, o) < sb.center && !(poly_x(P, o + 1) < sb.center)) seg0 = o;
+                    if (ranged) seg0 = active_segment_at(sb.center);   // (the lists of the earlier column ranges are gone)
+                    else {
+                        const int ls = r > 0 ? P.segoff[r - 1] : 0, le = P.segoff[r];
+                        for (int e = ls; e < le; e++) {
+                            const int o = P.entries[e];
+                            if (poly_x(P, o) < sb.center && !(poly_x(P, o + 1) < sb.center)) seg0 = o;
+                        }
                     }
                     sgp0 = pos1;
                     while (sgp0 > 0 && !(poly_x(P, P.perm[sgp0 - 1]) < sb.center)) sgp0--;
@@ -1405,10 +1464,13 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                     const int r = c0 - 1;
                     const int pos1 = P.binoff[r + 1];
                     const SubInt s = poly_subinterval(r, poly_x(P, P.perm[pos1 - 1]), poly_x(P, P.perm[pos1]));
-                    const int ls = r > 0 ? P.segoff[r - 1] : 0, le = P.segoff[r];
-                    for (int e = ls; e < le; e++) {
-                        const int o = P.entries[e];
-                        if (poly_x(P, o) < s.center && !(poly_x(P, o + 1) < s.center)) seg0 = o;
+                    if (ranged) seg0 = active_segment_at(s.center);
+                    else {
+                        const int ls = r > 0 ? P.segoff[r - 1] : 0, le = P.segoff[r];
+                        for (int e = ls; e < le; e++) {
+                            const int o = P.entries[e];
+                            if (poly_x(P, o) < s.center && !(poly_x(P, o + 1) < s.center)) seg0 = o;
+                        }
                     }
                     sgp0 = pos1;
                     while (sgp0 > 0 && !(poly_x(P, P.perm[sgp0 - 1]) < s.center)) sgp0--;

@@ -250,11 +250,39 @@ def test_8k_sharp_rows_with_ties(engine, kind):
         assert np.array_equal(g, w_), (kind, name)
 
 
-def test_order_dependent_rows_take_the_wave_replay(engine):
-    """Noise depth on 8-bit levels ties everywhere (equal |disparity| on overlapping layers): every row is order-dependent
-    and goes through the sequential replay of the reference's active list -- done by a whole wave since round 2.  Bit-exact
-    against the oracle, at a width that spans several tiles, both polylines variants, plus the single-lane form (the wave
-    form's fallback) through its development switch where the build allows it."""
+@pytest.mark.parametrize("kind", ["clipped", "random8", "stepped"])
+def test_row_kernel_column_ranges(engine, dev_switch, kind):
+    """The polylines row kernel evaluates a row whose per-pixel segment lists do not fit its LDS in 2 .. 4 column ranges (wide
+    polylines_sharp rows need that; cs_debug_set(dbg, 30) forces two ranges on any row): same pixels as one pass and as the oracle,
+    with the tile kernels off so that every row takes the row kernel, both polylines variants, lean + replay path and full kernel."""
+    h, w = 6, 1540
+    img = synth.image_f32(1, h, w, seed=31)
+    depth = synth.depth_batch(kind, 1, h, w, channels=3)
+    for fill in ("polylines_soft", "polylines_sharp"):
+        want = node_oracle.generate(img, depth, 6.0, 0.0, "left-right", 0.0, 0.5, 2.0, UI[fill], 20.0, 20.0, False, batch_size=12)
+        for switches in ((("dbg", 30),), (("dbg", 30), ("no_tile", 1)), (("dbg", 30), ("no_tile", 1), ("no_replay_kernel", 1))):
+            for k, v in switches:
+                dev_switch(k, v)
+            got = gen(engine, img, depth, fill, "left-right", blur=False, div=6.0)
+            for k, v in switches:
+                dev_switch(k, 0)
+            for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+                assert np.array_equal(g, w_), (kind, fill, switches, name)
+    # a general exponent: the second eye's disparities need the powf tables again, whose LDS block the later ranges borrow
+    want = node_oracle.generate(img, depth, 6.0, 0.0, "left-right", 0.0, 0.5, 1.4, UI["polylines_sharp"], 20.0, 20.0, False, batch_size=12)
+    dev_switch("dbg", 30); dev_switch("no_tile", 1)
+    got = [t.cpu().numpy() for t in engine.generate(cuda(img), cuda(depth), 6.0, 0.0, "left-right", 0.0, 0.5, 1.4, "polylines_sharp",
+                                                    20.0, 20.0, False, depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)]
+    for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+        assert np.array_equal(g, w_), (kind, "exponent 1.4", name)
+
+
+def test_order_dependent_rows_take_the_wave_replay(engine, dev_switch):
+    """Noise depth on 8-bit levels: dozens of overlapping layers per pixel -- the per-pixel segment lists of the row kernel
+    overflow and (where two layers tie) the rows are order-dependent.  With the column ranges switched off (round 4's ranges
+    evaluate such rows in parallel after all: cs_debug_set(dbg, 31)) every row goes through the sequential replay of the
+    reference's active list as ONE whole-row stretch -- done by a whole wave since round 2, by the replay kernel since round 4.
+    Bit-exact against the oracle in both forms, at a width that spans several tiles, both polylines variants, SBS and anaglyph."""
     h, w = 24, 1540
     img = synth.image_f32(1, h, w, seed=12)
     depth = synth.depth_batch("random8", 1, h, w, channels=3)
@@ -264,11 +292,16 @@ def test_order_dependent_rows_take_the_wave_replay(engine):
         for mode in ("left-right", "red-cyan-anaglyph"):
             want = node_oracle.generate(img, depth, 6.0, 0.0, mode, 0.0, 0.5, 2.0, ui, 20.0, 20.0, False, batch_size=12)
             p = engine.make_params(1, h, w, h, w, 3, fill, mode, 6.0, 0.0, 0.0, 0.5, 2.0, False, 20.0, 20.0, 1.0, 0, 12)
-            plan = engine.Plan(p, torch.device("cuda"))
-            got = [t.cpu().numpy() for t in plan.run(cuda(img), cuda(depth))]
-            assert int(plan.stats()[:, 10].sum()) > 0   # rows replayed sequentially
-            for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
-                assert np.array_equal(g, w_), (fill, mode, name)
+            for ranges_off in (1, 0):
+                dev_switch("dbg", 31 if ranges_off else 0)
+                plan = engine.Plan(p, torch.device("cuda"))
+                got = [t.cpu().numpy() for t in plan.run(cuda(img), cuda(depth))]
+                assert int(plan.stats()[:, 11].sum()) > 0   # rows the tile kernel handed to the row kernel
+                if ranges_off:
+                    assert int(plan.stats()[:, 10].sum()) > 0   # rows replayed sequentially
+                for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+                    assert np.array_equal(g, w_), (fill, mode, ranges_off, name)
+            dev_switch("dbg", 0)
 
 
 @pytest.mark.parametrize("fill,ui", [("polylines_soft", "Fill - Polylines Soft"), ("polylines_sharp", "Fill - Polylines Sharp")])

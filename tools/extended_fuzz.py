@@ -15,6 +15,9 @@ from oracle import node_oracle, oracle
 from comfystereo_amd import engine
 from test_gpu_fuzz import FILLS, make_case
 
+if os.environ.get("CS_DBG"):   # a development switch for the whole run (30: the polylines row kernel in two column ranges)
+    from comfystereo_amd import _native
+    _native.debug_set("dbg", int(os.environ["CS_DBG"]))
 if os.environ.get("CS_FUZZ_FILLS"):   # restrict the run to some techniques (a kernel under development): "polylines_soft,polylines_sharp"
     FILLS = [f for f in FILLS if f in os.environ["CS_FUZZ_FILLS"].split(",")]
 
