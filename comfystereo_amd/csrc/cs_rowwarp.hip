@@ -1089,8 +1089,11 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
     // P3a/b: per-pixel lists of the forward segments that can be active inside the pixel (CSR).
     // Segments spanning > 3 pixels (disocclusion bridges) are rasterised cooperatively, 64 pixels
     // per wave step, instead of serialising one lane.
+#ifndef RW_MAX_RANGES
+#define RW_MAX_RANGES 4   // (32 measured on 4K noise depth, whose rows need ~20: the rows DO tie nearly everywhere, so the evaluation in
+#endif                    // ranges is paid on top of the whole-row replay: 69.8 -> 63.7 frames/s; 4 sends such rows straight to the replay)
     // Column RANGES (round 4): the lists of all pixels together may not fit `entries` (polylines_sharp rows beyond 6 950 columns:
-    // 3.0 entries per column needed, 2.9 left by the LDS) -- then the row is evaluated in 2 .. 4 ranges of columns, each with its
+    // 3.0 entries per column needed, 2.9 left by the LDS) -- then the row is evaluated in 2 .. RW_MAX_RANGES ranges of columns, each with its
     // own count / scan / fill / evaluate over the same arrays (segments clipped to the range; boundaries on multiples of 64 so that
     // every hazard / reset word belongs to one range).  The long-segment list of the ranges after the first lives in the (dead
     // since P1) table block, because the first range's hazard / reset words already sit in P.longs.  One range = the old flow.
@@ -1126,10 +1129,10 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         __syncthreads();
         const int nl = min(*nlong, longcap_r);
         const bool over_r = *nlong > longcap_r || *ntotal > P.cap;
-        if (over_r && nr == 1 && !ranged && !DIALECT && *nlong <= LONGCAP && *ntotal <= 4 * (P.cap - P.cap / 8) && *ntotal < 60000 &&
-            w >= 256 && dbg != 31) {
-            // too many entries for one pass, few enough for up to four: start over in ranges
-            nr = min(4, (*ntotal + (P.cap - P.cap / 8) - 1) / (P.cap - P.cap / 8));
+        if (over_r && nr == 1 && !ranged && !DIALECT && *ntotal <= RW_MAX_RANGES * (P.cap - P.cap / 8) && w >= 256 && dbg != 31) {
+            // too many entries for one pass, few enough for RW_MAX_RANGES: start over in ranges (the prefix sums are 16 bits wide, but
+            // per range; the whole row's count of long segments does not matter either -- they are clipped and listed per range)
+            nr = min(RW_MAX_RANGES, (*ntotal + (P.cap - P.cap / 8) - 1) / (P.cap - P.cap / 8));
             nr = max(nr, 2);
             ranged = true;
             r = -1;
