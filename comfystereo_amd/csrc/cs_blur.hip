@@ -947,7 +947,7 @@ __global__ void __launch_bounds__(256) k_lazy_rows(const uint32_t* list, const u
     const uint32_t nrows = list ? *count : (uint32_t)total;
     const int gy = (h + BLUR_TR - 1) / BLUR_TR;
     for (uint32_t i = blockIdx.x; i < nrows; i += gridDim.x) {
-        const uint32_t fr = list ? list[i] : i;
+        const uint32_t fr = list ? (list[i] & 0x3fffffffu) : i;   // (bits 30-31 of a list entry: the eyes the row kernel redoes, k_collect_rows)
         const int frame = (int)(fr / (uint32_t)h), row = (int)(fr - (uint32_t)frame * (uint32_t)h);
         const float scale = stats[frame * ST_WORDS + ST_SCALE255] ? 255.0f : 1.0f;
         const uint32_t* tm = tilemap + ((size_t)frame * gy + row / BLUR_TR) * tm_words;

@@ -1028,7 +1028,11 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         }
         if (pend) emit(q, csm::f32_to_u8_wrap(color0), csm::f32_to_u8_wrap(color1), csm::f32_to_u8_wrap(color2));
     }
-    if (hazard) A.rowflag[(uint32_t)frame * (uint32_t)h + (uint32_t)row] = 1;  // the general kernel redoes this row (both eyes)
+    if (hazard) {   // the row kernel redoes this EYE of the row (flag byte: bit 1 / 2 = eye 0 / 1; the byte is shared by both eyes'
+                    // workgroups: an atomic OR on its word -- flagged rows are rare)
+        const uint32_t idx = (uint32_t)frame * (uint32_t)h + (uint32_t)row;
+        atomicOr(reinterpret_cast<unsigned*>(A.rowflag + (idx & ~3u)), (eyei ? 4u : 2u) << (8u * (idx & 3u)));
+    }
 }
 
 // Depth-map output of an eye the tile kernel does not visit (modes left-only / only-right still return both depth maps,

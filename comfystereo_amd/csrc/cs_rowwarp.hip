@@ -2350,7 +2350,10 @@ struct RowOut {
 };
 
 template <int FILL, bool DIALECT, bool LEAN = false>
-__device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, const int frame, char* smem) {
+// eyemask (flagged rows): the eyes of the row the tile kernel could not finish (k_polypoint flags per eye since round 4: a row whose
+// ties sit in one eye only is not evaluated again for the other -- 18 % of the eye rows of a saturated depth map); anaglyph
+// layouts compose both eyes here and take both
+__device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, const int frame, char* smem, const int eyemask = 3) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int w = A.w, h = A.h;
     Lds L = carve(smem, FILL, w, A.anaglyph);
@@ -2415,6 +2418,7 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
         E.st_min = e ? A.eye[1].st_min : A.eye[0].st_min; E.st_max = e ? A.eye[1].st_max : A.eye[0].st_max;
         E.xoff = e ? A.eye[1].xoff : A.eye[0].xoff; E.yoff = e ? A.eye[1].yoff : A.eye[0].yoff;
         if (A.single >= 0 && A.single != e) continue;
+        if (!A.anaglyph && !((eyemask >> e) & 1)) continue;
         const bool last = (e == A.neyes - 1) || A.single >= 0;
         RowOut out{A.out_u8, A.stereo, A.mask, L.ana, L.ana, L.lut, A.h, A.out_h, A.out_w, E.xoff, E.yoff, A.anaglyph, A.stereo_is_u8,
                    frame, row, w, A.anaglyph != 0 && !last};
@@ -2553,16 +2557,17 @@ __global__ void __launch_bounds__(LEAN ? RW_LEAN_NT : 1024, LEAN ? RW_LEAN_W : 4
     const uint32_t count = listed ? A.row_count[0] : 1u;
     __shared__ uint32_t s_next;
     for (uint32_t it = 0;; it++) {
-        int row = blockIdx.x, frame = blockIdx.y;
+        int row = blockIdx.x, frame = blockIdx.y, eyemask = 3;
         if (listed) {
             if (threadIdx.x == 0) s_next = atomicAdd(const_cast<uint32_t*>(&A.row_count[1]), 1u);
             __syncthreads();
             const uint32_t i = s_next;
             if (i >= count) break;
-            const uint32_t e = A.row_list[i];
+            const uint32_t e = A.row_list[i] & 0x3fffffffu;
+            eyemask = (int)(A.row_list[i] >> 30);
             row = (int)(e % (uint32_t)A.h); frame = (int)(e / (uint32_t)A.h);
         } else if (it) break;
-        rowwarp_row<FILL, DIALECT, LEAN>(A, row, frame, smem);
+        rowwarp_row<FILL, DIALECT, LEAN>(A, row, frame, smem, eyemask);
         __syncthreads();  // the row's LDS (and s_next) is reused by the next one
     }
 }
@@ -2757,7 +2762,13 @@ hipError_t launch_poly_replay(int sharp, const RowArgs& A, int halo, hipStream_t
 // rows flagged by the tiled path -> compact list
 __global__ void __launch_bounds__(256) k_collect_rows(const uint8_t* __restrict__ flag, int total, uint32_t* count, uint32_t* list) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < total && flag[i]) list[atomicAdd(count, 1u)] = (uint32_t)i;
+    // flag byte: bit 0 = the row (both eyes: what every flagging kernel but k_polypoint writes), bits 1 / 2 = eye 0 / eye 1 only
+    // (k_polypoint, round 4).  List entry: row index | eye mask << 30
+    if (i < total && flag[i]) {
+        const unsigned f = flag[i];
+        const unsigned mask = (f & 1u) ? 3u : ((f >> 1) & 3u);
+        list[atomicAdd(count, 1u)] = (uint32_t)i | (mask << 30);
+    }
 }
 
 hipError_t launch_collect_rows(const uint8_t* flag, int total, uint32_t* count, uint32_t* list, hipStream_t stream) {
