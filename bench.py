@@ -52,8 +52,15 @@ CONFIGS = {
     "cfg5": dict(h=2160, w=3840, frames=64, fill="none", mode="red-cyan-anaglyph", div=8.0, depth="stepped", bytes_px=64,
                  name="anaglyph frames/sec, 64x4K no-fill + mask (BASELINE cfg 5)", kernel="k_fwdtile (halo-tile forward map, both eyes per workgroup)",
                  what="BASELINE.json configs[4]: batch of 64 4K frames, red-cyan-anaglyph + no_fill mask output, stepped depth"),
+    # the two other fills north_star names, at the metric's size (profiles of their own)
+    "naive_interp": dict(h=2160, w=3840, frames=64, fill="naive_interpolating", mode="left-right", div=8.0, depth="stepped", bytes_px=80,
+                         name="SBS frames/sec, 4K warp+naive_interpolating", kernel="k_fwdtile<naive_interpolating>",
+                         what="4K 3840x2160, naive_interpolating, left-right SBS, divergence 8.0, stepped depth"),
+    "sharp": dict(h=2160, w=3840, frames=64, fill="polylines_sharp", mode="left-right", div=8.0, depth="stepped", bytes_px=80,
+                  name="SBS frames/sec, 4K warp+polylines_sharp", kernel="k_polypoint<SHARP> (+ k_rowwarp<polylines_sharp> over the rows it flags)",
+                  what="4K 3840x2160, polylines_sharp, left-right SBS, divergence 8.0, stepped depth"),
 }
-UI_FILL = {"polylines_soft": "Fill - Polylines Soft", "hybrid_edge": "Imperfect fill - Hybrid Edge", "gpu_warp": "GPU Warp (Fast)",
+UI_FILL = {"naive_interpolating": "Fill - Naive interpolating", "polylines_sharp": "Fill - Polylines Sharp", "polylines_soft": "Fill - Polylines Soft", "hybrid_edge": "Imperfect fill - Hybrid Edge", "gpu_warp": "GPU Warp (Fast)",
            "none": "No fill"}
 
 
@@ -122,8 +129,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--verify", action="store_true", help="N > 1: check the reassembled float32 batch against a local float32 run")
-    ap.add_argument("--gather", default="collective", choices=["collective", "p2p"],
-                    help="N > 1: all_gather_into_tensor (RCCL) or the direct peer fan-out (batched send / recv to every peer)")
+    ap.add_argument("--gather", default="collective", choices=["collective", "p2p", "none"],
+                    help="N > 1: all_gather_into_tensor (RCCL), the direct peer fan-out (batched send / recv to every peer), or none: "
+                         "every rank keeps the float32 results of its own frame block (sharding.generate_sharded(..., gather=()), the "
+                         "deployment form of DESIGN.md section 6) -- `value` is then the kernels-only rate and the config says so")
+    ap.add_argument("--no-other-depths", action="store_true", help="metric config, N = 1: skip the radial / blobs depth lines")
     a = ap.parse_args()
     cfg = dict(CONFIGS[a.config])
     frames = a.frames or cfg["frames"]
@@ -174,7 +184,8 @@ def main():
     # is expanded to float32 on every rank (sharding.ShardedStereoJob).  gpu_warp colours are genuine floats: one float32
     # all-gather of the rank's block.
     job = None
-    if world > 1 and not gpu_warp:
+    no_gather = world > 1 and a.gather == "none"
+    if world > 1 and not gpu_warp and not no_gather:
         job = sharding.ShardedStereoJob(params, frames, (out_h, out_w, 3), device, method=a.gather)
         plans = job.plans
     else:
@@ -182,7 +193,7 @@ def main():
         tie_pool = nloc * H * W * 2 * 6 + (64 << 20) if (a.depth == "random8" and cfg["fill"].startswith("polylines")) else 0
         plan = engine.Plan(params(nloc), device, tie_pool_bytes=tie_pool)
         plans = [plan]
-        if world > 1:
+        if world > 1 and not no_gather:
             sizes = {bounds[r + 1] - bounds[r] for r in range(world)}
             if len(sizes) != 1:
                 raise SystemExit(f"--frames {frames} does not split into equal sub-batch-aligned blocks over {world} GPUs")
@@ -195,7 +206,7 @@ def main():
             plan.run(image, depth)
 
     def step(expand=True):
-        if world == 1:
+        if world == 1 or no_gather:
             plan.run(image, depth)
         elif job is not None:
             job.step(image, depth, expand=expand)
@@ -244,7 +255,7 @@ def main():
     err_flags = sum(int(q.stats()[:, 9].sum()) for q in plans)
 
     split = None
-    if world > 1:  # kernels only / + all-gather / end to end, each timed like the headline
+    if world > 1 and not no_gather:  # kernels only / + all-gather / end to end, each timed like the headline
         dt_k = timed(compute_only, a.steps)
         dt_g = timed((lambda: step(expand=False)), a.steps) if job is not None else dt
         split = {"kernels_only_fps": frames * a.steps / dt_k, "kernels_plus_allgather_fps": frames * a.steps / dt_g,
@@ -259,7 +270,32 @@ def main():
         value_blur_off = frames * a.steps / timed(lambda: plan_off.run(image, depth), a.steps)
         del plan_off
 
-    if a.verify and world > 1:
+    value_other_depths = None
+    if world == 1 and a.config == "metric" and not a.depth and not a.no_other_depths:
+        # the same workload on depth maps without plateaus (a gain that only exists on the stepped depth's flat
+        # regions must be visible as such): radial = the stepped map before quantisation, blobs = smooth random hills
+        value_other_depths = {}
+        import numpy as np
+        import synth
+        for kind in ("radial", "blobs"):
+            if kind == "radial":
+                _, d2 = make_inputs(torch, dict(cfg, depth="radial"), nloc, b0, device)
+            else:
+                base = np.stack([synth.DEPTHS[kind](H, W, seed=b0 + i) for i in range(min(8, nloc))])
+                reps = (nloc + base.shape[0] - 1) // base.shape[0]
+                d2 = torch.from_numpy(np.tile(base, (reps, 1, 1))[:nloc]).to(device)[..., None].expand(nloc, H, W, 3).contiguous()
+            plan.run(image, d2)
+            value_other_depths[kind] = frames * a.steps / timed(lambda: plan.run(image, d2), a.steps)
+            del d2
+        plan.run(image, depth)
+
+    if a.verify and world > 1 and no_gather:
+        ref = engine.Plan(params(nloc), device).run(image, depth)[0]
+        ok = torch.equal(plan.stereo, ref)
+        print(f"[verify] rank {rank}: {'OK' if ok else 'MISMATCH'} (own block only: --gather none)", flush=True)
+        if not ok:
+            raise SystemExit(1)
+    elif a.verify and world > 1:
         # every rank: its own block of the reassembled batch == the float32 output computed locally in one piece
         full = job.gathered if job is not None else gathered_f32[0]
         ref = engine.Plan(params(nloc), device).run(image, depth)[0]
@@ -326,6 +362,8 @@ def main():
                        "frames_total": frames, "frames_per_gpu": nloc, "sharding": "by frame, contiguous blocks",
                        "gather": a.gather if world > 1 else None,
                        "collective": "none" if world == 1 else (
+                           "none: every rank keeps the float32 results of its own frame block (--gather none, sharding.generate_sharded"
+                           "(gather=())); value = frames of all ranks / slowest rank's kernel time" if no_gather else
                            f"all_gather(stereoscope as uint8 codes) over RCCL in {job.n_chunks} chunk(s) overlapped with compute"
                            " + expand to float32 on every rank" if job is not None else "all_gather(stereoscope float32) over RCCL")},
             "roofline": roofline,
@@ -334,6 +372,8 @@ def main():
         }
         if value_blur_off is not None:
             line["value_blur_off"] = value_blur_off
+        if value_other_depths is not None:
+            line["value_other_depths"] = value_other_depths
         if split is not None:
             line["split"] = split
         if ranks is not None:

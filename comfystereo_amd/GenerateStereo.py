@@ -46,14 +46,30 @@ FILL_TECHNIQUE_MAPPING = dict(FILL_TECHNIQUES, **{
 CHUNK_BYTES = 96 << 30
 
 
-# Warm-up at import (inside ComfyUI only; tools call host_pipeline.prewarm themselves): the first `generate` of a process would
-# otherwise page-lock its result and staging memory inside the call (24 GB/s: 0.8 s for a 32-frame 4K batch, four times the call
-# itself -- 24-48 instead of 150+ frames/s).  A daemon thread allocates the buffers of a call of this shape and releases them into
-# PyTorch's caching allocators while ComfyUI is still loading its models: ~19 GB of pinned host memory and ~12 GB of HBM stay
-# cached for (frames, height, width) = (32, 2160, 3840).  None switches it off; a smaller shape warms less.
-PREWARM = (32, 2160, 3840)
-if _IN_COMFYUI and PREWARM:
-    host_pipeline.prewarm_async(*PREWARM)
+# OPT-IN warm-up.  Importing this module allocates nothing and starts no thread (like the reference's).  A deployment that wants
+# the first `generate` of the process to find its page-locked staging buffers and device buffers cached names a shape
+# (frames, height, width) -- here, or as COMFYSTEREO_PREWARM=FxHxW in ComfyUI's environment -- and a daemon thread allocates and
+# releases them into PyTorch's caching allocators while ComfyUI is still loading its models (host_pipeline.prewarm: result
+# tensors are pinned only while everything stays under host_pipeline.PINNED_POOL_BYTES, 8 GB by default; for 32 x 4K frames
+# that is 4.5 GB of pinned staging and 12 GB of HBM).  Without it the first call pins its staging buffers itself, the second
+# slot's on a helper thread (profiles/r05_host.txt: first-call numbers with and without).
+PREWARM = None
+
+
+def _prewarm_shape():
+    import os
+    spec = os.environ.get("COMFYSTEREO_PREWARM", "")
+    if PREWARM:
+        return tuple(PREWARM)
+    try:
+        f, h, w = (int(v) for v in spec.lower().split("x"))
+        return (f, h, w) if min(f, h, w) > 0 else None
+    except ValueError:
+        return None
+
+
+if _IN_COMFYUI and _prewarm_shape():
+    host_pipeline.prewarm_async(*_prewarm_shape())
 
 
 class StereoImageNode:

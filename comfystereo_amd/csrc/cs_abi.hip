@@ -287,9 +287,26 @@ static std::atomic<bool> g_prof_on{false};
 static hipEvent_t g_prof_ev[2 * PROF_MAX];
 static int g_prof_made = 0, g_prof_used = 0;
 // the lazy-tile map of the last profiled cs_generate call (null: the call's warp kernel read complete blurred maps)
-static const uint32_t* g_prof_map = nullptr;
-static int g_prof_map_n = 0, g_prof_map_h = 0, g_prof_map_w = 0;
-static hipStream_t g_prof_map_stream = nullptr;
+// share of the lazy blur tiles the profiled calls wrote (cs_profile_tiles): counted on the device into a LIBRARY-OWNED pair of
+// words {tiles set, tiles in all}, accumulated over the chunks of every profiled cs_generate -- no pointer into a caller's
+// workspace outlives the call
+static unsigned long long* g_prof_tiles = nullptr;
+static bool g_prof_tiles_any = false;
+static hipStream_t g_prof_tiles_stream = nullptr;
+__global__ void __launch_bounds__(256) k_prof_count_tiles(const uint32_t* __restrict__ map, int rows, int words, int tcols,
+                                                          unsigned long long* acc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned cnt = 0;
+    if (i < rows * words) {
+        const int wi = i % words, first = wi * 32;
+        const int valid = tcols - first;   // tiles of the row this word holds (the pad word and the tail bits: none)
+        const uint32_t m = valid >= 32 ? 0xffffffffu : (valid <= 0 ? 0u : (1u << valid) - 1u);
+        cnt = __popc(map[i] & m);
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&acc[0], (unsigned long long)cnt);
+    if (i == 0) atomicAdd(&acc[1], (unsigned long long)rows * (unsigned long long)tcols);
+}
 struct ProfScope {
     hipStream_t s; int slot;
     explicit ProfScope(hipStream_t stream) : s(stream), slot(-1) {
@@ -688,6 +705,15 @@ static int generate_chunk(const cs_params* p, const float* image, const float* d
         if (rc) return fail_blur(rc);
         dL = L; dR = R;
         scale_from_stats = 0;  // the blur kernel already wrote scaled depth
+        if (lazy && g_prof_on.load(std::memory_order_relaxed)) {   // (measurement: cs_profile_tiles; outside the timed kernel scope)
+            std::lock_guard<std::mutex> lock(g_prof_mu);
+            if (g_prof_tiles) {
+                const int words = blur_tilemap_words(w), rows = (int)(blur_tilemap_bytes(n, h, w) / ((size_t)words * 4));
+                hipLaunchKernelGGL(k_prof_count_tiles, dim3((rows * words + 255) / 256), dim3(256), 0, sp, (const uint32_t*)(ws + W.tilemap),
+                                   rows, words, (w + 63) / 64, g_prof_tiles);
+                g_prof_tiles_any = true; g_prof_tiles_stream = sp;
+            }
+        }
     }
     const double left_div = p->divergence * (1 + p->stereo_balance);
     const double right_div = p->divergence * (1 - p->stereo_balance);
@@ -730,11 +756,6 @@ static int generate_chunk(const cs_params* p, const float* image, const float* d
     A.single = -1;
     A.dbg = dev_switch(CS_DEBUG_DBG);
     if (lazy) { A.tilemap = (const uint32_t*)(ws + W.tilemap); A.lazy_gray = gray; A.tm_words = blur_tilemap_words(w); }
-    if (g_prof_on.load(std::memory_order_relaxed)) {   // (measurement: cs_profile_tiles reads this call's tile map afterwards)
-        std::lock_guard<std::mutex> lock(g_prof_mu);
-        g_prof_map = lazy ? (const uint32_t*)(ws + W.tilemap) : nullptr;
-        g_prof_map_n = n; g_prof_map_h = h; g_prof_map_w = w; g_prof_map_stream = stream;
-    }
     switch (p->mode) {
     case CS_MODE_LEFT_RIGHT: A.eye[1].xoff = w; break;
     case CS_MODE_RIGHT_LEFT: A.eye[0].xoff = w; break;
@@ -1049,7 +1070,12 @@ int cs_stereo_shift(const float* input, const float* depth, int b, int c, int h,
 int cs_profile(int enable) {
     std::lock_guard<std::mutex> lock(g_prof_mu);
     g_prof_on.store(enable != 0);
-    if (enable) g_prof_used = 0;
+    if (enable) {   // a new measurement: events and tile counts start from zero (switching off keeps them readable)
+        g_prof_used = 0;
+        g_prof_tiles_any = false; g_prof_tiles_stream = nullptr;
+        if (!g_prof_tiles && hipMalloc(&g_prof_tiles, 16) != hipSuccess) { g_prof_tiles = nullptr; (void)hipGetLastError(); }
+        if (g_prof_tiles && hipMemset(g_prof_tiles, 0, 16) != hipSuccess) return fail_hip(hipGetLastError(), "cs_profile");
+    }
     return CS_OK;
 }
 
@@ -1080,25 +1106,20 @@ int cs_profile_read(double* total_ms, int* launches) {
     return CS_OK;
 }
 
-// Which share of the 64 x 32 tiles of the last profiled cs_generate call had been written to the blurred depth maps (the others
-// are read from the shared gray depth by both eyes: 4 instead of 8 bytes per pixel of depth input for the warp kernel).
-// Blocking (waits for the call's stream, copies the map).  *fraction = -1: that call did not use lazy tiles.
+// Which share of the 64 x 32 tiles of the cs_generate calls profiled since cs_profile(1) had been written to the blurred depth maps
+// (the others are read from the shared gray depth by both eyes: 4 instead of 8 bytes per pixel of depth input for the warp
+// kernel), over all their chunks.  Blocking (waits for the last such call's stream, copies two words from a buffer the library
+// owns).  *fraction = -1: none of those calls used lazy tiles.
 int cs_profile_tiles(double* fraction) {
     if (!fraction) return fail(CS_EINVAL, "null pointer");
     std::lock_guard<std::mutex> lock(g_prof_mu);
     *fraction = -1.0;
-    if (!g_prof_map) return CS_OK;
-    const int n = g_prof_map_n, h = g_prof_map_h, w = g_prof_map_w;
-    const int words = blur_tilemap_words(w), trows = (int)(blur_tilemap_bytes(n, h, w) / ((size_t)n * words * 4));
-    const int tcols = (w + 63) / 64;   // (64-column tiles: cs_blur.hip BLUR_TW)
-    std::vector<uint32_t> host(blur_tilemap_bytes(n, h, w) / 4);
-    hipError_t e = hipStreamSynchronize(g_prof_map_stream);
-    if (e == hipSuccess) e = hipMemcpy(host.data(), g_prof_map, host.size() * 4, hipMemcpyDeviceToHost);
+    if (!g_prof_tiles || !g_prof_tiles_any) return CS_OK;
+    unsigned long long host[2] = {0, 0};
+    hipError_t e = hipStreamSynchronize(g_prof_tiles_stream);
+    if (e == hipSuccess) e = hipMemcpy(host, g_prof_tiles, 16, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail_hip(e, "cs_profile_tiles");
-    size_t set = 0;
-    for (size_t r = 0; r < (size_t)n * trows; r++)
-        for (int t = 0; t < tcols; t++) set += (host[r * words + (t >> 5)] >> (t & 31)) & 1u;
-    *fraction = (double)set / ((double)n * trows * tcols);
+    if (host[1]) *fraction = (double)host[0] / (double)host[1];
     return CS_OK;
 }
 

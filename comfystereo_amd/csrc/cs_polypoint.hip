@@ -86,6 +86,24 @@ struct PolyPointArgs {
 
 struct F3 { float x, y, z; };
 struct B3 { uint8_t x, y, z; };
+// the float32 output stores of the tile (stereoscope / depth map: 12 bytes per pixel, mask: 4).  -DPP_NT_STORES (experiment, round 5):
+// the nontemporal forms -- the outputs are never read back by this kernel
+typedef float pp_f3v __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void out_store3(char* p, float a, float b, float c) {
+#ifdef PP_NT_STORES
+    const pp_f3v v{a, b, c};
+    asm volatile("global_store_dwordx3 %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
+#else
+    *reinterpret_cast<F3*>(p) = F3{a, b, c};
+#endif
+}
+__device__ __forceinline__ void out_store1(char* p, float a) {
+#ifdef PP_NT_STORES
+    __builtin_nontemporal_store(a, reinterpret_cast<float*>(p));
+#else
+    *reinterpret_cast<float*>(p) = a;
+#endif
+}
 
 // lane i receives lane i + 1's value, lane 63 +inf -- one DPP move instead of a ds_bpermute round trip
 __device__ __forceinline__ float wave_next(float v) {
@@ -302,18 +320,18 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // colour codes of tile pixel q as integer-valued floats 0..255
     auto emit_f = [&](int q, float r, float g, float b) {
         const uint32_t uq = (uint32_t)q;
-        if (OUT == PO_F32) *reinterpret_cast<F3*>(st_row + 12u * uq) = F3{code_over_255(r), code_over_255(g), code_over_255(b)};
+        if (OUT == PO_F32) out_store3(st_row + 12u * uq, code_over_255(r), code_over_255(g), code_over_255(b));
         else *reinterpret_cast<B3*>(st_row + 3u * uq) = B3{(uint8_t)(int)r, (uint8_t)(int)g, (uint8_t)(int)b};
-        if (OUT != PO_ASD && OUT != PO_U8NM) *reinterpret_cast<float*>(mk_row + 4u * uq) = __builtin_fmaxf(__builtin_fmaxf(r, g), b) == 0.0f ? 1.0f : 0.0f;
+        if (OUT != PO_ASD && OUT != PO_U8NM) out_store1(mk_row + 4u * uq, __builtin_fmaxf(__builtin_fmaxf(r, g), b) == 0.0f ? 1.0f : 0.0f);
     };
     auto emit = [&](int q, int r, int g, int b) { emit_f(q, (float)r, (float)g, (float)b); };   // the same from integer codes
     // the same from the colour sums 0.5 <= k < 255.5 before truncation (the two hot call sites): the conversion truncates
     auto emit_k = [&](int q, float k0, float k1, float k2) {
         const uint32_t uq = (uint32_t)q;
         const uint32_t r = (uint32_t)k0, g = (uint32_t)k1, b = (uint32_t)k2;
-        if (OUT == PO_F32) *reinterpret_cast<F3*>(st_row + 12u * uq) = F3{lut[r], lut[g], lut[b]};
+        if (OUT == PO_F32) out_store3(st_row + 12u * uq, lut[r], lut[g], lut[b]);
         else *reinterpret_cast<B3*>(st_row + 3u * uq) = B3{(uint8_t)r, (uint8_t)g, (uint8_t)b};
-        if (OUT != PO_ASD && OUT != PO_U8NM) *reinterpret_cast<float*>(mk_row + 4u * uq) = (r | g | b) == 0u ? 1.0f : 0.0f;
+        if (OUT != PO_ASD && OUT != PO_U8NM) out_store1(mk_row + 4u * uq, (r | g | b) == 0u ? 1.0f : 0.0f);
     };
 
     // =====================================================================================================
@@ -331,7 +349,11 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
                        ((uint32_t)__builtin_amdgcn_fmed3f(cpre[k].z * 255.0f, 0.0f, 255.0f) << 16);
     }
     // this eye's depth-map output: (depth * 255).astype(uint8) wraps mod 256 (quirk Q7), value code / 255 on three channels
+#if defined(PP_SKELETON) && PP_SKELETON >= 3
+    if (false) {
+#else
     if (OUT != PO_ASD && !PP_DEV_IS(37)) {
+#endif
         float* const dd = eyei == 0 ? A.depth_l : A.depth_r;
         char* const dd_row = (char*)dd + (size_t)(rowpix + (uint32_t)o0) * 12;
         int code[SLOTS];
@@ -346,7 +368,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             const int q = tid + k * NT + qoff;   // tile pixel of this source column
             if ((unsigned)q < (unsigned)wt) {
                 const float v = OUT == PO_F32 ? lut[code[k] & 0xff] : code_over_255((float)(code[k] & 0xff));
-                *reinterpret_cast<F3*>(dd_row + 12u * (uint32_t)q) = F3{v, v, v};
+                out_store3(dd_row + 12u * (uint32_t)q, v, v, v);
             }
         }
     }
@@ -358,6 +380,19 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         }
         return;
     }
+#if defined(PP_SKELETON) && PP_SKELETON == 2
+    {   // (memory skeleton without the staging arithmetic: x = column + a cheap function of the depth; records as in production)
+        PQ* const Pw = P + 1 + tid;
+        float* const pzw = pz + 1 + tid;
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) {
+            const int j = tid + k * NT;
+            const float x = (float)(s0 + j) + 0.5f + dpre[k] * E.div32;
+            if (SLOTS * NT + 4 == NPT || 1 + j < NPT) { Pw[k * NT] = PQ{rgbk[k], x}; pzw[k * NT] = dpre[k] - dmin; }
+        }
+        if (tid == 0) P[0] = PQ{rgbk[0], (float)(-1.0 * w)};
+    }
+#else
     {
         const bool flat = dmax == dmin;
         const float range = dmax - dmin;
@@ -447,8 +482,31 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         if (lane == 0) { atomicMin(&flags[PF_JLO], wjlo); atomicMax(&flags[PF_JHI], wjhi); }
         if (tid == 0) P[0] = PQ{rgbk[0], (float)(-1.0 * w)};   // left sentinel (:1921): the first column's colour (frame border only)
     }
+#endif
     __syncthreads();  // barrier 1: points staged, in-wave reversed segments marked
     if (PP_DEV_IS(31)) return;
+#ifdef PP_SKELETON
+    // (measurement, round 5: the kernel's MEMORY SKELETON -- every global load, the LDS point records and their read-back, every
+    // output store in today's form (lane = source slot: dwordx3 at the slot's tile pixel + the mask dword; the depth-map stores
+    // above) -- with the polyline arithmetic removed: a pixel's colour is a cheap function of the three records the fast path
+    // reads.  Results are meaningless; never defined in a release.  PP_SKELETON=2: without the staging arithmetic as well,
+    // PP_SKELETON=3: like 2 with the loads only (no output store at all), 4: like 2 without the depth-map stores)
+    {
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) {
+            const int j = min(tid + k * NT, ns - 1), o = 1 + j;
+            const PQ pm = P[o - 1], pc = P[o], pp = P[o + 1];
+            const int q = tid + k * NT + qoff;
+            const uint32_t mix = (pm.rgb + pp.rgb) ^ pc.rgb ^ (uint32_t)(pc.x > pm.x);
+#if PP_SKELETON == 3
+            if (mix == 0x12345678u && q == 77777) emit_k(0, 1.0f, 2.0f, 3.0f);
+#else
+            if ((unsigned)q < (unsigned)wt) emit_k(q, (float)(mix & 0xffu), (float)((mix >> 8) & 0xffu), (float)((mix >> 16) & 0xffu));
+#endif
+        }
+        return;
+    }
+#endif
     // (model experiment, tools/r04_model.sh: -DPP_PAD_S=n / -DPP_PAD_V=n add n independent scalar / vector adds per wave here,
     // so that the cost of one more instruction of either kind is measured on the production kernel; never defined in a release)
 #if defined(PP_PAD_S) || defined(PP_PAD_V)

@@ -1661,6 +1661,20 @@ __global__ void __launch_bounds__(1024) k_hybrid_splat(RowArgs A) {
 struct Px3f { float x, y, z; };
 struct Px3b { uint8_t x, y, z; };
 
+// -DHYB_WTAB (experiment, round 5): the Gaussian weight of a contribution is exp((double)(-(diff * diff) / 2.0f))
+// with diff = dest_x - (float)column, an EXACT float32 difference (reference :1643-1644).  For dest_x >= 512 the float32 dest_x is
+// a multiple of 2^-14, so |diff| < 2 is one of 32 768 multiples of 2^-14 (coarser binades use a subset): ONE table of the
+// libm-exact doubles, indexed by (int)(|diff| * 2^14), replaces the ~25-instruction float64 evaluation by a gather.
+#ifdef HYB_WTAB
+__device__ double d_hyb_wtab[32768];
+__global__ void __launch_bounds__(256) k_hyb_wtab_init() {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float d = (float)i * 0x1p-14f;
+    const float arg = -(d * d) / 2.0f;
+    d_hyb_wtab[i] = csm::exp_exact_small((double)arg, d_hyb_exp_tab);
+}
+#endif
+
 // The same splat for an output TILE of one eye row (node path, float32 image): only the sources within S + 2 columns of
 // the tile can touch it, so a 256-thread workgroup stages them three per lane and runs the counting sort, the in-bin
 // ranking and the 3-way merge on ~770 sources out of 14 KB of LDS (8 workgroups per CU) instead of on a whole row out of
@@ -1863,10 +1877,17 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
         int p2 = e1, e2 = mono ? binoff[q + 3] : binoff[q + 2];
         float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, ws = 0.0f;
         bool touched = false;
+#ifdef HYB_WTAB
+        const bool wtab = o0 - 1 >= 512;   // every dest_x that can touch the tile is >= o0 - 1 (tile-uniform)
+#endif
         auto contribute = [&](int j) {
             const float diff = destx[j] - (float)jcol;
             const float arg = -(diff * diff) / 2.0f;
+#ifdef HYB_WTAB
+            const double wg = wtab ? d_hyb_wtab[(uint32_t)(fabsf(diff) * 16384.0f)] : csm::exp_exact_small((double)arg, etab);
+#else
             const double wg = csm::exp_exact_small((double)arg, etab);   // (-8 < arg <= 0: no range test, cs_math.h)
+#endif
             const uint32_t c = img[j];
             acc0 = (float)((double)acc0 + (double)(c & 0xffu) * wg);
             acc1 = (float)((double)acc1 + (double)((c >> 8) & 0xffu) * wg);
@@ -2892,6 +2913,9 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int pl
             uint16_t* lst = (uint16_t*)((char*)cnt + hybrid_count_bytes(A.n, A.h));
             e = hipMemsetAsync(cnt, 0, (size_t)A.n * A.neyes * A.h * 4, stream);
             if (e != hipSuccess) return CS_EHIP;
+#ifdef HYB_WTAB
+            hipLaunchKernelGGL(k_hyb_wtab_init, dim3(128), dim3(256), 0, stream);   // (experiment: every call; a product would do it once)
+#endif
             hipLaunchKernelGGL(k_hybrid_splat_tile<true>, grid, dim3(HYT_NT), 0, stream, A, halo, T, cnt, lst);
             hipLaunchKernelGGL(k_hybrid_gaps<true>, dim3(A.h, A.neyes, A.n), dim3(64), 0, stream, A, (const uint32_t*)cnt, (const uint16_t*)lst);
             return hipGetLastError() == hipSuccess ? CS_OK : CS_EHIP;

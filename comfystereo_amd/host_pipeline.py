@@ -42,6 +42,31 @@ from . import _native, engine
 CHUNK_OUT_BYTES = 3 << 30
 # compact boundary: a chunk is sized by its float32 INPUTS instead (0.2 GB per 4K frame; outputs are 83 MB)
 CHUNK_IN_BYTES = 1 << 30
+# Cap on the page-locked host memory the pipeline allocates for itself (staging buffers + result tensors).  A call whose
+# results fit beside its staging buffers gets PINNED result tensors (the device / the expansion threads write straight into
+# blocks PyTorch's host allocator caches); a larger call -- 32 x 4K frames are 15 GB of float32 results -- gets ordinary
+# pageable result tensors like the reference's, and only the staging buffers (a few GB) are pinned.  The node shares its host
+# with diffusion models and their offload buffers: the default keeps it below 8 GB whatever the batch.  A deployment with
+# RAM to spare may raise it (steady state +5 % at 32 x 4K, profiles/r05_host.txt).
+PINNED_POOL_BYTES = 8 << 30
+_last_pinned_need = 0   # pinned bytes the previous call asked for (module state only: nothing is persisted)
+
+
+def _release_pinned_cache():
+    """Give the pinned blocks PyTorch's caching host allocator holds (and nobody uses) back to the system."""
+    fn = getattr(torch._C, "_host_emptyCache", None)
+    if fn is not None:
+        fn()
+
+
+def _pinned_budget(need):
+    """Called once per generate_host / prewarm with the pinned bytes the call will ask for: when the need SHRINKS against the
+    previous call's (another resolution, a shorter batch) the cached blocks of the old shape would stay page-locked for
+    nothing -- PyTorch never returns them by itself -- so they are released first."""
+    global _last_pinned_need
+    if need < _last_pinned_need:
+        _release_pinned_cache()
+    _last_pinned_need = need
 
 
 def _chunk_frames(total, per_frame_out, fill, batch_size):
@@ -100,6 +125,40 @@ def result_shapes(image_shape, modes, fill="polylines_soft"):
     p = engine.make_params(1, h, w, h, w, 1, fill, modes, 1.0, 0.0, 0.0, 0.5, 1.0, False, 0.0, 0.0, 1.0, 0, 1)
     oh, ow, mh, mw = engine.output_shape(p)
     return (n, oh, ow, 3), (n, h, w, 3), (n, h, w, 3), (n, mh, mw)
+
+
+class _Lazy:
+    """A value built on a helper thread (the second pipeline slot: its page-locked buffers are not needed before the second chunk)."""
+
+    def __init__(self, fn, device):
+        self.value, self.error = None, None
+
+        def run():
+            try:
+                torch.cuda.set_device(device)
+                self.value = fn()
+            except BaseException as e:   # (re-raised by get() on the caller's thread)
+                self.error = e
+        self.thread = threading.Thread(target=run, name="comfystereo-slot", daemon=True)
+        self.thread.start()
+
+    def get(self):
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+        return self.value
+
+
+def _small_bytes_per_frame(routes, oh, ow, h, w, mh, mw):
+    """Bytes per frame of the compact output forms that travel through pinned landing buffers."""
+    sizes = (oh * ow * 3, h * w, h * w, mh * mw)   # values per frame in compact form (depth maps: one channel)
+    total = 0
+    for k, r in enumerate(routes):
+        if r == "u8":
+            total += sizes[k]
+        elif r == "f1":
+            total += 4 * sizes[k]
+    return total
 
 
 class _Results:
@@ -172,6 +231,16 @@ def generate_host(image, depth_map, divergence, separation, modes, stereo_balanc
     else:
         chunk = _chunk_frames(total, per_frame_out, fill, batch_size)
     shapes = ((total, oh, ow, 3), (total, h, w, 3), (total, h, w, 3), (total, mh, mw))
+    ranges = [(b0, min(b0 + chunk, total)) for b0 in range(0, total, chunk)]
+    # page-locked memory this call asks for: the staging buffers of its slots always (asynchronous copies need them), the result
+    # tensors only while everything stays under PINNED_POOL_BYTES
+    per_frame_in = 4 * (h * w * 3 + dshape[0] * dshape[1] * dshape[2])
+    nslot_frames = chunk * min(2, len(ranges)) + (total % chunk if total % chunk and len(ranges) > 1 else 0)
+    staging_bytes = nslot_frames * (per_frame_in + _small_bytes_per_frame(routes, oh, ow, h, w, mh, mw))
+    result_bytes = total * per_frame_out
+    if out is None and pinned_outputs and staging_bytes + result_bytes > PINNED_POOL_BYTES:
+        pinned_outputs = False
+    _pinned_budget(staging_bytes + (result_bytes if (out is None and pinned_outputs) else 0))
     results = None   # helper thread that allocates the result tensors
     final = None
     if out is not None:
@@ -192,7 +261,6 @@ def generate_host(image, depth_map, divergence, separation, modes, stereo_balanc
     direct_known = final is not None
     direct = direct_known and all(final[k].is_pinned() for k, r in enumerate(routes) if r == "f32")
     staged_f32 = has_f32 and direct_known and not direct
-    ranges = [(b0, min(b0 + chunk, total)) for b0 in range(0, total, chunk)]
     L = _native.lib()
     nthreads = expand_threads if expand_threads > 0 else max(1, min(32, (os.cpu_count() or 1)))
     copy_threads = max(1, min(16, (os.cpu_count() or 1)))
@@ -245,14 +313,33 @@ def generate_host(image, depth_map, divergence, separation, modes, stereo_balanc
             progress(b1 - b0)
 
     state["direct"] = direct
+    pending = {}   # slots being built by helper threads
     try:
-        slots = [_Stage(params(chunk), dshape, device, routes, staged_f32) for _ in range(min(2, len(ranges)))]
-        tail = None  # a shorter last chunk gets its own (smaller) slot
-        if ranges[-1][1] - ranges[-1][0] != chunk:
-            tail = _Stage(params(ranges[-1][1] - ranges[-1][0]), dshape, device, routes, staged_f32)
-            slots.append(tail)
+        # the first slot now, the second one (and a shorter last chunk's own, smaller slot) on a helper thread: page-locking a slot's
+        # buffers (2 GB for eight 4K frames) takes as long as the first chunk's staging + transfer + kernels, which do not need them
+        nring = min(2, len(ranges))
+        slots = [_Stage(params(chunk), dshape, device, routes, staged_f32)]
+        tail_n = ranges[-1][1] - ranges[-1][0]
+        if nring > 1 and (len(ranges) > 2 or tail_n == chunk):   # (two chunks of which the last is shorter: ring slot 1 is never used)
+            pending[1] = _Lazy(lambda: _Stage(params(chunk), dshape, device, routes, staged_f32), device)
+        if tail_n != chunk:
+            pending["tail"] = _Lazy(lambda: _Stage(params(tail_n), dshape, device, routes, staged_f32), device)
+
+        def take(key):   # a slot built by the helper thread, registered with `slots` so that the epilogue drains and waits for it
+            st = pending.pop(key).get()
+            slots.append(st)
+            return st
+        ring = {0: slots[0]}
+        tail = None
         for i, (b0, b1) in enumerate(ranges):
-            slot = tail if (tail is not None and i == len(ranges) - 1) else slots[i % min(2, len(ranges))]
+            if "tail" in pending and i == len(ranges) - 1:
+                tail = take("tail")
+            if tail is not None and i == len(ranges) - 1:
+                slot = tail
+            else:
+                if i % nring not in ring:
+                    ring[i % nring] = take(i % nring)
+                slot = ring[i % nring]
             if slot.range is not None:  # the slot still holds the chunk of two iterations ago
                 drain(slot)
             # staging copy pageable -> pinned by the library's own threads (torch's CPU copy_ is bimodal on the MI355X boxes:
@@ -316,17 +403,19 @@ def generate_host(image, depth_map, divergence, separation, modes, stereo_balanc
                 except BaseException:
                     pass
         s_h2d.synchronize(); s_d2h.synchronize()
+        for lz in pending.values():   # (an exception before a helper-built slot was taken)
+            lz.thread.join()
         if results is not None:
             results.thread.join()
 
 
-def prewarm(frames, h, w, depth_shape=None, modes="left-right", fill="polylines_soft", batch_size=12, device=None, calls=2):
-    """Allocate -- and release into PyTorch's caching allocators -- the pinned result tensors, the pinned staging buffers and
-    the device buffers a `generate_host` call of this shape needs, so that the FIRST call of a process finds them cached
-    (a pinned allocation runs at 24 GB/s: 0.8 s for the 19 GB of a 32-frame 4K call, four times the call itself).
-    `calls`: result sets to warm (a caller that still holds the previous results needs a second set).  Blocking; run it on a
-    thread (`prewarm_async`).  The memory stays in PyTorch's caches (torch.cuda.empty_cache() / the host allocator's own
-    release give it back)."""
+def prewarm(frames, h, w, depth_shape=None, modes="left-right", fill="polylines_soft", batch_size=12, device=None, calls=1):
+    """OPT-IN warm-up (nothing calls it unless the user asks: GenerateStereo.PREWARM / COMFYSTEREO_PREWARM): allocate -- and
+    release into PyTorch's caching allocators -- the pinned staging buffers, the device buffers and, when they fit under
+    PINNED_POOL_BYTES, the pinned result tensors a `generate_host` call of this shape needs, so that the FIRST call of a
+    process finds them cached (a pinned allocation runs at 24 GB/s).  `calls`: result sets to warm (a caller that still holds the
+    previous results needs a second set).  Blocking; run it on a thread (`prewarm_async`).  The memory stays in PyTorch's caches
+    until a call with a smaller need releases it (`_pinned_budget`) or torch.cuda.empty_cache() / `_release_pinned_cache()`."""
     if not torch.cuda.is_available():
         return False
     device = device or torch.device("cuda", torch.cuda.current_device())
@@ -343,8 +432,15 @@ def prewarm(frames, h, w, depth_shape=None, modes="left-right", fill="polylines_
     else:
         chunk = _chunk_frames(frames, 4 * (oh * ow * 3 + 2 * h * w * 3 + mh * mw), fill, batch_size)
     shapes = ((frames, oh, ow, 3), (frames, h, w, 3), (frames, h, w, 3), (frames, mh, mw))
-    keep = [[torch.empty(sh, dtype=torch.float32, pin_memory=True) for sh in shapes] for _ in range(max(1, calls))]
     nslots = min(2, (frames + chunk - 1) // chunk)
+    per_frame_in = 4 * (h * w * 3 + dshape[0] * dshape[1] * dshape[2])
+    staging_bytes = (chunk * nslots + frames % chunk) * (per_frame_in + _small_bytes_per_frame(ROUTES[kind], oh, ow, h, w, mh, mw))
+    result_bytes = 4 * frames * (oh * ow * 3 + 2 * h * w * 3 + mh * mw)
+    pin_results = staging_bytes + result_bytes <= PINNED_POOL_BYTES   # (what generate_host will decide for this shape)
+    _pinned_budget(staging_bytes + (result_bytes if pin_results else 0))
+    keep = []
+    if pin_results:
+        keep = [[torch.empty(sh, dtype=torch.float32, pin_memory=True) for sh in shapes] for _ in range(max(1, calls))]
     keep.append([_Stage(p(chunk), dshape, device, ROUTES[kind], False) for _ in range(nslots)])
     if frames % chunk:
         keep.append(_Stage(p(frames % chunk), dshape, device, ROUTES[kind], False))

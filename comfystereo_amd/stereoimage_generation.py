@@ -113,11 +113,12 @@ def _create_stereoimages_numpy(original_image, depthmap, divergence, separation,
     dep_t = torch.from_numpy(np.ascontiguousarray(depth)).to(dev)
     dep_l = dep_r = dep_t
     if direction_aware_depth_blur:   # (strength <= 0: the depth map itself for both eyes, :1374)
-        try:
-            dep_l, dep_r = engine.directional_blur_scipy(dep_t, depth_blur_strength, depth_blur_edge_threshold, depth_blur_strength,
-                                                         depth_blur_falloff, depth_blur_vert_smooth)
-        except RuntimeError as e:   # a strength that rounds to a box of 0 taps: scipy raises in the reference as well
-            raise RuntimeError("no filter weights given") from e
+        # a strength that rounds to a box of 0 taps: scipy's convolve1d raises in the reference as well (:1402-1405).  Tested here,
+        # not by re-labelling whatever the native call raises (a HIP failure or an out-of-memory error must stay what it is)
+        if depth_blur_strength > 0 and int(round(depth_blur_strength)) < 1:
+            raise RuntimeError("no filter weights given")
+        dep_l, dep_r = engine.directional_blur_scipy(dep_t, depth_blur_strength, depth_blur_edge_threshold, depth_blur_strength,
+                                                     depth_blur_falloff, depth_blur_vert_smooth)
     left_div, right_div = divergence * (1 + stereo_balance), divergence * (1 - stereo_balance)
 
     def eye(dep, div_signed, sep_signed, enabled):

@@ -105,3 +105,44 @@ def test_chunks_on_a_1080p_batch(engine, dev_switch):
     one = run(engine, img, depth, "polylines_soft", "left-right", True)
     for a, b in zip(auto, one):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_profile_tiles_counts_on_the_device_over_all_chunks(engine, dev_switch):
+    """cs_profile_tiles (the share of 64 x 32 blur tiles the profiled calls wrote, which bench.py turns into the kernel's own byte
+    count): counted on the device into a buffer the LIBRARY owns, accumulated over the chunks of a call -- ADVICE r4: the first
+    version read the last chunk's map through a pointer into the caller's workspace, which dangles once that is freed."""
+    import ctypes
+    from comfystereo_amd import _native
+    L = _native.lib()
+    n, h, w = 6, 160, 1100
+    img = cuda(synth.image_f32(n, h, w, seed=5))
+    depth = cuda(synth.depth_batch("stepped", n, h, w, channels=3))
+    p = lambda: engine.make_params(n, h, w, h, w, 3, "polylines_soft", "left-right", 6.0, 0.0, 0.0, 0.5, 2.0, True, 20.0, 20.0, 2.0, 6, 12)
+    frac = ctypes.c_double(-2.0)
+
+    def measure(chunks):
+        dev_switch("chunks", chunks)
+        plan = engine.Plan(p(), img.device)
+        L.cs_profile(1)
+        plan.run(img, depth)
+        L.cs_profile(0)
+        del plan   # the workspace goes back to the allocator before the count is read
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        _native.check(L.cs_profile_tiles(ctypes.byref(frac)))
+        return frac.value
+
+    one, three = measure(1), measure(3)
+    assert 0.0 < one < 1.0 and one == three
+    # the map itself, from the blur call: tiles with an edge in reach on stepped depth are a minority
+    assert one < 0.6
+    # nothing profiled since cs_profile(1): -1
+    L.cs_profile(1); L.cs_profile(0)
+    _native.check(L.cs_profile_tiles(ctypes.byref(frac)))
+    assert frac.value == -1.0
+    # a technique whose warp kernel does not read lazy tiles (complete maps): -1 as well
+    L.cs_profile(1)
+    q = engine.make_params(2, h, w, h, w, 3, "polylines_soft", "left-only", 6.0, 0.0, 0.0, 0.5, 2.0, True, 20.0, 20.0, 2.0, 6, 12)
+    engine.Plan(q, img.device).run(img[:2], depth[:2])
+    L.cs_profile(0)
+    _native.check(L.cs_profile_tiles(ctypes.byref(frac)))
+    assert frac.value == -1.0

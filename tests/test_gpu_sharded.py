@@ -115,7 +115,7 @@ def test_two_ranks_with_the_hip_kernels_equal_the_oracle_on_the_whole_batch(fill
 
 
 @pytest.mark.parametrize("config,frames,gather", [("metric", 8, "collective"), ("cfg5", 4, "collective"), ("cfg4", 48, "collective"),
-                                                  ("metric", 8, "p2p"), ("cfg4", 48, "p2p")])
+                                                  ("metric", 8, "p2p"), ("cfg4", 48, "p2p"), ("metric", 8, "none"), ("cfg4", 48, "none")])
 def test_bench_two_ranks_verify(config, frames, gather):
     """`bench.py --gpus 2 --verify` (the N > 1 step the driver times) as two torchrun ranks sharing the GPU: every rank's
     block of the reassembled batch and one foreign sub-batch equal a local float32 run; the line carries the three-way
@@ -130,7 +130,10 @@ def test_bench_two_ranks_verify(config, frames, gather):
     assert r.stdout.count("[verify] rank") == 2 and "MISMATCH" not in r.stdout
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["frames_total"] == frames
-    assert set(line["split"]) >= {"kernels_only_fps", "kernels_plus_allgather_fps", "end_to_end_fps"}
+    if gather == "none":   # every rank keeps its own float32 block: no exchange step, the value IS the kernels-only rate
+        assert "split" not in line and line["config"]["collective"].startswith("none")
+    else:
+        assert set(line["split"]) >= {"kernels_only_fps", "kernels_plus_allgather_fps", "end_to_end_fps"}
     assert line["diagnostics"]["kernel_error_flags"] == 0
     assert line["ranks"]["world_size"] == 2 and line["ranks"]["all_reduce_of_ones"] == 2 and len(line["ranks"]["devices"]) == 2
     assert line["config"]["gather"] == gather

@@ -81,12 +81,67 @@ def test_fails_loudly_without_a_gpu():
         sig.apply_stereo_divergence(torch.zeros(4, 4, 3, dtype=torch.uint8), dep[0, :, :, 0], 5.0, 0.0, 2.0, "none_post")
 
 
+def test_import_allocates_nothing_and_starts_no_thread():
+    """ADVICE r4 (medium) / VERDICT r4 item 8: the node module's warm-up is OPT-IN (GenerateStereo.PREWARM / COMFYSTEREO_PREWARM).
+    With PREWARM None -- the default -- importing the module inside ComfyUI starts no thread, initialises no GPU and page-locks
+    nothing, like the reference's module."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, types, threading\n"
+        "m = types.ModuleType('comfy'); u = types.ModuleType('comfy.utils')\n"
+        "class ProgressBar:\n"
+        "    def __init__(self, total): pass\n"
+        "    def update(self, k): pass\n"
+        "u.ProgressBar = ProgressBar; m.utils = u; sys.modules['comfy'] = m; sys.modules['comfy.utils'] = u\n"
+        "import torch\n"
+        "from comfystereo_amd import GenerateStereo as gs, host_pipeline as hp\n"
+        "assert gs._IN_COMFYUI is True and gs.PREWARM is None\n"
+        "assert hp._prewarm_thread is None\n"
+        "assert not [t.name for t in threading.enumerate() if t.name.startswith('comfystereo')]\n"
+        "assert not torch.cuda.is_initialized()\n"
+        "st = torch.cuda.host_memory_stats() if hasattr(torch.cuda, 'host_memory_stats') else {}\n"
+        "assert st.get('allocated_bytes.current', 0) == 0 and st.get('reserved_bytes.current', 0) == 0, st\n"
+        "print('inert')\n")
+    env = {k: v for k, v in os.environ.items() if k != "COMFYSTEREO_PREWARM"}
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "inert" in out.stdout, out.stderr[-2000:]
+
+
+def test_prewarm_shape_is_opt_in_by_attribute_or_environment(monkeypatch):
+    assert gs._prewarm_shape() is None
+    monkeypatch.setenv("COMFYSTEREO_PREWARM", "32x2160x3840")
+    assert gs._prewarm_shape() == (32, 2160, 3840)
+    monkeypatch.setenv("COMFYSTEREO_PREWARM", "nonsense")
+    assert gs._prewarm_shape() is None
+    monkeypatch.setattr(gs, "PREWARM", (8, 1080, 1920))
+    assert gs._prewarm_shape() == (8, 1080, 1920)
+
+
+def test_pinned_pool_cap_and_release_when_the_need_shrinks(monkeypatch):
+    """host_pipeline.PINNED_POOL_BYTES caps what the pipeline page-locks for itself; a call that needs less than the previous one
+    releases PyTorch's cached pinned blocks first (they would stay locked for ever otherwise)."""
+    from comfystereo_amd import host_pipeline as hp
+    assert hp.PINNED_POOL_BYTES <= 8 << 30
+    calls = []
+    monkeypatch.setattr(hp, "_release_pinned_cache", lambda: calls.append(1))
+    monkeypatch.setattr(hp, "_last_pinned_need", 0)
+    hp._pinned_budget(4 << 30); assert not calls
+    hp._pinned_budget(4 << 30); assert not calls
+    hp._pinned_budget(5 << 30); assert not calls
+    hp._pinned_budget(1 << 30); assert calls == [1]
+    # compact output forms per 4K frame: stereoscope codes 2 x 3 bytes per pixel, two depth codes, the SBS mask's two
+    assert hp._small_bytes_per_frame(hp.ROUTES["compact"], 2160, 7680, 2160, 3840, 2160, 7680) == 2160 * 3840 * (6 + 1 + 1 + 2)
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
-def test_import_time_warm_up_is_inert_without_a_gpu_and_outside_comfyui():
-    """GenerateStereo.PREWARM (the pinned-memory warm-up the node module starts at import inside ComfyUI):
-    nothing is started outside ComfyUI, and without a GPU the warm-up itself declines instead of raising."""
+def test_warm_up_is_inert_without_a_gpu_and_outside_comfyui():
+    """host_pipeline.prewarm (opt-in): nothing is started outside ComfyUI, and without a GPU the warm-up
+    itself declines instead of raising."""
     from comfystereo_amd import host_pipeline
-    assert gs.PREWARM == (32, 2160, 3840) and gs._IN_COMFYUI is False
+    assert gs.PREWARM is None and gs._IN_COMFYUI is False
     assert host_pipeline._prewarm_thread is None
     assert host_pipeline.prewarm(2, 64, 64) is False
     t = host_pipeline.prewarm_async(2, 64, 64)

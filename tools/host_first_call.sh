@@ -1,0 +1,13 @@
+#!/bin/bash
+# first-call frames/s of the node with host tensors, one fresh process per measurement: three shapes x {cold, opt-in warm-up}
+#  -> stdout (copied to profiles/r05_host.txt by the session script)
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+for shape in "32 2160 3840" "8 2160 3840" "96 1080 1920"; do
+  set -- $shape
+  for pw in 0 1; do
+    echo "== $1 frames $3x$2, prewarm=$pw"
+    timeout 300 python tools/node_host_bench.py --n $1 --h $2 --w $3 --prewarm $pw --first-only 1 2>&1 | grep -v Warning
+  done
+done
+echo "== steady state, 32 frames 4K (pageable results under the 8 GB cap)"
+timeout 300 python tools/node_host_bench.py --n 32 --prewarm 0 --iters 3 2>&1 | grep -v Warning

@@ -20,13 +20,14 @@ ap.add_argument("--iters", type=int, default=2)
 ap.add_argument("--fill", default="Fill - Polylines Soft")
 ap.add_argument("--prewarm", type=int, default=1, help="1: what GenerateStereo.py does at import inside ComfyUI (host_pipeline."
                 "prewarm of this shape, waited for: ComfyUI loads its models meanwhile); 0: cold caches")
+ap.add_argument("--first-only", type=int, default=0, help="1: stop after the first two calls (first-call measurements per shape)")
 a = ap.parse_args()
 from comfystereo_amd import host_pipeline as _hp
 from comfystereo_amd.GenerateStereo import FILL_TECHNIQUE_MAPPING as _FM
 if a.prewarm:
     t0 = time.perf_counter()
     _hp.prewarm(a.n, a.h, a.w, fill=_FM[a.fill])
-    print(f"prewarm (at import, off the first call's path): {time.perf_counter() - t0:.2f} s")
+    print(f"prewarm (opt-in, off the first call's path): {time.perf_counter() - t0:.2f} s")
 img = torch.from_numpy(synth.image_f32(1, a.h, a.w, seed=1)).expand(a.n, -1, -1, -1).contiguous()
 dep = torch.from_numpy(synth.depth_batch("stepped", a.n, a.h, a.w, channels=3))
 node = StereoImageNode()
@@ -41,7 +42,12 @@ out2 = node.generate(img, dep, *args)   # (the first call's results still held b
 torch.cuda.synchronize()
 dt_second = time.perf_counter() - t0
 print(f"second call, first results still held: {dt_second*1e3:.1f} ms -> {a.n/dt_second:.1f} frames/s")
+print(f"results pinned: {out[0].is_pinned()}; pinned host memory reserved by PyTorch: "
+      f"{torch.cuda.host_memory_stats().get('reserved_bytes.current', 0) / 1e9:.2f} GB; 4K-equivalent first call: "
+      f"{a.n * (a.h * a.w) / (2160 * 3840) / dt_first:.1f} frames/s")
 del out2
+if a.first_only:
+    sys.exit(0)
 t0 = time.perf_counter()
 for _ in range(a.iters):
     out = node.generate(img, dep, *args)
