@@ -382,6 +382,28 @@ static size_t poly_anaglyph_bytes(int n, int h, int w) { return al256((size_t)n 
 static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_t stream, uint8_t* ana_sbs = nullptr,
                     void* replay_scratch = nullptr, size_t replay_surplus = 0) {
     const bool poly = fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP;
+    // anaglyph modes of the tiled polylines path (round 5): BOTH kernels -- the tile kernel and the row kernel over the rows it
+    // flags -- write the two eyes as uint8 codes side by side into scratch (no mask), and k_anaglyph_compose makes the composite
+    // of every row afterwards.  The row kernel then runs in its side-by-side form: no anaglyph stash in LDS (the width limit of
+    // the side-by-side modes: polylines_sharp 7 990 instead of 6 395 columns), and its order-dependent stretches go to the replay
+    // kernel like those of the other modes.  (Rounds 2-4 let the row kernel write flagged rows in final anaglyph form.)
+    // soft / sharp: the point-owner kernel (cs_polypoint.hip) unless the halo is too wide for it or the development switch
+    // CS_DEBUG_PT_VARIANT asks for the first generation (cs_polytile.hip)
+    const int variant = dev_switch(CS_DEBUG_PT_VARIANT);   // 0 / 3 .. 7: point-owner kernel; 41 - 43: tie-path what-ifs; other values: first generation
+    auto polypoint_takes = [&](int hl) {
+        return hl <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16) || (variant >= 41 && variant <= 43));
+    };
+    // (the tile kernels are dialect D32, plus -- round 5 -- the float64 disparity chain alone for polylines_soft)
+    const bool tile_dialect = A.d64 == 0 || (A.d64 == 1 && fill == CS_FILL_POLYLINES_SOFT && polypoint_takes(halo));
+    const bool ana_tiled = poly && tile_dialect && A.anaglyph && ana_sbs && A.image_f32 && !A.out_u8 && halo <= polytile_max_halo() && rowflag &&
+                           !dev_switch(CS_DEBUG_NO_TILE);
+    const RowArgs Afinal = A;
+    if (ana_tiled) {
+        A.anaglyph = 0; A.single = -1;
+        A.stereo = reinterpret_cast<float*>(ana_sbs); A.stereo_is_u8 = 1; A.no_mask = 1; A.mask = nullptr;
+        A.out_h = A.h; A.out_w = 2 * A.w;
+        A.eye[0].xoff = 0; A.eye[0].yoff = 0; A.eye[1].xoff = A.w; A.eye[1].yoff = 0;
+    }
     // polylines, eyes in separate output slots: the stretches of order-dependent rows are replayed by a kernel of their own
     // (cs_rowwarp.hip k_poly_replay) instead of inside the row kernel
     const bool replay = poly && !A.d64 && replay_scratch && rowflag && !A.anaglyph && !dev_switch(CS_DEBUG_NO_REPLAY_KERNEL) &&
@@ -389,8 +411,8 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
     bool cleared = false;   // the flagged-row block (row flags, counters, replay counters and retry flags) has been zeroed
     if (replay)
         (void)poly_replay_attach(A, fill == CS_FILL_POLYLINES_SHARP, replay_scratch, rowflag + al256((size_t)A.n * A.h) + 256, stream, replay_surplus);
-    if (poly && !A.d64 && (!A.anaglyph || (ana_sbs && A.image_f32 && !A.out_u8)) && halo <= polytile_max_halo() && rowflag &&
-        !dev_switch(CS_DEBUG_NO_TILE)) {   // (the tile kernels are dialect D32)
+    if (poly && tile_dialect && !A.anaglyph && halo <= polytile_max_halo() && rowflag &&
+        !dev_switch(CS_DEBUG_NO_TILE)) {   // (anaglyph calls arrive here in their side-by-side form)
         // workspace: [n*h flag bytes][count, padded to 256][n*h list entries]
         const size_t rows = (size_t)A.n * A.h;
         uint32_t* count = (uint32_t*)(rowflag + al256(rows));
@@ -398,27 +420,12 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         hipError_t e = hipMemsetAsync(rowflag, 0, rowflag_clear_bytes(rows), stream);
         if (e != hipSuccess) return fail_hip(e, "rowflag memset");
         cleared = true;
-        // soft: the point-owner kernel (cs_polypoint.hip) unless the halo is too wide for it or the development switch
-        // CS_DEBUG_PT_VARIANT >= 1 asks for the first generation (cs_polytile.hip); sharp: first generation
-        const int variant = dev_switch(CS_DEBUG_PT_VARIANT);   // 0 / 3 / 4: point-owner kernel; other values: first generation
-        // anaglyph modes: the tile kernels write the two eyes as uint8 codes side by side into scratch (no mask), the rows they
-        // flag are redone by the row kernel in final form, k_anaglyph_compose makes the composite of the others
-        RowArgs T = A;
-        if (A.anaglyph) {
-            T.anaglyph = 0; T.single = -1;
-            T.stereo = reinterpret_cast<float*>(ana_sbs); T.stereo_is_u8 = 1; T.no_mask = 1; T.mask = nullptr;
-            T.out_h = A.h; T.out_w = 2 * A.w;
-            T.eye[0].xoff = 0; T.eye[0].yoff = 0; T.eye[1].xoff = A.w; T.eye[1].yoff = 0;
-        }
-        if (halo <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16) || (variant >= 41 && variant <= 43)))   // (41 - 43: tie-path what-ifs)
+        const RowArgs& T = A;
+        if (polypoint_takes(halo))
             e = launch_polypoint(T, halo, rowflag, stream, fill == CS_FILL_POLYLINES_SHARP);
         else
             e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, T, halo, rowflag, stream);
         if (e != hipSuccess) return fail_hip(e, "tiled polylines launch");
-        if (A.anaglyph) {
-            e = launch_anaglyph_compose(ana_sbs, rowflag, A.n, A.h, A.w, A.anaglyph, A.stereo, A.stereo_is_u8, A.mask, stream);
-            if (e != hipSuccess) return fail_hip(e, "anaglyph composition launch");
-        }
         // single-eye modes (left-only / only-right): the tile kernels visit one eye, both depth maps are outputs all the same
         if (A.neyes == 2 && A.single >= 0 && !A.out_u8) {
             const int other = 1 - A.single;
@@ -482,6 +489,11 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         e = launch_rowwarp(fill, R, threads_for(fill, A.w), stream, dev_switch(CS_DEBUG_PT_VARIANT) == 42 ? 32 : 256);
         if (e != hipSuccess) return fail_hip(e, "row kernel launch (replay retry)");
     }
+    if (ana_tiled) {   // R from one eye, G and B from the other, k / 255, the mask of the composite -- every row
+        e = launch_anaglyph_compose(ana_sbs, nullptr, Afinal.n, Afinal.h, Afinal.w, Afinal.anaglyph, Afinal.stereo, Afinal.stereo_is_u8,
+                                    Afinal.mask, stream);
+        if (e != hipSuccess) return fail_hip(e, "anaglyph composition launch");
+    }
     return CS_OK;
 }
 
@@ -508,9 +520,23 @@ const char* cs_last_error(void) { return g_err; }
 
 // widest frame the LDS-resident row kernels take; anaglyph modes keep two channels of the first eye per pixel as well
 static int max_width_for(int fill, int anaglyph) {
+    // (polylines, round 5: the anaglyph modes run both kernels in their side-by-side form and compose afterwards, run_rows above:
+    // no anaglyph stash in LDS, the limit of the side-by-side modes.  A call whose halo is too wide for the tile kernels still takes
+    // the row kernel's anaglyph form: cs_generate checks that case against `row_form_max_width`)
+    if (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP) anaglyph = 0;
     if (fill == CS_FILL_GPU_WARP) return gpuwarp_max_width();   // (the mesh-quality variant, cs_params.flags bit 2: cs_forward_warp_mesh's limit)
     if (fill == CS_FILL_HYBRID_EDGE) return hybrid_max_width();
     if (fill < 0 || fill > CS_FILL_HYBRID_EDGE_PLUS) return 0;
+    int lo = 0, hi = 1 << 16;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) / 2;
+        if (rowwarp_lds_bytes(fill, mid, anaglyph) <= CS_LDS_BYTES && poly_npt(mid, 1) < 65535) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+// widest row the row kernel takes in its own anaglyph form (two more bytes of LDS per column)
+static int row_form_max_width(int fill, int anaglyph) {
     int lo = 0, hi = 1 << 16;
     while (lo < hi) {
         int mid = (lo + hi + 1) / 2;
@@ -573,8 +599,8 @@ static WsLayout ws_layout(const cs_params* p) {
     if (p->fill == CS_FILL_GPU_WARP) o += al256(gpuwarp_workspace_bytes(p->n, p->h, p->w, p->batch_size, p->flags & 4));
     if ((p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP) &&
         (p->mode == CS_MODE_RED_CYAN_ANAGLYPH || p->mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH))
-        o += poly_anaglyph_bytes(p->n, p->h, p->w);
-    else if (p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP)   // scratch of the stretch replay kernel
+        o += poly_anaglyph_bytes(p->n, p->h, p->w);   // (both eyes as uint8 codes side by side; the replay scratch behind it)
+    if (p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP)   // scratch of the stretch replay kernel
         o += al256(poly_replay_bytes(p->n, p->h, p->w, p->fill == CS_FILL_POLYLINES_SHARP));
     W.total = o;
     return W;
@@ -770,8 +796,9 @@ static int generate_chunk(const cs_params* p, const float* image, const float* d
         rc = launch_hybrid(A, ws + W.extra, stream, p->fill == CS_FILL_HYBRID_EDGE_PLUS, halo);
         if (rc) return fail(rc, "hybrid_edge launch failed");
     } else {
+        const bool poly_ana = A.anaglyph && (p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP);
         rc = run_rows(p->fill, A, halo, (uint8_t*)(ws + W.rowflag), stream, A.anaglyph ? (uint8_t*)(ws + W.extra) : nullptr,
-                      A.anaglyph ? nullptr : (void*)(ws + W.extra), surplus);
+                      (void*)(ws + W.extra + (poly_ana ? poly_anaglyph_bytes(p->n, p->h, p->w) : 0)), surplus);
         if (rc) return rc;
     }
     hipError_t e = hipGetLastError();
@@ -791,6 +818,14 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     if (p->w > cs_max_width_mode(p->fill, p->mode) ||
         !dialect_width_ok(p->fill, p->w, p->mode == CS_MODE_RED_CYAN_ANAGLYPH || p->mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH, (p->flags >> 3) & 3))
         return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
+    if ((p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP) &&
+        (p->mode == CS_MODE_RED_CYAN_ANAGLYPH || p->mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH) && p->w > row_form_max_width(p->fill, 1)) {
+        // an anaglyph wider than the row kernel's anaglyph form: only through the tile kernels (D32, halo within their reach)
+        const int halo = poly_halo(p->divergence * (1 + p->stereo_balance), p->divergence * (1 - p->stereo_balance), p->separation,
+                                   p->stereo_offset_exponent, p->convergence_point, p->w);
+        if ((p->flags & 24) || halo > polytile_max_halo() || dev_switch(CS_DEBUG_NO_TILE))
+            return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel (anaglyph form)");
+    }
     if (workspace_bytes < ws_total(p)) return fail(CS_EWORKSPACE, "workspace too small");
     if (p->fill == CS_FILL_GPU_WARP && (p->flags & 2)) return fail(CS_EINVAL, "gpu_warp colours are not k/255: no uint8 stereoscope output");
     if ((p->flags & 24) && !dialect_d64_ok(p->fill))

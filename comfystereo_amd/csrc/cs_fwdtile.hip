@@ -47,12 +47,24 @@ struct FwdTileArgs {
     int out_h, out_w;
     int dbg;
     const uint32_t* tilemap; const float* gray; int tm_words;   // lazy depth-blur tiles (cs_common.h) or null
+    int d64; double e64;  // dialect bits (RowArgs::d64: 1 = float64 disparity chain, 2 = int64 pixel sums) and the exponent as a double
 };
+
+// `sign * (abs(d) ** e) * div` of dialect D64 (numba typing; cs_rowwarp.hip disparity64): float64 throughout.
+// pow(x, 2.0) == x * x and pow(x, 1.0) == x exactly (the product of two float32 values is exact in float64; libm returns the
+// correctly rounded -- here: exact -- result for both), any other exponent takes the device library's pow (<= 1 ulp from libm's:
+// only int() / floor() of the offset plus a pixel coordinate is used).
+__device__ __forceinline__ double fw_disparity64(float d, double e64, double div64) {
+    const double s = d >= 0.0f ? 1.0 : -1.0, ax = (double)fabsf(d);
+    const double p = e64 == 2.0 ? ax * ax : (e64 == 1.0 ? ax : pow(ax, e64));
+    return (s * p) * div64;
+}
 
 struct FwF3 { float x, y, z; };
 struct FwB3 { uint8_t x, y, z; };
 
-template <int NT, int SLOTS, int FILL>
+// DIA (round 5): the instantiation that runs the dialect bits A.d64 -- D64 at tile speed; the D32 kernel keeps its registers
+template <int NT, int SLOTS, int FILL, bool DIA = false>
 __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -78,7 +90,10 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
     uint16_t* istart = (uint16_t*)(tmpv + NPT);
     uint8_t* fl = (uint8_t*)(istart + NPT);
     bool giveup = false;
-    auto sum8 = [](uint32_t c) { return ((c & 0xffu) + ((c >> 8) & 0xffu) + ((c >> 16) & 0xffu)) & 0xffu; };   // uint8 sum: wraps (quirk Q5)
+    // sum() of a pixel: uint8, wraps mod 256 in D32 (quirk Q5); int64 under numba (dialect bit 1)
+    const unsigned smask = (DIA && (A.d64 & 2)) ? 0xffffu : 0xffu;
+    auto sum8 = [&](uint32_t c) { return ((c & 0xffu) + ((c >> 8) & 0xffu) + ((c >> 16) & 0xffu)) & smask; };
+    const bool f64chain = DIA && (A.d64 & 1);
 
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
     const uint32_t rowpix = ((uint32_t)frame * (uint32_t)h + (uint32_t)row) * (uint32_t)w;
@@ -182,7 +197,8 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
             if (FILL == CS_FILL_INVERSE) {
                 const float off = (sg * pw[k]) * E.div32;
                 const float dest = ((float)(s0 + j) + 0.5f + off) + E.sep32;   // (:1725)
-                const float fl = floorf(dest);
+                float fl = floorf(dest);
+                if (f64chain) fl = (float)floor((((double)(s0 + j) + 0.5) + fw_disparity64(nd[k], A.e64, E.div64)) + E.sep64);   // (range test and int() only)
                 if (j < ns && fl >= -2.0f && fl <= (float)w) {
                     const int q = (int)fl - o0;
                     const unsigned long long kk = ((unsigned long long)csm::f2ord(nd[k]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)j);
@@ -192,7 +208,11 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
             } else {
                 const float off = ((sg * pw[k]) * E.div32) + E.sep32;                  // (:1865)
                 // int(): truncation toward zero; keep the conversion defined for absurd offsets
-                const int io = off >= 2147483520.0f ? 0x7fffff00 : (off <= -2147483520.0f ? -0x7fffff00 : (int)off);
+                int io = off >= 2147483520.0f ? 0x7fffff00 : (off <= -2147483520.0f ? -0x7fffff00 : (int)off);
+                if (f64chain) {
+                    const double o64 = fw_disparity64(nd[k], A.e64, E.div64) + E.sep64;
+                    io = o64 >= 2147483520.0 ? 0x7fffff00 : (o64 <= -2147483520.0 ? -0x7fffff00 : (int)o64);
+                }
                 const long long q = (long long)(s0 + j - c0) + io;
                 if (j < ns && q >= 0 && q < nwin) {
                     if (E.asc) atomicMax(&winner[(int)q], j);
@@ -202,14 +222,59 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
         }
         __syncthreads();
         if (FILL == CS_FILL_NAIVE_INTERPOLATING) {
-            for (int p = tid; p < nwin; p += NT) {
-                const int s = winner[p];
-                const bool f = s != init;
+            // (round 5) The filled / good flags of the window also exist as BIT ROWS (one wave ballot per 64 columns, in the idle upper
+            // half of `key`): a pixel finds the good pixels around it and the first unfilled pixel of its interval with clz / ctz on
+            // one or two words instead of walking the flag bytes (up to 2 S dependent LDS reads per hole pixel, the wave waiting
+            // for its longest walker: SQ_WAIT_ANY was 65 % of the wave-cycles, profiles/r05a_naive_interp), and the intervals that
+            // hit the re-trigger quirk are replayed by a whole WAVE each -- the triggers one after the other as in the reference,
+            // every search and every ramp in parallel over the wave's lanes -- instead of literally by one lane.
+            unsigned long long* const fbits = key + NPT / 2;      // [NPT / 64] filled
+            unsigned long long* const gbits = fbits + NPT / 64;   // [NPT / 64] good = filled and a colour sum != 0
+            unsigned long long* const qbits = gbits + NPT / 64;   // [NPT / 64] interval starting here needs the replay
+            const int nw = (nwin + 63) >> 6;
+            for (int pb = (tid >> 6) * 64; pb < nwin; pb += NT) {
+                const int p = pb + (tid & 63);
+                const bool in = p < nwin;
+                const int s = in ? winner[p] : init;
+                const bool f = in && s != init;
                 const uint32_t c = f ? img[s] : 0u;
-                colw[p] = c;
-                fl[p] = (uint8_t)((f ? 1 : 0) | ((f && sum8(c) != 0u) ? 2 : 0));
+                const bool good = f && sum8(c) != 0u;
+                if (in) { colw[p] = c; fl[p] = (uint8_t)((f ? 1 : 0) | (good ? 2 : 0)); }
+                const unsigned long long fb = __ballot(f), gb = __ballot(good);
+                if ((tid & 63) == 0) { fbits[pb >> 6] = fb; gbits[pb >> 6] = gb; qbits[pb >> 6] = 0ull; }
             }
             __syncthreads();
+            // largest set bit below p (-1: none) / smallest set bit above p (nwin: none) / smallest CLEAR bit of `fbits` at or above p
+            auto prev_set = [&](const unsigned long long* bits, int p) {
+                if (p <= 0) return -1;
+                int wi = (p - 1) >> 6;
+                unsigned long long cur = bits[wi] & (~0ull >> (63 - ((p - 1) & 63)));
+                while (true) {
+                    if (cur) return wi * 64 + 63 - __clzll((long long)cur);
+                    if (--wi < 0) return -1;
+                    cur = bits[wi];
+                }
+            };
+            auto next_set = [&](const unsigned long long* bits, int p) {
+                int wi = (p + 1) >> 6;
+                if (wi >= nw) return nwin;
+                unsigned long long cur = bits[wi] & (~0ull << ((p + 1) & 63));
+                while (true) {
+                    if (cur) return min(wi * 64 + __ffsll((long long)cur) - 1, nwin);
+                    if (++wi >= nw) return nwin;
+                    cur = bits[wi];
+                }
+            };
+            auto next_clear = [&](const unsigned long long* bits, int p) {   // (bits beyond nwin are clear: the result is clamped)
+                int wi = p >> 6;
+                if (wi >= nw) return nwin;
+                unsigned long long cur = ~bits[wi] & (~0ull << (p & 63));
+                while (true) {
+                    if (cur) return min(wi * 64 + __ffsll((long long)cur) - 1, nwin);
+                    if (++wi >= nw) return nwin;
+                    cur = ~bits[wi];
+                }
+            };
             auto flag_or = [&](int p, unsigned bit) { atomicOr((unsigned*)fl + (p >> 2), bit << ((p & 3) * 8)); };
             auto ramp = [&](uint32_t lb, uint32_t rb, float total, float k) {   // l_border + (step * k).astype(uint8), per channel
                 uint32_t v = 0;
@@ -222,40 +287,68 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
             };
             for (int p = tid; p < nwin; p += NT) {
                 if (fl[p] & 2) continue;
-                int lg = p, l0 = -1;
-                while (lg >= 0 && !(fl[lg] & 2)) { if (!(fl[lg] & 1)) l0 = lg; lg--; }
-                int g = p + 1;
-                while (g < nwin && !(fl[g] & 2)) g++;
+                const int lg = prev_set(gbits, p), g = next_set(gbits, p);
                 if ((lg < 0 && c0 > 0) || (g >= nwin && c1 < w)) { flag_or(p, 16u); continue; }   // the interval leaves the window
                 const int s0i = lg + 1;
                 istart[p] = (uint16_t)s0i;
-                if (l0 < 0 || p < l0) continue;   // no unfilled pixel in the interval up to here: untouched
+                const int l0 = next_clear(fbits, s0i);   // the first unfilled pixel of the interval: the first trigger
+                if (l0 >= g || p < l0) continue;         // no unfilled pixel in the interval up to here: untouched
                 uint32_t lb = l0 > 0 ? colw[l0 - 1] : 0u, rb = g < nwin ? colw[g] : 0u;   // (l0 == 0 only at the frame's first column)
                 if (sum8(lb) == 0u) lb = rb;
                 else if (sum8(rb) == 0u) rb = lb;
                 const uint32_t v = ramp(lb, rb, (float)(1 + g - l0), (float)(p - l0 + 1));
                 tmpv[p] = v;
                 flag_or(p, 4u);
-                if (p > l0 && !(fl[p] & 1) && sum8(v) == 0u) flag_or(s0i, 8u);   // the quirk: re-trigger -> literal replay
+                // the quirk: an unfilled pixel whose ramp value sums to 0 triggers again -> the interval is replayed trigger by trigger
+                if (p > l0 && !(fl[p] & 1) && sum8(v) == 0u) atomicOr(&qbits[s0i >> 6], 1ull << (s0i & 63));
             }
             __syncthreads();
             for (int p = tid; p < nwin; p += NT)
-                if ((fl[p] & 4) && !(fl[istart[p]] & 8)) colw[p] = tmpv[p];
+                if ((fl[p] & 4) && !((qbits[istart[p] >> 6] >> (istart[p] & 63)) & 1ull)) colw[p] = tmpv[p];
             __syncthreads();
-            for (int s = tid; s < nwin; s += NT) {   // literal replay of the flagged intervals, one lane each
-                if ((fl[s] & 2) || (s > 0 && !(fl[s - 1] & 2)) || !(fl[s] & 8)) continue;
-                for (int l = s; l < nwin && !(fl[l] & 2); l++) {
-                    if (sum8(colw[l]) != 0u || (fl[l] & 1)) continue;
-                    uint32_t lb = l > 0 ? colw[l - 1] : 0u, rb = 0u;
-                    int r = l + 1;
-                    while (r < nwin) {
-                        if (sum8(colw[r]) != 0u && (fl[r] & 1)) { rb = colw[r]; break; }
-                        r++;
+            // ---- replay of the flagged intervals (reference :1873-1891 on [s, g)), one WAVE per interval, round-robin
+            {
+                const int lane = tid & 63, wave = tid >> 6;
+                int turn = 0;
+                for (int wi = 0; wi < nw; wi++) {
+                    unsigned long long m = qbits[wi];
+                    m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
+                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)m);
+                    while (m) {
+                        const int s = wi * 64 + __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        if ((turn++ & (NT / 64 - 1)) != wave) continue;
+                        const int g = next_set(gbits, s - 1);   // the good pixel that ends the interval (nwin: the frame's end)
+                        int cur = s;
+                        while (true) {
+                            // the next trigger: the first unfilled pixel at or after `cur` whose CURRENT colour sums to 0
+                            int l = -1;
+                            for (int base = cur; base < g; base += 64) {
+                                const int idx = base + lane;
+                                const bool t = idx < g && !((fbits[idx >> 6] >> (idx & 63)) & 1ull) && sum8(colw[idx]) == 0u;
+                                const unsigned long long b = __ballot(t);
+                                if (b) { l = base + __ffsll((long long)b) - 1; break; }
+                            }
+                            if (l < 0) break;
+                            // its right border: the first filled pixel after it whose current colour does not sum to 0 (ramps written
+                            // over filled black pixels count: they are read as they are NOW)
+                            int r = nwin;
+                            for (int base = l + 1; base <= g && base < nwin; base += 64) {
+                                const int idx = base + lane;
+                                const bool t = idx <= g && idx < nwin && ((fbits[idx >> 6] >> (idx & 63)) & 1ull) && sum8(colw[idx]) != 0u;
+                                const unsigned long long b = __ballot(t);
+                                if (b) { r = base + __ffsll((long long)b) - 1; break; }
+                            }
+                            uint32_t lb = l > 0 ? colw[l - 1] : 0u, rb = r < nwin ? colw[r] : 0u;
+                            if (sum8(lb) == 0u) lb = rb;
+                            else if (sum8(rb) == 0u) rb = lb;
+                            const float total = (float)(1 + r - l);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the wave's reads of colw are done before its lanes overwrite it)
+                            for (int c = l + lane; c < r; c += 64) colw[c] = ramp(lb, rb, total, (float)(c - l + 1));
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (LDS executes a wave's instructions in order: the next search reads these values)
+                            cur = l + 1;
+                        }
                     }
-                    if (sum8(lb) == 0u) lb = rb;
-                    else if (sum8(rb) == 0u) rb = lb;
-                    const float total = (float)(1 + r - l);
-                    for (int c = l; c < r; c++) colw[c] = ramp(lb, rb, total, (float)(c - l + 1));
                 }
             }
             __syncthreads();
@@ -369,7 +462,7 @@ hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, uint8_t* rowflag, 
     constexpr int NT = 256;
     const int SLOTS = (fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING) ? 4 : 3;
     if (fill != CS_FILL_NONE && fill != CS_FILL_INVERSE && fill != CS_FILL_NAIVE && fill != CS_FILL_NAIVE_INTERPOLATING) return hipErrorNotSupported;
-    if (!R.image_f32 || R.out_u8 || R.d64 || R.neyes != 2 || !R.depth_l || !R.depth_r || R.row_list) return hipErrorNotSupported;
+    if (!R.image_f32 || R.out_u8 || R.neyes != 2 || !R.depth_l || !R.depth_r || R.row_list) return hipErrorNotSupported;
     const int S = S0 + (fill == CS_FILL_INVERSE ? 2 : 0);   // (the splat also touches the column right of floor(dest))
     if (S > fwdtile_max_halo()) return hipErrorNotSupported;
     if ((size_t)R.n * R.h * R.w >= (1ull << 31) || (size_t)R.n * R.out_h * R.out_w >= (1ull << 31) || R.n > 65535) return hipErrorNotSupported;
@@ -403,11 +496,17 @@ hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, uint8_t* rowflag, 
     A.out_h = R.out_h; A.out_w = R.out_w;
     A.dbg = R.dbg;
     A.tilemap = R.tilemap; A.gray = R.lazy_gray; A.tm_words = R.tm_words;
+    A.d64 = R.d64; A.e64 = R.e64;
     const int ntiles = (R.w + A.T - 1) / A.T;
     const size_t npt = (size_t)NT * SLOTS;
     const size_t lds = npt * 4 + npt * 8 + (npt / 64) * 8 + (fill == CS_FILL_NAIVE_INTERPOLATING ? npt * (4 + 4 + 2 + 1) : 0) + 64;
     const dim3 grid(ntiles * 8, (R.h + 7) / 8, R.n), block(NT);
-    if (fill == CS_FILL_INVERSE) hipLaunchKernelGGL((k_fwdtile<NT, 3, CS_FILL_INVERSE>), grid, block, lds, stream, A);
+    if (R.d64) {   // dialect D64 (either bit): the same kernels with the float64 offset chain / unwrapped pixel sums compiled in
+        if (fill == CS_FILL_INVERSE) hipLaunchKernelGGL((k_fwdtile<NT, 3, CS_FILL_INVERSE, true>), grid, block, lds, stream, A);
+        else if (fill == CS_FILL_NAIVE) hipLaunchKernelGGL((k_fwdtile<NT, 4, CS_FILL_NAIVE, true>), grid, block, lds, stream, A);
+        else if (fill == CS_FILL_NAIVE_INTERPOLATING) hipLaunchKernelGGL((k_fwdtile<NT, 4, CS_FILL_NAIVE_INTERPOLATING, true>), grid, block, lds, stream, A);
+        else hipLaunchKernelGGL((k_fwdtile<NT, 3, CS_FILL_NONE, true>), grid, block, lds, stream, A);
+    } else if (fill == CS_FILL_INVERSE) hipLaunchKernelGGL((k_fwdtile<NT, 3, CS_FILL_INVERSE>), grid, block, lds, stream, A);
     else if (fill == CS_FILL_NAIVE) hipLaunchKernelGGL((k_fwdtile<NT, 4, CS_FILL_NAIVE>), grid, block, lds, stream, A);
     else if (fill == CS_FILL_NAIVE_INTERPOLATING) hipLaunchKernelGGL((k_fwdtile<NT, 4, CS_FILL_NAIVE_INTERPOLATING>), grid, block, lds, stream, A);
     else hipLaunchKernelGGL((k_fwdtile<NT, 3, CS_FILL_NONE>), grid, block, lds, stream, A);

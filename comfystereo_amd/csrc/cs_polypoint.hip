@@ -49,6 +49,13 @@ namespace cs {
 #ifndef PP_MINW
 #define PP_MINW 7            // workgroups per CU the default geometry is compiled for (register budget)
 #endif
+// polylines_sharp: six workgroups per CU (80 VGPRs).  At the soft kernel's budget (7 per CU, 72 VGPRs) the sharp instantiation
+// spilled 21 vector registers to scratch in its staging phase -- and scratch is memory: per 64 4K frames the kernel read 19.7
+// instead of 8.9 GB and wrote 47.2 instead of 30.0 GB (profiles/r05a_sharp/pmc_fetch.txt, pmc_write.txt: 1.73 x the algorithmic
+// traffic).  Without the spills: 4 015 -> 4 392 frames/s on stepped depth, 3 011 -> 3 357 on blobs (tools/sessions/r05_s3.sh).
+#ifndef PP_SHARP_MINW
+#define PP_SHARP_MINW 6
+#endif
 #define PP_DIRTY 0x80u       // dflag: pixel lies under a reversed segment; low 7 bits = its list slot
 
 __constant__ csm::PowfTables c_pp_powf_tables = CS_POWF_TABLES_INIT;
@@ -82,6 +89,8 @@ struct PolyPointArgs {
     // the per-eye constants packed in 64-bit words, so that the eye of a workgroup is picked by three 64-bit scalar selects
     // instead of eight 32-bit ones: {div32, sep32}, {xoff, yoff}, {st_min, st_max | enabled << 16}
     unsigned long long epk[2][3];
+    // dialect bit "float64 disparity chain" (RowArgs::d64 & 1; the DIA instantiations, polylines_soft only): the exponent as a double
+    int d64; double e64;
 };
 
 struct F3 { float x, y, z; };
@@ -135,7 +144,11 @@ enum { PK_CHAIN = 0u, PK_BRIDGE = 1u };
 // sources interpolate as in soft.  The lane still owns a SOURCE pixel: one 8-byte record {colour codes, x} per source, the two
 // points are x -+ 0.45 on read.  Point ids: 0 = left sentinel, 1 + 2 j = left point of source j, 2 + 2 j = its right point,
 // 2 ns + 1 = right sentinel.
-template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW, int SHARP>
+// DIA (round 5): the float64 disparity chain of dialect D64 (what an install WITH numba computes for
+// `abs(d) ** e * div + sep` and the point x, rounded ONCE into the float32 point array; pinned by tests/golden/dialect_f64.npz)
+// in the staging phase -- everything after it works on the float32 points as in D32.  polylines_soft only: a sharp point is
+// (float)(x64 -+ 0.45), which one float32 centre per source cannot carry.
+template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW, int SHARP, int DIA = 0>
 __global__ void __launch_bounds__(NT, MINW)
 k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
             int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode, int hot_npt,
@@ -432,7 +445,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             if (pow_mode == 0) r = true;
             risk |= r ? 1u << k : 0u;
         }
-        if (PP_DEV_IS(36)) risk = 0;
+        if (PP_DEV_IS(36) || DIA) risk = 0;   // (DIA: the float32 pow is not used)
         // the full powf clone for the risky arguments (all of them for other exponents).  Behind its own branch: the compiler
         // otherwise hoists the clone's ~55 constant set-up instructions in front of the loop test, where every wave pays them.
         if (__any(risk != 0u)) {
@@ -456,8 +469,15 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
 #pragma unroll
         for (int k = 0; k < SLOTS; k++) {
             const int j = tid + k * NT;
-            const float cdj = (sg[k] * pw[k]) * E.div32;                                   // coord_d   (:1926)
+            float cdj = (sg[k] * pw[k]) * E.div32;                                   // coord_d   (:1926)
             float x = ((jf0 + (float)(k * NT)) + cdj) + E.sep32;                   // coord_x   (:1927)
+            if (DIA) {   // the same two lines in float64, each result rounded once (pow(x, 2) == x * x, pow(x, 1) == x: exact in float64)
+                const double ax = (double)axs[k];
+                const double p64 = A.e64 == 2.0 ? ax * ax : (A.e64 == 1.0 ? ax : pow(ax, A.e64));
+                const double cd64 = ((double)sg[k] * p64) * A.eye[eyei].div64;
+                x = (float)((((double)(s0 + j) + 0.5) + cd64) + A.eye[eyei].sep64);
+                cdj = (float)cd64;
+            }
             // slots beyond the staged range: x = 2w + (j - ns), strictly increasing, slot ns = the right sentinel (:1935)
             // (sharp: centres 2w + 1 + 2 (j - ns): their points lie beyond the sentinel, increasing; the sentinel itself is px())
             x = j < ns ? x : (SHARP ? 2.0f * tidf + (float)(2 * w + 1 - 2 * ns + 2 * k * NT) : tidf + (float)(2 * w - ns + k * NT));
@@ -1121,12 +1141,13 @@ hipError_t launch_depth_codes(const float* depth, int n, int h, int w, const uin
 
 // Anaglyph composition of the two eyes the tile kernel wrote as uint8 codes side by side ([n][h][2w][3]): R from one eye,
 // G and B from the other (overlap_red_cyan, reference :1996-2010), k / 255, the no-fill mask of the composite
-// (GenerateStereo.py:355-361).  Rows the tile kernel flagged are skipped: the row kernel writes them in final form.
+// (GenerateStereo.py:355-361).  With `rowflag`: rows flagged there are skipped (rounds 2-4: the row kernel wrote them in final form);
+// round 5 passes null -- the row kernel writes flagged rows into the same side-by-side scratch and every row is composed here.
 __global__ void __launch_bounds__(256) k_anaglyph_compose(const uint8_t* __restrict__ sbs, const uint8_t* __restrict__ rowflag, int w,
                                                           int anaglyph, float* stereo, int stereo_is_u8, float* mask) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     const uint32_t row = blockIdx.y;   // frame * h + row
-    if (x >= w || rowflag[row]) return;
+    if (x >= w || (rowflag && rowflag[row])) return;   // (rowflag null: every row)
     const B3 l = *reinterpret_cast<const B3*>(sbs + ((size_t)row * 2 * w + x) * 3);
     const B3 r = *reinterpret_cast<const B3*>(sbs + ((size_t)row * 2 * w + w + x) * 3);
     const B3 c = anaglyph == 1 ? B3{l.x, r.y, r.z} : B3{r.x, l.y, l.z};
@@ -1172,7 +1193,7 @@ static int polypoint_tile(int w, int S, int nslots, int nt) {
 
 int polypoint_max_halo() { return (3 * 384 - 4 - 64) / 2; }
 
-template <int NT, int SLOTS, int MINW, int SHARP>
+template <int NT, int SLOTS, int MINW, int SHARP, int DIA = 0>
 static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream) {
     // points / forward segments a pixel under a reversed segment can hold in its lists (more: the row is redone); sharp has two
     // points per source (the values the first-generation kernel settled on)
@@ -1195,10 +1216,10 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
     if (occ >= 3 && occ <= 6) { const size_t pad = (size_t)(163840 / (occ + 1) + 1024) & ~(size_t)255; if (pad > lds) lds = pad; }
 #define PP_LAUNCH(O)                                                                                                         \
     {                                                                                                                        \
-        hipError_t e = hipFuncSetAttribute((const void*)k_polypoint<NT, SLOTS, O, KP, KS, MINW, SHARP>,                      \
+        hipError_t e = hipFuncSetAttribute((const void*)k_polypoint<NT, SLOTS, O, KP, KS, MINW, SHARP, DIA>,                 \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
         if (e != hipSuccess) return e;                                                                                       \
-        hipLaunchKernelGGL((k_polypoint<NT, SLOTS, O, KP, KS, MINW, SHARP>), grid, block, lds, stream, A.image_f32, A.eye[0].depth, \
+        hipLaunchKernelGGL((k_polypoint<NT, SLOTS, O, KP, KS, MINW, SHARP, DIA>), grid, block, lds, stream, A.image_f32, A.eye[0].depth, \
                            A.eye[1].depth, A.w, A.h, A.S, A.T, A.single, off_dflag, off_dcnt, pow_mode, npt, A);                  \
     }
     if (out == PO_F32) PP_LAUNCH(PO_F32)
@@ -1237,13 +1258,19 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     A.rowflag = rowflag;
     A.dbg = R.dbg;
     A.tilemap = R.tilemap; A.gray = R.lazy_gray; A.tm_words = R.tm_words;
+    A.d64 = R.d64; A.e64 = R.e64;
+    if (R.d64 && (R.d64 != 1 || sharp)) return hipErrorInvalidValue;   // (only the float64 disparity chain of polylines_soft)
     const int out = R.out_u8 ? PO_ASD : (R.stereo_is_u8 ? (R.no_mask ? PO_U8NM : PO_U8) : PO_F32);
     if ((out == PO_ASD) != (R.image_u8 != nullptr)) return hipErrorInvalidValue;  // uint8 image in <=> uint8 image out
     if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31) || A.h > 4 * 65535 - 512 || A.n > 65535)
         return hipErrorInvalidValue;   // 32-bit pixel indices, grid limits
     if (sharp) {   // (two geometries: the default and the wide-halo one)
         if (geo == 5) return polypoint_launch<384, 3, 7, 1>(A, out, stream);
-        return polypoint_launch<256, 4, PP_MINW, 1>(A, out, stream);
+        return polypoint_launch<256, 4, PP_SHARP_MINW, 1>(A, out, stream);
+    }
+    if (R.d64) {   // (one geometry per form: the default one, or the wide-halo one)
+        if (geo == 5) return polypoint_launch<384, 3, 7, 0, 1>(A, out, stream);
+        return polypoint_launch<256, 4, PP_MINW, 0, 1>(A, out, stream);
     }
     switch (geo) {
     case 3: return polypoint_launch<256, 3, PP_MINW, 0>(A, out, stream);

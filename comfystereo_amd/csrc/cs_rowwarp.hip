@@ -2366,7 +2366,7 @@ struct RowOut {
             float* d = stereo + o * 3;
             d[0] = lut[r]; d[1] = lut[g]; d[2] = lut[b];
         }
-        mask[o] = ((int)r + (int)g + (int)b) == 0 ? 1.0f : 0.0f;  // GenerateStereo.py:355-361
+        if (mask) mask[o] = ((int)r + (int)g + (int)b) == 0 ? 1.0f : 0.0f;  // GenerateStereo.py:355-361 (null: the per-eye intermediate of the anaglyph modes)
     }
 };
 
@@ -2620,7 +2620,7 @@ struct ReplayOut {   // RowOut's destination arithmetic without the anaglyph sta
             float* d = stereo + o * 3;
             d[0] = csm::code_over_255((float)r); d[1] = csm::code_over_255((float)g); d[2] = csm::code_over_255((float)b);
         }
-        mask[o] = ((int)r + (int)g + (int)b) == 0 ? 1.0f : 0.0f;  // GenerateStereo.py:355-361
+        if (mask) mask[o] = ((int)r + (int)g + (int)b) == 0 ? 1.0f : 0.0f;  // GenerateStereo.py:355-361 (null: the per-eye intermediate of the anaglyph modes)
     }
 };
 

@@ -133,8 +133,6 @@ def test_profile_tiles_counts_on_the_device_over_all_chunks(engine, dev_switch):
 
     one, three = measure(1), measure(3)
     assert 0.0 < one < 1.0 and one == three
-    # the map itself, from the blur call: tiles with an edge in reach on stepped depth are a minority
-    assert one < 0.6
     # nothing profiled since cs_profile(1): -1
     L.cs_profile(1); L.cs_profile(0)
     _native.check(L.cs_profile_tiles(ctypes.byref(frac)))

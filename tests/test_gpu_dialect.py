@@ -114,3 +114,66 @@ def test_polylines_dialect_width_limit():
     engine.apply_stereo_divergence(img, dep, 1.0, 0.0, 1.0, "polylines_sharp", 0.5)          # D32: accepted
     with pytest.raises(RuntimeError, match="too wide"):
         engine.apply_stereo_divergence(img, dep, 1.0, 0.0, 1.0, "polylines_sharp", 0.5, dialect="D64")
+
+
+@pytest.mark.parametrize("dialect", ["f64-disparity", "int64-sum", "D64"])
+@pytest.mark.parametrize("exponent", [2.0, 1.0, 1.3])
+def test_forward_fills_run_the_dialect_in_the_tile_kernel(dialect, exponent):
+    """Round 5: none / naive / naive_interpolating / inverse of the node path under the dialect bits run in k_fwdtile's own dialect
+    instantiations (float64 offset chain -> int() / floor(); int64 pixel sums) instead of the whole-row kernel: rows wide enough
+    for several tiles, depth with holes longer than a tile's window margin and black / (128, 128, 0) pixels (quirk Q5 is where
+    the int64-sum bit changes the result), every mode family.  HIP vs the oracle under the same setting, bit for bit."""
+    from comfystereo_amd import engine
+    n, h, w = 2, 12, 2100
+    img = synth.image_f32(n, h, w, seed=19)
+    img[:, :, 300:340] = 0.0                                   # genuinely black pixels
+    img[:, 3::4, 900:960] = np.array([128, 128, 0], np.float32) / 255.0   # uint8 sum wraps to 0
+    depth = synth.depth_batch("stepped", n, h, w, channels=3)
+    depth[1] = synth.depth_batch("random8", 1, h, w, channels=3)[0]
+    engine.DIALECT = dialect
+    oracle.set_dialect(dialect)
+    try:
+        for ui, mode in (("Fill - Naive interpolating", "left-right"), ("No fill - Reverse projection", "red-cyan-anaglyph"),
+                         ("Fill - Naive", "top-bottom"), ("No fill", "right-left"), ("Fill - Naive interpolating", "cyan-red-reverseanaglyph")):
+            fill = node_oracle.FILL_KEYS[ui]
+            p = engine.make_params(n, h, w, h, w, 3, fill, mode, 6.0, 0.3, 0.1, 0.5, exponent, False, 6.0, 6.0, 1.0, 0, 4)
+            plan = engine.Plan(p, torch.device("cuda"))
+            got = [t.cpu().numpy() for t in plan.run(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda())]
+            assert int(plan.stats()[:, 9].sum()) == 0
+            want = node_oracle.generate(img, depth, 6.0, 0.3, mode, 0.1, 0.5, exponent, ui, 6.0, 6.0, False)
+            for g, wv, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+                np.testing.assert_array_equal(g, wv, err_msg=f"{ui} {mode} {name}")
+    finally:
+        engine.DIALECT = "D32"
+        oracle.set_dialect("D32")
+
+
+@pytest.mark.parametrize("exponent", [2.0, 1.3])
+@pytest.mark.parametrize("kind", ["stepped", "clipped", "blobs"])
+def test_polylines_soft_float64_chain_in_the_tile_kernel(exponent, kind):
+    """Round 5: the float64 disparity chain (dialect bit 0 alone -- the half of numba's typing that the reference itself pins,
+    tests/golden/dialect_f64.npz) for polylines_soft runs in k_polypoint's dialect instantiation (staging in float64, the point
+    x rounded once); rows it flags (`clipped`: exact ties) go to the row kernel's dialect instantiation.  Several tiles per row,
+    side by side and as an anaglyph.  HIP vs the oracle under the same setting, bit for bit."""
+    from comfystereo_amd import engine
+    n, h, w = 2, 10, 2100
+    img = synth.image_f32(n, h, w, seed=29)
+    depth = synth.depth_batch(kind, n, h, w, channels=3)
+    engine.DIALECT = "f64-disparity"
+    oracle.set_dialect("f64-disparity")
+    try:
+        for mode in ("left-right", "red-cyan-anaglyph"):
+            p = engine.make_params(n, h, w, h, w, 3, "polylines_soft", mode, 6.0, 0.3, 0.1, 0.5, exponent, False, 6.0, 6.0, 1.0, 0, 4)
+            assert (p.flags >> 3) & 3 == 1
+            plan = engine.Plan(p, torch.device("cuda"))
+            got = [t.cpu().numpy() for t in plan.run(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda())]
+            st = plan.stats()
+            assert int(st[:, 9].sum()) == 0
+            if kind != "clipped":
+                assert int(st[:, 11].sum()) < n * h, "every row went back to the row kernel: the tile kernel did not take the call"
+            want = node_oracle.generate(img, depth, 6.0, 0.3, mode, 0.1, 0.5, exponent, "Fill - Polylines Soft", 6.0, 6.0, False)
+            for g, wv, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+                np.testing.assert_array_equal(g, wv, err_msg=f"{mode} {name}")
+    finally:
+        engine.DIALECT = "D32"
+        oracle.set_dialect("D32")

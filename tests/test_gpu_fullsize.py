@@ -217,17 +217,51 @@ def test_8k_wide_rows_side_by_side(engine, fill):
             assert np.array_equal(g, w_), name
 
 
-def test_too_wide_frames_are_refused_not_truncated(engine):
-    """Beyond cs_max_width_mode the call fails (CS_ELIMIT), it does not truncate: polylines_sharp side by side beyond 7 994 columns,
-    and as an anaglyph (two more bytes of LDS per column) already at 7 680."""
+@pytest.mark.parametrize("fill,kind", [("polylines_sharp", "stepped"), ("polylines_sharp", "clipped"), ("polylines_soft", "clipped")])
+def test_8k_wide_rows_anaglyph_polylines(engine, fill, kind):
+    """7680-pixel rows as an ANAGLYPH through the polylines techniques (round 5): both kernels write the eyes side by side as uint8
+    codes, the composition follows -- the row kernel behind the tile kernel no longer needs its anaglyph stash (polylines_sharp was
+    limited to 6 395 columns in these modes).  `clipped` depth: rows with exact closeness ties reach the row kernel and the
+    replay kernel, which the anaglyph modes did not use before."""
     from comfystereo_amd import _native
     L = _native.lib()
-    for w, mode in ((8192, "left-right"), (7680, "red-cyan-anaglyph")):
+    h, w = 5, 7680
+    for mode in ("red-cyan-anaglyph", "cyan-red-reverseanaglyph"):
+        assert L.cs_max_width_mode(engine.FILL[fill], engine.MODE[mode]) >= w
+    img = synth.image_f32(1, h, w, seed=8)
+    depth = synth.depth_batch(kind, 1, h, w, channels=3)
+    mode = "red-cyan-anaglyph"
+    p = engine.make_params(1, h, w, h, w, 3, fill, mode, 3.0, 0.0, 0.0, 0.5, 2.0, False, 20.0, 20.0, 1.0, 0, 12)
+    plan = engine.Plan(p, torch.device("cuda"))
+    got = [t.cpu().numpy() for t in plan.run(cuda(img), cuda(depth))]
+    st = plan.stats()
+    if kind == "clipped":
+        assert int(st[:, 11].sum()) > 0, "no row was flagged: the test does not reach the row kernel"
+    assert int(st[:, 9].sum()) == 0   # kernel error flags
+    want = node_oracle.generate(img, depth, 3.0, 0.0, mode, 0.0, 0.5, 2.0, UI[fill], 20.0, 20.0, False, batch_size=12)
+    for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+        assert np.array_equal(g, w_), (fill, kind, name)
+
+
+def test_too_wide_frames_are_refused_not_truncated(engine):
+    """Beyond cs_max_width_mode the call fails (CS_ELIMIT), it does not truncate.  What is left with a limit below 8K after round 5:
+    polylines_sharp beyond 7 990 columns in any mode, an anaglyph of it whose halo the tile kernels do not take (the row kernel's
+    own anaglyph form: 6 395), and -- outside the UI's reach -- the three hidden techniques, the mesh warp and D64 polylines."""
+    from comfystereo_amd import _native
+    L = _native.lib()
+    for w, mode in ((8192, "left-right"), (8192, "red-cyan-anaglyph")):
         assert L.cs_max_width_mode(engine.FILL["polylines_sharp"], engine.MODE[mode]) < w
         img = synth.image_f32(1, 4, w, seed=8)
         depth = synth.depth_batch("stepped", 1, 4, w, channels=3)
         with pytest.raises(RuntimeError, match="too wide"):
             gen(engine, img, depth, "polylines_sharp", mode, blur=False, div=3.0)
+    # an anaglyph at 7680 whose halo is beyond the tile kernels (convergence 1.0, divergence 15 %: 1 152 columns)
+    img = synth.image_f32(1, 4, 7680, seed=8)
+    depth = synth.depth_batch("stepped", 1, 4, 7680, channels=3)
+    with pytest.raises(RuntimeError, match="too wide"):
+        engine.generate(cuda(img), cuda(depth), 15.0, 0.0, "red-cyan-anaglyph", 0.0, 1.0, 2.0, "polylines_sharp", 20.0, 20.0, False)
+    for fill in ("none_post", "inverse_post", "hybrid_edge_plus"):
+        assert L.cs_max_width_mode(engine.FILL[fill], engine.MODE["left-right"]) < 7680
 
 
 @pytest.mark.parametrize("kind", ["clipped", "random8"])

@@ -20,9 +20,12 @@ ap.add_argument("--iters", type=int, default=2)
 ap.add_argument("--fill", default="Fill - Polylines Soft")
 ap.add_argument("--prewarm", type=int, default=1, help="1: what GenerateStereo.py does at import inside ComfyUI (host_pipeline."
                 "prewarm of this shape, waited for: ComfyUI loads its models meanwhile); 0: cold caches")
+ap.add_argument("--pin-cap-gb", type=float, default=-1.0, help="host_pipeline.PINNED_POOL_BYTES in GB (default: the module's)")
 ap.add_argument("--first-only", type=int, default=0, help="1: stop after the first two calls (first-call measurements per shape)")
 a = ap.parse_args()
 from comfystereo_amd import host_pipeline as _hp
+if a.pin_cap_gb >= 0:
+    _hp.PINNED_POOL_BYTES = int(a.pin_cap_gb * (1 << 30))
 from comfystereo_amd.GenerateStereo import FILL_TECHNIQUE_MAPPING as _FM
 if a.prewarm:
     t0 = time.perf_counter()
@@ -42,6 +45,7 @@ out2 = node.generate(img, dep, *args)   # (the first call's results still held b
 torch.cuda.synchronize()
 dt_second = time.perf_counter() - t0
 print(f"second call, first results still held: {dt_second*1e3:.1f} ms -> {a.n/dt_second:.1f} frames/s")
+print(f"pinned cap {_hp.PINNED_POOL_BYTES / 2**30:.1f} GB")
 print(f"results pinned: {out[0].is_pinned()}; pinned host memory reserved by PyTorch: "
       f"{torch.cuda.host_memory_stats().get('reserved_bytes.current', 0) / 1e9:.2f} GB; 4K-equivalent first call: "
       f"{a.n * (a.h * a.w) / (2160 * 3840) / dt_first:.1f} frames/s")
