@@ -363,11 +363,10 @@ static int poly_halo(double div_percent_a, double div_percent_b, double sep_perc
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // techniques with a D64 (numba typing) instantiation: the forward-map family, the z-buffered inverse map and -- through the
 // general row kernel only, the sweep of full D64 as a literal one-lane replay -- the polylines techniques
-static bool dialect_d64_ok(int fill) {
-    return fill == CS_FILL_NONE || fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING || fill == CS_FILL_INVERSE ||
-           fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP || fill == CS_FILL_HYBRID_EDGE;
-}
-static const char* const DIALECT_MSG = "dialect D64 (flags bits 3/4) exists for none / naive / naive_interpolating / inverse / polylines_soft / polylines_sharp / hybrid_edge";
+// (round 5: also the three techniques no UI string reaches -- none_post / inverse_post: their mapping functions are @njit, the
+// float64 offset chain is all numba changes; hybrid_edge_plus = hybrid_edge + polylines_soft, both of which have the dialect)
+static bool dialect_d64_ok(int fill) { return fill >= 0 && fill <= CS_FILL_HYBRID_EDGE_PLUS && fill != CS_FILL_GPU_WARP; }
+static const char* const DIALECT_MSG = "dialect D64 (flags bits 3/4) exists for the CPU techniques, not for gpu_warp (torch arithmetic in both installs)";
 // flags of the rows the tiled polylines path hands to the row kernel + their compacted list (run_rows)
 // flagged-row block: [row flags, one byte per row][count / cursor pairs, 256 B][stretch-replay counters, 256 B][replay retry
 // flags, one byte per row] -- everything one memset clears -- then [row list, 4 B per row]
@@ -547,7 +546,7 @@ static int row_form_max_width(int fill, int anaglyph) {
 }
 // polylines under the float64 disparity chain keep 8 more bytes per column in LDS (cs_rowwarp.hip Poly::xd)
 static bool dialect_width_ok(int fill, int w, int anaglyph, int d64) {
-    if (!(d64 & 1) || (fill != CS_FILL_POLYLINES_SOFT && fill != CS_FILL_POLYLINES_SHARP && fill != CS_FILL_HYBRID_EDGE)) return true;
+    if (!(d64 & 1) || (fill != CS_FILL_POLYLINES_SOFT && fill != CS_FILL_POLYLINES_SHARP && fill != CS_FILL_HYBRID_EDGE && fill != CS_FILL_HYBRID_EDGE_PLUS)) return true;
     return rowwarp_lds_bytes(fill, w, fill == CS_FILL_HYBRID_EDGE ? 0 : anaglyph) + 8 * (size_t)w + 16 <= CS_LDS_BYTES;
 }
 int cs_max_width(int fill) { return max_width_for(fill, 1); }

@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
                 D[x] = (float)x + p;
             }
         }
-        for (int x = tid; x < w + 3 * NR; x += nt) M[x] = -1;   // (M, W0, W1 are contiguous)
+        for (int x = tid; x < w + 3 * NR; x += nt) M[x] = 0;   // (M, W0, W1 are contiguous; 0 = no pair)
         __syncthreads();
         if (GW_DEV_IS(51)) continue;
         // ---- the 8 scatter rounds (:330-391).  In round k the pair (i, i+1) targets column clamp(fs_i + k, 0, w-1),
@@ -310,19 +310,22 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
         // interior column c in round k is the highest i with fs_i == c - k, whatever k: ONE atomic pass builds
         // M[v] = max{i : fs_i == v}; columns 0 and w-1 collect the clamped pairs per round (W0 / W1).  Then one lane per
         // column replays its rounds in order out of registers -- no barrier between rounds.
+        // (round 5) The table holds 2 (i + 1) + connected: the order by pair index is kept, 0 means "no pair" (it reads as an
+        // unconnected pair: no `>= 0` test, no clamp of the index in the column pass), and the connected bit travels with the
+        // index instead of through a flag byte per pair (one LDS read-modify-write here and a read + two tests per round there).
         for (int i = tid; i < w - 1; i += nt) {
             {
                 const float dl = D[i], dr = D[i + 1];
                 const float fs = floorf(fminf(dl, dr));
                 const bool connected = fabsf(po[i + 1] - po[i]) < conn_thr;
-                flags[i] = (uint8_t)((flags[i] & 1u) | (connected ? 2u : 0u));
-                if (fs >= -(float)(NR - 1) && fs <= (float)(w - 2)) atomicMax(&M[(int)fs + NR - 1], i);
+                const int key = 2 * (i + 1) + (connected ? 1 : 0);
+                if (fs >= -(float)(NR - 1) && fs <= (float)(w - 2)) atomicMax(&M[(int)fs + NR - 1], key);
                 if (!(fs > 0.0f) || fs + (float)(NR - 1) >= sxw) {
 #pragma unroll
                     for (int k = 0; k < NR; k++) {
                         const float cfl = fs + (float)k;
-                        if (!(cfl > 0.0f)) atomicMax(&W0[k], i);          // fmaxf(NaN, 0) == 0 as well
-                        else if (cfl >= sxw) atomicMax(&W1[k], i);
+                        if (!(cfl > 0.0f)) atomicMax(&W0[k], key);          // fmaxf(NaN, 0) == 0 as well
+                        else if (cfl >= sxw) atomicMax(&W1[k], key);
                     }
                 }
             }
@@ -332,15 +335,16 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
         // Only rounds 0..3 can pass the z-test: a valid proposal needs connected (|po[i+1] - po[i]| < 1.5, so
         // dr - dl < 2.51) and 0 <= frac < 1, i.e. dl <= fs + k < dr -- with fs >= dl - 1 that leaves k <= 3; a
         // deciding pair that is not valid changes nothing (it writes back what it gathered, quirk Q3).
-        // One proposal: pair i for the column value cfl (== fs_i + k).
-        auto propose = [&](int i, float cfl, float& z, float& src) {
+        // One proposal: table entry `key` (2 (i + 1) + connected; 0: no pair) for the column value cfl (== fs_i + k).
+        auto propose = [&](int key, float cfl, float& z, float& src) {
+            const int i = max((key >> 1) - 1, 0);
             const float dl = D[i], dr = D[i + 1];
             const float sw = dr - dl;
             const float safe = fabsf(sw) < (float)1e-4 ? 1.0f : sw;
             const float num = cfl - dl;
             // (the quotient of operands of opposite sign is negative, and |num| >= 1.001 |safe| rounds to >= 1: such a
             // proposal fails `frac >= 0 && frac < 1` whatever the rounding -- three of four do, no division for them)
-            const bool maybe = (flags[i] & 2u) && cfl >= 0.0f && cfl < (float)w &&
+            const bool maybe = (key & 1) && cfl >= 0.0f && cfl < (float)w &&
                                !((num < 0.0f && safe > 0.0f) || (num > 0.0f && safe < 0.0f) || fabsf(num) >= 1.001f * fabsf(safe));
             if (!maybe) return;
             // (here 1e-4 <= |safe| < 2.51 and |num| < 2.6: inside the division core's range unless num is tiny)
@@ -357,22 +361,22 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
             float z = -1.0f, src = -1.0f;
             if (GEN && x > 0 && x < w - 1) {
                 for (int k = 0; k < RV; k++) {   // (general parameters: the rounds one after the other)
-                    const int i = M[x - k + NR - 1];
-                    if (i >= 0) propose(i, (float)x, z, src);
+                    const int key = M[x - k + NR - 1];
+                    if (key) propose(key, (float)x, z, src);
                 }
             } else if (x > 0 && x < w - 1) {
                 // interior column: the deciding pair of round k has fs == x - k, so its column value is x itself.  The LDS
-                // reads of the four rounds go out together (clamped index, validity applied afterwards): the rounds are
-                // only sequential in the z-test -- the kernel is bound by such dependent chains, not by the instruction count
-                int ii[4];
+                // reads of the four rounds go out together (entry 0 = "no pair" reads pair 0's columns and fails the connected
+                // bit): the rounds are only sequential in the z-test
+                int kk[4];
                 float dlk[4], drk[4];
-                unsigned fgk[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) ii[k] = M[x - k + NR - 1];
+                for (int k = 0; k < 4; k++) kk[k] = M[x - k + NR - 1];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const int j = max(ii[k], 0);
-                    dlk[k] = D[j]; drk[k] = D[j + 1]; fgk[k] = flags[j];
+                    // (byte offset of D[i], i = (key >> 1) - 1: (key >> 1) * 4 - 4; key == 0 reads D[-1] = po[w - 1]: harmless)
+                    const float* dp = D + (kk[k] >> 1);
+                    dlk[k] = dp[-1]; drk[k] = dp[0];
                 }
                 const float cfl = (float)x;
 #pragma unroll
@@ -383,9 +387,9 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
                     // (round 4: ONE test instead of a cascade of five exec-mask branches per round.  The filter only has to be
                     // conservative -- the exact test is `valid` below: a product below zero means operands of opposite sign, a
                     // product that underflows to zero is let through)
-                    const bool maybe = (ii[k] >= 0) & ((fgk[k] & 2u) != 0u) & !(num * safe < 0.0f) & !(fabsf(num) >= 1.001f * fabsf(safe));
+                    const bool maybe = ((kk[k] & 1) != 0) & !(num * safe < 0.0f) & !(fabsf(num) >= 1.001f * fabsf(safe));
                     if (maybe) {
-                        const int i = ii[k];
+                        const int i = (kk[k] >> 1) - 1;
                         const float frac = gw_div(num, safe);
                         const bool valid = frac >= 0.0f && frac < 1.0f;
                         const float iz = ndn[i] * (1.0f - frac) + ndn[i + 1] * frac;
@@ -398,8 +402,11 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
             } else {
                 // the clamped columns: the deciding pair's own fs + k decides whether it is in range at all
                 for (int k = 0; k < RV; k++) {
-                    const int i = x == 0 ? W0[k] : W1[k];
-                    if (i >= 0) propose(i, floorf(fminf(D[i], D[i + 1])) + (float)k, z, src);
+                    const int key = x == 0 ? W0[k] : W1[k];
+                    if (key) {
+                        const int i = (key >> 1) - 1;
+                        propose(key, floorf(fminf(D[i], D[i + 1])) + (float)k, z, src);
+                    }
                 }
             }
             const bool filled = !(src < 0.0f);

@@ -2490,6 +2490,7 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
                 // hybrid_edge into `res`, then the polylines_soft row into `alt`; pixels that stayed black take the latter
                 technique_hybrid_fill(L, A, frame, row, e);
                 size_t ta = lds_tech_bytes(CS_FILL_HYBRID_EDGE, w), tb = lds_tech_bytes(CS_FILL_POLYLINES_SOFT, w);
+                if (DIALECT && (A.d64 & 1)) tb += align16(8 * (size_t)w);   // Poly::xd behind the polylines arrays (launch_rowwarp adds the bytes)
                 uint8_t* alt = (uint8_t*)(L.tech + (ta > tb ? ta : tb));
                 for (int c = tid; c < w; c += nt) {
                     float d = drow[c] * scale;
@@ -2497,7 +2498,7 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
                 }
                 __syncthreads();
                 auto into_alt = [=](int c, uint8_t r, uint8_t g, uint8_t b) { alt[3 * c] = r; alt[3 * c + 1] = g; alt[3 * c + 2] = b; };
-                technique_polylines<0, false>(L, w, E, A.e32, st_rw, into_alt, A.dbg);
+                technique_polylines<0, DIALECT>(L, w, E, A.e32, st_rw, into_alt, A.dbg, nullptr, A.d64, A.e64);
                 __syncthreads();
                 for (int c = tid; c < w; c += nt)
                     if (L.res[3 * c] == 0 && L.res[3 * c + 1] == 0 && L.res[3 * c + 2] == 0) {
@@ -2800,7 +2801,8 @@ hipError_t launch_collect_rows(const uint8_t* flag, int total, uint32_t* count, 
 // host-side launcher (called from cs_abi.hip)
 hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t stream, int max_groups, int lean) {
     size_t lds = lds_common_bytes(fill, A.w, A.anaglyph) + lds_tech_bytes(fill, A.w);
-    if ((A.d64 & 1) && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP)) lds += align16(8 * (size_t)A.w);   // Poly::xd
+    if ((A.d64 & 1) && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP || fill == CS_FILL_HYBRID_EDGE_PLUS))
+        lds += align16(8 * (size_t)A.w);   // Poly::xd
     if (lds + CS_ROW_LDS_STATIC > CS_LDS_BYTES) return hipErrorInvalidValue;
     const long long rows = (long long)A.h * A.n;
     dim3 grid(A.h, A.n), block(threads);
@@ -2845,6 +2847,12 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
         if (e != hipSuccess) return e;
         if (fill == CS_FILL_POLYLINES_SOFT) hipLaunchKernelGGL((k_rowwarp<CS_FILL_POLYLINES_SOFT, true>), grid, block, lds, stream, A);
         else hipLaunchKernelGGL((k_rowwarp<CS_FILL_POLYLINES_SHARP, true>), grid, block, lds, stream, A);
+        return hipGetLastError();
+    }
+    if ((A.d64 & 3) && fill == CS_FILL_HYBRID_EDGE_PLUS) {   // (its polylines half in the dialect instantiation)
+        hipError_t e = hipFuncSetAttribute((const void*)k_rowwarp<CS_FILL_HYBRID_EDGE_PLUS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_rowwarp<CS_FILL_HYBRID_EDGE_PLUS, true>), grid, block, lds, stream, A);
         return hipGetLastError();
     }
     switch (fill) {

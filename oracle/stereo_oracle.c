@@ -561,6 +561,9 @@ EXPORT void oracle_naive_post(const uint8_t *img, const float *nd, int h, int w,
             int col = asc ? n : w - 1 - n;
             float off = disparity_f32(nd[(size_t)row * w + col], e32, div32) + sep32; /* :1679 */
             int col_d = col + (int)off;
+            /* dialect bit 0 (numba: naive_mapping_with_mask is @njit, :1662): the offset chain in float64 like oracle_naive's;
+             * everything after the mapping is plain numpy in both dialects (derived, like every D64 statement) */
+            if (g_dialect & 1) col_d = col + (int)(disparity_f64(nd[(size_t)row * w + col], exponent, div_px) + sep_px);
             if (0 <= col_d && col_d < w) {
                 memcpy(&out[((size_t)row * w + col_d) * 3], &img[((size_t)row * w + col) * 3], 3);
                 filled[(size_t)row * w + col_d] = 1;
@@ -585,6 +588,8 @@ EXPORT void oracle_inverse_post(const uint8_t *img, const float *nd, int h, int 
             float off = disparity_f32(d, e32, div32);
             float dest_x = ((float)(x + 0.5) + off) + sep32;
             long j = (long)floorf(dest_x);
+            /* dialect bit 0 (inverse_mapping_with_mask is @njit, :1688): dest_x in float64 like oracle_inverse's */
+            if (g_dialect & 1) j = (long)floor((((double)x + 0.5) + disparity_f64(d, exponent, div_px)) + sep_px);
             for (int t = 0; t < 2; t++) {
                 long jj = j + t;
                 if (0 <= jj && jj < w && d > zb[jj]) {

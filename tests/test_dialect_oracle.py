@@ -63,6 +63,20 @@ def test_f64_disparity_chain_hybrid_edge(gold):
     assert differs > 0
 
 
+def test_f64_disparity_chain_hidden_techniques(gold):
+    """Round 5: none_post / inverse_post / hybrid_edge_plus (no UI string reaches them) under the float64 chain -- what the
+    reference's own functions return for normalized_depth.astype(float64) (their mapping functions are @njit: this chain is all
+    numba changes for the two `_post` techniques).  Pinned bit for bit."""
+    z, cases = gold
+    differs = 0
+    for c in cases:
+        for fill in ("none_post", "inverse_post", "hybrid_edge_plus"):
+            got = _run(z, c, fill, "f64-disparity")
+            np.testing.assert_array_equal(got, z[f"{c['id']}/{fill}"], err_msg=f"{c['id']}/{fill}")
+            differs += int((got != _run(z, c, fill, "D32")).any(-1).sum())
+    assert differs > 0
+
+
 def test_numba_sweep_typing_is_close_to_the_float32_sweep(gold):
     """Full D64 for polylines (float64 sub-intervals, interpolation and products: derived from numba's typing rules, not
     pinnable here): colours differ from the float64-chain / float32-sweep frames by one code on a minority of the pixels, and

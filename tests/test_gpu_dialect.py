@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "dialect_f64.npz")
 # polylines: through the general row kernel (the tile kernels are dialect D32); the float64 chain is pinned by the fixture, the
 # numba typing of the sweep (full D64) is derived -- checked against the oracle's statement of the same rules
-FILLS = ("none", "naive", "naive_interpolating", "inverse", "polylines_soft", "polylines_sharp", "hybrid_edge")
+FILLS = ("none", "naive", "naive_interpolating", "inverse", "polylines_soft", "polylines_sharp", "hybrid_edge",
+         "none_post", "inverse_post", "hybrid_edge_plus")
 
 
 def _gpu(img, depth, c, fill, dialect):
@@ -48,13 +49,43 @@ def test_d64_matches_the_oracle_and_differs_from_d32_where_it_should():
     assert int((a != b).any(-1).sum()) == c["pixels_differing_from_d32"]
 
 
-def test_other_techniques_refuse_the_dialect():
+@pytest.mark.parametrize("dialect", ["f64-disparity", "int64-sum", "D64"])
+@pytest.mark.parametrize("fill", ["none_post", "inverse_post", "hybrid_edge_plus"])
+def test_hidden_techniques_run_the_dialect(fill, dialect):
+    """Round 5 (was: test_other_techniques_refuse_the_dialect): the three techniques no UI string reaches take the dialect bits too.
+    none_post / inverse_post: their mapping functions are @njit (reference :1662, :1688) -- the float64 offset chain is all numba
+    changes, the np.interp post-fill is plain numpy in both installs; hybrid_edge_plus = hybrid_edge + polylines_soft, both of
+    which have the dialect.  HIP vs the oracle under the same setting (derived typing, like every D64 statement)."""
     from comfystereo_amd import engine
-    img = torch.zeros((1, 16, 32, 3), dtype=torch.uint8, device="cuda")
-    dep = torch.rand((1, 16, 32), device="cuda")
-    for fill in ("hybrid_edge_plus", "none_post", "inverse_post"):
+    rs = np.random.RandomState(41)
+    h, w = 8, 700
+    img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    img[:, 100:130] = 0
+    depth = synth.depth_batch("blobs", 1, h, w, channels=1)[0, ..., 0].astype(np.float32)
+    depth[3] = np.round(depth[3] * 5) / 5
+    depth[5] = rs.randint(0, 256, w).astype(np.float32) / 255.0
+    c = dict(divergence=5.0, separation=0.5, exponent=1.3, convergence=0.5)
+    oracle.set_dialect(dialect)
+    try:
+        want = oracle.apply_stereo_divergence(img, depth, 5.0, 0.5, 1.3, fill, 0.5)
+    finally:
+        oracle.set_dialect("D32")
+    np.testing.assert_array_equal(_gpu(img, depth, c, fill, dialect), want)
+
+
+def test_gpu_warp_has_no_dialect():
+    """What genuinely has no D64: gpu_warp is torch arithmetic in both installs -- the flag is refused, not ignored."""
+    from comfystereo_amd import engine
+    n, h, w = 1, 16, 64
+    img = torch.rand((n, h, w, 3), device="cuda")
+    dep = torch.rand((n, h, w, 3), device="cuda")
+    engine.DIALECT = "D64"
+    try:
+        p = engine.make_params(n, h, w, h, w, 3, "gpu_warp", "left-right", 5.0, 0.0, 0.0, 0.5, 2.0, False, 6.0, 6.0, 1.0, 0, 4)
         with pytest.raises(RuntimeError, match="D64"):
-            engine.apply_stereo_divergence(img, dep, 3.0, 0.0, 1.0, fill, 0.5, dialect="D64")
+            engine.Plan(p, torch.device("cuda")).run(img, dep)
+    finally:
+        engine.DIALECT = "D32"
 
 
 def test_node_path_with_the_dialect_switch():
@@ -77,9 +108,6 @@ def test_node_path_with_the_dialect_switch():
             want = node_oracle.generate(img, depth, 7.0, 0.5, mode, 0.0, 0.5, 1.3, ui, 6.0, 6.0, False)
             for g, wv in zip(got, want):
                 np.testing.assert_array_equal(g, wv)
-        with pytest.raises(RuntimeError, match="D64"):
-            p = engine.make_params(n, h, w, h, w, 3, "hybrid_edge_plus", "left-right", 7.0, 0.5, 0.0, 0.5, 1.3, False, 6.0, 6.0, 1.0, 0, 4)
-            engine.Plan(p, torch.device("cuda")).run(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda())
     finally:
         engine.DIALECT = "D32"
         oracle.set_dialect("D32")

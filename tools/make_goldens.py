@@ -439,6 +439,10 @@ def gen_dialect_f64(sig):
             arrays[f"{cid}/{fill}"] = sig.apply_stereo_divergence_polylines(img, nd64, div_px, sep_px, e, fill)
         # hybrid_edge: dest_x, its distance to the column and the exp argument in float64 (:1636-1644)
         arrays[f"{cid}/hybrid_edge"] = sig.apply_stereo_divergence_hybrid_edge(img, nd64, div_px, sep_px, e)
+        # (round 5) the three techniques no UI string reaches: their mapping functions run the same chain (:1662-1713)
+        arrays[f"{cid}/none_post"] = sig.apply_stereo_divergence_naive_post(img, nd64, div_px, sep_px, e)
+        arrays[f"{cid}/inverse_post"] = sig.apply_stereo_divergence_inverse_post(img, nd64, div_px, sep_px, e)
+        arrays[f"{cid}/hybrid_edge_plus"] = sig.apply_stereo_divergence_hybrid_edge_plus(img, nd64, div_px, sep_px, e)
         # how often the two dialects disagree on this case (reported by the tests)
         d32 = sig.apply_stereo_divergence_naive(img, nd32, div_px, sep_px, e, "none")
         cases.append(dict(id=str(cid), kind=kind, divergence=div, separation=sep, exponent=e, convergence=conv,

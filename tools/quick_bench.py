@@ -31,9 +31,11 @@ ap.add_argument("--kind", default="stepped")
 ap.add_argument("--div", type=float, default=8.0)
 ap.add_argument("--blur", type=int, default=0)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--dialect", default="D32", help="engine.DIALECT: D32 | f64-disparity | int64-sum | D64")
 ap.add_argument("--tie-pool-mb", type=int, default=0, help="extra workspace for the stretch-replay pool (engine.Plan tie_pool_bytes)")
 a = ap.parse_args()
 
+engine.DIALECT = a.dialect
 dev = torch.device("cuda:0")
 img = torch.from_numpy(synth.image_f32(1, a.h, a.w, seed=1)).to(dev).expand(a.n, -1, -1, -1).contiguous()
 depth = torch.from_numpy(synth.depth_batch(a.kind, a.n, a.h, a.w, channels=3)).to(dev)
