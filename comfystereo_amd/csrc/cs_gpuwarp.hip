@@ -163,7 +163,11 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
     int* W1 = W0 + NR;             // [NR] per round: highest pair index clamped to column w-1
     int* winner = (int*)ndn;
     float* sm = po;
-    uint8_t* flags = (uint8_t*)(W1 + NR);   // bit 0: gap in some eye (the mask output); bit 1: pair x is connected (this eye)
+    // (round 5) bit rows, one bit per column: fbits = filled by this eye's column pass (the gap fill finds its left neighbour with
+    // clz on them instead of two DPP prefix-maximum passes over every column), gbits = gap in some eye (the mask output)
+    uint32_t* fbits = (uint32_t*)(W1 + NR);
+    uint32_t* gbits = fbits + ((w + 31) >> 5);
+    uint8_t* flags = (uint8_t*)fbits;
     int* ws = (int*)(flags + align16((size_t)w));
     csm::PowfTables* T = (csm::PowfTables*)(ws + 32);
     if (A.pow_mode == 4) {
@@ -172,7 +176,7 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
     }
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
     const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
-    for (int x = tid; x < w; x += nt) flags[x] = 0;
+    for (int x = tid; x < 2 * ((w + 31) >> 5); x += nt) fbits[x] = 0u;
     __syncthreads();
     // torch.linspace(-1, 1, H)[y] (symmetric two-sided fill, each value one fused multiply-add: bit-equal to CPU torch for
     // every H probed, 48 .. 2160) and its unnormalisation
@@ -220,6 +224,7 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
         float *ndn, *po, *D, *zb, *sm, sxw;
         int *M, *W0, *W1, *winner, *ws;
         uint8_t* flags;
+        uint32_t *fbits, *gbits;
         csm::PowfTables* T;
         auto reread = [&]() {
             int w_eye = w_row, lds0 = 0;   // (an opaque OFFSET: the pointer itself must keep its LDS address space)
@@ -229,6 +234,7 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
             M = (int*)(zb + w); W0 = M + w + NR; W1 = W0 + NR;
             winner = (int*)ndn; sm = po;
             flags = (uint8_t*)(W1 + NR);
+            fbits = (uint32_t*)flags; gbits = fbits + ((w + 31) >> 5);
             ws = (int*)(flags + align16((size_t)w));
             T = (csm::PowfTables*)(ws + 32);
             sxw = (float)(w - 1);
@@ -269,6 +275,10 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
         float* const depth_out = !A.depth_l ? nullptr : (e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + y) * w) * 3;
         for (int xb = tid; xb < w; xb += 4 * nt) {
             float dv[4], dm[4];
+            // (round 5, measured and taken back: the statistics words through readfirstlane, separate loops for the lazy / plain loads
+            // and 32-bit offsets for the depth-map stores removed 46 vector instructions per wave from this pass -- and made the
+            // kernel 3.9 % SLOWER, 5 247 -> 5 452 us per 128 1080p frames, tools/sessions/r05_s6.sh: more scalar registers live
+            // across the eye loop at the 80-SGPR budget)
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int x = min(xb + u * nt, w - 1);
@@ -413,6 +423,13 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
             if (filled) myright = max(myright, x);
             zb[x] = z;
             sm[x] = src;   // (po's storage: the offsets were last read by the pair pass)
+            // the wave's 64 consecutive columns as bits (lanes beyond the row end are inactive: zero bits)
+            const unsigned long long fb = __ballot(filled), gb = __ballot(!filled);
+            if (lane == 0) {
+                const int wi = x >> 5;
+                fbits[wi] = (uint32_t)fb; gbits[wi] |= (uint32_t)gb;
+                if (x + 32 < w) { fbits[wi + 1] = (uint32_t)(fb >> 32); gbits[wi + 1] |= (uint32_t)(gb >> 32); }
+            }
         }
         if (GW_DEV_IS(53)) { __syncthreads(); continue; }
         // gap fill (:393-438): "left nearest" = prefix max of the filled columns, "right nearest" = the row's RIGHTMOST
@@ -423,37 +440,26 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
         __syncthreads();   // (every read of ndn is done: its storage takes the scan)
         int rightmost = -1;
         for (int i = 0; i < (nt >> 6); i++) rightmost = max(rightmost, ws[16 + i]);
-        // "left nearest filled" of the gap pixels = prefix maximum of (filled ? x : -1).  A wave's lanes hold 64 consecutive
-        // columns per pass, so the prefix inside a chunk is a DPP scan (6 steps), the chunks' totals go through the (now idle)
-        // M array and every chunk takes the maximum of the totals before it -- no dependent LDS walk over the gap (round 2-3:
-        // every gap pixel walked left, up to 48 dependent reads, the wave waiting for its longest gap: 21 % of the kernel at
-        // divergence 8 %), and no whole-row scan for wide gaps
-        int* const ctot = M;         // [chunks] last filled column of chunk c, or -1
-        const int wpb = nt >> 6;     // chunks per pass
-        for (int xb = 0, k = 0; xb < w; xb += nt, k++) {   // (workgroup-uniform trip count: the DPP scan needs whole waves)
-            const int x = xb + tid;
-            const bool gap = x < w && sm[x] < 0.0f;
-            const int f = (x < w && !gap) ? x : -1;
-            const int incl = wave_incl_max(f);
-            if (lane == 63) ctot[k * wpb + wave] = incl;
-            if (gap) { flags[x] |= 1u; winner[x] = incl; }   // (completed below by this same thread)
-        }
-        __syncthreads();
-        for (int xb = 0, k = 0; xb < w; xb += nt, k++) {
-            const int c = k * wpb + wave;   // this wave's chunk: the totals of chunks 0 .. c-1 (c <= 121)
-            int t = lane < c ? ctot[lane] : -1;
-            if (c > 64) t = max(t, lane + 64 < c ? ctot[lane + 64] : -1);
-            t = __builtin_amdgcn_readlane(wave_incl_max(t), 63);
-            const int x = xb + tid;
-            if (x < w && sm[x] < 0.0f) winner[x] = max(winner[x], t);   // (-1: no filled column to the left)
-        }
+        // "left nearest filled" of a gap pixel = the highest set bit of `fbits` below it: one or two words and a clz, only for the
+        // gap pixels (rounds 3-4: two DPP prefix-maximum passes over every column of the row, 596 of the kernel's 2 970 vector
+        // instructions per wave, profiles/r05_s5/phases.txt; rounds 2-3: every gap pixel walked left over the source map)
+        auto left_filled = [&](int x) {
+            if (x <= 0) return -1;
+            int wi = (x - 1) >> 5;
+            uint32_t cur = fbits[wi] & (0xffffffffu >> (31 - ((x - 1) & 31)));
+            while (true) {
+                if (cur) return wi * 32 + 31 - __clz((int)cur);
+                if (--wi < 0) return -1;
+                cur = fbits[wi];
+            }
+        };
         if (GW_DEV_IS(54)) { __syncthreads(); continue; }
         // final source position of column x (gap fill :393-438), then the bilinear taps of the grid_sample round trip (:440-448)
         struct Taps { int ix0, ix1; float nw, ne, sw2, se; };
         auto taps_of = [&](int x) {
             float s = sm[x];
             if (s < 0.0f) {
-                int left = winner[x];
+                int left = left_filled(x);
                 int right = rightmost >= x ? rightmost : -1;
                 bool hl = left >= 0, hr = right >= 0;
                 int li = hl ? left : 0, ri = hr ? right : 0;
@@ -522,9 +528,9 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
         __syncthreads();
     }
     if (A.mask_u8)
-        for (int x = tid; x < w; x += nt) A.mask_u8[((size_t)frame * h + y) * w + x] = flags[x] & 1u;
+        for (int x = tid; x < w; x += nt) A.mask_u8[((size_t)frame * h + y) * w + x] = (uint8_t)((gbits[x >> 5] >> (x & 31)) & 1u);
     if (A.mask_f32)
-        for (int x = tid; x < w; x += nt) A.mask_f32[((size_t)frame * h + y) * w + x] = (flags[x] & 1u) ? 1.0f : 0.0f;
+        for (int x = tid; x < w; x += nt) A.mask_f32[((size_t)frame * h + y) * w + x] = ((gbits[x >> 5] >> (x & 31)) & 1u) ? 1.0f : 0.0f;
     if (A.depth_l) {
         // left_depth / 255 if its (sub-batch) max > 1 (:1125-1126), clamp(0,1), 3 channels (GenerateStereo.py:165-168).
         // Eyes that ran the warp wrote theirs in pass 1, where the depth is in registers anyway (and the stores overlap

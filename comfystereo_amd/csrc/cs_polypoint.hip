@@ -759,25 +759,25 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         }
         const float fa = floorf(q1), fb = floorf(q2), f3 = floorf(q3);
         const float ina = fminf(fa - tlo, thi - fa), inb = fminf(fb - tlo, thi - fb);   // > 0: that pixel belongs to this tile
-        const bool A = fminf(fa - q0, ina) > 0.0f;                                      // q1 is the first point of a pixel of the tile
-        const bool B = fminf(fb - q1, inb) > 0.0f;                                      // q2 is
-        const float colf = A ? fa : fb, colp1 = colf + 1.0f;
-        const bool e2 = q2 < colp1, e3 = q3 < colp1;                                     // q2 / q3 inside the pixel (A: q2 may be; B: q2 is)
+        const bool ownA = fminf(fa - q0, ina) > 0.0f;                                      // q1 is the first point of a pixel of the tile
+        const bool ownB = fminf(fb - q1, inb) > 0.0f;                                      // q2 is
+        const float colf = ownA ? fa : fb, colp1 = colf + 1.0f;
+        const bool e2 = q2 < colp1, e3 = q3 < colp1;                                     // q2 / q3 inside the pixel (ownA: q2 may be; ownB: q2 is)
         // piece bounds (from = col or point + eps, to = point - eps or col + 1: float32, col >= 2 checked below)
-        const float to0 = q1 - eps32, sg0 = A ? to0 - colf : 0.0f, c0 = colf + 0.5f * sg0;
-        const float fr1 = A ? q1 + eps32 : colf, to1 = e2 ? q2 - eps32 : colp1, sg1 = to1 - fr1, c1 = fr1 + 0.5f * sg1;
+        const float to0 = q1 - eps32, sg0 = ownA ? to0 - colf : 0.0f, c0 = colf + 0.5f * sg0;
+        const float fr1 = ownA ? q1 + eps32 : colf, to1 = e2 ? q2 - eps32 : colp1, sg1 = to1 - fr1, c1 = fr1 + 0.5f * sg1;
         const float fr2 = q2 + eps32, to2 = e3 ? q3 - eps32 : colp1, sg2r = to2 - fr2, c2 = fr2 + 0.5f * sg2r, sg2 = e2 ? sg2r : 0.0f;
         const float fr3 = q3 + eps32, sg3r = colp1 - fr3, c3 = fr3 + 0.5f * sg3r, sg3 = e3 ? sg3r : 0.0f;
         const float den0 = q1 - q0, den2 = q3 - q2;
         // margins: owner of a pixel with col >= 2; the interpolating segments forward; the point after the pixel's last one
         // beyond the pixel; every present piece of positive length with its centre right of its segment's start
         float g = fmin3(colf - 1.5f, den2, (floorf(q4) - colf) - 0.5f);
-        g = fminf(g, A ? fmin3(den0, sg0, c1 - q1) : 1.0f);
+        g = fminf(g, ownA ? fmin3(den0, sg0, c1 - q1) : 1.0f);
         g = fminf(g, sg1);
         g = fminf(g, e2 ? fminf(sg2r, c2 - q2) : 1.0f);
         g = fminf(g, e3 ? fminf(sg3r, c3 - q3) : 1.0f);
         if (edge_tile) g = fminf(g, fminf((float)j - 0.5f, (float)(ns - 1 - j) - 0.5f));   // sentinel neighbours: other typing
-        const bool own = A || B;
+        const bool own = ownA || ownB;
         const int q = (int)colf - o0;
         bool dirty = false;
         if (fold_tile) dirty = own && (dflag[own ? q : 0] & PP_DIRTY) != 0;
@@ -785,7 +785,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         {
             // (without piece 0 its quotient must still be finite -- the segment (q0 -> q1) may be reversed or empty then, and
             // NaN * 0 would poison the sums: 0 / 1)
-            const float ip0 = div_core(A ? c0 - q0 : 0.0f, A ? den0 : 1.0f), ip2 = div_core(c2 - q2, den2);
+            const float ip0 = div_core(ownA ? c0 - q0 : 0.0f, ownA ? den0 : 1.0f), ip2 = div_core(c2 - q2, den2);
             const float om0 = 1.0f - ip0, om2 = 1.0f - ip2;
             const float mr = ch0(pm.rgb), mg = ch1(pm.rgb), mb = ch2(pm.rgb);
             const float cr = ch0(pc.rgb), cg = ch1(pc.rgb), cb = ch2(pc.rgb);
@@ -801,8 +801,8 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             if (fast) emit_k(q, k0, k1, k2);
         }
         // pixels this source's points are the first of, not done: pass 2 (chain path from that point)
-        if (own && !fast && !dirty && act) list_push(PK_CHAIN, A ? oa : ob, q);
-        if (A && B && act) {   // both points first in their (different) pixels: the second one's takes the chain path
+        if (own && !fast && !dirty && act) list_push(PK_CHAIN, ownA ? oa : ob, q);
+        if (ownA && ownB && act) {   // both points first in their (different) pixels: the second one's takes the chain path
             const int qb = (int)fb - o0;
             if (!(fold_tile && (dflag[qb] & PP_DIRTY))) list_push(PK_CHAIN, ob, qb);
         }
