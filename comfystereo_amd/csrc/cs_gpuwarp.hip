@@ -256,8 +256,14 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
                                 A.image[frame * A.img_sf + y * A.img_sy + x * A.img_sx + c * A.img_sc];
             continue;
         }
+#ifdef GW_P1_RFL
+        const bool div255 = __builtin_amdgcn_readfirstlane((int)st[E.st_div]) != 0;
+        float dmin = csm::ord2f((uint32_t)__builtin_amdgcn_readfirstlane((int)st[E.st_min])),
+              dmax = csm::ord2f((uint32_t)__builtin_amdgcn_readfirstlane((int)st[E.st_max]));
+#else
         const bool div255 = st[E.st_div] != 0;
         float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
+#endif
         if (div255) { dmin = dmin / 255.0f; dmax = dmax / 255.0f; }
         const float range = dmax - dmin;
         const float crange = fmaxf(range, (float)1e-6);
@@ -275,16 +281,28 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
         float* const depth_out = !A.depth_l ? nullptr : (e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + y) * w) * 3;
         for (int xb = tid; xb < w; xb += 4 * nt) {
             float dv[4], dm[4];
-            // (round 5, measured and taken back: the statistics words through readfirstlane, separate loops for the lazy / plain loads
-            // and 32-bit offsets for the depth-map stores removed 46 vector instructions per wave from this pass -- and made the
-            // kernel 3.9 % SLOWER, 5 247 -> 5 452 us per 128 1080p frames, tools/sessions/r05_s6.sh: more scalar registers live
-            // across the eye loop at the 80-SGPR budget)
+            // (round 5, measured one by one, tools/sessions/r05_s7.sh: separate loops for the lazy / plain loads -DGW_P1_SPLIT - 1.4 %,
+            // the statistics words through readfirstlane -DGW_P1_RFL - 1.3 % -- fewer vector instructions, more scalar registers live
+            // across the eye loop at the 80-SGPR budget; both stay off.  32-bit offsets for the depth-map stores: + 0.4 %, on)
+#ifdef GW_P1_SPLIT
+            if (lazy) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) dv[u] = lazy_load2(Z, Zhi, (uint32_t)min(xb + u * nt, w - 1), dm[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    dm[u] = scale;
+                    dv[u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(drow) + 4u * (uint32_t)min(xb + u * nt, w - 1));
+                }
+            }
+#else
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int x = min(xb + u * nt, w - 1);
                 dm[u] = scale;
                 dv[u] = lazy ? lazy_load2(Z, Zhi, (uint32_t)x, dm[u]) : drow[x];
             }
+#endif
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int x = xb + u * nt;
@@ -296,7 +314,8 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
                 }
                 if (depth_out) {   // this eye's depth-map output (see the end of the kernel)
                     const float vo = A.noclamp ? v : fminf(fmaxf(v, 0.0f), 1.0f);
-                    *reinterpret_cast<Px3*>(depth_out + 3 * x) = Px3{vo, vo, vo};
+                    // (scalar base + 32-bit lane offset: + 0.4 % alone, tools/sessions/r05_s7.sh)
+                    *reinterpret_cast<Px3*>(reinterpret_cast<char*>(depth_out) + 12u * (uint32_t)x) = Px3{vo, vo, vo};
                 }
                 const float num = v - dmin;
                 float nrm = gw_div_y(num, crange, yr, crange_ok);

@@ -1431,6 +1431,11 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                 const bool room = at + total16 <= (unsigned long long)X->pool16 && base + (uint32_t)nstr <= X->cap;
                 if (!room)   // replay here; the reserved descriptors (those inside the list) say "skip"
                     for (uint32_t i = base; i < base + (uint32_t)nstr && i < X->cap; i++) X->list[(size_t)i * RP_DESC] = 0xffffffffu;
+                // (give the units back when the POOL was what did not fit -- the counter only grew, so after one row had found
+                // the pool full every later row, however small, took the retry pass as well; a reservation made between this add and
+                // the subtraction sees a counter that is too high: it fails spuriously or leaves a hole, never an overlap)
+                if (!room && at + total16 > (unsigned long long)X->pool16)
+                    atomicAdd(reinterpret_cast<unsigned long long*>(X->ctr + 4), 0ull - (unsigned long long)total16);
                 if (!room) *rp_ok = 0;   // replay here
                 if (!room && dbg == 14 && stats_rw) atomicAdd(&stats_rw[14], 1u);   // (diagnostics: rows that found the pool full)
             }

@@ -6,7 +6,7 @@ set -u
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-B="python3 bench.py $* --no-cpu-baseline"
+B="python3 bench.py $* --no-cpu-baseline --no-other-depths"
 run() { # name, extra rocprof args...
   local name=$1; shift
   rm -rf /tmp/prof_$name
