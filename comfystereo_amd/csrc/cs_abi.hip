@@ -392,8 +392,8 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
     auto polypoint_takes = [&](int hl) {
         return hl <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16) || (variant >= 41 && variant <= 43));
     };
-    // (the tile kernels are dialect D32, plus -- round 5 -- the float64 disparity chain alone for polylines_soft)
-    const bool tile_dialect = A.d64 == 0 || (A.d64 == 1 && fill == CS_FILL_POLYLINES_SOFT && polypoint_takes(halo));
+    // (the tile kernels are dialect D32, plus -- round 5 -- the float64 disparity chain alone: k_polypoint<..., DIA>)
+    const bool tile_dialect = A.d64 == 0 || (A.d64 == 1 && polypoint_takes(halo));
     const bool ana_tiled = poly && tile_dialect && A.anaglyph && ana_sbs && A.image_f32 && !A.out_u8 && halo <= polytile_max_halo() && rowflag &&
                            !dev_switch(CS_DEBUG_NO_TILE);
     const RowArgs Afinal = A;

@@ -146,12 +146,13 @@ enum { PK_CHAIN = 0u, PK_BRIDGE = 1u };
 // 2 ns + 1 = right sentinel.
 // DIA (round 5): the float64 disparity chain of dialect D64 (what an install WITH numba computes for
 // `abs(d) ** e * div + sep` and the point x, rounded ONCE into the float32 point array; pinned by tests/golden/dialect_f64.npz)
-// in the staging phase -- everything after it works on the float32 points as in D32.  polylines_soft only: a sharp point is
-// (float)(x64 -+ 0.45), which one float32 centre per source cannot carry.
+// in the staging phase -- everything after it works on the float32 points as in D32.  polylines_sharp: a point is
+// (float)(x64 -+ 0.45), which one float32 centre per source cannot carry -- the dialect instantiation keeps both points of every
+// source in a second LDS array `xq` (8 more bytes per record: five instead of six workgroups per CU) and reads them from there.
 template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW, int SHARP, int DIA = 0>
 __global__ void __launch_bounds__(NT, MINW)
 k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
-            int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode, int hot_npt,
+            int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode, int hot_npt, int hot_off_xq,
             PolyPointArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -206,10 +207,15 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // point o of the polyline: x, the staged source column its colour comes from, |coord_d| (the slow paths; the fast path
     // reads the records of its three sources directly)
     auto pcol = [&](int o) { return min(max(SHARP ? (o - 1) >> 1 : o - 1, 0), ns - 1); };
+    // (sharp under the dialect: left / right point of record r at xq[2 r], xq[2 r + 1]; `hot_off_xq` = 0 otherwise)
+    const float* const xq = reinterpret_cast<const float*>(smem + hot_off_xq);
+    auto sl = [&](int r, float xc) -> float { return (SHARP && DIA) ? xq[2 * r] : xc - HW; };       // left point of record r (centre xc)
+    auto sr = [&](int r, float xc) -> float { return (SHARP && DIA) ? xq[2 * r + 1] : xc + HW; };   // right point
     auto px = [&](int o) -> float {
         if (!SHARP) return P[o].x;
-        const float xc = P[1 + pcol(o)].x;
-        const float v = ((o - 1) & 1) ? xc + HW : xc - HW;
+        const int rr = 1 + pcol(o);
+        const float xc = P[rr].x;
+        const float v = ((o - 1) & 1) ? sr(rr, xc) : sl(rr, xc);
         return o <= 0 ? (float)(-1.0 * w) : (o >= npts - 1 ? (float)(2.0 * w) : v);
     };
     auto prgb = [&](int o) -> uint32_t { return SHARP ? P[1 + pcol(o)].rgb : P[o].rgb; };
@@ -471,36 +477,48 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             const int j = tid + k * NT;
             float cdj = (sg[k] * pw[k]) * E.div32;                                   // coord_d   (:1926)
             float x = ((jf0 + (float)(k * NT)) + cdj) + E.sep32;                   // coord_x   (:1927)
+            double cx64 = 0.0;
             if (DIA) {   // the same two lines in float64, each result rounded once (pow(x, 2) == x * x, pow(x, 1) == x: exact in float64)
                 const double ax = (double)axs[k];
                 const double p64 = A.e64 == 2.0 ? ax * ax : (A.e64 == 1.0 ? ax : pow(ax, A.e64));
                 const double cd64 = ((double)sg[k] * p64) * A.eye[eyei].div64;
-                x = (float)((((double)(s0 + j) + 0.5) + cd64) + A.eye[eyei].sep64);
+                cx64 = (((double)(s0 + j) + 0.5) + cd64) + A.eye[eyei].sep64;
+                x = (float)cx64;
                 cdj = (float)cd64;
             }
             // slots beyond the staged range: x = 2w + (j - ns), strictly increasing, slot ns = the right sentinel (:1935)
             // (sharp: centres 2w + 1 + 2 (j - ns): their points lie beyond the sentinel, increasing; the sentinel itself is px())
             x = j < ns ? x : (SHARP ? 2.0f * tidf + (float)(2 * w + 1 - 2 * ns + 2 * k * NT) : tidf + (float)(2 * w - ns + k * NT));
+            // the two points of a sharp source: x -+ 0.45 in float32 (:1933-1934); under the dialect (float)(x64 -+ 0.45), kept in xq
+            float xl = x - HW, xr = x + HW;
+            if (SHARP && DIA && j < ns) { xl = (float)(cx64 - 0.45); xr = (float)(cx64 + 0.45); }
             if (SLOTS * NT + 4 == NPT || 1 + j < NPT) {   // (compile-time true for geometries whose every slot is allocated)
                 Pw[k * NT] = PQ{rgbk[k], x};
                 pzw[k * NT] = fabsf(cdj);
+                if (SHARP && DIA) {
+                    float* const xqw = const_cast<float*>(xq) + 2 * (1 + j);
+                    xqw[0] = xl; xqw[1] = xr;
+                }
             }
             // reversed segment (j -> j+1)?  The right neighbour sits in the next lane (lane 63: +inf; the pairs across wave
             // chunks and the left sentinel's pair are checked after the barrier).
             // (sharp: the segment between the sources runs from this source's right point to the next one's left point; the
             // segment inside a source, 0.9 long, is never reversed)
-            const float xfrom = SHARP ? x + HW : x, xn = SHARP ? wave_next(x) - HW : wave_next(x);
+            const float xfrom = SHARP ? xr : x, xn = SHARP ? wave_next(xl) : wave_next(x);
             const unsigned long long mrev = __ballot(!(xfrom < xn));
             if (mrev) mark_reversed(mrev, xfrom, xn);
             // the range of points that can lie in the tile: first j with x >= o0, last j with x < o0 + wt (wave-uniform
             // candidates from ballots; one pair of atomics per wave below)
-            const unsigned long long m1 = __ballot(xfrom >= o0f), m2 = __ballot((SHARP ? x - HW : x) < o1f);
+            const unsigned long long m1 = __ballot(xfrom >= o0f), m2 = __ballot((SHARP ? xl : x) < o1f);
             const int base = k * NT + wave * 64;
             wjlo = min(wjlo, m1 ? base + __ffsll((long long)m1) - 1 : 0x7fffffff);
             wjhi = max(wjhi, m2 ? base + 63 - __clzll((long long)m2) : -1);
         }
         if (lane == 0) { atomicMin(&flags[PF_JLO], wjlo); atomicMax(&flags[PF_JHI], wjhi); }
-        if (tid == 0) P[0] = PQ{rgbk[0], (float)(-1.0 * w)};   // left sentinel (:1921): the first column's colour (frame border only)
+        if (tid == 0) {
+            P[0] = PQ{rgbk[0], (float)(-1.0 * w)};   // left sentinel (:1921): the first column's colour (frame border only)
+            if (SHARP && DIA) { float* const xq0 = const_cast<float*>(xq); xq0[0] = (float)(-1.0 * w); xq0[1] = (float)(-1.0 * w); }
+        }
     }
 #endif
     __syncthreads();  // barrier 1: points staged, in-wave reversed segments marked
@@ -588,7 +606,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
             if (j <= ns - 2) o = 1 + j;   // the pair (j, j + 1) of real points
         } else if (lane == SLOTS && wave == 0 && left_edge) o = 0;
         // (records o and o + 1; sharp: right point of the one, left point of the other -- record 0 holds the sentinel's x itself)
-        const float xa = o >= 0 ? P[o].x + ((SHARP && o > 0) ? HW : 0.0f) : 0.0f, xb = o >= 0 ? P[o + 1].x - (SHARP ? HW : 0.0f) : 1.0f;
+        const float xa = o >= 0 ? ((SHARP && o > 0) ? sr(o, P[o].x) : P[o].x) : 0.0f, xb = o >= 0 ? (SHARP ? sl(o + 1, P[o + 1].x) : P[o + 1].x) : 1.0f;
         const unsigned long long mrev = __ballot(o >= 0 && !(xa < xb));
         if (mrev) mark_reversed(mrev, xa, xb);
         __syncthreads();
@@ -751,8 +769,8 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         // an absent piece gets length 0 (adds +0 exactly).  Same margins as soft: pieces of positive length whose centres lie
         // right of their segment's start (to the left of its end they lie by monotone rounding).
         const int oa = 1 + 2 * j, ob = oa + 1;
-        float q0 = pm.x + HW, q3 = pp.x - HW, q4 = pp.x + HW;
-        const float q1 = pc.x - HW, q2 = pc.x + HW;
+        float q0 = sr(o - 1, pm.x), q3 = sl(o + 1, pp.x), q4 = sr(o + 1, pp.x);
+        const float q1 = sl(o, pc.x), q2 = sr(o, pc.x);
         if (edge_tile) {   // the frame's sentinels instead of the filler records: exact -w / 2w, no point beyond
             if (left_edge && j == 0) q0 = (float)(-1.0 * w);
             if (right_edge && j == ns - 1) { q3 = (float)(2.0 * w); q4 = INFINITY; }
@@ -943,7 +961,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         if (__any(lean)) {
             // (sharp: a bridge is always the segment between two sources -- right point of the one, left point of the other)
             const PQ a = P[lean ? (SHARP ? o >> 1 : o) : 1], b = P[lean ? (SHARP ? (o >> 1) + 1 : o + 1) : 2];
-            const float ax = SHARP ? a.x + HW : a.x, bx = SHARP ? b.x - HW : b.x;
+            const float ax = SHARP ? sr(lean ? (o >> 1) : 1, a.x) : a.x, bx = SHARP ? sl(lean ? (o >> 1) + 1 : 2, b.x) : b.x;
             const float colf = (float)(o0 + q);
             const float center = colf + 0.5f;
             const float ip = div_core(center - ax, bx - ax), om = 1.0f - ip;
@@ -1204,6 +1222,9 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
     // (development: CS_DEBUG_PT_VARIANT 13..16 pads the LDS request so that only 3..6 workgroups fit a CU -- occupancy what-if)
     const int npt = polypoint_npt(NT, SLOTS, A.T, A.S);
     const int off_dflag = 8 * npt + 4 * npt + 4 * (A.T > 128 ? A.T : 128), off_dcnt = off_dflag + ((A.T + 3) & ~3);
+    // sharp under the dialect: both points of every record, behind everything else
+    const int off_xq = (SHARP && DIA) ? (int)((lds + 15) & ~(size_t)15) : 0;
+    if (SHARP && DIA) lds = (size_t)off_xq + 8 * (size_t)npt + 64;
     const int pow_mode = (A.dbg == 17 || !(A.e32 == 2.0f || A.e32 == 1.0f)) ? 0 : (A.e32 == 2.0f ? 2 : 1);
     for (int e = 0; e < 2; e++) {
         const EyeArgs& E = A.eye[e];
@@ -1220,7 +1241,7 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
         if (e != hipSuccess) return e;                                                                                       \
         hipLaunchKernelGGL((k_polypoint<NT, SLOTS, O, KP, KS, MINW, SHARP, DIA>), grid, block, lds, stream, A.image_f32, A.eye[0].depth, \
-                           A.eye[1].depth, A.w, A.h, A.S, A.T, A.single, off_dflag, off_dcnt, pow_mode, npt, A);                  \
+                           A.eye[1].depth, A.w, A.h, A.S, A.T, A.single, off_dflag, off_dcnt, pow_mode, npt, off_xq, A);                  \
     }
     if (out == PO_F32) PP_LAUNCH(PO_F32)
     else if (out == PO_U8) PP_LAUNCH(PO_U8)
@@ -1259,18 +1280,19 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     A.dbg = R.dbg;
     A.tilemap = R.tilemap; A.gray = R.lazy_gray; A.tm_words = R.tm_words;
     A.d64 = R.d64; A.e64 = R.e64;
-    if (R.d64 && (R.d64 != 1 || sharp)) return hipErrorInvalidValue;   // (only the float64 disparity chain of polylines_soft)
+    if (R.d64 && R.d64 != 1) return hipErrorInvalidValue;   // (only the float64 disparity chain: the sweep's typing stays D32)
     const int out = R.out_u8 ? PO_ASD : (R.stereo_is_u8 ? (R.no_mask ? PO_U8NM : PO_U8) : PO_F32);
     if ((out == PO_ASD) != (R.image_u8 != nullptr)) return hipErrorInvalidValue;  // uint8 image in <=> uint8 image out
     if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31) || A.h > 4 * 65535 - 512 || A.n > 65535)
         return hipErrorInvalidValue;   // 32-bit pixel indices, grid limits
+    if (R.d64) {   // the float64 disparity chain (one geometry per form: the default one, or the wide-halo one)
+        if (sharp) return geo == 5 ? polypoint_launch<384, 3, 5, 1, 1>(A, out, stream) : polypoint_launch<256, 4, 5, 1, 1>(A, out, stream);
+        if (geo == 5) return polypoint_launch<384, 3, 7, 0, 1>(A, out, stream);
+        return polypoint_launch<256, 4, PP_MINW, 0, 1>(A, out, stream);
+    }
     if (sharp) {   // (two geometries: the default and the wide-halo one)
         if (geo == 5) return polypoint_launch<384, 3, 7, 1>(A, out, stream);
         return polypoint_launch<256, 4, PP_SHARP_MINW, 1>(A, out, stream);
-    }
-    if (R.d64) {   // (one geometry per form: the default one, or the wide-halo one)
-        if (geo == 5) return polypoint_launch<384, 3, 7, 0, 1>(A, out, stream);
-        return polypoint_launch<256, 4, PP_MINW, 0, 1>(A, out, stream);
     }
     switch (geo) {
     case 3: return polypoint_launch<256, 3, PP_MINW, 0>(A, out, stream);

@@ -125,7 +125,11 @@ __device__ __forceinline__ float disparity(float d, float e32, float div32, cons
 // device library's (<= 1 ulp from libm's; the callers only take int() / floor() of the result plus a pixel coordinate).
 __device__ __forceinline__ double disparity64(float d, double e64, double div64) {
     const double s = d >= 0.0f ? 1.0 : -1.0;
-    return (s * pow((double)fabsf(d), e64)) * div64;
+    // (exponents 2 and 1 exactly, like the tile kernels: the device library's pow(0.25, 2.0) is one ulp short of 0.0625, which
+    // moves int() at offsets that are whole numbers -- found by the dialect fuzz, round 5)
+    const double ax = (double)fabsf(d);
+    const double p = e64 == 2.0 ? ax * ax : (e64 == 1.0 ? ax : pow(ax, e64));
+    return (s * p) * div64;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1665,6 +1669,7 @@ __global__ void __launch_bounds__(1024) k_hybrid_splat(RowArgs A) {
 
 struct Px3f { float x, y, z; };
 struct Px3b { uint8_t x, y, z; };
+__device__ __forceinline__ float ax32_of(float nd) { return fabsf(nd); }
 
 // -DHYB_WTAB (experiment, round 5): the Gaussian weight of a contribution is exp((double)(-(diff * diff) / 2.0f))
 // with diff = dest_x - (float)column, an EXACT float32 difference (reference :1643-1644).  For dest_x >= 512 the float32 dest_x is
@@ -1693,10 +1698,14 @@ __global__ void __launch_bounds__(256) k_hyb_wtab_init() {
 // mask, this eye's depth-map codes -- and the untouched pixels to the gap list of their row, i.e. everything k_hybrid_out4
 // does in a pass of its own (2.1 ms per 16 4K frames at 4 TB/s) happens under the float64 arithmetic of this kernel, which
 // leaves the memory pipes idle.  The 3 + 1 byte splat result is still written: k_hybrid_gaps reads the neighbours from it.
-template <bool FUSED>
+// DIA (round 5): the dialect bits A.d64 at tile speed -- bit 0: dest_x, its distance to the column and the exp argument in float64
+// (8 more bytes of LDS per staged source; pinned by tests/golden/dialect_f64.npz), bit 1: the weight sum adds in float64 (derived)
+template <bool FUSED, bool DIA = false>
 __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, int T, uint32_t* __restrict__ gap_count,
                                                               uint16_t* __restrict__ gap_list) {
     __shared__ unsigned long long etab[256];
+    __shared__ double destx64[DIA ? HYT_NPT : 1];
+    const bool f64chain = DIA && (A.d64 & 1);
     __shared__ uint32_t img[HYT_NPT];          // colour codes r | g << 8 | b << 16 of source s0 + j
     __shared__ float destx[HYT_NPT];
     __shared__ short bin[HYT_NPT];             // bin of source j: j_c - (o0 - 1), -1: cannot touch the tile
@@ -1809,7 +1818,14 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
         else p = 0.0f;
         if (risky) p = csm::powf_exact(ax, A.e32, &c_powf_tables);
         const float off = ((nd >= 0.0f ? 1.0f : -1.0f) * p) * E.div32;
-        const float dx = ((float)x + 0.5f + off) + E.sep32;
+        float dx = ((float)x + 0.5f + off) + E.sep32;
+        if (f64chain) {   // (the float32 array then holds floor(dest_x), clamped: everything below only takes its floor)
+            const double ax = (double)ax32_of(nd), p64 = A.e64 == 2.0 ? ax * ax : (A.e64 == 1.0 ? ax : pow(ax, A.e64));
+            const double dx64 = (((double)x + 0.5) + ((nd >= 0.0f ? 1.0 : -1.0) * p64) * E.div64) + E.sep64;
+            destx64[j] = dx64;
+            const double fd = floor(dx64);
+            dx = fd < (double)(o0 - 4) ? (float)(o0 - 4) : (fd > (double)(o0 + wt + 4) ? (float)(o0 + wt + 4) : (float)fd);
+        }
         destx[j] = dx;
         const float fl = floorf(dx);
         int b_ = -1;
@@ -1889,15 +1905,19 @@ __global__ void __launch_bounds__(HYT_NT) k_hybrid_splat_tile(RowArgs A, int S, 
             const float diff = destx[j] - (float)jcol;
             const float arg = -(diff * diff) / 2.0f;
 #ifdef HYB_WTAB
-            const double wg = wtab ? d_hyb_wtab[(uint32_t)(fabsf(diff) * 16384.0f)] : csm::exp_exact_small((double)arg, etab);
+            double wg = wtab ? d_hyb_wtab[(uint32_t)(fabsf(diff) * 16384.0f)] : csm::exp_exact_small((double)arg, etab);
 #else
-            const double wg = csm::exp_exact_small((double)arg, etab);   // (-8 < arg <= 0: no range test, cs_math.h)
+            double wg = csm::exp_exact_small((double)arg, etab);   // (-8 < arg <= 0: no range test, cs_math.h)
 #endif
+            if (f64chain) {
+                const double d64v = destx64[j] - (double)jcol;
+                wg = csm::exp_exact_small(-(d64v * d64v) / 2.0, etab);
+            }
             const uint32_t c = img[j];
             acc0 = (float)((double)acc0 + (double)(c & 0xffu) * wg);
             acc1 = (float)((double)acc1 + (double)((c >> 8) & 0xffu) * wg);
             acc2 = (float)((double)acc2 + (double)((c >> 16) & 0xffu) * wg);
-            ws = ws + (float)wg;
+            ws = (DIA && (A.d64 & 2)) ? (float)((double)ws + wg) : ws + (float)wg;   // (numba: float32 += float64 adds in float64)
             touched = true;
         };
         // The three bins are adjacent in `sorted`.  Where the polyline runs forward the sources of bin q all precede those of
@@ -2897,7 +2917,8 @@ int hybrid_max_width() {
 // caller decides with it whether the depth blur may leave its edge-free tiles unwritten)
 bool hybrid_fused_ok(int n, int w, int halo, int anaglyph, int single, int d64, int plus) {
     const int tmax = (HYT_NPT - 2 * (halo + 2) - 8) & ~3;
-    return halo >= 0 && tmax >= 128 && !d64 && !dev_switch(CS_DEBUG_NO_TILE) && (size_t)n * 2 <= 65535 && !plus && !anaglyph && single < 0 &&
+    (void)d64;   // (round 5: the tile kernel has a dialect instantiation)
+    return halo >= 0 && tmax >= 128 && !dev_switch(CS_DEBUG_NO_TILE) && (size_t)n * 2 <= 65535 && !plus && !anaglyph && single < 0 &&
            w <= 65535 && !dev_switch(CS_DEBUG_HYBRID_UNFUSED);
 }
 int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int plus, int halo) {
@@ -2912,7 +2933,7 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int pl
     if (e != hipSuccess) return CS_EHIP;
     // the tile form of the splat for the node path (float32 image) when a tile fits next to its halo
     const int tmax = (HYT_NPT - 2 * (halo + 2) - 8) & ~3;
-    if (halo >= 0 && A.image_f32 && tmax >= 128 && !A.d64 && !dev_switch(CS_DEBUG_NO_TILE) && (size_t)A.n * A.neyes <= 65535) {   // (tile form: dialect D32)
+    if (halo >= 0 && A.image_f32 && tmax >= 128 && !dev_switch(CS_DEBUG_NO_TILE) && (size_t)A.n * A.neyes <= 65535) {
         const int tiles = (A.w + tmax - 1) / tmax;
         const int T = ((A.w + tiles - 1) / tiles + 3) & ~3;
         // two-eye layouts: the splat writes the node outputs itself, only the gap pixels are left (CS_DEBUG_HYBRID_UNFUSED: the
@@ -2929,11 +2950,13 @@ int launch_hybrid(const RowArgs& A0, void* workspace, hipStream_t stream, int pl
 #ifdef HYB_WTAB
             hipLaunchKernelGGL(k_hyb_wtab_init, dim3(128), dim3(256), 0, stream);   // (experiment: every call; a product would do it once)
 #endif
-            hipLaunchKernelGGL(k_hybrid_splat_tile<true>, grid, dim3(HYT_NT), 0, stream, A, halo, T, cnt, lst);
+            if (A.d64) hipLaunchKernelGGL((k_hybrid_splat_tile<true, true>), grid, dim3(HYT_NT), 0, stream, A, halo, T, cnt, lst);
+            else hipLaunchKernelGGL(k_hybrid_splat_tile<true>, grid, dim3(HYT_NT), 0, stream, A, halo, T, cnt, lst);
             hipLaunchKernelGGL(k_hybrid_gaps<true>, dim3(A.h, A.neyes, A.n), dim3(64), 0, stream, A, (const uint32_t*)cnt, (const uint16_t*)lst);
             return hipGetLastError() == hipSuccess ? CS_OK : CS_EHIP;
         }
-        hipLaunchKernelGGL(k_hybrid_splat_tile<false>, grid, dim3(HYT_NT), 0, stream, A, halo, T, (uint32_t*)nullptr, (uint16_t*)nullptr);
+        if (A.d64) hipLaunchKernelGGL((k_hybrid_splat_tile<false, true>), grid, dim3(HYT_NT), 0, stream, A, halo, T, (uint32_t*)nullptr, (uint16_t*)nullptr);
+        else hipLaunchKernelGGL(k_hybrid_splat_tile<false>, grid, dim3(HYT_NT), 0, stream, A, halo, T, (uint32_t*)nullptr, (uint16_t*)nullptr);
     } else
         hipLaunchKernelGGL(k_hybrid_splat, dim3(A.h, A.n, A.neyes), dim3(threads), lds, stream, A);
     if (plus) e = launch_rowwarp(CS_FILL_HYBRID_EDGE_PLUS, A, threads, stream);

@@ -147,8 +147,8 @@ def test_polylines_dialect_width_limit():
 @pytest.mark.parametrize("dialect", ["f64-disparity", "int64-sum", "D64"])
 @pytest.mark.parametrize("exponent", [2.0, 1.0, 1.3])
 def test_forward_fills_run_the_dialect_in_the_tile_kernel(dialect, exponent):
-    """Round 5: none / naive / naive_interpolating / inverse of the node path under the dialect bits run in k_fwdtile's own dialect
-    instantiations (float64 offset chain -> int() / floor(); int64 pixel sums) instead of the whole-row kernel: rows wide enough
+    """Round 5: none / naive / naive_interpolating / inverse / hybrid_edge of the node path under the dialect bits run in the tile
+    kernels' own dialect instantiations (float64 offset chain -> int() / floor(); int64 pixel sums) instead of the whole-row kernel: rows wide enough
     for several tiles, depth with holes longer than a tile's window margin and black / (128, 128, 0) pixels (quirk Q5 is where
     the int64-sum bit changes the result), every mode family.  HIP vs the oracle under the same setting, bit for bit."""
     from comfystereo_amd import engine
@@ -162,7 +162,10 @@ def test_forward_fills_run_the_dialect_in_the_tile_kernel(dialect, exponent):
     oracle.set_dialect(dialect)
     try:
         for ui, mode in (("Fill - Naive interpolating", "left-right"), ("No fill - Reverse projection", "red-cyan-anaglyph"),
-                         ("Fill - Naive", "top-bottom"), ("No fill", "right-left"), ("Fill - Naive interpolating", "cyan-red-reverseanaglyph")):
+                         ("Fill - Naive", "top-bottom"), ("No fill", "right-left"), ("Fill - Naive interpolating", "cyan-red-reverseanaglyph"),
+                         ("Imperfect fill - Hybrid Edge", "left-right"), ("Imperfect fill - Hybrid Edge", "bottom-top")):
+            # (hybrid_edge: k_hybrid_splat_tile's dialect instantiation -- dest_x, its distance to the column and the exp argument in
+            # float64, the weight sum adds in float64 under the second bit)
             fill = node_oracle.FILL_KEYS[ui]
             p = engine.make_params(n, h, w, h, w, 3, fill, mode, 6.0, 0.3, 0.1, 0.5, exponent, False, 6.0, 6.0, 1.0, 0, 4)
             plan = engine.Plan(p, torch.device("cuda"))
@@ -178,11 +181,13 @@ def test_forward_fills_run_the_dialect_in_the_tile_kernel(dialect, exponent):
 
 @pytest.mark.parametrize("exponent", [2.0, 1.3])
 @pytest.mark.parametrize("kind", ["stepped", "clipped", "blobs"])
-def test_polylines_soft_float64_chain_in_the_tile_kernel(exponent, kind):
+@pytest.mark.parametrize("fill", ["polylines_soft", "polylines_sharp"])
+def test_polylines_float64_chain_in_the_tile_kernel(fill, exponent, kind):
     """Round 5: the float64 disparity chain (dialect bit 0 alone -- the half of numba's typing that the reference itself pins,
-    tests/golden/dialect_f64.npz) for polylines_soft runs in k_polypoint's dialect instantiation (staging in float64, the point
-    x rounded once); rows it flags (`clipped`: exact ties) go to the row kernel's dialect instantiation.  Several tiles per row,
-    side by side and as an anaglyph.  HIP vs the oracle under the same setting, bit for bit."""
+    tests/golden/dialect_f64.npz) for the polylines techniques runs in k_polypoint's dialect instantiations (staging in float64, the
+    point x rounded once; sharp: both points (float)(x64 -+ 0.45) of every source in a second LDS array); rows it flags (`clipped`:
+    exact ties) go to the row kernel's dialect instantiation.  Several tiles per row, side by side and as an anaglyph.  HIP vs the
+    oracle under the same setting, bit for bit."""
     from comfystereo_amd import engine
     n, h, w = 2, 10, 2100
     img = synth.image_f32(n, h, w, seed=29)
@@ -191,7 +196,7 @@ def test_polylines_soft_float64_chain_in_the_tile_kernel(exponent, kind):
     oracle.set_dialect("f64-disparity")
     try:
         for mode in ("left-right", "red-cyan-anaglyph"):
-            p = engine.make_params(n, h, w, h, w, 3, "polylines_soft", mode, 6.0, 0.3, 0.1, 0.5, exponent, False, 6.0, 6.0, 1.0, 0, 4)
+            p = engine.make_params(n, h, w, h, w, 3, fill, mode, 6.0, 0.3, 0.1, 0.5, exponent, False, 6.0, 6.0, 1.0, 0, 4)
             assert (p.flags >> 3) & 3 == 1
             plan = engine.Plan(p, torch.device("cuda"))
             got = [t.cpu().numpy() for t in plan.run(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda())]
@@ -199,9 +204,37 @@ def test_polylines_soft_float64_chain_in_the_tile_kernel(exponent, kind):
             assert int(st[:, 9].sum()) == 0
             if kind != "clipped":
                 assert int(st[:, 11].sum()) < n * h, "every row went back to the row kernel: the tile kernel did not take the call"
-            want = node_oracle.generate(img, depth, 6.0, 0.3, mode, 0.1, 0.5, exponent, "Fill - Polylines Soft", 6.0, 6.0, False)
+            ui = "Fill - Polylines Soft" if fill == "polylines_soft" else "Fill - Polylines Sharp"
+            want = node_oracle.generate(img, depth, 6.0, 0.3, mode, 0.1, 0.5, exponent, ui, 6.0, 6.0, False)
             for g, wv, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
-                np.testing.assert_array_equal(g, wv, err_msg=f"{mode} {name}")
+                np.testing.assert_array_equal(g, wv, err_msg=f"{fill} {mode} {name}")
     finally:
         engine.DIALECT = "D32"
         oracle.set_dialect("D32")
+
+
+@pytest.mark.parametrize("exponent", [2.0, 1.0])
+def test_exact_powers_under_the_float64_chain(dev_switch, exponent):
+    """`abs(d) ** e` for e = 2 and e = 1 is exact in float64, and offsets that are whole numbers sit on int()'s boundary: depth
+    levels that normalise to -0.25 / 0.25 / 0.75 and a divergence_px one ulp off a whole number (-14 % of 1 600 columns =
+    -224.00000000000003) put the float64 offset a hair on the other side of the integer the float32 chain (and a pow() that is one ulp
+    short: the device library's pow(0.25, 2.0)) lands on.  The dialect fuzz found the row kernels one pixel off on such a row
+    (round 5); every technique, tile kernels and row kernels alike, against the oracle."""
+    h, w = 3, 1600
+    rs = np.random.RandomState(77)
+    img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    depth = rs.choice(np.array([0.0, 120.0, 240.0], np.float32), size=(h, w // 8)).repeat(8, axis=1)
+    depth[:, :8] = 0.0; depth[:, -8:] = 240.0
+    c = dict(divergence=-14.0 if exponent == 2.0 else -7.0, separation=-1.0 if exponent == 2.0 else -2.0, exponent=exponent, convergence=0.25)
+    for dialect in ("f64-disparity", "D64"):
+        oracle.set_dialect(dialect)
+        try:
+            want = {f: oracle.apply_stereo_divergence(img, depth, c["divergence"], c["separation"], exponent, f, c["convergence"]) for f in FILLS}
+        finally:
+            oracle.set_dialect("D32")
+        d32 = oracle.apply_stereo_divergence(img, depth, c["divergence"], c["separation"], exponent, "none", c["convergence"])
+        assert (want["none"] != d32).any(), "the case does not separate the dialects"
+        for no_tile in (0, 1):
+            dev_switch("no_tile", no_tile)
+            for f in FILLS:
+                np.testing.assert_array_equal(_gpu(img, depth, c, f, dialect), want[f], err_msg=f"{dialect} {f} no_tile={no_tile}")

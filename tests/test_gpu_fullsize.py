@@ -148,6 +148,55 @@ def test_naive_interpolating_hole_lengths_around_the_walk_limit(engine, hole):
         assert np.array_equal(got, want), (hole, sign, int((got != want).sum()))
 
 
+@pytest.mark.parametrize("hole", [12, 40, 63, 64, 65, 90, 128, 200])
+def test_naive_interpolating_tile_kernel_retrigger_chains(engine, hole):
+    """The NODE path of naive_interpolating (k_fwdtile, round 5: flags as bit rows, quirk intervals replayed by a whole wave): holes
+    shorter than / equal to / longer than a wave and longer than the tile's window margin (those rows go back to the row kernel),
+    starting at tile boundaries on some rows, an image in which 30 % of the pixels sum to 0 mod 256 -- so that most intervals
+    re-trigger, several times in a row -- and genuinely black FILLED pixels inside the intervals (a ramp written over them becomes a
+    right border of the next trigger).  Both eyes (opposite sweep directions), every output, against the oracle."""
+    h, w = 10, 2100
+    rng = np.random.default_rng(1000 + hole)
+    img8 = rng.integers(0, 256, (1, h, w, 3), dtype=np.uint8)
+    img8[rng.random((1, h, w)) < 0.3] = [128, 128, 0]
+    img8[rng.random((1, h, w)) < 0.1] = [255, 1, 0]
+    img8[rng.random((1, h, w)) < 0.1] = 0
+    img = img8.astype(np.float32) / np.float32(255.0)
+    depth = np.zeros((1, h, w, 3), np.float32)
+    for r in range(h):                      # a step per row, at a different column: some land on tile boundaries (w / 4, w / 3 ...)
+        c = [w // 2, w // 4, w // 3, 640, 641, 1279, 1280, 700, 1400, 1050][r]
+        depth[0, r, c:] = 1.0
+        if r % 3 == 0:
+            depth[0, r, c + 300: c + 500] = 0.0   # and back: holes of the other eye
+    div = hole * 100.0 / w                  # exponent 1, convergence 0: the far side moves by `hole` columns
+    got = engine.generate(cuda(img), cuda(depth), div, 0.0, "left-right", 0.0, 0.0, 1.0, "naive_interpolating", 20.0, 20.0, False)
+    want = node_oracle.generate(img, depth, div, 0.0, "left-right", 0.0, 0.0, 1.0, "Fill - Naive interpolating", 20.0, 20.0, False)
+    for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+        g = g.cpu().numpy()
+        assert np.array_equal(g, w_), (hole, name, int((g != w_).sum()))
+
+
+@pytest.mark.parametrize("div", [2.0, 9.0, 15.0])
+def test_gpu_warp_wide_gaps_and_empty_rows(engine, div):
+    """k_gpuwarp's gap fill on bit rows (round 5): gaps wider than one and than two 32-bit words, gaps that start at column 0 (no
+    filled column to the left), rows whose every pair is disconnected (nothing filled at all), next to ordinary rows.  Mask exact,
+    colours within the forward-warp tolerances, against the oracle."""
+    h, w = 12, 1500
+    img = synth.image_f32(1, h, w, seed=77)
+    depth = np.zeros((1, h, w, 3), np.float32)
+    depth[0, :, w // 2:] = 1.0
+    depth[0, 1] = np.tile(np.array([0.0, 1.0], np.float32), w // 2)[:, None]   # every pair disconnected
+    depth[0, 2, :40] = 1.0
+    depth[0, 3, 100:700] = np.linspace(0.0, 1.0, 600, dtype=np.float32)[:, None]
+    depth[0, 4:, :] = synth.depth_batch("stepped", 1, h - 4, w, channels=3)[0]
+    got = engine.generate(cuda(img), cuda(depth), div, 0.0, "left-right", 0.0, 0.5, 1.0, "gpu_warp", 20.0, 20.0, False)
+    want = node_oracle.generate(img, depth, div, 0.0, "left-right", 0.0, 0.5, 1.0, "GPU Warp (Fast)", 20.0, 20.0, False)
+    got = [g.cpu().numpy() for g in got]
+    assert np.array_equal(got[3], want[3])
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    assert np.abs(got[0] - want[0]).max() <= 1e-4
+
+
 def test_digests_at_baseline_sizes_on_the_gpu():
     """cfg 1 (512 x 512 naive_interpolating), cfg 2 (1080p polylines_soft), cfg 3 at a quarter (1080p hybrid_edge), depth blur
     on: the HIP path against SHA-256 digests of the reference's own outputs (tests/golden/digests.json)."""
