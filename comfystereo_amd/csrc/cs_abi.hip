@@ -70,7 +70,12 @@ __global__ void __launch_bounds__(256) k_gray(const float* __restrict__ depth, f
             g.y = (0.2989f * a.w + 0.5870f * b.x) + 0.1140f * b.y;
             g.z = (0.2989f * b.z + 0.5870f * b.w) + 0.1140f * cc.x;
             g.w = (0.2989f * cc.y + 0.5870f * cc.z) + 0.1140f * cc.w;
+#ifdef GRAY_NT_STORE   // (experiment, round 5: like k_gray_edges)
+            typedef float gr_v4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(gr_v4{g.x, g.y, g.z, g.w}, reinterpret_cast<gr_v4*>(d4 + q));
+#else
             d4[q] = g;
+#endif
             mn = fminf(fminf(mn, g.x), fminf(g.y, fminf(g.z, g.w)));
             mx = fmaxf(fmaxf(mx, g.x), fmaxf(g.y, fmaxf(g.z, g.w)));
         }

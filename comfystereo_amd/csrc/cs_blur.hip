@@ -115,6 +115,13 @@ __global__ void __launch_bounds__(1024) k_blur_weights(BlurArgs A) {
 // rows y0-v .. y0+TR-1+v and the depth columns x0-pad .. x0+TW-1+(bs-1-pad) of the tile are staged in
 // LDS once (zero outside the frame == the reference's zero padding; fmaf(k, 0, acc) == acc exactly),
 // so every weight is fetched from HBM/L2 (TR+2v)/TR times instead of 2v+1 times.
+// (-DCS_DEV builds: cs_debug_set(CS_DEBUG_DBG, 21 .. 24) cuts k_blur_fused's tile function short after a phase; a release build
+// has no such tests -- four loop-invariant conditions are eight scalar registers in a kernel that spills them)
+#ifdef CS_DEV
+#define BLUR_DEV_IS(n) (A.dbg == (n))
+#else
+#define BLUR_DEV_IS(n) false
+#endif
 #define BLUR_TW 64
 #define BLUR_TR 32
 __global__ void __launch_bounds__(256) k_blur_apply(BlurArgs A) {
@@ -376,7 +383,14 @@ __global__ void __launch_bounds__(64) k_gray_edges(const float* __restrict__ rgb
         const bool rowok = yy >= 0 && yy < h;
         const float* r = src + ((size_t)(rowok ? yy : 0) * w) * 3;
         const float4* q = reinterpret_cast<const float4*>(r + (size_t)(incol ? x : 0) * 3);
+#ifdef GE_NT_LOAD   // (experiment, round 5: the RGB depth is read exactly once -- nontemporal loads)
+        typedef float ge_v4 __attribute__((ext_vector_type(4)));
+        const ge_v4* qv = reinterpret_cast<const ge_v4*>(q);
+        const ge_v4 va = __builtin_nontemporal_load(qv), vb = __builtin_nontemporal_load(qv + 1), vc = __builtin_nontemporal_load(qv + 2);
+        const float4 ta = make_float4(va.x, va.y, va.z, va.w), tb = make_float4(vb.x, vb.y, vb.z, vb.w), tc = make_float4(vc.x, vc.y, vc.z, vc.w);
+#else
         const float4 ta = q[0], tb = q[1], tc = q[2];
+#endif
         const bool ok = rowok && incol;
         a = make_float4(ok ? ta.x : 0.f, ok ? ta.y : 0.f, ok ? ta.z : 0.f, ok ? ta.w : 0.f);
         b = make_float4(ok ? tb.x : 0.f, ok ? tb.y : 0.f, ok ? tb.z : 0.f, ok ? tb.w : 0.f);
@@ -423,7 +437,12 @@ __global__ void __launch_bounds__(64) k_gray_edges(const float* __restrict__ rgb
             const int y = y0 + j;
             if (y < h && incol) {
                 const float4 q = G[1 + j].v;
+#ifndef GE_PLAIN_STORE   // (round 5: the gray map is not read back by this kernel -- nontemporal stores, -5 % on the kernel)
+                typedef float ge_v4s __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(ge_v4s{q.x, q.y, q.z, q.w}, reinterpret_cast<ge_v4s*>(dst + (size_t)y * w + x));
+#else
                 *reinterpret_cast<float4*>(dst + (size_t)y * w + x) = q;
+#endif
                 mn = fminf(fminf(mn, fminf(q.x, q.y)), fminf(q.z, q.w));
                 mx = fmaxf(fmaxf(mx, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
             }
@@ -642,7 +661,57 @@ __global__ void __launch_bounds__(256) k_blur_classify(BlurArgs A, const unsigne
     const bool second = A.mask_plane && A.stats && A.stats[frame * ST_WORDS + ST_SCALE255];
     const float bscale = second ? 255.0f : 1.0f;   // (two planes: the summaries are unscaled)
     mask_l += second ? A.mask_plane : 0; mask_r += second ? A.mask_plane : 0;
-    if (live && !edge) {
+    // (round 5) first the block summaries within reach, all of them, with nothing between the loads that depends on a loaded value
+    // (twelve 16-byte loads in flight per lane): four tiles in five have no edge bit in any of them and are done.  The exact test on
+    // the bit rows below, with its early exits, used to run for every tile -- up to 33 dependent round trips per lane.
+    bool cand = live && !edge;
+    float pmn = INFINITY, pmx = -INFINITY;
+    unsigned long long cmask = 0ull;   // candidate blocks: bit 3 (b - b0) + k <-> block row b, word wa0 + k has edge bits
+    const bool compact = (xz >> 6) - (xa >> 6) <= 2 && yz / BLUR_ER4 - ya / BLUR_ER4 < 21;
+    if (cand && compact) {
+        const int b0 = ya / BLUR_ER4, b1 = yz / BLUR_ER4, wa0 = xa >> 6, wz0 = xz >> 6;
+        for (int bb = b0; bb <= b1; bb += 4) {
+            float4 sm[4][3];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) sm[i][k] = fb[(size_t)min(bb + i, b1) * MW + min(wa0 + k, wz0)];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    if (bb + i <= b1 && wa0 + k <= wz0 && (second ? sm[i][k].w : sm[i][k].z) != 0.0f) cmask |= 1ull << (3 * (bb + i - b0) + k);
+            // (the tile's own blocks are among them: its extremes for the edge-free case, below)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    if (wa0 + k == tx && bb + i >= y0 / BLUR_ER4 && bb + i <= min(y0 + BLUR_TR - 1, h - 1) / BLUR_ER4) {
+                        pmn = fminf(pmn, sm[i][k].x * bscale); pmx = fmaxf(pmx, sm[i][k].y * bscale);
+                    }
+        }
+        // the exact test on the bit rows of the candidate blocks, one block per round trip (its rows' words of both eyes are loaded
+        // together; the first version walked them one dependent load at a time, and the slowest lane sets the kernel's time)
+        while (cmask && !edge) {
+            const int bit = __ffsll((long long)cmask) - 1;
+            cmask &= cmask - 1ull;
+            const int b = b0 + bit / 3, wi = wa0 + bit % 3;
+            const int lo = max(xa, wi * 64) - wi * 64, hi = min(xz, wi * 64 + 63) - wi * 64;
+            const unsigned long long colmask = (~0ull >> (63 - hi)) & (~0ull << lo);
+            unsigned long long acc = 0ull;
+#pragma unroll
+            for (int j = 0; j < BLUR_ER4; j++) {
+                const int y = b * BLUR_ER4 + j;
+                const bool in = y >= ya && y <= yz;
+                const size_t ro = ((size_t)frame * h + (in ? y : ya)) * MW + wi;
+                const unsigned long long bits = mask_l[ro] | mask_r[ro];
+                acc |= in ? bits : 0ull;
+            }
+            if (acc & colmask) edge = true;
+        }
+        cand = false;
+    }
+    if (cand) {   // (mask radii beyond 64 columns / more than 80 rows of vertical reach: the plain walk)
         for (int b = ya / BLUR_ER4; b <= yz / BLUR_ER4 && !edge; b++)
             for (int wi = xa >> 6; wi <= (xz >> 6) && !edge; wi++) {
                 const float4 sm = fb[(size_t)b * MW + wi];
@@ -656,9 +725,20 @@ __global__ void __launch_bounds__(256) k_blur_classify(BlurArgs A, const unsigne
             }
     }
     float mn = INFINITY, mx = -INFINITY;
+    // (round 5) one atomicAdd per WAVE on the list counter: 56 000 tiles of the metric workload queueing on one address were most of
+    // this kernel's 0.12 ms
+    const unsigned long long em = __ballot(live && edge);
+    uint32_t slot = 0;
+    if (em) {
+        const int leader = __ffsll((long long)em) - 1, lane = threadIdx.x & 63;
+        if (lane == leader) slot = atomicAdd(work_count, (uint32_t)__popcll(em));
+        slot = __shfl(slot, leader) + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+    }
     if (live && edge) {
-        worklist[atomicAdd(work_count, 1u)] = ((uint32_t)frame << 20) | ((uint32_t)ty << 10) | (uint32_t)tx;
+        worklist[slot] = ((uint32_t)frame << 20) | ((uint32_t)ty << 10) | (uint32_t)tx;
         atomicOr(&tilemap[((size_t)frame * gy + ty) * tm_words + (tx >> 5)], 1u << (tx & 31));
+    } else if (live && compact) {
+        mn = pmn; mx = pmx;
     } else if (live) {
         for (int b = y0 / BLUR_ER4; b <= min(y0 + BLUR_TR - 1, h - 1) / BLUR_ER4; b++) {
             const float4 q = fb[(size_t)b * MW + tx];
@@ -677,15 +757,34 @@ __global__ void __launch_bounds__(256) k_blur_classify(BlurArgs A, const unsigne
 // `tstat` (worklist form): the tile's output extremes {min L, max L, min R, max R} per wave, 4 x float4 per worklist entry --
 // k_blur_tile_stats folds them into the frame statistics afterwards (two workgroup reductions with four barriers and the
 // atomic pre-checks per tile were 10 % of this kernel)
+// workgroup barrier that only waits for the wave's LDS traffic: __syncthreads() also drains the vector-memory counter, which would
+// stall on the NEXT tile's loads that k_blur_fused<FAST> keeps in flight across its phases
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// one tile's global inputs in registers (FAST): the depth tile as four 16-byte loads per lane, one bit-row window item per lane
+struct BlurPre { float4 t4[4]; unsigned long long llo, lhi, rlo, rhi; };   // (raw: frame-border selects, the x255 scale and the window shifts happen when they are stored to LDS)
+
+// FAST (round 5): the instantiation for the usual case -- worklist form, w % 4 == 0 with a 16-byte aligned depth, mask radius 1 .. 31 --
+// without the other forms' code (the one kernel for everything kept 106 scalar registers live and spilled 50 more)
+template <bool FAST>
 __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigned long long* mask_l,
-                                                    const unsigned long long* mask_r, int MW, const uint32_t* work_count,
-                                                    const uint32_t* worklist, float4* tstat) {
+                                                    const unsigned long long* mask_r, int MW, const uint32_t* __restrict__ work_count,
+                                                    const uint32_t* __restrict__ worklist, float4* tstat) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (FAST) the frames' x255 decisions as a bit row in LDS: a tile's scale is an LDS read instead of a global load that the fetch
+    // of the next tile would have to wait for (worklist entries hold 12 bits of frame index)
+    __shared__ uint32_t scale_bits[FAST ? 128 : 1];
+    if (FAST) {
+        if (tid < 128) scale_bits[tid] = 0u;
+        __syncthreads();
+        if (A.stats)
+            for (int f = tid; f < A.n; f += 256)
+                if (A.stats[f * ST_WORDS + ST_SCALE255]) atomicOr(&scale_bits[f >> 5], 1u << (f & 31));
+    }
         // weight as a function of the nearest-edge distance d = 0 .. R (d >= R: clamp(1 - d/R) == 0), once per workgroup
     {
-        const int v = A.vert, R = A.radius, WR = BLUR_TR + 2 * v, NW = (BLUR_TW + 2 * R + 63) >> 6, DC = (BLUR_TW + A.bs - 1 + 3) & ~3;
-        float* wl0 = (float*)smem + ((BLUR_TR * DC + 3) & ~3);
+        const int v = A.vert, R = A.radius, WR = BLUR_TR + 2 * v, NW = (BLUR_TW + 2 * R + 63) >> 6, DC = ((BLUR_TW + A.bs - 1 + 3) & ~3) + 4;
+        float* wl0 = (float*)smem + 8 + ((BLUR_TR * DC + 3) & ~3);
         csm::PowfTables* T = (csm::PowfTables*)((unsigned long long*)(wl0 + 2 * WR * BLUR_TW) + 2 * WR * NW);
         float* wtab = (float*)((int*)(T + 1) + 4);
         if (A.fall_mode == 4) {
@@ -700,13 +799,21 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
         }
         __syncthreads();
     }
-    auto tile = [&](const int x0, const int y0, const int frame, float4* tile_stat) {
+    // FAST: `P` holds this tile's inputs (fetched while the previous tile was computed); `next` (a worklist entry, ~0u: none) is
+    // fetched into it as soon as they have been stored to LDS -- its loads are in flight during the weights and the boxes
+    auto tile = [&](const int x0, const int y0, const int frame, float4* tile_stat, BlurPre& P, const uint32_t next, const bool fetch_only = false) {
         const int w = A.w, h = A.h, v = A.vert, bs = A.bs, pad = A.bs / 2, R = A.radius;
         const int WR = BLUR_TR + 2 * v;          // weight rows: frame rows y0 - v ..
         const int EW = BLUR_TW + 2 * R;          // edge columns: frame cols x0 - R ..
-        const int DC = (BLUR_TW + bs - 1 + 3) & ~3;   // depth tile: rows y0 .., cols x0 - pad .. (row stride: a multiple of 4)
+        // depth tile: rows y0 .., cols x0 - pad .., stored in ROW PAIRS: element (r, c) at ((r >> 1) * DC + c) * 2 + (r & 1) -- the
+        // two rows a lane of the box phase owns lie side by side, so that every tap is one packed FMA over the pair (v_pk_fma_f32;
+        // round 5).  DC: a multiple of 4 with four spare columns per row, and eight floats in front of pair 0, so that the 16-byte
+        // loader below stores every element it loaded without a bounds test: what falls left of a pair's first column lands in the
+        // previous pair's spare columns.
+        const int DC = ((BLUR_TW + bs - 1 + 3) & ~3) + 4;
+        auto d_at = [&](int r, int c) -> int { return (((r >> 1) * DC + c) << 1) + (r & 1); };
         const int NW = (EW + 63) >> 6;           // 64-bit words per mask row
-        float* D = (float*)smem;                                   // [TR][DC]
+        float* D = (float*)smem + 8;                               // [TR / 2][DC][2]
         float* wlt = D + ((BLUR_TR * DC + 3) & ~3);                // [WR][TW]
         float* wrt = wlt + WR * BLUR_TW;                           // [WR][TW]
         unsigned long long* mL = (unsigned long long*)(wrt + WR * BLUR_TW);  // [WR][NW]
@@ -714,13 +821,103 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
         csm::PowfTables* T = (csm::PowfTables*)(mR + WR * NW);
         int* any_edge = (int*)(T + 1);
         const float* wtab = (const float*)(any_edge + 4);          // [R + 1] weight of nearest-edge distance d (set up by the caller)
-        if (tid == 0) *any_edge = 0;
-        const float scale = (A.stats && A.stats[frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
+        if (!FAST && tid == 0) *any_edge = 0;
+        const float scale = FAST ? ((scale_bits[frame >> 5] >> (frame & 31)) & 1u ? 255.0f : 1.0f)
+                                 : ((A.stats && A.stats[frame * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f);
         const float* d = A.depth + (size_t)frame * h * w;
         const size_t po = (A.mask_plane && scale != 1.0f) ? A.mask_plane : 0;
-        __syncthreads();
-        // 2. the tile's window of the frame-wide edge bit rows (k_blur_edges): rows y0-v .., bits x0-R ..
+        // 1. (round 5) the depth tile's global loads go out FIRST, as 16-byte accesses: 8 lanes per tile row, the row read from
+        // the 16-byte boundary at or left of x0 - pad (w % 4 == 0: a float4 lies inside the frame or outside it as a whole).  They
+        // are in flight while the bit-row windows are fetched (one memory round trip per tile instead of two), and there is no
+        // division per element (the scalar form below spent 80 instructions on each of its 11 loads per lane: a third of the kernel).
+        const bool vec = FAST || ((w & 3) == 0 && (reinterpret_cast<uintptr_t>(A.depth) & 15) == 0);
+        const int pad4 = (pad + 3) & ~3, shl = pad4 - pad;
+        const int NQ = (pad4 + BLUR_TW + (bs - 1 - pad) + 3) >> 2;   // float4 per tile row
+        constexpr int QU = 4;
+        float4 t4[QU];
+        const int drow_i = tid >> 3, dq = tid & 7;   // (the generic 16-byte loader: 8 lanes per row)
+        const int pp = tid >> 4, pq = tid & 15;      // (FAST: 16 lanes per row pair)
+        auto load_qf = [&](const float* fd, float fscale, int fx0, int fy0, int q) -> float4 {
+            const int yy = fy0 + drow_i, xx = fx0 - pad4 + 4 * q;
+            const bool ok = q < NQ && yy < h && xx >= 0 && xx < w;
+            // (a clamped, always valid address and a select on the values: see k_gray_edges)
+            const float4 t = *reinterpret_cast<const float4*>(fd + (size_t)(ok ? yy : 0) * w + (ok ? xx : 0));
+            return make_float4(ok ? t.x * fscale : 0.0f, ok ? t.y * fscale : 0.0f, ok ? t.z * fscale : 0.0f, ok ? t.w * fscale : 0.0f);
+        };
+        auto load_q = [&](int q) -> float4 { return load_qf(d, scale, x0, y0, q); };
         const unsigned long long lastmask = (EW & 63) ? (~0ull >> (64 - (EW & 63))) : ~0ull;
+        // (FAST) every global input of tile (fx0, fy0, fframe) into registers, RAW: nothing here consumes a loaded value, so no wait
+        // is placed before the phases that follow (NQ <= 32 and WR * NW <= 256: launch_blur checks).  Clamped, always valid addresses.
+        auto fscale_of = [&](int fframe) -> float { return (scale_bits[fframe >> 5] >> (fframe & 31)) & 1u ? 255.0f : 1.0f; };
+        auto fetch = [&](int fx0, int fy0, int fframe, BlurPre& Q) {
+            const float* fd = A.depth + (size_t)fframe * h * w;
+            const size_t fpo = (A.mask_plane && fscale_of(fframe) != 1.0f) ? A.mask_plane : 0;
+            // (16 lanes per row pair: t4[0], t4[1] = rows 2p, 2p + 1 at float4 column `pq`; t4[2], t4[3] = the same at pq + 16)
+#pragma unroll
+            for (int k = 0; k < QU; k++) {
+                const int q = pq + 16 * (k >> 1), yy = fy0 + 2 * pp + (k & 1), xx = fx0 - pad4 + 4 * q;
+                const bool ok = q < NQ && yy < h && xx >= 0 && xx < w;
+                Q.t4[k] = *reinterpret_cast<const float4*>(fd + (size_t)(ok ? yy : 0) * w + (ok ? xx : 0));
+            }
+            const int r = tid >> 1, k = tid & 1, yy = fy0 - v + r;   // (NW == 2)
+            const bool rowok = r < WR && yy >= 0 && yy < h;
+            const int wi = (fx0 - R + 64 * k) >> 6;                  // (-1 for the first tile's left reach)
+            const int w0 = min(max(wi, 0), MW - 1), w1 = min(max(wi + 1, 0), MW - 1);
+            const size_t ro = fpo + ((size_t)fframe * h + (rowok ? yy : 0)) * MW;
+            Q.llo = mask_l[ro + w0]; Q.lhi = mask_l[ro + w1];
+            Q.rlo = mask_r[ro + w0]; Q.rhi = mask_r[ro + w1];
+        };
+        // ... and into LDS, with everything fetch() left out (the tile is (x0, y0, frame) again)
+        auto commit = [&](const BlurPre& Q) {
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const int q = pq + 16 * m, xx = x0 - pad4 + 4 * q;
+                const bool okx = xx >= 0 && xx < w, ok0 = okx && y0 + 2 * pp < h, ok1 = okx && y0 + 2 * pp + 1 < h;
+                if (q < NQ) {
+                    float2* const dst = reinterpret_cast<float2*>(D) + (pp * DC + (4 * q - shl));   // one 8-byte store per column
+                    const float4 a = Q.t4[2 * m], b = Q.t4[2 * m + 1];
+                    dst[0] = make_float2(ok0 ? a.x * scale : 0.0f, ok1 ? b.x * scale : 0.0f);
+                    dst[1] = make_float2(ok0 ? a.y * scale : 0.0f, ok1 ? b.y * scale : 0.0f);
+                    dst[2] = make_float2(ok0 ? a.z * scale : 0.0f, ok1 ? b.z * scale : 0.0f);
+                    dst[3] = make_float2(ok0 ? a.w * scale : 0.0f, ok1 ? b.w * scale : 0.0f);
+                }
+            }
+            const int r = tid >> 1, k = tid & 1, yy = y0 - v + r;
+            if (r < WR) {
+                const int fb = x0 - R + 64 * k, wi = fb >> 6, sh = fb & 63;   // mask_window(): bits fb .. fb + 63 of the row
+                unsigned long long bl = 0ull, br = 0ull;
+                if (yy >= 0 && yy < h) {
+                    if (fb < 0) { bl = Q.lhi << (-fb); br = Q.rhi << (-fb); }   // (fb > -64: R <= 31; both loads were word 0)
+                    else {
+                        const unsigned long long ll = wi < MW ? Q.llo : 0ull, lh = wi + 1 < MW ? Q.lhi : 0ull;
+                        const unsigned long long rl = wi < MW ? Q.rlo : 0ull, rh = wi + 1 < MW ? Q.rhi : 0ull;
+                        bl = sh ? (ll >> sh) | (lh << (64 - sh)) : ll;
+                        br = sh ? (rl >> sh) | (rh << (64 - sh)) : rl;
+                    }
+                    if (k == 1) { bl &= lastmask; br &= lastmask; }
+                }
+                mL[tid] = bl; mR[tid] = br;
+            }
+        };
+        auto store_q = [&](int q, const float4& t) {   // (columns -shl .. 4 NQ - shl - 1 <= BLUR_TW + bs + 1 < DC: see DC)
+            if (q >= NQ) return;
+            float* const dst = D + d_at(drow_i, 4 * q - shl);
+            dst[0] = t.x; dst[2] = t.y; dst[4] = t.z; dst[6] = t.w;
+        };
+        if (FAST && fetch_only) { fetch(x0, y0, frame, P); return; }   // (the workgroup's first tile)
+        if (FAST) {
+            // (the previous tile's last LDS reads are behind the barrier at the end of the worklist loop)
+            commit(P);
+            if (next != ~0u) fetch((int)(next & 1023u) * BLUR_TW, (int)((next >> 10) & 1023u) * BLUR_TR, (int)(next >> 20), P);
+            lds_barrier();
+        }
+        if (!FAST && vec) {
+#pragma unroll
+            for (int k = 0; k < QU; k++) t4[k] = load_q(dq + 8 * k);
+        }
+        if (!FAST) __syncthreads();
+        // 2. the tile's window of the frame-wide edge bit rows (k_blur_edges): rows y0-v .., bits x0-R ..
+        if (!FAST)
         for (int item = tid; item < WR * NW; item += 256) {
             const int r = item / NW, k = item - r * NW;
             const int yy = y0 - v + r;
@@ -734,9 +931,9 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
             mL[item] = bl; mR[item] = br;
             if (bl | br) *any_edge = 1;
         }
-        __syncthreads();   // (the bit-row windows are read by every thread in step 3)
-        if (A.dbg == 21) return;
-        if (*any_edge == 0 && A.fall_mode != 5) {
+        if (!FAST) __syncthreads();   // (the bit-row windows are read by every thread in step 3)
+        if (BLUR_DEV_IS(21)) return;
+        if (!FAST && *any_edge == 0 && A.fall_mode != 5) {   // (FAST: the worklist only names tiles with an edge in reach)
             // no edge within reach of the tile: every weight is exactly 0, so 0*blur + (1-0)*depth == depth
             float mn = INFINITY, mx = -INFINITY;
             for (int i = tid; i < BLUR_TR * BLUR_TW; i += 256) {
@@ -761,7 +958,16 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
         }
         // depth tile for the box filter (zero outside the frame == the reference's zero padding); the loads of a chunk
         // are all issued before the first LDS store so that a chunk costs one memory round trip, not one per element
-        {
+        if (!FAST && vec) {
+#pragma unroll
+            for (int k = 0; k < QU; k++) store_q(dq + 8 * k, t4[k]);
+            for (int qb = 8 * QU; qb < NQ; qb += 8 * QU) {   // (box widths beyond 100 columns)
+#pragma unroll
+                for (int k = 0; k < QU; k++) t4[k] = load_q(qb + dq + 8 * k);
+#pragma unroll
+                for (int k = 0; k < QU; k++) store_q(qb + dq + 8 * k, t4[k]);
+            }
+        } else if (!FAST) {
             constexpr int CH = 12;
             const int total = BLUR_TR * DC;
             for (int base = 0; base < total; base += CH * 256) {
@@ -777,11 +983,11 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
 #pragma unroll
                 for (int k = 0; k < CH; k++) {
                     const int i = base + k * 256 + tid;
-                    if (i < total) D[i] = tmp[k];
+                    if (i < total) D[d_at(i / DC, i % DC)] = tmp[k];
                 }
             }
         }
-        if (A.dbg == 22) return;
+        if (BLUR_DEV_IS(22)) return;
         // 3. weights from the bit rows.  Only edges within R columns give a non-zero weight, so a pixel looks at the 2R + 1
         // bits around its own column: one funnel shift puts them into a 64-bit word (R <= 31), the nearest set bit on
         // either side is a clz / ctz of its two halves.  (Wider masks: word-by-word searches over the whole window.)
@@ -800,6 +1006,31 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
             const int a = mask_dist_left(m, p), b = mask_dist_right(m, NW, p);
             return min(a >= 0 ? a : R + 1, b >= 0 ? b : R + 1);
         };
+        if (FAST || (narrow && NW == 2)) {
+            // (round 5) 32-bit form: a wave owns a weight row, the lane a column -- the row's four dwords come from one broadcast
+            // 16-byte LDS read, two v_alignbit put window bits c .. c + 63 into a register pair, the nearest edge on the left is a
+            // clz of its low R + 1 bits (clz(0) == 32 gives R + 1 by itself), on the right an ffs of bits R .. 2R: 15 instructions
+            // per pixel and eye instead of ~40 in 64-bit arithmetic
+            const int kq = lane >> 5, sh = lane & 31;
+            const unsigned lmask = R == 31 ? ~0u : (2u << R) - 1u;
+            auto dist32 = [&](const uint4& q) -> int {
+                const unsigned a = kq ? q.y : q.x, b = kq ? q.z : q.y, c2 = kq ? q.w : q.z;
+                const unsigned w0 = __builtin_amdgcn_alignbit(b, a, sh), w1 = __builtin_amdgcn_alignbit(c2, b, sh);
+                const unsigned dl = (unsigned)(R - 31 + __clz((int)(w0 & lmask)));
+                const unsigned rr = __builtin_amdgcn_alignbit(w1, w0, R) & lmask;
+                const unsigned dr = (unsigned)(__ffs((int)rr) - 1);   // (no bit: 0xffffffff)
+                return (int)min(min(dl, dr), (unsigned)R);
+            };
+            for (int r = wave; r < WR; r += 4) {
+                const int yy = y0 - v + r;
+                float wl = 0.0f, wr = 0.0f;
+                if (yy >= 0 && yy < h && x0 + lane < w) {
+                    wl = wtab[dist32(*reinterpret_cast<const uint4*>(mL + r * 2))];
+                    wr = wtab[dist32(*reinterpret_cast<const uint4*>(mR + r * 2))];
+                }
+                wlt[r * BLUR_TW + lane] = wl; wrt[r * BLUR_TW + lane] = wr;
+            }
+        } else if (!FAST)
         for (int i = tid; i < WR * BLUR_TW; i += 256) {
             const int r = i >> 6, c = i & 63;
             const int yy = y0 - v + r;
@@ -811,34 +1042,49 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
             }
             wlt[i] = wl; wrt[i] = wr;
         }
-        __syncthreads();
-        if (A.dbg == 23) return;
+        if (FAST) lds_barrier(); else __syncthreads();
+        if (BLUR_DEV_IS(23)) return;
         // 4. boxes + blend: a thread owns 4 consecutive columns of 2 consecutive rows and reads its operands as float4 --
         // 13x fewer LDS instructions than one column per lane (the phase was bound by LDS issue, not by the fmaf chains);
         // every chain keeps the reference's order (taps ascending from an accumulator of 0)
         const int cx = 4 * (tid & 15), r0 = 2 * (tid >> 4);
         const float kb = 1.0f / (float)bs, kv = 1.0f / (float)(2 * v + 1);
+        // (round 5) packed float32 FMAs: the vertical weight sums pair neighbouring columns, the horizontal box sums pair the lane's
+        // two rows (the depth tile's row-pair layout) -- v_pk_fma_f32 is two IEEE fmaf per issue slot, same results
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 kb2 = {kb, kb}, kv2 = {kv, kv};
         float wa[2][4], wb[2][4], acc[2][4];
         if (v > 0) {
+            f2 wa2[2][2], wb2[2][2];
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int c = 0; c < 4; c++) { wa[j][c] = 0.0f; wb[j][c] = 0.0f; }
+                for (int c = 0; c < 2; c++) { wa2[j][c] = f2{0.0f, 0.0f}; wb2[j][c] = f2{0.0f, 0.0f}; }
             const int nv = 2 * v + 1;
             for (int kk = 0; kk <= nv; kk++) {   // weight row r0 + kk is tap kk of output row r0 and tap kk - 1 of row r0 + 1
                 const int rr = min(r0 + kk, WR - 1);
                 const float4 l4 = *reinterpret_cast<const float4*>(wlt + rr * BLUR_TW + cx);
                 const float4 r4 = *reinterpret_cast<const float4*>(wrt + rr * BLUR_TW + cx);
-                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+                const f2 lv[2] = {f2{l4.x, l4.y}, f2{l4.z, l4.w}}, rv[2] = {f2{r4.x, r4.y}, f2{r4.z, r4.w}};
                 if (kk < nv) {
 #pragma unroll
-                    for (int c = 0; c < 4; c++) { wa[0][c] = fmaf(kv, lv[c], wa[0][c]); wb[0][c] = fmaf(kv, rv[c], wb[0][c]); }
+                    for (int c = 0; c < 2; c++) {
+                        wa2[0][c] = __builtin_elementwise_fma(kv2, lv[c], wa2[0][c]);
+                        wb2[0][c] = __builtin_elementwise_fma(kv2, rv[c], wb2[0][c]);
+                    }
                 }
                 if (kk >= 1) {
 #pragma unroll
-                    for (int c = 0; c < 4; c++) { wa[1][c] = fmaf(kv, lv[c], wa[1][c]); wb[1][c] = fmaf(kv, rv[c], wb[1][c]); }
+                    for (int c = 0; c < 2; c++) {
+                        wa2[1][c] = __builtin_elementwise_fma(kv2, lv[c], wa2[1][c]);
+                        wb2[1][c] = __builtin_elementwise_fma(kv2, rv[c], wb2[1][c]);
+                    }
                 }
             }
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) { wa[j][c] = wa2[j][c >> 1][c & 1]; wb[j][c] = wb2[j][c >> 1][c & 1]; }
         } else {
 #pragma unroll
             for (int j = 0; j < 2; j++) {
@@ -848,33 +1094,41 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
                 wb[j][0] = r4.x; wb[j][1] = r4.y; wb[j][2] = r4.z; wb[j][3] = r4.w;
             }
         }
-        if (A.dbg == 24) return;
-        // horizontal box: tap k of column c is D column c + k (the tile starts at frame column x0 - pad)
+        if (BLUR_DEV_IS(24)) return;
+        // horizontal box: tap k of column c is D column c + k (the tile starts at frame column x0 - pad); dp[c] = {row r0, row r0 + 1}
+        const float2* const dp = reinterpret_cast<const float2*>(D) + ((tid >> 4) * DC + cx);
         float lmin = INFINITY, lmax = -INFINITY, rmin = INFINITY, rmax = -INFINITY;
+        {
+            f2 acc2[4];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const float* drow = D + (r0 + j) * DC + cx;
-#pragma unroll
-            for (int c = 0; c < 4; c++) acc[j][c] = 0.0f;
-            float4 nx = *reinterpret_cast<const float4*>(drow);
+            for (int c = 0; c < 4; c++) acc2[c] = f2{0.0f, 0.0f};
+            float4 na = *reinterpret_cast<const float4*>(dp), nb = *reinterpret_cast<const float4*>(dp + 2);
             for (int k0 = 0; k0 < bs; k0 += 4) {
-                const float4 cur = nx;
-                nx = *reinterpret_cast<const float4*>(drow + k0 + 4);   // (the last chunk may read past the row: unused, in bounds)
-                const float d8[8] = {cur.x, cur.y, cur.z, cur.w, nx.x, nx.y, nx.z, nx.w};
+                const float4 ca = na, cb = nb;
+                na = *reinterpret_cast<const float4*>(dp + k0 + 4);   // (the last chunk may read the row pair's spare columns: unused)
+                nb = *reinterpret_cast<const float4*>(dp + k0 + 6);
+                const f2 d8[8] = {f2{ca.x, ca.y}, f2{ca.z, ca.w}, f2{cb.x, cb.y}, f2{cb.z, cb.w},
+                                  f2{na.x, na.y}, f2{na.z, na.w}, f2{nb.x, nb.y}, f2{nb.z, nb.w}};
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) {
                     if (k0 + kk < bs) {
 #pragma unroll
-                        for (int c = 0; c < 4; c++) acc[j][c] = fmaf(kb, d8[c + kk], acc[j][c]);
+                        for (int c = 0; c < 4; c++) acc2[c] = __builtin_elementwise_fma(kb2, d8[c + kk], acc2[c]);
                     }
                 }
             }
+#pragma unroll
+            for (int c = 0; c < 4; c++) { acc[0][c] = acc2[c][0]; acc[1][c] = acc2[c][1]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
             const int y = y0 + r0 + j, x = x0 + cx;
             if (y < h && x < w) {
                 float ol[4], orr[4];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    const float dvv = drow[c + pad];
+                    const float2 dv2 = dp[c + pad];
+                    const float dvv = j ? dv2.y : dv2.x;
                     ol[c] = wa[j][c] * acc[j][c] + (1.0f - wa[j][c]) * dvv;
                     orr[c] = wb[j][c] * acc[j][c] + (1.0f - wb[j][c]) * dvv;
                 }
@@ -896,21 +1150,37 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
         if (A.stats_rw && tile_stat) {
             lmin = wave_min(lmin); lmax = wave_max(lmax); rmin = wave_min(rmin); rmax = wave_max(rmax);
             if (lane == 0) tile_stat[wave] = make_float4(lmin, lmax, rmin, rmax);
-        } else if (A.stats_rw) {
+        } else if (!FAST && A.stats_rw) {
             __shared__ float red[2 * 16];
             uint32_t* st = A.stats_rw + frame * ST_WORDS;
             block_minmax_update(lmin, lmax, &st[ST_L_MIN], &st[ST_L_MAX], red);
             block_minmax_update(rmin, rmax, &st[ST_R_MIN], &st[ST_R_MAX], red);
         }
     };
-    if (!worklist) {
-        tile(blockIdx.x * BLUR_TW, blockIdx.y * BLUR_TR, blockIdx.z, nullptr);
+    BlurPre P;
+    if (!FAST && !worklist) {
+        tile(blockIdx.x * BLUR_TW, blockIdx.y * BLUR_TR, blockIdx.z, nullptr, P, ~0u);
         return;
     }
     const uint32_t count = *work_count;
+    if (FAST) {
+        // software pipeline over the workgroup's tiles: tile i's inputs were fetched during tile i - stride
+        uint32_t i = blockIdx.x;
+        if (i >= count) return;
+        uint32_t e = worklist[i];
+        tile((int)(e & 1023u) * BLUR_TW, (int)((e >> 10) & 1023u) * BLUR_TR, (int)(e >> 20), nullptr, P, ~0u, true);
+        for (; i < count; i += gridDim.x) {
+            const uint32_t nx = i + gridDim.x;
+            const uint32_t e2 = nx < count ? worklist[nx] : ~0u;
+            tile((int)(e & 1023u) * BLUR_TW, (int)((e >> 10) & 1023u) * BLUR_TR, (int)(e >> 20), tstat ? tstat + 4 * (size_t)i : nullptr, P, e2);
+            lds_barrier();  // the tile's LDS is reused by the next one
+            e = e2;
+        }
+        return;
+    }
     for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
         const uint32_t e = worklist[i];
-        tile((int)(e & 1023u) * BLUR_TW, (int)((e >> 10) & 1023u) * BLUR_TR, (int)(e >> 20), tstat ? tstat + 4 * (size_t)i : nullptr);
+        tile((int)(e & 1023u) * BLUR_TW, (int)((e >> 10) & 1023u) * BLUR_TR, (int)(e >> 20), tstat ? tstat + 4 * (size_t)i : nullptr, P, ~0u);
         __syncthreads();  // the tile's LDS is reused by the next one
     }
 }
@@ -1003,7 +1273,7 @@ __global__ void __launch_bounds__(256) k_blur_copy_tiles(BlurArgs A, const uint3
 static size_t blur_fused_lds(int v, int R, int bs) {
     int WR = BLUR_TR + 2 * v, EW = BLUR_TW + 2 * R, NW = (EW + 63) >> 6;
     (void)EW;
-    return (size_t)(BLUR_TR * ((BLUR_TW + bs - 1 + 3) & ~3)) * 4 + 2 * (size_t)WR * BLUR_TW * 4 + 2 * (size_t)WR * NW * 8 +
+    return 32 + (size_t)(BLUR_TR * (((BLUR_TW + bs - 1 + 3) & ~3) + 4)) * 4 + 2 * (size_t)WR * BLUR_TW * 4 + 2 * (size_t)WR * NW * 8 +
            sizeof(csm::PowfTables) + 64 + 4 * (size_t)(R + 2);
 }
 
@@ -1090,7 +1360,8 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
     if (pre_edges && !P.lazy) return CS_EINVAL;   // (the caller asked blur_pre_edges_ok)
     size_t ldsF = blur_fused_lds(A.vert, A.radius, A.bs);
     if (P.fused) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_blur_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
+        hipError_t e = hipFuncSetAttribute((const void*)k_blur_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_blur_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsF);
         if (e != hipSuccess) return CS_EHIP;
         // the weight scratch buffers double as the frame-wide edge bit rows (2 x ceil(w/64) words per image row)
         const int MW = P.MW;
@@ -1125,13 +1396,22 @@ int launch_blur(const float* depth, int n, int h, int w, double strength, double
             const size_t total = (size_t)n * gy * gx;
             const int pg = (int)(total < 2048 ? total : 2048);
             float4* tstat = A.stats_rw ? reinterpret_cast<float4*>(reinterpret_cast<char*>(worklist) + ((total * 4 + 15) & ~(size_t)15)) : nullptr;
-            hipLaunchKernelGGL(k_blur_fused, dim3(pg), dim3(256), ldsF, stream, A, (const unsigned long long*)mask_l,
-                               (const unsigned long long*)mask_r, MW, (const uint32_t*)work_count, (const uint32_t*)worklist, tstat);
+            // (one float4 chunk per lane: box widths up to 100 columns; one bit-row item per lane: vertical smoothing up to 48 rows)
+            const int pad4 = (A.bs / 2 + 3) & ~3;
+            const bool fast = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(depth) & 15) == 0 && A.radius >= 1 && A.radius <= 31 &&
+                              ((pad4 + BLUR_TW + (A.bs - 1 - A.bs / 2) + 3) >> 2) <= 32 && (BLUR_TR + 2 * A.vert) * 2 <= 256 &&
+                              !dev_switch(CS_DEBUG_BLUR_EDGES_SCALAR);
+            if (fast)
+                hipLaunchKernelGGL(k_blur_fused<true>, dim3(pg), dim3(256), ldsF, stream, A, (const unsigned long long*)mask_l,
+                                   (const unsigned long long*)mask_r, MW, (const uint32_t*)work_count, (const uint32_t*)worklist, tstat);
+            else
+                hipLaunchKernelGGL(k_blur_fused<false>, dim3(pg), dim3(256), ldsF, stream, A, (const unsigned long long*)mask_l,
+                                   (const unsigned long long*)mask_r, MW, (const uint32_t*)work_count, (const uint32_t*)worklist, tstat);
             if (tstat)
                 hipLaunchKernelGGL(k_blur_tile_stats, dim3(4, n), dim3(256), 0, stream, (const uint32_t*)work_count,
                                    (const uint32_t*)worklist, (const float4*)tstat, A.stats_rw);
         } else {
-            hipLaunchKernelGGL(k_blur_fused, dim3(gx, gy, n), dim3(256), ldsF, stream, A, (const unsigned long long*)mask_l,
+            hipLaunchKernelGGL(k_blur_fused<false>, dim3(gx, gy, n), dim3(256), ldsF, stream, A, (const unsigned long long*)mask_l,
                                (const unsigned long long*)mask_r, MW, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (float4*)nullptr);
         }
         return CS_OK;
