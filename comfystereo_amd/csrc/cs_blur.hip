@@ -1021,12 +1021,17 @@ __global__ void __launch_bounds__(256, 4) k_blur_fused(BlurArgs A, const unsigne
                 const unsigned dr = (unsigned)(__ffs((int)rr) - 1);   // (no bit: 0xffffffff)
                 return (int)min(min(dl, dr), (unsigned)R);
             };
+            const float w_none = wtab[R];
             for (int r = wave; r < WR; r += 4) {
                 const int yy = y0 - v + r;
                 float wl = 0.0f, wr = 0.0f;
                 if (yy >= 0 && yy < h && x0 + lane < w) {
-                    wl = wtab[dist32(*reinterpret_cast<const uint4*>(mL + r * 2))];
-                    wr = wtab[dist32(*reinterpret_cast<const uint4*>(mR + r * 2))];
+                    // (a window row without bits -- most rows have them for one eye at most: an edge is rising or falling -- is all
+                    // "no edge in reach": wtab[R].  The test is the same for every lane: the row is a broadcast read.)
+                    const uint4 ql = *reinterpret_cast<const uint4*>(mL + r * 2), qr = *reinterpret_cast<const uint4*>(mR + r * 2);
+                    wl = wr = w_none;
+                    if (ql.x | ql.y | ql.z | ql.w) wl = wtab[dist32(ql)];
+                    if (qr.x | qr.y | qr.z | qr.w) wr = wtab[dist32(qr)];
                 }
                 wlt[r * BLUR_TW + lane] = wl; wrt[r * BLUR_TW + lane] = wr;
             }
