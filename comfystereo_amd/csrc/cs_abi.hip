@@ -375,8 +375,11 @@ static const char* const DIALECT_MSG = "dialect D64 (flags bits 3/4) exists for 
 // flags of the rows the tiled polylines path hands to the row kernel + their compacted list (run_rows)
 // flagged-row block: [row flags, one byte per row][count / cursor pairs, 256 B][stretch-replay counters, 256 B][replay retry
 // flags, one byte per row] -- everything one memset clears -- then [row list, 4 B per row]
-static size_t rowflag_bytes(size_t rows) { return 2 * al256(rows) + 512 + al256(rows * 4); }
-static size_t rowflag_clear_bytes(size_t rows) { return 2 * al256(rows) + 512; }
+// (round 5: + [tile hints, one 32-bit word per row and eye: bit t = tile t of that row-eye could not be finished by k_polypoint]
+// behind the retry flags, inside the cleared part)
+static size_t rowflag_hint_off(size_t rows) { return 2 * al256(rows) + 512; }
+static size_t rowflag_clear_bytes(size_t rows) { return rowflag_hint_off(rows) + al256(rows * 8); }
+static size_t rowflag_bytes(size_t rows) { return rowflag_clear_bytes(rows) + al256(rows * 4); }
 static uint32_t* rowflag_list(uint8_t* rowflag, size_t rows) { return (uint32_t*)(rowflag + rowflag_clear_bytes(rows)); }
 
 // polylines: tiled fast path + general row kernel over the rows it flagged; everything else: row kernel
@@ -395,7 +398,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
     // CS_DEBUG_PT_VARIANT asks for the first generation (cs_polytile.hip)
     const int variant = dev_switch(CS_DEBUG_PT_VARIANT);   // 0 / 3 .. 7: point-owner kernel; 41 - 43: tie-path what-ifs; other values: first generation
     auto polypoint_takes = [&](int hl) {
-        return hl <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16) || (variant >= 41 && variant <= 43));
+        return hl <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16) || (variant >= 41 && variant <= 45));
     };
     // (the tile kernels are dialect D32, plus -- round 5 -- the float64 disparity chain alone: k_polypoint<..., DIA>)
     const bool tile_dialect = A.d64 == 0 || (A.d64 == 1 && polypoint_takes(halo));
@@ -412,6 +415,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
     // (cs_rowwarp.hip k_poly_replay) instead of inside the row kernel
     const bool replay = poly && !A.d64 && replay_scratch && rowflag && !A.anaglyph && !dev_switch(CS_DEBUG_NO_REPLAY_KERNEL) &&
                         poly_replay_bytes(A.n, A.h, A.w, fill == CS_FILL_POLYLINES_SHARP) > 0;
+    int hint_T = 0;         // tile width of k_polypoint when it took the call (its hint words are then valid)
     bool cleared = false;   // the flagged-row block (row flags, counters, replay counters and retry flags) has been zeroed
     if (replay)
         (void)poly_replay_attach(A, fill == CS_FILL_POLYLINES_SHARP, replay_scratch, rowflag + al256((size_t)A.n * A.h) + 256, stream, replay_surplus);
@@ -426,7 +430,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         cleared = true;
         const RowArgs& T = A;
         if (polypoint_takes(halo))
-            e = launch_polypoint(T, halo, rowflag, stream, fill == CS_FILL_POLYLINES_SHARP);
+            e = launch_polypoint(T, halo, rowflag, stream, fill == CS_FILL_POLYLINES_SHARP, (uint32_t*)(rowflag + rowflag_hint_off(rows)), &hint_T);
         else
             e = launch_polytile(fill == CS_FILL_POLYLINES_SHARP, T, halo, rowflag, stream);
         if (e != hipSuccess) return fail_hip(e, "tiled polylines launch");
@@ -442,6 +446,10 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         e = launch_collect_rows(rowflag, (int)rows, count, list, stream);
         if (e != hipSuccess) return fail_hip(e, "flagged-row collection");
         A.row_list = list; A.row_count = count;
+        // (the lean first pass works on the flagged tiles' column ranges; CS_DEBUG_PT_VARIANT 44: whole rows as in round 4)
+        if (hint_T > 0 && dev_switch(CS_DEBUG_PT_VARIANT) != 44) {
+            A.hint = (const uint32_t*)(rowflag + rowflag_hint_off(rows)); A.hint_T = hint_T; A.hint_S = halo;
+        }
     }
     if ((fill == CS_FILL_NONE || fill == CS_FILL_INVERSE || fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING) &&
         !dev_switch(CS_DEBUG_NO_TILE)) {
@@ -487,7 +495,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         e = launch_collect_rows(poly_replay_retry_flags(A), (int)rows, count2, list, stream);
         if (e != hipSuccess) return fail_hip(e, "replay retry collection");
         RowArgs R = A;
-        R.rp_dump = nullptr; R.row_list = list; R.row_count = count2;
+        R.rp_dump = nullptr; R.row_list = list; R.row_count = count2; R.hint = nullptr;
         // (one workgroup per CU: on saturated depth a few hundred rows per frame come back -- stretches whose list outgrows the
         // wave form's 64 entries --, 32 workgroups made them the tail of the call; an empty launch of 256 costs 0.03 ms)
         e = launch_rowwarp(fill, R, threads_for(fill, A.w), stream, dev_switch(CS_DEBUG_PT_VARIANT) == 42 ? 32 : 256);

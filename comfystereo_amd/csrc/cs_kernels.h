@@ -65,6 +65,11 @@ struct RowArgs {
     uint32_t rp_pool16, rp_cap;   // dump pool in 16-byte units, descriptors in the list
     const uint32_t* row_list;     // or null: process only these rows (frame * h + row), *row_count of them (tiled-path fallback)
     const uint32_t* row_count;
+    // tile hints of k_polypoint (round 5): word [(frame * h + row) * 2 + eye], bit t = tile t (hint_T pixels wide) of that row-eye raised
+    // the hazard, bit 31 = any tile from 31 on; the lean first pass over the flagged rows confines itself to those tiles' columns
+    // plus a margin (and the sources within hint_S + 2 of them).  Null: whole rows.
+    const uint32_t* hint;
+    int hint_T, hint_S;
     int dbg;            // development only (cs_debug_set(CS_DEBUG_DBG, n)): see dev_switch() below
 };
 
@@ -96,7 +101,8 @@ hipError_t launch_fwdtile(int fill, const RowArgs& A, int S, uint8_t* rowflag, h
 int fwdtile_max_halo();
 
 // cs_polypoint.hip: second generation of the tiled path (polylines_soft): one lane per polyline point
-hipError_t launch_polypoint(const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream, int sharp = 0);
+hipError_t launch_polypoint(const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream, int sharp = 0, uint32_t* hint = nullptr,
+                            int* tile_width = nullptr);
 int polypoint_max_halo();
 // anaglyph modes behind the tile kernel: the eyes as uint8 codes side by side -> the composite (rows flagged in rowflag excepted)
 hipError_t launch_anaglyph_compose(const uint8_t* sbs, const uint8_t* rowflag, int n, int h, int w, int anaglyph, float* stereo,

@@ -91,6 +91,9 @@ struct PolyPointArgs {
     unsigned long long epk[2][3];
     // dialect bit "float64 disparity chain" (RowArgs::d64 & 1; the DIA instantiations, polylines_soft only): the exponent as a double
     int d64; double e64;
+    // tile hints (round 5): bit t of word [(frame * h + row) * 2 + eye] = tile t of that row-eye raised a hazard (tiles from 31 on
+    // share bit 31); null: not recorded.  The row kernel can then confine itself to those tiles' columns.
+    uint32_t* hint;
 };
 
 struct F3 { float x, y, z; };
@@ -1128,6 +1131,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
                     // workgroups: an atomic OR on its word -- flagged rows are rare)
         const uint32_t idx = (uint32_t)frame * (uint32_t)h + (uint32_t)row;
         atomicOr(reinterpret_cast<unsigned*>(A.rowflag + (idx & ~3u)), (eyei ? 4u : 2u) << (8u * (idx & 3u)));
+        if (A.hint) atomicOr(&A.hint[2u * idx + (uint32_t)eyei], 1u << min(tile, 31));
     }
 }
 
@@ -1253,7 +1257,7 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
 
 // Launch for the eyes of `R` (SBS / TB / single-eye / uint8 outputs; no anaglyph).  `rowflag` must be zeroed by the caller;
 // afterwards the general kernel is run over the flagged rows.
-hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream_t stream, int sharp) {
+hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream_t stream, int sharp, uint32_t* hint, int* tile_width) {
     // workgroup geometry: threads x point slots per lane.  256 x 4 (7 workgroups per CU at the bench halo, 19.5 KB of LDS each) is
     // the default; development switch CS_DEBUG_PT_VARIANT: 3 = 256 x 3 (the default until the end of round 3), 4 = 256 x 4,
     // 5 = 384 x 3, 6 = 320 x 3
@@ -1280,6 +1284,8 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     A.dbg = R.dbg;
     A.tilemap = R.tilemap; A.gray = R.lazy_gray; A.tm_words = R.tm_words;
     A.d64 = R.d64; A.e64 = R.e64;
+    A.hint = hint;
+    if (tile_width) *tile_width = A.T;
     if (R.d64 && R.d64 != 1) return hipErrorInvalidValue;   // (only the float64 disparity chain: the sweep's typing stays D32)
     const int out = R.out_u8 ? PO_ASD : (R.stereo_is_u8 ? (R.no_mask ? PO_U8NM : PO_U8) : PO_F32);
     if ((out == PO_ASD) != (R.image_u8 != nullptr)) return hipErrorInvalidValue;  // uint8 image in <=> uint8 image out

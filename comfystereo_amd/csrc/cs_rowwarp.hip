@@ -1026,10 +1026,26 @@ __host__ __device__ inline uint32_t rp_win16(int npw, int ncw) { return (uint32_
 // parallel evaluation, the stretch list and the export only -- a row that would need the in-row replay (export impossible,
 // no reset points, list overflow) is flagged for the second pass (the full kernel, export off) instead.  Without the replay
 // code the kernel fits 64 registers: two 1024-thread workgroups per CU instead of one.
+// RANGE (round 5, LEAN only): the first pass over a flagged row-eye confined to the columns [cA, cB) around the tiles that raised
+// the hazard (k_polypoint's tile hints) and to the sources [sA, sB) that can reach them (cA - halo - 2 .. cB + halo + 2): every
+// phase -- disparities, sort, segment lists, evaluation -- then costs what the range costs, not what the row costs (on saturated
+// depth a flagged row-eye has 1.4 of 5 tiles flagged, tools/sessions/r05_s20.sh).  The row kernel as a generalised tile: points of
+// sources outside the range cannot lie within 4.5 columns of it, so the sorted order, the segment lists and every sub-interval
+// inside [cA, cB) are the whole row's (a predecessor / successor point outside only enters through max(col, a) / min(col + 1, b)).
+// Pixels outside keep what the tile kernel wrote: they are final there.  A stretch must start behind a reset pixel INSIDE the
+// range; a row that has none in front of its first order-dependent pixel goes to the retry pass (whole row).  cA < 0: whole row.
+struct PolyRange { int cA, cB, sA, sB; };
 template <int SHARP, bool DIALECT, class Emit, bool LEAN = false>
 __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float e32, uint32_t* stats_rw,
-                                    const Emit& emit, int dbg, const RpCtx* X = nullptr, int d64_ = 0, double e64 = 0.0) {
+                                    const Emit& emit, int dbg, const RpCtx* X = nullptr, int d64_ = 0, double e64 = 0.0,
+                                    const PolyRange RG = PolyRange{-1, 0, 0, 0}) {
     const int d64 = DIALECT ? d64_ : 0;
+    const bool restricted = LEAN && !DIALECT && RG.cA >= 0;
+    // restricted: the points of sources sA .. sB - 1 (ids pfirst .. plast) plus the two sentinels; segments between them (plus the
+    // sentinels' segments where the range touches the row's ends)
+    const int srcA = restricted ? RG.sA : 0, srcB = restricted ? RG.sB : w;
+    const int pfirst = SHARP ? 1 + 2 * srcA : 1 + srcA, plast = SHARP ? 2 * srcB : srcB;   // (whole row: 1 .. npt - 2)
+    const int npts_r = plast - pfirst + 3;
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
     Poly P;
     P.w = w; P.sharp = SHARP; P.npt = poly_npt(w, SHARP); P.cap = poly_cap(w, SHARP);
@@ -1056,26 +1072,30 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
             L.nd[c] = (float)cd;   // (only |coord_d| as float32 is read from here on: the z of the point)
         }
     } else {
-        for (int c = tid; c < w; c += nt) L.nd[c] = disparity(L.nd[c], e32, E.div32, L.tabs);
+        // (one source beyond either end as well: the replay's window loader fetches the right neighbour of every window point)
+        for (int c = max(srcA - 1, 0) + tid; c < min(srcB + 1, w); c += nt) L.nd[c] = disparity(L.nd[c], e32, E.div32, L.tabs);
     }
     for (int i = tid; i < (w + 4) / 2; i += nt) ((unsigned*)P.binoff)[i] = 0;
     for (int i = tid; i < (w + 2) / 2; i += nt) ((unsigned*)P.segoff)[i] = 0;
     if (tid == 0) { *flag_hazard = 0; *nlong = 0; *ntotal = 0; }
     __syncthreads();
     if (dbg == 1) return;
-    for (int o = tid; o < npt; o += nt) atomic_add_u16(P.binoff, poly_bin(P, poly_x(P, o)) + 1, 1);
+    // (the point set as one index space: k = 0 .. npts_r - 1 -> left sentinel, pfirst .. plast, right sentinel)
+    auto point_of = [&](int k) -> int { return k == 0 ? 0 : (k == npts_r - 1 ? npt - 1 : pfirst + k - 1); };
+    for (int k = tid; k < npts_r; k += nt) atomic_add_u16(P.binoff, poly_bin(P, poly_x(P, point_of(k))) + 1, 1);
     __syncthreads();
     if (dbg == 2) return;
     // P2: counting sort by bin, then rank inside the bin by (x, reference index) == the reference's
     // stable insertion sort (:1941-1946).  After the scatter binoff[b] = END of bin b.
     block_scan_inclusive(P.binoff, nbin + 1, 0, OpAdd(), scan_ws);
     uint16_t* scratch = P.entries;
-    for (int o = tid; o < npt; o += nt) {
+    for (int k = tid; k < npts_r; k += nt) {
+        const int o = point_of(k);
         unsigned slot = atomic_add_u16(P.binoff, poly_bin(P, poly_x(P, o)), 1);
         scratch[slot] = (uint16_t)o;
     }
     __syncthreads();
-    for (int k = tid; k < npt; k += nt) {
+    for (int k = tid; k < npts_r; k += nt) {
         int o = scratch[k];
         float x = poly_x(P, o);
         int b = poly_bin(P, x);
@@ -1105,8 +1125,8 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
     bool overflow = false;
     bool ranged = false;
     for (int r = 0; r < nr && !overflow; r++) {
-        const int cA = nr == 1 ? 0 : (int)(((long long)w * r / nr) & ~63LL);
-        const int cB = (nr == 1 || r == nr - 1) ? w : (int)(((long long)w * (r + 1) / nr) & ~63LL);
+        const int cA = restricted ? RG.cA : (nr == 1 ? 0 : (int)(((long long)w * r / nr) & ~63LL));
+        const int cB = restricted ? RG.cB : ((nr == 1 || r == nr - 1) ? w : (int)(((long long)w * (r + 1) / nr) & ~63LL));
         uint16_t* const longs_r = r == 0 ? P.longs : (uint16_t*)L.tabs;
         const int longcap_r = r == 0 ? LONGCAP : (int)(sizeof(csm::PowfTables) / 2);
         if (r > 0 || ranged) {   // (a fresh count: the whole-row pass below only told us that ranges are needed)
@@ -1115,7 +1135,15 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
             __syncthreads();
         }
         int local = 0;
-        for (int o = tid; o < npt - 1; o += nt) {
+        // (the segment set as one index space: k = 0 .. nseg_r - 1 -> the left sentinel's segment (if the range starts at source 0),
+        // pfirst .. plast - 1, the right sentinel's (if it ends at source w - 1))
+        const int nseg_r = plast - pfirst + 2;
+        auto seg_of = [&](int k) -> int {
+            return k == 0 ? (srcA == 0 ? 0 : -1) : (k == nseg_r - 1 ? (srcB == w ? npt - 2 : -1) : pfirst + k - 1);
+        };
+        for (int k = tid; k < nseg_r; k += nt) {
+            const int o = seg_of(k);
+            if (o < 0) continue;
             int p0, p1;
             poly_seg_pixels<0>(P, o, p0, p1);
             p0 = max(p0, cA); p1 = min(p1, cB - 1);
@@ -1133,7 +1161,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         __syncthreads();
         const int nl = min(*nlong, longcap_r);
         const bool over_r = *nlong > longcap_r || *ntotal > P.cap;
-        if (over_r && nr == 1 && !ranged && !DIALECT && *ntotal <= RW_MAX_RANGES * (P.cap - P.cap / 8) && w >= 256 && dbg != 31) {
+        if (over_r && nr == 1 && !ranged && !DIALECT && !restricted && *ntotal <= RW_MAX_RANGES * (P.cap - P.cap / 8) && w >= 256 && dbg != 31) {
             // too many entries for one pass, few enough for RW_MAX_RANGES: start over in ranges (the prefix sums are 16 bits wide, but
             // per range; the whole row's count of long segments does not matter either -- they are clipped and listed per range)
             nr = min(RW_MAX_RANGES, (*ntotal + (P.cap - P.cap / 8) - 1) / (P.cap - P.cap / 8));
@@ -1143,7 +1171,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
             __syncthreads();
             continue;
         }
-        if (!over_r && nr == 1 && !ranged && dbg == 30 && w >= 256 && !DIALECT) {   // (development: two ranges although one would do)
+        if (!over_r && nr == 1 && !ranged && dbg == 30 && w >= 256 && !DIALECT && !restricted) {   // (development: two ranges although one would do)
             nr = 2; ranged = true; r = -1;
             __syncthreads();
             continue;
@@ -1159,7 +1187,9 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         }
         __syncthreads();
         block_scan_inclusive(P.segoff, w + 1, 0, OpAdd(), scan_ws);
-        for (int o = tid; o < npt - 1; o += nt) {
+        for (int k = tid; k < nseg_r; k += nt) {
+            const int o = seg_of(k);
+            if (o < 0) continue;
             int p0, p1;
             poly_seg_pixels<1>(P, o, p0, p1);
             p0 = max(p0, cA); p1 = min(p1, cB - 1);
@@ -1236,6 +1266,9 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         // rows over the (idle) long-segment array
         unsigned long long* hzw = (unsigned long long*)P.longs;
         unsigned long long* rsw = hzw + ((w + 63) >> 6);
+        if (restricted)   // (nothing outside the range is evaluated: no events there)
+            for (int wi = tid; wi < ((w + 63) >> 6); wi += nt)
+                if (wi < (cA >> 6) || wi >= ((cB + 63) >> 6)) { hzw[wi] = 0ull; rsw[wi] = 0ull; }
         for (int colb = cA; colb < cB; colb += nt) {
             const int col = colb + tid;
             bool hazard = false, reset = false;
@@ -1294,6 +1327,10 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += nt) dst[i] = src[i];
     }
     __syncthreads();
+    if (restricted && overflow) {   // (the whole-row export below would need the whole row's sorted order)
+        if (tid == 0) X->retry[X->rowid] = 1;
+        return;
+    }
     if (DIALECT && (d64 & 2)) {
         if ((overflow || *flag_hazard) && tid == 0) {   // order-dependent row: the literal replay (it rewrites every pixel)
             const int rc = poly_sequential64(P, L, E.csg_cap, emit);
@@ -1338,7 +1375,8 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
             const unsigned long long* hzw = (const unsigned long long*)P.longs;
             const unsigned long long* rsw = hzw + ((w + 63) >> 6);
             int count = 0, last_reset = -1, start = 0, end = 0;
-            bool open = false;
+            bool open = false, badstart = false;   // (restricted: a stretch that would start in front of the range)
+            const int cA0 = restricted ? RG.cA : 0;
             for (int wi = 0; wi < (w + 63) >> 6; wi++) {
                 const unsigned long long hz = hzw[wi], rs = rsw[wi];
                 if (hz == 0ull) {   // (the common word: no order-dependent pixel)
@@ -1354,7 +1392,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                     ev &= ev - 1;
                     const int col = wi * 64 + b;
                     if ((hz >> b) & 1ull) {
-                        if (!open) { open = true; start = last_reset + 1; }
+                        if (!open) { open = true; start = last_reset + 1; badstart = badstart || start < cA0; }
                         end = col;
                     } else {
                         if (open) { if (count < NSTR) slist[count] = (uint32_t)start | ((uint32_t)end << 16); count++; open = false; }
@@ -1363,7 +1401,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                 }
             }
             if (open) { if (count < NSTR) slist[count] = (uint32_t)start | ((uint32_t)end << 16); count++; }
-            *nstretch = count <= NSTR ? count : -1;
+            *nstretch = (count <= NSTR && !badstart) ? count : -1;
             *stretch_bad = 0;
         }
         __syncthreads();
@@ -1399,7 +1437,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                 }
                 // sorted points the replay can look at: from three below its two cursors to a 64-entry window past the last
                 // point left of pixel c1 + 1; source columns: those points', their right neighbours', the start segment's
-                const int pw0 = max(min((int)P.binoff[c0] - 1, sgp0) - 3, 0), pw1 = min((int)P.binoff[c1 + 1] + 66, npt - 1);
+                const int pw0 = max(min((int)P.binoff[c0] - 1, sgp0) - 3, 0), pw1 = min((int)P.binoff[c1 + 1] + 66, npts_r - 1);
                 int cmin = 0x7fffffff, cmax = -1;
                 for (int i = pw0 + lane; i <= pw1; i += 64) {
                     const int o = P.perm[i];
@@ -2417,12 +2455,12 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
     }
     // source row -> uint8 RGB (np.clip(x*255, 0, 255).astype(uint8), reference :1508)
     const size_t rowpix = ((size_t)frame * h + row) * w;
-    auto stage_image = [&]() {
+    auto stage_image = [&](const int s0, const int s1) {   // source columns s0 .. s1 - 1 (the whole row: 0, w)
     if (A.image_f32) {
         const float* src = A.image_f32 + rowpix * 3;
         if ((w & 3) == 0) {
             const float4* s4 = reinterpret_cast<const float4*>(src);
-            for (int i = tid; i < (3 * w) / 4; i += nt) {
+            for (int i = ((3 * s0) >> 2) + tid; i < ((3 * s1 + 3) >> 2); i += nt) {
                 float4 v = s4[i];
                 float f[4] = {v.x, v.y, v.z, v.w};
                 uint32_t pk = 0;
@@ -2435,7 +2473,7 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
                 reinterpret_cast<uint32_t*>(L.img)[i] = pk;
             }
         } else {
-            for (int i = tid; i < 3 * w; i += nt) {
+            for (int i = 3 * s0 + tid; i < 3 * s1; i += nt) {
                 float x = src[i] * 255.0f;
                 x = fminf(fmaxf(x, 0.0f), 255.0f);
                 L.img[i] = (uint8_t)(int)x;
@@ -2443,16 +2481,14 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
         }
     } else {
         const uint8_t* src = A.image_u8 + rowpix * 3;
-        for (int i = tid; i < 3 * w; i += nt) L.img[i] = src[i];
+        for (int i = 3 * s0 + tid; i < 3 * s1; i += nt) L.img[i] = src[i];
     }
     __syncthreads();
     };
-    stage_image();
+    if (!LEAN) stage_image(0, w);   // (LEAN: per eye below -- its export phase uses the colour row as scratch, and an eye may need a range only)
 
     const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
     for (int e = 0; e < A.neyes; e++) {
-        // (the lean polylines kernel uses the colour row as the scratch of its export phase: staged again for the second eye)
-        if (LEAN && e > 0) { __syncthreads(); stage_image(); }   // (barrier: the first eye's export may still be reading its scratch)
         // (field-by-field selects: a dynamically indexed -- or aggregate-selected -- kernel-argument array makes the compiler copy
         // the whole argument struct to scratch memory)
         EyeArgs E;
@@ -2465,6 +2501,22 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
         E.xoff = e ? A.eye[1].xoff : A.eye[0].xoff; E.yoff = e ? A.eye[1].yoff : A.eye[0].yoff;
         if (A.single >= 0 && A.single != e) continue;
         if (!A.anaglyph && !((eyemask >> e) & 1)) continue;
+        // (round 5) the flagged tiles of this row-eye -> the column range the lean pass works on (technique_polylines, PolyRange):
+        // first .. last flagged tile, 192 columns of margin for the reset pixel a stretch starts behind, multiples of 64
+        PolyRange RG{-1, 0, 0, 0};
+        if (LEAN && A.hint && E.enabled) {
+            const uint32_t m = A.hint[((size_t)frame * h + row) * 2 + e];
+            if (m) {
+                const int t0 = __ffs((int)m) - 1, t1 = 31 - __clz((int)m);
+                const int ra = max(t0 * A.hint_T - 192, 0) & ~63;
+                const int rb = t1 >= 31 ? w : min(w, ((t1 + 1) * A.hint_T + 192 + 63) & ~63);
+                if (rb - ra <= (3 * w) / 4) RG = PolyRange{ra, rb, max(0, ra - A.hint_S - 2), min(w, rb + A.hint_S + 2)};
+            }
+        }
+        const int st0 = RG.cA >= 0 ? max(RG.sA - 1, 0) : 0, st1 = RG.cA >= 0 ? min(RG.sB + 1, w) : w;   // sources staged for this eye
+        // (the lean polylines kernel uses the colour row as the scratch of its export phase: staged per eye; the barrier: the previous
+        // eye's export may still be reading its scratch)
+        if (LEAN) { __syncthreads(); stage_image(st0, st1); }
         const bool last = (e == A.neyes - 1) || A.single >= 0;
         RowOut out{A.out_u8, A.stereo, A.mask, L.ana, L.ana, L.lut, A.h, A.out_h, A.out_w, E.xoff, E.yoff, A.anaglyph, A.stereo_is_u8,
                    frame, row, w, A.anaglyph != 0 && !last};
@@ -2475,7 +2527,7 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
             const bool flat = dmax == dmin;
             const float range = dmax - dmin;
             if (FILL != CS_FILL_HYBRID_EDGE && FILL != CS_FILL_HYBRID_EDGE_PLUS) {
-                for (int c = tid; c < w; c += nt) {
+                for (int c = st0 + tid; c < st1; c += nt) {
                     float d = drow[c] * scale;
                     L.nd[c] = flat ? 0.0f - A.conv32 : ((d - dmin) / range) - A.conv32;
                 }
@@ -2509,7 +2561,7 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
                 if (LEAN) asm volatile("" : "+s"(we), "+s"(l0));
 #endif
                 const Lds Le = carve(smem + l0, FILL, we, A.anaglyph);
-                technique_polylines<FILL == CS_FILL_POLYLINES_SHARP ? 1 : 0, DIALECT, decltype(out), LEAN>(Le, we, E, A.e32, st_rw, out, A.dbg, &X, A.d64, A.e64);
+                technique_polylines<FILL == CS_FILL_POLYLINES_SHARP ? 1 : 0, DIALECT, decltype(out), LEAN>(Le, we, E, A.e32, st_rw, out, A.dbg, &X, A.d64, A.e64, RG);
             }
             else if (FILL == CS_FILL_HYBRID_EDGE_PLUS) {
                 // hybrid_edge into `res`, then the polylines_soft row into `alt`; pixels that stayed black take the latter
@@ -2575,7 +2627,9 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
         __syncthreads();
     }
     // depth-map outputs: (depth*255).astype(uint8) wraps mod 256 (quirk Q7), then /255, 3 channels
-    if (A.depth_l) {
+    // (not for the rows k_polypoint flagged -- `hint` says it was the tile kernel: it writes the depth maps of every row itself, whatever
+    // it makes of the row's pixels; rewriting them here was 92 KB of stores per flagged row, round 5)
+    if (A.depth_l && !(A.row_list && A.hint)) {
         for (int e = 0; e < 2; e++) {
             const float* drow = (e == 0 ? A.eye[0].depth : A.eye[1].depth) + rowpix;
             float* dst = (e == 0 ? A.depth_l : A.depth_r) + rowpix * 3;
@@ -2760,6 +2814,184 @@ __global__ void __launch_bounds__(64, CWS > 2048 ? 1 : RP_MINW) k_poly_replay(Ro
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_poly_replay_lanes (round 5): a LANE per stretch.  k_poly_replay gives a stretch a whole wave -- the list work of a step is
+// spread over the lanes, everything else is wave-uniform and lands on the CU's one scalar unit, which is what bounds it (19 waves
+// per CU x ~380 scalar instructions per sub-interval step).  On the inputs that matter most (depth saturated to 0 / 1: the active
+// list holds two to four segments) there is no list work to spread: here every lane replays ITS stretch with the reference's
+// literal sweep (:1951-1991, the statements of poly_sequential above) -- list of at most RPL_K segment ids per lane in LDS, points
+// and coord_d straight from the stretch's dump windows, colours from the image -- 64 stretches per wave, no scalar work per step.
+// A lane whose list outgrows RPL_K, or that would have to read outside its windows, gives up; a stretch that was finished is marked
+// "skip" (slot word of its descriptor) and k_poly_replay, launched behind this kernel, does what is left.
+// A stretch that starts at column 0 begins with the reference's bulk add of every point left of the first centre (77 at 4K and
+// divergence 8) and the swap-with-last removal pass over them: simulated on the VIRTUAL list (position i holds perm[i] until it is
+// written; the pass only ever writes position ci, and everything below ci is a survivor) -- no storage beyond the survivors.
+// ---------------------------------------------------------------------------------------------
+#ifndef RPL_K
+#define RPL_K 16
+#endif
+// Per step a lane's only dependent global loads are: the next sorted point (perm -> coord_d, issued at the top of the step), the
+// right end of a segment that is added (coord_d), and the winner's colours.  The list entries keep both ends' x and |disparity|
+// in LDS (18 B per entry and lane), so that removal, closeness scan and the winner's interpolation read no global memory; the sweep
+// keeps x of the points around its cursor in registers (the first sub-interval of a column spans the same two points as the
+// last one of the column before: the reference's `while x < col: pt_i++; pt_i--` never moves).
+template <int SHARP>
+__global__ void __launch_bounds__(64) k_poly_replay_lanes(RowArgs A) {
+    __shared__ float4 ent_all[RPL_K * 64];      // {x0, x1, z0, z1} of entry k of lane l at [64 k + l]
+    __shared__ uint16_t csg_all[RPL_K * 64];    // its segment id
+    const int lane = threadIdx.x;
+    const uint32_t count = min(A.rp_ctr[1], A.rp_cap);
+    if (count == 0) return;
+    const int w = A.w, h = A.h, npt = poly_npt(w, SHARP);
+    uint16_t* const csg = csg_all + lane;
+    float4* const ent = ent_all + lane;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&A.rp_ctr[3], 64u);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= count) break;
+        const uint32_t idx = base + (uint32_t)lane;
+        if (idx >= count) continue;
+        uint32_t* const q = A.rp_list + (size_t)idx * RP_DESC;
+        const uint32_t slot = q[0];
+        if (slot == 0xffffffffu) continue;
+        const int c0 = (int)(q[1] & 0xffffu), c1 = (int)(q[1] >> 16), seg0 = (int)q[2], sgp0 = (int)q[3];
+        const int pw0 = (int)(q[4] & 0xffffu), pw1 = (int)(q[4] >> 16), cmin = (int)(q[5] & 0xffffu), cmax = (int)(q[5] >> 16);
+        const uint32_t rowid = q[6] & 0x7fffffffu;
+        const int eye = (int)(q[6] >> 31), pt0 = (int)q[7];
+        const int frame = (int)(rowid / (uint32_t)h), row = (int)(rowid - (uint32_t)frame * (uint32_t)h);
+        const uint8_t* d = A.rp_dump + ((size_t)slot << 4);
+        const uint16_t* const gperm = (const uint16_t*)d - pw0;                                       // gperm[i], i in [pw0, pw1]
+        const float* const gcd = (const float*)(d + align16(2 * (size_t)(pw1 - pw0 + 1))) - cmin;     // gcd[c], c in [cmin, cmax]
+        const float sep32 = eye ? A.eye[1].sep32 : A.eye[0].sep32;
+        const int cap = min(eye ? A.eye[1].csg_cap : A.eye[0].csg_cap, poly_cap(w, SHARP));
+        const size_t rowpix = ((size_t)frame * h + row) * w;
+        bool lost = false;   // a read outside the windows / a list beyond RPL_K: the wave kernel's business
+        int err = 0;         // the reference's own list capacity exceeded (it would raise)
+        auto perm_at = [&](int i) -> int { if (i < pw0 || i > pw1) { lost = true; return 0; } return (int)gperm[i]; };
+        auto cd_at = [&](int c) -> float { if (c < cmin || c > cmax) { lost = true; return 0.0f; } return gcd[c]; };
+        auto pcol = [&](int o) -> int { return o <= 0 ? 0 : (o >= npt - 1 ? w - 1 : (SHARP ? (o - 1) >> 1 : o - 1)); };
+        // x and |coord_d| of point o (poly_x / poly_z)
+        auto pxz = [&](int o, float& x, float& z) {
+            if (o <= 0) { x = (float)(-1.0 * w); z = 0.0f; return; }
+            if (o >= npt - 1) { x = (float)(2.0 * w); z = 0.0f; return; }
+            const int c = SHARP ? (o - 1) >> 1 : o - 1;
+            const float cd = cd_at(c);
+            x = ((float)c + 0.5f + cd) + sep32;
+            if (SHARP) x = ((o - 1) & 1) ? x + (float)0.45 : x - (float)0.45;
+            z = fabsf(cd);
+        };
+        auto px = [&](int o) -> float { float x, z; pxz(o, x, z); return x; };
+        auto code = [&](int col, int c) -> float {   // the source row as uint8 codes (rowwarp_row's stage_image), as a float
+            if (A.image_f32) {
+                float x = A.image_f32[(rowpix + col) * 3 + c] * 255.0f;
+                x = fminf(fmaxf(x, 0.0f), 255.0f);
+                return (float)(uint8_t)(int)x;
+            }
+            return (float)A.image_u8[(rowpix + col) * 3 + c];
+        };
+        auto push = [&](int k, int o, float x0, float z0) {   // entry k = segment (o, o + 1)
+            float x1, z1;
+            pxz(o + 1, x1, z1);
+            csg[64 * k] = (uint16_t)o; ent[64 * k] = make_float4(x0, x1, z0, z1);
+        };
+        const ReplayOut out{A.out_u8, A.stereo, A.mask, h, A.out_h, A.out_w, eye ? A.eye[1].xoff : A.eye[0].xoff,
+                            eye ? A.eye[1].yoff : A.eye[0].yoff, A.stereo_is_u8, frame, row, w};
+        const int sg_end = npt - 1;
+        int csg_end = 0, sg_pointer = c0 > 0 ? sgp0 : 0;
+        if (c0 > 0) { float x0, z0; pxz(seg0, x0, z0); push(0, seg0, x0, z0); csg_end = 1; }
+        // the add cursor: point `os` at sorted position sg_pointer, its x and |coord_d|
+        int os = sg_pointer < sg_end ? perm_at(sg_pointer) : 0;
+        float xs = 0.0f, zs = 0.0f;
+        if (sg_pointer < sg_end) pxz(os, xs, zs);
+        // the sweep cursor: pt_i = the last point left of the column; xa / xb = x of the points at pt_i / pt_i + 1
+        int pt_i = pt0 - 1;
+        float xa = px(perm_at(pt_i)), xb = px(perm_at(pt_i + 1)), xp = xa;
+        for (int col = c0; col <= c1 && !lost && !err; col++) {
+            float color[3] = {0.5f, 0.5f, 0.5f};
+            while (!lost && !err && xa < (float)(col + 1)) {
+                // (the point after next: on its way while the list is worked on)
+                const int onext = perm_at(pt_i + 2 <= pw1 ? pt_i + 2 : pw1);
+                const float xnext = px(onext);
+                const SubInt s = poly_subinterval(col, xa, xb);
+                if (csg_end == 0 && sg_pointer == 0) {
+                    // the bulk add at column 0 and its removal pass, on the virtual list: N points lie left of the centre
+                    int N = 0;
+                    while (N < sg_end && !lost && px(perm_at(N)) < s.center) N++;
+                    if (N > cap) err = 1;
+                    int ci = 0, end = N;
+                    int cur = N > 0 ? perm_at(0) : 0;
+                    while (ci < end && !lost) {
+                        if (px(cur + 1) < s.center) { end--; cur = end > ci ? perm_at(end) : cur; }
+                        else {
+                            if (ci >= RPL_K) { lost = true; break; }
+                            float x0, z0; pxz(cur, x0, z0); push(ci, cur, x0, z0); ci++;
+                            cur = ci < end ? perm_at(ci) : cur;
+                        }
+                    }
+                    csg_end = end; sg_pointer = N;
+                    os = sg_pointer < sg_end ? perm_at(sg_pointer) : 0;
+                    if (sg_pointer < sg_end) pxz(os, xs, zs);
+                } else {
+                    while (sg_pointer < sg_end && !lost && xs < s.center) {
+                        if (csg_end >= cap) { err = 1; break; }
+                        if (csg_end >= RPL_K) { lost = true; break; }
+                        push(csg_end, os, xs, zs); csg_end++; sg_pointer++;
+                        if (sg_pointer < sg_end) { os = perm_at(sg_pointer); pxz(os, xs, zs); }
+                    }
+                    int ci = 0;
+                    while (ci < csg_end) {
+                        if (ent[64 * ci].y < s.center) { csg[64 * ci] = csg[64 * (csg_end - 1)]; ent[64 * ci] = ent[64 * (csg_end - 1)]; csg_end--; }
+                        else ci++;
+                    }
+                }
+                if (lost || err) break;
+                int best = 0;
+                if (csg_end != 1) {
+                    float bc = (float)(-1e-7);
+                    for (int ci = 0; ci < csg_end; ci++) {
+                        const float4 e = ent[64 * ci];
+                        const float ip_k = (s.center - e.x) / (e.y - e.x);
+                        const float cl = (1.0f - ip_k) * e.z + ip_k * e.w;
+                        if (bc < cl && 0.0f < ip_k && ip_k < 1.0f) { bc = cl; best = ci; }
+                    }
+                }
+                {   // poly_accumulate
+                    const int seg = csg[64 * best];
+                    const float4 e = ent[64 * best];
+                    const int col_l = pcol(seg), col_r = pcol(seg + 1);
+                    if (col_l == col_r) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            if (s.sig64) color[c] = (float)((double)color[c] + (double)code(col_l, c) * s.sig_d);
+                            else color[c] = color[c] + code(col_l, c) * s.sig_f;
+                        }
+                    } else {
+                        const float ip_k = (s.center - e.x) / (e.y - e.x);
+                        const float om = 1.0f - ip_k;
+                        const float sg = s.sig64 ? (float)s.sig_d : s.sig_f;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const float a = code(col_l, c) * om;
+                            const float b = code(col_r, c) * ip_k;
+                            color[c] = color[c] + (a + b) * sg;
+                        }
+                    }
+                }
+                pt_i++;
+                xp = xa; xa = xb; xb = xnext;
+                if (pt_i + 1 > pw1) lost = true;   // (xb would be a point outside the window)
+            }
+            if (!lost && !err) out(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
+            // the next column starts one point back: its first sub-interval spans the points of this column's last one
+            pt_i--;
+            xb = xa; xa = xp;
+        }
+        if (!lost && !err) q[0] = 0xffffffffu;   // done: k_poly_replay skips it (a stretch given up here is replayed from its start there)
+        if (A.dbg == 14 && A.stats_rw) atomicAdd(&A.stats_rw[(size_t)frame * ST_WORDS + ((lost || err) ? 15 : 12)], 1u);
+    }
+}
+
 // The dump pool.  A stretch's windows average ~2 KB and an order-dependent eye row holds 1.3 stretches: 4 KB per image row carry
 // a batch whose every row ties in places (saturated depth).  A row WITHOUT reset points (depth noise) is one stretch of the
 // whole row: 6 B per pixel and eye.  Batches small enough get that much outright (up to 1 GiB: eleven 4K frames -- the chunks of
@@ -2799,6 +3031,13 @@ hipError_t launch_poly_replay(int sharp, const RowArgs& A, int halo, hipStream_t
     const bool wide = 4 * (halo + 2) + 80 > RP_CWS;
     const dim3 grid(256 * (wide ? 5 : 19)), block(64);   // (resident waves per CU: 29 KB / 8.3 KB of LDS each)
     uint8_t* retry = poly_replay_retry_flags(A);
+    // first a lane per stretch (short lists: saturated depth), then a wave per stretch for what that kernel gave up
+    // (CS_DEBUG_PT_VARIANT 45: the wave kernel alone, as in round 4)
+    if (dev_switch(CS_DEBUG_PT_VARIANT) != 45) {
+        const dim3 lgrid(256 * 8);
+        if (sharp) hipLaunchKernelGGL((k_poly_replay_lanes<1>), lgrid, block, 0, stream, A);
+        else hipLaunchKernelGGL((k_poly_replay_lanes<0>), lgrid, block, 0, stream, A);
+    }
     if (sharp && wide) hipLaunchKernelGGL((k_poly_replay<1, RP_PWS, RP_CWS_WIDE>), grid, block, 0, stream, A, retry, halo + 2);
     else if (sharp) hipLaunchKernelGGL((k_poly_replay<1, RP_PWS, RP_CWS>), grid, block, 0, stream, A, retry, halo + 2);
     else if (wide) hipLaunchKernelGGL((k_poly_replay<0, RP_PWS, RP_CWS_WIDE>), grid, block, 0, stream, A, retry, halo + 2);

@@ -526,3 +526,39 @@ def test_4k_saturated_depth_stretch_replay_kernel_vs_oracle(engine, dev_switch):
     for g, r, w_, name in zip(got, inrow, want, NAMES):
         assert np.array_equal(g, r), ("replay kernel vs row kernel", name)
         assert np.array_equal(g, w_), ("vs oracle", name)
+
+
+@pytest.mark.parametrize("fill,ui", [("polylines_soft", "Fill - Polylines Soft"), ("polylines_sharp", "Fill - Polylines Sharp")])
+def test_lean_pass_on_the_flagged_tiles_column_ranges(engine, dev_switch, fill, ui):
+    """Round 5: k_polypoint records WHICH tiles of a row-eye raised the hazard (tile hints) and the lean first pass of the row kernel
+    stages, sorts, lists and evaluates only those tiles' columns plus a margin (technique_polylines, PolyRange) -- the rest of the row
+    keeps the tile kernel's pixels.  4K-wide rows, smooth depth with saturated patches (exact ties) at the left end, in the middle and
+    at the right end of the row, so that ranges touch either sentinel and rows have one, two or three flagged tiles; against the
+    oracle, and the same bits as the whole-row form of round 4 (cs_debug_set pt_variant 44)."""
+    n, h, w = 2, 40, 3840
+    img = synth.image_f32(n, h, w, seed=41)
+    ramp = np.linspace(0.2, 0.8, w, dtype=np.float32)[None, None, :] + 0.05 * np.sin(np.arange(h, dtype=np.float32))[None, :, None]
+    depth = np.repeat(ramp, n, axis=0)
+    clip = np.stack([synth.clipped(2160, w, seed=s)[700:700 + h] for s in (1, 2)])
+    depth[0, :, :420] = clip[0, :, :420]                 # frame 0: left end (every row) ...
+    depth[0, 10:, 1700:2300] = clip[0, 10:, 1700:2300]   # ... and the middle (rows 10 on: two or three flagged tiles)
+    depth[1, :, 3400:] = clip[1, :, 3400:]               # frame 1: right end
+    depth[1, ::3, 900:1100] = clip[1, ::3, 900:1100]
+    depth = np.ascontiguousarray(depth[..., None].repeat(3, -1))
+    for mode, div in (("left-right", 8.0), ("top-bottom", 5.0)):
+        want = node_oracle.generate(img, depth, div, 0.0, mode, 0.0, 0.5, 2.0, ui, 20.0, 20.0, False, batch_size=12)
+        p = engine.make_params(n, h, w, h, w, 3, fill, mode, div, 0.0, 0.0, 0.5, 2.0, False, 20.0, 20.0, 1.0, 0, 12)
+        plan = engine.Plan(p, torch.device("cuda"))
+        got = [t.cpu().numpy() for t in plan.run(cuda(img), cuda(depth))]
+        st = plan.stats()
+        assert int(st[:, 11].sum()) > 0 and int(st[:, 9].sum()) == 0   # rows went back to the row kernel; no kernel error flags
+        dev_switch("pt_variant", 44)
+        whole = [t.cpu().numpy() for t in engine.Plan(p, torch.device("cuda")).run(cuda(img), cuda(depth))]
+        # (... and the stretches replayed by a lane each, k_poly_replay_lanes, against a wave each alone: pt_variant 45)
+        dev_switch("pt_variant", 45)
+        waves = [t.cpu().numpy() for t in engine.Plan(p, torch.device("cuda")).run(cuda(img), cuda(depth))]
+        dev_switch("pt_variant", 0)
+        for g, r, v, w_, name in zip(got, whole, waves, want, NAMES):
+            assert np.array_equal(g, r), (mode, "column ranges vs whole rows", name)
+            assert np.array_equal(g, v), (mode, "lane replay vs wave replay", name)
+            assert np.array_equal(g, w_), (mode, "vs oracle", name)
