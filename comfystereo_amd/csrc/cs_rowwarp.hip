@@ -1011,6 +1011,9 @@ __device__ __forceinline__ void poly_seg_pixels(const Poly& P, int o, int& p0, i
 #define RP_PW 1024    // a typical stretch's windows in the dump (pool sizing only: the windows have no upper limit any more)
 #define RP_CW 1024
 #define RP_DESC 8   // words per stretch descriptor
+#ifndef RPL_K
+#define RPL_K 16   // list entries a lane of k_poly_replay_lanes holds (18 B each in LDS)
+#endif
 struct RpCtx {      // where a row exports its stretches to (dump == null: replay inside the row kernel)
     uint8_t* dump; uint32_t* list; uint32_t* ctr; uint32_t pool16, cap; uint32_t rowid; int eye;   // pool16: dump bytes / 16
     uint8_t* retry;   // LEAN: one byte per row, set when the row needs the full kernel (its inline replay)
@@ -1446,11 +1449,19 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { cmin = min(cmin, __shfl_xor(cmin, d)); cmax = max(cmax, __shfl_xor(cmax, d)); }
                 if (seg0 >= 0) { cmin = min(cmin, poly_col(P, seg0)); cmax = max(cmax, poly_col(P, seg0 + 1)); }
+                // (round 5) can a LANE replay this stretch (k_poly_replay_lanes: lists of at most RPL_K entries)?  The per-pixel segment
+                // lists bound the active list; without them (whole-row export, column ranges) the answer is no: bit 31 of word 3
+                int longest = whole_row || ranged ? 0x7fff : 0;
+                if (!whole_row && !ranged)
+                    for (int p = c0 + lane; p <= c1; p += 64) longest = max(longest, (int)P.segoff[p] - (p > 0 ? (int)P.segoff[p - 1] : 0));
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) longest = max(longest, __shfl_xor(longest, d));
                 if (lane == 0) {
                     const bool good = c0 == 0 || seg0 >= 0;   // (always: the pixel before was marked because one segment is active)
                     if (!good) *rp_ok = 0;
                     uint32_t* q = sinfo + RP_DESC * si;
-                    q[1] = slist[si]; q[2] = (uint32_t)seg0; q[3] = (uint32_t)sgp0; q[4] = (uint32_t)pw0 | ((uint32_t)pw1 << 16);
+                    q[1] = slist[si]; q[2] = (uint32_t)seg0; q[3] = (uint32_t)sgp0 | (longest > RPL_K - 3 ? 0x80000000u : 0u);
+                    q[4] = (uint32_t)pw0 | ((uint32_t)pw1 << 16);
                     q[5] = (uint32_t)cmin | ((uint32_t)cmax << 16); q[6] = X->rowid | ((uint32_t)X->eye << 31); q[7] = (uint32_t)P.binoff[c0];
                 }
             }
@@ -2777,7 +2788,7 @@ __global__ void __launch_bounds__(64, CWS > 2048 ? 1 : RP_MINW) k_poly_replay(Ro
         const uint32_t* q = A.rp_list + (size_t)idx * RP_DESC;
         const uint32_t slot = q[0];
         if (slot == 0xffffffffu) continue;
-        const int c0 = (int)(q[1] & 0xffffu), c1 = (int)(q[1] >> 16), seg0 = (int)q[2], sgp0 = (int)q[3];
+        const int c0 = (int)(q[1] & 0xffffu), c1 = (int)(q[1] >> 16), seg0 = (int)q[2], sgp0 = (int)(q[3] & 0x7fffffffu);   // (bit 31: not for the lane kernel)
         const int pw0 = (int)(q[4] & 0xffffu), pw1 = (int)(q[4] >> 16), cmin = (int)(q[5] & 0xffffu), cmax = (int)(q[5] >> 16);
         const uint32_t rowid = q[6] & 0x7fffffffu;
         const int eye = (int)(q[6] >> 31), pt0 = (int)q[7];
@@ -2827,9 +2838,6 @@ __global__ void __launch_bounds__(64, CWS > 2048 ? 1 : RP_MINW) k_poly_replay(Ro
 // divergence 8) and the swap-with-last removal pass over them: simulated on the VIRTUAL list (position i holds perm[i] until it is
 // written; the pass only ever writes position ci, and everything below ci is a survivor) -- no storage beyond the survivors.
 // ---------------------------------------------------------------------------------------------
-#ifndef RPL_K
-#define RPL_K 16
-#endif
 // Per step a lane's only dependent global loads are: the next sorted point (perm -> coord_d, issued at the top of the step), the
 // right end of a segment that is added (coord_d), and the winner's colours.  The list entries keep both ends' x and |disparity|
 // in LDS (18 B per entry and lane), so that removal, closeness scan and the winner's interpolation read no global memory; the sweep
@@ -2854,7 +2862,7 @@ __global__ void __launch_bounds__(64) k_poly_replay_lanes(RowArgs A) {
         if (idx >= count) continue;
         uint32_t* const q = A.rp_list + (size_t)idx * RP_DESC;
         const uint32_t slot = q[0];
-        if (slot == 0xffffffffu) continue;
+        if (slot == 0xffffffffu || (q[3] >> 31)) continue;   // (skipped / lists too long for a lane: the wave kernel's)
         const int c0 = (int)(q[1] & 0xffffu), c1 = (int)(q[1] >> 16), seg0 = (int)q[2], sgp0 = (int)q[3];
         const int pw0 = (int)(q[4] & 0xffffu), pw1 = (int)(q[4] >> 16), cmin = (int)(q[5] & 0xffffu), cmax = (int)(q[5] >> 16);
         const uint32_t rowid = q[6] & 0x7fffffffu;
