@@ -398,7 +398,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
     // CS_DEBUG_PT_VARIANT asks for the first generation (cs_polytile.hip)
     const int variant = dev_switch(CS_DEBUG_PT_VARIANT);   // 0 / 3 .. 7: point-owner kernel; 41 - 43: tie-path what-ifs; other values: first generation
     auto polypoint_takes = [&](int hl) {
-        return hl <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16) || (variant >= 41 && variant <= 45));
+        return hl <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16) || (variant >= 41 && variant <= 46));
     };
     // (the tile kernels are dialect D32, plus -- round 5 -- the float64 disparity chain alone: k_polypoint<..., DIA>)
     const bool tile_dialect = A.d64 == 0 || (A.d64 == 1 && polypoint_takes(halo));

@@ -1014,6 +1014,9 @@ __device__ __forceinline__ void poly_seg_pixels(const Poly& P, int o, int& p0, i
 #ifndef RPL_K
 #define RPL_K 16   // list entries a lane of k_poly_replay_lanes holds (18 B each in LDS)
 #endif
+#ifndef RPL_KL
+#define RPL_KL 64  // ... of its second instantiation (lists of dozens: noise depth; 74 KB of LDS per wave, two waves per CU)
+#endif
 struct RpCtx {      // where a row exports its stretches to (dump == null: replay inside the row kernel)
     uint8_t* dump; uint32_t* list; uint32_t* ctr; uint32_t pool16, cap; uint32_t rowid; int eye;   // pool16: dump bytes / 16
     uint8_t* retry;   // LEAN: one byte per row, set when the row needs the full kernel (its inline replay)
@@ -1460,7 +1463,9 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                     const bool good = c0 == 0 || seg0 >= 0;   // (always: the pixel before was marked because one segment is active)
                     if (!good) *rp_ok = 0;
                     uint32_t* q = sinfo + RP_DESC * si;
-                    q[1] = slist[si]; q[2] = (uint32_t)seg0; q[3] = (uint32_t)sgp0 | (longest > RPL_K - 3 ? 0x80000000u : 0u);
+                    // (bit 31: not for the 16-entry lane kernel; bit 30 with it: for the 64-entry one -- lists of up to ~56, or unknown)
+                    q[1] = slist[si]; q[2] = (uint32_t)seg0;
+                    q[3] = (uint32_t)sgp0 | (longest > RPL_K - 3 ? 0x80000000u : 0u) | ((longest > RPL_K - 3 && (longest <= RPL_KL - 8 || longest == 0x7fff)) ? 0x40000000u : 0u);
                     q[4] = (uint32_t)pw0 | ((uint32_t)pw1 << 16);
                     q[5] = (uint32_t)cmin | ((uint32_t)cmax << 16); q[6] = X->rowid | ((uint32_t)X->eye << 31); q[7] = (uint32_t)P.binoff[c0];
                 }
@@ -2788,7 +2793,7 @@ __global__ void __launch_bounds__(64, CWS > 2048 ? 1 : RP_MINW) k_poly_replay(Ro
         const uint32_t* q = A.rp_list + (size_t)idx * RP_DESC;
         const uint32_t slot = q[0];
         if (slot == 0xffffffffu) continue;
-        const int c0 = (int)(q[1] & 0xffffu), c1 = (int)(q[1] >> 16), seg0 = (int)q[2], sgp0 = (int)(q[3] & 0x7fffffffu);   // (bit 31: not for the lane kernel)
+        const int c0 = (int)(q[1] & 0xffffu), c1 = (int)(q[1] >> 16), seg0 = (int)q[2], sgp0 = (int)(q[3] & 0x3fffffffu);   // (bits 30 / 31: which lane kernel may try it)
         const int pw0 = (int)(q[4] & 0xffffu), pw1 = (int)(q[4] >> 16), cmin = (int)(q[5] & 0xffffu), cmax = (int)(q[5] >> 16);
         const uint32_t rowid = q[6] & 0x7fffffffu;
         const int eye = (int)(q[6] >> 31), pt0 = (int)q[7];
@@ -2843,10 +2848,12 @@ __global__ void __launch_bounds__(64, CWS > 2048 ? 1 : RP_MINW) k_poly_replay(Ro
 // in LDS (18 B per entry and lane), so that removal, closeness scan and the winner's interpolation read no global memory; the sweep
 // keeps x of the points around its cursor in registers (the first sub-interval of a column spans the same two points as the
 // last one of the column before: the reference's `while x < col: pt_i++; pt_i--` never moves).
-template <int SHARP>
+template <int SHARP, int K>
 __global__ void __launch_bounds__(64) k_poly_replay_lanes(RowArgs A) {
-    __shared__ float4 ent_all[RPL_K * 64];      // {x0, x1, z0, z1} of entry k of lane l at [64 k + l]
-    __shared__ uint16_t csg_all[RPL_K * 64];    // its segment id
+    extern __shared__ __attribute__((aligned(16))) char lane_smem[];
+    float4* const ent_all = reinterpret_cast<float4*>(lane_smem);                 // {x0, x1, z0, z1} of entry k of lane l at [64 k + l]
+    uint16_t* const csg_all = reinterpret_cast<uint16_t*>(lane_smem + (size_t)K * 64 * 16);   // its segment id
+    constexpr bool LONG = K > RPL_K;   // the second instantiation: the stretches flagged for it (bits 31 + 30 of word 3), its own cursor
     const int lane = threadIdx.x;
     const uint32_t count = min(A.rp_ctr[1], A.rp_cap);
     if (count == 0) return;
@@ -2855,15 +2862,15 @@ __global__ void __launch_bounds__(64) k_poly_replay_lanes(RowArgs A) {
     float4* const ent = ent_all + lane;
     for (;;) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&A.rp_ctr[3], 64u);
+        if (lane == 0) base = atomicAdd(&A.rp_ctr[LONG ? 0 : 3], 64u);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= count) break;
         const uint32_t idx = base + (uint32_t)lane;
         if (idx >= count) continue;
         uint32_t* const q = A.rp_list + (size_t)idx * RP_DESC;
         const uint32_t slot = q[0];
-        if (slot == 0xffffffffu || (q[3] >> 31)) continue;   // (skipped / lists too long for a lane: the wave kernel's)
-        const int c0 = (int)(q[1] & 0xffffu), c1 = (int)(q[1] >> 16), seg0 = (int)q[2], sgp0 = (int)q[3];
+        if (slot == 0xffffffffu || (LONG ? (q[3] >> 30) != 3u : (q[3] >> 31) != 0u)) continue;   // (done / another kernel's)
+        const int c0 = (int)(q[1] & 0xffffu), c1 = (int)(q[1] >> 16), seg0 = (int)q[2], sgp0 = (int)(q[3] & 0x3fffffffu);
         const int pw0 = (int)(q[4] & 0xffffu), pw1 = (int)(q[4] >> 16), cmin = (int)(q[5] & 0xffffu), cmax = (int)(q[5] >> 16);
         const uint32_t rowid = q[6] & 0x7fffffffu;
         const int eye = (int)(q[6] >> 31), pt0 = (int)q[7];
@@ -2932,7 +2939,7 @@ __global__ void __launch_bounds__(64) k_poly_replay_lanes(RowArgs A) {
                     while (ci < end && !lost) {
                         if (px(cur + 1) < s.center) { end--; cur = end > ci ? perm_at(end) : cur; }
                         else {
-                            if (ci >= RPL_K) { lost = true; break; }
+                            if (ci >= K) { lost = true; break; }
                             float x0, z0; pxz(cur, x0, z0); push(ci, cur, x0, z0); ci++;
                             cur = ci < end ? perm_at(ci) : cur;
                         }
@@ -2943,7 +2950,7 @@ __global__ void __launch_bounds__(64) k_poly_replay_lanes(RowArgs A) {
                 } else {
                     while (sg_pointer < sg_end && !lost && xs < s.center) {
                         if (csg_end >= cap) { err = 1; break; }
-                        if (csg_end >= RPL_K) { lost = true; break; }
+                        if (csg_end >= K) { lost = true; break; }
                         push(csg_end, os, xs, zs); csg_end++; sg_pointer++;
                         if (sg_pointer < sg_end) { os = perm_at(sg_pointer); pxz(os, xs, zs); }
                     }
@@ -3043,8 +3050,21 @@ hipError_t launch_poly_replay(int sharp, const RowArgs& A, int halo, hipStream_t
     // (CS_DEBUG_PT_VARIANT 45: the wave kernel alone, as in round 4)
     if (dev_switch(CS_DEBUG_PT_VARIANT) != 45) {
         const dim3 lgrid(256 * 8);
-        if (sharp) hipLaunchKernelGGL((k_poly_replay_lanes<1>), lgrid, block, 0, stream, A);
-        else hipLaunchKernelGGL((k_poly_replay_lanes<0>), lgrid, block, 0, stream, A);
+        const size_t lds16 = (size_t)RPL_K * 64 * 18, lds64 = (size_t)RPL_KL * 64 * 18;
+        if (sharp) hipLaunchKernelGGL((k_poly_replay_lanes<1, RPL_K>), lgrid, block, lds16, stream, A);
+        else hipLaunchKernelGGL((k_poly_replay_lanes<0, RPL_K>), lgrid, block, lds16, stream, A);
+        // ... then, ONLY under CS_DEBUG_PT_VARIANT 46, the stretches with lists of dozens (noise depth) by the 64-entry instantiation, two
+        // waves per CU.  Measured (tools/sessions/r05_s26.sh): it finishes them all, bit-exact, and is 2.4 x SLOWER than the wave kernel
+        // (8 noise frames: 263 against 110 ms) -- one wave per SIMD walks two 40-entry loops of dependent LDS reads per step, 23 us
+        // a step.  The scalar-bound wave kernel stays the path for long lists.
+        if (dev_switch(CS_DEBUG_PT_VARIANT) == 46) {
+            hipError_t e = sharp ? hipFuncSetAttribute((const void*)k_poly_replay_lanes<1, RPL_KL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64)
+                                 : hipFuncSetAttribute((const void*)k_poly_replay_lanes<0, RPL_KL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
+            if (e != hipSuccess) return e;
+            const dim3 g64(256 * 2);
+            if (sharp) hipLaunchKernelGGL((k_poly_replay_lanes<1, RPL_KL>), g64, block, lds64, stream, A);
+            else hipLaunchKernelGGL((k_poly_replay_lanes<0, RPL_KL>), g64, block, lds64, stream, A);
+        }
     }
     if (sharp && wide) hipLaunchKernelGGL((k_poly_replay<1, RP_PWS, RP_CWS_WIDE>), grid, block, 0, stream, A, retry, halo + 2);
     else if (sharp) hipLaunchKernelGGL((k_poly_replay<1, RP_PWS, RP_CWS>), grid, block, 0, stream, A, retry, halo + 2);
