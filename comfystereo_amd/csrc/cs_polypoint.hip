@@ -38,7 +38,9 @@ namespace cs {
 #ifdef CS_DEV
 #define PP_DEV_IS(n) (A.dbg == (n))
 // (development) why a row was handed to the general kernel: reason bits OR-ed into the frame's spare stats word 12
-#define PP_HAZARD(code) do { hazard = true; if (A.stats_rw) atomicOr(&A.stats_rw[(size_t)frame * ST_WORDS + 12], (unsigned)(code)); } while (0)
+// (CS_DEBUG_DBG 15: lane events per reason as well -- word 13: list / point capacities (1, 4, 256), 14: ties (128), 15: everything else)
+#define PP_HAZARD(code) do { hazard = true; if (A.stats_rw) { atomicOr(&A.stats_rw[(size_t)frame * ST_WORDS + 12], (unsigned)(code)); \
+    if (A.dbg == 15) atomicAdd(&A.stats_rw[(size_t)frame * ST_WORDS + (((code) & (1 | 4 | 256)) ? 13 : ((code) == 128 ? 14 : 15))], 1u); } } while (0)
 #else
 #define PP_DEV_IS(n) false
 #define PP_HAZARD(code) do { hazard = true; } while (0)
