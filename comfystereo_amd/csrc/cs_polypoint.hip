@@ -46,7 +46,12 @@ namespace cs {
 #define PP_HAZARD(code) do { hazard = true; } while (0)
 #endif
 #ifndef PP_DCAP
-#define PP_DCAP 128          // pixels under reversed segments a tile can hold in its lists (more -> row redo)
+// (round 5: 128 -> 160, with 16-bit flags per tile pixel.  On depth saturated to 0 / 1 -- wide overlaps of a near and a far plateau -- the 128
+// slots of the one-byte flags were what sent 47 % of the rows to the row kernel with the blur ON, where not one of them holds a tie
+// (tools/sessions/r05_s28.sh): 64 x 4K saturated frames with the blur 2 770 -> 5 040 frames/s, polylines_sharp 1 060 -> 3 100.  160 is what fits:
+// 21 584 B of LDS per workgroup at the bench geometry; from 176 slots on (21 936 B) the seventh workgroup per CU no longer fits and
+// the kernel takes 9.88 instead of 9.65 ms per 64 frames on the headline workload (tools/sessions/r05_s29.sh ... r05_s32.sh))
+#define PP_DCAP 160          // pixels under reversed segments a tile can hold in its lists (more -> row redo)
 #endif
 #ifndef PP_MINW
 #define PP_MINW 7            // workgroups per CU the default geometry is compiled for (register budget)
@@ -58,7 +63,7 @@ namespace cs {
 #ifndef PP_SHARP_MINW
 #define PP_SHARP_MINW 6
 #endif
-#define PP_DIRTY 0x80u       // dflag: pixel lies under a reversed segment; low 7 bits = its list slot
+#define PP_DIRTY 0x8000u     // dflag (16 bits per tile pixel since round 5): pixel lies under a reversed segment; low 15 bits = its list slot
 
 __constant__ csm::PowfTables c_pp_powf_tables = CS_POWF_TABLES_INIT;
 // k / 255 by true division (convertResult / np2tensor, reference GenerateStereo.py:41-44): evaluated by the compiler in IEEE
@@ -235,8 +240,8 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     csm::PowfTables* const tabs_lds = (csm::PowfTables*)plist;
     const bool all_powf = hot_pow_mode == 0;   // (host: dbg == 17 or an exponent other than 1 and 2)
     static_assert(sizeof(csm::PowfTables) == 512, "tables overlay");
-    // (the two offsets that depend on T come precomputed in preloaded kernel arguments: plist + max(T, 128) and + (T + 3 & ~3))
-    uint8_t* dflag = (uint8_t*)(smem + hot_off_dflag);                            // [T] PP_DIRTY | slot
+    // (the two offsets that depend on T come precomputed in preloaded kernel arguments: plist + max(T, 128) and + (2 T + 3 & ~3))
+    uint16_t* dflag = (uint16_t*)(smem + hot_off_dflag);                          // [T] PP_DIRTY | slot
     uint16_t* dcnt = (uint16_t*)(smem + hot_off_dcnt);                            // [DCAP] points (low 8) | segments (high 8)
     uint16_t* dpix = dcnt + PP_DCAP;                                              // [DCAP] pixel of the slot
     uint16_t* pts = dpix + PP_DCAP;                                               // [DCAP][PT_KP]
@@ -293,7 +298,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // LDS set-up in the shadow of the loads
     if (all_powf && tid < (int)(sizeof(csm::PowfTables) / 4))
         reinterpret_cast<uint32_t*>(tabs_lds)[tid] = reinterpret_cast<const uint32_t*>(&c_pp_powf_tables)[tid];
-    if (tid < (T + 3) / 4) reinterpret_cast<uint32_t*>(dflag)[tid] = 0;   // T <= 4 NT (checked on the host)
+    for (int i = tid; i < (T + 1) / 2; i += NT) reinterpret_cast<uint32_t*>(dflag)[i] = 0;   // (two 16-bit flags per word)
     if (tid < PP_DCAP / 2) reinterpret_cast<uint32_t*>(dcnt)[tid] = 0;
     if (OUT == PO_F32) {
         for (int i = tid; i < 256; i += NT) lut[i] = code_over_255((float)i);
@@ -331,7 +336,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
                       lbase = __builtin_amdgcn_readlane(base, src);
             for (int i = lane; i < ln; i += 64) {
                 const int s = lbase + i;
-                if (s < PP_DCAP) { dflag[llo + i] = (uint8_t)(PP_DIRTY | s); dpix[s] = (uint16_t)(llo + i); }
+                if (s < PP_DCAP) { dflag[llo + i] = (uint16_t)(PP_DIRTY | s); dpix[s] = (uint16_t)(llo + i); }
                 else PP_HAZARD(2);
             }
         }
@@ -673,7 +678,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // pixels under reversed segments they lie in / pass over.  Called by whole waves.
     auto fold_register = [&](bool pt_in_tile, int qp, int op, bool has_seg, int os, float fl0, float fl1, float den) {
         if (pt_in_tile && (dflag[qp] & PP_DIRTY)) {
-            const int sl = dflag[qp] & 0x7f;
+            const int sl = dflag[qp] & 0x7fff;
             const unsigned idx = atomic_add_u16(dcnt, sl, 1u) & 0xffu;
             if (idx < PT_KP) pts[sl * PT_KP + idx] = (uint16_t)op;
             else PP_HAZARD(8);
@@ -687,7 +692,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         auto reg_seg = [&](int p, int oo) {
             const unsigned fl = dflag[p];
             if (fl & PP_DIRTY) {
-                const int sl = fl & 0x7f;
+                const int sl = fl & 0x7fff;
                 const unsigned idx = (atomic_add_u16(dcnt, sl, 0x100u) >> 8) & 0xffu;
                 if (idx < PT_KS) sgs[sl * PT_KS + idx] = (uint16_t)oo;
                 else PP_HAZARD(16);
@@ -850,7 +855,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
                 for (int p = max(0, dlo); p <= e2; p++) {
                     const unsigned fl = dflag[p];
                     if (fl & PP_DIRTY) {
-                        const int s = fl & 0x7f;
+                        const int s = fl & 0x7fff;
                         const unsigned idx = (atomic_add_u16(dcnt, s, 0x100u) >> 8) & 0xffu;
                         if (idx < PT_KS) sgs[s * PT_KS + idx] = (uint16_t)0;
                         else PP_HAZARD(16);
@@ -992,7 +997,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         const int s = base + lane;
         bool pend = s < ndirty;
         const int q = dpix[pend ? s : 0];
-        pend = pend && dflag[q] == (uint8_t)(PP_DIRTY | s);   // (a slot that lost its pixel to an overlapping reversed segment)
+        pend = pend && dflag[q] == (uint16_t)(PP_DIRTY | s);   // (a slot that lost its pixel to an overlapping reversed segment)
         const int col = o0 + q;
         const unsigned c = pend ? dcnt[s] : 0u;
         if ((c & 0xffu) > PT_KP || (c >> 8) > PT_KS) PP_HAZARD(256);
@@ -1198,7 +1203,7 @@ static int polypoint_npt(int nt, int slots, int T, int S) {
 }
 static size_t polypoint_lds(int nt, int slots, int T, int S, int KP, int KS) {
     const size_t npt = (size_t)polypoint_npt(nt, slots, T, S);
-    return 8 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((T + 3) & ~3) + 2 * PP_DCAP * (2 + (size_t)KP + KS) +
+    return 8 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((2 * T + 3) & ~3) + 2 * PP_DCAP * (2 + (size_t)KP + KS) +
            4 * PF_WORDS + 1024 + 64;
 }
 
@@ -1229,7 +1234,7 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
     size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS);
     // (development: CS_DEBUG_PT_VARIANT 13..16 pads the LDS request so that only 3..6 workgroups fit a CU -- occupancy what-if)
     const int npt = polypoint_npt(NT, SLOTS, A.T, A.S);
-    const int off_dflag = 8 * npt + 4 * npt + 4 * (A.T > 128 ? A.T : 128), off_dcnt = off_dflag + ((A.T + 3) & ~3);
+    const int off_dflag = 8 * npt + 4 * npt + 4 * (A.T > 128 ? A.T : 128), off_dcnt = off_dflag + ((2 * A.T + 3) & ~3);
     // sharp under the dialect: both points of every record, behind everything else
     const int off_xq = (SHARP && DIA) ? (int)((lds + 15) & ~(size_t)15) : 0;
     if (SHARP && DIA) lds = (size_t)off_xq + 8 * (size_t)npt + 64;
