@@ -2,7 +2,7 @@
 # round-5 session 28: why does k_polypoint flag rows of saturated depth WITH the blur on (no stretch comes of them)?  hazard reason bits
 # (dev build: PP_HAZARD codes OR-ed into stats word 12) and the tile-hint distribution, blur on / off
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r05_s28; mkdir -p $O
+O=gpurun_out/r05_s28b; mkdir -p $O
 CS_LIB_PATH=$PWD/comfystereo_amd/libcomfystereo_hip_dev.so timeout 600 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee $O/hazard_reasons.txt
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tools")
