@@ -48,6 +48,9 @@ struct FwdTileArgs {
     int dbg;
     const uint32_t* tilemap; const float* gray; int tm_words;   // lazy depth-blur tiles (cs_common.h) or null
     int d64; double e64;  // dialect bits (RowArgs::d64: 1 = float64 disparity chain, 2 = int64 pixel sums) and the exponent as a double
+    // second tier (round 5): only the rows of this list (frame * h + row, *row_count of them), persistent workgroups -- the rows a first
+    // launch flagged, with a wider window.  Null: every row, blockIdx = (tile x 8 rows, rows / 8, frame)
+    const uint32_t* row_list; const uint32_t* row_count;
 };
 
 // `sign * (abs(d) ** e) * div` of dialect D64 (numba typing; cs_rowwarp.hip disparity64): float64 throughout.
@@ -69,10 +72,24 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     // grid = (tiles x 8 rows, rows / 8, frames): all tiles of a row on one XCD (see cs_polypoint.hip)
-    const int xi = blockIdx.x;
-    const int row = blockIdx.y * 8 + (xi & 7);
-    if (row >= A.h) return;
-    const int tile = xi >> 3, frame = blockIdx.z;
+    // listed form (second tier): grid = (tiles, G): workgroup (t, g) does tile t of list entries g, g + G, ...
+    const bool listed = A.row_list != nullptr;
+    const uint32_t lcount = listed ? A.row_count[0] : 0u;
+    for (uint32_t it = 0;; it++) {
+    int row, tile, frame;
+    if (listed) {
+        const uint32_t li = blockIdx.y + it * gridDim.y;
+        if (li >= lcount) break;
+        const uint32_t e = A.row_list[li] & 0x3fffffffu;
+        frame = (int)(e / (uint32_t)A.h); row = (int)(e - (uint32_t)frame * (uint32_t)A.h); tile = blockIdx.x;
+        if (it) __syncthreads();   // (the previous row's LDS)
+    } else {
+        if (it) break;
+        const int xi = blockIdx.x;
+        row = blockIdx.y * 8 + (xi & 7);
+        if (row >= A.h) break;
+        tile = xi >> 3; frame = blockIdx.z;
+    }
     const int w = A.w, h = A.h, T = A.T;
     const int o0 = tile * T, wt = min(T, w - o0);
     const int c0 = max(0, o0 - A.R), c1 = min(w, o0 + wt + A.R), nwin = c1 - c0;   // columns of the forward map (the tile + R)
@@ -449,6 +466,7 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
             *reinterpret_cast<FwF3*>(A.depth_r + p) = FwF3{v1, v1, v1};
         }
     }
+    }   // (rows of the list)
 }
 
 // Largest halo the tile kernel takes (beyond it: the row kernel)
@@ -456,13 +474,18 @@ int fwdtile_max_halo() { return (256 * 3 - 64) / 2; }
 
 // `none` / `naive` / `inverse` through the tile kernel (`naive`: rows it flags in `rowflag` must be redone by the row kernel).  Returns hipErrorNotSupported when the call is not one of its cases (the caller then
 // launches the row kernel).
-hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, uint8_t* rowflag, hipStream_t stream) {
+hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, uint8_t* rowflag, hipStream_t stream, const uint32_t* tier2_list,
+                          const uint32_t* tier2_count) {
+    // tier2_list (round 5, naive_interpolating): the rows a first launch flagged, once more with a window of 2 halo + 16 on either side (every
+    // hole fits: holes are at most 2 halo wide) -- persistent workgroups over the list; what it flags in `rowflag` goes to the row kernel
+    const bool tier2 = tier2_list != nullptr;
+    if (tier2 && fill != CS_FILL_NAIVE_INTERPOLATING) return hipErrorNotSupported;
     // source slots per lane: 3 for the pure streaming fills (none / inverse: HBM-bound, wider tiles only cost occupancy: -2..4 %),
     // 4 for naive / naive_interpolating, whose tiles carry a search window on top of the halo (+13 % / +10 %)
     constexpr int NT = 256;
     const int SLOTS = (fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING) ? 4 : 3;
     if (fill != CS_FILL_NONE && fill != CS_FILL_INVERSE && fill != CS_FILL_NAIVE && fill != CS_FILL_NAIVE_INTERPOLATING) return hipErrorNotSupported;
-    if (!R.image_f32 || R.out_u8 || R.neyes != 2 || !R.depth_l || !R.depth_r || R.row_list) return hipErrorNotSupported;
+    if (!R.image_f32 || R.out_u8 || R.neyes != 2 || !R.depth_l || !R.depth_r || (R.row_list && !tier2)) return hipErrorNotSupported;
     const int S = S0 + (fill == CS_FILL_INVERSE ? 2 : 0);   // (the splat also touches the column right of floor(dest))
     if (S > fwdtile_max_halo()) return hipErrorNotSupported;
     if ((size_t)R.n * R.h * R.w >= (1ull << 31) || (size_t)R.n * R.out_h * R.out_w >= (1ull << 31) || R.n > 65535) return hipErrorNotSupported;
@@ -481,7 +504,7 @@ hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, uint8_t* rowflag, 
     // pixels) goes to the row kernel
     if (fill == CS_FILL_NAIVE_INTERPOLATING) {
         if (!rowflag) return hipErrorNotSupported;
-        A.R = S + 8;
+        A.R = tier2 ? 2 * S + 16 : S + 8;
     }
     int tmax = (NT * SLOTS - 2 * S - 2 * A.R) & ~3;
     if (tmax < 128) return hipErrorNotSupported;
@@ -497,10 +520,12 @@ hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, uint8_t* rowflag, 
     A.dbg = R.dbg;
     A.tilemap = R.tilemap; A.gray = R.lazy_gray; A.tm_words = R.tm_words;
     A.d64 = R.d64; A.e64 = R.e64;
+    A.row_list = tier2_list; A.row_count = tier2_count;
     const int ntiles = (R.w + A.T - 1) / A.T;
     const size_t npt = (size_t)NT * SLOTS;
     const size_t lds = npt * 4 + npt * 8 + (npt / 64) * 8 + (fill == CS_FILL_NAIVE_INTERPOLATING ? npt * (4 + 4 + 2 + 1) : 0) + 64;
-    const dim3 grid(ntiles * 8, (R.h + 7) / 8, R.n), block(NT);
+    const dim3 grid = tier2 ? dim3(ntiles, (unsigned)((1536 + ntiles - 1) / ntiles)) : dim3(ntiles * 8, (R.h + 7) / 8, R.n);
+    const dim3 block(NT);
     if (R.d64) {   // dialect D64 (either bit): the same kernels with the float64 offset chain / unwrapped pixel sums compiled in
         if (fill == CS_FILL_INVERSE) hipLaunchKernelGGL((k_fwdtile<NT, 3, CS_FILL_INVERSE, true>), grid, block, lds, stream, A);
         else if (fill == CS_FILL_NAIVE) hipLaunchKernelGGL((k_fwdtile<NT, 4, CS_FILL_NAIVE, true>), grid, block, lds, stream, A);

@@ -97,7 +97,8 @@ int polytile_max_halo();
 
 // cs_fwdtile.hip: fills 'none' / 'naive' / 'inverse' as a halo-tile kernel (node path); hipErrorNotSupported: not one of its
 // cases.  'naive' flags the rows it cannot finish in `rowflag` (zeroed by the caller) for the row kernel.
-hipError_t launch_fwdtile(int fill, const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream);
+hipError_t launch_fwdtile(int fill, const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream, const uint32_t* tier2_list = nullptr,
+                          const uint32_t* tier2_count = nullptr);
 int fwdtile_max_halo();
 
 // cs_polypoint.hip: second generation of the tiled path (polylines_soft): one lane per polyline point

@@ -562,3 +562,34 @@ def test_lean_pass_on_the_flagged_tiles_column_ranges(engine, dev_switch, fill, 
             assert np.array_equal(g, r), (mode, "column ranges vs whole rows", name)
             assert np.array_equal(g, v), (mode, "lane replay vs wave replay", name)
             assert np.array_equal(g, w_), (mode, "vs oracle", name)
+
+
+def test_naive_interpolating_second_tier_on_saturated_depth(engine, dev_switch):
+    """Round 5: rows whose holes outgrow k_fwdtile's window (halo + 8 on either side: the holes between a near and a far plateau of depth
+    saturated to 0 / 1 are up to twice the halo wide) no longer go to the whole-row kernel but through the tile kernel once more with a
+    window of 2 halo + 16 (persistent workgroups over the flagged-row list); what that flags -- intervals lengthened by black pixels --
+    still does.  4K-wide rows of saturated depth with black patches, SBS and anaglyph, blur off and on: the oracle's bits, and the same
+    bits without the second tier (cs_debug_set pt_variant 47)."""
+    n, h, w = 2, 48, 3840
+    img = synth.image_f32(n, h, w, seed=51)
+    img[:, 5:9, 1000:1400] = 0.0                      # black pixels lengthen intervals: beyond any window
+    depth = np.stack([synth.clipped(2160, w, seed=s)[600:600 + h] for s in (4, 5)])[..., None].repeat(3, -1)
+    depth = np.ascontiguousarray(depth)
+    for mode, blur in (("left-right", False), ("red-cyan-anaglyph", False), ("left-right", True)):
+        want = node_oracle.generate(img, depth, 8.0, 0.0, mode, 0.0, 0.5, 2.0, "Fill - Naive interpolating", 20.0, 20.0, blur,
+                                    depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+        p = engine.make_params(n, h, w, h, w, 3, "naive_interpolating", mode, 8.0, 0.0, 0.0, 0.5, 2.0, blur, 20.0, 20.0, 2.0, 6, 12)
+        got = [t.cpu().numpy() for t in engine.Plan(p, torch.device("cuda")).run(cuda(img), cuda(depth))]
+        dev_switch("pt_variant", 47)
+        plan1 = engine.Plan(p, torch.device("cuda"))
+        one = [t.cpu().numpy() for t in plan1.run(cuda(img), cuda(depth))]
+        rows_one_tier = int(plan1.stats()[:, 11].sum())
+        dev_switch("pt_variant", 0)
+        plan2 = engine.Plan(p, torch.device("cuda"))
+        plan2.run(cuda(img), cuda(depth))
+        rows_two_tiers = int(plan2.stats()[:, 11].sum())
+        if not blur:
+            assert rows_two_tiers < rows_one_tier, (mode, rows_two_tiers, rows_one_tier)   # the second tier takes rows off the row kernel
+        for g, r, w_, name in zip(got, one, want, NAMES):
+            assert np.array_equal(g, r), (mode, blur, "two tiers vs one", name)
+            assert np.array_equal(g, w_), (mode, blur, "vs oracle", name)
