@@ -307,6 +307,11 @@ def main():
         print(f"[verify] rank {rank}: {'OK' if ok else 'MISMATCH'}", flush=True)
         if not ok:
             raise SystemExit(1)
+    if world > 1:
+        # (every rank's own prints are out before rank 0 writes the JSON line: the line is longer than a pipe's atomic write, and a
+        # [verify] line of another rank landing inside it cost tests/test_gpu_sharded.py one run in ten sessions)
+        sys.stdout.flush()
+        dist.barrier()
     if rank == 0:
         fps = frames * a.steps / dt
         kern_ms = tot_ms.value / max(launches.value, 1)

@@ -67,15 +67,18 @@ struct FwF3 { float x, y, z; };
 struct FwB3 { uint8_t x, y, z; };
 
 // DIA (round 5): the instantiation that runs the dialect bits A.d64 -- D64 at tile speed; the D32 kernel keeps its registers
-template <int NT, int SLOTS, int FILL, bool DIA = false>
+// LISTED (round 5): the second-tier instantiation -- persistent workgroups over a list of rows.  A template parameter, not a runtime
+// test: with the loop around its body the one-pass kernel went from 44-63 to 59-137 registers and spilled 55-217 scalar ones (cfg 5
+// 5.3 -> 6.6 ms per 64 frames, tools/sessions/r05_s36.sh)
+template <int NT, int SLOTS, int FILL, bool DIA = false, bool LISTED = false>
 __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     // grid = (tiles x 8 rows, rows / 8, frames): all tiles of a row on one XCD (see cs_polypoint.hip)
     // listed form (second tier): grid = (tiles, G): workgroup (t, g) does tile t of list entries g, g + G, ...
-    const bool listed = A.row_list != nullptr;
+    constexpr bool listed = LISTED;
     const uint32_t lcount = listed ? A.row_count[0] : 0u;
-    for (uint32_t it = 0;; it++) {
+    for (uint32_t it = 0; listed || it == 0; it++) {
     int row, tile, frame;
     if (listed) {
         const uint32_t li = blockIdx.y + it * gridDim.y;
@@ -84,10 +87,9 @@ __global__ void __launch_bounds__(NT) k_fwdtile(FwdTileArgs A) {
         frame = (int)(e / (uint32_t)A.h); row = (int)(e - (uint32_t)frame * (uint32_t)A.h); tile = blockIdx.x;
         if (it) __syncthreads();   // (the previous row's LDS)
     } else {
-        if (it) break;
         const int xi = blockIdx.x;
         row = blockIdx.y * 8 + (xi & 7);
-        if (row >= A.h) break;
+        if (row >= A.h) return;
         tile = xi >> 3; frame = blockIdx.z;
     }
     const int w = A.w, h = A.h, T = A.T;
@@ -526,6 +528,11 @@ hipError_t launch_fwdtile(int fill, const RowArgs& R, int S0, uint8_t* rowflag, 
     const size_t lds = npt * 4 + npt * 8 + (npt / 64) * 8 + (fill == CS_FILL_NAIVE_INTERPOLATING ? npt * (4 + 4 + 2 + 1) : 0) + 64;
     const dim3 grid = tier2 ? dim3(ntiles, (unsigned)((1536 + ntiles - 1) / ntiles)) : dim3(ntiles * 8, (R.h + 7) / 8, R.n);
     const dim3 block(NT);
+    if (tier2) {
+        if (R.d64) hipLaunchKernelGGL((k_fwdtile<NT, 4, CS_FILL_NAIVE_INTERPOLATING, true, true>), grid, block, lds, stream, A);
+        else hipLaunchKernelGGL((k_fwdtile<NT, 4, CS_FILL_NAIVE_INTERPOLATING, false, true>), grid, block, lds, stream, A);
+        return hipGetLastError();
+    }
     if (R.d64) {   // dialect D64 (either bit): the same kernels with the float64 offset chain / unwrapped pixel sums compiled in
         if (fill == CS_FILL_INVERSE) hipLaunchKernelGGL((k_fwdtile<NT, 3, CS_FILL_INVERSE, true>), grid, block, lds, stream, A);
         else if (fill == CS_FILL_NAIVE) hipLaunchKernelGGL((k_fwdtile<NT, 4, CS_FILL_NAIVE, true>), grid, block, lds, stream, A);
