@@ -2961,6 +2961,7 @@ __global__ void __launch_bounds__(64) k_poly_replay_lanes(RowArgs A) {
                     }
                 }
                 if (lost || err) break;
+                if (csg_end == 0) { lost = true; break; }   // (cannot happen -- the polyline is connected from -w to 2w; slot 0 would be stale)
                 int best = 0;
                 if (csg_end != 1) {
                     float bc = (float)(-1e-7);
