@@ -96,7 +96,7 @@ struct PolyPointArgs {
     // the per-eye constants packed in 64-bit words, so that the eye of a workgroup is picked by three 64-bit scalar selects
     // instead of eight 32-bit ones: {div32, sep32}, {xoff, yoff}, {st_min, st_max | enabled << 16}
     unsigned long long epk[2][3];
-    // dialect bit "float64 disparity chain" (RowArgs::d64 & 1; the DIA instantiations, polylines_soft only): the exponent as a double
+    // dialect bit "float64 disparity chain" (RowArgs::d64 & 1; the DIA instantiations, soft and sharp): the exponent as a double
     int d64; double e64;
     // tile hints (round 5): bit t of word [(frame * h + row) * 2 + eye] = tile t of that row-eye raised a hazard (tiles from 31 on
     // share bit 31); null: not recorded.  The row kernel can then confine itself to those tiles' columns.

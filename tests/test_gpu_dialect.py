@@ -12,8 +12,8 @@ from oracle import node_oracle, oracle
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "dialect_f64.npz")
-# polylines: through the general row kernel (the tile kernels are dialect D32); the float64 chain is pinned by the fixture, the
-# numba typing of the sweep (full D64) is derived -- checked against the oracle's statement of the same rules
+# the float64 chain (pinned by the fixture) runs in every technique's tile kernel since round 5; the numba typing of the polylines sweep
+# (full D64) stays in the general row kernel and is derived -- checked against the oracle's statement of the same rules
 FILLS = ("none", "naive", "naive_interpolating", "inverse", "polylines_soft", "polylines_sharp", "hybrid_edge",
          "none_post", "inverse_post", "hybrid_edge_plus")
 
