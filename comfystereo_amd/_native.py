@@ -24,10 +24,10 @@ MODE = {
 }
 
 # the ABI version the ctypes signatures below were written for (include/comfystereo_amd.h CS_ABI_VERSION)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = [
-    "cs_version", "cs_last_error", "cs_max_width", "cs_max_width_mode", "cs_output_shape", "cs_workspace_bytes", "cs_generate",
+    "cs_version", "cs_last_error", "cs_max_width", "cs_max_width_mode", "cs_max_width_params", "cs_output_shape", "cs_workspace_bytes", "cs_generate",
     "cs_asd_workspace_bytes", "cs_asd_workspace_bytes_for", "cs_apply_stereo_divergence", "cs_apply_stereo_divergence2", "cs_blur_workspace_bytes", "cs_directional_blur", "cs_blur_scipy_workspace_bytes", "cs_directional_blur_scipy",
     "cs_warp_workspace_bytes", "cs_forward_warp", "cs_forward_warp2", "cs_warp_mesh_workspace_bytes", "cs_forward_warp_mesh", "cs_expand_u8", "cs_pack_u8", "cs_host_expand_u8", "cs_host_copy", "cs_take_f32", "cs_host_replicate_f32", "cs_stereo_shift_workspace_bytes", "cs_stereo_shift", "cs_profile", "cs_profile_read", "cs_profile_tiles", "cs_debug_set",
     "cs_test_powf", "cs_test_exp", "cs_test_edge_threshold",
@@ -83,6 +83,8 @@ def lib():
     L.cs_last_error.argtypes = []
     L.cs_max_width_mode.restype = c_int
     L.cs_max_width_mode.argtypes = [c_int, c_int]
+    L.cs_max_width_params.restype = c_int
+    L.cs_max_width_params.argtypes = [ctypes.POINTER(Params)]
     L.cs_max_width.restype = c_int
     L.cs_max_width.argtypes = [c_int]
     L.cs_output_shape.restype = c_int

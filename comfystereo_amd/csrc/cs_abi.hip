@@ -575,6 +575,35 @@ static bool dialect_width_ok(int fill, int w, int anaglyph, int d64) {
     if (!(d64 & 1) || (fill != CS_FILL_POLYLINES_SOFT && fill != CS_FILL_POLYLINES_SHARP && fill != CS_FILL_HYBRID_EDGE && fill != CS_FILL_HYBRID_EDGE_PLUS)) return true;
     return rowwarp_lds_bytes(fill, w, fill == CS_FILL_HYBRID_EDGE ? 0 : anaglyph) + 8 * (size_t)w + 16 <= CS_LDS_BYTES;
 }
+// The ONE width predicate of cs_generate: nullptr when a frame of `w` columns with p's technique, mode, dialect flags
+// and disparity parameters is accepted, else the reason.  cs_max_width_params searches it, so a caller that pre-validates gets
+// exactly the answer the call itself would give.
+static const char* width_refusal(const cs_params* p, int w) {
+    const bool ana = p->mode == CS_MODE_RED_CYAN_ANAGLYPH || p->mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH;
+    if (w > max_width_for(p->fill, ana) || !dialect_width_ok(p->fill, w, ana, (p->flags >> 3) & 3))
+        return "frame too wide for the LDS-resident row kernel";
+    if ((p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP) && ana && w > row_form_max_width(p->fill, 1)) {
+        // an anaglyph wider than the row kernel's anaglyph form: only through the tile kernels -- the predicate run_rows uses
+        // for its tiled anaglyph path (D32, or the float64 disparity chain alone with a halo within the point kernel's reach;
+        // cs_generate's images are float32)
+        const int halo = poly_halo(p->divergence * (1 + p->stereo_balance), p->divergence * (1 - p->stereo_balance), p->separation,
+                                   p->stereo_offset_exponent, p->convergence_point, w);
+        const int d64 = (p->flags >> 3) & 3;
+        const bool tile_dialect = d64 == 0 || (d64 == 1 && halo <= polypoint_max_halo());
+        if (!tile_dialect || halo > polytile_max_halo() || dev_switch(CS_DEBUG_NO_TILE))
+            return "frame too wide for the LDS-resident row kernel (anaglyph form)";
+    }
+    return nullptr;
+}
+int cs_max_width_params(const cs_params* p) {
+    if (!p || p->fill < 0 || p->fill > CS_FILL_HYBRID_EDGE_PLUS) return 0;
+    int lo = 0, hi = 1 << 16;   // (monotone: LDS bytes and the halo both grow with the width)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (!width_refusal(p, mid)) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
 int cs_max_width(int fill) { return max_width_for(fill, 1); }
 int cs_max_width_mode(int fill, int mode) {
     return max_width_for(fill, mode == CS_MODE_RED_CYAN_ANAGLYPH || mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH);
@@ -840,17 +869,7 @@ int cs_generate(const cs_params* p, const float* image, const float* depth, floa
     int out_h, out_w, mask_h, mask_w;
     int rc = cs_output_shape(p, &out_h, &out_w, &mask_h, &mask_w);
     if (rc) return rc;
-    if (p->w > cs_max_width_mode(p->fill, p->mode) ||
-        !dialect_width_ok(p->fill, p->w, p->mode == CS_MODE_RED_CYAN_ANAGLYPH || p->mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH, (p->flags >> 3) & 3))
-        return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel");
-    if ((p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP) &&
-        (p->mode == CS_MODE_RED_CYAN_ANAGLYPH || p->mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH) && p->w > row_form_max_width(p->fill, 1)) {
-        // an anaglyph wider than the row kernel's anaglyph form: only through the tile kernels (D32, halo within their reach)
-        const int halo = poly_halo(p->divergence * (1 + p->stereo_balance), p->divergence * (1 - p->stereo_balance), p->separation,
-                                   p->stereo_offset_exponent, p->convergence_point, p->w);
-        if ((p->flags & 24) || halo > polytile_max_halo() || dev_switch(CS_DEBUG_NO_TILE))
-            return fail(CS_ELIMIT, "frame too wide for the LDS-resident row kernel (anaglyph form)");
-    }
+    if (const char* why = width_refusal(p, p->w)) return fail(CS_ELIMIT, why);
     if (workspace_bytes < ws_total(p)) return fail(CS_EWORKSPACE, "workspace too small");
     if (p->fill == CS_FILL_GPU_WARP && (p->flags & 2)) return fail(CS_EINVAL, "gpu_warp colours are not k/255: no uint8 stereoscope output");
     if ((p->flags & 24) && !dialect_d64_ok(p->fill))

@@ -589,6 +589,348 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// k_gpuwarp_q (round 6): the same warp for the node's layout and forward_warp_gpu's default parameters, FOUR CONTIGUOUS
+// COLUMNS PER LANE.  k_gpuwarp above is bound by its vector instructions (2 599 per wave at 1080p, the vector pipes ~80 % busy,
+// profiles/r05d_cfg4_pmc), a third of them address arithmetic, loop control and single-dword LDS / global accesses of its
+// column-strided loops (lane t: columns t, t + nt, ...).  Here lane t owns the columns 4t .. 4t + 3 in every phase:
+//   * stage + pair pass in ONE phase: depth as one 16-byte load, ndn / D as one 16-byte LDS store each, the depth-map output as
+//     three 16-byte stores; the pixel offsets never go to LDS -- the pairs (i, i + 1) of a lane's columns take their operands
+//     from registers, the fourth from the next lane (DPP wave_shl:1).  A wave covers 63 groups and lane 63 stages the group that
+//     lane 0 of the next wave owns (the same values written twice), so that no pair crosses a wave without both operands: one
+//     barrier and a pass over LDS less per eye;
+//   * column pass: the seven table entries the four rounds of four neighbouring columns can name (M[x0 - 3 .. x0 + 3]) are read
+//     as two 16-byte LDS loads and decoded ONCE (pair index, dl, dr, the guarded width) instead of once per column and round;
+//   * sampling: rows whose vertical blend weight is EXACTLY zero (the grid_sample round trip returns the integer row: 69 % of the
+//     rows at 1080p and 4K) read one image row instead of two -- x + 0 * p == x for every finite pixel p (non-finite pixels of
+//     the unweighted row do not propagate here; the reference would turn the column into NaN) -- and the four columns of a lane
+//     leave as three 16-byte stores.
+// Arithmetic: the expressions of k_gpuwarp, operation for operation (same tests: masks bit-exact, colours as before).
+// Requirements (gw_launch falls back to k_gpuwarp otherwise): node layout, both eyes enabled, w % 4 == 0, w >= 8, 16-byte aligned
+// buffers, default gradient_threshold / max_stretch.
+// ---------------------------------------------------------------------------------------------------------------------
+struct GwQuad { float x, y, z, w; };
+static size_t gwq_bit_words(int w) { return (size_t)((w + 127) >> 7) << 2; }   // one bit per column, padded to 16 bytes
+static size_t gwq_lds_bytes(int w) { return 4 * (size_t)w * 4 + ((size_t)w + 24) * 4 + 2 * gwq_bit_words(w) * 4 + 32 * 4 + sizeof(csm::PowfTables) + 64; }
+
+template <int MINW, int POW>
+__attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+__global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
+    constexpr int NR = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
+    const int y = blockIdx.x, frame = blockIdx.y, w = A.w, h = A.h, G = w >> 2;
+    const int nbw = ((w + 127) >> 7) << 2;
+    float* const ndn = (float*)smem;      // [w] normalised depth (not convergence-shifted)
+    float* const D = ndn + w;             // [w] x + offset = dl of pair x = dr of pair x - 1   (D[-1] is readable: table entry 0)
+    float* const zb = D + w;              // [w] z-buffer
+    float* const sm = zb + w;             // [w] source map
+    int* const M = (int*)(sm + w);        // [w + NR] highest (2 (i + 1) + connected) per floor(min(dl, dr)) = -(NR - 1) .. w - 2
+    int* const W0 = M + w + NR;           // [NR] per round: the same for the pairs clamped to column 0
+    int* const W1 = W0 + NR;              // [NR] ... to column w - 1
+    uint32_t* const fbits = (uint32_t*)(W1 + NR);   // filled by this eye's column pass, one bit per column
+    uint32_t* const gbits = fbits + nbw;            // gap in some eye (the mask output)
+    int* const ws = (int*)(gbits + nbw);
+    csm::PowfTables* const T = (csm::PowfTables*)(ws + 32);
+    if (POW != 2 && A.pow_mode == 4) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_gw_powf_tables);
+        for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += nt) reinterpret_cast<uint32_t*>(T)[i] = src[i];
+    }
+    const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
+    const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
+    for (int q = tid; q < ((w + 3 * NR) >> 2) + (2 * nbw >> 2); q += nt) reinterpret_cast<int4*>(M)[q] = make_int4(0, 0, 0, 0);   // M, W0, W1, fbits, gbits
+    // torch.linspace(-1, 1, H)[y] and its unnormalisation (as in k_gpuwarp)
+    float gy;
+    {
+        float step = h > 1 ? 2.0f / (float)(h - 1) : 0.0f;
+        gy = y < h / 2 ? fmaf(step, (float)y, -1.0f) : fmaf(-step, (float)(h - y - 1), 1.0f);
+    }
+    float yy = (gy + 1.0f) * ((float)(h - 1) / 2.0f);
+    yy = fminf(fmaxf(yy, 0.0f), (float)(h - 1));
+    const float yn = floorf(yy);
+    const float wn = yy - yn, wsth = 1.0f - wn;
+    const int iy0 = (int)yn, iy1 = min(iy0 + 1, h - 1);
+    const float sxw = (float)(w - 1);
+    const bool sxw_ok = w <= (1 << 20);   // the division core's denominator range (w >= 8 here)
+    const float ysx = sxw_ok ? gw_rcp_refined(sxw) : 0.0f;
+    const bool lazy = A.tilemap != nullptr;
+    const bool one_row = wn == 0.0f;      // the second image row of the blend has weight exactly zero
+    __syncthreads();
+
+    for (int e = 0; e < 2; e++) {
+        const GwEye& E = A.eye[e];
+        const bool div255 = st[E.st_div] != 0;
+        float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
+        if (div255) { dmin = dmin / 255.0f; dmax = dmax / 255.0f; }
+        const float range = dmax - dmin;
+        const float crange = fmaxf(range, (float)1e-6);
+        const bool has_range = range > (float)1e-6;
+        const bool crange_ok = crange < 0x1p40f;   // (>= 1e-6 by construction)
+        const float yr = crange_ok ? gw_rcp_refined(crange) : 0.0f;
+        const char* const r0 = reinterpret_cast<const char*>(A.image + frame * A.img_sf + iy0 * A.img_sy);
+        const char* const r1 = reinterpret_cast<const char*>(A.image + frame * A.img_sf + iy1 * A.img_sy);
+        char* const out_row = reinterpret_cast<char*>(A.out + frame * A.out_sf + (y + E.yoff) * A.out_sy + E.xoff * 3);
+        const char* const drow = reinterpret_cast<const char*>(E.depth + ((size_t)frame * h + y) * w);
+        char* const depth_out = reinterpret_cast<char*>((e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + y) * w) * 3);
+        LazySel Z;
+        uint32_t Zhi = 0;
+        Z.base = nullptr; Z.bits = 0; Z.delta = 0; Z.mul_set = Z.mul_clr = 0;
+        if (lazy) {
+            const char* grow = reinterpret_cast<const char*>(A.gray + ((size_t)frame * h + y) * w);
+            Z = lazy_select(A.tilemap, A.tm_words, frame, h, y, 0, drow, grow, st[ST_SCALE255]);
+            if (w > 2048) Zhi = lazy_select(A.tilemap, A.tm_words, frame, h, y, 2048, drow + 4 * 2048, grow + 4 * 2048, st[ST_SCALE255]).bits;
+        }
+        // ---- stage (:300-328) + the pair pass of the scatter rounds (:330-391, see k_gpuwarp): M[v] = max{2 (i + 1) + connected : fs_i == v}
+        for (int gb = wave * 63; gb < G; gb += nwaves * 63) {
+            const int g = gb + lane;
+            const bool gv = g < G;
+            const uint32_t x0 = 4u * (uint32_t)(gv ? g : G - 1);   // (lanes past the row end repeat the last group and store nothing)
+            float dm = scale;
+            GwQuad dq;
+            if (lazy) {
+                const uint32_t bits = x0 >= 2048u ? Zhi : Z.bits;
+                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, x0 >> 6, 1u);   // 0 / ~0: the tile of these four columns
+                dm = __builtin_bit_cast(float, (m & Z.mul_set) | (~m & Z.mul_clr));
+                dq = *reinterpret_cast<const GwQuad*>(Z.base + (4u * x0 + (m & Z.delta)));
+            } else
+                dq = *reinterpret_cast<const GwQuad*>(drow + 4u * x0);
+            float v[4] = {dq.x * dm, dq.y * dm, dq.z * dm, dq.w * dm};
+            if (div255) {
+                asm volatile("" ::: "memory");   // (a real branch: the division is not worth speculating)
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = v[u] / 255.0f;
+            }
+            float nd[4], p[4], d[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float num = v[u] - dmin;
+                float nrm = gw_div_y(num, crange, yr, crange_ok);
+                nrm = has_range ? nrm : 0.0f;
+                nd[u] = nrm;
+                const float s = nrm - A.conv32;
+                float od;
+                if (POW == 2) od = s * fabsf(s);   // == sign(s) * (|s| * |s|): a product rounds independently of its sign
+                else {
+                    const float sg = s > 0.0f ? 1.0f : (s < 0.0f ? -1.0f : 0.0f);
+                    od = sg * torch_pow(fabsf(s), A.pow_mode, A.e32, T);
+                }
+                p[u] = od * E.div32 + E.sep32;
+                d[u] = (float)(x0 + (uint32_t)u) + p[u];
+            }
+            if (gv) {
+                *reinterpret_cast<GwQuad*>(ndn + x0) = GwQuad{nd[0], nd[1], nd[2], nd[3]};
+                *reinterpret_cast<GwQuad*>(D + x0) = GwQuad{d[0], d[1], d[2], d[3]};
+                float o[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) o[u] = A.noclamp ? v[u] : fminf(fmaxf(v[u], 0.0f), 1.0f);
+                GwQuad* dst = reinterpret_cast<GwQuad*>(depth_out + 12u * x0);
+                dst[0] = GwQuad{o[0], o[0], o[0], o[1]};
+                dst[1] = GwQuad{o[1], o[1], o[2], o[2]};
+                dst[2] = GwQuad{o[2], o[3], o[3], o[3]};
+            }
+            // the next lane's first column (lane 63 owns no pair: its group belongs to lane 0 of the next wave)
+            const float dnext = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d[0]), 0x130, 0xf, 0xf, false));
+            const float pnext = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p[0]), 0x130, 0xf, 0xf, false));
+            if (gv && lane < 63) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = (int)x0 + u;
+                    if (i >= w - 1) continue;
+                    const float dl = d[u], dr = u < 3 ? d[u < 3 ? u + 1 : 3] : dnext;
+                    const float pl = p[u], pr = u < 3 ? p[u < 3 ? u + 1 : 3] : pnext;
+                    const float fs = floorf(fminf(dl, dr));
+                    const bool connected = fabsf(pr - pl) < 1.5f;
+                    const int key = 2 * (i + 1) + (connected ? 1 : 0);
+                    if (fs >= -(float)(NR - 1) && fs <= (float)(w - 2)) atomicMax(&M[(int)fs + NR - 1], key);
+                    if (!(fs > 0.0f) || fs + (float)(NR - 1) >= sxw) {
+#pragma unroll
+                        for (int k = 0; k < NR; k++) {
+                            const float cfl = fs + (float)k;
+                            if (!(cfl > 0.0f)) atomicMax(&W0[k], key);          // fmaxf(NaN, 0) == 0 as well
+                            else if (cfl >= sxw) atomicMax(&W1[k], key);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (GW_DEV_IS(52)) { __syncthreads(); continue; }
+        // ---- column pass: the z-tests of rounds 0 .. 3 in order (see k_gpuwarp), four columns per lane
+        auto propose = [&](int key, float cfl, float& z, float& src) {   // the clamped columns (k_gpuwarp's form)
+            const int i = max((key >> 1) - 1, 0);
+            const float dl = D[i], dr = D[i + 1];
+            const float sw = dr - dl;
+            const float safe = fabsf(sw) < (float)1e-4 ? 1.0f : sw;
+            const float num = cfl - dl;
+            const bool maybe = (key & 1) && cfl >= 0.0f && cfl < (float)w &&
+                               !((num < 0.0f && safe > 0.0f) || (num > 0.0f && safe < 0.0f) || fabsf(num) >= 1.001f * fabsf(safe));
+            if (!maybe) return;
+            const float frac = gw_div(num, safe);
+            const bool valid = frac >= 0.0f && frac < 1.0f;
+            const float iz = ndn[i] * (1.0f - frac) + ndn[i + 1] * frac;
+            if (valid && iz > z + (float)1e-6) {
+                z = iz;
+                src = (float)i + frac;
+            }
+        };
+        int myright = -1;
+        for (int g = tid; g < G; g += nt) {
+            const int x0 = 4 * g;
+            // entry j: the deciding pair with fs == x0 - 3 + j; column x0 + u meets it in round k = u + 3 - j
+            const int4 e0 = *reinterpret_cast<const int4*>(M + x0 + 4), e1 = *reinterpret_cast<const int4*>(M + x0 + 8);
+            const int key[7] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z};
+            float dl[7], safe[7], lim[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                // (entry 0 = "no pair" reads D[-1], D[0] and fails the connected bit)
+                const float* dp = D + (key[j] >> 1);
+                const float a = dp[-1], b = dp[0];
+                const float sw = b - a;
+                dl[j] = a;
+                safe[j] = fabsf(sw) < (float)1e-4 ? 1.0f : sw;
+                lim[j] = 1.001f * fabsf(safe[j]);
+            }
+            float z[4], src[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int x = x0 + u;
+                z[u] = -1.0f; src[u] = -1.0f;
+                const bool interior = x > 0 && x < w - 1;
+                const float cfl = (float)x;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int j = u + 3 - k;
+                    const float num = cfl - dl[j];
+                    // (conservative filter, the exact test is `valid`: see k_gpuwarp)
+                    const bool maybe = interior & ((key[j] & 1) != 0) & !(num * safe[j] < 0.0f) & !(fabsf(num) >= lim[j]);
+                    if (maybe) {
+                        const int i = (key[j] >> 1) - 1;
+                        const float frac = gw_div(num, safe[j]);
+                        const bool valid = frac >= 0.0f && frac < 1.0f;
+                        const float iz = ndn[i] * (1.0f - frac) + ndn[i + 1] * frac;
+                        if (valid && iz > z[u] + (float)1e-6) {
+                            z[u] = iz;
+                            src[u] = (float)i + frac;
+                        }
+                    }
+                }
+            }
+            if (g == 0 || g == G - 1) {   // the clamped columns 0 and w - 1: the deciding pair's own fs + k decides whether it is in range at all
+                const int u = g == 0 ? 0 : 3;
+                float zz = -1.0f, ss = -1.0f;
+                for (int k = 0; k < 4; k++) {
+                    const int kk = g == 0 ? W0[k] : W1[k];
+                    if (kk) {
+                        const int i = (kk >> 1) - 1;
+                        propose(kk, floorf(fminf(D[i], D[i + 1])) + (float)k, zz, ss);
+                    }
+                }
+                if (u == 0) { z[0] = zz; src[0] = ss; } else { z[3] = zz; src[3] = ss; }
+            }
+            *reinterpret_cast<GwQuad*>(zb + x0) = GwQuad{z[0], z[1], z[2], z[3]};
+            *reinterpret_cast<GwQuad*>(sm + x0) = GwQuad{src[0], src[1], src[2], src[3]};
+            uint32_t nib = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (!(src[u] < 0.0f)) { nib |= 1u << u; myright = x0 + u; }
+            const uint32_t sh = (uint32_t)x0 & 31u;
+            if (nib) atomicOr(&fbits[x0 >> 5], nib << sh);
+            if (nib != 15u) atomicOr(&gbits[x0 >> 5], (nib ^ 15u) << sh);
+        }
+        if (GW_DEV_IS(53)) { __syncthreads(); __syncthreads(); continue; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) myright = max(myright, __shfl_xor(myright, off));
+        if (lane == 0) ws[16 + wave] = myright;
+        __syncthreads();
+        int rightmost = -1;
+        for (int i = 0; i < nwaves; i++) rightmost = max(rightmost, ws[16 + i]);
+        // the table of the next eye (every read of this eye's is behind the barrier above)
+        for (int q = tid; q < ((w + 3 * NR) >> 2); q += nt) reinterpret_cast<int4*>(M)[q] = make_int4(0, 0, 0, 0);
+        if (GW_DEV_IS(54)) { __syncthreads(); continue; }
+        auto left_filled = [&](int x) {
+            if (x <= 0) return -1;
+            int wi = (x - 1) >> 5;
+            uint32_t cur = fbits[wi] & (0xffffffffu >> (31 - ((x - 1) & 31)));
+            while (true) {
+                if (cur) return wi * 32 + 31 - __clz((int)cur);
+                if (--wi < 0) return -1;
+                cur = fbits[wi];
+            }
+        };
+        // final source position of column x (gap fill :393-438), then the horizontal taps of the grid_sample round trip (:440-448)
+        auto taps_of = [&](int x, float s, int& ix0, int& ix1, float& ww, float& we) {
+            if (s < 0.0f) {
+                int left = left_filled(x);
+                int right = rightmost >= x ? rightmost : -1;
+                bool hl = left >= 0, hr = right >= 0;
+                int li = hl ? left : 0, ri = hr ? right : 0;
+                float lsrc = sm[li], rsrc = sm[ri], lz = zb[li], rz = zb[ri];
+                float ld = (float)(x - left), rd = (float)(right - x);
+                float tot = fmaxf(ld + rd, 1.0f);
+                float t = ld / tot;
+                if (!hl) t = 1.0f;
+                if (!hr) t = 0.0f;
+                float tb = (lz < rz) ? sqrtf(t) : 1.0f - sqrtf(1.0f - t);
+                float gg = lsrc * (1.0f - tb) + rsrc * tb;
+                if (hl || hr) s = gg;
+            }
+            const float pos = fminf(fmaxf(s, 0.0f), sxw);
+            const float p2 = pos * 2.0f;
+            float gx = gw_div_y(p2, sxw, ysx, sxw_ok) - 1.0f;
+            float xx = (gx + 1.0f) * (sxw / 2.0f);
+            xx = fminf(fmaxf(xx, 0.0f), sxw);
+            const float xw = floorf(xx);
+            ww = xx - xw; we = 1.0f - ww;
+            ix0 = (int)xw; ix1 = min(ix0 + 1, w - 1);
+        };
+        for (int g = tid; g < G; g += nt) {
+            const int x0 = 4 * g;
+            const GwQuad sq = *reinterpret_cast<const GwQuad*>(sm + x0);
+            const float sv[4] = {sq.x, sq.y, sq.z, sq.w};
+            Px3 r[4];
+            if (one_row) {
+                // wn == 0: the taps of row iy1 carry the weights 0 * we and 0 * ww -- x + 0 * p == x for finite p
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    int ix0, ix1; float ww, we;
+                    taps_of(x0 + u, sv[u], ix0, ix1, ww, we);
+                    const Px3 pa = *reinterpret_cast<const Px3*>(r0 + 12u * (uint32_t)ix0), pb = *reinterpret_cast<const Px3*>(r0 + 12u * (uint32_t)ix1);
+                    const float nw = wsth * we, ne = wsth * ww;   // (wsth == 1)
+                    r[u].x = pa.x * nw + pb.x * ne;
+                    r[u].y = pa.y * nw + pb.y * ne;
+                    r[u].z = pa.z * nw + pb.z * ne;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    int ix0, ix1; float ww, we;
+                    taps_of(x0 + u, sv[u], ix0, ix1, ww, we);
+                    const uint32_t a0 = 12u * (uint32_t)ix0, a1 = 12u * (uint32_t)ix1;
+                    const Px3 pa = *reinterpret_cast<const Px3*>(r0 + a0), pb = *reinterpret_cast<const Px3*>(r0 + a1),
+                              pc = *reinterpret_cast<const Px3*>(r1 + a0), pd = *reinterpret_cast<const Px3*>(r1 + a1);
+                    const float nw = wsth * we, ne = wsth * ww, sw2 = wn * we, se = wn * ww;
+                    r[u].x = pa.x * nw + pb.x * ne + pc.x * sw2 + pd.x * se;
+                    r[u].y = pa.y * nw + pb.y * ne + pc.y * sw2 + pd.y * se;
+                    r[u].z = pa.z * nw + pb.z * ne + pc.z * sw2 + pd.z * se;
+                }
+            }
+            GwQuad* dst = reinterpret_cast<GwQuad*>(out_row + 12u * (uint32_t)x0);
+            dst[0] = GwQuad{r[0].x, r[0].y, r[0].z, r[1].x};
+            dst[1] = GwQuad{r[1].y, r[1].z, r[2].x, r[2].y};
+            dst[2] = GwQuad{r[2].z, r[3].x, r[3].y, r[3].z};
+        }
+        __syncthreads();
+        if (e == 0)   // (this eye's filled bits; the gap bits accumulate over the eyes)
+            for (int q = tid; q < (nbw >> 2); q += nt) reinterpret_cast<int4*>(fbits)[q] = make_int4(0, 0, 0, 0);
+    }
+    float* const mrow = A.mask_f32 + ((size_t)frame * h + y) * w;
+    for (int g = tid; g < G; g += nt) {
+        const int x0 = 4 * g;
+        const uint32_t nib = gbits[x0 >> 5] >> (x0 & 31);
+        *reinterpret_cast<GwQuad*>(mrow + x0) = GwQuad{(nib & 1u) ? 1.0f : 0.0f, (nib & 2u) ? 1.0f : 0.0f, (nib & 4u) ? 1.0f : 0.0f, (nib & 8u) ? 1.0f : 0.0f};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Mesh-quality warp: forward_warp_mesh (reference stereoimage_generation.py:453-689), what the reference runs whenever
 // `moderngl` is importable (:1068-1071).  The reference hands a triangle mesh to OpenGL; here the rasteriser is written
 // out.  Vertices move horizontally only, so output row k is one scanline through ONE row of quads (r = floor(wy),

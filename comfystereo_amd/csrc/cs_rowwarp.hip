@@ -1490,10 +1490,13 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                 if (!room)   // replay here; the reserved descriptors (those inside the list) say "skip"
                     for (uint32_t i = base; i < base + (uint32_t)nstr && i < X->cap; i++) X->list[(size_t)i * RP_DESC] = 0xffffffffu;
                 // (give the units back when the POOL was what did not fit -- the counter only grew, so after one row had found
-                // the pool full every later row, however small, took the retry pass as well; a reservation made between this add and
-                // the subtraction sees a counter that is too high: it fails spuriously or leaves a hole, never an overlap)
+                // the pool full every later row, however small, took the retry pass as well.  ADVICE r5: a plain subtraction can hand
+                // out overlapping regions -- A and B fail, A refunds, D succeeds above B's failed units, B refunds, and E lands
+                // inside D.  The refund is therefore ONE compare-and-swap that only succeeds while this failed reservation is still
+                // the topmost one (counter == at + total16 -> at); otherwise the units stay lost: a later row fails spuriously and
+                // takes the retry pass, never an overlap.  One attempt, no loop: the starvation of the round-4 CAS loop does not arise)
                 if (!room && at + total16 > (unsigned long long)X->pool16)
-                    atomicAdd(reinterpret_cast<unsigned long long*>(X->ctr + 4), 0ull - (unsigned long long)total16);
+                    atomicCAS(reinterpret_cast<unsigned long long*>(X->ctr + 4), at + (unsigned long long)total16, at);
                 if (!room) *rp_ok = 0;   // replay here
                 if (!room && dbg == 14 && stats_rw) atomicAdd(&stats_rw[14], 1u);   // (diagnostics: rows that found the pool full)
             }
@@ -3015,10 +3018,13 @@ __global__ void __launch_bounds__(64) k_poly_replay_lanes(RowArgs A) {
 // second pass (in-row replay), and a caller can always give more (workspace beyond cs_workspace_bytes extends the pool).
 static size_t rp_pool_bytes(size_t rows, int w, int sharp) {
     // (development: CS_DEBUG_PT_VARIANT 41 quadruples the per-row budget -- does a workload run out of pool?)
-    const size_t per_row = dev_switch(CS_DEBUG_PT_VARIANT) == 41 ? 16384 : 4096;
+    // (48: a deliberately tiny pool -- most flagged rows find it full: tests/test_gpu_stress.py exercises the refund path)
+    const int variant = dev_switch(CS_DEBUG_PT_VARIANT);
+    const size_t per_row = variant == 41 ? 16384 : 4096;
     const size_t every_row = rows * 2 * ((size_t)rp_win16(poly_npt(w, sharp), w) << 4), budget = rows * per_row + (64u << 10);
     const size_t cap = (size_t)1 << 30;
     size_t pool = every_row <= cap ? every_row : (budget > cap ? budget : cap);
+    if (variant == 48) pool = rows * 96 + 8192;
     if (pool > every_row) pool = every_row;
     return (pool + 15) & ~(size_t)15;
 }

@@ -49,24 +49,56 @@ CHUNK_IN_BYTES = 1 << 30
 # with diffusion models and their offload buffers: the default keeps it below 8 GB whatever the batch.  A deployment with
 # RAM to spare may raise it (steady state +5 % at 32 x 4K, profiles/r05_host.txt).
 PINNED_POOL_BYTES = 8 << 30
-_last_pinned_need = 0   # pinned bytes the previous call asked for (module state only: nothing is persisted)
+_pinned_lock = threading.Lock()   # generate_host and the prewarm_async daemon thread both pass through _pinned_budget
+_pinned_needs = set()             # distinct pinned needs (bytes) served since the cache was last released (module state only)
+_warned_no_empty_cache = False
 
 
 def _release_pinned_cache():
-    """Give the pinned blocks PyTorch's caching host allocator holds (and nobody uses) back to the system."""
+    """Give the pinned blocks PyTorch's caching host allocator holds (and nobody uses) back to the system.  The hook is a private
+    one (torch._C._host_emptyCache); a PyTorch without it keeps its cache -- said once, not silently."""
+    global _warned_no_empty_cache
     fn = getattr(torch._C, "_host_emptyCache", None)
     if fn is not None:
         fn()
+    elif not _warned_no_empty_cache:
+        _warned_no_empty_cache = True
+        import warnings
+        warnings.warn("comfystereo_amd: this PyTorch has no torch._C._host_emptyCache -- page-locked blocks of earlier shapes stay "
+                      "cached beyond host_pipeline.PINNED_POOL_BYTES until the process ends")
 
 
 def _pinned_budget(need):
-    """Called once per generate_host / prewarm with the pinned bytes the call will ask for: when the need SHRINKS against the
-    previous call's (another resolution, a shorter batch) the cached blocks of the old shape would stay page-locked for
-    nothing -- PyTorch never returns them by itself -- so they are released first."""
-    global _last_pinned_need
-    if need < _last_pinned_need:
-        _release_pinned_cache()
-    _last_pinned_need = need
+    """Called once per generate_host / prewarm with the pinned bytes the call will ask for.  PyTorch never returns cached pinned
+    blocks by itself, so blocks of shapes no longer in use would stay page-locked for nothing -- but releasing on every change of
+    shape makes a caller that ALTERNATES between two shapes re-pin gigabytes per call at 24 GB/s.  Hysteresis: the
+    distinct needs served since the last release bound what the cache can hold; it is released only when that bound, with this
+    call's need, exceeds PINNED_POOL_BYTES."""
+    with _pinned_lock:
+        if need in _pinned_needs:
+            return
+        if sum(_pinned_needs) + need > PINNED_POOL_BYTES and _pinned_needs:
+            _release_pinned_cache()
+            _pinned_needs.clear()
+        _pinned_needs.add(need)
+
+
+def _plan_pinned(total, chunk, unit, per_frame_in, small_per_frame, f32_per_frame, per_frame_out, want_pinned_results):
+    """(chunk, staging bytes, pin the results?) of a call -- ONE statement of it for generate_host and prewarm (they
+    disagreed, and the float32 routes' pinned staging was not counted).  Staging = what the slots page-lock: inputs, compact landing
+    buffers and -- when the RESULTS are not pinned -- a staging copy of each float32-route output (gpu_warp's colours: `pin_out`).
+    Results are pinned while staging + results fit under PINNED_POOL_BYTES; otherwise the chunk shrinks (in multiples of `unit`, the
+    gpu_warp sub-batch) until the staging alone does."""
+    def slot_frames(ch):
+        nranges = (total + ch - 1) // ch
+        return ch * min(2, nranges) + (total % ch if total % ch and nranges > 1 else 0)
+    base = per_frame_in + small_per_frame
+    if want_pinned_results and slot_frames(chunk) * base + total * per_frame_out <= PINNED_POOL_BYTES:
+        return chunk, slot_frames(chunk) * base, True
+    per = base + (f32_per_frame if want_pinned_results is not None else 0)   # (None: caller-provided PINNED results, no staging copy)
+    while chunk > unit and slot_frames(chunk) * per > PINNED_POOL_BYTES:
+        chunk = max(unit, (chunk // 2) // unit * unit)
+    return chunk, slot_frames(chunk) * per, False
 
 
 def _chunk_frames(total, per_frame_out, fill, batch_size):
@@ -223,26 +255,21 @@ def generate_host(image, depth_map, divergence, separation, modes, stereo_balanc
         raise ValueError("gpu_warp colours are not k/255: no compact boundary")
     kind = "compact" if compact else ("warp" if fill == 'gpu_warp' else "float")
     routes = ROUTES[kind]
+    per_frame_in = 4 * (h * w * 3 + dshape[0] * dshape[1] * dshape[2])
+    unit = 1
     if kind == "compact":
-        per_frame_in = 4 * (h * w * 3 + dshape[0] * dshape[1] * dshape[2])
         chunk = max(1, min(total, CHUNK_IN_BYTES // max(per_frame_in, 1)))
         if total >= 4:   # at least four chunks so that staging, transfers, kernels and the host expansion overlap
             chunk = min(chunk, (total + 3) // 4)
     else:
         chunk = _chunk_frames(total, per_frame_out, fill, batch_size)
+        if fill == 'gpu_warp':
+            unit = max(1, min(batch_size, total))
     shapes = ((total, oh, ow, 3), (total, h, w, 3), (total, h, w, 3), (total, mh, mw))
-    ranges = [(b0, min(b0 + chunk, total)) for b0 in range(0, total, chunk)]
-    # page-locked memory this call asks for: the staging buffers of its slots always (asynchronous copies need them), the result
-    # tensors only while everything stays under PINNED_POOL_BYTES
-    per_frame_in = 4 * (h * w * 3 + dshape[0] * dshape[1] * dshape[2])
-    nslot_frames = chunk * min(2, len(ranges)) + (total % chunk if total % chunk and len(ranges) > 1 else 0)
-    staging_bytes = nslot_frames * (per_frame_in + _small_bytes_per_frame(routes, oh, ow, h, w, mh, mw))
-    result_bytes = total * per_frame_out
-    if out is None and pinned_outputs and staging_bytes + result_bytes > PINNED_POOL_BYTES:
-        pinned_outputs = False
-    _pinned_budget(staging_bytes + (result_bytes if (out is None and pinned_outputs) else 0))
-    results = None   # helper thread that allocates the result tensors
-    final = None
+    # page-locked memory this call asks for (_plan_pinned): the staging buffers of its slots always (asynchronous copies need them)
+    # -- including, when the results are pageable, the staging copies of the float32-route outputs --, the result tensors only
+    # while everything stays under PINNED_POOL_BYTES
+    f32_per_frame = sum(4 * sz for sz, r in zip((oh * ow * 3, h * w * 3, h * w * 3, mh * mw), routes) if r == "f32")
     if out is not None:
         out = tuple(out)
         if len(out) != 4:
@@ -250,6 +277,18 @@ def generate_host(image, depth_map, divergence, separation, modes, stereo_balanc
         for t, sh in zip(out, shapes):
             if t.device.type != "cpu" or t.dtype != torch.float32 or tuple(t.shape) != sh or not t.is_contiguous():
                 raise ValueError(f"out tensors must be contiguous CPU float32 tensors of shapes {shapes}")
+    if out is None:
+        want = bool(pinned_outputs)
+    else:   # caller-provided results: pinned ones are written directly, pageable ones through the slots' staging copies
+        want = None if all(t.is_pinned() for t, r in zip(tuple(out), routes) if r == "f32") else False
+    chunk, staging_bytes, pinned_outputs = _plan_pinned(total, chunk, unit, per_frame_in,
+                                                        _small_bytes_per_frame(routes, oh, ow, h, w, mh, mw), f32_per_frame,
+                                                        per_frame_out, want)
+    ranges = [(b0, min(b0 + chunk, total)) for b0 in range(0, total, chunk)]
+    _pinned_budget(staging_bytes + (total * per_frame_out if pinned_outputs else 0))
+    results = None   # helper thread that allocates the result tensors
+    final = None
+    if out is not None:
         final = out
     else:
         # (pinned for the compact boundary too: the host threads then write into blocks that PyTorch's host allocator caches -- no
@@ -424,26 +463,31 @@ def prewarm(frames, h, w, depth_shape=None, modes="left-right", fill="polylines_
                                      20.0, 20.0, 2.0, 6, batch_size)
     oh, ow, mh, mw = engine.output_shape(p(1))
     kind = "warp" if fill == "gpu_warp" else "compact"
+    routes = ROUTES[kind]
+    per_frame_in = 4 * (h * w * 3 + dshape[0] * dshape[1] * dshape[2])
+    per_frame_out = 4 * (oh * ow * 3 + 2 * h * w * 3 + mh * mw)
+    unit = 1
     if kind == "compact":
-        per_frame_in = 4 * (h * w * 3 + dshape[0] * dshape[1] * dshape[2])
         chunk = max(1, min(frames, CHUNK_IN_BYTES // max(per_frame_in, 1)))
         if frames >= 4:
             chunk = min(chunk, (frames + 3) // 4)
     else:
-        chunk = _chunk_frames(frames, 4 * (oh * ow * 3 + 2 * h * w * 3 + mh * mw), fill, batch_size)
+        chunk = _chunk_frames(frames, per_frame_out, fill, batch_size)
+        unit = max(1, min(batch_size, frames))
     shapes = ((frames, oh, ow, 3), (frames, h, w, 3), (frames, h, w, 3), (frames, mh, mw))
+    f32_per_frame = sum(4 * sz for sz, r in zip((oh * ow * 3, h * w * 3, h * w * 3, mh * mw), routes) if r == "f32")
+    # (the decisions generate_host will take for this shape: same helper)
+    chunk, staging_bytes, pin_results = _plan_pinned(frames, chunk, unit, per_frame_in, _small_bytes_per_frame(routes, oh, ow, h, w, mh, mw),
+                                                     f32_per_frame, per_frame_out, True)
     nslots = min(2, (frames + chunk - 1) // chunk)
-    per_frame_in = 4 * (h * w * 3 + dshape[0] * dshape[1] * dshape[2])
-    staging_bytes = (chunk * nslots + frames % chunk) * (per_frame_in + _small_bytes_per_frame(ROUTES[kind], oh, ow, h, w, mh, mw))
-    result_bytes = 4 * frames * (oh * ow * 3 + 2 * h * w * 3 + mh * mw)
-    pin_results = staging_bytes + result_bytes <= PINNED_POOL_BYTES   # (what generate_host will decide for this shape)
-    _pinned_budget(staging_bytes + (result_bytes if pin_results else 0))
+    staged_f32 = "f32" in routes and not pin_results   # (pageable results: the float32 routes go through the slots' staging copies)
+    _pinned_budget(staging_bytes + (frames * per_frame_out if pin_results else 0))
     keep = []
     if pin_results:
         keep = [[torch.empty(sh, dtype=torch.float32, pin_memory=True) for sh in shapes] for _ in range(max(1, calls))]
-    keep.append([_Stage(p(chunk), dshape, device, ROUTES[kind], False) for _ in range(nslots)])
-    if frames % chunk:
-        keep.append(_Stage(p(frames % chunk), dshape, device, ROUTES[kind], False))
+    keep.append([_Stage(p(chunk), dshape, device, routes, staged_f32) for _ in range(nslots)])
+    if frames % chunk and (frames + chunk - 1) // chunk > 1:
+        keep.append(_Stage(p(frames % chunk), dshape, device, routes, staged_f32))
     torch.cuda.synchronize(device)
     del keep
     return True

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 3
+#define CS_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define CS_API __attribute__((visibility("default")))
@@ -117,6 +117,11 @@ CS_API int cs_max_width(int fill);
 /* The same for one output mode: the side-by-side / top-bottom / single-eye modes need 2 bytes less LDS per pixel than the
  * anaglyphs (cs_max_width is the anaglyph, i.e. smallest, limit). */
 CS_API int cs_max_width_mode(int fill, int mode);
+/* ABI 4: the widest frame cs_generate accepts with p's technique, mode, dialect flags (bits 3 / 4) and disparity parameters
+ * (p->w, p->h, p->n are ignored): the same predicate the call itself applies, so pre-validation cannot disagree with it.
+ * It can be lower than cs_max_width_mode -- e.g. an anaglyph of a polylines technique beyond the row kernel's own anaglyph
+ * form only passes while the tile kernels take it (halo within their reach, no full-D64 flag). */
+CS_API int cs_max_width_params(const cs_params *p);
 
 /* Shape of the outputs of cs_generate for `p`: stereoscope [n][*out_h][*out_w][3],
  * mask [n][*mask_h][*mask_w] (output-shaped for the CPU techniques, eye-shaped for gpu_warp). */

@@ -22,7 +22,7 @@ def test_library_is_built_and_exports_every_declared_symbol():
     assert len(syms) >= 14 and set(syms) == set(_native.EXPORTS)
     for s in syms:
         assert hasattr(L, s), s
-    assert L.cs_version() == _native.ABI_VERSION == 3
+    assert L.cs_version() == _native.ABI_VERSION == 4
 
 
 def test_enums_match_header():
@@ -82,6 +82,31 @@ def test_too_wide_frames_are_rejected_with_elimit():
     p.w = 64
     p.depth_w = 64
     assert L.cs_generate(ctypes.byref(p), fake, fake, fake, fake, fake, fake, fake, 16, None) == _native.CS_EWORKSPACE
+
+
+def test_max_width_params_is_the_predicate_cs_generate_applies():
+    """cs_max_width_mode reports the side-by-side limit for anaglyph polylines, but a call whose halo the tile kernels
+    do not take, or that carries the full-D64 flag, is refused between the row kernel's own anaglyph form and that limit.
+    cs_max_width_params (ABI 4) searches the SAME predicate cs_generate applies: at its answer the call passes the width gate
+    (and fails on the 16-byte workspace), one column beyond it the call is CS_ELIMIT -- for every technique, mode and dialect flag."""
+    L = _native.lib()
+    from comfystereo_amd import engine
+    fake = ctypes.c_void_p(16)
+    seen_lower = 0
+    for fill in sorted(_native.FILL):
+        for mode in ("left-right", "red-cyan-anaglyph", "top-bottom"):
+            for flags, div, conv in ((0, 3.0, 0.5), (8, 3.0, 0.5), (24, 3.0, 0.5), (0, 15.0, 1.0), (8, 15.0, 1.0)):
+                p = engine.make_params(1, 4, 64, 4, 64, 3, fill, mode, div, 0.0, 0.0, conv, 2.0, False, 20.0, 20.0, 1.0, 0, 12)
+                p.flags = flags
+                wmax = L.cs_max_width_params(ctypes.byref(p))
+                assert 3840 <= wmax <= L.cs_max_width_mode(p.fill, p.mode), (fill, mode, flags)
+                seen_lower += wmax < L.cs_max_width_mode(p.fill, p.mode)
+                for w, want in ((wmax, (_native.CS_EWORKSPACE, _native.CS_EINVAL)), (wmax + 1, (_native.CS_ELIMIT,))):
+                    p.w = p.depth_w = w
+                    rc = L.cs_generate(ctypes.byref(p), fake, fake, fake, fake, fake, fake, fake, 16, None)
+                    assert rc in want, (fill, mode, flags, div, w, rc, L.cs_last_error())
+    assert seen_lower > 0   # (the cases the advisor named exist: a pre-validation with cs_max_width_mode alone would have passed them)
+    assert L.cs_max_width_params(None) == 0
 
 
 def test_debug_switches_are_explicit_and_release_builds_reject_the_phase_cutoffs():

@@ -529,6 +529,29 @@ def test_4k_saturated_depth_stretch_replay_kernel_vs_oracle(engine, dev_switch):
 
 
 @pytest.mark.parametrize("fill,ui", [("polylines_soft", "Fill - Polylines Soft"), ("polylines_sharp", "Fill - Polylines Sharp")])
+def test_replay_pool_nearly_full_never_hands_out_overlapping_windows(engine, dev_switch, fill, ui):
+    """a row that finds the dump pool full gives its units back.  With a plain subtraction two failed rows
+    refunding around a successful one could hand a later row a window inside the successful row's live region (its stretches
+    were then replayed from another row's sorted points: silently wrong, nondeterministic pixels).  The refund is now one
+    compare-and-swap that only succeeds while the failed reservation is the topmost one.  A deliberately tiny pool
+    (cs_debug_set pt_variant 48: ~100 bytes per row) on saturated depth -- hundreds of flagged rows reserving at once, most of
+    them failing -- must give the oracle's bits, several runs in a row (the interleaving differs from run to run)."""
+    n, h, w = 4, 160, 2048
+    img = synth.image_f32(n, h, w, seed=77)
+    depth = np.stack([synth.clipped(1200, w, seed=s)[500:500 + h] for s in range(n)])[..., None].repeat(3, -1)
+    want = node_oracle.generate(img, depth, 7.0, 0.0, "left-right", 0.0, 0.5, 2.0, ui, 20.0, 20.0, False, batch_size=12)
+    p = engine.make_params(n, h, w, h, w, 3, fill, "left-right", 7.0, 0.0, 0.0, 0.5, 2.0, False, 20.0, 20.0, 1.0, 0, 12)
+    dev_switch("pt_variant", 48)
+    plan = engine.Plan(p, torch.device("cuda"))
+    dimg, ddepth = cuda(img), cuda(depth)
+    for rep in range(6):
+        got = [t.cpu().numpy() for t in plan.run(dimg, ddepth)]
+        assert int(plan.stats()[:, 10].sum()) > 0 and int(plan.stats()[:, 9].sum()) == 0
+        for g, w_, name in zip(got, want, NAMES):
+            assert np.array_equal(g, w_), (rep, name)
+
+
+@pytest.mark.parametrize("fill,ui", [("polylines_soft", "Fill - Polylines Soft"), ("polylines_sharp", "Fill - Polylines Sharp")])
 def test_lean_pass_on_the_flagged_tiles_column_ranges(engine, dev_switch, fill, ui):
     """Round 5: k_polypoint records WHICH tiles of a row-eye raised the hazard (tile hints) and the lean first pass of the row kernel
     stages, sorts, lists and evaluates only those tiles' columns plus a margin (technique_polylines, PolyRange) -- the rest of the row

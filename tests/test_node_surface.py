@@ -120,18 +120,41 @@ def test_prewarm_shape_is_opt_in_by_attribute_or_environment(monkeypatch):
     assert gs._prewarm_shape() == (8, 1080, 1920)
 
 
-def test_pinned_pool_cap_and_release_when_the_need_shrinks(monkeypatch):
-    """host_pipeline.PINNED_POOL_BYTES caps what the pipeline page-locks for itself; a call that needs less than the previous one
-    releases PyTorch's cached pinned blocks first (they would stay locked for ever otherwise)."""
+def test_pinned_pool_cap_release_with_hysteresis_and_staging_accounting(monkeypatch):
+    """host_pipeline.PINNED_POOL_BYTES caps what the pipeline page-locks for itself.  PyTorch never returns cached pinned blocks, so
+    the cache is released when the distinct needs served since the last release could no longer fit under the cap together -- and NOT
+    on every change of shape (alternating between two shapes re-pinned gigabytes per call).  The float32 routes'
+    staging copies (gpu_warp's colours when the results are pageable) are part of the accounting, and the chunk shrinks until
+    the staging alone fits; generate_host and prewarm use the same helper."""
     from comfystereo_amd import host_pipeline as hp
     assert hp.PINNED_POOL_BYTES <= 8 << 30
     calls = []
     monkeypatch.setattr(hp, "_release_pinned_cache", lambda: calls.append(1))
-    monkeypatch.setattr(hp, "_last_pinned_need", 0)
+    monkeypatch.setattr(hp, "_pinned_needs", set())
     hp._pinned_budget(4 << 30); assert not calls
     hp._pinned_budget(4 << 30); assert not calls
-    hp._pinned_budget(5 << 30); assert not calls
-    hp._pinned_budget(1 << 30); assert calls == [1]
+    hp._pinned_budget(1 << 30); assert not calls          # 4 + 1 GB: both shapes' blocks may stay cached
+    for _ in range(4):                                      # alternating between the two: nothing is released
+        hp._pinned_budget(4 << 30); hp._pinned_budget(1 << 30)
+    assert not calls
+    hp._pinned_budget(5 << 30); assert calls == [1]        # 4 + 1 + 5 GB would exceed the cap: release, start over
+    hp._pinned_budget(2 << 30); assert calls == [1]
+    # gpu_warp, 24 x 4K: float32 colours.  Pageable results -> each slot pins a staging copy of its chunk's stereoscope
+    h, w = 2160, 3840
+    fin = 4 * (h * w * 3 + h * w * 3)
+    small = hp._small_bytes_per_frame(hp.ROUTES["warp"], h, 2 * w, h, w, h, w)
+    f32 = 4 * h * 2 * w * 3
+    fout = 4 * (h * 2 * w * 3 + 2 * h * w * 3 + h * w)
+    chunk0 = hp._chunk_frames(24, fout, "gpu_warp", 4)
+    chunk, staging, pin = hp._plan_pinned(24, chunk0, 4, fin, small, f32, fout, True)
+    assert not pin and staging <= hp.PINNED_POOL_BYTES and chunk % 4 == 0 and chunk <= chunk0
+    nr = (24 + chunk - 1) // chunk
+    assert staging == (chunk * min(2, nr) + (24 % chunk if 24 % chunk and nr > 1 else 0)) * (fin + small + f32)
+    # a small batch fits with its results: pinned results, no staging copies counted
+    chunk, staging, pin = hp._plan_pinned(2, 2, 1, fin, small, f32, fout, True)
+    assert pin and staging == 2 * (fin + small)
+    # caller-provided pinned results (None): never "pin the results", no staging copies
+    assert hp._plan_pinned(2, 2, 1, fin, small, f32, fout, None) == (2, 2 * (fin + small), False)
     # compact output forms per 4K frame: stereoscope codes 2 x 3 bytes per pixel, two depth codes, the SBS mask's two
     assert hp._small_bytes_per_frame(hp.ROUTES["compact"], 2160, 7680, 2160, 3840, 2160, 7680) == 2160 * 3840 * (6 + 1 + 1 + 2)
 
