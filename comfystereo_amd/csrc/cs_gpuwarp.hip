@@ -609,6 +609,13 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
 // buffers, default gradient_threshold / max_stretch.
 // ---------------------------------------------------------------------------------------------------------------------
 struct GwQuad { float x, y, z, w; };
+// a scheduling fence between the columns of a lane: the loads of the next column are not hoisted above the arithmetic of this one
+// (four columns' taps in flight do not fit the 64 registers of the 8-waves-per-SIMD instantiation)
+#ifndef GWQ_NO_FENCE
+#define GWQ_FENCE() asm volatile("" ::: "memory")
+#else
+#define GWQ_FENCE()
+#endif
 static size_t gwq_bit_words(int w) { return (size_t)((w + 127) >> 7) << 2; }   // one bit per column, padded to 16 bytes
 static size_t gwq_lds_bytes(int w) { return 4 * (size_t)w * 4 + ((size_t)w + 24) * 4 + 2 * gwq_bit_words(w) * 4 + 32 * 4 + sizeof(csm::PowfTables) + 64; }
 
@@ -636,7 +643,10 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
         for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += nt) reinterpret_cast<uint32_t*>(T)[i] = src[i];
     }
     const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
-    const float scale = (A.scale_from_stats && st[ST_SCALE255]) ? 255.0f : 1.0f;
+    // wave-uniform values that come out of vector instructions (loaded statistics, float arithmetic) go back to scalar registers:
+    // the vector registers are the scarce ones here (64 at eight waves per SIMD)
+    auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    const float scale = (A.scale_from_stats && __builtin_amdgcn_readfirstlane((int)st[ST_SCALE255])) ? 255.0f : 1.0f;
     for (int q = tid; q < ((w + 3 * NR) >> 2) + (2 * nbw >> 2); q += nt) reinterpret_cast<int4*>(M)[q] = make_int4(0, 0, 0, 0);   // M, W0, W1, fbits, gbits
     // torch.linspace(-1, 1, H)[y] and its unnormalisation (as in k_gpuwarp)
     float gy;
@@ -647,25 +657,26 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
     float yy = (gy + 1.0f) * ((float)(h - 1) / 2.0f);
     yy = fminf(fmaxf(yy, 0.0f), (float)(h - 1));
     const float yn = floorf(yy);
-    const float wn = yy - yn, wsth = 1.0f - wn;
-    const int iy0 = (int)yn, iy1 = min(iy0 + 1, h - 1);
+    const float wn = uni(yy - yn), wsth = uni(1.0f - wn);
+    const int iy0 = __builtin_amdgcn_readfirstlane((int)yn), iy1 = min(iy0 + 1, h - 1);
     const float sxw = (float)(w - 1);
     const bool sxw_ok = w <= (1 << 20);   // the division core's denominator range (w >= 8 here)
-    const float ysx = sxw_ok ? gw_rcp_refined(sxw) : 0.0f;
+    const float ysx = uni(sxw_ok ? gw_rcp_refined(sxw) : 0.0f), sxw_half = uni(sxw / 2.0f);
     const bool lazy = A.tilemap != nullptr;
     const bool one_row = wn == 0.0f;      // the second image row of the blend has weight exactly zero
     __syncthreads();
 
     for (int e = 0; e < 2; e++) {
         const GwEye& E = A.eye[e];
-        const bool div255 = st[E.st_div] != 0;
-        float dmin = csm::ord2f(st[E.st_min]), dmax = csm::ord2f(st[E.st_max]);
-        if (div255) { dmin = dmin / 255.0f; dmax = dmax / 255.0f; }
-        const float range = dmax - dmin;
-        const float crange = fmaxf(range, (float)1e-6);
-        const bool has_range = range > (float)1e-6;
+        const bool div255 = __builtin_amdgcn_readfirstlane((int)st[E.st_div]) != 0;
+        float dmin_v = csm::ord2f(st[E.st_min]), dmax_v = csm::ord2f(st[E.st_max]);
+        if (div255) { dmin_v = dmin_v / 255.0f; dmax_v = dmax_v / 255.0f; }
+        const float dmin = uni(dmin_v);
+        const float range = dmax_v - dmin_v;
+        const float crange = uni(fmaxf(range, (float)1e-6));
+        const bool has_range = uni(range) > (float)1e-6;
         const bool crange_ok = crange < 0x1p40f;   // (>= 1e-6 by construction)
-        const float yr = crange_ok ? gw_rcp_refined(crange) : 0.0f;
+        const float yr = uni(crange_ok ? gw_rcp_refined(crange) : 0.0f);
         const char* const r0 = reinterpret_cast<const char*>(A.image + frame * A.img_sf + iy0 * A.img_sy);
         const char* const r1 = reinterpret_cast<const char*>(A.image + frame * A.img_sf + iy1 * A.img_sy);
         char* const out_row = reinterpret_cast<char*>(A.out + frame * A.out_sf + (y + E.yoff) * A.out_sy + E.xoff * 3);
@@ -680,32 +691,36 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
             if (w > 2048) Zhi = lazy_select(A.tilemap, A.tm_words, frame, h, y, 2048, drow + 4 * 2048, grow + 4 * 2048, st[ST_SCALE255]).bits;
         }
         // ---- stage (:300-328) + the pair pass of the scatter rounds (:330-391, see k_gpuwarp): M[v] = max{2 (i + 1) + connected : fs_i == v}
-        for (int gb = wave * 63; gb < G; gb += nwaves * 63) {
-            const int g = gb + lane;
-            const bool gv = g < G;
-            const uint32_t x0 = 4u * (uint32_t)(gv ? g : G - 1);   // (lanes past the row end repeat the last group and store nothing)
-            float dm = scale;
-            GwQuad dq;
-            if (lazy) {
-                const uint32_t bits = x0 >= 2048u ? Zhi : Z.bits;
-                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, x0 >> 6, 1u);   // 0 / ~0: the tile of these four columns
-                dm = __builtin_bit_cast(float, (m & Z.mul_set) | (~m & Z.mul_clr));
-                dq = *reinterpret_cast<const GwQuad*>(Z.base + (4u * x0 + (m & Z.delta)));
-            } else
-                dq = *reinterpret_cast<const GwQuad*>(drow + 4u * x0);
-            float v[4] = {dq.x * dm, dq.y * dm, dq.z * dm, dq.w * dm};
-            if (div255) {
-                asm volatile("" ::: "memory");   // (a real branch: the division is not worth speculating)
-#pragma unroll
-                for (int u = 0; u < 4; u++) v[u] = v[u] / 255.0f;
-            }
-            float nd[4], p[4], d[4];
+        // Global accesses stay column-strided (lane = column inside a block of 64: a wave's load or store covers whole lines; with the
+        // quad layout of the column pass every instruction touched four times as many lines, and the kernel ran 57 % slower,
+        // tools/sessions/r06_s2.sh).  A wave stages 256 consecutive columns as four blocks and owns the pairs of the first 252: the
+        // right operand of a pair is the next lane's column (DPP wave_shl:1), for lane 63 lane 0 of the wave's next block; the last
+        // four columns are staged again by the next wave (same values), so no pair crosses a wave.
+        for (int cb = wave * 252; cb < w; cb += nwaves * 252) {
+            float p[4], d[4];
+            float dv[4], dm[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const float num = v[u] - dmin;
+                const uint32_t x = (uint32_t)min(cb + 64 * u + lane, w - 1);
+                dm[u] = scale;
+                if (lazy) {
+                    LazySel Zs = Z;
+                    Zs.bits = x >= 2048u ? Zhi : Z.bits;
+                    dv[u] = lazy_load(Zs, x, x, dm[u]);
+                } else
+                    dv[u] = *reinterpret_cast<const float*>(drow + 4u * x);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int x = cb + 64 * u + lane;
+                float v = dv[u] * dm[u];
+                if (div255) {
+                    asm volatile("" ::: "memory");   // (a real branch: the division is not worth speculating)
+                    v = v / 255.0f;
+                }
+                const float num = v - dmin;
                 float nrm = gw_div_y(num, crange, yr, crange_ok);
                 nrm = has_range ? nrm : 0.0f;
-                nd[u] = nrm;
                 const float s = nrm - A.conv32;
                 float od;
                 if (POW == 2) od = s * fabsf(s);   // == sign(s) * (|s| * |s|): a product rounds independently of its sign
@@ -714,29 +729,27 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
                     od = sg * torch_pow(fabsf(s), A.pow_mode, A.e32, T);
                 }
                 p[u] = od * E.div32 + E.sep32;
-                d[u] = (float)(x0 + (uint32_t)u) + p[u];
+                d[u] = (float)x + p[u];
+                if (x < w) {
+                    ndn[x] = nrm;
+                    D[x] = d[u];
+                    const float vo = A.noclamp ? v : fminf(fmaxf(v, 0.0f), 1.0f);
+                    *reinterpret_cast<Px3*>(depth_out + 12u * (uint32_t)x) = Px3{vo, vo, vo};
+                }
             }
-            if (gv) {
-                *reinterpret_cast<GwQuad*>(ndn + x0) = GwQuad{nd[0], nd[1], nd[2], nd[3]};
-                *reinterpret_cast<GwQuad*>(D + x0) = GwQuad{d[0], d[1], d[2], d[3]};
-                float o[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) o[u] = A.noclamp ? v[u] : fminf(fmaxf(v[u], 0.0f), 1.0f);
-                GwQuad* dst = reinterpret_cast<GwQuad*>(depth_out + 12u * x0);
-                dst[0] = GwQuad{o[0], o[0], o[0], o[1]};
-                dst[1] = GwQuad{o[1], o[1], o[2], o[2]};
-                dst[2] = GwQuad{o[2], o[3], o[3], o[3]};
-            }
-            // the next lane's first column (lane 63 owns no pair: its group belongs to lane 0 of the next wave)
-            const float dnext = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d[0]), 0x130, 0xf, 0xf, false));
-            const float pnext = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p[0]), 0x130, 0xf, 0xf, false));
-            if (gv && lane < 63) {
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int i = (int)x0 + u;
-                    if (i >= w - 1) continue;
-                    const float dl = d[u], dr = u < 3 ? d[u < 3 ? u + 1 : 3] : dnext;
-                    const float pl = p[u], pr = u < 3 ? p[u < 3 ? u + 1 : 3] : pnext;
+            for (int u = 0; u < 4; u++) {
+                // the pair's right column: the next lane's; lane 63: lane 0 of the wave's next block (block 3: not owned)
+                float dr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d[u]), 0x130, 0xf, 0xf, false));
+                float pr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p[u]), 0x130, 0xf, 0xf, false));
+                if (u < 3) {
+                    const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d[u < 3 ? u + 1 : 3]), 0));
+                    const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p[u < 3 ? u + 1 : 3]), 0));
+                    dr = lane == 63 ? d0 : dr; pr = lane == 63 ? p0 : pr;
+                }
+                const int i = cb + 64 * u + lane;
+                if (i < w - 1 && (u < 3 || lane < 60)) {
+                    const float dl = d[u], pl = p[u];
                     const float fs = floorf(fminf(dl, dr));
                     const bool connected = fabsf(pr - pl) < 1.5f;
                     const int key = 2 * (i + 1) + (connected ? 1 : 0);
@@ -778,7 +791,7 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
             // entry j: the deciding pair with fs == x0 - 3 + j; column x0 + u meets it in round k = u + 3 - j
             const int4 e0 = *reinterpret_cast<const int4*>(M + x0 + 4), e1 = *reinterpret_cast<const int4*>(M + x0 + 8);
             const int key[7] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z};
-            float dl[7], safe[7], lim[7];
+            float dl[7], safe[7];
 #pragma unroll
             for (int j = 0; j < 7; j++) {
                 // (entry 0 = "no pair" reads D[-1], D[0] and fails the connected bit)
@@ -787,7 +800,6 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
                 const float sw = b - a;
                 dl[j] = a;
                 safe[j] = fabsf(sw) < (float)1e-4 ? 1.0f : sw;
-                lim[j] = 1.001f * fabsf(safe[j]);
             }
             float z[4], src[4];
 #pragma unroll
@@ -801,7 +813,7 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
                     const int j = u + 3 - k;
                     const float num = cfl - dl[j];
                     // (conservative filter, the exact test is `valid`: see k_gpuwarp)
-                    const bool maybe = interior & ((key[j] & 1) != 0) & !(num * safe[j] < 0.0f) & !(fabsf(num) >= lim[j]);
+                    const bool maybe = interior & ((key[j] & 1) != 0) & !(num * safe[j] < 0.0f) & !(fabsf(num) >= 1.001f * fabsf(safe[j]));
                     if (maybe) {
                         const int i = (key[j] >> 1) - 1;
                         const float frac = gw_div(num, safe[j]);
@@ -876,58 +888,58 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
             const float pos = fminf(fmaxf(s, 0.0f), sxw);
             const float p2 = pos * 2.0f;
             float gx = gw_div_y(p2, sxw, ysx, sxw_ok) - 1.0f;
-            float xx = (gx + 1.0f) * (sxw / 2.0f);
+            float xx = (gx + 1.0f) * sxw_half;
             xx = fminf(fmaxf(xx, 0.0f), sxw);
             const float xw = floorf(xx);
             ww = xx - xw; we = 1.0f - ww;
             ix0 = (int)xw; ix1 = min(ix0 + 1, w - 1);
         };
-        for (int g = tid; g < G; g += nt) {
-            const int x0 = 4 * g;
-            const GwQuad sq = *reinterpret_cast<const GwQuad*>(sm + x0);
-            const float sv[4] = {sq.x, sq.y, sq.z, sq.w};
-            Px3 r[4];
-            if (one_row) {
-                // wn == 0: the taps of row iy1 carry the weights 0 * we and 0 * ww -- x + 0 * p == x for finite p
+        // (column-strided like the stage: a wave's gathers and 12-byte stores cover neighbouring columns)
+        if (one_row) {
+            // wn == 0: the taps of row iy1 carry the weights 0 * we and 0 * ww -- x + 0 * p == x for finite p
+            constexpr int NC = MINW < 8 ? 2 : 1;   // columns in flight per lane
+            for (int xb = tid; xb < w; xb += NC * nt) {
+                int ix0[NC], ix1[NC]; float ww[NC], we[NC];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    int ix0, ix1; float ww, we;
-                    taps_of(x0 + u, sv[u], ix0, ix1, ww, we);
-                    const Px3 pa = *reinterpret_cast<const Px3*>(r0 + 12u * (uint32_t)ix0), pb = *reinterpret_cast<const Px3*>(r0 + 12u * (uint32_t)ix1);
-                    const float nw = wsth * we, ne = wsth * ww;   // (wsth == 1)
-                    r[u].x = pa.x * nw + pb.x * ne;
-                    r[u].y = pa.y * nw + pb.y * ne;
-                    r[u].z = pa.z * nw + pb.z * ne;
+                for (int c = 0; c < NC; c++) { const int x = min(xb + c * nt, w - 1); taps_of(x, sm[x], ix0[c], ix1[c], ww[c], we[c]); }
+                Px3 pa[NC], pb[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    pa[c] = *reinterpret_cast<const Px3*>(r0 + 12u * (uint32_t)ix0[c]); pb[c] = *reinterpret_cast<const Px3*>(r0 + 12u * (uint32_t)ix1[c]);
                 }
-            } else {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    int ix0, ix1; float ww, we;
-                    taps_of(x0 + u, sv[u], ix0, ix1, ww, we);
-                    const uint32_t a0 = 12u * (uint32_t)ix0, a1 = 12u * (uint32_t)ix1;
-                    const Px3 pa = *reinterpret_cast<const Px3*>(r0 + a0), pb = *reinterpret_cast<const Px3*>(r0 + a1),
-                              pc = *reinterpret_cast<const Px3*>(r1 + a0), pd = *reinterpret_cast<const Px3*>(r1 + a1);
-                    const float nw = wsth * we, ne = wsth * ww, sw2 = wn * we, se = wn * ww;
-                    r[u].x = pa.x * nw + pb.x * ne + pc.x * sw2 + pd.x * se;
-                    r[u].y = pa.y * nw + pb.y * ne + pc.y * sw2 + pd.y * se;
-                    r[u].z = pa.z * nw + pb.z * ne + pc.z * sw2 + pd.z * se;
+                for (int c = 0; c < NC; c++) {
+                    const int x = xb + c * nt;
+                    if (x >= w) continue;
+                    const float nw = wsth * we[c], ne = wsth * ww[c];   // (wsth == 1)
+                    Px3 r;
+                    r.x = pa[c].x * nw + pb[c].x * ne;
+                    r.y = pa[c].y * nw + pb[c].y * ne;
+                    r.z = pa[c].z * nw + pb[c].z * ne;
+                    *reinterpret_cast<Px3*>(out_row + 12u * (uint32_t)x) = r;
                 }
             }
-            GwQuad* dst = reinterpret_cast<GwQuad*>(out_row + 12u * (uint32_t)x0);
-            dst[0] = GwQuad{r[0].x, r[0].y, r[0].z, r[1].x};
-            dst[1] = GwQuad{r[1].y, r[1].z, r[2].x, r[2].y};
-            dst[2] = GwQuad{r[2].z, r[3].x, r[3].y, r[3].z};
+        } else {
+            for (int x = tid; x < w; x += nt) {
+                int ix0, ix1; float ww, we;
+                taps_of(x, sm[x], ix0, ix1, ww, we);
+                const uint32_t a0 = 12u * (uint32_t)ix0, a1 = 12u * (uint32_t)ix1;
+                const Px3 pa = *reinterpret_cast<const Px3*>(r0 + a0), pb = *reinterpret_cast<const Px3*>(r0 + a1),
+                          pc = *reinterpret_cast<const Px3*>(r1 + a0), pd = *reinterpret_cast<const Px3*>(r1 + a1);
+                const float nw = wsth * we, ne = wsth * ww, sw2 = wn * we, se = wn * ww;
+                Px3 r;
+                r.x = pa.x * nw + pb.x * ne + pc.x * sw2 + pd.x * se;
+                r.y = pa.y * nw + pb.y * ne + pc.y * sw2 + pd.y * se;
+                r.z = pa.z * nw + pb.z * ne + pc.z * sw2 + pd.z * se;
+                *reinterpret_cast<Px3*>(out_row + 12u * (uint32_t)x) = r;
+            }
         }
         __syncthreads();
         if (e == 0)   // (this eye's filled bits; the gap bits accumulate over the eyes)
             for (int q = tid; q < (nbw >> 2); q += nt) reinterpret_cast<int4*>(fbits)[q] = make_int4(0, 0, 0, 0);
     }
     float* const mrow = A.mask_f32 + ((size_t)frame * h + y) * w;
-    for (int g = tid; g < G; g += nt) {
-        const int x0 = 4 * g;
-        const uint32_t nib = gbits[x0 >> 5] >> (x0 & 31);
-        *reinterpret_cast<GwQuad*>(mrow + x0) = GwQuad{(nib & 1u) ? 1.0f : 0.0f, (nib & 2u) ? 1.0f : 0.0f, (nib & 4u) ? 1.0f : 0.0f, (nib & 8u) ? 1.0f : 0.0f};
-    }
+    for (int x = tid; x < w; x += nt) mrow[x] = ((gbits[x >> 5] >> (x & 31)) & 1u) ? 1.0f : 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1254,6 +1266,27 @@ static int gw_launch(GwArgs& A, hipStream_t stream) {
                                   : (pow2 ? (const void*)k_gpuwarp<6, 2, false, true> : (const void*)k_gpuwarp<6, -1, false, true>))
                           : wide ? (pow2 ? (const void*)k_gpuwarp<8, 2> : (const void*)k_gpuwarp<8, -1>)
                                  : (pow2 ? (const void*)k_gpuwarp<6, 2> : (const void*)k_gpuwarp<6, -1>);
+    // (round 6) the node's layout with four contiguous columns per lane: k_gpuwarp_q.  CS_DEBUG_PT_VARIANT 27: k_gpuwarp as before
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    const bool quad = node && forced != 27 && A.neyes == 2 && A.eye[0].enabled && A.eye[1].enabled && (A.w & 3) == 0 && A.w >= 8 &&
+                      A.depth_l && A.depth_r && A.mask_f32 && !A.mask_u8 && al16(A.out) && al16(A.depth_l) && al16(A.depth_r) &&
+                      al16(A.mask_f32) && al16(A.eye[0].depth) && al16(A.eye[1].depth) && (!A.tilemap || al16(A.gray));
+    if (quad) {
+        size_t lq = gwq_lds_bytes(A.w);
+        if (A.pow_mode != 4) lq -= sizeof(csm::PowfTables) + 64;
+        const bool four_q = threads == 512 && 4 * ((lq + 511) & ~(size_t)511) <= CS_LDS_BYTES && forced != 24;
+        const bool wide_q = threads > 512 || four_q;
+        const void* fq = wide_q ? (pow2 ? (const void*)k_gpuwarp_q<8, 2> : (const void*)k_gpuwarp_q<8, -1>)
+                                : (pow2 ? (const void*)k_gpuwarp_q<6, 2> : (const void*)k_gpuwarp_q<6, -1>);
+        hipError_t eq = hipFuncSetAttribute(fq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);
+        if (eq != hipSuccess) return CS_EHIP;
+        const dim3 grid(A.h, A.n), block(threads);
+        if (wide_q && pow2) hipLaunchKernelGGL((k_gpuwarp_q<8, 2>), grid, block, lq, stream, A);
+        else if (wide_q) hipLaunchKernelGGL((k_gpuwarp_q<8, -1>), grid, block, lq, stream, A);
+        else if (pow2) hipLaunchKernelGGL((k_gpuwarp_q<6, 2>), grid, block, lq, stream, A);
+        else hipLaunchKernelGGL((k_gpuwarp_q<6, -1>), grid, block, lq, stream, A);
+        return CS_OK;
+    }
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return CS_EHIP;
 #ifdef GW_XCD_ROWS
