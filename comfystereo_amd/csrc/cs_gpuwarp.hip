@@ -54,8 +54,12 @@ struct GwArgs {
     // lazy depth-blur tiles (cs_common.h lazy_select; rows of at most 2048 columns, scatter-round warp only): the blurred maps
     // only hold the tiles the map names, everything else is gray * (the frame's x255 scale)
     const uint32_t* tilemap; const float* gray; int tm_words;
+    // (round 6) per-frame constants of k_gpuwarp_q, written by k_gpuwarp_flags: GWC_WORDS floats per frame (see there)
+    const float* fconst;
+    float lin_step;    // 2 / (h - 1): the step of torch.linspace(-1, 1, h) (IEEE division on the host)
 };
 
+enum { GWC_EYE = 4, GWC_YSX = 8, GWC_SCALE = 9, GWC_S255 = 10, GWC_WORDS = 16 };   // per-frame constants of k_gpuwarp_q (k_gpuwarp_flags writes them)
 struct Px3 { float x, y, z; };
 #ifdef CS_DEV
 #define GW_DEV_IS(n) (A.dbg == (n))
@@ -473,6 +477,10 @@ __global__ void __launch_bounds__(1024) k_gpuwarp(GwArgs A) {
             }
         };
         if (GW_DEV_IS(54)) { __syncthreads(); continue; }
+        if (GW_DEV_IS(60)) {   // (development: the row's intermediate state instead of colours)
+            for (int x = tid; x < w; x += nt) *reinterpret_cast<Px3*>(reinterpret_cast<char*>(out_row) + 12u * (uint32_t)x) = Px3{((float*)winner)[x], D[x], sm[x]};
+            __syncthreads(); continue;
+        }
         // final source position of column x (gap fill :393-438), then the bilinear taps of the grid_sample round trip (:440-448)
         struct Taps { int ix0, ix1; float nw, ne, sw2, se; };
         auto taps_of = [&](int x) {
@@ -619,67 +627,84 @@ struct GwQuad { float x, y, z, w; };
 static size_t gwq_bit_words(int w) { return (size_t)((w + 127) >> 7) << 2; }   // one bit per column, padded to 16 bytes
 static size_t gwq_lds_bytes(int w) { return 4 * (size_t)w * 4 + ((size_t)w + 24) * 4 + 2 * gwq_bit_words(w) * 4 + 32 * 4 + sizeof(csm::PowfTables) + 64; }
 
+// LDS carve-up of k_gpuwarp_q, re-derived at the top of EVERY phase from an opaque copy of the width: what the compiler hoists out
+// of the loops (a dozen LDS addresses, loop bounds, lane masks) is then recomputed per phase with a few scalar instructions instead of
+// being carried across the kernel -- it held ~170 scalars live and spilled 90 of them into vector lanes (v_writelane / v_readlane are
+// vector instructions: 50 in the prologue alone)
+struct GwqLds {
+    float *ndn, *D, *zb, *sm;   // [w] each: normalised depth (not convergence-shifted); x + offset (D[-1] is readable: table entry 0); z-buffer; source map
+    int *M, *W0, *W1;           // [w + NR] highest (2 (i + 1) + connected) per floor(min(dl, dr)) = -(NR - 1) .. w - 2; [NR] each: the pairs clamped to column 0 / w - 1, per round
+    uint32_t *fbits, *gbits;    // one bit per column: filled by this eye's column pass; gap in some eye (the mask output)
+    int* ws;
+    csm::PowfTables* T;
+    int w, nbw, frame, y;
+};
+__device__ __forceinline__ GwqLds gwq_carve(char* smem, int w_arg) {
+    constexpr int NR = 8;
+    GwqLds L;
+    int w = w_arg, lds0 = 0, fr = blockIdx.y, yy = blockIdx.x;   // (an opaque OFFSET: the pointer itself must keep its LDS address space)
+    asm volatile("" : "+s"(w), "+s"(lds0), "+s"(fr), "+s"(yy));
+    L.w = w; L.nbw = ((w + 127) >> 7) << 2; L.frame = fr; L.y = yy;
+    L.ndn = (float*)(smem + lds0); L.D = L.ndn + w; L.zb = L.D + w; L.sm = L.zb + w;
+    L.M = (int*)(L.sm + w); L.W0 = L.M + w + NR; L.W1 = L.W0 + NR;
+    L.fbits = (uint32_t*)(L.W1 + NR); L.gbits = L.fbits + L.nbw;
+    L.ws = (int*)(L.gbits + L.nbw);
+    L.T = (csm::PowfTables*)(L.ws + 32);
+    return L;
+}
+
 template <int MINW, int POW>
 __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
     constexpr int NR = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
-    const int y = blockIdx.x, frame = blockIdx.y, w = A.w, h = A.h, G = w >> 2;
-    const int nbw = ((w + 127) >> 7) << 2;
-    float* const ndn = (float*)smem;      // [w] normalised depth (not convergence-shifted)
-    float* const D = ndn + w;             // [w] x + offset = dl of pair x = dr of pair x - 1   (D[-1] is readable: table entry 0)
-    float* const zb = D + w;              // [w] z-buffer
-    float* const sm = zb + w;             // [w] source map
-    int* const M = (int*)(sm + w);        // [w + NR] highest (2 (i + 1) + connected) per floor(min(dl, dr)) = -(NR - 1) .. w - 2
-    int* const W0 = M + w + NR;           // [NR] per round: the same for the pairs clamped to column 0
-    int* const W1 = W0 + NR;              // [NR] ... to column w - 1
-    uint32_t* const fbits = (uint32_t*)(W1 + NR);   // filled by this eye's column pass, one bit per column
-    uint32_t* const gbits = fbits + nbw;            // gap in some eye (the mask output)
-    int* const ws = (int*)(gbits + nbw);
-    csm::PowfTables* const T = (csm::PowfTables*)(ws + 32);
-    if (POW != 2 && A.pow_mode == 4) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_gw_powf_tables);
-        for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += nt) reinterpret_cast<uint32_t*>(T)[i] = src[i];
-    }
-    const uint32_t* st = A.stats + (size_t)frame * ST_WORDS;
-    // wave-uniform values that come out of vector instructions (loaded statistics, float arithmetic) go back to scalar registers:
-    // the vector registers are the scarce ones here (64 at eight waves per SIMD)
+    const int h = A.h;
     auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-    const float scale = (A.scale_from_stats && __builtin_amdgcn_readfirstlane((int)st[ST_SCALE255])) ? 255.0f : 1.0f;
-    for (int q = tid; q < ((w + 3 * NR) >> 2) + (2 * nbw >> 2); q += nt) reinterpret_cast<int4*>(M)[q] = make_int4(0, 0, 0, 0);   // M, W0, W1, fbits, gbits
-    // torch.linspace(-1, 1, H)[y] and its unnormalisation (as in k_gpuwarp)
-    float gy;
+    float wn, wsth, sxw_half, ysx, scale;
+    uint32_t s255;
+    int iy0;
     {
-        float step = h > 1 ? 2.0f / (float)(h - 1) : 0.0f;
-        gy = y < h / 2 ? fmaf(step, (float)y, -1.0f) : fmaf(-step, (float)(h - y - 1), 1.0f);
+        const GwqLds L = gwq_carve(smem, A.w);
+        const int w = L.w, y = L.y;
+        if (POW != 2 && A.pow_mode == 4) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&c_gw_powf_tables);
+            for (int i = tid; i < (int)(sizeof(csm::PowfTables) / 4); i += nt) reinterpret_cast<uint32_t*>(L.T)[i] = src[i];
+        }
+        // the frame's constants (k_gpuwarp_flags), by SCALAR loads: they are wave-uniform, and a vector load + readfirstlane per
+        // value -- what the compiler makes of a load it cannot prove unclobbered -- is vector issue this kernel does not have to spare
+        // (one 32-bit output per value: a 4-vector asm output whose elements are bit-cast to float is miscompiled by this hipcc -- the
+        // constant-bus legalisation of an instruction with two of them reads element 0 twice; tools/sessions/r06_s7*.py found it)
+        asm volatile("s_load_dword %0, %3, 0x20\n\ts_load_dword %1, %3, 0x24\n\ts_load_dword %2, %3, 0x28\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(ysx), "=&s"(scale), "=&s"(s255) : "s"(A.fconst + (size_t)L.frame * GWC_WORDS) : "memory");
+        for (int q = tid; q < ((w + 3 * NR) >> 2) + (2 * L.nbw >> 2); q += nt) reinterpret_cast<int4*>(L.M)[q] = make_int4(0, 0, 0, 0);   // M, W0, W1, fbits, gbits
+        // torch.linspace(-1, 1, H)[y] and its unnormalisation (as in k_gpuwarp; the step is an IEEE division on the host)
+        const float step = A.lin_step;
+        const float gy = y < h / 2 ? fmaf(step, (float)y, -1.0f) : fmaf(-step, (float)(h - y - 1), 1.0f);
+        float yy = (gy + 1.0f) * ((float)(h - 1) / 2.0f);
+        yy = fminf(fmaxf(yy, 0.0f), (float)(h - 1));
+        const float yn = floorf(yy);
+        wn = uni(yy - yn); wsth = uni(1.0f - wn);
+        iy0 = __builtin_amdgcn_readfirstlane((int)yn);
+        sxw_half = uni((float)(w - 1) / 2.0f);
     }
-    float yy = (gy + 1.0f) * ((float)(h - 1) / 2.0f);
-    yy = fminf(fmaxf(yy, 0.0f), (float)(h - 1));
-    const float yn = floorf(yy);
-    const float wn = uni(yy - yn), wsth = uni(1.0f - wn);
-    const int iy0 = __builtin_amdgcn_readfirstlane((int)yn), iy1 = min(iy0 + 1, h - 1);
-    const float sxw = (float)(w - 1);
-    const bool sxw_ok = w <= (1 << 20);   // the division core's denominator range (w >= 8 here)
-    const float ysx = uni(sxw_ok ? gw_rcp_refined(sxw) : 0.0f), sxw_half = uni(sxw / 2.0f);
     const bool lazy = A.tilemap != nullptr;
     const bool one_row = wn == 0.0f;      // the second image row of the blend has weight exactly zero
     __syncthreads();
 
     for (int e = 0; e < 2; e++) {
         const GwEye& E = A.eye[e];
-        const bool div255 = __builtin_amdgcn_readfirstlane((int)st[E.st_div]) != 0;
-        float dmin_v = csm::ord2f(st[E.st_min]), dmax_v = csm::ord2f(st[E.st_max]);
-        if (div255) { dmin_v = dmin_v / 255.0f; dmax_v = dmax_v / 255.0f; }
-        const float dmin = uni(dmin_v);
-        const float range = dmax_v - dmin_v;
-        const float crange = uni(fmaxf(range, (float)1e-6));
-        const bool has_range = uni(range) > (float)1e-6;
-        const bool crange_ok = crange < 0x1p40f;   // (>= 1e-6 by construction)
-        const float yr = uni(crange_ok ? gw_rcp_refined(crange) : 0.0f);
-        const char* const r0 = reinterpret_cast<const char*>(A.image + frame * A.img_sf + iy0 * A.img_sy);
-        const char* const r1 = reinterpret_cast<const char*>(A.image + frame * A.img_sf + iy1 * A.img_sy);
-        char* const out_row = reinterpret_cast<char*>(A.out + frame * A.out_sf + (y + E.yoff) * A.out_sy + E.xoff * 3);
+      {
+        const GwqLds L = gwq_carve(smem, A.w);
+        const int w = L.w, frame = L.frame, y = L.y;
+        float* const ndn = L.ndn; float* const D = L.D; int* const M = L.M; int* const W0 = L.W0; int* const W1 = L.W1;
+        csm::PowfTables* const T = L.T;
+        const float sxw = (float)(w - 1);
+        float dmin, crange, yr;
+        uint32_t eflags;
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x4\n\ts_load_dword %2, %4, 0x8\n\ts_load_dword %3, %4, 0xc\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(dmin), "=&s"(crange), "=&s"(yr), "=&s"(eflags) : "s"(A.fconst + (size_t)frame * GWC_WORDS + GWC_EYE * e) : "memory");
+        const bool has_range = (eflags & 1u) != 0, crange_ok = (eflags & 2u) != 0, div255 = (eflags & 4u) != 0;
         const char* const drow = reinterpret_cast<const char*>(E.depth + ((size_t)frame * h + y) * w);
         char* const depth_out = reinterpret_cast<char*>((e == 0 ? A.depth_l : A.depth_r) + (((size_t)frame * h + y) * w) * 3);
         LazySel Z;
@@ -687,8 +712,8 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
         Z.base = nullptr; Z.bits = 0; Z.delta = 0; Z.mul_set = Z.mul_clr = 0;
         if (lazy) {
             const char* grow = reinterpret_cast<const char*>(A.gray + ((size_t)frame * h + y) * w);
-            Z = lazy_select(A.tilemap, A.tm_words, frame, h, y, 0, drow, grow, st[ST_SCALE255]);
-            if (w > 2048) Zhi = lazy_select(A.tilemap, A.tm_words, frame, h, y, 2048, drow + 4 * 2048, grow + 4 * 2048, st[ST_SCALE255]).bits;
+            Z = lazy_select(A.tilemap, A.tm_words, frame, h, y, 0, drow, grow, s255);
+            if (w > 2048) Zhi = lazy_select(A.tilemap, A.tm_words, frame, h, y, 2048, drow + 4 * 2048, grow + 4 * 2048, s255).bits;
         }
         // ---- stage (:300-328) + the pair pass of the scatter rounds (:330-391, see k_gpuwarp): M[v] = max{2 (i + 1) + connected : fs_i == v}
         // Global accesses stay column-strided (lane = column inside a block of 64: a wave's load or store covers whole lines; with the
@@ -765,9 +790,15 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
                 }
             }
         }
+      }
         __syncthreads();
-        if (GW_DEV_IS(52)) { __syncthreads(); continue; }
+        if (GW_DEV_IS(52)) { __syncthreads(); __syncthreads(); continue; }
         // ---- column pass: the z-tests of rounds 0 .. 3 in order (see k_gpuwarp), four columns per lane
+      {
+        const GwqLds L = gwq_carve(smem, A.w);
+        const int w = L.w, G = w >> 2;
+        float* const ndn = L.ndn; float* const D = L.D; float* const zb = L.zb; float* const sm = L.sm;
+        int* const M = L.M; int* const W0 = L.W0; int* const W1 = L.W1;
         auto propose = [&](int key, float cfl, float& z, float& src) {   // the clamped columns (k_gpuwarp's form)
             const int i = max((key >> 1) - 1, 0);
             const float dl = D[i], dr = D[i + 1];
@@ -827,7 +858,6 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
                 }
             }
             if (g == 0 || g == G - 1) {   // the clamped columns 0 and w - 1: the deciding pair's own fs + k decides whether it is in range at all
-                const int u = g == 0 ? 0 : 3;
                 float zz = -1.0f, ss = -1.0f;
                 for (int k = 0; k < 4; k++) {
                     const int kk = g == 0 ? W0[k] : W1[k];
@@ -836,7 +866,7 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
                         propose(kk, floorf(fminf(D[i], D[i + 1])) + (float)k, zz, ss);
                     }
                 }
-                if (u == 0) { z[0] = zz; src[0] = ss; } else { z[3] = zz; src[3] = ss; }
+                if (g == 0) { z[0] = zz; src[0] = ss; } else { z[3] = zz; src[3] = ss; }
             }
             *reinterpret_cast<GwQuad*>(zb + x0) = GwQuad{z[0], z[1], z[2], z[3]};
             *reinterpret_cast<GwQuad*>(sm + x0) = GwQuad{src[0], src[1], src[2], src[3]};
@@ -845,19 +875,29 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
             for (int u = 0; u < 4; u++)
                 if (!(src[u] < 0.0f)) { nib |= 1u << u; myright = x0 + u; }
             const uint32_t sh = (uint32_t)x0 & 31u;
-            if (nib) atomicOr(&fbits[x0 >> 5], nib << sh);
-            if (nib != 15u) atomicOr(&gbits[x0 >> 5], (nib ^ 15u) << sh);
+            if (nib) atomicOr(&L.fbits[x0 >> 5], nib << sh);
+            if (nib != 15u) atomicOr(&L.gbits[x0 >> 5], (nib ^ 15u) << sh);
         }
         if (GW_DEV_IS(53)) { __syncthreads(); __syncthreads(); continue; }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) myright = max(myright, __shfl_xor(myright, off));
-        if (lane == 0) ws[16 + wave] = myright;
+        // the row's rightmost filled column: maximum over the wave (DPP), then over the waves
+        myright = wave_incl_max(myright);
+        if (lane == 63) L.ws[16 + wave] = myright;
+      }
         __syncthreads();
-        int rightmost = -1;
-        for (int i = 0; i < nwaves; i++) rightmost = max(rightmost, ws[16 + i]);
+      {
+        const GwqLds L = gwq_carve(smem, A.w);
+        const int w = L.w, frame = L.frame, y = L.y;
+        const float* const zb = L.zb; const float* const sm = L.sm; const uint32_t* const fbits = L.fbits;
+        const int rightmost = __builtin_amdgcn_readlane(wave_incl_max(lane < nwaves ? L.ws[16 + lane] : -1), 63);
         // the table of the next eye (every read of this eye's is behind the barrier above)
-        for (int q = tid; q < ((w + 3 * NR) >> 2); q += nt) reinterpret_cast<int4*>(M)[q] = make_int4(0, 0, 0, 0);
+        for (int q = tid; q < ((w + 3 * NR) >> 2); q += nt) reinterpret_cast<int4*>(L.M)[q] = make_int4(0, 0, 0, 0);
         if (GW_DEV_IS(54)) { __syncthreads(); continue; }
+        const float sxw = (float)(w - 1);
+        const bool sxw_ok = w <= (1 << 20);   // the division core's denominator range (w >= 8 here)
+        const int iy1 = min(iy0 + 1, h - 1);
+        const char* const r0 = reinterpret_cast<const char*>(A.image + frame * A.img_sf + iy0 * A.img_sy);
+        const char* const r1 = reinterpret_cast<const char*>(A.image + frame * A.img_sf + iy1 * A.img_sy);
+        char* const out_row = reinterpret_cast<char*>(A.out + frame * A.out_sf + (y + E.yoff) * A.out_sy + E.xoff * 3);
         auto left_filled = [&](int x) {
             if (x <= 0) return -1;
             int wi = (x - 1) >> 5;
@@ -894,6 +934,10 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
             ww = xx - xw; we = 1.0f - ww;
             ix0 = (int)xw; ix1 = min(ix0 + 1, w - 1);
         };
+        if (GW_DEV_IS(60)) {   // (development: the row's intermediate state instead of colours)
+            for (int x = tid; x < w; x += nt) *reinterpret_cast<Px3*>(out_row + 12u * (uint32_t)x) = Px3{L.ndn[x], L.D[x], sm[x]};
+            __syncthreads(); continue;
+        }
         // (column-strided like the stage: a wave's gathers and 12-byte stores cover neighbouring columns)
         if (one_row) {
             // wn == 0: the taps of row iy1 carry the weights 0 * we and 0 * ww -- x + 0 * p == x for finite p
@@ -934,12 +978,19 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
                 *reinterpret_cast<Px3*>(out_row + 12u * (uint32_t)x) = r;
             }
         }
+      }
         __syncthreads();
-        if (e == 0)   // (this eye's filled bits; the gap bits accumulate over the eyes)
-            for (int q = tid; q < (nbw >> 2); q += nt) reinterpret_cast<int4*>(fbits)[q] = make_int4(0, 0, 0, 0);
+        if (e == 0) {   // (this eye's filled bits; the gap bits accumulate over the eyes)
+            const GwqLds L = gwq_carve(smem, A.w);
+            for (int q = tid; q < (L.nbw >> 2); q += nt) reinterpret_cast<int4*>(L.fbits)[q] = make_int4(0, 0, 0, 0);
+        }
     }
-    float* const mrow = A.mask_f32 + ((size_t)frame * h + y) * w;
-    for (int x = tid; x < w; x += nt) mrow[x] = ((gbits[x >> 5] >> (x & 31)) & 1u) ? 1.0f : 0.0f;
+    {
+        const GwqLds L = gwq_carve(smem, A.w);
+        const int w = L.w;
+        float* const mrow = A.mask_f32 + ((size_t)L.frame * h + L.y) * w;
+        for (int x = tid; x < w; x += nt) mrow[x] = ((L.gbits[x >> 5] >> (x & 31)) & 1u) ? 1.0f : 0.0f;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1172,7 +1223,11 @@ __global__ void __launch_bounds__(1024, MINW) k_meshwarp(GwArgs A) {
 
 // forward_warp_gpu's `if (d_max_all > 1.0).any(): d = d / 255.0` is global over the tensor it is handed,
 // i.e. over one reference sub-batch (`group` frames).
-__global__ void k_gpuwarp_flags(uint32_t* stats, int n, int group) {
+// (round 6) ... and the wave-uniform constants k_gpuwarp_q would otherwise derive in every wave of every row (two IEEE divisions, the
+// refined reciprocals, the key decoding: ~170 of the 470 vector instructions a wave spent per eye on 3.75 columns): per frame
+// GWC_WORDS floats -- per eye {dmin, clamped range, its refined reciprocal, flags: bit 0 has_range, bit 1 range inside the division
+// core's reach, bit 2 divide by 255}, then the refined reciprocal of w - 1, the scale the kernel multiplies with, the frame's x255 flag.
+__global__ void k_gpuwarp_flags(uint32_t* stats, int n, int group, float* fconst, int w, int scale_from_stats) {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
     int g0 = (f / group) * group, g1 = min(g0 + group, n);
@@ -1183,6 +1238,26 @@ __global__ void k_gpuwarp_flags(uint32_t* stats, int n, int group) {
     }
     stats[f * ST_WORDS + ST_WARP_DIV255_L] = fl;
     stats[f * ST_WORDS + ST_WARP_DIV255_R] = fr;
+    if (!fconst) return;
+    float* C = fconst + (size_t)f * GWC_WORDS;
+    for (int e = 0; e < 2; e++) {
+        const bool div255 = (e ? fr : fl) != 0;
+        float dmin = csm::ord2f(stats[f * ST_WORDS + (e ? ST_R_MIN : ST_L_MIN)]), dmax = csm::ord2f(stats[f * ST_WORDS + (e ? ST_R_MAX : ST_L_MAX)]);
+        if (div255) { dmin = dmin / 255.0f; dmax = dmax / 255.0f; }
+        const float range = dmax - dmin;
+        const float crange = fmaxf(range, (float)1e-6);
+        const bool has_range = range > (float)1e-6;
+        const bool crange_ok = crange < 0x1p40f;   // (>= 1e-6 by construction)
+        C[GWC_EYE * e + 0] = dmin;
+        C[GWC_EYE * e + 1] = crange;
+        C[GWC_EYE * e + 2] = crange_ok ? gw_rcp_refined(crange) : 0.0f;
+        C[GWC_EYE * e + 3] = __builtin_bit_cast(float, (has_range ? 1u : 0u) | (crange_ok ? 2u : 0u) | (div255 ? 4u : 0u));
+    }
+    const float sxw = (float)(w - 1);
+    const bool sxw_ok = w >= 2 && w <= (1 << 20);
+    C[GWC_YSX] = sxw_ok ? gw_rcp_refined(sxw) : 0.0f;
+    C[GWC_SCALE] = (scale_from_stats && stats[f * ST_WORDS + ST_SCALE255]) ? 255.0f : 1.0f;
+    C[GWC_S255] = __builtin_bit_cast(float, stats[f * ST_WORDS + ST_SCALE255]);   // (the lazy tiles' gray values take the scale whatever scale_from_stats says)
 }
 
 static size_t gw_lds_bytes(int w, int gen = 0) {
@@ -1191,10 +1266,12 @@ static size_t gw_lds_bytes(int w, int gen = 0) {
 static size_t mesh_lds_bytes(int w) { return 8 * (size_t)w + 5 * (size_t)w * 4 + align16((size_t)w) + 32 * 4 + sizeof(csm::PowfTables) + 64; }
 static size_t mesh_keep_lds_bytes(int w) { return 3 * (size_t)w * 4 + align16((size_t)w) + sizeof(csm::PowfTables) + 64; }
 // (the mesh variant's keep bits: 2 eyes x groups x (h-1)(w-1) bytes)
+// [256 B][per-frame constants of k_gpuwarp_q: GWC_WORDS floats each][mesh: keep bits]
+static size_t gw_const_bytes(int n) { return ((size_t)n * GWC_WORDS * 4 + 255) & ~(size_t)255; }
 size_t gpuwarp_workspace_bytes(int n, int h, int w, int group, int mesh) {
-    if (!mesh) return 256;
+    if (!mesh) return 256 + gw_const_bytes(n);
     const int g = group > 0 && group < n ? group : n;
-    return 256 + 2 * (size_t)((n + g - 1) / g) * h * w;
+    return 256 + gw_const_bytes(n) + 2 * (size_t)((n + g - 1) / g) * h * w;
 }
 int meshwarp_max_width() {
     int lo = 2, hi = 1 << 15;
@@ -1226,6 +1303,7 @@ static int gw_rounds(double gradient_threshold, int max_stretch) {
 static int pow_mode_of(double e) { return e == 1.0 ? 0 : e == 0.5 ? 1 : e == 2.0 ? 2 : e == 3.0 ? 3 : e == 0.0 ? 5 : 4; }
 
 static int gw_launch(GwArgs& A, hipStream_t stream) {
+    A.lin_step = A.h > 1 ? 2.0f / (float)(A.h - 1) : 0.0f;
     if (A.mesh) {
         if (A.h < 2 || A.w < 2) return CS_EINVAL;   // the reference divides by H - 1 and W - 1
         if (A.w > meshwarp_max_width()) return CS_ELIMIT;
@@ -1310,7 +1388,8 @@ static int gw_launch(GwArgs& A, hipStream_t stream) {
 int launch_gpuwarp_plain(const float* image, const float* depth, int n, int h, int w, double div_px, double sep_px,
                          double exponent, double convergence, float* warped, uint8_t* gap_mask, uint32_t* stats,
                          void* extra, hipStream_t stream, int mesh, double grad_thr, int max_stretch) {
-    hipLaunchKernelGGL(k_gpuwarp_flags, dim3((n + 63) / 64), dim3(64), 0, stream, stats, n, n);
+    float* const fconst = reinterpret_cast<float*>((uint8_t*)extra + 256);
+    hipLaunchKernelGGL(k_gpuwarp_flags, dim3((n + 63) / 64), dim3(64), 0, stream, stats, n, n, fconst, w, 0);
     GwArgs A;
     memset(&A, 0, sizeof(A));
     A.n = n; A.h = h; A.w = w;
@@ -1330,7 +1409,7 @@ int launch_gpuwarp_plain(const float* image, const float* depth, int n, int h, i
     A.out_sf = A.img_sf; A.out_sc = A.img_sc; A.out_sy = w; A.out_sx = 1;
     A.mask_u8 = gap_mask;
     A.dbg = dev_switch(CS_DEBUG_DBG);
-    A.mesh = mesh; A.grad_thr = (float)grad_thr; A.keep = (uint8_t*)extra + 256; A.group = n;
+    A.mesh = mesh; A.grad_thr = (float)grad_thr; A.keep = (uint8_t*)extra + 256 + gw_const_bytes(n); A.group = n; A.fconst = fconst;
     A.rounds = gw_rounds(grad_thr, max_stretch);
     if (!mesh && A.rounds < 0) return CS_ELIMIT;
     return gw_launch(A, stream);
@@ -1341,7 +1420,8 @@ int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL,
                         int out_w, void* extra, hipStream_t stream, const uint32_t* tilemap, const float* gray, int tm_words) {
     const int n = p->n, h = p->h, w = p->w;
     int group = p->batch_size > 0 ? (p->batch_size < n ? p->batch_size : n) : n;
-    hipLaunchKernelGGL(k_gpuwarp_flags, dim3((n + 63) / 64), dim3(64), 0, stream, stats, n, group);
+    float* const fconst = reinterpret_cast<float*>((uint8_t*)extra + 256);
+    hipLaunchKernelGGL(k_gpuwarp_flags, dim3((n + 63) / 64), dim3(64), 0, stream, stats, n, group, fconst, w, scale_from_stats);
     GwArgs A;
     memset(&A, 0, sizeof(A));
     A.n = n; A.h = h; A.w = w;
@@ -1377,7 +1457,7 @@ int launch_gpuwarp_node(const cs_params* p, const float* image, const float* dL,
     A.depth_l = depth_l; A.depth_r = depth_r;
     A.noclamp = p->flags & 1;
     A.dbg = dev_switch(CS_DEBUG_DBG);
-    A.mesh = (p->flags & 4) ? 1 : 0; A.grad_thr = 1.5f; A.rounds = 4; A.keep = (uint8_t*)extra + 256; A.group = group;   // (create_stereoimages_gpu calls the warp with its defaults, :1068-1083)
+    A.mesh = (p->flags & 4) ? 1 : 0; A.grad_thr = 1.5f; A.rounds = 4; A.keep = (uint8_t*)extra + 256 + gw_const_bytes(n); A.group = group; A.fconst = fconst;   // (create_stereoimages_gpu calls the warp with its defaults, :1068-1083)
     if (tilemap && (A.mesh || w > gpuwarp_lazy_max_width())) return CS_EINVAL;   // (the caller asked gpuwarp_lazy_max_width)
     A.tilemap = tilemap; A.gray = gray; A.tm_words = tm_words;
     return gw_launch(A, stream);
