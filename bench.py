@@ -17,7 +17,8 @@ Prints ONE JSON line on rank 0 (contract in the task description) with extra obj
   roofline     : dominant kernel of the configuration -- algorithmic bytes per launch / its mean duration measured with HIP
                  events on the launch stream inside the timed region
   cpu_baseline : the CPU oracle (C port of the reference's D32 arithmetic) on a bounded sample of the same workload:
-                 1 thread, and all host cores (OpenMP over rows = the analogue of the reference's numba prange)
+                 1 thread; all host cores as OpenMP over rows in one process (the analogue of the reference's numba prange);
+                 64 single-threaded processes, a frame each
   value_blur_off (metric config, N = 1): the same workload with the depth blur switched off
   split        (N > 1): kernels only / kernels + all-gather / end to end
 """
@@ -102,7 +103,15 @@ def cpu_baseline(cfg, frames_sample, blur, seconds_budget=12.0):
     t_one = run(1)
     n1 = max(1, min(frames_sample, int(seconds_budget / max(t_one, 1e-3))))
     dt1 = run(n1) if n1 > 1 else t_one
-    # all cores: frames in parallel, one single-threaded process per frame (the port is memory-bound when run in parallel:
+    # all cores, form 1 ("OpenMP over rows = the prange analogue, at all cores"): ONE process, the C oracle's row loops
+    # on every visible core (oracle.set_threads(os.cpu_count())); the node glue around them (numpy) stays on one thread
+    cores = os.cpu_count() or 1
+    oracle.set_threads(cores)
+    run(1)
+    n_omp = max(1, min(frames_sample, 4))
+    dt_omp = run(n_omp)
+    oracle.set_threads(1)
+    # all cores, form 2: frames in parallel, one single-threaded process per frame (the port is memory-bound when run in parallel:
     # more than 64 workers do not help on the 256-core boxes of the pool)
     import cpu_allcores
     workers = max(1, min(os.cpu_count() or 1, 64))
@@ -110,6 +119,9 @@ def cpu_baseline(cfg, frames_sample, blur, seconds_budget=12.0):
     return {"value": n1 / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{n1} frame(s) of the same workload (both eyes, full node path) through the C oracle, {dt1:.1f} s on 1 of "
                       f"{os.cpu_count()} visible host cores",
+            "openmp_rows": {"value": n_omp / dt_omp, "unit": "frames/s", "cores": cores,
+                            "sample": f"{n_omp} frame(s), one process, OpenMP over rows on all {cores} visible host cores "
+                                      f"(oracle.set_threads), {dt_omp:.1f} s"},
             "all_cores": {"value": fps_all, "unit": "frames/s", "cores": workers,
                           "sample": f"{workers} frame(s) in parallel, one single-threaded oracle process per frame on {workers} of "
                                     f"{os.cpu_count()} host cores, {dta:.1f} s ({mean_s:.2f} s per frame per core)"}}
@@ -334,8 +346,8 @@ def main():
                 traffic = None
         # The dominant kernel's OWN algorithmic bytes: it reads the image (12 B/px) and one 4-byte depth value per eye (the
         # blurred maps of the two eyes; one shared gray map with the blur off) and writes every output; the 12 B/px RGB depth
-        # input of the node is read by the gray / blur pre-pass, not by this kernel.  `frac` is quoted on these bytes;
-        # `frac_node_bytes` divides the whole node boundary's bytes by the same kernel time and
+        # input of the node is read by the gray / blur pre-pass, not by this kernel.  `frac_own_bytes` is quoted on these bytes;
+        # `frac` (= `frac_node_bytes`) divides the whole node boundary's bytes by the same kernel time and
         # `pipeline_frac` by the whole step.
         # With the blur on, the tile kernels read the blurred maps only for the 64 x 32 tiles the blur touched (cs_profile_tiles:
         # their share of this run's batch); everywhere else both eyes read ONE shared gray value: 4 instead of 8 B/px.
@@ -346,19 +358,49 @@ def main():
         own_bytes = frames_per_launch * own_px * H * W
         achieved_own = own_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         pipeline = frames * a.steps * cfg["bytes_px"] * H * W / dt / 1e9 / world
-        roofline = {"bound": "hbm", "achieved": achieved_own, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved_own / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+        # The vector-issue side: instruction counters and the issue floor of the dominant kernel from the
+        # committed PMC passes (tools/make_valu.py -> profiles/pmc_valu.json; counters per wave do not depend on the box), set
+        # against THIS run's kernel time.  `bound` stays the roof the contract prices (`peak` / `unit` are HBM figures);
+        # `binding_roof` names the roof that actually binds: "valu" when the kernel's vector-issue floor exceeds its memory
+        # floor (own bytes at the 6.29 TB/s copy ceiling of MI355X_MICROARCH.md).
+        valu, binding = None, "hbm"
+        vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
+        if os.path.exists(vpath) and not a.depth:
+            try:
+                vj = json.load(open(vpath))
+                key = f"{cfg['fill']}_{'4k' if H == 2160 else '1080p'}_blur{int(blur)}" if a.config != "metric" else f"polylines_soft_4k_blur{int(blur)}"
+                if key in vj:
+                    v = vj[key]
+                    frames_profile = v.get("frames_per_dispatch") or frames_per_launch
+                    floor_ms = v["issue_floor_us"] * 1e-3 * frames_per_launch / frames_profile if "issue_floor_us" in v else None
+                    mem_floor_ms = own_bytes / 6.29e12 * 1e3
+                    valu = {"valu_per_wave": v["valu_per_wave"], "salu_per_wave": v["salu_per_wave"], "lds_per_wave": v["lds_per_wave"],
+                            "simd_busy": v["simd_busy"], "wait_any": v["wait_any"], "wait_inst": v["wait_inst"],
+                            "mean_cycles_per_valu": v.get("mean_cycles_per_valu"), "issue_floor_ms": floor_ms,
+                            "frac_of_issue_floor": (floor_ms / kern_ms) if (floor_ms and kern_ms > 0) else None,
+                            "memory_floor_ms": mem_floor_ms, "kernel_ms_profile": v["kernel_us_profile"] * 1e-3 * frames_per_launch / frames_profile,
+                            "source": f"profiles/pmc_valu.json[{key}] (PMC passes + ISA census of {v.get('profile', 'the committed profile')}: "
+                                      "instruction counts per wave; the floor is priced at that profile's clock, not measured in this run)"}
+                    if floor_ms and floor_ms > mem_floor_ms:
+                        binding = "valu"
+            except Exception:  # noqa: BLE001
+                valu = None
+        # `achieved` / `frac`: the CONTRACT formula -- SURVEY.md 8d's algorithmic bytes of the node boundary per launch over the
+        # dominant kernel's measured time; the kernel's own bytes are `achieved_own_bytes` / `frac_own_bytes`
+        roofline = {"bound": "hbm", "binding_roof": binding, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": cfg["kernel"], "kernel_ms": kern_ms, "launches": launches.value,
                     "launches_per_step": launches_per_step,
-                    "algorithmic_bytes_per_launch": own_bytes,
-                    "algorithmic_bytes_note": f"{own_px:.2f} B per source pixel = what this kernel reads and writes once: image 12, depth "
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "algorithmic_bytes_note": f"{cfg['bytes_px']} B per source pixel at the float32 node boundary (SURVEY.md 8d) x the pixels of one launch; "
+                                              f"the kernel itself reads and writes {own_px:.2f} B per source pixel once: image 12, depth "
                                               f"{depth_px:.2f} (one blurred value per eye in the {max(tile_frac.value, 0.0) * 100:.1f} % of the 64 x 32 tiles the "
-                                              "blur touched, one shared gray value elsewhere; measured on this run's tile map), every output; "
-                                              f"the node boundary of SURVEY.md 8d is {cfg['bytes_px']} B/px (it adds the 12 B/px RGB depth input that the "
-                                              "gray / blur pre-pass reads)",
+                                              "blur touched, one shared gray value elsewhere; measured on this run's tile map), every output -- the 12 B/px "
+                                              "RGB depth input is read by the gray / blur pre-pass",
                     "blurred_tile_fraction": tile_frac.value if tile_frac.value >= 0 else None,
-                    "achieved_node_bytes": achieved, "frac_node_bytes": achieved / HBM_PEAK_GBS,
-                    "pipeline_achieved": pipeline, "pipeline_frac": pipeline / HBM_PEAK_GBS}
+                    "achieved_own_bytes": achieved_own, "frac_own_bytes": achieved_own / HBM_PEAK_GBS, "own_bytes_per_launch": own_bytes,
+                    "frac_node_bytes": achieved / HBM_PEAK_GBS,
+                    "pipeline_achieved": pipeline, "pipeline_frac": pipeline / HBM_PEAK_GBS, "valu": valu}
         line = {
             "metric": cfg["name"], "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,

@@ -779,8 +779,8 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
                     const bool connected = fabsf(pr - pl) < 1.5f;
                     const int key = 2 * (i + 1) + (connected ? 1 : 0);
                     if (fs >= -(float)(NR - 1) && fs <= (float)(w - 2)) atomicMax(&M[(int)fs + NR - 1], key);
-                    if (!(fs > 0.0f) || fs + (float)(NR - 1) >= sxw) {
-#pragma unroll
+                    if (!(fs > 0.0f) || fs + (float)(NR - 1) >= sxw) {   // (the first and the last columns of a row only: a rolled loop)
+#pragma unroll 1
                         for (int k = 0; k < NR; k++) {
                             const float cfl = fs + (float)k;
                             if (!(cfl > 0.0f)) atomicMax(&W0[k], key);          // fmaxf(NaN, 0) == 0 as well
@@ -822,35 +822,68 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
             // entry j: the deciding pair with fs == x0 - 3 + j; column x0 + u meets it in round k = u + 3 - j
             const int4 e0 = *reinterpret_cast<const int4*>(M + x0 + 4), e1 = *reinterpret_cast<const int4*>(M + x0 + 8);
             const int key[7] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z};
+            // decoded once per entry: dl and the guarded width -- ZERO for an unconnected pair or no pair (a real `safe` is never 0:
+            // widths below 1e-4 become 1), which fails the pre-test below for every numerator.
+            // (The clamped columns 0 and w - 1 run through the same code; their result is replaced below.)
             float dl[7], safe[7];
 #pragma unroll
             for (int j = 0; j < 7; j++) {
-                // (entry 0 = "no pair" reads D[-1], D[0] and fails the connected bit)
+                // (entry 0 = "no pair" reads D[-1], D[0])
                 const float* dp = D + (key[j] >> 1);
                 const float a = dp[-1], b = dp[0];
                 const float sw = b - a;
                 dl[j] = a;
-                safe[j] = fabsf(sw) < (float)1e-4 ? 1.0f : sw;
+                const float sf = fabsf(sw) < (float)1e-4 ? 1.0f : sw;
+                safe[j] = (key[j] & 1) ? sf : 0.0f;
             }
             float z[4], src[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int x = x0 + u;
                 z[u] = -1.0f; src[u] = -1.0f;
-                const bool interior = x > 0 && x < w - 1;
                 const float cfl = (float)x;
+                // EXACT pre-test of a proposal (interior columns: x >= 1, so the numerator x - dl is 0 or at least 2^-24 in magnitude -- no
+                // underflow in the quotient): frac = RN(num / safe) lies in [0, 1) iff num is zero or has safe's sign, and |num| < |safe|
+                // (the quotient of two floats with |num| < |safe| is at most 1 - 2^-24: it does not round up to 1).  An unconnected pair
+                // has safe == 0 and fails; NaN fails like the reference's comparison.
+                float num[4];
+                bool m[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int j = u + 3 - k;
-                    const float num = cfl - dl[j];
-                    // (conservative filter, the exact test is `valid`: see k_gpuwarp)
-                    const bool maybe = interior & ((key[j] & 1) != 0) & !(num * safe[j] < 0.0f) & !(fabsf(num) >= 1.001f * fabsf(safe[j]));
-                    if (maybe) {
-                        const int i = (key[j] >> 1) - 1;
-                        const float frac = gw_div(num, safe[j]);
+                    num[k] = cfl - dl[j];
+                    const bool opposite = (int)(__builtin_bit_cast(uint32_t, num[k]) ^ __builtin_bit_cast(uint32_t, safe[j])) < 0 && num[k] != 0.0f;
+                    m[k] = !opposite & (fabsf(num[k]) < fabsf(safe[j]));
+                }
+                // One valid proposal per column is the rule (two: a fold -- foreground and background both cover the column); then
+                // the rounds need no order: select the proposal per lane and divide ONCE, with every lane of the wave busy, instead of
+                // once per round that has a taker somewhere in the wave (9 of the 16 round blocks of a lane's four columns ran).
+                const bool two = (m[0] & (m[1] | m[2] | m[3])) | (m[1] & (m[2] | m[3])) | (m[2] & m[3]);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(two) != 0, 0)) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {   // the rounds in order (k_gpuwarp's form)
+                        const int j = u + 3 - k;
+                        if (m[k]) {
+                            const int i = (key[j] >> 1) - 1;
+                            const float frac = gw_div(num[k], safe[j]);
+                            const bool valid = frac >= 0.0f && frac < 1.0f;
+                            const float iz = ndn[i] * (1.0f - frac) + ndn[i + 1] * frac;
+                            if (valid && iz > z[u] + (float)1e-6) {
+                                z[u] = iz;
+                                src[u] = (float)i + frac;
+                            }
+                        }
+                    }
+                } else {
+                    const float nsel = m[0] ? num[0] : (m[1] ? num[1] : (m[2] ? num[2] : num[3]));
+                    const float ssel = m[0] ? safe[u + 3] : (m[1] ? safe[u + 2] : (m[2] ? safe[u + 1] : safe[u]));
+                    const int ksel = m[0] ? key[u + 3] : (m[1] ? key[u + 2] : (m[2] ? key[u + 1] : key[u]));
+                    if (m[0] | m[1] | m[2] | m[3]) {
+                        const int i = (ksel >> 1) - 1;
+                        const float frac = gw_div(nsel, ssel);
                         const bool valid = frac >= 0.0f && frac < 1.0f;
                         const float iz = ndn[i] * (1.0f - frac) + ndn[i + 1] * frac;
-                        if (valid && iz > z[u] + (float)1e-6) {
+                        if (valid && iz > -1.0f + (float)1e-6) {
                             z[u] = iz;
                             src[u] = (float)i + frac;
                         }
@@ -927,7 +960,10 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
             }
             const float pos = fminf(fmaxf(s, 0.0f), sxw);
             const float p2 = pos * 2.0f;
-            float gx = gw_div_y(p2, sxw, ysx, sxw_ok) - 1.0f;
+            // (gw_div_y with its range test reduced to what can fail here: 0 <= p2 <= 2 (w - 1) < 2^60, so only 0 < p2 < 2^-60)
+            float q = gw_div_with(p2, sxw, ysx);
+            if (__builtin_expect(!sxw_ok || (p2 < 0x1p-60f && p2 != 0.0f), 0)) { asm volatile("" ::: "memory"); q = p2 / sxw; }
+            float gx = q - 1.0f;
             float xx = (gx + 1.0f) * sxw_half;
             xx = fminf(fmaxf(xx, 0.0f), sxw);
             const float xw = floorf(xx);
@@ -955,7 +991,7 @@ __global__ void __launch_bounds__(1024) k_gpuwarp_q(GwArgs A) {
                 for (int c = 0; c < NC; c++) {
                     const int x = xb + c * nt;
                     if (x >= w) continue;
-                    const float nw = wsth * we[c], ne = wsth * ww[c];   // (wsth == 1)
+                    const float nw = we[c], ne = ww[c];   // (wsth == 1 - 0: the products wsth * we, wsth * ww are we and ww)
                     Px3 r;
                     r.x = pa[c].x * nw + pb[c].x * ne;
                     r.y = pa[c].y * nw + pb[c].y * ne;
