@@ -135,9 +135,10 @@ def main():
     ap.add_argument("--config", default="metric", choices=sorted(CONFIGS))
     ap.add_argument("--frames", type=int, default=0, help="total frames in the batch (sharded over the GPUs); 0 = the config's")
     ap.add_argument("--no-blur", action="store_true")
-    ap.add_argument("--depth", default="", choices=["", "clipped", "random8", "blobs"],
+    ap.add_argument("--depth", default="", choices=["", "clipped", "random8", "blobs", "scene8"],
                     help="replace the config's synthetic depth: clipped = saturated to exact 0 / 1 over large areas (exact closeness "
-                         "ties: order-dependent rows, the stretch replay kernel), random8 = 8-bit noise (every row replayed whole)")
+                         "ties: order-dependent rows, the stretch replay kernel), random8 = 8-bit noise (every row replayed whole), "
+                         "scene8 = an 8-bit gradient with flat ellipses (quantised smooth depth with object silhouettes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--verify", action="store_true", help="N > 1: check the reassembled float32 batch against a local float32 run")
@@ -289,7 +290,7 @@ def main():
         value_other_depths = {}
         import numpy as np
         import synth
-        for kind in ("radial", "blobs"):
+        for kind in ("radial", "blobs", "scene8"):
             if kind == "radial":
                 _, d2 = make_inputs(torch, dict(cfg, depth="radial"), nloc, b0, device)
             else:

@@ -377,8 +377,12 @@ static const char* const DIALECT_MSG = "dialect D64 (flags bits 3/4) exists for 
 // flags, one byte per row] -- everything one memset clears -- then [row list, 4 B per row]
 // (round 5: + [tile hints, one 32-bit word per row and eye: bit t = tile t of that row-eye could not be finished by k_polypoint]
 // behind the retry flags, inside the cleared part)
+// (round 6: + [second-tier row flags, one byte per row][second-tier tile hints] behind the hints, inside the cleared part: what
+// k_polypoint_listed flags among the rows the first tier handed it)
 static size_t rowflag_hint_off(size_t rows) { return 2 * al256(rows) + 512; }
-static size_t rowflag_clear_bytes(size_t rows) { return rowflag_hint_off(rows) + al256(rows * 8); }
+static size_t rowflag_flag2_off(size_t rows) { return rowflag_hint_off(rows) + al256(rows * 8); }
+static size_t rowflag_hint2_off(size_t rows) { return rowflag_flag2_off(rows) + al256(rows); }
+static size_t rowflag_clear_bytes(size_t rows) { return rowflag_hint2_off(rows) + al256(rows * 8); }
 static size_t rowflag_bytes(size_t rows) { return rowflag_clear_bytes(rows) + al256(rows * 4); }
 static uint32_t* rowflag_list(uint8_t* rowflag, size_t rows) { return (uint32_t*)(rowflag + rowflag_clear_bytes(rows)); }
 
@@ -398,7 +402,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
     // CS_DEBUG_PT_VARIANT asks for the first generation (cs_polytile.hip)
     const int variant = dev_switch(CS_DEBUG_PT_VARIANT);   // 0 / 3 .. 7: point-owner kernel; 41 - 43: tie-path what-ifs; other values: first generation
     auto polypoint_takes = [&](int hl) {
-        return hl <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16) || (variant >= 41 && variant <= 47));
+        return hl <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16) || (variant >= 41 && variant <= 50));
     };
     // (the tile kernels are dialect D32, plus -- round 5 -- the float64 disparity chain alone: k_polypoint<..., DIA>)
     const bool tile_dialect = A.d64 == 0 || (A.d64 == 1 && polypoint_takes(halo));
@@ -446,9 +450,29 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         e = launch_collect_rows(rowflag, (int)rows, count, list, stream);
         if (e != hipSuccess) return fail_hip(e, "flagged-row collection");
         A.row_list = list; A.row_count = count;
+        const uint32_t* hints = (const uint32_t*)(rowflag + rowflag_hint_off(rows));
+        // (round 6) second tier: the flagged rows through the point kernel once more with 512 instead of 160 slots for pixels under
+        // reversed segments and longer per-pixel lists (k_polypoint_listed); what THAT flags -- a second flag array and hint block,
+        // a third {count, cursor} pair -- is collected into the same list for the row kernel.  Depth maps with strong silhouettes
+        // (tools/synth.scene8) overflowed the first tier's lists in 15 % (soft) / 48 % (sharp) of the rows at the metric's divergence
+        // and sent them to the row kernel: 4 200 / 1 060 frames/s against 5 380 / 4 050 on stepped depth.  polylines_sharp only:
+        // for soft the lean row kernel on the hinted tiles' columns is the cheaper second stop (0.96 against 1.16 ms per 16 frames,
+        // tools/sessions/r06_s11.sh, s12: 4 100 against 3 750 frames/s; CS_DEBUG_PT_VARIANT 50 forces the tier for soft, 49: off)
+        if (hint_T > 0 && (fill == CS_FILL_POLYLINES_SHARP || dev_switch(CS_DEBUG_PT_VARIANT) == 50) && dev_switch(CS_DEBUG_PT_VARIANT) != 49) {
+            uint8_t* flag2 = rowflag + rowflag_flag2_off(rows);
+            uint32_t* hint2 = (uint32_t*)(rowflag + rowflag_hint2_off(rows));
+            uint32_t* count3 = count + 16;
+            e = launch_polypoint_tier2(T, halo, flag2, stream, fill == CS_FILL_POLYLINES_SHARP, hint2, hint_T, list, count);
+            if (e == hipSuccess) {
+                e = launch_collect_rows(flag2, (int)rows, count3, list, stream);
+                if (e != hipSuccess) return fail_hip(e, "flagged-row collection (second tier)");
+                A.row_count = count3;
+                hints = hint2;
+            } else if (e != hipErrorNotSupported) return fail_hip(e, "tiled polylines launch (second tier)");
+        }
         // (the lean first pass works on the flagged tiles' column ranges; CS_DEBUG_PT_VARIANT 44: whole rows as in round 4)
         if (hint_T > 0 && dev_switch(CS_DEBUG_PT_VARIANT) != 44) {
-            A.hint = (const uint32_t*)(rowflag + rowflag_hint_off(rows)); A.hint_T = hint_T; A.hint_S = halo;
+            A.hint = hints; A.hint_T = hint_T; A.hint_S = halo;
         }
     }
     if ((fill == CS_FILL_NONE || fill == CS_FILL_INVERSE || fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING) &&

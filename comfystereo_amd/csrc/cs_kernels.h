@@ -104,6 +104,9 @@ int fwdtile_max_halo();
 // cs_polypoint.hip: second generation of the tiled path (polylines_soft): one lane per polyline point
 hipError_t launch_polypoint(const RowArgs& A, int S, uint8_t* rowflag, hipStream_t stream, int sharp = 0, uint32_t* hint = nullptr,
                             int* tile_width = nullptr);
+// (round 6) second tier: the rows of `list` / `count` the first tier flagged, with more room for pixels under reversed segments
+hipError_t launch_polypoint_tier2(const RowArgs& A, int S, uint8_t* rowflag2, hipStream_t stream, int sharp, uint32_t* hint2, int tile_width,
+                                  const uint32_t* list, const uint32_t* count);
 int polypoint_max_halo();
 // anaglyph modes behind the tile kernel: the eyes as uint8 codes side by side -> the composite (rows flagged in rowflag excepted)
 hipError_t launch_anaglyph_compose(const uint8_t* sbs, const uint8_t* rowflag, int n, int h, int w, int anaglyph, float* stereo,

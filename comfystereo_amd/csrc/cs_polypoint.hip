@@ -63,6 +63,18 @@ namespace cs {
 #ifndef PP_SHARP_MINW
 #define PP_SHARP_MINW 6
 #endif
+// polylines_sharp, lists of a pixel under a reversed segment (points / forward segments): 6 / 9 since round 6 (5 / 7 before -- what a HARD
+// silhouette needs: three layers, two points per source; on depth with softened silhouettes, tools/synth.scene8, 48 % of the rows of a 4K
+// frame overflowed them at the metric's divergence and went to the row kernel: 1 050 frames/s against 4 000 on stepped depth.  6 / 9
+// flags 20 %: 1 690, with the second tier behind it 1 900; the price is 4 spilled vector registers at the 80-register budget,
+// -2.5 % on stepped depth, tools/sessions/r06_s13.sh.  More dirty SLOTS -- PP_DCAP_SHARP 240 / 320 -- changed nothing: s12)
+#ifndef PP_SHARP_KP
+#define PP_SHARP_KP 6
+#define PP_SHARP_KS 9
+#endif
+#ifndef PP_DCAP_SHARP
+#define PP_DCAP_SHARP PP_DCAP
+#endif
 #define PP_DIRTY 0x8000u     // dflag (16 bits per tile pixel since round 5): pixel lies under a reversed segment; low 15 bits = its list slot
 
 __constant__ csm::PowfTables c_pp_powf_tables = CS_POWF_TABLES_INIT;
@@ -159,28 +171,16 @@ enum { PK_CHAIN = 0u, PK_BRIDGE = 1u };
 // in the staging phase -- everything after it works on the float32 points as in D32.  polylines_sharp: a point is
 // (float)(x64 -+ 0.45), which one float32 centre per source cannot carry -- the dialect instantiation keeps both points of every
 // source in a second LDS array `xq` (8 more bytes per record: five instead of six workgroups per CU) and reads them from there.
-template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW, int SHARP, int DIA = 0>
-__global__ void __launch_bounds__(NT, MINW)
-k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
-            int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode, int hot_npt, int hot_off_xq,
-            PolyPointArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// The tile function: one tile of one row-eye.  Inlined into k_polypoint (every row once, blockIdx decoded below) and into
+// k_polypoint_listed (round 6: the second tier -- the rows the first pass flagged, once more with room for more pixels under reversed
+// segments and longer lists, before the general row kernel gets what is left).  DC: pixels under reversed segments a tile can hold.
+template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int SHARP, int DIA, int DC>
+__device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
+                                        int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode,
+                                        int hot_npt, int hot_off_xq, const PolyPointArgs& A, char* const smem, const int row, const int eyei,
+                                        const int tile, const int frame) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = hot_T;
-    // grid = (tiles x 8 rows, rows / 8 [x eyes], frames), decoded with shifts (a scalar division costs ~30 SALU instructions).
-    // Workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md; a speed assumption only): with blockIdx.x =
-    // tile * 8 + (row & 7) all tiles of a row land on one XCD, back to back, and the halo columns two neighbouring tiles share
-    // come from that XCD's L2 the second time instead of from HBM (FETCH_SIZE -21 %).  The two eyes: cs_common.h eye_group_decode
-    // (round 4: row groups of the two eyes alternate, the second eye's image rows come from L2; the eyes of a tile directly
-    // next to each other had been measured 4 % slower in round 2 and 3 % slower again in round 4).
-    const int xi = blockIdx.x;
-    // (two-eye launches: blockIdx.y interleaves the eyes by row groups, cs_common.h eye_group_decode; single-eye: z = frame)
-    int yrow = blockIdx.y, eyei = hot_single;
-    if (hot_single < 0) eye_group_decode((int)blockIdx.y, yrow, eyei);
-    const int row = yrow * 8 + (xi & 7);
-    if (row >= hot_h) return;
-    const int tile = xi >> 3;
-    const int frame = blockIdx.z;
     EyeArgs E;
     E.depth = eyei ? hot_depth1 : hot_depth0;
     {
@@ -243,10 +243,10 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     // (the two offsets that depend on T come precomputed in preloaded kernel arguments: plist + max(T, 128) and + (2 T + 3 & ~3))
     uint16_t* dflag = (uint16_t*)(smem + hot_off_dflag);                          // [T] PP_DIRTY | slot
     uint16_t* dcnt = (uint16_t*)(smem + hot_off_dcnt);                            // [DCAP] points (low 8) | segments (high 8)
-    uint16_t* dpix = dcnt + PP_DCAP;                                              // [DCAP] pixel of the slot
-    uint16_t* pts = dpix + PP_DCAP;                                               // [DCAP][PT_KP]
-    uint16_t* sgs = pts + PP_DCAP * PT_KP;                                        // [DCAP][PT_KS]
-    int* flags = (int*)(sgs + PP_DCAP * PT_KS);                                   // [PF_WORDS]
+    uint16_t* dpix = dcnt + DC;                                              // [DCAP] pixel of the slot
+    uint16_t* pts = dpix + DC;                                               // [DCAP][PT_KP]
+    uint16_t* sgs = pts + DC * PT_KP;                                        // [DCAP][PT_KS]
+    int* flags = (int*)(sgs + DC * PT_KS);                                   // [PF_WORDS]
     // k / 255 (convertResult / np2tensor, reference GenerateStereo.py:41-44) by table: the kernel is bound by the NUMBER of
     // vector instructions (one quad-cycle each whatever the type, profiles/r03_polypoint.txt), and a table read costs one
     // (the shift) where the arithmetic of cs_math.h code_over_255 costs three; the LDS pipe has room
@@ -299,7 +299,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     if (all_powf && tid < (int)(sizeof(csm::PowfTables) / 4))
         reinterpret_cast<uint32_t*>(tabs_lds)[tid] = reinterpret_cast<const uint32_t*>(&c_pp_powf_tables)[tid];
     for (int i = tid; i < (T + 1) / 2; i += NT) reinterpret_cast<uint32_t*>(dflag)[i] = 0;   // (two 16-bit flags per word)
-    if (tid < PP_DCAP / 2) reinterpret_cast<uint32_t*>(dcnt)[tid] = 0;
+    if (tid < DC / 2) reinterpret_cast<uint32_t*>(dcnt)[tid] = 0;
     if (OUT == PO_F32) {
         for (int i = tid; i < 256; i += NT) lut[i] = code_over_255((float)i);
     }
@@ -336,7 +336,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
                       lbase = __builtin_amdgcn_readlane(base, src);
             for (int i = lane; i < ln; i += 64) {
                 const int s = lbase + i;
-                if (s < PP_DCAP) { dflag[llo + i] = (uint16_t)(PP_DIRTY | s); dpix[s] = (uint16_t)(llo + i); }
+                if (s < DC) { dflag[llo + i] = (uint16_t)(PP_DIRTY | s); dpix[s] = (uint16_t)(llo + i); }
                 else PP_HAZARD(2);
             }
         }
@@ -621,10 +621,10 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
         if (mrev) mark_reversed(mrev, xa, xb);
         __syncthreads();
     }
-    const int ndirty = min(flags[PF_NDIRTY], PP_DCAP);
+    const int ndirty = min(flags[PF_NDIRTY], DC);
     const bool fold_tile = flags[PF_NDIRTY] > 0;
     const int dlo = flags[PF_DLO], dhi = flags[PF_DHI];
-    if (flags[PF_NDIRTY] > PP_DCAP) PP_HAZARD(1);
+    if (flags[PF_NDIRTY] > DC) PP_HAZARD(1);
     // points that can lie in the tile, plus the one before them (its segment may bridge into the tile); sentinels excluded
     const int jlo = max(flags[PF_JLO] - 1, 0), jhi = min(flags[PF_JHI], ns - 1);
     if (!SHARP && tid == 0) { pz[0] = 0.0f; pz[npts - 1] = 0.0f; }   // sentinels (:1921, :1935); read after barrier 2 (sharp: pzv())
@@ -1144,6 +1144,55 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     }
 }
 
+template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW, int SHARP, int DIA = 0>
+__global__ void __launch_bounds__(NT, MINW)
+k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
+            int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode, int hot_npt, int hot_off_xq,
+            PolyPointArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // grid = (tiles x 8 rows, rows / 8 [x eyes], frames), decoded with shifts (a scalar division costs ~30 SALU instructions).
+    // Workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md; a speed assumption only): with blockIdx.x =
+    // tile * 8 + (row & 7) all tiles of a row land on one XCD, back to back, and the halo columns two neighbouring tiles share
+    // come from that XCD's L2 the second time instead of from HBM (FETCH_SIZE -21 %).  The two eyes: cs_common.h eye_group_decode
+    // (round 4: row groups of the two eyes alternate, the second eye's image rows come from L2; the eyes of a tile directly
+    // next to each other had been measured 4 % slower in round 2 and 3 % slower again in round 4).
+    const int xi = blockIdx.x;
+    // (two-eye launches: blockIdx.y interleaves the eyes by row groups, cs_common.h eye_group_decode; single-eye: z = frame)
+    int yrow = blockIdx.y, eyei = hot_single;
+    if (hot_single < 0) eye_group_decode((int)blockIdx.y, yrow, eyei);
+    const int row = yrow * 8 + (xi & 7);
+    if (row >= hot_h) return;
+    pp_tile<NT, SLOTS, OUT, PT_KP, PT_KS, SHARP, DIA, (SHARP ? PP_DCAP_SHARP : PP_DCAP)>(hot_image, hot_depth0, hot_depth1, hot_w, hot_h, hot_S, hot_T, hot_single, hot_off_dflag,
+                                                                hot_off_dcnt, hot_pow_mode, hot_npt, hot_off_xq, A, smem, row, eyei, xi >> 3, (int)blockIdx.z);
+}
+
+// Second tier (round 6): the rows k_polypoint flagged (list entries frame * h + row | eye mask << 30, k_collect_rows), every flagged
+// eye of them through the same tile function with DC = 512 slots for pixels under reversed segments and longer per-pixel lists -- what a
+// depth map with strong silhouettes needs at the metric's divergence (tools/synth.scene8: a fold of a near object over the background is
+// ~130 pixels wide at 4K, three of them in a tile of 768; the first tier's 160 slots hold one).  grid = (tiles, G): workgroup (t, g)
+// does tile t of the list entries g, g + G, ...; an empty list costs a launch of idle workgroups.  Rows this pass cannot finish
+// either (exact ties, lists beyond even these capacities) are flagged in `A.rowflag` -- a second flag array -- for the row kernel.
+#define PP_DCAP2 512
+template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW, int SHARP>
+__global__ void __launch_bounds__(NT, MINW)
+k_polypoint_listed(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
+                   int hot_w, int hot_h, int hot_S, int hot_T, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode, int hot_npt,
+                   const uint32_t* __restrict__ row_list, const uint32_t* __restrict__ row_count, PolyPointArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t count = row_count[0];
+    for (uint32_t li = blockIdx.y; li < count; li += gridDim.y) {
+        const uint32_t e = row_list[li];
+        const uint32_t idx = e & 0x3fffffffu;
+        const int frame = (int)(idx / (uint32_t)hot_h), row = (int)(idx - (uint32_t)frame * (uint32_t)hot_h);
+        for (int eyei = 0; eyei < 2; eyei++) {
+            if (!((e >> (30 + eyei)) & 1u)) continue;
+            pp_tile<NT, SLOTS, OUT, PT_KP, PT_KS, SHARP, 0, PP_DCAP2>(hot_image, hot_depth0, hot_depth1, hot_w, hot_h, hot_S, hot_T, -1, hot_off_dflag,
+                                                                       hot_off_dcnt, hot_pow_mode, hot_npt, 0, A, smem, row, eyei, (int)blockIdx.x, frame);
+            __syncthreads();   // (the tile's LDS is reused)
+        }
+    }
+}
+
 // Depth-map output of an eye the tile kernel does not visit (modes left-only / only-right still return both depth maps,
 // reference stereoimage_generation.py:1511-1516): (depth * 255).astype(uint8) wraps mod 256 (quirk Q7), value code / 255.
 __global__ void __launch_bounds__(256) k_depth_codes(const float* __restrict__ depth, int hw, const uint32_t* stats,
@@ -1201,9 +1250,9 @@ static int polypoint_npt(int nt, int slots, int T, int S) {
     const int all = slots * nt + 4, need = ((T + 2 * S + 2 + 2 + 1 + 3) & ~3) + 4;
     return need < all ? need : all;
 }
-static size_t polypoint_lds(int nt, int slots, int T, int S, int KP, int KS) {
+static size_t polypoint_lds(int nt, int slots, int T, int S, int KP, int KS, int dcap = PP_DCAP) {
     const size_t npt = (size_t)polypoint_npt(nt, slots, T, S);
-    return 8 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((2 * T + 3) & ~3) + 2 * PP_DCAP * (2 + (size_t)KP + KS) +
+    return 8 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((2 * T + 3) & ~3) + 2 * (size_t)dcap * (2 + (size_t)KP + KS) +
            4 * PF_WORDS + 1024 + 64;
 }
 
@@ -1228,10 +1277,10 @@ template <int NT, int SLOTS, int MINW, int SHARP, int DIA = 0>
 static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream) {
     // points / forward segments a pixel under a reversed segment can hold in its lists (more: the row is redone); sharp has two
     // points per source (the values the first-generation kernel settled on)
-    constexpr int KP = SHARP ? 5 : 4, KS = SHARP ? 7 : 5;
+    constexpr int KP = SHARP ? PP_SHARP_KP : 4, KS = SHARP ? PP_SHARP_KS : 5;
     const int tiles = (A.w + A.T - 1) / A.T;
     dim3 grid(tiles * 8, A.single >= 0 ? (A.h + 7) / 8 : eye_group_grid_y(A.h), A.n), block(NT);   // (see the kernel's prologue)
-    size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS);
+    size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS, SHARP ? PP_DCAP_SHARP : PP_DCAP);
     // (development: CS_DEBUG_PT_VARIANT 13..16 pads the LDS request so that only 3..6 workgroups fit a CU -- occupancy what-if)
     const int npt = polypoint_npt(NT, SLOTS, A.T, A.S);
     const int off_dflag = 8 * npt + 4 * npt + 4 * (A.T > 128 ? A.T : 128), off_dcnt = off_dflag + ((2 * A.T + 3) & ~3);
@@ -1317,6 +1366,69 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     case 7: return polypoint_launch<256, 5, PP_MINW, 0>(A, out, stream);
     default: return polypoint_launch<256, 4, PP_MINW, 0>(A, out, stream);
     }
+}
+
+// Second tier (k_polypoint_listed): the flagged rows of `list` / `count` (k_collect_rows) once more, with PP_DCAP2 slots and longer
+// lists; what it cannot finish either is flagged in `rowflag2` (zeroed by the caller), tile hints (soft) in `hint2`.  Same tile width
+// as the first tier (the hints name tiles).  hipErrorNotSupported: not for this call (dialect, single-eye layouts, wide-halo geometry).
+template <int SHARP>
+static hipError_t polypoint_launch_listed(PolyPointArgs& A, int out, const uint32_t* list, const uint32_t* count, hipStream_t stream) {
+    constexpr int NT = 256, SLOTS = 4, MINW = 4;
+    constexpr int KP = SHARP ? 8 : 6, KS = SHARP ? 12 : 9;   // (first tier: 6 / 9 and 4 / 5)
+    const int tiles = (A.w + A.T - 1) / A.T;
+    // persistent workgroups: what is resident at once (4 per CU), spread over the tiles
+    dim3 grid(tiles, (unsigned)((4 * 256 + tiles - 1) / tiles)), block(NT);
+    const size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS, PP_DCAP2);
+    const int npt = polypoint_npt(NT, SLOTS, A.T, A.S);
+    const int off_dflag = 8 * npt + 4 * npt + 4 * (A.T > 128 ? A.T : 128), off_dcnt = off_dflag + ((2 * A.T + 3) & ~3);
+    const int pow_mode = (A.dbg == 17 || !(A.e32 == 2.0f || A.e32 == 1.0f)) ? 0 : (A.e32 == 2.0f ? 2 : 1);
+    for (int e = 0; e < 2; e++) {
+        const EyeArgs& E = A.eye[e];
+        A.epk[e][0] = (unsigned long long)__builtin_bit_cast(uint32_t, E.div32) | ((unsigned long long)__builtin_bit_cast(uint32_t, E.sep32) << 32);
+        A.epk[e][1] = (unsigned long long)(uint32_t)E.xoff | ((unsigned long long)(uint32_t)E.yoff << 32);
+        A.epk[e][2] = (unsigned long long)(uint32_t)E.st_min | ((unsigned long long)((uint32_t)E.st_max & 0xffffu) << 32) |
+                      ((unsigned long long)(E.enabled ? 1u : 0u) << 48);
+    }
+#define PP_LAUNCH2(O)                                                                                                        \
+    {                                                                                                                        \
+        hipError_t e = hipFuncSetAttribute((const void*)k_polypoint_listed<NT, SLOTS, O, KP, KS, MINW, SHARP>,               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        if (e != hipSuccess) return e;                                                                                       \
+        hipLaunchKernelGGL((k_polypoint_listed<NT, SLOTS, O, KP, KS, MINW, SHARP>), grid, block, lds, stream, A.image_f32, A.eye[0].depth, \
+                           A.eye[1].depth, A.w, A.h, A.S, A.T, off_dflag, off_dcnt, pow_mode, npt, list, count, A);          \
+    }
+    if (out == PO_F32) PP_LAUNCH2(PO_F32)
+    else if (out == PO_U8) PP_LAUNCH2(PO_U8)
+    else if (out == PO_U8NM) PP_LAUNCH2(PO_U8NM)
+    else return hipErrorNotSupported;
+#undef PP_LAUNCH2
+    return hipGetLastError();
+}
+
+hipError_t launch_polypoint_tier2(const RowArgs& R, int S, uint8_t* rowflag2, hipStream_t stream, int sharp, uint32_t* hint2, int tile_width,
+                                  const uint32_t* list, const uint32_t* count) {
+    if (R.d64 || R.neyes != 2 || R.single >= 0 || R.out_u8 || !R.image_f32) return hipErrorNotSupported;
+    const int nt = 256, slots = 4;
+    PolyPointArgs A;
+    A.n = R.n; A.h = R.h; A.w = R.w; A.S = S;
+    A.T = polypoint_tile(R.w, S, nt * slots, nt);
+    if (A.T == 0 || A.T != tile_width || A.T + 2 * S + 3 > nt * slots) return hipErrorNotSupported;   // (the first tier ran another geometry)
+    A.image_f32 = R.image_f32; A.image_u8 = nullptr;
+    A.stats = R.stats; A.stats_rw = R.stats_rw;
+    A.scale_from_stats = R.scale_from_stats;
+    A.e32 = R.e32; A.conv32 = R.conv32;
+    A.eye[0] = R.eye[0]; A.eye[1] = R.eye[1];
+    A.single = -1;
+    A.out_u8 = nullptr; A.stereo = R.stereo; A.mask = R.mask; A.depth_l = R.depth_l; A.depth_r = R.depth_r;
+    A.out_h = R.out_h; A.out_w = R.out_w;
+    A.rowflag = rowflag2;
+    A.dbg = R.dbg;
+    A.tilemap = R.tilemap; A.gray = R.lazy_gray; A.tm_words = R.tm_words;
+    A.d64 = 0; A.e64 = R.e64;
+    A.hint = hint2;
+    if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31)) return hipErrorNotSupported;
+    const int out = R.stereo_is_u8 ? (R.no_mask ? PO_U8NM : PO_U8) : PO_F32;
+    return sharp ? polypoint_launch_listed<1>(A, out, list, count, stream) : polypoint_launch_listed<0>(A, out, list, count, stream);
 }
 
 }  // namespace cs

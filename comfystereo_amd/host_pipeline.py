@@ -319,6 +319,14 @@ def generate_host(image, depth_map, divergence, separation, modes, stereo_balanc
         slot.e_out.synchronize()
         for k, r in enumerate(routes):
             if r == "f32":
+                # pageable results: the chunk's float32 output leaves its pinned staging copy here, on the library's copy threads and
+                # under the next chunk's transfers (round 6: it was a single-threaded torch copy_ on the caller's thread in drain() --
+                # gpu_warp, the node's default technique, ran at 17 frames/s at 4K with the default pinned cap)
+                if not state["direct"]:
+                    dst, src = fin[k][b0:b1], slot.pin_out[k][: b1 - b0]
+                    rc = L.cs_host_copy(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), src.numel() * 4, copy_threads)
+                    if rc:
+                        raise RuntimeError(f"cs_host_copy of output {k} failed ({rc})")
                 continue
             dst = fin[k][b0:b1]
             rep = 1 if k in (0, 3) else 3
@@ -342,7 +350,7 @@ def generate_host(image, depth_map, divergence, separation, modes, stereo_balanc
             slot.future.result()
             slot.future = None
         slot.e_out.synchronize()
-        if has_f32 and not state["direct"]:
+        if has_f32 and not state["direct"] and not host_jobs:   # (no worker: the float32 boundary of round 2, comparison only)
             fin = get_final()
             for k, r in enumerate(routes):
                 if r == "f32":

@@ -69,6 +69,30 @@ def golden_node_extra():
     return Golden("node_extra.npz")
 
 
+@pytest.fixture(scope="session")
+def golden_scene8():
+    """The reference's node on quantised depth with object silhouettes (tools/synth.scene8)."""
+    return Golden("scene8.npz")
+
+
+def scene8_case_inputs(g, case):
+    grp = case["group"]
+    depth = np.repeat((g[f"{grp}/depth_u8"].astype(np.float32) / np.float32(255.0))[..., None], 3, -1)
+    return g["img_u8"].astype(np.float32) / np.float32(255.0), depth
+
+
+def scene8_case_expected(g, case):
+    """(stereo, depth_left [N,H,W], depth_right, mask) of a scene8.npz case; gpu_warp: the stereoscope's rows [::row_step] only."""
+    cid = case["id"]
+    if g.has(f"{cid}/stereo_rows"):
+        stereo, dl, dr = g[f"{cid}/stereo_rows"], g[f"{cid}/dl"], g[f"{cid}/dr"]
+    else:
+        stereo, dl, dr = (g[f"{cid}/{k}_u8"].astype(np.float32) / np.float32(255.0) for k in ("stereo", "dl", "dr"))
+    mshape = case["shapes"]["mask"]
+    mask = np.unpackbits(g[f"{cid}/mask"])[: int(np.prod(mshape))].reshape(mshape).astype(np.float32)
+    return stereo, dl, dr, mask
+
+
 def extra_case_inputs(g, case):
     grp = case["group"]
     return g[f"{grp}/img_u8"].astype(np.float32) / np.float32(255.0), g[f"{grp}/depth"]

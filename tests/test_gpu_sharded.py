@@ -137,3 +137,34 @@ def test_bench_two_ranks_verify(config, frames, gather):
     assert line["diagnostics"]["kernel_error_flags"] == 0
     assert line["ranks"]["world_size"] == 2 and line["ranks"]["all_reduce_of_ones"] == 2 and len(line["ranks"]["devices"]) == 2
     assert line["config"]["gather"] == gather
+
+
+def _visible_gpus():
+    import torch
+    return torch.cuda.device_count()   # (counting devices does not initialise the GPU: the launcher below starts fresh processes)
+
+
+@pytest.mark.parametrize("config,frames,gather", [("metric", 8, "collective"), ("cfg4", 48, "collective"), ("cfg5", 4, "collective"),
+                                                  ("metric", 8, "p2p"), ("cfg4", 48, "p2p"), ("metric", 8, "none")])
+def test_bench_two_gpus_over_rccl_verify(config, frames, gather):
+    """the same step over RCCL on TWO DEVICES -- the device `all_gather_into_tensor(async_op=True)` of
+    sharding.ChunkedGather, the `batch_isend_irecv` fan-out, the single exchange at N = 2 and the `ranks` report have only ever run
+    through gloo on one GPU.  Skips on a one-GPU box (the pool's); on the first multi-GPU box it runs with no code change: torchrun
+    starts fresh processes (rendezvous on 127.0.0.1), backend nccl, one rank per device, --verify compares every rank's block of the
+    reassembled batch and one foreign sub-batch with a local float32 run."""
+    if _visible_gpus() < 2:
+        pytest.skip("needs two visible GPUs (RCCL refuses two ranks on one device)")
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("CS_BENCH_BACKEND", None)   # -> nccl
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--config", config, "--frames", str(frames), "--verify", "--no-cpu-baseline", "--gather", gather]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("[verify] rank") == 2 and "MISMATCH" not in r.stdout
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["frames_total"] == frames
+    assert line["ranks"]["backend"] == "nccl" and line["ranks"]["world_size"] == 2 and line["ranks"]["all_reduce_of_ones"] == 2
+    assert len({d["pci"] or d["local_rank"] for d in line["ranks"]["devices"]}) == 2   # two different devices
+    assert line["diagnostics"]["kernel_error_flags"] == 0 and line["config"]["gather"] == gather

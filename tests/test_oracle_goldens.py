@@ -263,3 +263,34 @@ def test_digests_at_baseline_sizes():
         assert sha(k[0]) == c["stereo_u8"], cid
         assert sha(k[1]) == c["dl_u8"] and sha(k[2]) == c["dr_u8"], cid
         assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"], cid
+
+
+def test_node_oracle_on_scene8_depth(golden_scene8):
+    """Depth of the kind the reference's own fixture maker draws (/root/reference/create_test_images.py:3-77): an 8-bit gradient with
+    flat ellipses, hard and softened silhouettes (tools/synth.scene8) -- every UI technique, blur off and on, against the reference
+    node's outputs (tools/make_goldens.py --only-scene8); plus the digests of one 1080p frame."""
+    from conftest import scene8_case_expected, scene8_case_inputs
+    g = golden_scene8
+    for case in g.meta["cases"]:
+        img, depth = scene8_case_inputs(g, case)
+        ui = {v: k for k, v in node_oracle.FILL_KEYS.items()}[case["fill"]]
+        got = node_oracle.generate(img, depth, case["divergence"], case["separation"], case["mode"], case["balance"],
+                                   case["convergence"], case["exponent"], ui, case["edge_threshold"], case["strength"],
+                                   case["blur"], **case["kw"])
+        want = scene8_case_expected(g, case)
+        cid = case["id"]
+        if case["fill"] == "gpu_warp":   # (the fixture keeps every 8th row of the float32 colours)
+            assert np.abs(got[0][:, ::case["row_step"]] - want[0]).max() <= GPU_WARP_COLOUR_TOL, (cid, np.abs(got[0][:, ::case["row_step"]] - want[0]).max())
+        else:
+            assert np.array_equal(got[0], want[0]), cid
+        assert np.array_equal(got[1][..., 0], want[1]) and np.array_equal(got[2][..., 0], want[2]), cid
+        assert np.array_equal(got[3], want[3]), cid
+    c = g.meta["digest_1080p"]
+    img = synth.image_u8(c["h"], c["w"], seed=c["image_seed"], hazards=False)[None].astype(np.float32) / np.float32(255.0)
+    depth = synth.depth_batch(c["kind"], 1, c["h"], c["w"], channels=3)
+    got = node_oracle.generate(img, depth, c["divergence"], 0.0, c["mode"], 0.0, 0.5, 2.0, c["fill_ui"], 20.0, 20.0, c["blur"],
+                               depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+    k = [np.round(a * 255.0).astype(np.uint8) for a in (got[0], got[1][..., 0], got[2][..., 0])]
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    assert sha(k[0]) == c["stereo_u8"] and sha(k[1]) == c["dl_u8"] and sha(k[2]) == c["dr_u8"]
+    assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"]

@@ -314,6 +314,51 @@ def gen_node_extra(gs):
     print("node_extra:", len(cases), "cases")
 
 
+def gen_scene8(gs):
+    """the reference's node on depth of the kind its own fixture maker draws (create_test_images.py:3-77: an 8-bit
+    gradient + flat ellipses with hard silhouettes) -- tools/synth.scene8, hard and softened silhouettes -- for every UI technique,
+    blur off and on, 2 x 256 x 256; plus SHA-256 digests of one 1080p frame (polylines_soft, blur on)."""
+    node = gs.StereoImageNode()
+    arrays, cases = {}, []
+    img8 = smooth_image(1, 256, 256, 19)   # (one frame per case, and every 8th row of the float32 gpu_warp colours: a small fixture)
+    arrays["img_u8"] = img8
+    image = torch.from_numpy(img8.astype(np.float32) / np.float32(255.0))
+    for grp, soften in (("hard", False), ("soft", True)):
+        depth8 = np.stack([np.round(synth.scene8(256, 256, seed=j, soften=soften) * 255) for j in range(1)]).astype(np.uint8)
+        arrays[f"{grp}/depth_u8"] = depth8
+        depth = torch.from_numpy(np.repeat((depth8.astype(np.float32) / np.float32(255.0))[..., None], 3, -1))
+        for fill in UI_FILLS:
+            for blur in ((False, True) if grp == "soft" else (False,)):
+                mode = "left-right" if fill != "none" else "red-cyan-anaglyph"
+                cid = f"{grp}/{fill}/blur{int(blur)}"
+                kw = dict(depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+                outs = node.generate(image, depth, 6.0, 0.0, mode, 0.0, 0.5, 2.0, UI_FILLS[fill], 20.0, 20.0, blur, **kw)
+                stereo, dl, dr, mask = [o.numpy() for o in outs]
+                if fill == "gpu_warp":
+                    arrays[f"{cid}/stereo_rows"], arrays[f"{cid}/dl"], arrays[f"{cid}/dr"] = stereo[:, ::8].copy(), dl[..., 0].copy(), dr[..., 0].copy()
+                else:
+                    for name, a in (("stereo", stereo), ("dl", dl[..., 0]), ("dr", dr[..., 0])):
+                        k = np.round(a * 255.0).astype(np.uint8)
+                        assert np.array_equal(k.astype(np.float32) / np.float32(255.0), a)
+                        arrays[f"{cid}/{name}_u8"] = k
+                arrays[f"{cid}/mask"] = np.packbits(mask.astype(bool))
+                cases.append(dict(id=cid, group=grp, fill=fill, row_step=8, mode=mode, divergence=6.0, separation=0.0, balance=0.0, convergence=0.5,
+                                  exponent=2.0, edge_threshold=20.0, strength=20.0, blur=blur, kw=kw,
+                                  shapes=dict(stereo=list(stereo.shape), depth=list(dl.shape), mask=list(mask.shape))))
+                print("scene8", cid, flush=True)
+    h, w = 1080, 1920
+    img1 = synth.image_u8(h, w, seed=1000, hazards=False)[None]
+    depth = synth.depth_batch("scene8", 1, h, w, channels=3)
+    outs = node.generate(torch.from_numpy(img1.astype(np.float32) / np.float32(255.0)), torch.from_numpy(depth), 3.5, 0.0, "left-right", 0.0,
+                         0.5, 2.0, "Fill - Polylines Soft", 20.0, 20.0, True, depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+    stereo, dl, dr, mask = [o.numpy() for o in outs]
+    k = [np.round(a * 255.0).astype(np.uint8) for a in (stereo, dl[..., 0], dr[..., 0])]
+    digest = dict(h=h, w=w, kind="scene8", fill_ui="Fill - Polylines Soft", mode="left-right", divergence=3.5, blur=True, image_seed=1000,
+                  stereo_u8=sha(k[0]), dl_u8=sha(k[1]), dr_u8=sha(k[2]), mask=sha(np.packbits(mask.astype(bool))), mask_sum=int(mask.sum()))
+    np.savez_compressed(os.path.join(OUT, "scene8.npz"), meta=json.dumps(dict(cases=cases, digest_1080p=digest)), **arrays)
+    print("scene8:", len(cases), "cases; 1080p digest", digest["stereo_u8"][:16])
+
+
 def gen_digests(gs):
     """SHA-256 digests of the reference's node outputs at BASELINE.json sizes: inputs come from tools/synth.py
     (seeded), so only the digests are committed.  Minutes of pure-Python reference time per case."""
@@ -563,6 +608,9 @@ def main():
     if "--only-dialect" in sys.argv:
         gen_dialect_f64(sig)
         return
+    if "--only-scene8" in sys.argv:
+        gen_scene8(gs)
+        return
     gen_apply_stereo_divergence(sig)
     gen_hidden(sig)
     gen_blur(sig)
@@ -576,6 +624,7 @@ def main():
     gen_numpy_inputs(sig)
     gen_forward_warp_params(sig)
     gen_numpy_blur(sig)
+    gen_scene8(gs)
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

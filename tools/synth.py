@@ -52,7 +52,37 @@ def clipped(h, w, seed=0):
     return np.clip(d, 0.0, 1.0).astype(np.float32)
 
 
-DEPTHS = {"clipped": clipped, "radial": radial, "stepped": stepped, "noisy_ramp": noisy_ramp, "random8": random8, "blobs": blobs}
+def scene8(h, w, seed=0, soften=True):
+    """Quantised smooth depth with object edges -- what real estimators deliver as an 8-bit map, the kind of depth the reference's own
+    fixture maker draws (/root/reference/create_test_images.py:3-77, described, not copied): an 8-bit vertical gradient as the far-to-mid
+    background, three flat ellipses (far, mid, near: levels 100 / 170 / 240) with hard silhouettes and a slightly brighter rim, values
+    k / 255.  `seed` moves the ellipses a little (frames of a batch differ); `soften`: a mild [1 2 1] / 4 blur across the silhouettes,
+    re-quantised to 8 bits (depth estimators do not deliver single-pixel steps)."""
+    rng = np.random.default_rng(7000 + seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    d = np.floor(80.0 + (y / h) * 50.0)
+    rim = max(2.0, 5.0 * min(h, w) / 600.0)
+    # (centre x, centre y, radius x, radius y) as fractions of the frame; fill level, rim level
+    for (cx, cy, rx, ry), lvl, rim_lvl in (((0.28, 0.375, 0.094, 0.125), 100.0, 120.0), ((0.5625, 0.5, 0.125, 0.167), 170.0, 190.0),
+                                          ((0.375, 0.75, 0.125, 0.167), 240.0, 255.0)):
+        cx, cy = (cx + rng.uniform(-0.04, 0.04)) * w, (cy + rng.uniform(-0.04, 0.04)) * h
+        rx, ry = rx * w, ry * h
+        q = ((x - cx) / rx) ** 2 + ((y - cy) / ry) ** 2
+        q_in = ((x - cx) / max(rx - rim, 1.0)) ** 2 + ((y - cy) / max(ry - rim, 1.0)) ** 2
+        d = np.where(q < 1.0, rim_lvl, d)
+        d = np.where(q_in < 1.0, lvl, d)
+    if soften:
+        for axis in (0, 1):
+            p = np.pad(d, [(1, 1) if a == axis else (0, 0) for a in (0, 1)], mode="edge")
+            lo = p[:-2] if axis == 0 else p[:, :-2]
+            hi = p[2:] if axis == 0 else p[:, 2:]
+            d = (lo + 2.0 * d + hi) / 4.0
+        d = np.floor(d + 0.5)
+    return (np.clip(d, 0, 255).astype(np.float32) / np.float32(255.0)).astype(np.float32)
+
+
+DEPTHS = {"clipped": clipped, "radial": radial, "stepped": stepped, "noisy_ramp": noisy_ramp, "random8": random8, "blobs": blobs,
+          "scene8": scene8}
 
 
 def image_u8(h, w, seed=0, hazards=True):
