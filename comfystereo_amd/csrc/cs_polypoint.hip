@@ -1167,30 +1167,35 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
 }
 
 // Second tier (round 6): the rows k_polypoint flagged (list entries frame * h + row | eye mask << 30, k_collect_rows), every flagged
-// eye of them through the same tile function with DC = 512 slots for pixels under reversed segments and longer per-pixel lists -- what a
-// depth map with strong silhouettes needs at the metric's divergence (tools/synth.scene8: a fold of a near object over the background is
-// ~130 pixels wide at 4K, three of them in a tile of 768; the first tier's 160 slots hold one).  grid = (tiles, G): workgroup (t, g)
-// does tile t of the list entries g, g + G, ...; an empty list costs a launch of idle workgroups.  Rows this pass cannot finish
-// either (exact ties, lists beyond even these capacities) are flagged in `A.rowflag` -- a second flag array -- for the row kernel.
-#define PP_DCAP2 512
+// eye of them through the same tile function with longer per-pixel lists (and PP_DCAP2 slots for pixels under reversed segments) -- what a
+// depth map with soft silhouettes needs at the metric's divergence (tools/synth.scene8: under a fold three layers overlap, a softened
+// silhouette is three steep segments instead of one).  A PLAIN launch: grid = (tiles x 2 eyes, entries the list can hold [y, z]); a workgroup
+// beyond the list's count, or of an eye the entry does not name, returns at once (the count is only known on the device; an idle
+// workgroup costs a dispatch slot).  The first version looped persistent workgroups over the list around the inlined tile function:
+// 128 registers, 37-57 of them spilled, four workgroups per CU -- 3-4 x the first tier's time per row (tools/sessions/r06_s11.sh).
+// Rows this pass cannot finish either (exact ties, lists beyond even these capacities) are flagged in `A.rowflag` -- a second flag
+// array -- for the row kernel.
+#ifndef PP_DCAP2
+#define PP_DCAP2 192
+#endif
+#ifndef PP_MINW2
+#define PP_MINW2 5
+#endif
 template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW, int SHARP>
 __global__ void __launch_bounds__(NT, MINW)
 k_polypoint_listed(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
                    int hot_w, int hot_h, int hot_S, int hot_T, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode, int hot_npt,
                    const uint32_t* __restrict__ row_list, const uint32_t* __restrict__ row_count, PolyPointArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t count = row_count[0];
-    for (uint32_t li = blockIdx.y; li < count; li += gridDim.y) {
-        const uint32_t e = row_list[li];
-        const uint32_t idx = e & 0x3fffffffu;
-        const int frame = (int)(idx / (uint32_t)hot_h), row = (int)(idx - (uint32_t)frame * (uint32_t)hot_h);
-        for (int eyei = 0; eyei < 2; eyei++) {
-            if (!((e >> (30 + eyei)) & 1u)) continue;
-            pp_tile<NT, SLOTS, OUT, PT_KP, PT_KS, SHARP, 0, PP_DCAP2>(hot_image, hot_depth0, hot_depth1, hot_w, hot_h, hot_S, hot_T, -1, hot_off_dflag,
-                                                                       hot_off_dcnt, hot_pow_mode, hot_npt, 0, A, smem, row, eyei, (int)blockIdx.x, frame);
-            __syncthreads();   // (the tile's LDS is reused)
-        }
-    }
+    const uint32_t li = blockIdx.z * 65535u + blockIdx.y;   // (grid.y is limited to 65535)
+    if (li >= row_count[0]) return;
+    const uint32_t e = row_list[li];
+    const int eyei = (int)(blockIdx.x & 1u);
+    if (!((e >> (30 + eyei)) & 1u)) return;
+    const uint32_t idx = e & 0x3fffffffu;
+    const int frame = (int)(idx / (uint32_t)hot_h), row = (int)(idx - (uint32_t)frame * (uint32_t)hot_h);
+    pp_tile<NT, SLOTS, OUT, PT_KP, PT_KS, SHARP, 0, PP_DCAP2>(hot_image, hot_depth0, hot_depth1, hot_w, hot_h, hot_S, hot_T, -1, hot_off_dflag,
+                                                               hot_off_dcnt, hot_pow_mode, hot_npt, 0, A, smem, row, eyei, (int)(blockIdx.x >> 1), frame);
 }
 
 // Depth-map output of an eye the tile kernel does not visit (modes left-only / only-right still return both depth maps,
@@ -1373,11 +1378,13 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
 // as the first tier (the hints name tiles).  hipErrorNotSupported: not for this call (dialect, single-eye layouts, wide-halo geometry).
 template <int SHARP>
 static hipError_t polypoint_launch_listed(PolyPointArgs& A, int out, const uint32_t* list, const uint32_t* count, hipStream_t stream) {
-    constexpr int NT = 256, SLOTS = 4, MINW = 4;
+    constexpr int NT = 256, SLOTS = 4, MINW = PP_MINW2;
     constexpr int KP = SHARP ? 8 : 6, KS = SHARP ? 12 : 9;   // (first tier: 6 / 9 and 4 / 5)
     const int tiles = (A.w + A.T - 1) / A.T;
-    // persistent workgroups: what is resident at once (4 per CU), spread over the tiles
-    dim3 grid(tiles, (unsigned)((4 * 256 + tiles - 1) / tiles)), block(NT);
+    const long long rows = (long long)A.n * A.h;
+    if (rows > 65535LL * 65535LL) return hipErrorNotSupported;
+    // (x: tile and eye; y, z: every list entry there can be -- grid.y is limited to 65535)
+    dim3 grid(tiles * 2, (unsigned)(rows < 65535 ? rows : 65535), (unsigned)((rows + 65534) / 65535)), block(NT);
     const size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS, PP_DCAP2);
     const int npt = polypoint_npt(NT, SLOTS, A.T, A.S);
     const int off_dflag = 8 * npt + 4 * npt + 4 * (A.T > 128 ? A.T : 128), off_dcnt = off_dflag + ((2 * A.T + 3) & ~3);
