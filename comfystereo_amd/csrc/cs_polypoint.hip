@@ -1169,7 +1169,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
 // Second tier (round 6): the rows k_polypoint flagged (list entries frame * h + row | eye mask << 30, k_collect_rows), every flagged
 // eye of them through the same tile function with longer per-pixel lists (and PP_DCAP2 slots for pixels under reversed segments) -- what a
 // depth map with soft silhouettes needs at the metric's divergence (tools/synth.scene8: under a fold three layers overlap, a softened
-// silhouette is three steep segments instead of one).  A PLAIN launch: grid = (tiles x 2 eyes, entries the list can hold [y, z]); a workgroup
+// silhouette is three steep segments instead of one).  A PLAIN launch: grid = (tiles x 2 eyes, the first list entries [polypoint_tier2_cap]); a workgroup
 // beyond the list's count, or of an eye the entry does not name, returns at once (the count is only known on the device; an idle
 // workgroup costs a dispatch slot).  The first version looped persistent workgroups over the list around the inlined tile function:
 // 128 registers, 37-57 of them spilled, four workgroups per CU -- 3-4 x the first tier's time per row (tools/sessions/r06_s11.sh).
@@ -1178,6 +1178,18 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
 #ifndef PP_DCAP2
 #define PP_DCAP2 192
 #endif
+static unsigned polypoint_tier2_cap(long long rows) {
+    const long long q = (rows + 3) / 4;
+    return (unsigned)(q < 256 ? (rows < 256 ? rows : 256) : (q > 65535 ? 65535 : q));
+}
+// list entries beyond the second tier's grid: flagged for the row kernel as they are (flag byte: bits 1 / 2 = eye 0 / 1, k_collect_rows)
+__global__ void __launch_bounds__(256) k_polypoint_carry(const uint32_t* __restrict__ row_list, const uint32_t* __restrict__ row_count, unsigned cap,
+                                                         uint8_t* __restrict__ rowflag2) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x + cap;
+    if (i >= row_count[0]) return;
+    const uint32_t e = row_list[i];
+    rowflag2[e & 0x3fffffffu] = (uint8_t)((e >> 30) << 1);   // (one list entry per row: no other writer of this byte)
+}
 #ifndef PP_MINW2
 #define PP_MINW2 5
 #endif
@@ -1187,7 +1199,7 @@ k_polypoint_listed(const float* __restrict__ hot_image, const float* __restrict_
                    int hot_w, int hot_h, int hot_S, int hot_T, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode, int hot_npt,
                    const uint32_t* __restrict__ row_list, const uint32_t* __restrict__ row_count, PolyPointArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t li = blockIdx.z * 65535u + blockIdx.y;   // (grid.y is limited to 65535)
+    const uint32_t li = blockIdx.y;
     if (li >= row_count[0]) return;
     const uint32_t e = row_list[li];
     const int eyei = (int)(blockIdx.x & 1u);
@@ -1382,9 +1394,12 @@ static hipError_t polypoint_launch_listed(PolyPointArgs& A, int out, const uint3
     constexpr int KP = SHARP ? 8 : 6, KS = SHARP ? 12 : 9;   // (first tier: 6 / 9 and 4 / 5)
     const int tiles = (A.w + A.T - 1) / A.T;
     const long long rows = (long long)A.n * A.h;
-    if (rows > 65535LL * 65535LL) return hipErrorNotSupported;
-    // (x: tile and eye; y, z: every list entry there can be -- grid.y is limited to 65535)
-    dim3 grid(tiles * 2, (unsigned)(rows < 65535 ? rows : 65535), (unsigned)((rows + 65534) / 65535)), block(NT);
+    // x: tile and eye; y: the list entries this tier takes -- the first quarter of the rows there are (at most 65535: grid.y); an idle
+    // workgroup costs a dispatch slot (1.97 M of them, every row of 64 4K frames: 0.71 ms, 5 % of the step, tools/sessions/r06_s15.sh),
+    // so the grid is sized for what the tier is for -- some rows of a frame -- and k_polypoint_carry hands the entries beyond it on
+    const unsigned cap = polypoint_tier2_cap(rows);
+    dim3 grid(tiles * 2, cap), block(NT);
+    hipLaunchKernelGGL(k_polypoint_carry, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, list, count, cap, A.rowflag);
     const size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS, PP_DCAP2);
     const int npt = polypoint_npt(NT, SLOTS, A.T, A.S);
     const int off_dflag = 8 * npt + 4 * npt + 4 * (A.T > 128 ? A.T : 128), off_dcnt = off_dflag + ((2 * A.T + 3) & ~3);
