@@ -75,6 +75,13 @@ namespace cs {
 #ifndef PP_DCAP_SHARP
 #define PP_DCAP_SHARP PP_DCAP
 #endif
+#ifndef PP_SOFT_PLCAP
+#define PP_SOFT_PLCAP 0   // polylines_soft: entries of the pass-2 pixel list (0: one per tile pixel)
+#endif
+#ifndef PP_SOFT_KP
+#define PP_SOFT_KP 4   // (polylines_soft: 72 registers, seven workgroups per CU, 21 584 bytes of LDS -- no room for more, section 10 of DESIGN.md)
+#define PP_SOFT_KS 5
+#endif
 #define PP_DIRTY 0x8000u     // dflag (16 bits per tile pixel since round 5): pixel lies under a reversed segment; low 15 bits = its list slot
 
 __constant__ csm::PowfTables c_pp_powf_tables = CS_POWF_TABLES_INIT;
@@ -233,7 +240,8 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
         if (!SHARP) return pz[o];
         return (o <= 0 || o >= npts - 1) ? 0.0f : pz[1 + ((o - 1) >> 1)];
     };
-    uint32_t* plist = (uint32_t*)(pz + NPT);                                      // [max(T, 128)] pixels evaluated in pass 2
+    uint32_t* plist = (uint32_t*)(pz + NPT);                                      // [max(plcap, 128)] pixels evaluated in pass 2
+    const int plcap = (!SHARP && PP_SOFT_PLCAP && DC == PP_DCAP) ? min(T, PP_SOFT_PLCAP) : T;   // (the host's polypoint_plcap)
     // The powf tables: exponents 1 and 2 only run the clone for the 0.4 % risky squares and read the tables where they are,
     // in constant memory (512 bytes, L1-resident: no copy, nothing to wait for before barrier 0: +2 %); any other exponent
     // sends every point through the clone, and the tables are copied into LDS (overlaying plist until barrier 1: +6 % there)
@@ -632,7 +640,7 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
 
     auto list_push = [&](uint32_t kind, int o, int q) {
         const unsigned idx = atomicAdd((unsigned*)&flags[PF_NLIST], 1u);
-        if (idx < (unsigned)T) plist[idx] = (kind << 28) | ((uint32_t)o << 12) | (uint32_t)q;
+        if (idx < (unsigned)plcap) plist[idx] = (kind << 28) | ((uint32_t)o << 12) | (uint32_t)q;
         else PP_HAZARD(4);
     };
     const float eps32 = (float)1e-7;
@@ -870,7 +878,7 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
     // =====================================================================================================
     // pass 2: the listed pixels, densely packed
     // =====================================================================================================
-    const int nlist = min(flags[PF_NLIST], T);
+    const int nlist = min(flags[PF_NLIST], plcap);
     // ---- chain path (first generation, cs_polytile.hip eval_chain): the pixel's np points are CONSECUTIVE polyline points
     // o1 .. o1+np-1 with strictly increasing x inside the pixel, the np+1 segments around them are forward, and no other
     // layer covers the pixel (it is not under a reversed segment) -- sub-interval k belongs to chain segment k.  np == 0:
@@ -1267,9 +1275,14 @@ static int polypoint_npt(int nt, int slots, int T, int S) {
     const int all = slots * nt + 4, need = ((T + 2 * S + 2 + 2 + 1 + 3) & ~3) + 4;
     return need < all ? need : all;
 }
-static size_t polypoint_lds(int nt, int slots, int T, int S, int KP, int KS, int dcap = PP_DCAP) {
+// entries of the pass-2 pixel list (pp_tile's plcap): one per tile pixel; the first tier of polylines_soft may take fewer (PP_SOFT_PLCAP)
+static int polypoint_plcap(int T, int sharp, int dcap) {
+    const int cap = (!sharp && PP_SOFT_PLCAP && dcap == PP_DCAP) ? (T < PP_SOFT_PLCAP ? T : PP_SOFT_PLCAP) : T;
+    return cap > 128 ? cap : 128;
+}
+static size_t polypoint_lds(int nt, int slots, int T, int S, int KP, int KS, int dcap = PP_DCAP, int sharp = 1) {
     const size_t npt = (size_t)polypoint_npt(nt, slots, T, S);
-    return 8 * npt + 4 * npt + 4 * (size_t)(T > 128 ? T : 128) + (size_t)((2 * T + 3) & ~3) + 2 * (size_t)dcap * (2 + (size_t)KP + KS) +
+    return 8 * npt + 4 * npt + 4 * (size_t)polypoint_plcap(T, sharp, dcap) + (size_t)((2 * T + 3) & ~3) + 2 * (size_t)dcap * (2 + (size_t)KP + KS) +
            4 * PF_WORDS + 1024 + 64;
 }
 
@@ -1294,13 +1307,13 @@ template <int NT, int SLOTS, int MINW, int SHARP, int DIA = 0>
 static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream) {
     // points / forward segments a pixel under a reversed segment can hold in its lists (more: the row is redone); sharp has two
     // points per source (the values the first-generation kernel settled on)
-    constexpr int KP = SHARP ? PP_SHARP_KP : 4, KS = SHARP ? PP_SHARP_KS : 5;
+    constexpr int KP = SHARP ? PP_SHARP_KP : PP_SOFT_KP, KS = SHARP ? PP_SHARP_KS : PP_SOFT_KS;
     const int tiles = (A.w + A.T - 1) / A.T;
     dim3 grid(tiles * 8, A.single >= 0 ? (A.h + 7) / 8 : eye_group_grid_y(A.h), A.n), block(NT);   // (see the kernel's prologue)
-    size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS, SHARP ? PP_DCAP_SHARP : PP_DCAP);
+    size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS, SHARP ? PP_DCAP_SHARP : PP_DCAP, SHARP);
     // (development: CS_DEBUG_PT_VARIANT 13..16 pads the LDS request so that only 3..6 workgroups fit a CU -- occupancy what-if)
     const int npt = polypoint_npt(NT, SLOTS, A.T, A.S);
-    const int off_dflag = 8 * npt + 4 * npt + 4 * (A.T > 128 ? A.T : 128), off_dcnt = off_dflag + ((2 * A.T + 3) & ~3);
+    const int off_dflag = 8 * npt + 4 * npt + 4 * polypoint_plcap(A.T, SHARP, SHARP ? PP_DCAP_SHARP : PP_DCAP), off_dcnt = off_dflag + ((2 * A.T + 3) & ~3);
     // sharp under the dialect: both points of every record, behind everything else
     const int off_xq = (SHARP && DIA) ? (int)((lds + 15) & ~(size_t)15) : 0;
     if (SHARP && DIA) lds = (size_t)off_xq + 8 * (size_t)npt + 64;
@@ -1400,7 +1413,7 @@ static hipError_t polypoint_launch_listed(PolyPointArgs& A, int out, const uint3
     const unsigned cap = polypoint_tier2_cap(rows);
     dim3 grid(tiles * 2, cap), block(NT);
     hipLaunchKernelGGL(k_polypoint_carry, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, list, count, cap, A.rowflag);
-    const size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS, PP_DCAP2);
+    const size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS, PP_DCAP2, SHARP);
     const int npt = polypoint_npt(NT, SLOTS, A.T, A.S);
     const int off_dflag = 8 * npt + 4 * npt + 4 * (A.T > 128 ? A.T : 128), off_dcnt = off_dflag + ((2 * A.T + 3) & ~3);
     const int pow_mode = (A.dbg == 17 || !(A.e32 == 2.0f || A.e32 == 1.0f)) ? 0 : (A.e32 == 2.0f ? 2 : 1);
