@@ -405,7 +405,9 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         return hl <= polypoint_max_halo() && (variant == 0 || (variant >= 3 && variant <= 7) || (variant >= 13 && variant <= 16) || (variant >= 41 && variant <= 50));
     };
     // (the tile kernels are dialect D32, plus -- round 5 -- the float64 disparity chain alone: k_polypoint<..., DIA>)
-    const bool tile_dialect = A.d64 == 0 || (A.d64 == 1 && polypoint_takes(halo));
+    // (round 6: numba's typing of the sweep as well -- d64 & 2, k_polypoint<..., SW> -- in the point kernel's default geometry)
+    const bool tile_dialect = A.d64 == 0 || (A.d64 == 1 && polypoint_takes(halo)) ||
+                              ((A.d64 & 2) && polypoint_takes(halo) && polypoint_sweep64_ok(A.w, halo) && !dev_switch(CS_DEBUG_PT_VARIANT));
     const bool ana_tiled = poly && tile_dialect && A.anaglyph && ana_sbs && A.image_f32 && !A.out_u8 && halo <= polytile_max_halo() && rowflag &&
                            !dev_switch(CS_DEBUG_NO_TILE);
     const RowArgs Afinal = A;
@@ -613,7 +615,8 @@ static const char* width_refusal(const cs_params* p, int w) {
         const int halo = poly_halo(p->divergence * (1 + p->stereo_balance), p->divergence * (1 - p->stereo_balance), p->separation,
                                    p->stereo_offset_exponent, p->convergence_point, w);
         const int d64 = (p->flags >> 3) & 3;
-        const bool tile_dialect = d64 == 0 || (d64 == 1 && halo <= polypoint_max_halo());
+        const bool tile_dialect = d64 == 0 || (d64 == 1 && halo <= polypoint_max_halo()) ||
+                                  ((d64 & 2) && halo <= polypoint_max_halo() && polypoint_sweep64_ok(w, halo) && !dev_switch(CS_DEBUG_PT_VARIANT));
         if (!tile_dialect || halo > polytile_max_halo() || dev_switch(CS_DEBUG_NO_TILE))
             return "frame too wide for the LDS-resident row kernel (anaglyph form)";
     }

@@ -108,6 +108,7 @@ hipError_t launch_polypoint(const RowArgs& A, int S, uint8_t* rowflag, hipStream
 hipError_t launch_polypoint_tier2(const RowArgs& A, int S, uint8_t* rowflag2, hipStream_t stream, int sharp, uint32_t* hint2, int tile_width,
                                   const uint32_t* list, const uint32_t* count);
 int polypoint_max_halo();
+bool polypoint_sweep64_ok(int w, int halo);
 // anaglyph modes behind the tile kernel: the eyes as uint8 codes side by side -> the composite (rows flagged in rowflag excepted)
 hipError_t launch_anaglyph_compose(const uint8_t* sbs, const uint8_t* rowflag, int n, int h, int w, int anaglyph, float* stereo,
                                    int stereo_is_u8, float* mask, hipStream_t stream);

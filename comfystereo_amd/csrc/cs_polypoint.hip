@@ -82,6 +82,12 @@ namespace cs {
 #define PP_SOFT_KP 4   // (polylines_soft: 72 registers, seven workgroups per CU, 21 584 bytes of LDS -- no room for more, section 10 of DESIGN.md)
 #define PP_SOFT_KS 5
 #endif
+#ifndef PP_DCAP2
+#define PP_DCAP2 192   // second tier (k_polypoint_listed): pixels under reversed segments a tile can hold
+#endif
+#ifndef PP_SW_MINW
+#define PP_SW_MINW 4   // workgroups per CU of the sweep-typing (SW) instantiations
+#endif
 #define PP_DIRTY 0x8000u     // dflag (16 bits per tile pixel since round 5): pixel lies under a reversed segment; low 15 bits = its list slot
 
 __constant__ csm::PowfTables c_pp_powf_tables = CS_POWF_TABLES_INIT;
@@ -181,7 +187,12 @@ enum { PK_CHAIN = 0u, PK_BRIDGE = 1u };
 // The tile function: one tile of one row-eye.  Inlined into k_polypoint (every row once, blockIdx decoded below) and into
 // k_polypoint_listed (round 6: the second tier -- the rows the first pass flagged, once more with room for more pixels under reversed
 // segments and longer lists, before the general row kernel gets what is left).  DC: pixels under reversed segments a tile can hold.
-template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int SHARP, int DIA, int DC>
+// SW (round 6, second session): numba's typing of the SWEEP as well (dialect bit "int64-sum" of cs_params.flags = RowArgs::d64 & 2; with the
+// float64 chain: full D64, what an install WITH numba computes, reference :1951-1991 under @njit, oracle_polylines `g_dialect & 2`) -- every
+// sub-interval quantity (from, to, length, centre, the segment parameter, the closeness, the colour term) in float64, the colour sums rounded
+// to float32 after every piece.  Derived typing like every D64 statement: checked against the oracle under the same
+// setting.  SW instantiations are compiled with DIA = 1 and pick the chain at run time (A.d64 & 1).
+template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int SHARP, int DIA, int DC, int SW = 0>
 __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
                                         int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode,
                                         int hot_npt, int hot_off_xq, const PolyPointArgs& A, char* const smem, const int row, const int eyei,
@@ -323,6 +334,8 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
 
     const float o0f = (float)o0, o1f = (float)(o0 + wt);   // tile = [o0f, o1f)
     bool hazard = false;
+    // the float64 disparity chain: compiled in by DIA; the sweep-typing instantiations (SW) decide per call
+    const bool chain64 = DIA && (!SW || (A.d64 & 1));
     // ---- pixels under the reversed segment (xa -> xb), xb <= xa: slots in the tile's lists.  Called by whole waves.
     auto mark_reversed = [&](unsigned long long m, float xa, float xb) {
         const bool rev = (m >> lane) & 1ull;
@@ -469,7 +482,7 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
             if (pow_mode == 0) r = true;
             risk |= r ? 1u << k : 0u;
         }
-        if (PP_DEV_IS(36) || DIA) risk = 0;   // (DIA: the float32 pow is not used)
+        if (PP_DEV_IS(36) || chain64) risk = 0;   // (float64 chain: the float32 pow is not used)
         // the full powf clone for the risky arguments (all of them for other exponents).  Behind its own branch: the compiler
         // otherwise hoists the clone's ~55 constant set-up instructions in front of the loop test, where every wave pays them.
         if (__any(risk != 0u)) {
@@ -496,7 +509,7 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
             float cdj = (sg[k] * pw[k]) * E.div32;                                   // coord_d   (:1926)
             float x = ((jf0 + (float)(k * NT)) + cdj) + E.sep32;                   // coord_x   (:1927)
             double cx64 = 0.0;
-            if (DIA) {   // the same two lines in float64, each result rounded once (pow(x, 2) == x * x, pow(x, 1) == x: exact in float64)
+            if (chain64) {   // the same two lines in float64, each result rounded once (pow(x, 2) == x * x, pow(x, 1) == x: exact in float64)
                 const double ax = (double)axs[k];
                 const double p64 = A.e64 == 2.0 ? ax * ax : (A.e64 == 1.0 ? ax : pow(ax, A.e64));
                 const double cd64 = ((double)sg[k] * p64) * A.eye[eyei].div64;
@@ -509,7 +522,7 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
             x = j < ns ? x : (SHARP ? 2.0f * tidf + (float)(2 * w + 1 - 2 * ns + 2 * k * NT) : tidf + (float)(2 * w - ns + k * NT));
             // the two points of a sharp source: x -+ 0.45 in float32 (:1933-1934); under the dialect (float)(x64 -+ 0.45), kept in xq
             float xl = x - HW, xr = x + HW;
-            if (SHARP && DIA && j < ns) { xl = (float)(cx64 - 0.45); xr = (float)(cx64 + 0.45); }
+            if (SHARP && chain64 && j < ns) { xl = (float)(cx64 - 0.45); xr = (float)(cx64 + 0.45); }
             if (SLOTS * NT + 4 == NPT || 1 + j < NPT) {   // (compile-time true for geometries whose every slot is allocated)
                 Pw[k * NT] = PQ{rgbk[k], x};
                 pzw[k * NT] = fabsf(cdj);
@@ -749,13 +762,37 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
         //   col <= c0 <= x - eps, c1 <= col + 1 <= xp  (monotone rounding of exact sums).
         const float g_first = fmin3(f0 - xm, f0 - tlo, thi - f0);
         float g = fmin3(fmin3(den0, den1, (f1 - f0) - 0.5f), fmin3(sig0, f0 - 1.5f, c1 - x), g_first);
+        // numba's typing of the sweep: the two pieces in float64 -- from = max(col, a) + eps, to = min(col + 1, b) - eps with a < col <= x <
+        // col + 1 <= b.  What the float32 form needs beyond "first and only point, both chain segments forward" (col >= 2, the centre of
+        // piece 1 right of x: float32 absorption) becomes: both pieces of positive length -- then col < centre 0 <= x - eps and x + eps <=
+        // centre 1 <= col + 1 - eps (+- an ulp of float64), each inside its own chain segment and in order.
+        double sgd0 = 0.0, sgd1 = 0.0, cd0 = 0.0, cd1 = 0.0;
+        if (SW) {
+            const double xd = (double)x, cold = (double)f0;
+            const double fr0 = cold + 1e-7, to0 = xd - 1e-7, fr1 = xd + 1e-7, to1 = (cold + 1.0) - 1e-7;
+            sgd0 = to0 - fr0; cd0 = fr0 + 0.5 * sgd0;
+            sgd1 = to1 - fr1; cd1 = fr1 + 0.5 * sgd1;
+            g = fmin3(fmin3(den0, den1, (f1 - f0) - 0.5f), g_first, (sgd0 > 0.0 && sgd1 > 0.0) ? 1.0f : -1.0f);
+        }
         // a sentinel neighbour makes a "flat" piece (other typing): frame-border tiles only
         if (edge_tile) g = fminf(g, fminf((float)j - 0.5f, (float)(ns - 1 - j) - 0.5f));
         const int q = (int)f0 - o0;
         bool dirty = false;
         if (fold_tile) dirty = g_first > 0.0f && (dflag[q] & PP_DIRTY) != 0;
         const bool fast = g > 0.0f && !dirty && act;
-        {
+        if (SW) {
+            // (center - x0) / (x1 - x0): the difference of the two float32 points is taken in float32 (:1986, both operands float32), the rest in float64
+            const double ip0 = (cd0 - (double)xm) / (double)den0, ip1 = (cd1 - (double)x) / (double)den1;
+            const double om0 = 1.0 - ip0, om1 = 1.0 - ip1;
+            const double cr = (double)ch0(pc.rgb), cg = (double)ch1(pc.rgb), cb = (double)ch2(pc.rgb);
+            float k0 = (float)(0.5 + ((double)ch0(pm.rgb) * om0 + cr * ip0) * sgd0);
+            float k1 = (float)(0.5 + ((double)ch1(pm.rgb) * om0 + cg * ip0) * sgd0);
+            float k2 = (float)(0.5 + ((double)ch2(pm.rgb) * om0 + cb * ip0) * sgd0);
+            k0 = (float)((double)k0 + (cr * om1 + (double)ch0(pp.rgb) * ip1) * sgd1);
+            k1 = (float)((double)k1 + (cg * om1 + (double)ch1(pp.rgb) * ip1) * sgd1);
+            k2 = (float)((double)k2 + (cb * om1 + (double)ch2(pp.rgb) * ip1) * sgd1);
+            if (fast) emit_k(q, k0, k1, k2);
+        } else {
             const float ip0 = div_core(c0 - xm, den0), ip1 = div_core(c1 - x, den1);
             const float om0 = 1.0f - ip0, om1 = 1.0f - ip1;
             // (both pieces have positive length here; the lerp operands are finite)
@@ -813,12 +850,47 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
         g = fminf(g, e2 ? fminf(sg2r, c2 - q2) : 1.0f);
         g = fminf(g, e3 ? fminf(sg3r, c3 - q3) : 1.0f);
         if (edge_tile) g = fminf(g, fminf((float)j - 0.5f, (float)(ns - 1 - j) - 0.5f));   // sentinel neighbours: other typing
+        // numba's typing of the sweep: the up to four pieces in float64 (see the soft branch): owner, the interpolating segments forward, the
+        // point after the pixel's last one beyond the pixel, every present piece of positive length
+        double s0d = 0.0, s1d = 0.0, s2d = 0.0, s3d = 0.0, c0d = 0.0, c2d = 0.0;
+        if (SW) {
+            const double cold = (double)colf, top = (cold + 1.0) - 1e-7;
+            const double q1d = (double)q1, q2d = (double)q2, q3d = (double)q3;
+            const double fr0d = cold + 1e-7, s0r = (q1d - 1e-7) - fr0d;
+            const double fr1d = (ownA ? q1d : cold) + 1e-7;
+            s1d = (e2 ? q2d - 1e-7 : top) - fr1d;
+            const double fr2d = q2d + 1e-7, s2r = (e3 ? q3d - 1e-7 : top) - fr2d;
+            const double fr3d = q3d + 1e-7, s3r = top - fr3d;
+            c0d = fr0d + 0.5 * s0r; c2d = fr2d + 0.5 * s2r;
+            s0d = ownA ? s0r : 0.0; s2d = e2 ? s2r : 0.0; s3d = (e2 && e3) ? s3r : 0.0;
+            const bool lens = s1d > 0.0 && (!ownA || s0r > 0.0) && (!e2 || s2r > 0.0) && (!(e2 && e3) || s3r > 0.0);
+            g = fmin3(den2, (floorf(q4) - colf) - 0.5f, lens ? 1.0f : -1.0f);
+            g = fminf(g, ownA ? den0 : 1.0f);
+            if (edge_tile) g = fminf(g, fminf((float)j - 0.5f, (float)(ns - 1 - j) - 0.5f));
+        }
         const bool own = ownA || ownB;
         const int q = (int)colf - o0;
         bool dirty = false;
         if (fold_tile) dirty = own && (dflag[own ? q : 0] & PP_DIRTY) != 0;
         const bool fast = g > 0.0f && own && !dirty && act;
-        {
+        if (SW) {
+            // lerp pieces: (cl * (1 - ip) + cr * ip) * sig; flat pieces (both ends one source, :1981-1984): c * sig; every term float64, the
+            // sum rounded to float32 piece by piece; an absent piece has length 0 and adds +0 exactly
+            const double ip0 = ((ownA ? c0d - (double)q0 : 0.0)) / (double)(ownA ? den0 : 1.0f), ip2 = (c2d - (double)q2) / (double)den2;
+            const double om0 = 1.0 - ip0, om2 = 1.0 - ip2;
+            const double mr = (double)ch0(pm.rgb), mg = (double)ch1(pm.rgb), mb = (double)ch2(pm.rgb);
+            const double cr = (double)ch0(pc.rgb), cg = (double)ch1(pc.rgb), cb = (double)ch2(pc.rgb);
+            const double nr = (double)ch0(pp.rgb), ng = (double)ch1(pp.rgb), nb = (double)ch2(pp.rgb);
+            float k0 = (float)(0.5 + (mr * om0 + cr * ip0) * s0d);
+            float k1 = (float)(0.5 + (mg * om0 + cg * ip0) * s0d);
+            float k2 = (float)(0.5 + (mb * om0 + cb * ip0) * s0d);
+            k0 = (float)((double)k0 + cr * s1d); k1 = (float)((double)k1 + cg * s1d); k2 = (float)((double)k2 + cb * s1d);
+            k0 = (float)((double)k0 + (cr * om2 + nr * ip2) * s2d);
+            k1 = (float)((double)k1 + (cg * om2 + ng * ip2) * s2d);
+            k2 = (float)((double)k2 + (cb * om2 + nb * ip2) * s2d);
+            k0 = (float)((double)k0 + nr * s3d); k1 = (float)((double)k1 + ng * s3d); k2 = (float)((double)k2 + nb * s3d);
+            if (fast) emit_k(q, k0, k1, k2);
+        } else {
             // (without piece 0 its quotient must still be finite -- the segment (q0 -> q1) may be reversed or empty then, and
             // NaN * 0 would poison the sums: 0 / 1)
             const float ip0 = div_core(ownA ? c0 - q0 : 0.0f, ownA ? den0 : 1.0f), ip2 = div_core(c2 - q2, den2);
@@ -923,6 +995,30 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
         chain = chain && cx[0] < colf && !(cxlast < colp1);
         float color0 = 0.5f, color1 = 0.5f, color2 = 0.5f;
         float prev = colf;
+        if (SW) {   // numba's typing: every piece in float64 (no piece is skipped: a piece of length 0 adds +-0)
+            double prevd = (double)colf;
+#pragma unroll
+            for (int k = 0; k <= PT_KP; k++) {
+                if (k <= wnp) {
+                    const bool live = chain && k <= np;
+                    const double ad = k == 0 ? (double)colf : fmax((double)colf, (double)cx[k]);   // (the point before the pixel lies left of it: checked above)
+                    const double bd = k < np ? fmin((double)colp1, (double)cx[k + 1]) : (double)colp1;
+                    const double fr = ad + 1e-7, sgd = (bd - 1e-7) - fr, cd = fr + 0.5 * sgd;
+                    const bool ok = ((double)cx[k] < cd) && !((double)cx[k + 1] < cd);
+                    chain = chain && (!live || ok) && (!live || (!(cd < prevd) && !(cd > (double)colp1)));
+                    prevd = live ? cd : prevd;
+                    const double ip_k = (cd - (double)cx[k]) / (double)(cx[k + 1] - cx[k]);
+                    const double om = 1.0 - ip_k;
+                    const bool flatp = cj[k] == cj[k + 1];
+                    const float n0 = (float)((double)color0 + (flatp ? (double)c0[k] * sgd : ((double)c0[k] * om + (double)c0[k + 1] * ip_k) * sgd));
+                    const float n1 = (float)((double)color1 + (flatp ? (double)c1[k] * sgd : ((double)c1[k] * om + (double)c1[k + 1] * ip_k) * sgd));
+                    const float n2 = (float)((double)color2 + (flatp ? (double)c2[k] * sgd : ((double)c2[k] * om + (double)c2[k + 1] * ip_k) * sgd));
+                    color0 = live ? n0 : color0;
+                    color1 = live ? n1 : color1;
+                    color2 = live ? n2 : color2;
+                }
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k <= PT_KP; k++) {
             if (k <= wnp) {
@@ -965,6 +1061,7 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
                 color2 = work ? n2 : color2;
             }
         }
+        }
         r8 = csm::f32_to_u8_wrap(color0); g8 = csm::f32_to_u8_wrap(color1); b8 = csm::f32_to_u8_wrap(color2);
         return chain;
     };
@@ -981,6 +1078,14 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
             const PQ a = P[lean ? (SHARP ? o >> 1 : o) : 1], b = P[lean ? (SHARP ? (o >> 1) + 1 : o + 1) : 2];
             const float ax = SHARP ? sr(lean ? (o >> 1) : 1, a.x) : a.x, bx = SHARP ? sl(lean ? (o >> 1) + 1 : 2, b.x) : b.x;
             const float colf = (float)(o0 + q);
+            if (SW) {   // the whole pixel as one piece in float64: [col + eps, col + 1 - eps]
+                const double fr = (double)colf + 1e-7, sgd = (((double)colf + 1.0) - 1e-7) - fr, cd = fr + 0.5 * sgd;
+                const double ip = (cd - (double)ax) / (double)(bx - ax), om = 1.0 - ip;
+                const float k0 = (float)(0.5 + ((double)ch0(a.rgb) * om + (double)ch0(b.rgb) * ip) * sgd);
+                const float k1 = (float)(0.5 + ((double)ch1(a.rgb) * om + (double)ch1(b.rgb) * ip) * sgd);
+                const float k2 = (float)(0.5 + ((double)ch2(a.rgb) * om + (double)ch2(b.rgb) * ip) * sgd);
+                if (lean) emit_k(q, k0, k1, k2);
+            } else {
             const float center = colf + 0.5f;
             const float ip = div_core(center - ax, bx - ax), om = 1.0f - ip;
             const float k0 = 0.5f + (ch0(a.rgb) * om + ch0(b.rgb) * ip) * sig_whole;
@@ -988,6 +1093,7 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
             const float k2 = 0.5f + (ch2(a.rgb) * om + ch2(b.rgb) * ip) * sig_whole;
             // the segment is forward, starts left of the pixel and ends right of it (checked when it was listed)
             if (lean) emit_k(q, k0, k1, k2);
+            }
         }
         const bool rest = act && !lean;
         if (__any(rest)) {
@@ -1052,6 +1158,77 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
             }
         }
         float color0 = 0.5f, color1 = 0.5f, color2 = 0.5f;
+        if (SW) {
+        // numba's typing of the same scan (oracle_polylines, `g_dialect & 2`; cs_rowwarp.hip P3c under the dialect): centre, segment parameter
+        // and closeness in float64; no piece is skipped
+        double prevd = (double)colf, ad = (double)colf;
+        for (int k = 0; k <= wnp; k++) {   // wave-uniform trip count; lanes with k > np idle
+            const bool live = pend && k <= np;
+            float b = INFINITY;
+#pragma unroll
+            for (int m2 = 0; m2 < PT_KP; m2++) b = (m2 == k && k < np) ? xs[m2] : b;
+            // (a: the previous point of the pixel, or anything left of it; b: the next one, or anything beyond the pixel)
+            const double bd = fmin((double)colp1, (double)b);
+            const double fr = ad + 1e-7, sgd = (bd - 1e-7) - fr, cd = fr + 0.5 * sgd;
+            ad = live ? fmax((double)colf, (double)b) : ad;
+            if (live && (cd < prevd || cd > (double)colp1)) PP_HAZARD(64);
+            prevd = live ? cd : prevd;
+            unsigned am = 0;
+#pragma unroll
+            for (int e = 0; e < PT_KS; e++)
+                if (e < wns) am |= (((double)se0[e] < cd) && !((double)se1[e] < cd)) ? (1u << e) : 0u;
+            const int nact = __popc(am);
+            int nqual = 0, o_pick = -1, o_best = -1;
+            double ip_pick = 0.0, ip_best = 0.0;
+            double bc = -1e-7;
+            bool tie = false;
+            auto scan_step = [&](bool on, int oe) {
+                const float x0 = px(oe), x1 = px(oe + 1);
+                const double ip_e = (cd - (double)x0) / (double)(x1 - x0);
+                o_pick = on ? oe : o_pick;
+                ip_pick = on ? ip_e : ip_pick;
+                const bool qual = on && 0.0 < ip_e && ip_e < 1.0;
+                const double cl = (1.0 - ip_e) * (double)pzv(oe) + ip_e * (double)pzv(oe + 1);
+                nqual += qual ? 1 : 0;
+                const bool better = qual && bc < cl;
+                tie = better ? false : (tie || (qual && cl == bc));
+                o_best = better ? oe : o_best;
+                ip_best = better ? ip_e : ip_best;
+                bc = better ? cl : bc;
+            };
+            if (!__any(live && nact > 2)) {
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const bool on = am != 0u;
+                    const int e = on ? __ffs((int)am) - 1 : 0;
+                    am &= am - 1u;
+                    scan_step(on, on ? (int)sgs[s * PT_KS + e] : 1);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < PT_KS; e++)
+                    if (e < wns) {
+                        const bool on = (am >> e) & 1u;
+                        scan_step(on, on ? (int)sgs[s * PT_KS + e] : 1);
+                    }
+            }
+            const bool multi = live && nact != 1;
+            if (multi && (nqual == 0 || tie)) PP_HAZARD(128);
+            const bool use_best = multi && o_best >= 0;
+            const bool contrib = live && (use_best || o_pick >= 0);
+            const int o = contrib ? (use_best ? o_best : o_pick) : 1;
+            const double ip_k = use_best ? ip_best : ip_pick;
+            const uint32_t rgb_l = prgb(o), rgb_r = prgb(o + 1);
+            const bool flatp = pcol(o) == pcol(o + 1);   // segment inside one source pixel: c * sig (:1981-1984)
+            const double om = 1.0 - ip_k;
+            const float n0 = (float)((double)color0 + (flatp ? (double)ch0(rgb_l) * sgd : ((double)ch0(rgb_l) * om + (double)ch0(rgb_r) * ip_k) * sgd));
+            const float n1 = (float)((double)color1 + (flatp ? (double)ch1(rgb_l) * sgd : ((double)ch1(rgb_l) * om + (double)ch1(rgb_r) * ip_k) * sgd));
+            const float n2 = (float)((double)color2 + (flatp ? (double)ch2(rgb_l) * sgd : ((double)ch2(rgb_l) * om + (double)ch2(rgb_r) * ip_k) * sgd));
+            color0 = contrib ? n0 : color0;
+            color1 = contrib ? n1 : color1;
+            color2 = contrib ? n2 : color2;
+        }
+        } else {
         float prev = colf, a = -INFINITY;
         for (int k = 0; k <= wnp; k++) {   // wave-uniform trip count; lanes with k > np idle
             const bool live = pend && k <= np;
@@ -1140,6 +1317,7 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
             color1 = contrib ? n1 : color1;
             color2 = contrib ? n2 : color2;
         }
+        }
         if (pend) emit(q, csm::f32_to_u8_wrap(color0), csm::f32_to_u8_wrap(color1), csm::f32_to_u8_wrap(color2));
     }
     if (hazard) {   // the row kernel redoes this EYE of the row (flag byte: bit 1 / 2 = eye 0 / 1; the byte is shared by both eyes'
@@ -1148,11 +1326,13 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
         atomicOr(reinterpret_cast<unsigned*>(A.rowflag + (idx & ~3u)), (eyei ? 4u : 2u) << (8u * (idx & 3u)));
         // (soft only: in the sharp instantiation, at its 80-register budget, this second atomic costs a spilled vector register --
         // scratch, +5 % HBM traffic, -3 % on ordinary depth; its flagged row-eyes leave the hint word 0 = the whole row)
-        if (!SHARP && A.hint) atomicOr(&A.hint[2u * idx + (uint32_t)eyei], 1u << min(tile, 31));
+        // (round 6: the SECOND tier of sharp -- 96 registers at five workgroups per CU -- records them: the lean row kernel then confines itself
+        // to the flagged tiles' columns for polylines_sharp too)
+        if ((!SHARP || DC == PP_DCAP2) && A.hint) atomicOr(&A.hint[2u * idx + (uint32_t)eyei], 1u << min(tile, 31));
     }
 }
 
-template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW, int SHARP, int DIA = 0>
+template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW, int SHARP, int DIA = 0, int SW = 0>
 __global__ void __launch_bounds__(NT, MINW)
 k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
             int hot_w, int hot_h, int hot_S, int hot_T, int hot_single, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode, int hot_npt, int hot_off_xq,
@@ -1170,7 +1350,7 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
     if (hot_single < 0) eye_group_decode((int)blockIdx.y, yrow, eyei);
     const int row = yrow * 8 + (xi & 7);
     if (row >= hot_h) return;
-    pp_tile<NT, SLOTS, OUT, PT_KP, PT_KS, SHARP, DIA, (SHARP ? PP_DCAP_SHARP : PP_DCAP)>(hot_image, hot_depth0, hot_depth1, hot_w, hot_h, hot_S, hot_T, hot_single, hot_off_dflag,
+    pp_tile<NT, SLOTS, OUT, PT_KP, PT_KS, SHARP, DIA, (SHARP ? PP_DCAP_SHARP : PP_DCAP), SW>(hot_image, hot_depth0, hot_depth1, hot_w, hot_h, hot_S, hot_T, hot_single, hot_off_dflag,
                                                                 hot_off_dcnt, hot_pow_mode, hot_npt, hot_off_xq, A, smem, row, eyei, xi >> 3, (int)blockIdx.z);
 }
 
@@ -1183,9 +1363,6 @@ k_polypoint(const float* __restrict__ hot_image, const float* __restrict__ hot_d
 // 128 registers, 37-57 of them spilled, four workgroups per CU -- 3-4 x the first tier's time per row (tools/sessions/r06_s11.sh).
 // Rows this pass cannot finish either (exact ties, lists beyond even these capacities) are flagged in `A.rowflag` -- a second flag
 // array -- for the row kernel.
-#ifndef PP_DCAP2
-#define PP_DCAP2 192
-#endif
 static unsigned polypoint_tier2_cap(long long rows) {
     const long long q = (rows + 3) / 4;
     return (unsigned)(q < 256 ? (rows < 256 ? rows : 256) : (q > 65535 ? 65535 : q));
@@ -1302,8 +1479,10 @@ static int polypoint_tile(int w, int S, int nslots, int nt) {
 }
 
 int polypoint_max_halo() { return (3 * 384 - 4 - 64) / 2; }
+// numba's typing of the sweep (SW instantiations): the default geometry only (256 threads x 4 point slots)
+bool polypoint_sweep64_ok(int w, int halo) { return polypoint_tile(w, halo, 256 * 4, 256) != 0; }
 
-template <int NT, int SLOTS, int MINW, int SHARP, int DIA = 0>
+template <int NT, int SLOTS, int MINW, int SHARP, int DIA = 0, int SW = 0>
 static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream) {
     // points / forward segments a pixel under a reversed segment can hold in its lists (more: the row is redone); sharp has two
     // points per source (the values the first-generation kernel settled on)
@@ -1329,10 +1508,10 @@ static hipError_t polypoint_launch(PolyPointArgs& A, int out, hipStream_t stream
     if (occ >= 3 && occ <= 6) { const size_t pad = (size_t)(163840 / (occ + 1) + 1024) & ~(size_t)255; if (pad > lds) lds = pad; }
 #define PP_LAUNCH(O)                                                                                                         \
     {                                                                                                                        \
-        hipError_t e = hipFuncSetAttribute((const void*)k_polypoint<NT, SLOTS, O, KP, KS, MINW, SHARP, DIA>,                 \
+        hipError_t e = hipFuncSetAttribute((const void*)k_polypoint<NT, SLOTS, O, KP, KS, MINW, SHARP, DIA, SW>,                 \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
         if (e != hipSuccess) return e;                                                                                       \
-        hipLaunchKernelGGL((k_polypoint<NT, SLOTS, O, KP, KS, MINW, SHARP, DIA>), grid, block, lds, stream, A.image_f32, A.eye[0].depth, \
+        hipLaunchKernelGGL((k_polypoint<NT, SLOTS, O, KP, KS, MINW, SHARP, DIA, SW>), grid, block, lds, stream, A.image_f32, A.eye[0].depth, \
                            A.eye[1].depth, A.w, A.h, A.S, A.T, A.single, off_dflag, off_dcnt, pow_mode, npt, off_xq, A);                  \
     }
     if (out == PO_F32) PP_LAUNCH(PO_F32)
@@ -1374,11 +1553,17 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
     A.d64 = R.d64; A.e64 = R.e64;
     A.hint = hint;
     if (tile_width) *tile_width = A.T;
-    if (R.d64 && R.d64 != 1) return hipErrorInvalidValue;   // (only the float64 disparity chain: the sweep's typing stays D32)
+    // (dialect bits: 1 = the float64 disparity chain alone -- the sweep's typing stays D32; 2 / 3 = numba's typing of the sweep, without /
+    // with the chain: the SW instantiations, default geometry only)
+    if ((R.d64 & 2) && geo != 4) return hipErrorInvalidValue;
     const int out = R.out_u8 ? PO_ASD : (R.stereo_is_u8 ? (R.no_mask ? PO_U8NM : PO_U8) : PO_F32);
     if ((out == PO_ASD) != (R.image_u8 != nullptr)) return hipErrorInvalidValue;  // uint8 image in <=> uint8 image out
     if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31) || A.h > 4 * 65535 - 512 || A.n > 65535)
         return hipErrorInvalidValue;   // 32-bit pixel indices, grid limits
+    if (R.d64 & 2) {   // numba's sweep (float64 pieces: 128 registers, four workgroups per CU)
+        if (sharp) return polypoint_launch<256, 4, PP_SW_MINW, 1, 1, 1>(A, out, stream);
+        return polypoint_launch<256, 4, PP_SW_MINW, 0, 1, 1>(A, out, stream);
+    }
     if (R.d64) {   // the float64 disparity chain (one geometry per form: the default one, or the wide-halo one)
         if (sharp) return geo == 5 ? polypoint_launch<384, 3, 5, 1, 1>(A, out, stream) : polypoint_launch<256, 4, 5, 1, 1>(A, out, stream);
         if (geo == 5) return polypoint_launch<384, 3, 7, 0, 1>(A, out, stream);

@@ -238,3 +238,46 @@ def test_exact_powers_under_the_float64_chain(dev_switch, exponent):
             dev_switch("no_tile", no_tile)
             for f in FILLS:
                 np.testing.assert_array_equal(_gpu(img, depth, c, f, dialect), want[f], err_msg=f"{dialect} {f} no_tile={no_tile}")
+
+
+@pytest.mark.parametrize("dialect", ["int64-sum", "D64"])
+@pytest.mark.parametrize("fill", ["polylines_soft", "polylines_sharp"])
+def test_numba_sweep_runs_in_the_point_kernel(fill, dialect, dev_switch):
+    """Round 6: numba's typing of the polylines SWEEP (reference :1951-1991 under @njit -- from / to / length / centre, the
+    segment parameter, the closeness and every colour term in float64, the sums rounded to float32 piece by piece) in the point kernel
+    (k_polypoint<..., DIA, SW>: fast path, bridges, chain path, general search) instead of the general row kernel only.  4K-wide bands of
+    scene8 depth (hard and softened silhouettes: folds, bridges, several points per pixel) at the metric's divergence plus a row of exact
+    ties, SBS and anaglyph, exponents 2 and 1.3: HIP vs the oracle under the same setting, bit for bit -- and the same bits from the row
+    kernel alone (no_tile).  That the tile kernel took the call shows in ST_TILE_REDO_ROWS: only a tile kernel flags rows, and it must
+    flag the tie row and not every row."""
+    from comfystereo_amd import engine
+    n, h, w = 2, 40, 3840
+    img = synth.image_f32(n, h, w, seed=83)
+    depth = np.stack([synth.scene8(2160, w, seed=s, soften=bool(s & 1))[y0:y0 + h] for s, y0 in ((2, 740), (5, 1490))]).astype(np.float32)
+    depth[0, 7] = np.where((np.arange(w) // 96) & 1, 0.75, 0.25)   # plateaus with equal |disparity| on both sides of every fold: exact ties
+    depth[1, 9] = np.random.RandomState(5).randint(0, 256, w).astype(np.float32) / 255.0   # 8-bit noise: dozens of layers per pixel
+    depth = depth[..., None].repeat(3, -1)
+    engine.DIALECT = dialect
+    oracle.set_dialect(dialect)
+    try:
+        for mode, e in (("left-right", 2.0), ("red-cyan-anaglyph", 1.3), ("top-bottom", 1.0)):
+            ui = {v: k for k, v in node_oracle.FILL_KEYS.items()}[fill]
+            want = node_oracle.generate(img, depth, 8.0, 0.0, mode, 0.0, 0.5, e, ui, 20.0, 20.0, False, batch_size=12)
+            p = engine.make_params(n, h, w, h, w, 3, fill, mode, 8.0, 0.0, 0.0, 0.5, e, False, 20.0, 20.0, 1.0, 0, 12)
+            assert (p.flags >> 3) & 2
+            for no_tile in (0, 1):
+                dev_switch("no_tile", no_tile)
+                plan = engine.Plan(p, torch.device("cuda"))
+                got = [t.cpu().numpy() for t in plan.run(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda())]
+                st = plan.stats()
+                assert int(st[:, 9].sum()) == 0
+                for g, wv, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+                    np.testing.assert_array_equal(g, wv, err_msg=f"{fill}/{dialect}/{mode}/no_tile={no_tile}/{name}")
+                redo = int(st[:, 11].sum())
+                if no_tile:
+                    assert redo == 0
+                else:
+                    assert 0 < redo < n * h // 2, redo
+    finally:
+        engine.DIALECT = "D32"
+        oracle.set_dialect("D32")
