@@ -390,6 +390,24 @@ static uint32_t* rowflag_list(uint8_t* rowflag, size_t rows) { return (uint32_t*
 // anaglyph scratch of the tiled polylines path: both eyes as uint8 codes side by side
 static size_t poly_anaglyph_bytes(int n, int h, int w) { return al256((size_t)n * h * 2 * w * 3); }
 
+// Anaglyph modes of the forward fills and the two `_post` techniques beyond the width their row kernel takes WITH its anaglyph stash (two
+// more bytes of LDS per column): the row kernel runs in its side-by-side form into uint8 scratch -- every row, no tile kernel -- and
+// k_anaglyph_compose makes the composite, as the polylines techniques do since round 5.  Row-kernel speed, for frames that were refused
+// before (round 6: naive_interpolating 7 365 -> 8 104 columns, i.e. an 8K anaglyph; none 10 128 -> 11 578, naive / inverse 8 104 -> 9 004).
+static bool ana_wide_fill(int fill) {
+    return fill == CS_FILL_NONE || fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING || fill == CS_FILL_INVERSE ||
+           fill == CS_FILL_NONE_POST || fill == CS_FILL_INVERSE_POST;
+}
+static int stash_form_max_width(int fill) {   // widest row the row kernel takes in its own anaglyph form
+    int lo = 0, hi = 1 << 16;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (rowwarp_lds_bytes(fill, mid, 1) <= CS_LDS_BYTES && poly_npt(mid, 1) < 65535) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+static bool ana_wide_call(int fill, int anaglyph, int w) { return anaglyph && ana_wide_fill(fill) && w > stash_form_max_width(fill); }
+
 static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_t stream, uint8_t* ana_sbs = nullptr,
                     void* replay_scratch = nullptr, size_t replay_surplus = 0) {
     const bool poly = fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP;
@@ -410,8 +428,9 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
                               ((A.d64 & 2) && polypoint_takes(halo) && polypoint_sweep64_ok(A.w, halo) && !dev_switch(CS_DEBUG_PT_VARIANT));
     const bool ana_tiled = poly && tile_dialect && A.anaglyph && ana_sbs && A.image_f32 && !A.out_u8 && halo <= polytile_max_halo() && rowflag &&
                            !dev_switch(CS_DEBUG_NO_TILE);
+    const bool ana_wide = ana_wide_call(fill, A.anaglyph, A.w) && ana_sbs && A.image_f32 && !A.out_u8;
     const RowArgs Afinal = A;
-    if (ana_tiled) {
+    if (ana_tiled || ana_wide) {
         A.anaglyph = 0; A.single = -1;
         A.stereo = reinterpret_cast<float*>(ana_sbs); A.stereo_is_u8 = 1; A.no_mask = 1; A.mask = nullptr;
         A.out_h = A.h; A.out_w = 2 * A.w;
@@ -478,7 +497,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         }
     }
     if ((fill == CS_FILL_NONE || fill == CS_FILL_INVERSE || fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING) &&
-        !dev_switch(CS_DEBUG_NO_TILE)) {
+        !dev_switch(CS_DEBUG_NO_TILE) && !ana_wide) {
         // the halo-tile kernel where it applies; 'naive' hands the rows it cannot decide to the row kernel
         const bool flagging = (fill == CS_FILL_NAIVE || fill == CS_FILL_NAIVE_INTERPOLATING) && rowflag;
         const size_t rows = (size_t)A.n * A.h;
@@ -540,7 +559,7 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         e = launch_rowwarp(fill, R, threads_for(fill, A.w), stream, dev_switch(CS_DEBUG_PT_VARIANT) == 42 ? 32 : 256);
         if (e != hipSuccess) return fail_hip(e, "row kernel launch (replay retry)");
     }
-    if (ana_tiled) {   // R from one eye, G and B from the other, k / 255, the mask of the composite -- every row
+    if (ana_tiled || ana_wide) {   // R from one eye, G and B from the other, k / 255, the mask of the composite -- every row
         e = launch_anaglyph_compose(ana_sbs, nullptr, Afinal.n, Afinal.h, Afinal.w, Afinal.anaglyph, Afinal.stereo, Afinal.stereo_is_u8,
                                     Afinal.mask, stream);
         if (e != hipSuccess) return fail_hip(e, "anaglyph composition launch");
@@ -575,6 +594,7 @@ static int max_width_for(int fill, int anaglyph) {
     // no anaglyph stash in LDS, the limit of the side-by-side modes.  A call whose halo is too wide for the tile kernels still takes
     // the row kernel's anaglyph form: cs_generate checks that case against `row_form_max_width`)
     if (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP) anaglyph = 0;
+    if (ana_wide_fill(fill)) anaglyph = 0;   // (round 6: beyond the stash form's width the row kernel runs side by side + composition, run_rows)
     if (fill == CS_FILL_GPU_WARP) return gpuwarp_max_width();   // (the mesh-quality variant, cs_params.flags bit 2: cs_forward_warp_mesh's limit)
     if (fill == CS_FILL_HYBRID_EDGE) return hybrid_max_width();
     if (fill < 0 || fill > CS_FILL_HYBRID_EDGE_PLUS) return 0;
@@ -681,6 +701,8 @@ static WsLayout ws_layout(const cs_params* p) {
     if ((p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP) &&
         (p->mode == CS_MODE_RED_CYAN_ANAGLYPH || p->mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH))
         o += poly_anaglyph_bytes(p->n, p->h, p->w);   // (both eyes as uint8 codes side by side; the replay scratch behind it)
+    if (ana_wide_call(p->fill, p->mode == CS_MODE_RED_CYAN_ANAGLYPH || p->mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH, p->w))
+        o += poly_anaglyph_bytes(p->n, p->h, p->w);   // (the same scratch for an anaglyph too wide for the row kernel's stash form)
     if (p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP)   // scratch of the stretch replay kernel
         o += al256(poly_replay_bytes(p->n, p->h, p->w, p->fill == CS_FILL_POLYLINES_SHARP));
     W.total = o;

@@ -1326,9 +1326,9 @@ __device__ __forceinline__ void pp_tile(const float* __restrict__ hot_image, con
         atomicOr(reinterpret_cast<unsigned*>(A.rowflag + (idx & ~3u)), (eyei ? 4u : 2u) << (8u * (idx & 3u)));
         // (soft only: in the sharp instantiation, at its 80-register budget, this second atomic costs a spilled vector register --
         // scratch, +5 % HBM traffic, -3 % on ordinary depth; its flagged row-eyes leave the hint word 0 = the whole row)
-        // (round 6: the SECOND tier of sharp -- 96 registers at five workgroups per CU -- records them: the lean row kernel then confines itself
-        // to the flagged tiles' columns for polylines_sharp too)
-        if ((!SHARP || DC == PP_DCAP2) && A.hint) atomicOr(&A.hint[2u * idx + (uint32_t)eyei], 1u << min(tile, 31));
+        // (round 6, measured: hints from the SECOND tier of sharp -- no spill there -- change nothing: on saturated depth the flagged tiles
+        // span more than three quarters of the row, so the lean row kernel takes the whole row anyway, profiles/r06_s23/ab_sharp.txt)
+        if (!SHARP && A.hint) atomicOr(&A.hint[2u * idx + (uint32_t)eyei], 1u << min(tile, 31));
     }
 }
 

@@ -69,7 +69,9 @@ __host__ __device__ inline int poly_cap(int w, int sharp) {
                             (long long)align16(2 * ((size_t)w + 4)) + (long long)align16(2 * ((size_t)w + 2)) + 2048;
     const long long fit = (((long long)CS_LDS_BYTES - CS_ROW_LDS_STATIC - other) / 2) & ~7LL;
     if ((long long)full <= fit) return full;
-    return fit >= 2LL * w + 2 + 4096 ? (int)fit : full;   // (too wide even so: the full figure makes the width check fail)
+    // (round 6: 2 048 entries beyond the point count are enough to accept the row -- 4 096 until then, which put the limit at 7 990 columns;
+    // rows whose lists need more than the capacity are evaluated in column ranges, RW_MAX_RANGES, as they are at 7 680: 8 206 columns)
+    return fit >= 2LL * w + 2 + 2048 ? (int)fit : full;   // (too wide even so: the full figure makes the width check fail)
 }
 __host__ __device__ inline size_t lds_tech_bytes(int fill, int w) {
     switch (fill) {
@@ -78,8 +80,10 @@ __host__ __device__ inline size_t lds_tech_bytes(int fill, int w) {
     case CS_FILL_NAIVE_INTERPOLATING:  // winner, flags, new colours, interval starts
         return align16(4 * (size_t)w) + align16((size_t)w) + align16(3 * (size_t)w) + align16(2 * (size_t)w);
     case CS_FILL_INVERSE: return align16(8 * (size_t)w);
-    case CS_FILL_NONE_POST: return 3 * align16(4 * (size_t)w);                       // winner, L, R
-    case CS_FILL_INVERSE_POST: return align16(8 * (size_t)w) + 2 * align16(4 * (size_t)w);  // keys, L, R
+    // (round 6: the nearest-valid-column arrays L, R of the post-fill overlay the normalised depth and the winner / key words: 11 578 / 9 004
+    // instead of 7 368 / 6 234 columns)
+    case CS_FILL_NONE_POST: return align16(4 * (size_t)w);                       // winner
+    case CS_FILL_INVERSE_POST: return align16(8 * (size_t)w);                   // keys
     case CS_FILL_HYBRID_EDGE:  // splat kernel: dest_x, bin offsets, scratch, sorted ids, exp table
         return align16(4 * (size_t)w) + 3 * align16(2 * ((size_t)w + 4)) + 2048;
     case CS_FILL_HYBRID_EDGE_PLUS: {  // the hybrid fill pass, then the polylines row technique (same region), + its pixels
@@ -310,10 +314,21 @@ template <class Valid>
 __device__ void technique_post_interp(const Lds& L, int w, int* Lf, int* Rf, const Valid& valid) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int BIG = 1 << 29;
-    for (int c = tid; c < w; c += nt) {
-        const bool f = valid(c);
-        Lf[c] = f ? c : -BIG;
-        Rf[c] = f ? c : BIG;
+    // (round 6: Lf / Rf overlay arrays that are dead once the validity of every column is known -- the normalised depth and the forward
+    // map's winner / key words -- so the flags are collected in a register first: at most 32 columns per lane, checked by the launcher)
+    unsigned fm = 0;
+    {
+        int i = 0;
+        for (int c = tid; c < w; c += nt, i++) fm |= valid(c) ? 1u << i : 0u;
+    }
+    __syncthreads();
+    {
+        int i = 0;
+        for (int c = tid; c < w; c += nt, i++) {
+            const bool f = (fm >> i) & 1u;
+            Lf[c] = f ? c : -BIG;
+            Rf[c] = f ? c : BIG;
+        }
     }
     __syncthreads();
     block_scan_inclusive(Lf, w, -BIG, OpMax(), L.misc + 8);
@@ -2558,15 +2573,12 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
                 technique_forward<CS_FILL_NONE>(L, w, E, A.e32, A.d64, A.e64);
                 const int* winner = (const int*)L.tech;
                 const int init = E.asc ? -1 : 0x7fffffff;
-                technique_post_interp(L, w, (int*)(L.tech + align16(4 * (size_t)w)), (int*)(L.tech + 2 * align16(4 * (size_t)w)),
-                                      [=](int c) { return winner[c] != init; });
+                technique_post_interp(L, w, (int*)L.nd, (int*)L.tech, [=](int c) { return winner[c] != init; });
             } else if (FILL == CS_FILL_INVERSE_POST) {
                 technique_inverse(L, w, E, A.e32, A.d64, A.e64);
                 const unsigned long long* key = (const unsigned long long*)L.tech;
                 const unsigned long long init = ((unsigned long long)csm::f2ord(-1.0f) << 32) | 0xffffffffull;
-                technique_post_interp(L, w, (int*)(L.tech + align16(8 * (size_t)w)),
-                                      (int*)(L.tech + align16(8 * (size_t)w) + align16(4 * (size_t)w)),
-                                      [=](int c) { return key[c] > init; });
+                technique_post_interp(L, w, (int*)L.nd, (int*)L.tech, [=](int c) { return key[c] > init; });
             } else if (FILL == CS_FILL_INVERSE) technique_inverse(L, w, E, A.e32, A.d64, A.e64);
             else if (FILL == CS_FILL_POLYLINES_SOFT || FILL == CS_FILL_POLYLINES_SHARP) {
                 // (eyes in separate output slots: the stretches of order-dependent rows may go to the replay kernel)
@@ -2638,9 +2650,11 @@ __device__ __forceinline__ void rowwarp_row(const RowArgs& A, const int row, con
                 } else {
                     for (int i = tid; i < 3 * w; i += nt) dst[i] = L.lut[L.res[i]];
                 }
-                float* m = A.mask + ((size_t)frame * A.out_h + oy) * A.out_w + ox;
-                for (int c = tid; c < w; c += nt)
-                    m[c] = ((int)L.res[3 * c] + (int)L.res[3 * c + 1] + (int)L.res[3 * c + 2]) == 0 ? 1.0f : 0.0f;
+                if (A.mask) {   // (null: the per-eye intermediate of an anaglyph too wide for the stash form, cs_abi.hip run_rows)
+                    float* m = A.mask + ((size_t)frame * A.out_h + oy) * A.out_w + ox;
+                    for (int c = tid; c < w; c += nt)
+                        m[c] = ((int)L.res[3 * c] + (int)L.res[3 * c + 1] + (int)L.res[3 * c + 2]) == 0 ? 1.0f : 0.0f;
+                }
             }
         }
         __syncthreads();
@@ -3103,6 +3117,8 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
     if ((A.d64 & 1) && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP || fill == CS_FILL_HYBRID_EDGE_PLUS))
         lds += align16(8 * (size_t)A.w);   // Poly::xd
     if (lds + CS_ROW_LDS_STATIC > CS_LDS_BYTES) return hipErrorInvalidValue;
+    if ((fill == CS_FILL_NONE_POST || fill == CS_FILL_INVERSE_POST) && (A.w + threads - 1) / threads > 32)
+        return hipErrorInvalidValue;   // (technique_post_interp keeps a lane's validity flags in one 32-bit register)
     const long long rows = (long long)A.h * A.n;
     dim3 grid(A.h, A.n), block(threads);
     if (A.row_list) {

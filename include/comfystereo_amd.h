@@ -114,8 +114,9 @@ CS_API const char *cs_last_error(void);
 
 /* Largest frame width the LDS-resident row kernels accept for `fill` (160 KiB LDS per CU). */
 CS_API int cs_max_width(int fill);
-/* The same for one output mode: the side-by-side / top-bottom / single-eye modes need 2 bytes less LDS per pixel than the
- * anaglyphs (cs_max_width is the anaglyph, i.e. smallest, limit). */
+/* The same for one output mode.  The row kernels' own anaglyph form keeps 2 more bytes of LDS per pixel; since round 6 every technique but
+ * hybrid_edge_plus runs an anaglyph beyond that form's width side by side into scratch and composes afterwards, so the anaglyph limit equals
+ * the side-by-side limit (cs_max_width is the anaglyph, i.e. smallest, limit). */
 CS_API int cs_max_width_mode(int fill, int mode);
 /* ABI 4: the widest frame cs_generate accepts with p's technique, mode, dialect flags (bits 3 / 4) and disparity parameters
  * (p->w, p->h, p->n are ignored): the same predicate the call itself applies, so pre-validation cannot disagree with it.

@@ -266,6 +266,25 @@ def test_8k_wide_rows_side_by_side(engine, fill):
             assert np.array_equal(g, w_), name
 
 
+@pytest.mark.parametrize("fill,w", [("none_post", 7680), ("inverse_post", 7680), ("none_post", 11578), ("inverse_post", 9004)])
+def test_wide_rows_post_fill_techniques(engine, fill, w):
+    """Round 6: none_post / inverse_post (reference :1804-1833; no UI string reaches them) at 8K and at their new limits -- the nearest-valid-
+    column arrays of the np.interp post-fill overlay the normalised depth and the forward map's winner / key words in LDS (7 368 / 6 234
+    columns until then).  Depth with long holes (stepped, divergence 6), SBS, against the oracle."""
+    from comfystereo_amd import _native
+    L = _native.lib()
+    assert L.cs_max_width_mode(engine.FILL[fill], engine.MODE["left-right"]) >= w
+    ui = {v: k for k, v in node_oracle.FILL_KEYS.items()}[fill]
+    h = 6
+    img = synth.image_f32(1, h, w, seed=8)
+    depth = synth.depth_batch("stepped", 1, h, w, channels=3)
+    depth[0, 2] = synth.depth_batch("random8", 1, h, w, channels=3)[0, 2]
+    got = gen(engine, img, depth, fill, "right-left", blur=False, div=6.0)
+    want = node_oracle.generate(img, depth, 6.0, 0.0, "right-left", 0.0, 0.5, 2.0, ui, 20.0, 20.0, False, batch_size=12)
+    for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+        assert np.array_equal(g, w_), (fill, w, name)
+
+
 @pytest.mark.parametrize("fill,kind", [("polylines_sharp", "stepped"), ("polylines_sharp", "clipped"), ("polylines_soft", "clipped")])
 def test_8k_wide_rows_anaglyph_polylines(engine, fill, kind):
     """7680-pixel rows as an ANAGLYPH through the polylines techniques (round 5): both kernels write the eyes side by side as uint8
@@ -292,14 +311,38 @@ def test_8k_wide_rows_anaglyph_polylines(engine, fill, kind):
         assert np.array_equal(g, w_), (fill, kind, name)
 
 
-def test_too_wide_frames_are_refused_not_truncated(engine):
-    """Beyond cs_max_width_mode the call fails (CS_ELIMIT), it does not truncate.  What is left with a limit below 8K after round 5:
-    polylines_sharp beyond 7 990 columns in any mode, an anaglyph of it whose halo the tile kernels do not take (the row kernel's
-    own anaglyph form: 6 395), and -- outside the UI's reach -- the three hidden techniques, the mesh warp and D64 polylines."""
+@pytest.mark.parametrize("fill,w,blur", [("naive_interpolating", 7680, False), ("naive_interpolating", 8104, True), ("naive", 8192, False),
+                                         ("inverse", 9004, False), ("none", 10240, True), ("none_post", 10240, False), ("inverse_post", 8192, True)])
+def test_wide_anaglyph_rows_through_the_side_by_side_form(engine, fill, w, blur):
+    """Round 6: an anaglyph wider than the row kernel takes WITH its anaglyph stash (two more bytes of LDS per column) -- e.g. an 8K frame
+    through naive_interpolating, refused until now -- runs the row kernel in its side-by-side form into uint8 scratch and composes
+    afterwards (cs_abi.hip run_rows, ana_wide), like the polylines techniques since round 5: the anaglyph modes' width limit is the
+    side-by-side modes' limit.  Both anaglyph modes, blur off and on (lazy blur tiles completed per row), against the oracle."""
     from comfystereo_amd import _native
     L = _native.lib()
-    for w, mode in ((8192, "left-right"), (8192, "red-cyan-anaglyph")):
-        assert L.cs_max_width_mode(engine.FILL["polylines_sharp"], engine.MODE[mode]) < w
+    ui = {v: k for k, v in node_oracle.FILL_KEYS.items()}[fill]
+    h = 8
+    img = synth.image_f32(1, h, w, seed=8)
+    img[:, :, 500:560] = 0.0   # genuinely black pixels (mask, quirk Q6)
+    depth = synth.depth_batch("stepped", 1, h, w, channels=3)
+    for mode in ("red-cyan-anaglyph", "cyan-red-reverseanaglyph"):
+        assert L.cs_max_width_mode(engine.FILL[fill], engine.MODE[mode]) == L.cs_max_width_mode(engine.FILL[fill], engine.MODE["left-right"]) >= w
+        got = gen(engine, img, depth, fill, mode, blur=blur, div=4.0)
+        want = node_oracle.generate(img, depth, 4.0, 0.0, mode, 0.0, 0.5, 2.0, ui, 20.0, 20.0, blur, depth_blur_falloff=2.0,
+                                    depth_blur_vert_smooth=6, batch_size=12)
+        for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+            assert np.array_equal(g, w_), (fill, mode, name)
+
+
+def test_too_wide_frames_are_refused_not_truncated(engine):
+    """Beyond cs_max_width_mode the call fails (CS_ELIMIT), it does not truncate.  What is left with a limit below 8 192 after round 6:
+    gpu_warp (7 763), an anaglyph of polylines_sharp whose halo the tile kernels do not take (the row kernel's own anaglyph form:
+    6 395), and -- outside the UI's reach -- the three hidden techniques, the mesh warp and D64 polylines.  (polylines_sharp itself:
+    7 990 -> 8 206 columns in round 6, test_8192_wide_sharp_rows.)"""
+    from comfystereo_amd import _native
+    L = _native.lib()
+    for w, mode in ((8320, "left-right"), (8320, "red-cyan-anaglyph")):
+        assert 8192 <= L.cs_max_width_mode(engine.FILL["polylines_sharp"], engine.MODE[mode]) < w
         img = synth.image_f32(1, 4, w, seed=8)
         depth = synth.depth_batch("stepped", 1, 4, w, channels=3)
         with pytest.raises(RuntimeError, match="too wide"):
@@ -309,8 +352,38 @@ def test_too_wide_frames_are_refused_not_truncated(engine):
     depth = synth.depth_batch("stepped", 1, 4, 7680, channels=3)
     with pytest.raises(RuntimeError, match="too wide"):
         engine.generate(cuda(img), cuda(depth), 15.0, 0.0, "red-cyan-anaglyph", 0.0, 1.0, 2.0, "polylines_sharp", 20.0, 20.0, False)
-    for fill in ("none_post", "inverse_post", "hybrid_edge_plus"):
-        assert L.cs_max_width_mode(engine.FILL[fill], engine.MODE["left-right"]) < 7680
+    assert L.cs_max_width_mode(engine.FILL["hybrid_edge_plus"], engine.MODE["left-right"]) < 7680
+    for fill in ("none_post", "inverse_post"):   # (round 6: their post-fill arrays overlay dead LDS -- the limits of none / inverse)
+        assert L.cs_max_width_mode(engine.FILL[fill], engine.MODE["left-right"]) >= 8192
+    # one column beyond the limit of a forward fill's anaglyph (the side-by-side limit since round 6)
+    wmax = L.cs_max_width_mode(engine.FILL["naive_interpolating"], engine.MODE["red-cyan-anaglyph"])
+    img = synth.image_f32(1, 4, wmax + 1, seed=8)
+    depth = synth.depth_batch("stepped", 1, 4, wmax + 1, channels=3)
+    with pytest.raises(RuntimeError, match="too wide"):
+        gen(engine, img, depth, "naive_interpolating", "red-cyan-anaglyph", blur=False, div=3.0)
+
+
+@pytest.mark.parametrize("kind,mode", [("stepped", "left-right"), ("clipped", "left-right"), ("clipped", "red-cyan-anaglyph"), ("scene8", "top-bottom")])
+def test_8192_wide_sharp_rows(engine, kind, mode):
+    """Round 6: polylines_sharp rows of 8 192 columns (limit 8 206; 7 990 until then).  The row kernel behind the tile kernel keeps a
+    per-pixel list capacity of only 2 w + 2 + 2 048 entries at that width (cs_rowwarp.hip poly_cap) and evaluates the rows the tile
+    kernel flags in column ranges; `clipped` depth: exact ties, rows that reach the row kernel and the replay."""
+    from comfystereo_amd import _native
+    L = _native.lib()
+    h, w = 6, 8192
+    assert L.cs_max_width_mode(engine.FILL["polylines_sharp"], engine.MODE[mode]) >= w
+    img = synth.image_f32(1, h, w, seed=8)
+    depth = synth.depth_batch(kind, 1, h, w, channels=3)
+    p = engine.make_params(1, h, w, h, w, 3, "polylines_sharp", mode, 5.0, 0.0, 0.0, 0.5, 2.0, False, 20.0, 20.0, 1.0, 0, 12)
+    plan = engine.Plan(p, torch.device("cuda"))
+    got = [t.cpu().numpy() for t in plan.run(cuda(img), cuda(depth))]
+    st = plan.stats()
+    if kind == "clipped":
+        assert int(st[:, 11].sum()) > 0, "no row was flagged: the test does not reach the row kernel"
+    assert int(st[:, 9].sum()) == 0   # kernel error flags
+    want = node_oracle.generate(img, depth, 5.0, 0.0, mode, 0.0, 0.5, 2.0, UI["polylines_sharp"], 20.0, 20.0, False, batch_size=12)
+    for g, w_, name in zip(got, want, ("stereoscope", "depth_left", "depth_right", "mask")):
+        assert np.array_equal(g, w_), (kind, mode, name)
 
 
 @pytest.mark.parametrize("kind", ["clipped", "random8"])
