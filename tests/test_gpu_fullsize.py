@@ -266,11 +266,13 @@ def test_8k_wide_rows_side_by_side(engine, fill):
             assert np.array_equal(g, w_), name
 
 
-@pytest.mark.parametrize("fill,w", [("none_post", 7680), ("inverse_post", 7680), ("none_post", 11578), ("inverse_post", 9004)])
-def test_wide_rows_post_fill_techniques(engine, fill, w):
+@pytest.mark.parametrize("fill,w", [("none_post", 7680), ("inverse_post", 7680), ("none_post", 11578), ("inverse_post", 9004),
+                                    ("naive", 11578), ("naive_interpolating", 9536)])
+def test_wide_rows_at_the_new_limits(engine, fill, w):
     """Round 6: none_post / inverse_post (reference :1804-1833; no UI string reaches them) at 8K and at their new limits -- the nearest-valid-
     column arrays of the np.interp post-fill overlay the normalised depth and the forward map's winner / key words in LDS (7 368 / 6 234
-    columns until then).  Depth with long holes (stepped, divergence 6), SBS, against the oracle."""
+    columns until then) -- and naive / naive_interpolating at theirs (nearest-filled columns / new colours over the dead normalised
+    depth: 9 004 -> 11 578, 8 104 -> 9 536).  Depth with long holes (stepped, divergence 6) and a noise row, SBS, against the oracle."""
     from comfystereo_amd import _native
     L = _native.lib()
     assert L.cs_max_width_mode(engine.FILL[fill], engine.MODE["left-right"]) >= w
@@ -311,13 +313,15 @@ def test_8k_wide_rows_anaglyph_polylines(engine, fill, kind):
         assert np.array_equal(g, w_), (fill, kind, name)
 
 
-@pytest.mark.parametrize("fill,w,blur", [("naive_interpolating", 7680, False), ("naive_interpolating", 8104, True), ("naive", 8192, False),
+@pytest.mark.parametrize("fill,w,blur", [("naive_interpolating", 7680, False), ("naive_interpolating", 9536, True), ("naive", 10240, False),
                                          ("inverse", 9004, False), ("none", 10240, True), ("none_post", 10240, False), ("inverse_post", 8192, True)])
 def test_wide_anaglyph_rows_through_the_side_by_side_form(engine, fill, w, blur):
-    """Round 6: an anaglyph wider than the row kernel takes WITH its anaglyph stash (two more bytes of LDS per column) -- e.g. an 8K frame
-    through naive_interpolating, refused until now -- runs the row kernel in its side-by-side form into uint8 scratch and composes
-    afterwards (cs_abi.hip run_rows, ana_wide), like the polylines techniques since round 5: the anaglyph modes' width limit is the
-    side-by-side modes' limit.  Both anaglyph modes, blur off and on (lazy blur tiles completed per row), against the oracle."""
+    """Round 6: an anaglyph wider than the row kernel takes WITH its anaglyph stash (two more bytes of LDS per column) runs the row kernel
+    in its side-by-side form into uint8 scratch and composes afterwards (cs_abi.hip run_rows, ana_wide), like the polylines techniques
+    since round 5: the anaglyph modes' width limit is the side-by-side modes' limit.  (Every case but the first is beyond the stash form;
+    the first is the 8K anaglyph of naive_interpolating, refused until round 6 -- 7 365 columns -- and inside the stash form since the
+    technique's scratch arrays overlay the dead normalised depth.)  Both anaglyph modes, blur off and on (lazy blur tiles completed
+    per row), against the oracle."""
     from comfystereo_amd import _native
     L = _native.lib()
     ui = {v: k for k, v in node_oracle.FILL_KEYS.items()}[fill]
