@@ -73,6 +73,19 @@ __host__ __device__ inline int poly_cap(int w, int sharp) {
     // rows whose lists need more than the capacity are evaluated in column ranges, RW_MAX_RANGES, as they are at 7 680: 8 206 columns)
     return fit >= 2LL * w + 2 + 2048 ? (int)fit : full;   // (too wide even so: the full figure makes the width check fail)
 }
+// The LEAN instantiation (first pass over the rows the tile kernel flags) wants TWO rows per CU.  polylines_sharp at 4K asks for 92 KB with
+// its full list capacity (4 w + 64 entries) -- one row per CU, and the first pass fell to the full kernel (64 x 4K saturated depth: 13 of
+// 22 ms in it, tools/sessions/r06_s27.sh).  With the capacity that half the LDS leaves (2.67 entries per column at 3 840; a sharp row
+// needs ~3) the row is evaluated in two column ranges, two rows at a time (round 6).
+__host__ __device__ inline int poly_cap_lean(int w, int sharp) {
+    const int full = poly_cap(w, sharp);
+    if (!sharp) return full;
+    const long long other = (long long)lds_common_bytes(CS_FILL_POLYLINES_SHARP, w, 0) + (long long)align16(2 * (size_t)(2 * w + 2)) +
+                            (long long)align16(2 * ((size_t)w + 4)) + (long long)align16(2 * ((size_t)w + 2)) + 2048;
+    const long long fit2 = (((long long)CS_LDS_BYTES / 2 - CS_ROW_LDS_STATIC - other) / 2) & ~7LL;
+    if ((long long)full <= fit2) return full;
+    return fit2 >= 2LL * w + 2 + 2048 ? (int)fit2 : full;
+}
 __host__ __device__ inline size_t lds_tech_bytes(int fill, int w) {
     switch (fill) {
     case CS_FILL_NONE: return align16(4 * (size_t)w);                       // winner
@@ -1072,7 +1085,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
     const int npts_r = plast - pfirst + 3;
     const int tid = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
     Poly P;
-    P.w = w; P.sharp = SHARP; P.npt = poly_npt(w, SHARP); P.cap = poly_cap(w, SHARP);
+    P.w = w; P.sharp = SHARP; P.npt = poly_npt(w, SHARP); P.cap = LEAN ? poly_cap_lean(w, SHARP) : poly_cap(w, SHARP);
     P.sep32 = E.sep32;
     char* t = L.tech;
     P.perm = (uint16_t*)t; t += align16(2 * (size_t)P.npt);
@@ -1101,7 +1114,10 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
     }
     for (int i = tid; i < (w + 4) / 2; i += nt) ((unsigned*)P.binoff)[i] = 0;
     for (int i = tid; i < (w + 2) / 2; i += nt) ((unsigned*)P.segoff)[i] = 0;
-    if (tid == 0) { *flag_hazard = 0; *nlong = 0; *ntotal = 0; }
+    // (round 6) rows evaluated in column ranges: the longest per-pixel segment list of the row -- the lists of a range are gone when the
+    // stretches are exported, and without a bound on the active list every stretch of such a row went to the wave replay
+    int* maxlist = L.misc + 24;
+    if (tid == 0) { *flag_hazard = 0; *nlong = 0; *ntotal = 0; *maxlist = 0; }
     __syncthreads();
     if (dbg == 1) return;
     // (the point set as one index space: k = 0 .. npts_r - 1 -> left sentinel, pfirst .. plast, right sentinel)
@@ -1340,6 +1356,12 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
             }
             const unsigned long long hm = __ballot(hazard), rm = __ballot(reset);
             if (lane == 0 && colb + 64 * wave < cB && w <= 8192) { hzw[(colb >> 6) + wave] = hm; rsw[(colb >> 6) + wave] = rm; }
+            if (ranged) {   // (wave-uniform)
+                int ll = col < cB ? (int)P.segoff[col] - (col > 0 ? (int)P.segoff[col - 1] : 0) : 0;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) ll = max(ll, __shfl_xor(ll, d));
+                if (lane == 0 && ll > 0) atomicMax(maxlist, ll);
+            }
         }
         }
         }
@@ -1472,7 +1494,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                 if (seg0 >= 0) { cmin = min(cmin, poly_col(P, seg0)); cmax = max(cmax, poly_col(P, seg0 + 1)); }
                 // (round 5) can a LANE replay this stretch (k_poly_replay_lanes: lists of at most RPL_K entries)?  The per-pixel segment
                 // lists bound the active list; without them (whole-row export, column ranges) the answer is no: bit 31 of word 3
-                int longest = whole_row || ranged ? 0x7fff : 0;
+                int longest = whole_row ? 0x7fff : (ranged ? *maxlist : 0);   // (ranged: the row's longest list bounds every stretch's)
                 if (!whole_row && !ranged)
                     for (int p = c0 + lane; p <= c1; p += 64) longest = max(longest, (int)P.segoff[p] - (p > 0 ? (int)P.segoff[p - 1] : 0));
 #pragma unroll
@@ -3147,15 +3169,27 @@ hipError_t launch_rowwarp(int fill, const RowArgs& A, int threads, hipStream_t s
     // (... and for sharp rows so wide that their list capacity is reduced, poly_cap: the lean kernel exports the rows whose lists
     // overflow as whole-row stretches, the full kernel would sweep them sequentially)
     const bool reduced_cap = fill == CS_FILL_POLYLINES_SHARP && poly_cap(A.w, 1) < 4 * A.w + 64;
-    if (lean && !(A.d64 & 3) && A.rp_dump && (2 * lds <= CS_LDS_BYTES || reduced_cap) && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP)) {
+    // (round 6: the lean instantiation carves its per-pixel lists with poly_cap_lean -- what lets two sharp rows share a CU)
+    size_t lds_lean = lds;
+    if (fill == CS_FILL_POLYLINES_SHARP)
+        lds_lean = lds - align16(2 * (size_t)poly_cap(A.w, 1)) + align16(2 * (size_t)poly_cap_lean(A.w, 1));
+    if (lean && !(A.d64 & 3) && A.rp_dump && (2 * lds_lean <= CS_LDS_BYTES || reduced_cap) && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP)) {
         // first pass with the replay kernel attached: the instantiation without the in-row replay (64 registers, two rows per CU)
         hipError_t e = fill == CS_FILL_POLYLINES_SOFT
-            ? hipFuncSetAttribute((const void*)k_rowwarp<CS_FILL_POLYLINES_SOFT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-            : hipFuncSetAttribute((const void*)k_rowwarp<CS_FILL_POLYLINES_SHARP, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            ? hipFuncSetAttribute((const void*)k_rowwarp<CS_FILL_POLYLINES_SOFT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lean)
+            : hipFuncSetAttribute((const void*)k_rowwarp<CS_FILL_POLYLINES_SHARP, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lean);
         if (e != hipSuccess) return e;
+        if (A.row_list && lds_lean != lds) {   // (the persistent grid was sized with the full request: two rows per CU now)
+            long long per_cu = (long long)(CS_LDS_BYTES / lds_lean);
+            if (per_cu > 2048 / threads) per_cu = 2048 / threads;
+            if (per_cu < 1) per_cu = 1;
+            long long groups = rows < 256 * per_cu ? rows : 256 * per_cu;
+            if (max_groups > 0 && groups > max_groups) groups = max_groups;
+            grid = dim3((unsigned)groups, 1);
+        }
         const dim3 lblock(threads < RW_LEAN_NT ? threads : RW_LEAN_NT);
-        if (fill == CS_FILL_POLYLINES_SOFT) hipLaunchKernelGGL((k_rowwarp<CS_FILL_POLYLINES_SOFT, false, true>), grid, lblock, lds, stream, A);
-        else hipLaunchKernelGGL((k_rowwarp<CS_FILL_POLYLINES_SHARP, false, true>), grid, lblock, lds, stream, A);
+        if (fill == CS_FILL_POLYLINES_SOFT) hipLaunchKernelGGL((k_rowwarp<CS_FILL_POLYLINES_SOFT, false, true>), grid, lblock, lds_lean, stream, A);
+        else hipLaunchKernelGGL((k_rowwarp<CS_FILL_POLYLINES_SHARP, false, true>), grid, lblock, lds_lean, stream, A);
         return hipGetLastError();
     }
     if ((A.d64 & 3) && (fill == CS_FILL_POLYLINES_SOFT || fill == CS_FILL_POLYLINES_SHARP)) {   // the dialect instantiations
