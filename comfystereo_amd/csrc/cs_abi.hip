@@ -479,7 +479,8 @@ static int run_rows(int fill, RowArgs& A, int halo, uint8_t* rowflag, hipStream_
         // and sent them to the row kernel: 4 200 / 1 060 frames/s against 5 380 / 4 050 on stepped depth.  polylines_sharp only:
         // for soft the lean row kernel on the hinted tiles' columns is the cheaper second stop (0.96 against 1.16 ms per 16 frames,
         // tools/sessions/r06_s11.sh, s12: 4 100 against 3 750 frames/s; CS_DEBUG_PT_VARIANT 50 forces the tier for soft, 49: off)
-        if (hint_T > 0 && (fill == CS_FILL_POLYLINES_SHARP || dev_switch(CS_DEBUG_PT_VARIANT) == 50) && dev_switch(CS_DEBUG_PT_VARIANT) != 49) {
+        // (numba's sweep, d64 & 2: both techniques -- what the tier does not finish takes the dialect row kernel whole, there is no lean pass)
+        if (hint_T > 0 && (fill == CS_FILL_POLYLINES_SHARP || (A.d64 & 2) || dev_switch(CS_DEBUG_PT_VARIANT) == 50) && dev_switch(CS_DEBUG_PT_VARIANT) != 49) {
             uint8_t* flag2 = rowflag + rowflag_flag2_off(rows);
             uint32_t* hint2 = (uint32_t*)(rowflag + rowflag_hint2_off(rows));
             uint32_t* count3 = count + 16;

@@ -1378,10 +1378,10 @@ __global__ void __launch_bounds__(256) k_polypoint_carry(const uint32_t* __restr
 #ifndef PP_MINW2
 #define PP_MINW2 5
 #endif
-template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW, int SHARP>
+template <int NT, int SLOTS, int OUT, int PT_KP, int PT_KS, int MINW, int SHARP, int SW = 0>
 __global__ void __launch_bounds__(NT, MINW)
 k_polypoint_listed(const float* __restrict__ hot_image, const float* __restrict__ hot_depth0, const float* __restrict__ hot_depth1,
-                   int hot_w, int hot_h, int hot_S, int hot_T, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode, int hot_npt,
+                   int hot_w, int hot_h, int hot_S, int hot_T, int hot_off_dflag, int hot_off_dcnt, int hot_pow_mode, int hot_npt, int hot_off_xq,
                    const uint32_t* __restrict__ row_list, const uint32_t* __restrict__ row_count, PolyPointArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t li = blockIdx.y;
@@ -1391,8 +1391,9 @@ k_polypoint_listed(const float* __restrict__ hot_image, const float* __restrict_
     if (!((e >> (30 + eyei)) & 1u)) return;
     const uint32_t idx = e & 0x3fffffffu;
     const int frame = (int)(idx / (uint32_t)hot_h), row = (int)(idx - (uint32_t)frame * (uint32_t)hot_h);
-    pp_tile<NT, SLOTS, OUT, PT_KP, PT_KS, SHARP, 0, PP_DCAP2>(hot_image, hot_depth0, hot_depth1, hot_w, hot_h, hot_S, hot_T, -1, hot_off_dflag,
-                                                               hot_off_dcnt, hot_pow_mode, hot_npt, 0, A, smem, row, eyei, (int)(blockIdx.x >> 1), frame);
+    // (SW: numba's typing of the sweep, compiled with the float64 chain picked at run time like the first tier's SW instantiations)
+    pp_tile<NT, SLOTS, OUT, PT_KP, PT_KS, SHARP, (SW ? 1 : 0), PP_DCAP2, SW>(hot_image, hot_depth0, hot_depth1, hot_w, hot_h, hot_S, hot_T, -1, hot_off_dflag,
+                                                                              hot_off_dcnt, hot_pow_mode, hot_npt, hot_off_xq, A, smem, row, eyei, (int)(blockIdx.x >> 1), frame);
 }
 
 // Depth-map output of an eye the tile kernel does not visit (modes left-only / only-right still return both depth maps,
@@ -1586,9 +1587,9 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
 // Second tier (k_polypoint_listed): the flagged rows of `list` / `count` (k_collect_rows) once more, with PP_DCAP2 slots and longer
 // lists; what it cannot finish either is flagged in `rowflag2` (zeroed by the caller), tile hints (soft) in `hint2`.  Same tile width
 // as the first tier (the hints name tiles).  hipErrorNotSupported: not for this call (dialect, single-eye layouts, wide-halo geometry).
-template <int SHARP>
+template <int SHARP, int SW = 0>
 static hipError_t polypoint_launch_listed(PolyPointArgs& A, int out, const uint32_t* list, const uint32_t* count, hipStream_t stream) {
-    constexpr int NT = 256, SLOTS = 4, MINW = PP_MINW2;
+    constexpr int NT = 256, SLOTS = 4, MINW = SW ? PP_SW_MINW : PP_MINW2;
     constexpr int KP = SHARP ? 8 : 6, KS = SHARP ? 12 : 9;   // (first tier: 6 / 9 and 4 / 5)
     const int tiles = (A.w + A.T - 1) / A.T;
     const long long rows = (long long)A.n * A.h;
@@ -1598,9 +1599,12 @@ static hipError_t polypoint_launch_listed(PolyPointArgs& A, int out, const uint3
     const unsigned cap = polypoint_tier2_cap(rows);
     dim3 grid(tiles * 2, cap), block(NT);
     hipLaunchKernelGGL(k_polypoint_carry, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, list, count, cap, A.rowflag);
-    const size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS, PP_DCAP2, SHARP);
+    size_t lds = polypoint_lds(NT, SLOTS, A.T, A.S, KP, KS, PP_DCAP2, SHARP);
     const int npt = polypoint_npt(NT, SLOTS, A.T, A.S);
     const int off_dflag = 8 * npt + 4 * npt + 4 * (A.T > 128 ? A.T : 128), off_dcnt = off_dflag + ((2 * A.T + 3) & ~3);
+    // sharp under the dialect: both points of every record, behind everything else (as in polypoint_launch)
+    const int off_xq = (SHARP && SW) ? (int)((lds + 15) & ~(size_t)15) : 0;
+    if (SHARP && SW) lds = (size_t)off_xq + 8 * (size_t)npt + 64;
     const int pow_mode = (A.dbg == 17 || !(A.e32 == 2.0f || A.e32 == 1.0f)) ? 0 : (A.e32 == 2.0f ? 2 : 1);
     for (int e = 0; e < 2; e++) {
         const EyeArgs& E = A.eye[e];
@@ -1611,11 +1615,11 @@ static hipError_t polypoint_launch_listed(PolyPointArgs& A, int out, const uint3
     }
 #define PP_LAUNCH2(O)                                                                                                        \
     {                                                                                                                        \
-        hipError_t e = hipFuncSetAttribute((const void*)k_polypoint_listed<NT, SLOTS, O, KP, KS, MINW, SHARP>,               \
+        hipError_t e = hipFuncSetAttribute((const void*)k_polypoint_listed<NT, SLOTS, O, KP, KS, MINW, SHARP, SW>,               \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
         if (e != hipSuccess) return e;                                                                                       \
-        hipLaunchKernelGGL((k_polypoint_listed<NT, SLOTS, O, KP, KS, MINW, SHARP>), grid, block, lds, stream, A.image_f32, A.eye[0].depth, \
-                           A.eye[1].depth, A.w, A.h, A.S, A.T, off_dflag, off_dcnt, pow_mode, npt, list, count, A);          \
+        hipLaunchKernelGGL((k_polypoint_listed<NT, SLOTS, O, KP, KS, MINW, SHARP, SW>), grid, block, lds, stream, A.image_f32, A.eye[0].depth, \
+                           A.eye[1].depth, A.w, A.h, A.S, A.T, off_dflag, off_dcnt, pow_mode, npt, off_xq, list, count, A);  \
     }
     if (out == PO_F32) PP_LAUNCH2(PO_F32)
     else if (out == PO_U8) PP_LAUNCH2(PO_U8)
@@ -1627,7 +1631,8 @@ static hipError_t polypoint_launch_listed(PolyPointArgs& A, int out, const uint3
 
 hipError_t launch_polypoint_tier2(const RowArgs& R, int S, uint8_t* rowflag2, hipStream_t stream, int sharp, uint32_t* hint2, int tile_width,
                                   const uint32_t* list, const uint32_t* count) {
-    if (R.d64 || R.neyes != 2 || R.single >= 0 || R.out_u8 || !R.image_f32) return hipErrorNotSupported;
+    // (dialect: numba's typing of the sweep -- d64 & 2, round 6 -- has its instantiations; the float64 chain alone has none)
+    if (R.d64 == 1 || R.neyes != 2 || R.single >= 0 || R.out_u8 || !R.image_f32) return hipErrorNotSupported;
     const int nt = 256, slots = 4;
     PolyPointArgs A;
     A.n = R.n; A.h = R.h; A.w = R.w; A.S = S;
@@ -1644,10 +1649,11 @@ hipError_t launch_polypoint_tier2(const RowArgs& R, int S, uint8_t* rowflag2, hi
     A.rowflag = rowflag2;
     A.dbg = R.dbg;
     A.tilemap = R.tilemap; A.gray = R.lazy_gray; A.tm_words = R.tm_words;
-    A.d64 = 0; A.e64 = R.e64;
+    A.d64 = R.d64; A.e64 = R.e64;
     A.hint = hint2;
     if ((size_t)A.n * A.h * A.w >= (1ull << 31) || (size_t)A.n * A.out_h * A.out_w >= (1ull << 31)) return hipErrorNotSupported;
     const int out = R.stereo_is_u8 ? (R.no_mask ? PO_U8NM : PO_U8) : PO_F32;
+    if (R.d64 & 2) return sharp ? polypoint_launch_listed<1, 1>(A, out, list, count, stream) : polypoint_launch_listed<0, 1>(A, out, list, count, stream);
     return sharp ? polypoint_launch_listed<1>(A, out, list, count, stream) : polypoint_launch_listed<0>(A, out, list, count, stream);
 }
 

@@ -551,13 +551,20 @@ __device__ int poly_sequential(const Poly& P, const Lds& L, int csg_cap_ref, con
 // the epsilon always alive --, float32 array elements meet them in float64 compares, ip_k is a float64 numerator over the
 // float32 difference x1 - x0, closeness and the colour products are float64, and every sub-interval rounds once into the
 // float32 `color`.  One lane replays a row literally; the dialect is a compatibility path, not a fast one.
+// (round 6, second session) The same statements over a STRETCH c0 .. c1 of the row from a known state -- behind a reset pixel the
+// active list is [seg0] whatever happened before (poly_replay_stretch's argument), `sgp0` sorted points lie left of that pixel's last
+// centre, `pt0` points left of pixel c0 -- with the list in `csg` (capacity `csg_room`).  The whole row: c0 = 0, c1 = w - 1, seg0 < 0.
+// Until then an order-dependent row under numba's sweep typing was swept whole by one lane (3 ms per 4K row); now a lane per
+// stretch, a few dozen columns each.  Returns 0, -1 (the reference's list would overflow), -3 (`csg_room` exceeded: the whole-row form).
+// (a real call: inlined at its two call sites it took the dialect row kernels from 113 to 328 spilled vector registers)
 template <class Emit>
-__device__ int poly_sequential64(const Poly& P, const Lds& L, int csg_cap_ref, const Emit& emit) {
-    const int w = P.w, sg_end = P.npt - 1;
-    uint16_t* csg = P.entries;
+__device__ __noinline__ int poly_stretch64(const Poly& P, const Lds& L, int csg_cap_ref, const Emit& emit, int c0, int c1, int seg0, int sgp0, int pt0,
+                                           uint16_t* csg, int csg_room) {
+    const int sg_end = P.npt - 1;
     const int cap = min(csg_cap_ref, P.cap);
-    int csg_end = 0, sg_pointer = 0, pt_i = 0;
-    for (int col = 0; col < w; col++) {
+    int csg_end = 0, sg_pointer = sgp0, pt_i = max(pt0 - 1, 0);
+    if (seg0 >= 0) { csg[0] = (uint16_t)seg0; csg_end = 1; }
+    for (int col = c0; col <= c1; col++) {
         float color[3] = {0.5f, 0.5f, 0.5f};
         while (poly_x(P, P.perm[pt_i]) < (float)col) pt_i++;
         pt_i--;
@@ -568,6 +575,7 @@ __device__ int poly_sequential64(const Poly& P, const Lds& L, int csg_cap_ref, c
             const double center = from_d + 0.5 * sig;
             while (sg_pointer < sg_end && (double)poly_x(P, P.perm[sg_pointer]) < center) {
                 if (csg_end >= cap) return -1;
+                if (csg_end >= csg_room) return -3;
                 csg[csg_end++] = P.perm[sg_pointer++];
             }
             int ci = 0;
@@ -605,6 +613,11 @@ __device__ int poly_sequential64(const Poly& P, const Lds& L, int csg_cap_ref, c
         emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
     }
     return 0;
+}
+template <class Emit>
+__device__ __forceinline__ int poly_sequential64(const Poly& P, const Lds& L, int csg_cap_ref, const Emit& emit) {
+    // the whole row: from column 0 with an empty list, the list in the row's per-pixel segment lists (dead by then)
+    return poly_stretch64(P, L, csg_cap_ref, emit, 0, P.w - 1, -1, 0, 0, P.entries, P.cap);
 }
 
 // The same replay by a whole WAVE.  The sweep itself is sequential (the active list carries its order from column to
@@ -1248,11 +1261,17 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
             // P3c with numba's typing of the sweep (poly_sequential64 has the statements): one lane per output pixel; a pixel
             // whose choice depends on the order of the active list (several active segments, none or two equally close)
             // sends the row to the literal one-lane replay below
-            for (int col = tid; col < w; col += nt) {
+            // (round 6: next to the colour, the pixel's hazard and reset bits -- one active segment at its last sub-interval -- as bit rows over
+            // the idle long-segment array, as in the float32 branch: the order-dependent stretches are then replayed one by one)
+            unsigned long long* hzw64 = (unsigned long long*)P.longs;
+            unsigned long long* rsw64 = hzw64 + ((w + 63) >> 6);
+            for (int colb = 0; colb < w; colb += nt) {
+                const int col = colb + tid;
+                bool hazard = false, reset = false;
+                if (col < w) {
                 float color[3] = {0.5f, 0.5f, 0.5f};
                 const int pos0 = P.binoff[col], pos1 = P.binoff[col + 1];
                 const int ls = col > 0 ? P.segoff[col - 1] : 0, le = P.segoff[col];
-                bool hazard = false;
                 double prev = (double)col;
                 float a = poly_x(P, P.perm[pos0 - 1]);
                 for (int k = pos0 - 1; k < pos1; k++) {
@@ -1282,6 +1301,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                     int seg;
                     if (nact == 1) seg = single;
                     else { if (nqual == 0 || tie) hazard = true; seg = nqual ? best : single; }
+                    reset = k == pos1 - 1 && nact == 1;
                     if (seg < 0) { hazard = true; continue; }
                     const int col_l = poly_col(P, seg), col_r = poly_col(P, seg + 1);
                     if (col_l == col_r) {
@@ -1297,8 +1317,12 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                         }
                     }
                 }
+                reset = reset && !hazard;
                 if (hazard) *flag_hazard = 1;
                 else emit(col, csm::f32_to_u8_wrap(color[0]), csm::f32_to_u8_wrap(color[1]), csm::f32_to_u8_wrap(color[2]));
+                }
+                const unsigned long long hm = __ballot(hazard), rm = __ballot(reset);
+                if (lane == 0 && colb + 64 * wave < w && w <= 8192) { hzw64[(colb >> 6) + wave] = hm; rsw64[(colb >> 6) + wave] = rm; }
             }
         } else {
         // P3c: one lane per output pixel (reference :1951-1991).  Next to the pixel's colour: is it ORDER-DEPENDENT (hazard), and
@@ -1378,7 +1402,81 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
         return;
     }
     if (DIALECT && (d64 & 2)) {
-        if ((overflow || *flag_hazard) && tid == 0) {   // order-dependent row: the literal replay (it rewrites every pixel)
+        // order-dependent row under numba's typing of the sweep.  Round 6: the stretches between reset pixels, a LANE each (lane 0 of
+        // wave si takes stretch si: poly_stretch64, the literal statements from a known state), their lists in the idle tail of the
+        // per-pixel segment lists; what that cannot do (no room for the scratch, more than 256 stretches, a list beyond 128 entries,
+        // lists that overflowed) is swept whole by one lane as before (poly_sequential64 rewrites every pixel).
+        constexpr int NSTR64 = 256, ROOM64 = 128;
+        int* nstretch64 = L.misc + 3;
+        int* bad64 = L.misc + 4;
+        const int tail64 = (*ntotal + 7) & ~7;
+        bool done = false;
+        if (!overflow && *flag_hazard && w <= 8192 && dbg != 26 && tail64 + 2 * NSTR64 + ROOM64 * nwaves + 8 <= P.cap) {
+            uint32_t* slist = (uint32_t*)(P.entries + tail64);          // start | end << 16 (pixel columns)
+            uint16_t* wscr = P.entries + tail64 + 2 * NSTR64;           // [nwaves][ROOM64]
+            if (tid == 0) {
+                const unsigned long long* hzw = (const unsigned long long*)P.longs;
+                const unsigned long long* rsw = hzw + ((w + 63) >> 6);
+                int count = 0, last_reset = -1, start = 0, end = 0;
+                bool open = false;
+                for (int wi = 0; wi < (w + 63) >> 6; wi++) {
+                    const unsigned long long hz = hzw[wi], rs = rsw[wi];
+                    unsigned long long ev = hz | rs;
+                    while (ev) {
+                        const int b = __ffsll((long long)ev) - 1;
+                        ev &= ev - 1;
+                        const int col = wi * 64 + b;
+                        if ((hz >> b) & 1ull) {
+                            if (!open) { open = true; start = last_reset + 1; }
+                            end = col;
+                        } else {
+                            if (open) { if (count < NSTR64) slist[count] = (uint32_t)start | ((uint32_t)end << 16); count++; open = false; }
+                            last_reset = col;
+                        }
+                    }
+                }
+                if (open) { if (count < NSTR64) slist[count] = (uint32_t)start | ((uint32_t)end << 16); count++; }
+                *nstretch64 = count <= NSTR64 ? count : -1;
+                *bad64 = 0;
+            }
+            __syncthreads();
+            const int nstr = *nstretch64;
+            if (nstr > 0) {
+                for (int si = wave; si < nstr; si += nwaves) {
+                    const int c0 = (int)(slist[si] & 0xffffu), c1 = (int)(slist[si] >> 16);
+                    int rc = 0;
+                    if (lane == 0) {
+                        int seg0 = -1, sgp0 = 0;
+                        if (c0 > 0) {   // the state after pixel c0 - 1: its single active segment, the points left of its last centre (float64 compares)
+                            const int r = c0 - 1;
+                            const int pos1 = P.binoff[r + 1];
+                            const double from_d = fmax((double)r, (double)poly_x(P, P.perm[pos1 - 1])) + 1e-7;
+                            const double to_d = fmin((double)(r + 1), (double)poly_x(P, P.perm[pos1])) - 1e-7;
+                            const double center = from_d + 0.5 * (to_d - from_d);
+                            const int ls = r > 0 ? P.segoff[r - 1] : 0, le = P.segoff[r];
+                            for (int e = ls; e < le; e++) {
+                                const int o = P.entries[e];
+                                if ((double)poly_x(P, o) < center && !((double)poly_x(P, o + 1) < center)) seg0 = o;
+                            }
+                            sgp0 = pos1;
+                            while (sgp0 > 0 && !((double)poly_x(P, P.perm[sgp0 - 1]) < center)) sgp0--;
+                            if (seg0 < 0) rc = -3;   // (cannot happen: the pixel was marked because exactly one segment is active there)
+                        }
+                        if (rc == 0) rc = poly_stretch64(P, L, E.csg_cap, emit, c0, c1, seg0, sgp0, (int)P.binoff[c0], wscr + ROOM64 * wave, ROOM64);
+                        if (rc) *bad64 = rc;
+                    }
+                }
+            }
+            __syncthreads();
+            done = nstr > 0 && *bad64 == 0;
+            if (done && stats_rw && tid == 0) atomicAdd(&stats_rw[ST_FALLBACK_ROWS], 1u);
+            if (dbg == 14 && stats_rw && tid == 0) {   // diagnostics: row-eyes done in stretches / stretches / attempts that gave up (by reason)
+                if (done) { atomicAdd(&stats_rw[12], 1u); atomicAdd(&stats_rw[13], (unsigned)nstr); }
+                else atomicAdd(&stats_rw[15], nstr <= 0 ? 1u : (*bad64 == -3 ? 0x100u : 0x10000u));
+            }
+        }
+        if (dbg == 14 && stats_rw && tid == 0 && !done && (overflow || *flag_hazard)) atomicAdd(&stats_rw[14], 1u);
+        if (!done && (overflow || *flag_hazard) && tid == 0) {   // the literal replay of the whole row (it rewrites every pixel)
             const int rc = poly_sequential64(P, L, E.csg_cap, emit);
             if (stats_rw) {
                 atomicAdd(&stats_rw[ST_FALLBACK_ROWS], 1u);
