@@ -20,6 +20,7 @@ Prints ONE JSON line on rank 0 (contract in the task description) with extra obj
                  1 thread; all host cores as OpenMP over rows in one process (the analogue of the reference's numba prange);
                  64 single-threaded processes, a frame each
   value_blur_off (metric config, N = 1): the same workload with the depth blur switched off
+  value_dialect_d64 (metric config, N = 1): the same workload under dialect D64 (what an install of the reference with numba computes)
   split        (N > 1): kernels only / kernels + all-gather / end to end
 """
 import argparse
@@ -307,6 +308,22 @@ def main():
             del d2
         plan.run(image, depth)
 
+    # the same workload under dialect D64 -- what an install of the reference WITH numba computes (float64 disparity chain + numba's typing
+    # of the polylines sweep; derived typing): in the point kernel since round 6.  Reported next to the metric, never as it.
+    value_dialect_d64 = None
+    if world == 1 and a.config == "metric" and not a.depth and not a.no_other_depths:
+        try:
+            engine.DIALECT = "D64"
+            plan64 = engine.Plan(params(nloc), device)
+            plan64.run(image, depth)
+            value_dialect_d64 = frames * a.steps / timed(lambda: plan64.run(image, depth), a.steps)
+            del plan64
+        except Exception as ex:  # noqa: BLE001  (an extra, never a reason to lose the bench line)
+            value_dialect_d64 = None
+            print(f"bench.py: D64 leg skipped: {ex}", file=sys.stderr)
+        finally:
+            engine.DIALECT = "D32"
+
     if a.verify and world > 1 and no_gather:
         ref = engine.Plan(params(nloc), device).run(image, depth)[0]
         ok = torch.equal(plan.stereo, ref)
@@ -427,6 +444,8 @@ def main():
             line["value_blur_off"] = value_blur_off
         if value_other_depths is not None:
             line["value_other_depths"] = value_other_depths
+        if value_dialect_d64 is not None:
+            line["value_dialect_d64"] = value_dialect_d64
         if split is not None:
             line["split"] = split
         if ranks is not None:

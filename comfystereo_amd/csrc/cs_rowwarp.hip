@@ -1380,7 +1380,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
             }
             const unsigned long long hm = __ballot(hazard), rm = __ballot(reset);
             if (lane == 0 && colb + 64 * wave < cB && w <= 8192) { hzw[(colb >> 6) + wave] = hm; rsw[(colb >> 6) + wave] = rm; }
-            if (ranged) {   // (wave-uniform)
+            if (SHARP && ranged) {   // (wave-uniform; sharp only: in the soft lean kernel this cost 5 more spilled vector registers, - 2 % on saturated depth)
                 int ll = col < cB ? (int)P.segoff[col] - (col > 0 ? (int)P.segoff[col - 1] : 0) : 0;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) ll = max(ll, __shfl_xor(ll, d));
@@ -1592,7 +1592,7 @@ __device__ void technique_polylines(const Lds& L, int w, const EyeArgs& E, float
                 if (seg0 >= 0) { cmin = min(cmin, poly_col(P, seg0)); cmax = max(cmax, poly_col(P, seg0 + 1)); }
                 // (round 5) can a LANE replay this stretch (k_poly_replay_lanes: lists of at most RPL_K entries)?  The per-pixel segment
                 // lists bound the active list; without them (whole-row export, column ranges) the answer is no: bit 31 of word 3
-                int longest = whole_row ? 0x7fff : (ranged ? *maxlist : 0);   // (ranged: the row's longest list bounds every stretch's)
+                int longest = (whole_row || (ranged && !SHARP)) ? 0x7fff : (ranged ? *maxlist : 0);   // (ranged, sharp: the row's longest list bounds every stretch's)
                 if (!whole_row && !ranged)
                     for (int p = c0 + lane; p <= c1; p += 64) longest = max(longest, (int)P.segoff[p] - (p > 0 ? (int)P.segoff[p - 1] : 0));
 #pragma unroll
