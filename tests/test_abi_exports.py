@@ -194,3 +194,29 @@ def test_graft_entry_build_checks_the_current_abi_version():
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "__graft_entry__.py")).read()
     assert "_native.ABI_VERSION" in src
     assert not re.search(r"cs_version\(\)\s*==\s*\d", src)
+
+
+def test_width_limits_of_round_6():
+    """Host-side width logic (no GPU): the anaglyph modes' limit is the side-by-side modes' for every technique but hybrid_edge_plus
+    (an anaglyph beyond the row kernel's stash form runs side by side into scratch + composition: the workspace grows by that
+    scratch exactly there), every technique but gpu_warp and hybrid_edge_plus takes 8 192 columns, and the numbers the documentation
+    quotes are the library's."""
+    L = _native.lib()
+    from comfystereo_amd import engine
+    sbs, ana = _native.MODE["left-right"], _native.MODE["red-cyan-anaglyph"]
+    quoted = {"none": 11578, "naive": 11578, "naive_interpolating": 9536, "polylines_soft": 8414, "polylines_sharp": 8206, "inverse": 9004,
+              "hybrid_edge": 9412, "gpu_warp": 7763, "none_post": 11578, "inverse_post": 9004, "hybrid_edge_plus": 6394}
+    for fill, want in quoted.items():
+        f = _native.FILL[fill]
+        assert L.cs_max_width_mode(f, sbs) == want, fill
+        if fill != "hybrid_edge_plus":
+            assert L.cs_max_width_mode(f, ana) == want, fill
+            assert L.cs_max_width(f) == want, fill
+        if fill not in ("gpu_warp", "hybrid_edge_plus"):
+            assert want >= 8192, fill
+    # naive_interpolating: an 8K anaglyph fits the stash form; near the limit an anaglyph asks for the side-by-side scratch (n * h * 2 w * 3 bytes)
+    def ws(w, mode):
+        p = engine.make_params(2, 16, w, 16, w, 3, "naive_interpolating", mode, 4.0, 0.0, 0.0, 0.5, 2.0, False, 20.0, 20.0, 2.0, 6, 12)
+        return L.cs_workspace_bytes(ctypes.byref(p))
+    assert ws(7680, "red-cyan-anaglyph") == ws(7680, "left-right")
+    assert ws(9536, "red-cyan-anaglyph") - ws(9536, "left-right") >= 2 * 16 * 2 * 9536 * 3
