@@ -85,8 +85,11 @@ namespace cs {
 #ifndef PP_DCAP2
 #define PP_DCAP2 192   // second tier (k_polypoint_listed): pixels under reversed segments a tile can hold
 #endif
+#ifndef PP_SW_MINW_SOFT
+#define PP_SW_MINW_SOFT 5   // (soft first tier: 95 registers, no spill; 5 against 4 workgroups per CU: D64 3 607 -> 4 038 frames/s on stepped depth, + 9 % on scene8; 6: no better -- tools/sessions/r06_s35.sh)
+#endif
 #ifndef PP_SW_MINW
-#define PP_SW_MINW 4   // workgroups per CU of the sweep-typing (SW) instantiations
+#define PP_SW_MINW 4   // workgroups per CU of the sweep-typing (SW) instantiations (sharp; soft: PP_SW_MINW_SOFT)
 #endif
 #define PP_DIRTY 0x8000u     // dflag (16 bits per tile pixel since round 5): pixel lies under a reversed segment; low 15 bits = its list slot
 
@@ -1563,7 +1566,7 @@ hipError_t launch_polypoint(const RowArgs& R, int S, uint8_t* rowflag, hipStream
         return hipErrorInvalidValue;   // 32-bit pixel indices, grid limits
     if (R.d64 & 2) {   // numba's sweep (float64 pieces: 128 registers, four workgroups per CU)
         if (sharp) return polypoint_launch<256, 4, PP_SW_MINW, 1, 1, 1>(A, out, stream);
-        return polypoint_launch<256, 4, PP_SW_MINW, 0, 1, 1>(A, out, stream);
+        return polypoint_launch<256, 4, PP_SW_MINW_SOFT, 0, 1, 1>(A, out, stream);
     }
     if (R.d64) {   // the float64 disparity chain (one geometry per form: the default one, or the wide-halo one)
         if (sharp) return geo == 5 ? polypoint_launch<384, 3, 5, 1, 1>(A, out, stream) : polypoint_launch<256, 4, 5, 1, 1>(A, out, stream);
