@@ -826,7 +826,13 @@ static int generate_chunk(const cs_params* p, const float* image, const float* d
         const bool ana = p->mode == CS_MODE_RED_CYAN_ANAGLYPH || p->mode == CS_MODE_CYAN_RED_REVERSEANAGLYPH;
         const bool hyb_lazy = p->fill == CS_FILL_HYBRID_EDGE && two_eyes && !dev_switch(CS_DEBUG_HYBRID_FULL_MAPS) &&
                               hybrid_fused_ok(n, w, halo, ana, -1, (p->flags >> 3) & 3, 0);
-        const bool want_lazy = (tile_fill || warp_lazy || hyb_lazy) && !(p->flags & 24) && !dev_switch(CS_DEBUG_NO_TILE) && !dev_switch(CS_DEBUG_BLUR_FULL_COPY) &&
+        // (round 6: the polylines techniques under a dialect flag too -- the point kernel's dialect instantiations share the tile function,
+        // lazy loads included, and run_rows completes the rows of any call a row kernel ends up taking; the other techniques' dialect
+        // kernels keep complete maps: 0.94 of 17.1 ms per 64 frames under D64, profiles/r06_s39/)
+        const int d64f = (p->flags >> 3) & 3;
+        const bool poly_fill = p->fill == CS_FILL_POLYLINES_SOFT || p->fill == CS_FILL_POLYLINES_SHARP;
+        const bool dialect_lazy = d64f == 0 || (poly_fill && halo <= polypoint_max_halo() && (d64f == 1 || polypoint_sweep64_ok(w, halo)));
+        const bool want_lazy = (tile_fill || warp_lazy || hyb_lazy) && dialect_lazy && !dev_switch(CS_DEBUG_NO_TILE) && !dev_switch(CS_DEBUG_BLUR_FULL_COPY) &&
                                p->mode != CS_MODE_LEFT_ONLY && p->mode != CS_MODE_ONLY_RIGHT &&
                                al256((size_t)n * hw * 4) < (1ull << 32) - (1u << 20);
         rc = launch_blur(gray, n, h, w, p->depth_blur_strength, p->depth_blur_edge_threshold, p->depth_blur_strength, p->depth_blur_falloff,
