@@ -221,6 +221,32 @@ def test_digests_at_baseline_sizes_on_the_gpu():
         assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"], cid
 
 
+def test_digests_at_the_widths_round_6_opened_on_the_gpu():
+    """The HIP path against the REFERENCE node's own outputs at the widths round 6 opened (tests/golden/digests_wide.json,
+    tools/make_goldens.py --only-wide): wide anaglyphs of the forward and post fills, their new side-by-side limits, polylines_sharp
+    at 8 192 columns -- by SHA-256 of the uint8 codes and the mask, like the BASELINE-size digests above."""
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN
+    from comfystereo_amd import engine
+    from comfystereo_amd.GenerateStereo import FILL_TECHNIQUE_MAPPING
+    dig = json.load(open(os.path.join(GOLDEN, "digests_wide.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    for cid, c in dig.items():
+        img = synth.image_f32(1, c["h"], c["w"], seed=c["image_seed"])
+        img[:, :, c["black"][0]:c["black"][1]] = 0.0
+        depth = synth.depth_batch(c["kind"], 1, c["h"], c["w"], channels=3)
+        got = engine.generate(torch.from_numpy(img).cuda(), torch.from_numpy(depth).cuda(), c["divergence"], 0.0, c["mode"], 0.0,
+                              0.5, 2.0, FILL_TECHNIQUE_MAPPING[c["fill_ui"]], 20.0, 20.0, c["blur"], depth_blur_falloff=2.0,
+                              depth_blur_vert_smooth=6, batch_size=12)
+        got = [t.cpu().numpy() for t in got]
+        k = [np.round(a * 255.0).astype(np.uint8) for a in (got[0], got[1][..., 0], got[2][..., 0])]
+        assert sha(k[0]) == c["stereo_u8"], cid
+        assert sha(k[1]) == c["dl_u8"] and sha(k[2]) == c["dr_u8"], cid
+        assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"], cid
+
+
 def test_forward_warp_1080p_rows_on_the_gpu():
     """forward_warp_gpu at 1080p against rows captured from the reference (gap mask exact; colours to the last ulps outside
     the gaps, <= 1e-4 for the few gap pixels whose torch.sqrt weight is not correctly rounded)."""

@@ -383,6 +383,46 @@ def gen_digests(gs):
         json.dump(out, f, indent=1)
 
 
+WIDE_CASES = {   # id: (h, w, depth kind, UI string, mode, divergence, blur) -- the widths round 6 opened
+    "naive_interp_8k_anaglyph": (8, 7680, "stepped", "Fill - Naive interpolating", "red-cyan-anaglyph", 4.0, False),
+    "naive_interp_9536_anaglyph_blur": (8, 9536, "stepped", "Fill - Naive interpolating", "cyan-red-reverseanaglyph", 4.0, True),
+    "naive_10240_anaglyph": (8, 10240, "stepped", "Fill - Naive", "red-cyan-anaglyph", 4.0, False),
+    "inverse_9004_anaglyph": (8, 9004, "stepped", "No fill - Reverse projection", "cyan-red-reverseanaglyph", 4.0, False),
+    "none_10240_anaglyph_blur": (8, 10240, "stepped", "No fill", "red-cyan-anaglyph", 4.0, True),
+    "none_post_10240_anaglyph": (8, 10240, "stepped", "Fill - Post-fill", "red-cyan-anaglyph", 4.0, False),
+    "inverse_post_8192_anaglyph_blur": (8, 8192, "stepped", "Fill - Reverse projection with Post-fill", "cyan-red-reverseanaglyph", 4.0, True),
+    "none_post_11578_sbs": (6, 11578, "stepped", "Fill - Post-fill", "right-left", 6.0, False),
+    "inverse_post_9004_sbs": (6, 9004, "stepped", "Fill - Reverse projection with Post-fill", "right-left", 6.0, False),
+    "naive_11578_sbs": (6, 11578, "stepped", "Fill - Naive", "right-left", 6.0, False),
+    "naive_interp_9536_sbs": (6, 9536, "stepped", "Fill - Naive interpolating", "right-left", 6.0, False),
+    "sharp_8192_sbs_clipped": (6, 8192, "clipped", "Fill - Polylines Sharp", "left-right", 5.0, False),
+    "sharp_8192_anaglyph_clipped": (6, 8192, "clipped", "Fill - Polylines Sharp", "red-cyan-anaglyph", 5.0, False),
+    "sharp_8192_tb_scene8": (6, 8192, "scene8", "Fill - Polylines Sharp", "top-bottom", 5.0, False),
+}
+
+
+def gen_wide(gs):
+    """SHA-256 digests of the reference's node outputs on thin rows at the widths round 6 opened (anaglyphs beyond the row kernel's stash
+    form, the post-fill and naive techniques at their new limits, polylines_sharp at 8 192 columns): inputs from tools/synth.py (seeded),
+    digests only.  tests/test_oracle_goldens.py checks the oracle against them on the CPU, tests/test_gpu_fullsize.py the HIP path."""
+    node = gs.StereoImageNode()
+    out = {}
+    for cid, (h, w, kind, ui, mode, div, blur) in WIDE_CASES.items():
+        img = synth.image_f32(1, h, w, seed=8)
+        img[:, :, 500:560] = 0.0   # genuinely black pixels (mask, quirk Q6)
+        depth = synth.depth_batch(kind, 1, h, w, channels=3)
+        outs = node.generate(torch.from_numpy(img), torch.from_numpy(depth), div, 0.0, mode, 0.0, 0.5, 2.0, ui, 20.0, 20.0, blur,
+                             depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+        stereo, dl, dr, mask = [o.numpy() for o in outs]
+        k = [np.round(a * 255.0).astype(np.uint8) for a in (stereo, dl[..., 0], dr[..., 0])]
+        out[cid] = dict(h=h, w=w, kind=kind, fill_ui=ui, mode=mode, divergence=div, blur=blur, image_seed=8, black=[500, 560],
+                        stereo_u8=sha(k[0]), dl_u8=sha(k[1]), dr_u8=sha(k[2]), mask=sha(np.packbits(mask.astype(bool))),
+                        mask_sum=int(mask.sum()))
+        print("wide digest", cid, out[cid]["stereo_u8"][:16], flush=True)
+    with open(os.path.join(OUT, "digests_wide.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 WARP_1080P_ROWS = [0, 1, 110, 128, 129, 257, 332, 539, 540, 746, 822, 951, 1078, 1079]
 
 
@@ -611,6 +651,9 @@ def main():
     if "--only-scene8" in sys.argv:
         gen_scene8(gs)
         return
+    if "--only-wide" in sys.argv:
+        gen_wide(gs)
+        return
     gen_apply_stereo_divergence(sig)
     gen_hidden(sig)
     gen_blur(sig)
@@ -625,6 +668,7 @@ def main():
     gen_forward_warp_params(sig)
     gen_numpy_blur(sig)
     gen_scene8(gs)
+    gen_wide(gs)
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
