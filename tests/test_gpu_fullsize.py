@@ -221,6 +221,25 @@ def test_digests_at_baseline_sizes_on_the_gpu():
         assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"], cid
 
 
+def test_digest_of_the_metric_frame_at_4k_on_the_gpu(engine):
+    """The metric's own frame through the HIP path against the REFERENCE node's outputs (tests/golden/digest_metric_4k.json): the uint8
+    codes, the mask and the float32 arrays themselves, bit for bit -- `roofline` and `value` are quoted on a path whose result is the
+    reference's."""
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN
+    c = json.load(open(os.path.join(GOLDEN, "digest_metric_4k.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    img = synth.image_f32(1, c["h"], c["w"], seed=c["image_seed"])
+    depth = synth.depth_batch(c["kind"], 1, c["h"], c["w"], channels=3)
+    got = gen(engine, img, depth, "polylines_soft", c["mode"], blur=c["blur"], div=c["divergence"])
+    k = [np.round(a * 255.0).astype(np.uint8) for a in (got[0], got[1][..., 0], got[2][..., 0])]
+    assert sha(k[0]) == c["stereo_u8"] and sha(k[1]) == c["dl_u8"] and sha(k[2]) == c["dr_u8"]
+    assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"]
+    assert sha(got[0]) == c["stereo_f32"] and sha(got[1]) == c["dl_f32"] and sha(got[2]) == c["dr_f32"]
+
+
 def test_digests_at_the_widths_round_6_opened_on_the_gpu():
     """The HIP path against the REFERENCE node's own outputs at the widths round 6 opened (tests/golden/digests_wide.json,
     tools/make_goldens.py --only-wide): wide anaglyphs of the forward and post fills, their new side-by-side limits, polylines_sharp

@@ -265,6 +265,25 @@ def test_digests_at_baseline_sizes():
         assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"], cid
 
 
+def test_digest_of_the_metric_frame_at_4k():
+    """The metric's own frame (BASELINE.json configs[1]: 4K, polylines_soft, left-right SBS, divergence 8, stepped depth, blur on) against
+    SHA-256 digests of the REFERENCE node's outputs (tests/golden/digest_metric_4k.json, tools/make_goldens.py --only-metric-4k: a quarter
+    of an hour of the pure-Python reference): uint8 codes, mask AND the float32 arrays themselves."""
+    import json
+    import os
+    from conftest import GOLDEN
+    c = json.load(open(os.path.join(GOLDEN, "digest_metric_4k.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    img = synth.image_f32(1, c["h"], c["w"], seed=c["image_seed"])
+    depth = synth.depth_batch(c["kind"], 1, c["h"], c["w"], channels=3)
+    got = node_oracle.generate(img, depth, c["divergence"], 0.0, c["mode"], 0.0, 0.5, 2.0, c["fill_ui"], 20.0, 20.0, c["blur"],
+                               depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+    k = [np.round(a * 255.0).astype(np.uint8) for a in (got[0], got[1][..., 0], got[2][..., 0])]
+    assert sha(k[0]) == c["stereo_u8"] and sha(k[1]) == c["dl_u8"] and sha(k[2]) == c["dr_u8"]
+    assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"]
+    assert sha(got[0]) == c["stereo_f32"] and sha(got[1]) == c["dl_f32"] and sha(got[2]) == c["dr_f32"]
+
+
 def test_digests_at_the_widths_round_6_opened():
     """Thin rows at the widths round 6 opened (anaglyphs of the forward fills beyond the row kernel's stash form, naive /
     naive_interpolating / none_post / inverse_post at their new limits, polylines_sharp at 8 192 columns) against SHA-256 digests of the

@@ -423,6 +423,26 @@ def gen_wide(gs):
         json.dump(out, f, indent=1)
 
 
+def gen_metric_4k(gs):
+    """SHA-256 digests of the REFERENCE node's outputs on the metric's own frame (BASELINE.json configs[1]: 4K, polylines_soft, left-right
+    SBS, divergence 8, stepped depth, blur on; the inputs of tests/test_gpu_fullsize.py::test_4k_frame_bit_exact_vs_oracle).  The pure-Python
+    reference takes a quarter of an hour for this one frame; digests only."""
+    node = gs.StereoImageNode()
+    h, w = 2160, 3840
+    img = synth.image_f32(1, h, w, seed=1)
+    depth = synth.depth_batch("stepped", 1, h, w, channels=3)
+    outs = node.generate(torch.from_numpy(img), torch.from_numpy(depth), 8.0, 0.0, "left-right", 0.0, 0.5, 2.0, "Fill - Polylines Soft",
+                         20.0, 20.0, True, depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+    stereo, dl, dr, mask = [o.numpy() for o in outs]
+    k = [np.round(a * 255.0).astype(np.uint8) for a in (stereo, dl[..., 0], dr[..., 0])]
+    out = dict(h=h, w=w, kind="stepped", fill_ui="Fill - Polylines Soft", mode="left-right", divergence=8.0, blur=True, image_seed=1,
+               stereo_u8=sha(k[0]), dl_u8=sha(k[1]), dr_u8=sha(k[2]), mask=sha(np.packbits(mask.astype(bool))), mask_sum=int(mask.sum()),
+               stereo_f32=sha(stereo), dl_f32=sha(dl), dr_f32=sha(dr))
+    with open(os.path.join(OUT, "digest_metric_4k.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("metric 4K digest", out["stereo_u8"][:16], flush=True)
+
+
 WARP_1080P_ROWS = [0, 1, 110, 128, 129, 257, 332, 539, 540, 746, 822, 951, 1078, 1079]
 
 
@@ -654,6 +674,9 @@ def main():
     if "--only-wide" in sys.argv:
         gen_wide(gs)
         return
+    if "--only-metric-4k" in sys.argv:
+        gen_metric_4k(gs)
+        return
     gen_apply_stereo_divergence(sig)
     gen_hidden(sig)
     gen_blur(sig)
@@ -669,6 +692,7 @@ def main():
     gen_numpy_blur(sig)
     gen_scene8(gs)
     gen_wide(gs)
+    gen_metric_4k(gs)
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
