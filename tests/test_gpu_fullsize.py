@@ -240,6 +240,27 @@ def test_digest_of_the_metric_frame_at_4k_on_the_gpu(engine):
     assert sha(got[0]) == c["stereo_f32"] and sha(got[1]) == c["dl_f32"] and sha(got[2]) == c["dr_f32"]
 
 
+def test_digests_of_the_other_bench_configurations_at_4k_on_the_gpu(engine):
+    """One 4K frame of cfg 3 (hybrid_edge + blur), cfg 5 (`none`, red-cyan anaglyph + mask), naive_interpolating and polylines_sharp through
+    the HIP path against the REFERENCE node's own outputs (tests/golden/digests_4k.json): uint8 codes, mask, float32 arrays -- every
+    bench configuration but gpu_warp (tolerance-checked elsewhere) is quoted on a path whose full-size result is the reference's."""
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN
+    from comfystereo_amd.GenerateStereo import FILL_TECHNIQUE_MAPPING
+    dig = json.load(open(os.path.join(GOLDEN, "digests_4k.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    for cid, c in dig.items():
+        img = synth.image_f32(1, c["h"], c["w"], seed=c["image_seed"])
+        depth = synth.depth_batch(c["kind"], 1, c["h"], c["w"], channels=3)
+        got = gen(engine, img, depth, FILL_TECHNIQUE_MAPPING[c["fill_ui"]], c["mode"], blur=c["blur"], div=c["divergence"])
+        k = [np.round(a * 255.0).astype(np.uint8) for a in (got[0], got[1][..., 0], got[2][..., 0])]
+        assert sha(k[0]) == c["stereo_u8"] and sha(k[1]) == c["dl_u8"] and sha(k[2]) == c["dr_u8"], cid
+        assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"], cid
+        assert sha(got[0]) == c["stereo_f32"] and sha(got[1]) == c["dl_f32"] and sha(got[2]) == c["dr_f32"], cid
+
+
 def test_digests_at_the_widths_round_6_opened_on_the_gpu():
     """The HIP path against the REFERENCE node's own outputs at the widths round 6 opened (tests/golden/digests_wide.json,
     tools/make_goldens.py --only-wide): wide anaglyphs of the forward and post fills, their new side-by-side limits, polylines_sharp

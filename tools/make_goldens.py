@@ -443,6 +443,39 @@ def gen_metric_4k(gs):
     print("metric 4K digest", out["stereo_u8"][:16], flush=True)
 
 
+CASES_4K = {   # the other bench configurations at full size, one frame each (bench.py CONFIGS; gpu_warp is tolerance-checked, not hashed)
+    "cfg3_hybrid_edge": ("Imperfect fill - Hybrid Edge", "left-right"),
+    "cfg5_none_anaglyph": ("No fill", "red-cyan-anaglyph"),
+    "naive_interpolating": ("Fill - Naive interpolating", "left-right"),
+    "polylines_sharp": ("Fill - Polylines Sharp", "left-right"),
+}
+
+
+def gen_4k(gs, only=None):
+    """SHA-256 digests of the REFERENCE node's outputs on one 4K frame of every other bench configuration (BASELINE.json configs[2], [4]
+    and the two fills bench.py adds; divergence 8, stepped depth, blur on; inputs as for digest_metric_4k.json).  Minutes of the
+    pure-Python reference per case; `CS_GOLDEN_CASE=<id>` generates one case into digests_4k.<id>.json (cases in parallel processes,
+    merged by hand into digests_4k.json: the result does not depend on the order)."""
+    node = gs.StereoImageNode()
+    h, w = 2160, 3840
+    img = synth.image_f32(1, h, w, seed=1)
+    depth = synth.depth_batch("stepped", 1, h, w, channels=3)
+    out = {}
+    for cid, (ui, mode) in CASES_4K.items():
+        if only and cid != only:
+            continue
+        outs = node.generate(torch.from_numpy(img), torch.from_numpy(depth), 8.0, 0.0, mode, 0.0, 0.5, 2.0, ui, 20.0, 20.0, True,
+                             depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+        stereo, dl, dr, mask = [o.numpy() for o in outs]
+        k = [np.round(a * 255.0).astype(np.uint8) for a in (stereo, dl[..., 0], dr[..., 0])]
+        out[cid] = dict(h=h, w=w, kind="stepped", fill_ui=ui, mode=mode, divergence=8.0, blur=True, image_seed=1,
+                        stereo_u8=sha(k[0]), dl_u8=sha(k[1]), dr_u8=sha(k[2]), mask=sha(np.packbits(mask.astype(bool))),
+                        mask_sum=int(mask.sum()), stereo_f32=sha(stereo), dl_f32=sha(dl), dr_f32=sha(dr))
+        print("4K digest", cid, out[cid]["stereo_u8"][:16], flush=True)
+    with open(os.path.join(OUT, f"digests_4k.{only}.json" if only else "digests_4k.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 WARP_1080P_ROWS = [0, 1, 110, 128, 129, 257, 332, 539, 540, 746, 822, 951, 1078, 1079]
 
 
@@ -677,6 +710,9 @@ def main():
     if "--only-metric-4k" in sys.argv:
         gen_metric_4k(gs)
         return
+    if "--only-4k" in sys.argv:
+        gen_4k(gs, os.environ.get("CS_GOLDEN_CASE") or None)
+        return
     gen_apply_stereo_divergence(sig)
     gen_hidden(sig)
     gen_blur(sig)
@@ -693,6 +729,7 @@ def main():
     gen_scene8(gs)
     gen_wide(gs)
     gen_metric_4k(gs)
+    gen_4k(gs)
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
