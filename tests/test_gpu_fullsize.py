@@ -261,6 +261,32 @@ def test_digests_of_the_other_bench_configurations_at_4k_on_the_gpu(engine):
         assert sha(got[0]) == c["stereo_f32"] and sha(got[1]) == c["dl_f32"] and sha(got[2]) == c["dr_f32"], cid
 
 
+def test_digests_of_order_dependent_depth_at_full_width_on_the_gpu(engine):
+    """The tie path against the REFERENCE itself (tests/golden/digests_ties.json): a 4K frame of saturated depth and 48 rows of 8-bit noise
+    through polylines_soft and polylines_sharp, blur off -- tile kernel, second tier, lean row kernel, lane and wave replay -- uint8 codes,
+    mask and float32 arrays equal to what the reference's sequential sweep produced; and the rows did reach the row kernel."""
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN
+    from comfystereo_amd.GenerateStereo import FILL_TECHNIQUE_MAPPING
+    dig = json.load(open(os.path.join(GOLDEN, "digests_ties.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    for cid, c in dig.items():
+        img = synth.image_f32(1, c["h"], c["w"], seed=c["image_seed"])
+        depth = synth.depth_batch(c["kind"], 1, c["h"], c["w"], channels=3)
+        p = engine.make_params(1, c["h"], c["w"], c["h"], c["w"], 3, FILL_TECHNIQUE_MAPPING[c["fill_ui"]], c["mode"], c["divergence"], 0.0, 0.0, 0.5, 2.0,
+                               c["blur"], 20.0, 20.0, 2.0, 6, 12)
+        plan = engine.Plan(p, torch.device("cuda"))
+        got = [t.cpu().numpy() for t in plan.run(cuda(img), cuda(depth))]
+        st = plan.stats()
+        assert int(st[:, 9].sum()) == 0 and int(st[:, 11].sum()) > 0, cid   # no kernel error flag; rows were handed to the row kernel
+        k = [np.round(a * 255.0).astype(np.uint8) for a in (got[0], got[1][..., 0], got[2][..., 0])]
+        assert sha(k[0]) == c["stereo_u8"] and sha(k[1]) == c["dl_u8"] and sha(k[2]) == c["dr_u8"], cid
+        assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"], cid
+        assert sha(got[0]) == c["stereo_f32"] and sha(got[1]) == c["dl_f32"] and sha(got[2]) == c["dr_f32"], cid
+
+
 def test_digests_at_the_widths_round_6_opened_on_the_gpu():
     """The HIP path against the REFERENCE node's own outputs at the widths round 6 opened (tests/golden/digests_wide.json,
     tools/make_goldens.py --only-wide): wide anaglyphs of the forward and post fills, their new side-by-side limits, polylines_sharp

@@ -476,6 +476,37 @@ def gen_4k(gs, only=None):
         json.dump(out, f, indent=1)
 
 
+CASES_TIES = {   # id: (h, w, depth kind, UI string) -- order-dependent rows at full width, blur off (ties only survive without the blur)
+    "soft_clipped_4k": (2160, 3840, "clipped", "Fill - Polylines Soft"),
+    "sharp_clipped_4k": (2160, 3840, "clipped", "Fill - Polylines Sharp"),
+    "soft_random8_rows": (48, 3840, "random8", "Fill - Polylines Soft"),
+    "sharp_random8_rows": (48, 3840, "random8", "Fill - Polylines Sharp"),
+}
+
+
+def gen_ties(gs, only=None):
+    """SHA-256 digests of the REFERENCE node's outputs on ORDER-DEPENDENT depth at full width: a 4K frame saturated to exact 0 / 1 over
+    large areas (exact closeness ties under every fold: the stretch replay) and 48 rows of 8-bit noise (no reset points: every row replayed
+    whole), polylines_soft and polylines_sharp, divergence 8, left-right, blur off.  `CS_GOLDEN_CASE=<id>` as for --only-4k."""
+    node = gs.StereoImageNode()
+    out = {}
+    for cid, (h, w, kind, ui) in CASES_TIES.items():
+        if only and cid != only:
+            continue
+        img = synth.image_f32(1, h, w, seed=1)
+        depth = synth.depth_batch(kind, 1, h, w, channels=3)
+        outs = node.generate(torch.from_numpy(img), torch.from_numpy(depth), 8.0, 0.0, "left-right", 0.0, 0.5, 2.0, ui, 20.0, 20.0, False,
+                             depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+        stereo, dl, dr, mask = [o.numpy() for o in outs]
+        k = [np.round(a * 255.0).astype(np.uint8) for a in (stereo, dl[..., 0], dr[..., 0])]
+        out[cid] = dict(h=h, w=w, kind=kind, fill_ui=ui, mode="left-right", divergence=8.0, blur=False, image_seed=1,
+                        stereo_u8=sha(k[0]), dl_u8=sha(k[1]), dr_u8=sha(k[2]), mask=sha(np.packbits(mask.astype(bool))),
+                        mask_sum=int(mask.sum()), stereo_f32=sha(stereo), dl_f32=sha(dl), dr_f32=sha(dr))
+        print("tie digest", cid, out[cid]["stereo_u8"][:16], flush=True)
+    with open(os.path.join(OUT, f"digests_ties.{only}.json" if only else "digests_ties.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 WARP_1080P_ROWS = [0, 1, 110, 128, 129, 257, 332, 539, 540, 746, 822, 951, 1078, 1079]
 
 
@@ -713,6 +744,9 @@ def main():
     if "--only-4k" in sys.argv:
         gen_4k(gs, os.environ.get("CS_GOLDEN_CASE") or None)
         return
+    if "--only-ties" in sys.argv:
+        gen_ties(gs, os.environ.get("CS_GOLDEN_CASE") or None)
+        return
     gen_apply_stereo_divergence(sig)
     gen_hidden(sig)
     gen_blur(sig)
@@ -730,6 +764,7 @@ def main():
     gen_wide(gs)
     gen_metric_4k(gs)
     gen_4k(gs)
+    gen_ties(gs)
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
