@@ -287,6 +287,27 @@ def test_digests_of_order_dependent_depth_at_full_width_on_the_gpu(engine):
         assert sha(got[0]) == c["stereo_f32"] and sha(got[1]) == c["dl_f32"] and sha(got[2]) == c["dr_f32"], cid
 
 
+def test_digests_of_scene8_depth_at_4k_on_the_gpu(engine):
+    """Estimator-like depth at full size against the REFERENCE itself (tests/golden/digests_scene8_4k.json): one 4K frame of scene8 depth at
+    the metric's divergence through polylines_soft (blur on) and polylines_sharp (blur on / off) -- first tier, second tier, lean row pass in
+    column ranges -- uint8 codes, mask and float32 arrays."""
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN
+    from comfystereo_amd.GenerateStereo import FILL_TECHNIQUE_MAPPING
+    dig = json.load(open(os.path.join(GOLDEN, "digests_scene8_4k.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    img = synth.image_f32(1, 2160, 3840, seed=1)
+    depth = synth.depth_batch("scene8", 1, 2160, 3840, channels=3)
+    for cid, c in dig.items():
+        got = gen(engine, img, depth, FILL_TECHNIQUE_MAPPING[c["fill_ui"]], c["mode"], blur=c["blur"], div=c["divergence"])
+        k = [np.round(a * 255.0).astype(np.uint8) for a in (got[0], got[1][..., 0], got[2][..., 0])]
+        assert sha(k[0]) == c["stereo_u8"] and sha(k[1]) == c["dl_u8"] and sha(k[2]) == c["dr_u8"], cid
+        assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"], cid
+        assert sha(got[0]) == c["stereo_f32"] and sha(got[1]) == c["dl_f32"] and sha(got[2]) == c["dr_f32"], cid
+
+
 def test_digests_at_the_widths_round_6_opened_on_the_gpu():
     """The HIP path against the REFERENCE node's own outputs at the widths round 6 opened (tests/golden/digests_wide.json,
     tools/make_goldens.py --only-wide): wide anaglyphs of the forward and post fills, their new side-by-side limits, polylines_sharp

@@ -326,6 +326,28 @@ def test_digests_of_order_dependent_depth_at_full_width():
         assert sha(got[0]) == c["stereo_f32"] and sha(got[1]) == c["dl_f32"] and sha(got[2]) == c["dr_f32"], cid
 
 
+def test_digests_of_scene8_depth_at_4k():
+    """One 4K frame of scene8 depth (tools/synth.scene8: quantised smooth depth with softened object silhouettes -- what a depth estimator
+    delivers, and what overflows the tile kernels' per-pixel lists) at the metric's divergence against the REFERENCE node's own outputs
+    (tests/golden/digests_scene8_4k.json, tools/make_goldens.py --only-scene8-4k): polylines_soft with the blur, polylines_sharp with and
+    without."""
+    import json
+    import os
+    from conftest import GOLDEN
+    dig = json.load(open(os.path.join(GOLDEN, "digests_scene8_4k.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    assert len(dig) == 3
+    img = synth.image_f32(1, 2160, 3840, seed=1)
+    depth = synth.depth_batch("scene8", 1, 2160, 3840, channels=3)
+    for cid, c in dig.items():
+        got = node_oracle.generate(img, depth, c["divergence"], 0.0, c["mode"], 0.0, 0.5, 2.0, c["fill_ui"], 20.0, 20.0, c["blur"],
+                                   depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+        k = [np.round(a * 255.0).astype(np.uint8) for a in (got[0], got[1][..., 0], got[2][..., 0])]
+        assert sha(k[0]) == c["stereo_u8"] and sha(k[1]) == c["dl_u8"] and sha(k[2]) == c["dr_u8"], cid
+        assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"], cid
+        assert sha(got[0]) == c["stereo_f32"] and sha(got[1]) == c["dl_f32"] and sha(got[2]) == c["dr_f32"], cid
+
+
 def test_digests_at_the_widths_round_6_opened():
     """Thin rows at the widths round 6 opened (anaglyphs of the forward fills beyond the row kernel's stash form, naive /
     naive_interpolating / none_post / inverse_post at their new limits, polylines_sharp at 8 192 columns) against SHA-256 digests of the

@@ -507,6 +507,37 @@ def gen_ties(gs, only=None):
         json.dump(out, f, indent=1)
 
 
+CASES_SCENE8_4K = {   # id: (UI string, blur) -- estimator-like depth at full size (tools/synth.scene8, softened silhouettes, seed 0)
+    "soft_scene8_4k_blur": ("Fill - Polylines Soft", True),
+    "sharp_scene8_4k_blur": ("Fill - Polylines Sharp", True),
+    "sharp_scene8_4k": ("Fill - Polylines Sharp", False),
+}
+
+
+def gen_scene8_4k(gs, only=None):
+    """SHA-256 digests of the REFERENCE node's outputs on one 4K frame of scene8 depth (quantised smooth depth with softened object
+    silhouettes: what the tile kernels' per-pixel lists overflow on) at the metric's divergence, polylines_soft / polylines_sharp.
+    `CS_GOLDEN_CASE=<id>` as for --only-4k."""
+    node = gs.StereoImageNode()
+    h, w = 2160, 3840
+    img = synth.image_f32(1, h, w, seed=1)
+    depth = synth.depth_batch("scene8", 1, h, w, channels=3)
+    out = {}
+    for cid, (ui, blur) in CASES_SCENE8_4K.items():
+        if only and cid != only:
+            continue
+        outs = node.generate(torch.from_numpy(img), torch.from_numpy(depth), 8.0, 0.0, "left-right", 0.0, 0.5, 2.0, ui, 20.0, 20.0, blur,
+                             depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+        stereo, dl, dr, mask = [o.numpy() for o in outs]
+        k = [np.round(a * 255.0).astype(np.uint8) for a in (stereo, dl[..., 0], dr[..., 0])]
+        out[cid] = dict(h=h, w=w, kind="scene8", fill_ui=ui, mode="left-right", divergence=8.0, blur=blur, image_seed=1,
+                        stereo_u8=sha(k[0]), dl_u8=sha(k[1]), dr_u8=sha(k[2]), mask=sha(np.packbits(mask.astype(bool))),
+                        mask_sum=int(mask.sum()), stereo_f32=sha(stereo), dl_f32=sha(dl), dr_f32=sha(dr))
+        print("scene8 4K digest", cid, out[cid]["stereo_u8"][:16], flush=True)
+    with open(os.path.join(OUT, f"digests_scene8_4k.{only}.json" if only else "digests_scene8_4k.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 WARP_1080P_ROWS = [0, 1, 110, 128, 129, 257, 332, 539, 540, 746, 822, 951, 1078, 1079]
 
 
@@ -744,6 +775,9 @@ def main():
     if "--only-4k" in sys.argv:
         gen_4k(gs, os.environ.get("CS_GOLDEN_CASE") or None)
         return
+    if "--only-scene8-4k" in sys.argv:
+        gen_scene8_4k(gs, os.environ.get("CS_GOLDEN_CASE") or None)
+        return
     if "--only-ties" in sys.argv:
         gen_ties(gs, os.environ.get("CS_GOLDEN_CASE") or None)
         return
@@ -765,6 +799,7 @@ def main():
     gen_metric_4k(gs)
     gen_4k(gs)
     gen_ties(gs)
+    gen_scene8_4k(gs)
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
