@@ -308,6 +308,27 @@ def test_digests_of_scene8_depth_at_4k_on_the_gpu(engine):
         assert sha(got[0]) == c["stereo_f32"] and sha(got[1]) == c["dl_f32"] and sha(got[2]) == c["dr_f32"], cid
 
 
+def test_digests_of_8k_frames_on_the_gpu(engine):
+    """One 8K frame (7680 x 4320) against the REFERENCE itself (tests/golden/digests_8k.json): polylines_soft side by side (ten tiles per
+    row) and naive_interpolating as a red-cyan anaglyph -- refused until round 6 -- divergence 8, blur on: uint8 codes, mask, float32 arrays."""
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN
+    from comfystereo_amd.GenerateStereo import FILL_TECHNIQUE_MAPPING
+    dig = json.load(open(os.path.join(GOLDEN, "digests_8k.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    img = synth.image_f32(1, 4320, 7680, seed=1)
+    depth = synth.depth_batch("stepped", 1, 4320, 7680, channels=3)
+    for cid, c in dig.items():
+        got = gen(engine, img, depth, FILL_TECHNIQUE_MAPPING[c["fill_ui"]], c["mode"], blur=c["blur"], div=c["divergence"])
+        k = [np.round(a * 255.0).astype(np.uint8) for a in (got[0], got[1][..., 0], got[2][..., 0])]
+        assert sha(k[0]) == c["stereo_u8"] and sha(k[1]) == c["dl_u8"] and sha(k[2]) == c["dr_u8"], cid
+        assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"], cid
+        assert sha(got[0]) == c["stereo_f32"] and sha(got[1]) == c["dl_f32"] and sha(got[2]) == c["dr_f32"], cid
+        del got, k
+
+
 def test_digests_at_the_widths_round_6_opened_on_the_gpu():
     """The HIP path against the REFERENCE node's own outputs at the widths round 6 opened (tests/golden/digests_wide.json,
     tools/make_goldens.py --only-wide): wide anaglyphs of the forward and post fills, their new side-by-side limits, polylines_sharp

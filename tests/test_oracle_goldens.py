@@ -348,6 +348,28 @@ def test_digests_of_scene8_depth_at_4k():
         assert sha(got[0]) == c["stereo_f32"] and sha(got[1]) == c["dl_f32"] and sha(got[2]) == c["dr_f32"], cid
 
 
+def test_digests_of_8k_frames():
+    """One 8K frame (7680 x 4320), divergence 8, blur on, against the REFERENCE node's own outputs (tests/golden/digests_8k.json,
+    tools/make_goldens.py --only-8k: half an hour of the pure-Python reference per case): polylines_soft side by side and naive_interpolating
+    as a red-cyan anaglyph."""
+    import json
+    import os
+    from conftest import GOLDEN
+    dig = json.load(open(os.path.join(GOLDEN, "digests_8k.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    assert len(dig) == 2
+    img = synth.image_f32(1, 4320, 7680, seed=1)
+    depth = synth.depth_batch("stepped", 1, 4320, 7680, channels=3)
+    for cid, c in dig.items():
+        got = node_oracle.generate(img, depth, c["divergence"], 0.0, c["mode"], 0.0, 0.5, 2.0, c["fill_ui"], 20.0, 20.0, c["blur"],
+                                   depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+        k = [np.round(a * 255.0).astype(np.uint8) for a in (got[0], got[1][..., 0], got[2][..., 0])]
+        assert sha(k[0]) == c["stereo_u8"] and sha(k[1]) == c["dl_u8"] and sha(k[2]) == c["dr_u8"], cid
+        assert sha(np.packbits(got[3].astype(bool))) == c["mask"] and int(got[3].sum()) == c["mask_sum"], cid
+        assert sha(got[0]) == c["stereo_f32"] and sha(got[1]) == c["dl_f32"] and sha(got[2]) == c["dr_f32"], cid
+        del got, k
+
+
 def test_digests_at_the_widths_round_6_opened():
     """Thin rows at the widths round 6 opened (anaglyphs of the forward fills beyond the row kernel's stash form, naive /
     naive_interpolating / none_post / inverse_post at their new limits, polylines_sharp at 8 192 columns) against SHA-256 digests of the

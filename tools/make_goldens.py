@@ -538,6 +538,36 @@ def gen_scene8_4k(gs, only=None):
         json.dump(out, f, indent=1)
 
 
+CASES_8K = {   # id: (UI string, mode, blur) -- one 8K frame (7680 x 4320), divergence 8, stepped depth
+    "soft_8k_sbs_blur": ("Fill - Polylines Soft", "left-right", True),
+    "naive_interp_8k_anaglyph_blur": ("Fill - Naive interpolating", "red-cyan-anaglyph", True),
+}
+
+
+def gen_8k(gs, only=None):
+    """SHA-256 digests of the REFERENCE node's outputs on one 8K frame (7680 x 4320): polylines_soft side by side and naive_interpolating as
+    a red-cyan anaglyph (refused until round 6: the row kernel's anaglyph stash did not fit at that width), divergence 8, blur on.  Half an
+    hour of the pure-Python reference per case; `CS_GOLDEN_CASE=<id>` as for --only-4k."""
+    node = gs.StereoImageNode()
+    h, w = 4320, 7680
+    img = synth.image_f32(1, h, w, seed=1)
+    depth = synth.depth_batch("stepped", 1, h, w, channels=3)
+    out = {}
+    for cid, (ui, mode, blur) in CASES_8K.items():
+        if only and cid != only:
+            continue
+        outs = node.generate(torch.from_numpy(img), torch.from_numpy(depth), 8.0, 0.0, mode, 0.0, 0.5, 2.0, ui, 20.0, 20.0, blur,
+                             depth_blur_falloff=2.0, depth_blur_vert_smooth=6, batch_size=12)
+        stereo, dl, dr, mask = [o.numpy() for o in outs]
+        k = [np.round(a * 255.0).astype(np.uint8) for a in (stereo, dl[..., 0], dr[..., 0])]
+        out[cid] = dict(h=h, w=w, kind="stepped", fill_ui=ui, mode=mode, divergence=8.0, blur=blur, image_seed=1,
+                        stereo_u8=sha(k[0]), dl_u8=sha(k[1]), dr_u8=sha(k[2]), mask=sha(np.packbits(mask.astype(bool))),
+                        mask_sum=int(mask.sum()), stereo_f32=sha(stereo), dl_f32=sha(dl), dr_f32=sha(dr))
+        print("8K digest", cid, out[cid]["stereo_u8"][:16], flush=True)
+    with open(os.path.join(OUT, f"digests_8k.{only}.json" if only else "digests_8k.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 WARP_1080P_ROWS = [0, 1, 110, 128, 129, 257, 332, 539, 540, 746, 822, 951, 1078, 1079]
 
 
@@ -778,6 +808,9 @@ def main():
     if "--only-scene8-4k" in sys.argv:
         gen_scene8_4k(gs, os.environ.get("CS_GOLDEN_CASE") or None)
         return
+    if "--only-8k" in sys.argv:
+        gen_8k(gs, os.environ.get("CS_GOLDEN_CASE") or None)
+        return
     if "--only-ties" in sys.argv:
         gen_ties(gs, os.environ.get("CS_GOLDEN_CASE") or None)
         return
@@ -800,6 +833,7 @@ def main():
     gen_4k(gs)
     gen_ties(gs)
     gen_scene8_4k(gs)
+    gen_8k(gs)
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
